@@ -1,0 +1,155 @@
+/* wavenet_hip.h -- C ABI of libwavenet_hip.so (MI355X / gfx950 WaveNet-vocoder training path).
+ *
+ * Drop-in boundary.  The reference (kan-bayashi/PytorchWaveNetVocoder) has no FFI: its boundary
+ * is the Python API of wavenet_vocoder.nets.  This library is what a binding of
+ * that API calls instead of torch.nn ops; every entry point names the reference code it replaces.
+ *
+ * Conventions
+ *   - plain C types only: device pointers + sizes; the caller (PyTorch-ROCm, or any HIP program)
+ *     owns every buffer, the library allocates nothing and keeps no state between calls;
+ *   - activations are channel-major fp32 (B, C, T) exactly like the reference's tensors; sample
+ *     indices are int64 (torch.long); logits are written physically as (B, Q, T) -- the
+ *     reference's `(B, T, Q)` result is the `.transpose(1, 2)` view of that buffer
+ *     (wavenet.py:522 does the same);
+ *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream); no hidden synchronisation; re-entrant per stream;
+ *   - return value 0 = ok; non-zero = error, text via wn_last_error() (thread local).
+ *
+ * Parameters live in ONE flat fp32 buffer (and gradients / Adam moments in buffers of the same
+ * shape).  The flat order is the order in which the backward pass finishes gradients
+ *      [conv_post_2, conv_post_1, skip_1x1.0..L-1] [layer L-1] ... [layer 0] [causal, upsampling]
+ * so that data-parallel gradient buckets are contiguous ranges that become ready front to back.
+ * Inside the buffer every tensor keeps the reference's own layout (Conv1d weight (Cout,Cin,K)
+ * etc.), so nn.Parameter views of it carry the reference's state_dict keys and shapes
+ * (wavenet.py:187-210).  wn_param_offset() is the single source of truth for the offsets.
+ */
+#ifndef WAVENET_HIP_H_
+#define WAVENET_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WN_ABI_VERSION 1
+
+/* Same fields as the constructor WaveNet(n_quantize, n_aux, n_resch, n_skipch, dilation_depth,
+ * dilation_repeat, kernel_size, upsampling_factor)  -- reference wavenet.py:172-173. */
+typedef struct WnConfig {
+    int32_t n_quantize;
+    int32_t n_aux;
+    int32_t n_resch;
+    int32_t n_skipch;
+    int32_t dilation_depth;
+    int32_t dilation_repeat;
+    int32_t kernel_size;
+    int32_t upsampling_factor; /* 0 = no upsampling layer (h arrives at sample rate) */
+} WnConfig;
+
+/* Tensor kinds for wn_param_offset (reference state_dict key in the comment). */
+enum {
+    WN_P_CAUSAL_W = 0, /* causal.conv.weight        (R,Q,K)   wavenet.py:189 */
+    WN_P_CAUSAL_B,     /* causal.conv.bias          (R)                      */
+    WN_P_UP_W,         /* upsampling.conv.weight    (1,1,1,U) wavenet.py:136 */
+    WN_P_UP_B,         /* upsampling.conv.bias      (1)                      */
+    WN_P_DSIG_W,       /* dil_sigmoid.l.conv.weight (R,R,K)   wavenet.py:201 */
+    WN_P_DSIG_B,       /* dil_sigmoid.l.conv.bias   (R)                      */
+    WN_P_DTANH_W,      /* dil_tanh.l.conv.weight    (R,R,K)   wavenet.py:202 */
+    WN_P_DTANH_B,      /* dil_tanh.l.conv.bias      (R)                      */
+    WN_P_ASIG_W,       /* aux_1x1_sigmoid.l.weight  (R,A,1)   wavenet.py:203 */
+    WN_P_ASIG_B,       /* aux_1x1_sigmoid.l.bias    (R)                      */
+    WN_P_ATANH_W,      /* aux_1x1_tanh.l.weight     (R,A,1)   wavenet.py:204 */
+    WN_P_ATANH_B,      /* aux_1x1_tanh.l.bias       (R)                      */
+    WN_P_SKIP_W,       /* skip_1x1.l.weight         (S,R,1)   wavenet.py:205 */
+    WN_P_SKIP_B,       /* skip_1x1.l.bias           (S)                      */
+    WN_P_RES_W,        /* res_1x1.l.weight          (R,R,1)   wavenet.py:206 */
+    WN_P_RES_B,        /* res_1x1.l.bias            (R)                      */
+    WN_P_POST1_W,      /* conv_post_1.weight        (S,S,1)   wavenet.py:209 */
+    WN_P_POST1_B,      /* conv_post_1.bias          (S)                      */
+    WN_P_POST2_W,      /* conv_post_2.weight        (Q,S,1)   wavenet.py:210 */
+    WN_P_POST2_B,      /* conv_post_2.bias          (Q)                      */
+    WN_P_NKINDS
+};
+
+/* flags for wn_forward */
+#define WN_FLAG_NO_FUSED 1 /* force the any-size layered path even when the fused R=64 kernels apply */
+
+int wn_abi_version(void);
+const char* wn_last_error(void);
+
+/* receptive_field = (K-1)*sum(dilations)+1, dilations = [2^i for i<depth]*repeat (wavenet.py:184-185) */
+int wn_receptive_field(const WnConfig* cfg);
+int wn_num_layers(const WnConfig* cfg);
+
+/* Number of fp32 elements of the flat parameter buffer (== sum of numel of the reference state_dict). */
+int64_t wn_param_count(const WnConfig* cfg);
+/* Offset (in floats) and numel of tensor `kind` of layer `layer` (ignored for non per-layer kinds)
+ * inside the flat parameter / gradient buffers.  Returns non-zero if the tensor does not exist
+ * (upsampling tensors when upsampling_factor == 0). */
+int wn_param_offset(const WnConfig* cfg, int kind, int layer, int64_t* offset, int64_t* numel);
+
+/* Gradient buckets for data-parallel all-reduce: bucket 0 = post-net + all skip_1x1; then groups of
+ * `layers_per_bucket` residual layers from the last layer down; the final bucket = causal +
+ * upsampling.  [lo, hi) are float offsets into the flat gradient buffer. */
+int wn_num_buckets(const WnConfig* cfg, int layers_per_bucket);
+int wn_bucket_range(const WnConfig* cfg, int layers_per_bucket, int bucket, int64_t* lo, int64_t* hi);
+/* [lo, hi) of parameters that never receive a gradient (res_1x1 of the last layer; reference:
+ * wavenet.py:231-238 leaves its output unused, so torch reports grad None and Adam skips it). */
+int wn_dead_param_range(const WnConfig* cfg, int64_t* lo, int64_t* hi);
+
+/* Bytes of caller-provided scratch for batch B x T model inputs (forward + backward). */
+size_t wn_workspace_bytes(const WnConfig* cfg, int B, int T);
+
+/* WaveNet.forward(x, h)  -- reference wavenet.py:212-241 (+ _preprocess :513-516, UpSampling
+ * :141-154, _residual_forward :525-536, _postprocess :518-523).
+ *   params : flat parameter buffer                         (device, wn_param_count floats)
+ *   x      : (B, T) int64 sample indices, taken modulo n_quantize like OneHot (wavenet.py:88)
+ *   h      : (B, n_aux, T / upsampling_factor) fp32, or (B, n_aux, T) when upsampling_factor == 0
+ *   logits : (B, n_quantize, T) fp32 out  [view it as (B, T, Q) via transpose(1,2)]
+ * Everything the backward pass needs is kept in `ws`. */
+int wn_forward(const WnConfig* cfg, int B, int T, const float* params, const int64_t* x, const float* h,
+               float* logits, void* ws, size_t ws_bytes, int flags, void* stream);
+
+/* nn.CrossEntropyLoss()(out[:, t_start:].reshape(-1,Q), target[:, t_start:].reshape(-1))
+ *   -- reference train.py:461,534-536 (t_start = receptive_field there).
+ *   loss     : device scalar out = mean over B*(T-t_start) positions, times loss_scale
+ *   dlogits  : (B, Q, T) out = d(mean loss)/d(logits) * grad_scale  (zeros for t < t_start); may be NULL */
+int wn_softmax_ce_loss(const WnConfig* cfg, int B, int T, const float* logits, const int64_t* target, int t_start,
+                       float grad_scale, float loss_scale, float* loss, float* dlogits, void* ws, size_t ws_bytes,
+                       void* stream);
+
+/* Backward of wn_forward (what autograd does for train.py:538): writes EVERY element of the flat
+ * gradient buffer `grads` (the dead range gets zeros).  `ws` must still hold the matching
+ * wn_forward call.  If events != NULL, hipEvent_t events[i] is recorded on `stream` as soon as
+ * bucket i (wn_bucket_range) is final, so the caller can all-reduce it on another stream. */
+int wn_backward(const WnConfig* cfg, int B, int T, const float* params, const int64_t* x, const float* h,
+                const float* dlogits, float* grads, void* ws, size_t ws_bytes, void* const* events, int n_events,
+                int layers_per_bucket, int flags, void* stream);
+
+/* torch.optim.Adam step over the flat buffers (reference train.py:457-460,539): L2-in-gradient
+ * weight decay, bias correction with `step` (1-based); [skip_lo, skip_hi) is left untouched. */
+int wn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
+                 float lr, float beta1, float beta2, float eps, float weight_decay, int64_t skip_lo, int64_t skip_hi,
+                 void* stream);
+
+/* ---- op-level entry points (used by the composite calls above; exported for parity tests) ---- */
+
+/* OneHot + CausalConv1d(Q->R,K) as a gather (wavenet.py:78-92,513-516).  weight (R,Q,K), bias (R). */
+int wn_op_front(const float* weight, const float* bias, const int64_t* x, float* out /*(B,R,T)*/, float* scratch /*K*Q*R*/,
+                int B, int T, int Q, int R, int K, void* stream);
+
+/* CausalConv1d forward (wavenet.py:95-121): y[b,:,t] = bias + sum_k W[:,:,k] x[b,:,t-(K-1-k)d].
+ * weight (Cout,Cin,K) natural layout; scratch >= Cout*Cin*K floats. */
+int wn_op_causal_conv(const float* weight, const float* bias, const float* x /*(B,Cin,T)*/, float* y /*(B,Cout,T)*/,
+                      float* scratch, int B, int T, int Cin, int Cout, int K, int dilation, void* stream);
+
+/* Generic C[z] = A.B contraction on the f32 matrix cores; see csrc/wn_gemm.h for the argument block. */
+struct WnGemmArgs;
+int wn_op_gemm(const struct WnGemmArgs* args, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAVENET_HIP_H_ */

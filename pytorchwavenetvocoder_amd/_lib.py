@@ -1,0 +1,135 @@
+# -*- coding: utf-8 -*-
+"""ctypes binding of libwavenet_hip.so (C ABI: include/wavenet_hip.h).
+
+The product path loads the gfx950 library built in-tree at ``csrc/libwavenet_hip.so`` and FAILS
+LOUDLY when it is missing or cannot be built -- there is no CPU or eager-PyTorch fallback.
+(``load_library(path, _test_emulator=True)`` exists only so that tests/ can point the same binding
+at the host-compiled kernel emulator; nothing in this package ever passes that flag.)
+"""
+import ctypes
+import os
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libwavenet_hip.so")
+
+c_float_p = ctypes.c_void_p
+c_i64_p = ctypes.c_void_p
+
+
+class WnConfig(ctypes.Structure):
+    """Mirror of ``struct WnConfig`` == WaveNet.__init__ arguments (reference wavenet.py:172-173)."""
+    _fields_ = [("n_quantize", ctypes.c_int32), ("n_aux", ctypes.c_int32), ("n_resch", ctypes.c_int32),
+                ("n_skipch", ctypes.c_int32), ("dilation_depth", ctypes.c_int32),
+                ("dilation_repeat", ctypes.c_int32), ("kernel_size", ctypes.c_int32),
+                ("upsampling_factor", ctypes.c_int32)]
+
+
+class WnGemmArgs(ctypes.Structure):
+    """Mirror of ``struct WnGemmArgs`` (csrc/wn_gemm.h); used by the op-level parity tests."""
+    _fields_ = [
+        ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int),
+        ("A", ctypes.c_void_p), ("lda", ctypes.c_long), ("a_zstride", ctypes.c_long), ("a_kmajor", ctypes.c_int),
+        ("B", ctypes.c_void_p), ("ldb", ctypes.c_long), ("b_zstride", ctypes.c_long), ("b_kmajor", ctypes.c_int),
+        ("b_seg_len", ctypes.c_int), ("b_seg_stride", ctypes.c_long), ("b_shift0", ctypes.c_int),
+        ("b_shift_step", ctypes.c_int), ("b_clen", ctypes.c_int), ("b_relu", ctypes.c_int),
+        ("b_index", ctypes.c_void_p), ("b_index_zstride", ctypes.c_long), ("b_index_mod", ctypes.c_int),
+        ("C", ctypes.c_void_p), ("ldc", ctypes.c_long), ("c_zstride", ctypes.c_long),
+        ("bias", ctypes.c_void_p),
+        ("D", ctypes.c_void_p), ("ldd", ctypes.c_long), ("d_zstride", ctypes.c_long),
+        ("E", ctypes.c_void_p), ("lde", ctypes.c_long), ("e_zstride", ctypes.c_long),
+        ("relu", ctypes.c_int), ("accumulate", ctypes.c_int),
+        ("nbatch", ctypes.c_int), ("ksplit", ctypes.c_int), ("kchunk", ctypes.c_int),
+        ("a_rowsum", ctypes.c_void_p),
+    ]
+
+    @classmethod
+    def default(cls):
+        g = cls()
+        g.b_seg_len = 0x7fffffff
+        g.b_index_mod = 1
+        g.nbatch = 1
+        g.ksplit = 1
+        g.kchunk = 0x7fffffff
+        return g
+
+
+# tensor kinds (include/wavenet_hip.h)
+(P_CAUSAL_W, P_CAUSAL_B, P_UP_W, P_UP_B, P_DSIG_W, P_DSIG_B, P_DTANH_W, P_DTANH_B, P_ASIG_W, P_ASIG_B,
+ P_ATANH_W, P_ATANH_B, P_SKIP_W, P_SKIP_B, P_RES_W, P_RES_B, P_POST1_W, P_POST1_B, P_POST2_W, P_POST2_B) = range(20)
+
+FLAG_NO_FUSED = 1
+ABI_VERSION = 1
+
+# every symbol include/wavenet_hip.h declares
+EXPORTS = [
+    "wn_abi_version", "wn_last_error", "wn_receptive_field", "wn_num_layers", "wn_param_count", "wn_param_offset",
+    "wn_num_buckets", "wn_bucket_range", "wn_dead_param_range", "wn_workspace_bytes", "wn_forward",
+    "wn_softmax_ce_loss", "wn_backward", "wn_adam_step", "wn_op_front", "wn_op_causal_conv", "wn_op_gemm",
+]
+
+
+class WnError(RuntimeError):
+    pass
+
+
+class WnLibrary(object):
+    def __init__(self, path, is_emulator=False):
+        self.path = path
+        self.is_emulator = is_emulator
+        self.lib = ctypes.CDLL(path)
+        L = self.lib
+        vp, i, i64, f, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
+        cfgp = ctypes.POINTER(WnConfig)
+        L.wn_abi_version.restype = i
+        L.wn_last_error.restype = ctypes.c_char_p
+        L.wn_receptive_field.argtypes = [cfgp]
+        L.wn_num_layers.argtypes = [cfgp]
+        L.wn_param_count.argtypes = [cfgp]
+        L.wn_param_count.restype = i64
+        L.wn_param_offset.argtypes = [cfgp, i, i, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+        L.wn_num_buckets.argtypes = [cfgp, i]
+        L.wn_bucket_range.argtypes = [cfgp, i, i, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+        L.wn_dead_param_range.argtypes = [cfgp, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+        L.wn_workspace_bytes.argtypes = [cfgp, i, i]
+        L.wn_workspace_bytes.restype = sz
+        L.wn_forward.argtypes = [cfgp, i, i, vp, vp, vp, vp, vp, sz, i, vp]
+        L.wn_softmax_ce_loss.argtypes = [cfgp, i, i, vp, vp, i, f, f, vp, vp, vp, sz, vp]
+        L.wn_backward.argtypes = [cfgp, i, i, vp, vp, vp, vp, vp, vp, sz, ctypes.POINTER(vp), i, i, i, vp]
+        L.wn_adam_step.argtypes = [vp, vp, vp, vp, i64, i64, f, f, f, f, f, i64, i64, vp]
+        L.wn_op_front.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, vp]
+        L.wn_op_causal_conv.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
+        L.wn_op_gemm.argtypes = [ctypes.POINTER(WnGemmArgs), vp]
+        if L.wn_abi_version() != ABI_VERSION:
+            raise WnError("ABI mismatch: library %d, binding %d" % (L.wn_abi_version(), ABI_VERSION))
+
+    def check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.wn_last_error()
+            raise WnError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+    def __getattr__(self, name):
+        return getattr(self.lib, name)
+
+
+_lock = threading.Lock()
+_cached = None
+
+
+def load_library(path=None, _test_emulator=False):
+    """Load (building if necessary) the gfx950 library.  Raises if that is impossible."""
+    global _cached
+    if path is not None:
+        return WnLibrary(path, is_emulator=_test_emulator)
+    with _lock:
+        if _cached is None:
+            if not os.path.exists(LIB_PATH):
+                # build in-tree with hipcc (cross-compiles without a GPU); raises when hipcc is absent
+                from .csrc import build as _build
+                _build.build(verbose=False)
+            if not os.path.exists(LIB_PATH):
+                raise WnError("libwavenet_hip.so is missing and could not be built: the MI355X HIP "
+                              "extension is required (there is no CPU / eager fallback)")
+            _cached = WnLibrary(LIB_PATH)
+        return _cached

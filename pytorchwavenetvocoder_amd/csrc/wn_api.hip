@@ -1,0 +1,868 @@
+// wn_api.hip -- C-ABI entry points of libwavenet_hip.so (see include/wavenet_hip.h).
+//
+// Host-side orchestration only: parameter layout, workspace carving and the launch sequence of
+// the forward / loss / backward / Adam steps of the WaveNet training path.  All arithmetic is in
+// the HIP kernels of wn_gemm.hip, wn_elem.hip and wn_fused.hip.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/wavenet_hip.h"
+#include "wn_elem.h"
+#include "wn_fused.h"
+#include "wn_gemm.h"
+
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#ifdef WN_EMU
+static int rt_check(const char*) { return 0; }
+static void rt_event_record(void*, wn_stream_t) {}
+#else
+static int rt_check(const char* where) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(100, "HIP error after %s: %s", where, hipGetErrorString(e));
+    return 0;
+}
+static void rt_event_record(void* ev, wn_stream_t st) { (void)hipEventRecord((hipEvent_t)ev, st); }
+#endif
+
+#define WN_TRY(expr)                                                                     \
+    do {                                                                                 \
+        int _rc = (expr);                                                                \
+        if (_rc != 0) return (g_err[0] ? _rc : fail(_rc, "%s failed (rc=%d)", #expr, _rc)); \
+    } while (0)
+
+extern "C" int wn_abi_version(void) { return WN_ABI_VERSION; }
+extern "C" const char* wn_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------
+// configuration / parameter layout
+// ------------------------------------------------------------------------------------------
+struct Dims {
+    int Q, A, R, S, L, K, U;
+};
+
+static int check_cfg(const WnConfig* c, Dims* d) {
+    if (!c) return fail(1, "cfg is NULL");
+    if (c->n_quantize < 2 || c->n_aux < 1 || c->n_resch < 1 || c->n_skipch < 1 || c->dilation_depth < 1 ||
+        c->dilation_depth > 24 || c->dilation_repeat < 1 || c->kernel_size < 1 || c->kernel_size > 8 ||
+        c->upsampling_factor < 0)
+        return fail(1, "invalid WnConfig");
+    d->Q = c->n_quantize;
+    d->A = c->n_aux;
+    d->R = c->n_resch;
+    d->S = c->n_skipch;
+    d->L = c->dilation_depth * c->dilation_repeat;
+    d->K = c->kernel_size;
+    d->U = c->upsampling_factor;
+    return 0;
+}
+
+static inline int dilation_of(const WnConfig* c, int l) { return 1 << (l % c->dilation_depth); }
+
+struct Lay {
+    long post2_w, post2_b, post1_w, post1_b;
+    long skip0, ls_skip;          // skip_1x1.l : skip0 + l*ls_skip (+S*R for bias)
+    long layers0, LB;             // layer l block at layers0 + (L-1-l)*LB
+    long o_dsig_w, o_dsig_b, o_dtanh_w, o_dtanh_b, o_asig_w, o_asig_b, o_atanh_w, o_atanh_b, o_res_w, o_res_b;
+    long causal_w, causal_b, up_w, up_b;
+    long total;
+};
+
+static Lay make_lay(const Dims& d) {
+    Lay y;
+    long o = 0;
+    y.post2_w = o; o += (long)d.Q * d.S;
+    y.post2_b = o; o += d.Q;
+    y.post1_w = o; o += (long)d.S * d.S;
+    y.post1_b = o; o += d.S;
+    y.skip0 = o;
+    y.ls_skip = (long)d.S * d.R + d.S;
+    o += y.ls_skip * d.L;
+    y.layers0 = o;
+    long q = 0;
+    y.o_dsig_w = q; q += (long)d.R * d.R * d.K;
+    y.o_dsig_b = q; q += d.R;
+    y.o_dtanh_w = q; q += (long)d.R * d.R * d.K;
+    y.o_dtanh_b = q; q += d.R;
+    y.o_asig_w = q; q += (long)d.R * d.A;
+    y.o_asig_b = q; q += d.R;
+    y.o_atanh_w = q; q += (long)d.R * d.A;
+    y.o_atanh_b = q; q += d.R;
+    y.o_res_w = q; q += (long)d.R * d.R;
+    y.o_res_b = q; q += d.R;
+    y.LB = q;
+    o += y.LB * d.L;
+    y.causal_w = o; o += (long)d.R * d.Q * d.K;
+    y.causal_b = o; o += d.R;
+    if (d.U > 0) {
+        y.up_w = o; o += d.U;
+        y.up_b = o; o += 1;
+    } else {
+        y.up_w = y.up_b = -1;
+    }
+    y.total = o;
+    return y;
+}
+static inline long layer_base(const Lay& y, const Dims& d, int l) { return y.layers0 + (long)(d.L - 1 - l) * y.LB; }
+
+extern "C" int wn_num_layers(const WnConfig* cfg) {
+    Dims d;
+    if (check_cfg(cfg, &d)) return -1;
+    return d.L;
+}
+
+extern "C" int wn_receptive_field(const WnConfig* cfg) {
+    Dims d;
+    if (check_cfg(cfg, &d)) return -1;
+    long sum = 0;
+    for (int l = 0; l < d.L; ++l) sum += dilation_of(cfg, l);
+    return (int)((d.K - 1) * sum + 1);
+}
+
+extern "C" int64_t wn_param_count(const WnConfig* cfg) {
+    Dims d;
+    if (check_cfg(cfg, &d)) return -1;
+    return make_lay(d).total;
+}
+
+extern "C" int wn_param_offset(const WnConfig* cfg, int kind, int layer, int64_t* offset, int64_t* numel) {
+    Dims d;
+    WN_TRY(check_cfg(cfg, &d));
+    const Lay y = make_lay(d);
+    long off = -1, n = 0;
+    const bool per_layer = (kind >= WN_P_DSIG_W && kind <= WN_P_RES_B);
+    if (per_layer && (layer < 0 || layer >= d.L)) return fail(2, "layer %d out of range", layer);
+    const long lb = per_layer ? layer_base(y, d, layer) : 0;
+    switch (kind) {
+        case WN_P_CAUSAL_W: off = y.causal_w; n = (long)d.R * d.Q * d.K; break;
+        case WN_P_CAUSAL_B: off = y.causal_b; n = d.R; break;
+        case WN_P_UP_W: off = y.up_w; n = d.U; break;
+        case WN_P_UP_B: off = y.up_b; n = 1; break;
+        case WN_P_DSIG_W: off = lb + y.o_dsig_w; n = (long)d.R * d.R * d.K; break;
+        case WN_P_DSIG_B: off = lb + y.o_dsig_b; n = d.R; break;
+        case WN_P_DTANH_W: off = lb + y.o_dtanh_w; n = (long)d.R * d.R * d.K; break;
+        case WN_P_DTANH_B: off = lb + y.o_dtanh_b; n = d.R; break;
+        case WN_P_ASIG_W: off = lb + y.o_asig_w; n = (long)d.R * d.A; break;
+        case WN_P_ASIG_B: off = lb + y.o_asig_b; n = d.R; break;
+        case WN_P_ATANH_W: off = lb + y.o_atanh_w; n = (long)d.R * d.A; break;
+        case WN_P_ATANH_B: off = lb + y.o_atanh_b; n = d.R; break;
+        case WN_P_SKIP_W: off = y.skip0 + layer * y.ls_skip; n = (long)d.S * d.R; break;
+        case WN_P_SKIP_B: off = y.skip0 + layer * y.ls_skip + (long)d.S * d.R; n = d.S; break;
+        case WN_P_RES_W: off = lb + y.o_res_w; n = (long)d.R * d.R; break;
+        case WN_P_RES_B: off = lb + y.o_res_b; n = d.R; break;
+        case WN_P_POST1_W: off = y.post1_w; n = (long)d.S * d.S; break;
+        case WN_P_POST1_B: off = y.post1_b; n = d.S; break;
+        case WN_P_POST2_W: off = y.post2_w; n = (long)d.Q * d.S; break;
+        case WN_P_POST2_B: off = y.post2_b; n = d.Q; break;
+        default: return fail(2, "unknown tensor kind %d", kind);
+    }
+    if ((kind == WN_P_SKIP_W || kind == WN_P_SKIP_B) && (layer < 0 || layer >= d.L))
+        return fail(2, "layer %d out of range", layer);
+    if (off < 0) return fail(3, "tensor kind %d does not exist for this config", kind);
+    if (offset) *offset = off;
+    if (numel) *numel = n;
+    return 0;
+}
+
+extern "C" int wn_num_buckets(const WnConfig* cfg, int lpb) {
+    Dims d;
+    if (check_cfg(cfg, &d)) return -1;
+    if (lpb < 1) lpb = d.L;
+    return 1 + (d.L + lpb - 1) / lpb + 1;
+}
+
+extern "C" int wn_bucket_range(const WnConfig* cfg, int lpb, int bucket, int64_t* lo, int64_t* hi) {
+    Dims d;
+    WN_TRY(check_cfg(cfg, &d));
+    if (lpb < 1) lpb = d.L;
+    const Lay y = make_lay(d);
+    const int ngroups = (d.L + lpb - 1) / lpb;
+    long a, b;
+    if (bucket == 0) {
+        a = 0;
+        b = y.layers0;
+    } else if (bucket <= ngroups) {
+        const int g = bucket - 1;  // layers processed: L-1-g*lpb ... down
+        const int first = g * lpb;
+        int last = first + lpb;
+        if (last > d.L) last = d.L;
+        a = y.layers0 + (long)first * y.LB;
+        b = y.layers0 + (long)last * y.LB;
+    } else if (bucket == ngroups + 1) {
+        a = y.causal_w;
+        b = y.total;
+    } else {
+        return fail(2, "bucket %d out of range", bucket);
+    }
+    if (lo) *lo = a;
+    if (hi) *hi = b;
+    return 0;
+}
+
+extern "C" int wn_dead_param_range(const WnConfig* cfg, int64_t* lo, int64_t* hi) {
+    Dims d;
+    WN_TRY(check_cfg(cfg, &d));
+    const Lay y = make_lay(d);
+    const long lb = layer_base(y, d, d.L - 1);
+    if (lo) *lo = lb + y.o_res_w;
+    if (hi) *hi = lb + y.o_res_b + d.R;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// split-K plan for the weight-gradient GEMMs (contraction over time)
+// ------------------------------------------------------------------------------------------
+struct DwPlan {
+    int ksplit, kchunk, nz;
+};
+static DwPlan dw_plan(int M, int N, int Kdim, int nbatch) {
+    const int tm = (M + (M > 64 ? 127 : 63)) / (M > 64 ? 128 : 64);
+    const int tn = (N + (N > 64 ? 127 : 63)) / (N > 64 ? 128 : 64);
+    const long tiles = (long)tm * tn * nbatch;
+    long ks = (1024 + tiles - 1) / tiles;
+    const long maxks = (Kdim + 255) / 256;
+    if (ks > maxks) ks = maxks;
+    if (ks < 1) ks = 1;
+    int kchunk = (int)((Kdim + ks - 1) / ks);
+    kchunk = (kchunk + 31) / 32 * 32;
+    if (kchunk < 32) kchunk = 32;
+    DwPlan p;
+    p.kchunk = kchunk;
+    p.ksplit = (Kdim + kchunk - 1) / kchunk;
+    if (p.ksplit < 1) p.ksplit = 1;
+    p.nz = p.ksplit * nbatch;
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------
+// workspace
+// ------------------------------------------------------------------------------------------
+struct Ws {
+    // packed weights
+    long wc_f, wd_f, waux_f, cvec, rowsum_aux, wres_f, wskip_f, bskip, w1_f, w2_f, wd_b, one;
+    // fused-kernel weight images
+    long fw_fwd, fw_bwd;
+    // saved activations
+    long X, G, Sg, Gt, Z, O1, O2;
+    // scratch
+    long P, dO2, dSk, dZ, dXa, dXb, dG, dw_partial, dc, tmpS, partial, rs_partial, loss_partial;
+    long total;
+    int F;  // frames (T/U, or T without upsampling)
+};
+
+static inline long al64(long n) { return (n + 63) / 64 * 64; }
+
+static int make_ws(const Dims& d, int B, int T, Ws* w) {
+    if (B < 1 || T < 1) return fail(1, "B and T must be positive");
+    const int Ue = d.U > 0 ? d.U : 1;
+    if (T % Ue != 0) return fail(1, "T=%d is not a multiple of upsampling_factor=%d", T, d.U);
+    const int F = T / Ue;
+    w->F = F;
+    const long BRT = (long)B * d.R * T, BST = (long)B * d.S * T;
+    long o = 0;
+#define CARVE(field, n) \
+    w->field = o;       \
+    o += al64((long)(n));
+    CARVE(wc_f, (long)d.K * d.Q * d.R);
+    CARVE(wd_f, (long)d.L * d.K * d.R * 2 * d.R);
+    CARVE(waux_f, (long)d.A * d.L * 2 * d.R);
+    CARVE(cvec, (long)d.L * 2 * d.R);
+    CARVE(rowsum_aux, (long)d.L * 2 * d.R);
+    CARVE(wres_f, (long)d.L * d.R * d.R);
+    CARVE(wskip_f, (long)d.L * d.R * d.S);
+    CARVE(bskip, d.S);
+    CARVE(w1_f, (long)d.S * d.S);
+    CARVE(w2_f, (long)d.S * d.Q);
+    CARVE(wd_b, (long)d.L * d.K * 2 * d.R * d.R);
+    CARVE(one, 64);
+    CARVE(fw_fwd, wn_fused_fwd_weight_floats(d.R, d.K) * (long)d.L);
+    CARVE(fw_bwd, wn_fused_bwd_weight_floats(d.R, d.K, d.S) * (long)d.L);
+    CARVE(X, (long)d.L * BRT);
+    CARVE(G, (long)B * d.L * 2 * d.R * F);
+    CARVE(Sg, (long)d.L * BRT);
+    CARVE(Gt, (long)d.L * BRT);
+    CARVE(Z, (long)d.L * BRT);
+    CARVE(O1, BST);
+    CARVE(O2, BST);
+    CARVE(P, 2 * BRT);
+    CARVE(dO2, BST);
+    CARVE(dSk, BST);
+    CARVE(dZ, BRT);
+    CARVE(dXa, BRT);
+    CARVE(dXb, BRT);
+    CARVE(dG, (long)B * 2 * d.R * F);
+    CARVE(dw_partial, (long)d.L * B * 2 * d.R * Ue);
+    CARVE(dc, (long)d.L * 2 * d.R);
+    CARVE(tmpS, d.S > d.Q ? d.S : d.Q);
+    // partial buffers: max over the dW GEMMs issued by wn_backward
+    long pmax = 0, rmax = 0;
+    {
+        struct { int M, N, K; } gs[] = {
+            {d.Q, d.S, T}, {d.S, d.S, T}, {d.S, d.L * d.R, T}, {2 * d.R, d.K * d.R, T},
+            {d.R, d.R, T}, {2 * d.R, d.A, F}, {2 * d.R, d.A, T}, {d.R, d.K * d.Q, T}};
+        for (unsigned i = 0; i < sizeof(gs) / sizeof(gs[0]); ++i) {
+            DwPlan p = dw_plan(gs[i].M, gs[i].N, gs[i].K, B);
+            long need = (long)p.nz * gs[i].M * gs[i].N;
+            if (need > pmax) pmax = need;
+            long rneed = (long)p.nz * gs[i].M;
+            if (rneed > rmax) rmax = rneed;
+        }
+    }
+    CARVE(partial, pmax);
+    CARVE(rs_partial, rmax);
+    CARVE(loss_partial, wn_softmax_ce_nblocks(B, T) + 64);
+#undef CARVE
+    w->total = o;
+    return 0;
+}
+
+extern "C" size_t wn_workspace_bytes(const WnConfig* cfg, int B, int T) {
+    Dims d;
+    if (check_cfg(cfg, &d)) return 0;
+    Ws w;
+    if (make_ws(d, B, T, &w)) return 0;
+    return (size_t)w.total * sizeof(float);
+}
+
+struct Ctx {
+    const WnConfig* cfg;
+    Dims d;
+    Lay y;
+    Ws w;
+    int B, T;
+    float* ws;
+    wn_stream_t st;
+    bool fused;
+};
+
+static int make_ctx(Ctx* c, const WnConfig* cfg, int B, int T, void* ws, size_t ws_bytes, int flags, void* stream) {
+    c->cfg = cfg;
+    WN_TRY(check_cfg(cfg, &c->d));
+    c->y = make_lay(c->d);
+    WN_TRY(make_ws(c->d, B, T, &c->w));
+    if (!ws) return fail(1, "workspace is NULL");
+    if (ws_bytes < (size_t)c->w.total * sizeof(float))
+        return fail(1, "workspace too small: %zu < %zu bytes", ws_bytes, (size_t)c->w.total * sizeof(float));
+    c->B = B;
+    c->T = T;
+    c->ws = (float*)ws;
+    c->st = (wn_stream_t)stream;
+    c->fused = wn_fused_supported(c->d.R, c->d.K) && !(flags & WN_FLAG_NO_FUSED);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing (once per forward; weights change every optimizer step)
+// ------------------------------------------------------------------------------------------
+static int pack_weights(const Ctx& c, const float* params) {
+    const Dims& d = c.d;
+    const Lay& y = c.y;
+    const Ws& w = c.w;
+    float* ws = c.ws;
+    const long lb0 = layer_base(y, d, 0);
+    const long lstep = -y.LB;  // layer l block = lb0 + l*lstep
+    WnCopy4 cp;
+    // wc_f[tap][q][r] = causal_w[r][q][tap]
+    cp.n0 = d.K; cp.n1 = d.Q; cp.n2 = d.R; cp.nl = 1;
+    cp.d0 = (long)d.Q * d.R; cp.d1 = d.R; cp.d2 = 1; cp.dl = 0;
+    cp.s0 = 1; cp.s1 = d.K; cp.s2 = (long)d.Q * d.K; cp.sl = 0;
+    WN_TRY(wn_copy4(ws + w.wc_f, params + y.causal_w, &cp, c.st));
+    // wd_f[l][(tap*R+i)*2R + o'] = W{sig,tanh}[o][i][tap] ;  wd_b[l][(tap*2R+o')*R + i] = same
+    for (int half = 0; half < 2; ++half) {
+        const long src = lb0 + (half ? y.o_dtanh_w : y.o_dsig_w);
+        cp.n0 = d.K; cp.n1 = d.R /*i*/; cp.n2 = d.R /*o*/; cp.nl = d.L;
+        cp.s0 = 1; cp.s1 = d.K; cp.s2 = (long)d.R * d.K; cp.sl = lstep;
+        cp.d0 = (long)d.R * 2 * d.R; cp.d1 = 2 * d.R; cp.d2 = 1; cp.dl = (long)d.K * d.R * 2 * d.R;
+        WN_TRY(wn_copy4(ws + w.wd_f + (long)half * d.R, params + src, &cp, c.st));
+        cp.d0 = (long)2 * d.R * d.R; cp.d1 = 1; cp.d2 = d.R; cp.dl = (long)d.K * 2 * d.R * d.R;
+        WN_TRY(wn_copy4(ws + w.wd_b + (long)half * d.R * d.R, params + src, &cp, c.st));
+        // waux_f[a][l*2R + o'] = Waux{sig,tanh}_l[o][a]
+        const long asrc = lb0 + (half ? y.o_atanh_w : y.o_asig_w);
+        cp.n0 = 1; cp.n1 = d.A; cp.n2 = d.R; cp.nl = d.L;
+        cp.s0 = 0; cp.s1 = 1; cp.s2 = d.A; cp.sl = lstep;
+        cp.d0 = 0; cp.d1 = (long)d.L * 2 * d.R; cp.d2 = 1; cp.dl = 2 * d.R;
+        WN_TRY(wn_copy4(ws + w.waux_f + (long)half * d.R, params + asrc, &cp, c.st));
+    }
+    // wres_f[l][i*R + o] = Wres_l[o][i]
+    cp.n0 = 1; cp.n1 = d.R; cp.n2 = d.R; cp.nl = d.L;
+    cp.s0 = 0; cp.s1 = 1; cp.s2 = d.R; cp.sl = lstep;
+    cp.d0 = 0; cp.d1 = d.R; cp.d2 = 1; cp.dl = (long)d.R * d.R;
+    WN_TRY(wn_copy4(ws + w.wres_f, params + lb0 + y.o_res_w, &cp, c.st));
+    // wskip_f[(l*R + r)*S + s] = Wskip_l[s][r]
+    cp.n0 = 1; cp.n1 = d.R; cp.n2 = d.S; cp.nl = d.L;
+    cp.s0 = 0; cp.s1 = 1; cp.s2 = d.R; cp.sl = y.ls_skip;
+    cp.d0 = 0; cp.d1 = d.S; cp.d2 = 1; cp.dl = (long)d.R * d.S;
+    WN_TRY(wn_copy4(ws + w.wskip_f, params + y.skip0, &cp, c.st));
+    // w1_f[i*S + o] = W1[o][i] ; w2_f[i*Q + q] = W2[q][i]
+    cp.n0 = 1; cp.n1 = d.S; cp.n2 = d.S; cp.nl = 1;
+    cp.s0 = 0; cp.s1 = 1; cp.s2 = d.S; cp.sl = 0;
+    cp.d0 = 0; cp.d1 = d.S; cp.d2 = 1; cp.dl = 0;
+    WN_TRY(wn_copy4(ws + w.w1_f, params + y.post1_w, &cp, c.st));
+    cp.n1 = d.S; cp.n2 = d.Q; cp.s1 = 1; cp.s2 = d.S; cp.d1 = d.Q; cp.d2 = 1;
+    WN_TRY(wn_copy4(ws + w.w2_f, params + y.post2_w, &cp, c.st));
+    // cvec / rowsum_aux / bskip / one
+    WnCvecArgs ca;
+    ca.params = params;
+    ca.off_dsig_b = lb0 + y.o_dsig_b; ca.off_dtanh_b = lb0 + y.o_dtanh_b;
+    ca.off_asig_w = lb0 + y.o_asig_w; ca.off_atanh_w = lb0 + y.o_atanh_w;
+    ca.off_asig_b = lb0 + y.o_asig_b; ca.off_atanh_b = lb0 + y.o_atanh_b;
+    ca.ls_dil = lstep; ca.ls_aux = lstep;
+    ca.off_up_b = y.up_b;
+    ca.L = d.L; ca.R = d.R; ca.A = d.A;
+    ca.cvec = ws + w.cvec; ca.rowsum_aux = ws + w.rowsum_aux;
+    WN_TRY(wn_cvec(&ca, c.st));
+    WN_TRY(wn_sum_layers(params, y.skip0 + (long)d.S * d.R, y.ls_skip, d.L, d.S, ws + w.bskip, c.st));
+    WN_TRY(wn_fill(ws + w.one, 1.0f, 64, c.st));
+    if (c.fused) {
+        WN_TRY(wn_fused_pack_weights(params, lb0 + y.o_dsig_w, lb0 + y.o_dtanh_w, lb0 + y.o_res_w, lstep, y.skip0, y.ls_skip,
+                                     d.L, d.R, d.K, d.S, ws + w.fw_fwd, ws + w.fw_bwd, c.st));
+    }
+    return rt_check("pack_weights");
+}
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+extern "C" int wn_forward(const WnConfig* cfg, int B, int T, const float* params, const int64_t* x, const float* h,
+                          float* logits, void* wsp, size_t ws_bytes, int flags, void* stream) {
+    g_err[0] = 0;
+    Ctx c;
+    WN_TRY(make_ctx(&c, cfg, B, T, wsp, ws_bytes, flags, stream));
+    if (!params || !x || !h || !logits) return fail(1, "NULL argument");
+    const Dims& d = c.d;
+    const Lay& y = c.y;
+    const Ws& w = c.w;
+    float* ws = c.ws;
+    const int F = w.F, Ue = d.U > 0 ? d.U : 1;
+    const long BRT = (long)B * d.R * T;
+
+    WN_TRY(pack_weights(c, params));
+    // front: one-hot + causal conv as a gather  (wavenet.py:513-516)
+    WN_TRY(wn_front_gather(x, ws + w.wc_f, params + y.causal_b, ws + w.X, B, T, d.Q, d.R, d.K, c.st));
+    // frame-rate aux projection for all layers at once: G[b][l*2R+o'][f] = Waux_l . h[b][:, f]
+    {
+        WnGemmArgs g = wn_gemm_default();
+        g.M = d.L * 2 * d.R; g.N = F; g.K = d.A;
+        g.A = ws + w.waux_f; g.lda = (long)d.L * 2 * d.R;
+        g.B = h; g.ldb = F; g.b_zstride = (long)d.A * F; g.b_clen = F;
+        g.C = ws + w.G; g.ldc = F; g.c_zstride = (long)d.L * 2 * d.R * F;
+        g.nbatch = B;
+        WN_TRY(wn_gemm_launch(&g, c.st));
+    }
+    const float* upw = d.U > 0 ? params + y.up_w : ws + w.one;
+    const long g_bstride = (long)d.L * 2 * d.R * F;
+    for (int l = 0; l < d.L; ++l) {
+        const int dil = dilation_of(cfg, l);
+        const float* Xl = ws + w.X + (long)l * BRT;
+        float* Xn = (l + 1 < d.L) ? ws + w.X + (long)(l + 1) * BRT : nullptr;
+        const float* Gl = ws + w.G + (long)l * 2 * d.R * F;
+        float* Sl = ws + w.Sg + (long)l * BRT;
+        float* Gtl = ws + w.Gt + (long)l * BRT;
+        float* Zl = ws + w.Z + (long)l * BRT;
+        const long lb = layer_base(y, d, l);
+        if (c.fused) {
+            WN_TRY(wn_fused_resblock_fwd(ws + w.fw_fwd + (long)l * wn_fused_fwd_weight_floats(d.R, d.K), Xl, Gl, g_bstride, upw,
+                                         ws + w.cvec + (long)l * 2 * d.R, params + lb + y.o_res_b, Xn, Sl, Gtl, Zl, B, T, d.R,
+                                         d.K, dil, Ue, F, c.st));
+        } else {
+            // P = sum_tap W_tap . x[t-(K-1-tap)d]            (wavenet.py:527-528)
+            WnGemmArgs g = wn_gemm_default();
+            g.M = 2 * d.R; g.N = T; g.K = d.K * d.R;
+            g.A = ws + w.wd_f + (long)l * d.K * d.R * 2 * d.R; g.lda = 2 * d.R;
+            g.B = Xl; g.ldb = T; g.b_zstride = (long)d.R * T; g.b_clen = T;
+            g.b_seg_len = d.R; g.b_seg_stride = 0; g.b_shift0 = (d.K - 1) * dil; g.b_shift_step = -dil;
+            g.C = ws + w.P; g.ldc = T; g.c_zstride = (long)2 * d.R * T;
+            g.nbatch = B;
+            WN_TRY(wn_gemm_launch(&g, c.st));
+            // z = sigmoid(.)*tanh(.)                           (wavenet.py:529-532)
+            WN_TRY(wn_gate_fwd(ws + w.P, Gl, g_bstride, upw, ws + w.cvec + (long)l * 2 * d.R, Sl, Gtl, Zl, B, T, d.R, Ue, F,
+                               c.st));
+            // x_{l+1} = res_1x1(z) + x_l                       (wavenet.py:534-535); dead for the last layer
+            if (Xn) {
+                WnGemmArgs r = wn_gemm_default();
+                r.M = d.R; r.N = T; r.K = d.R;
+                r.A = ws + w.wres_f + (long)l * d.R * d.R; r.lda = d.R;
+                r.B = Zl; r.ldb = T; r.b_zstride = (long)d.R * T; r.b_clen = T;
+                r.C = Xn; r.ldc = T; r.c_zstride = (long)d.R * T;
+                r.bias = params + lb + y.o_res_b;
+                r.D = Xl; r.ldd = T; r.d_zstride = (long)d.R * T;
+                r.nbatch = B;
+                WN_TRY(wn_gemm_launch(&r, c.st));
+            }
+        }
+    }
+    // skip-sum over layers as ONE contraction with K = L*R (wavenet.py:533,238), relu fused (:519)
+    {
+        WnGemmArgs g = wn_gemm_default();
+        g.M = d.S; g.N = T; g.K = d.L * d.R;
+        g.A = ws + w.wskip_f; g.lda = d.S;
+        g.B = ws + w.Z; g.ldb = T; g.b_zstride = (long)d.R * T; g.b_clen = T;
+        g.b_seg_len = d.R; g.b_seg_stride = BRT;
+        g.C = ws + w.O1; g.ldc = T; g.c_zstride = (long)d.S * T;
+        g.bias = ws + w.bskip; g.relu = 1; g.nbatch = B;
+        WN_TRY(wn_gemm_launch(&g, c.st));
+    }
+    {   // conv_post_1 + relu  (wavenet.py:520-521)
+        WnGemmArgs g = wn_gemm_default();
+        g.M = d.S; g.N = T; g.K = d.S;
+        g.A = ws + w.w1_f; g.lda = d.S;
+        g.B = ws + w.O1; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = T;
+        g.C = ws + w.O2; g.ldc = T; g.c_zstride = (long)d.S * T;
+        g.bias = params + y.post1_b; g.relu = 1; g.nbatch = B;
+        WN_TRY(wn_gemm_launch(&g, c.st));
+    }
+    {   // conv_post_2  (wavenet.py:522)
+        WnGemmArgs g = wn_gemm_default();
+        g.M = d.Q; g.N = T; g.K = d.S;
+        g.A = ws + w.w2_f; g.lda = d.Q;
+        g.B = ws + w.O2; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = T;
+        g.C = logits; g.ldc = T; g.c_zstride = (long)d.Q * T;
+        g.bias = params + y.post2_b; g.nbatch = B;
+        WN_TRY(wn_gemm_launch(&g, c.st));
+    }
+    return rt_check("wn_forward");
+}
+
+// ------------------------------------------------------------------------------------------
+// loss
+// ------------------------------------------------------------------------------------------
+extern "C" int wn_softmax_ce_loss(const WnConfig* cfg, int B, int T, const float* logits, const int64_t* target, int t_start,
+                                  float grad_scale, float loss_scale, float* loss, float* dlogits, void* wsp, size_t ws_bytes,
+                                  void* stream) {
+    g_err[0] = 0;
+    Ctx c;
+    WN_TRY(make_ctx(&c, cfg, B, T, wsp, ws_bytes, 0, stream));
+    if (!logits || !target || !loss) return fail(1, "NULL argument");
+    if (t_start < 0 || t_start >= T) return fail(1, "t_start=%d outside [0,%d)", t_start, T);
+    int np = 0;
+    const float gs = grad_scale / ((float)B * (float)(T - t_start));
+    WN_TRY(wn_softmax_ce(logits, target, dlogits, c.ws + c.w.loss_partial, &np, B, T, c.d.Q, t_start, gs, c.st));
+    WN_TRY(wn_sum_partials(c.ws + c.w.loss_partial, np, loss_scale / ((float)B * (float)(T - t_start)), loss, c.st));
+    return rt_check("wn_softmax_ce_loss");
+}
+
+// ------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------
+struct DwOut {          // destination mapping of a weight-gradient (see WnReduceArgs)
+    float* out;
+    int m_seg, n_seg;
+    long m_seg_stride, m_stride, n_seg_stride, n_stride;
+    const float* addend_m;
+    const float* addend_scale_ptr;
+    float* rowsum_out;  // nullable: [M] contiguous destination of sum_k A(m,k)
+};
+
+// dW[m][n] = sum_{b, k} A_b(m,k) * B_b(n,k)   (k = time), split over (b, k-chunks), reduced in order.
+static int dw_gemm(const Ctx& c, WnGemmArgs g, const DwOut& o) {
+    const DwPlan p = dw_plan(g.M, g.N, g.K, c.B);
+    g.a_kmajor = 1; g.b_kmajor = 1;
+    g.nbatch = c.B; g.ksplit = p.ksplit; g.kchunk = p.kchunk;
+    g.C = c.ws + c.w.partial; g.ldc = g.N; g.c_zstride = (long)g.M * g.N;
+    g.a_rowsum = o.rowsum_out ? c.ws + c.w.rs_partial : nullptr;
+    WN_TRY(wn_gemm_launch(&g, c.st));
+    WnReduceArgs r;
+    r.partial = c.ws + c.w.partial; r.nz = p.nz; r.M = g.M; r.N = g.N;
+    r.out = o.out; r.m_seg = o.m_seg; r.n_seg = o.n_seg;
+    r.m_seg_stride = o.m_seg_stride; r.m_stride = o.m_stride; r.n_seg_stride = o.n_seg_stride; r.n_stride = o.n_stride;
+    r.scale = 1.0f; r.accumulate = 0; r.addend_m = o.addend_m; r.addend_scale_ptr = o.addend_scale_ptr;
+    WN_TRY(wn_reduce(&r, c.st));
+    if (o.rowsum_out) {
+        WnReduceArgs q;
+        q.partial = c.ws + c.w.rs_partial; q.nz = p.nz; q.M = g.M; q.N = 1;
+        q.out = o.rowsum_out; q.m_seg = 0x7fffffff; q.n_seg = 0x7fffffff;
+        q.m_seg_stride = 0; q.m_stride = 1; q.n_seg_stride = 0; q.n_stride = 0;
+        q.scale = 1.0f; q.accumulate = 0; q.addend_m = nullptr; q.addend_scale_ptr = nullptr;
+        WN_TRY(wn_reduce(&q, c.st));
+    }
+    return 0;
+}
+
+static DwOut dw_out_plain(float* out, long ld, float* rowsum_out) {
+    DwOut o;
+    o.out = out; o.m_seg = 0x7fffffff; o.n_seg = 0x7fffffff;
+    o.m_seg_stride = 0; o.m_stride = ld; o.n_seg_stride = 0; o.n_stride = 1;
+    o.addend_m = nullptr; o.addend_scale_ptr = nullptr; o.rowsum_out = rowsum_out;
+    return o;
+}
+
+extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* params, const int64_t* x, const float* h,
+                           const float* dlogits, float* grads, void* wsp, size_t ws_bytes, void* const* events, int n_events,
+                           int lpb, int flags, void* stream) {
+    g_err[0] = 0;
+    Ctx c;
+    WN_TRY(make_ctx(&c, cfg, B, T, wsp, ws_bytes, flags, stream));
+    if (!params || !x || !h || !dlogits || !grads) return fail(1, "NULL argument");
+    const Dims& d = c.d;
+    const Lay& y = c.y;
+    const Ws& w = c.w;
+    float* ws = c.ws;
+    const int F = w.F, Ue = d.U > 0 ? d.U : 1;
+    const long BRT = (long)B * d.R * T;
+    if (lpb < 1) lpb = d.L;
+    const int nb = wn_num_buckets(cfg, lpb);
+    if (events && n_events < nb) return fail(1, "need %d bucket events, got %d", nb, n_events);
+    int bucket = 0;
+
+    // ---- post-net backward (wavenet.py:518-523 reversed) ----
+    {   // dO2 = W2^T dlogits, masked by relu'(O2)
+        WnGemmArgs g = wn_gemm_default();
+        g.M = d.S; g.N = T; g.K = d.Q;
+        g.A = params + y.post2_w; g.lda = d.S;
+        g.B = dlogits; g.ldb = T; g.b_zstride = (long)d.Q * T; g.b_clen = T;
+        g.C = ws + w.dO2; g.ldc = T; g.c_zstride = (long)d.S * T;
+        g.E = ws + w.O2; g.lde = T; g.e_zstride = (long)d.S * T;
+        g.nbatch = B;
+        WN_TRY(wn_gemm_launch(&g, c.st));
+    }
+    {   // dSkip = W1^T dO2, masked by relu'(skip-sum)
+        WnGemmArgs g = wn_gemm_default();
+        g.M = d.S; g.N = T; g.K = d.S;
+        g.A = params + y.post1_w; g.lda = d.S;
+        g.B = ws + w.dO2; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = T;
+        g.C = ws + w.dSk; g.ldc = T; g.c_zstride = (long)d.S * T;
+        g.E = ws + w.O1; g.lde = T; g.e_zstride = (long)d.S * T;
+        g.nbatch = B;
+        WN_TRY(wn_gemm_launch(&g, c.st));
+    }
+    {   // d conv_post_2.{weight,bias}
+        WnGemmArgs g = wn_gemm_default();
+        g.M = d.Q; g.N = d.S; g.K = T;
+        g.A = dlogits; g.lda = T; g.a_zstride = (long)d.Q * T;
+        g.B = ws + w.O2; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = T;
+        WN_TRY(dw_gemm(c, g, dw_out_plain(grads + y.post2_w, d.S, grads + y.post2_b)));
+    }
+    {   // d conv_post_1.{weight,bias}
+        WnGemmArgs g = wn_gemm_default();
+        g.M = d.S; g.N = d.S; g.K = T;
+        g.A = ws + w.dO2; g.lda = T; g.a_zstride = (long)d.S * T;
+        g.B = ws + w.O1; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = T;
+        WN_TRY(dw_gemm(c, g, dw_out_plain(grads + y.post1_w, d.S, grads + y.post1_b)));
+    }
+    {   // d skip_1x1.l.weight for all layers in one contraction; bias = rowsum(dSkip) for every layer
+        WnGemmArgs g = wn_gemm_default();
+        g.M = d.S; g.N = d.L * d.R; g.K = T;
+        g.A = ws + w.dSk; g.lda = T; g.a_zstride = (long)d.S * T;
+        g.B = ws + w.Z; g.ldb = T; g.b_zstride = (long)d.R * T; g.b_clen = T;
+        g.b_seg_len = d.R; g.b_seg_stride = BRT;
+        DwOut o;
+        o.out = grads + y.skip0; o.m_seg = 0x7fffffff; o.m_seg_stride = 0; o.m_stride = d.R;
+        o.n_seg = d.R; o.n_seg_stride = y.ls_skip; o.n_stride = 1;
+        o.addend_m = nullptr; o.addend_scale_ptr = nullptr; o.rowsum_out = ws + w.tmpS;
+        WN_TRY(dw_gemm(c, g, o));
+        WnCopy4 cp;
+        cp.n0 = 1; cp.n1 = 1; cp.n2 = d.S; cp.nl = d.L;
+        cp.s0 = 0; cp.s1 = 0; cp.s2 = 1; cp.sl = 0;
+        cp.d0 = 0; cp.d1 = 0; cp.d2 = 1; cp.dl = y.ls_skip;
+        WN_TRY(wn_copy4(grads + y.skip0 + (long)d.S * d.R, ws + w.tmpS, &cp, c.st));
+    }
+    if (events) rt_event_record(events[bucket], c.st);
+    bucket++;
+
+    // ---- residual stack, last layer first (wavenet.py:525-536 reversed) ----
+    const float* upw = d.U > 0 ? params + y.up_w : ws + w.one;
+    const long g_bstride = (long)d.L * 2 * d.R * F;
+    float* dXn = nullptr;            // gradient w.r.t. the output of layer l (null: dead, last layer)
+    float* dXcur = ws + w.dXa;
+    float* dXother = ws + w.dXb;
+    for (int l = d.L - 1; l >= 0; --l) {
+        const int dil = dilation_of(cfg, l);
+        const long lb = layer_base(y, d, l);
+        const float* Xl = ws + w.X + (long)l * BRT;
+        const float* Sl = ws + w.Sg + (long)l * BRT;
+        const float* Gtl = ws + w.Gt + (long)l * BRT;
+        const float* Zl = ws + w.Z + (long)l * BRT;
+        const float* Gl = ws + w.G + (long)l * 2 * d.R * F;
+        float* dP = ws + w.P;
+        float* dc = ws + w.dc + (long)l * 2 * d.R;
+
+        // d res_1x1.l (needs dX_{l+1} and z_l); dead for the last layer -> zeros
+        if (dXn) {
+            WnGemmArgs g = wn_gemm_default();
+            g.M = d.R; g.N = d.R; g.K = T;
+            g.A = dXn; g.lda = T; g.a_zstride = (long)d.R * T;
+            g.B = Zl; g.ldb = T; g.b_zstride = (long)d.R * T; g.b_clen = T;
+            WN_TRY(dw_gemm(c, g, dw_out_plain(grads + lb + y.o_res_w, d.R, grads + lb + y.o_res_b)));
+        } else {
+            WN_TRY(wn_fill(grads + lb + y.o_res_w, 0.0f, (long)d.R * d.R + d.R, c.st));
+        }
+        if (c.fused) {
+            // dZ = Wskip^T dSk (+ Wres^T dXn) -> gate' -> dP
+            WN_TRY(wn_fused_resblock_bwd_gate(ws + w.fw_bwd + (long)l * wn_fused_bwd_weight_floats(d.R, d.K, d.S), ws + w.dSk, dXn,
+                                              Sl, Gtl, dP, B, T, d.R, d.S, c.st));
+        } else {
+            {   // dZ = Wskip_l^T dSkip
+                WnGemmArgs g = wn_gemm_default();
+                g.M = d.R; g.N = T; g.K = d.S;
+                g.A = params + y.skip0 + (long)l * y.ls_skip; g.lda = d.R;
+                g.B = ws + w.dSk; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = T;
+                g.C = ws + w.dZ; g.ldc = T; g.c_zstride = (long)d.R * T;
+                g.nbatch = B;
+                WN_TRY(wn_gemm_launch(&g, c.st));
+            }
+            if (dXn) {  // dZ += Wres_l^T dX_{l+1}
+                WnGemmArgs g = wn_gemm_default();
+                g.M = d.R; g.N = T; g.K = d.R;
+                g.A = params + lb + y.o_res_w; g.lda = d.R;
+                g.B = dXn; g.ldb = T; g.b_zstride = (long)d.R * T; g.b_clen = T;
+                g.C = ws + w.dZ; g.ldc = T; g.c_zstride = (long)d.R * T;
+                g.accumulate = 1; g.nbatch = B;
+                WN_TRY(wn_gemm_launch(&g, c.st));
+            }
+            WN_TRY(wn_gate_bwd(ws + w.dZ, Sl, Gtl, dP, B, T, d.R, c.st));
+        }
+        {   // d dil_{sigmoid,tanh}.l.conv.weight ; dc = rowsum(dP) -> conv + aux biases
+            WnGemmArgs g = wn_gemm_default();
+            g.M = 2 * d.R; g.N = d.K * d.R; g.K = T;
+            g.A = dP; g.lda = T; g.a_zstride = (long)2 * d.R * T;
+            g.B = Xl; g.ldb = T; g.b_zstride = (long)d.R * T; g.b_clen = T;
+            g.b_seg_len = d.R; g.b_seg_stride = 0; g.b_shift0 = (d.K - 1) * dil; g.b_shift_step = -dil;
+            DwOut o;
+            o.out = grads + lb + y.o_dsig_w;
+            o.m_seg = d.R; o.m_seg_stride = y.o_dtanh_w - y.o_dsig_w; o.m_stride = (long)d.R * d.K;
+            o.n_seg = d.R; o.n_seg_stride = 1; o.n_stride = d.K;
+            o.addend_m = nullptr; o.addend_scale_ptr = nullptr; o.rowsum_out = dc;
+            WN_TRY(dw_gemm(c, g, o));
+            WnCopy4 cp;  // biases: dil_{sig,tanh}.bias = dc ; aux_{sig,tanh}.bias = dc
+            cp.n0 = 1; cp.n1 = 2; cp.n2 = d.R; cp.nl = 1;
+            cp.s0 = 0; cp.s1 = d.R; cp.s2 = 1; cp.sl = 0;
+            cp.d0 = 0; cp.d1 = y.o_dtanh_b - y.o_dsig_b; cp.d2 = 1; cp.dl = 0;
+            WN_TRY(wn_copy4(grads + lb + y.o_dsig_b, dc, &cp, c.st));
+            cp.d1 = y.o_atanh_b - y.o_asig_b;
+            WN_TRY(wn_copy4(grads + lb + y.o_asig_b, dc, &cp, c.st));
+        }
+        {   // d aux_1x1_{sigmoid,tanh}.l.weight
+            DwOut o;
+            o.out = grads + lb + y.o_asig_w;
+            o.m_seg = d.R; o.m_seg_stride = y.o_atanh_w - y.o_asig_w; o.m_stride = d.A;
+            o.n_seg = 0x7fffffff; o.n_seg_stride = 0; o.n_stride = 1;
+            o.rowsum_out = nullptr;
+            WnGemmArgs g = wn_gemm_default();
+            g.M = 2 * d.R; g.N = d.A;
+            if (d.U > 0) {
+                // through the upsampling layer: dG[f] = sum_j w[j] dP[fU+j]; dW = dG.h^T + b_up*dc (x) 1
+                WN_TRY(wn_aux_bwd(dP, Gl, g_bstride, upw, ws + w.dG, ws + w.dw_partial + (long)l * B * 2 * d.R * Ue, B, T,
+                                  2 * d.R, Ue, F, c.st));
+                g.K = F;
+                g.A = ws + w.dG; g.lda = F; g.a_zstride = (long)2 * d.R * F;
+                g.B = h; g.ldb = F; g.b_zstride = (long)d.A * F; g.b_clen = F;
+                o.addend_m = dc; o.addend_scale_ptr = params + y.up_b;
+            } else {
+                g.K = T;
+                g.A = dP; g.lda = T; g.a_zstride = (long)2 * d.R * T;
+                g.B = h; g.ldb = T; g.b_zstride = (long)d.A * T; g.b_clen = T;
+                o.addend_m = nullptr; o.addend_scale_ptr = nullptr;
+            }
+            WN_TRY(dw_gemm(c, g, o));
+        }
+        {   // dX_l = dX_{l+1} + sum_tap W_tap^T dP[t + (K-1-tap) d]
+            WnGemmArgs g = wn_gemm_default();
+            g.M = d.R; g.N = T; g.K = d.K * 2 * d.R;
+            g.A = ws + w.wd_b + (long)l * d.K * 2 * d.R * d.R; g.lda = d.R;
+            g.B = dP; g.ldb = T; g.b_zstride = (long)2 * d.R * T; g.b_clen = T;
+            g.b_seg_len = 2 * d.R; g.b_seg_stride = 0; g.b_shift0 = -(d.K - 1) * dil; g.b_shift_step = dil;
+            g.C = dXcur; g.ldc = T; g.c_zstride = (long)d.R * T;
+            if (dXn) { g.D = dXn; g.ldd = T; g.d_zstride = (long)d.R * T; }
+            g.nbatch = B;
+            WN_TRY(wn_gemm_launch(&g, c.st));
+        }
+        dXn = dXcur;
+        float* t = dXcur; dXcur = dXother; dXother = t;
+        const int done = d.L - l;  // layers finished
+        if (done % lpb == 0 || l == 0) {
+            if (events) rt_event_record(events[bucket], c.st);
+            bucket++;
+        }
+    }
+    // ---- front conv (one-hot as an implicit operand) ----
+    {
+        WnGemmArgs g = wn_gemm_default();
+        g.M = d.R; g.N = d.K * d.Q; g.K = T;
+        g.A = dXn; g.lda = T; g.a_zstride = (long)d.R * T;
+        g.B = ws + w.X; /* unused (b_index set) */ g.ldb = 0; g.b_zstride = 0; g.b_clen = T;
+        g.b_seg_len = d.Q; g.b_shift0 = d.K - 1; g.b_shift_step = -1;
+        g.b_index = x; g.b_index_zstride = T; g.b_index_mod = d.Q;
+        DwOut o;
+        o.out = grads + y.causal_w; o.m_seg = 0x7fffffff; o.m_seg_stride = 0; o.m_stride = (long)d.Q * d.K;
+        o.n_seg = d.Q; o.n_seg_stride = 1; o.n_stride = d.K;
+        o.addend_m = nullptr; o.addend_scale_ptr = nullptr; o.rowsum_out = grads + y.causal_b;
+        WN_TRY(dw_gemm(c, g, o));
+    }
+    // ---- upsampling layer parameters ----
+    if (d.U > 0) {
+        WnReduceArgs r;
+        r.partial = ws + w.dw_partial; r.nz = d.L * B * 2 * d.R; r.M = 1; r.N = d.U;
+        r.out = grads + y.up_w; r.m_seg = 0x7fffffff; r.n_seg = 0x7fffffff;
+        r.m_seg_stride = 0; r.m_stride = 0; r.n_seg_stride = 0; r.n_stride = 1;
+        r.scale = 1.0f; r.accumulate = 0; r.addend_m = nullptr; r.addend_scale_ptr = nullptr;
+        WN_TRY(wn_reduce(&r, c.st));
+        // d b_up = sum_{l,o'} rowsum(Waux_l)[o'] * dc_l[o']
+        WN_TRY(wn_dot(ws + w.rowsum_aux, ws + w.dc, (long)d.L * 2 * d.R, grads + y.up_b, 0, c.st));
+    }
+    if (events) rt_event_record(events[bucket], c.st);
+    bucket++;
+    return rt_check("wn_backward");
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" int wn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
+                            float lr, float beta1, float beta2, float eps, float weight_decay, int64_t skip_lo,
+                            int64_t skip_hi, void* stream) {
+    g_err[0] = 0;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || n <= 0 || step < 1) return fail(1, "bad wn_adam_step argument");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    WN_TRY(wn_adam(params, grads, exp_avg, exp_avg_sq, (long)n, (float)((double)lr / bc1), (float)sqrt(bc2), beta1, beta2, eps,
+                   weight_decay, (long)skip_lo, (long)skip_hi, (wn_stream_t)stream));
+    return rt_check("wn_adam_step");
+}
+
+// ------------------------------------------------------------------------------------------
+// op-level entry points
+// ------------------------------------------------------------------------------------------
+extern "C" int wn_op_front(const float* weight, const float* bias, const int64_t* x, float* out, float* scratch, int B, int T,
+                           int Q, int R, int K, void* stream) {
+    g_err[0] = 0;
+    WnCopy4 cp;
+    cp.n0 = K; cp.n1 = Q; cp.n2 = R; cp.nl = 1;
+    cp.d0 = (long)Q * R; cp.d1 = R; cp.d2 = 1; cp.dl = 0;
+    cp.s0 = 1; cp.s1 = K; cp.s2 = (long)Q * K; cp.sl = 0;
+    WN_TRY(wn_copy4(scratch, weight, &cp, (wn_stream_t)stream));
+    WN_TRY(wn_front_gather(x, scratch, bias, out, B, T, Q, R, K, (wn_stream_t)stream));
+    return rt_check("wn_op_front");
+}
+
+extern "C" int wn_op_causal_conv(const float* weight, const float* bias, const float* x, float* y, float* scratch, int B, int T,
+                                 int Cin, int Cout, int K, int dilation, void* stream) {
+    g_err[0] = 0;
+    WnCopy4 cp;  // scratch[(tap*Cin + i)*Cout + o] = W[o][i][tap]
+    cp.n0 = K; cp.n1 = Cin; cp.n2 = Cout; cp.nl = 1;
+    cp.s0 = 1; cp.s1 = K; cp.s2 = (long)Cin * K; cp.sl = 0;
+    cp.d0 = (long)Cin * Cout; cp.d1 = Cout; cp.d2 = 1; cp.dl = 0;
+    WN_TRY(wn_copy4(scratch, weight, &cp, (wn_stream_t)stream));
+    WnGemmArgs g = wn_gemm_default();
+    g.M = Cout; g.N = T; g.K = K * Cin;
+    g.A = scratch; g.lda = Cout;
+    g.B = x; g.ldb = T; g.b_zstride = (long)Cin * T; g.b_clen = T;
+    g.b_seg_len = Cin; g.b_seg_stride = 0; g.b_shift0 = (K - 1) * dilation; g.b_shift_step = -dilation;
+    g.C = y; g.ldc = T; g.c_zstride = (long)Cout * T;
+    g.bias = bias; g.nbatch = B;
+    WN_TRY(wn_gemm_launch(&g, (wn_stream_t)stream));
+    return rt_check("wn_op_causal_conv");
+}
+
+extern "C" int wn_op_gemm(const struct WnGemmArgs* args, void* stream) {
+    g_err[0] = 0;
+    WN_TRY(wn_gemm_launch(args, (wn_stream_t)stream));
+    return rt_check("wn_op_gemm");
+}

@@ -1,0 +1,64 @@
+// wn_device.h -- device-side common definitions for the gfx950 (CDNA4 / MI355X) kernels.
+//
+// The product build is hipcc --offload-arch=gfx950.  The same sources also compile with g++
+// and -DWN_EMU against tests/emu/hip_emu.h (TEST INFRASTRUCTURE: index-math checks without a
+// GPU).  Everything architecture specific is funnelled through this header:
+//   * f32x16 / mfma32(): v_mfma_f32_32x32x2_f32 -- exact f32 (k-ordered fma chain) at the f32
+//     vector rate; lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31]; the 16 accumulator
+//     registers of lane l hold D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31].
+//   * WN_LAUNCH(): kernel launch on an explicit stream.
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef WN_EMU
+#include "hip_emu.h"
+typedef emu::f32x16_t f32x16;
+typedef void* wn_stream_t;
+#define WN_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    emu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
+#define WN_DYN_SMEM(name) char* name = emu::S().dyn_smem
+static inline f32x16 mfma32(float a, float b, f32x16 c) { return emu::mfma_f32_32x32x2f32(a, b, c); }
+#define WN_UNROLL
+#define WN_UNROLL_N(n)
+#else
+#include <hip/hip_runtime.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef hipStream_t wn_stream_t;
+#define WN_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kernel, (grid), (block), (smem), (stream), __VA_ARGS__)
+#define WN_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+static __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+#define WN_UNROLL _Pragma("unroll")
+#define WN_PRAGMA(x) _Pragma(#x)
+#define WN_UNROLL_N(n) WN_PRAGMA(unroll n)
+#endif
+
+// Row (M index) of accumulator register r for a lane whose upper-half flag is hi (= lane>>5).
+static __device__ __forceinline__ int mfma32_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+static __device__ __forceinline__ f32x16 f32x16_zero() {
+    f32x16 z;
+    WN_UNROLL
+    for (int i = 0; i < 16; ++i) z[i] = 0.0f;
+    return z;
+}
+
+// Accurate logistic / tanh built on expf (ocml expf is ~1 ulp).  tanh via expm1-free form:
+// tanh(x) = sign(x) * (1 - 2/(exp(2|x|)+1)).
+static __device__ __forceinline__ float wn_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+static __device__ __forceinline__ float wn_tanh(float x) { return tanhf(x); }
+
+static __device__ __forceinline__ float wave_reduce_sum(float v) {
+    WN_UNROLL
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+static __device__ __forceinline__ float wave_reduce_max(float v) {
+    WN_UNROLL
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}

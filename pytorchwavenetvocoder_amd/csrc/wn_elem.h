@@ -1,0 +1,81 @@
+// wn_elem.h -- launchers of the element-wise / reduction kernels of the WaveNet path (wn_elem.hip).
+// All tensors are channel-major (B, C, T) fp32 like the reference's; indices are int64.
+#pragma once
+#include "wn_device.h"
+
+// x0[b][r][t] = bc[r] + sum_tap Wc_f[tap][x[b][t-(K-1-tap)] mod Q][r]   (zero history)
+// == reference OneHot + CausalConv1d(Q->R,K)  (wavenet.py:88-92,513-516,118-121)
+int wn_front_gather(const int64_t* x, const float* wc_f /*[K][Q][R]*/, const float* bias /*[R]*/,
+                    float* x0 /*[B][R][T]*/, int B, int T, int Q, int R, int K, wn_stream_t st);
+
+// Gate: a = P[b][r][t] + w[t%U]*G[b][r][t/U] + c[r];  g likewise with r+R;
+//       s = sigmoid(a), gt = tanh(g), z = s*gt        (wavenet.py:529-532 with the upsampling of
+//       wavenet.py:152-154 applied at frame rate: aux(up(h)) = w[j]*(Waux.h[f]) + (b_up*rowsum(Waux)+b_aux))
+// U = 1, w = {1} expresses "no upsampling layer" (h at sample rate).
+int wn_gate_fwd(const float* P /*[B][2R][T]*/, const float* G /*[B][2R][F]*/, long g_bstride,
+                const float* upw /*[U]*/, const float* cvec /*[2R]*/, float* S, float* Gt, float* Z,
+                int B, int T, int R, int U, int F, wn_stream_t st);
+
+// dP[b][r][t] = dZ*gt*s*(1-s);  dP[b][R+r][t] = dZ*s*(1-gt^2)
+int wn_gate_bwd(const float* dZ, const float* S, const float* Gt, float* dP, int B, int T, int R, wn_stream_t st);
+
+// Softmax cross entropy over logits (B,Q,T) for positions t >= t_start (train.py:534-536):
+//   loss = mean_{b,t>=t_start} ( logsumexp_q - logit[target] );  dlogits = (softmax - onehot) * grad_scale
+// (zero for t < t_start).  loss_partial has one float per launched block; wn_loss_finalize sums
+// them in a fixed order and multiplies by loss_scale.
+int wn_softmax_ce(const float* logits, const int64_t* target, float* dlogits /*nullable*/,
+                  float* loss_partial, int* n_partial /*out: host*/, int B, int T, int Q, int t_start,
+                  float grad_scale, wn_stream_t st);
+int wn_sum_partials(const float* partial, int n, float scale, float* out /*device scalar*/, wn_stream_t st);
+int wn_softmax_ce_nblocks(int B, int T);
+
+// Adam over a flat fp32 buffer (torch.optim.Adam semantics, train.py:457-460): elements in
+// [skip_lo, skip_hi) are left untouched (parameters that never receive a gradient).
+int wn_adam(float* p, const float* g, float* m, float* v, long n, float lr_over_bc1, float inv_sqrt_bc2,
+            float beta1, float beta2, float eps, float weight_decay, long skip_lo, long skip_hi, wn_stream_t st);
+
+// dst[d_off + i0*d0 + i1*d1 + i2*d2 + l*dl] = src[s_off + i0*s0 + i1*s1 + i2*s2 + l*sl]
+typedef struct WnCopy4 {
+    int n0, n1, n2, nl;
+    long d0, d1, d2, dl, s0, s1, s2, sl;
+} WnCopy4;
+int wn_copy4(float* dst, const float* src, const WnCopy4* c, wn_stream_t st);
+
+// cvec[l][o'] = b_dil[o'] + b_aux[o'] + b_up * sum_a Waux[o'][a]   (o' in [0,2R): sigmoid then tanh)
+// rowsum_aux[l][o'] = sum_a Waux[o'][a]
+typedef struct WnCvecArgs {
+    const float* params;
+    long off_dsig_b, off_dtanh_b, off_asig_w, off_atanh_w, off_asig_b, off_atanh_b;  // layer 0
+    long ls_dil, ls_aux;                                                           // layer strides
+    long off_up_b;                                                                 // -1: none
+    int L, R, A;
+    float* cvec;
+    float* rowsum_aux;
+} WnCvecArgs;
+int wn_cvec(const WnCvecArgs* a, wn_stream_t st);
+// out[s] = sum_l params[off + l*ls + s]
+int wn_sum_layers(const float* params, long off, long ls, int L, int n, float* out, wn_stream_t st);
+
+// Aux backward for one layer (upsampling layer present):
+//   dG[b][o'][f] = sum_j w[j] dP[b][o'][fU+j];   dw_partial[(b*2R+o')][j] = sum_f dP[b][o'][fU+j] G[b][o'][f]
+int wn_aux_bwd(const float* dP, const float* G, long g_bstride, const float* upw, float* dG, float* dw_partial,
+               int B, int T, int R2, int U, int F, wn_stream_t st);
+
+// out[map(m,n)] (=|+=) scale * sum_z partial[z][m*N+n] (+ addend_m[m]*addend_scale)
+// map(m,n) = (m/m_seg)*m_seg_stride + (m%m_seg)*m_stride + (n/n_seg)*n_seg_stride + (n%n_seg)*n_stride
+typedef struct WnReduceArgs {
+    const float* partial;
+    int nz, M, N;
+    float* out;
+    int m_seg, n_seg;
+    long m_seg_stride, m_stride, n_seg_stride, n_stride;
+    float scale;
+    int accumulate;
+    const float* addend_m;  // nullable, [M]
+    const float* addend_scale_ptr;  // nullable device scalar multiplied onto addend_m
+} WnReduceArgs;
+int wn_reduce(const WnReduceArgs* a, wn_stream_t st);
+
+// out[0] (=|+=) sum_i a[i]*b[i]
+int wn_dot(const float* a, const float* b, long n, float* out, int accumulate, wn_stream_t st);
+int wn_fill(float* p, float v, long n, wn_stream_t st);

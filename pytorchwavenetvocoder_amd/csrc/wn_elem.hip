@@ -1,0 +1,329 @@
+// wn_elem.hip -- element-wise / reduction kernels of the WaveNet training path (gfx950).
+// These are the HBM-bound parts: every kernel walks the time axis with consecutive lanes on
+// consecutive samples (coalesced 256 B per wave-instruction) and all reductions are two-stage
+// and order-deterministic (no float atomics).
+#include "wn_elem.h"
+
+#define WN_TPB 256
+
+static __device__ __forceinline__ float block_reduce_sum(float v, float* red /*[4]*/) {
+    v = wave_reduce_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.0f;
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WN_TPB) void k_front_gather(const int64_t* __restrict__ x, const float* __restrict__ wc_f,
+                                                         const float* __restrict__ bias, float* __restrict__ x0, int T,
+                                                         int Q, int R, int K) {
+    const int t = blockIdx.x * WN_TPB + threadIdx.x;
+    const int b = blockIdx.y;
+    if (t >= T) return;
+    int q[8];
+    for (int tap = 0; tap < K; ++tap) {
+        const int idx = t - (K - 1 - tap);
+        int v = -1;
+        if (idx >= 0) {
+            long long xv = x[(long)b * T + idx] % Q;
+            if (xv < 0) xv += Q;
+            v = (int)xv;
+        }
+        q[tap] = v;
+    }
+    for (int r = 0; r < R; ++r) {
+        float v = bias[r];
+        for (int tap = 0; tap < K; ++tap)
+            if (q[tap] >= 0) v += wc_f[((long)tap * Q + q[tap]) * R + r];
+        x0[((long)b * R + r) * T + t] = v;
+    }
+}
+
+int wn_front_gather(const int64_t* x, const float* wc_f, const float* bias, float* x0, int B, int T, int Q, int R, int K,
+                    wn_stream_t st) {
+    if (K > 8 || K < 1) return 1;
+    dim3 grid((T + WN_TPB - 1) / WN_TPB, B);
+    WN_LAUNCH(k_front_gather, grid, dim3(WN_TPB), 0, st, x, wc_f, bias, x0, T, Q, R, K);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WN_TPB) void k_gate_fwd(const float* __restrict__ P, const float* __restrict__ G, long g_bstride,
+                                                     const float* __restrict__ upw, const float* __restrict__ cvec,
+                                                     float* __restrict__ S, float* __restrict__ Gt, float* __restrict__ Z, int T,
+                                                     int R, int U, int F) {
+    const int t = blockIdx.x * WN_TPB + threadIdx.x;
+    const int r = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    const int f = t / U, j = t - f * U;
+    const float w = upw[j];
+    const float* Gb = G + (long)b * g_bstride;
+    const float a = P[((long)b * 2 * R + r) * T + t] + (w * Gb[(long)r * F + f] + cvec[r]);
+    const float g = P[((long)b * 2 * R + R + r) * T + t] + (w * Gb[(long)(R + r) * F + f] + cvec[R + r]);
+    const float s = wn_sigmoid(a), gt = wn_tanh(g);
+    const long o = ((long)b * R + r) * T + t;
+    S[o] = s;
+    Gt[o] = gt;
+    Z[o] = s * gt;
+}
+
+int wn_gate_fwd(const float* P, const float* G, long g_bstride, const float* upw, const float* cvec, float* S, float* Gt,
+                float* Z, int B, int T, int R, int U, int F, wn_stream_t st) {
+    if (U < 1) return 1;
+    dim3 grid((T + WN_TPB - 1) / WN_TPB, R, B);
+    WN_LAUNCH(k_gate_fwd, grid, dim3(WN_TPB), 0, st, P, G, g_bstride, upw, cvec, S, Gt, Z, T, R, U, F);
+    return 0;
+}
+
+__global__ __launch_bounds__(WN_TPB) void k_gate_bwd(const float* __restrict__ dZ, const float* __restrict__ S,
+                                                     const float* __restrict__ Gt, float* __restrict__ dP, int T, int R) {
+    const int t = blockIdx.x * WN_TPB + threadIdx.x;
+    const int r = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    const long o = ((long)b * R + r) * T + t;
+    const float dz = dZ[o], s = S[o], g = Gt[o];
+    dP[((long)b * 2 * R + r) * T + t] = dz * g * (s * (1.0f - s));
+    dP[((long)b * 2 * R + R + r) * T + t] = dz * s * (1.0f - g * g);
+}
+
+int wn_gate_bwd(const float* dZ, const float* S, const float* Gt, float* dP, int B, int T, int R, wn_stream_t st) {
+    dim3 grid((T + WN_TPB - 1) / WN_TPB, R, B);
+    WN_LAUNCH(k_gate_bwd, grid, dim3(WN_TPB), 0, st, dZ, S, Gt, dP, T, R);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WN_TPB) void k_softmax_ce(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                       float* __restrict__ dlogits, float* __restrict__ loss_partial, int T,
+                                                       int Q, int t_start, float grad_scale) {
+    __shared__ float red[4];
+    const int t = blockIdx.x * WN_TPB + threadIdx.x;
+    const int b = blockIdx.y;
+    float my_loss = 0.0f;
+    const bool live = (t < T) && (t >= t_start);
+    const float* lg = logits + (long)b * Q * T + t;
+    if (live) {
+        float mx = lg[0], sum = 1.0f;
+        for (int q = 1; q < Q; ++q) {
+            const float v = lg[(long)q * T];
+            if (v > mx) {
+                sum = sum * expf(mx - v) + 1.0f;
+                mx = v;
+            } else {
+                sum += expf(v - mx);
+            }
+        }
+        long long tg = target[(long)b * T + t] % Q;
+        if (tg < 0) tg += Q;
+        const float lse = logf(sum) + mx;
+        my_loss = lse - lg[(long)tg * T];
+        if (dlogits != nullptr) {
+            float* dl = dlogits + (long)b * Q * T + t;
+            for (int q = 0; q < Q; ++q) {
+                float p = expf(lg[(long)q * T] - lse);
+                if (q == (int)tg) p -= 1.0f;
+                dl[(long)q * T] = p * grad_scale;
+            }
+        }
+    } else if (t < T && dlogits != nullptr) {
+        float* dl = dlogits + (long)b * Q * T + t;
+        for (int q = 0; q < Q; ++q) dl[(long)q * T] = 0.0f;
+    }
+    const float tot = block_reduce_sum(my_loss, red);
+    if (threadIdx.x == 0) loss_partial[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+}
+
+int wn_softmax_ce_nblocks(int B, int T) { return ((T + WN_TPB - 1) / WN_TPB) * B; }
+
+int wn_softmax_ce(const float* logits, const int64_t* target, float* dlogits, float* loss_partial, int* n_partial, int B,
+                  int T, int Q, int t_start, float grad_scale, wn_stream_t st) {
+    dim3 grid((T + WN_TPB - 1) / WN_TPB, B);
+    if (n_partial) *n_partial = (int)(grid.x * grid.y);
+    WN_LAUNCH(k_softmax_ce, grid, dim3(WN_TPB), 0, st, logits, target, dlogits, loss_partial, T, Q, t_start, grad_scale);
+    return 0;
+}
+
+__global__ __launch_bounds__(WN_TPB) void k_sum_partials(const float* __restrict__ partial, int n, float scale,
+                                                         float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < n; i += WN_TPB) s += partial[i];
+    const float tot = block_reduce_sum(s, red);
+    if (threadIdx.x == 0) out[0] = tot * scale;
+}
+
+int wn_sum_partials(const float* partial, int n, float scale, float* out, wn_stream_t st) {
+    WN_LAUNCH(k_sum_partials, dim3(1), dim3(WN_TPB), 0, st, partial, n, scale, out);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WN_TPB) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                 float* __restrict__ v, long n, float lr_over_bc1, float sqrt_bc2, float beta1,
+                                                 float beta2, float eps, float wd, long skip_lo, long skip_hi) {
+    const long stride = (long)gridDim.x * WN_TPB;
+    for (long i = (long)blockIdx.x * WN_TPB + threadIdx.x; i < n; i += stride) {
+        if (i >= skip_lo && i < skip_hi) continue;
+        const float pv = p[i];
+        float gv = g[i];
+        if (wd != 0.0f) gv += wd * pv;
+        const float mv = beta1 * m[i] + (1.0f - beta1) * gv;
+        const float vv = beta2 * v[i] + (1.0f - beta2) * gv * gv;
+        m[i] = mv;
+        v[i] = vv;
+        const float denom = sqrtf(vv) / sqrt_bc2 + eps;
+        p[i] = pv - lr_over_bc1 * (mv / denom);
+    }
+}
+
+int wn_adam(float* p, const float* g, float* m, float* v, long n, float lr_over_bc1, float sqrt_bc2, float beta1, float beta2,
+            float eps, float weight_decay, long skip_lo, long skip_hi, wn_stream_t st) {
+    long nb = (n + WN_TPB - 1) / WN_TPB;
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    WN_LAUNCH(k_adam, dim3((unsigned)nb), dim3(WN_TPB), 0, st, p, g, m, v, n, lr_over_bc1, sqrt_bc2, beta1, beta2, eps,
+              weight_decay, skip_lo, skip_hi);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WN_TPB) void k_copy4(float* __restrict__ dst, const float* __restrict__ src, WnCopy4 c) {
+    const long total = (long)c.nl * c.n0 * c.n1 * c.n2;
+    const long i = (long)blockIdx.x * WN_TPB + threadIdx.x;
+    if (i >= total) return;
+    const int i2 = (int)(i % c.n2);
+    long r = i / c.n2;
+    const int i1 = (int)(r % c.n1);
+    r /= c.n1;
+    const int i0 = (int)(r % c.n0);
+    const int l = (int)(r / c.n0);
+    dst[i0 * c.d0 + i1 * c.d1 + i2 * c.d2 + l * c.dl] = src[i0 * c.s0 + i1 * c.s1 + i2 * c.s2 + l * c.sl];
+}
+
+int wn_copy4(float* dst, const float* src, const WnCopy4* c, wn_stream_t st) {
+    const long total = (long)c->nl * c->n0 * c->n1 * c->n2;
+    if (total <= 0) return 0;
+    WN_LAUNCH(k_copy4, dim3((unsigned)((total + WN_TPB - 1) / WN_TPB)), dim3(WN_TPB), 0, st, dst, src, *c);
+    return 0;
+}
+
+__global__ __launch_bounds__(WN_TPB) void k_cvec(WnCvecArgs a) {
+    const int l = blockIdx.x;
+    const float bup = (a.off_up_b >= 0) ? a.params[a.off_up_b] : 0.0f;
+    for (int o = threadIdx.x; o < 2 * a.R; o += WN_TPB) {
+        const bool th = o >= a.R;
+        const int r = th ? o - a.R : o;
+        const float* w = a.params + (th ? a.off_atanh_w : a.off_asig_w) + (long)l * a.ls_aux + (long)r * a.A;
+        float rs = 0.0f;
+        for (int k = 0; k < a.A; ++k) rs += w[k];
+        const float bd = a.params[(th ? a.off_dtanh_b : a.off_dsig_b) + (long)l * a.ls_dil + r];
+        const float ba = a.params[(th ? a.off_atanh_b : a.off_asig_b) + (long)l * a.ls_aux + r];
+        a.cvec[(long)l * 2 * a.R + o] = (bd + ba) + bup * rs;
+        a.rowsum_aux[(long)l * 2 * a.R + o] = rs;
+    }
+}
+
+int wn_cvec(const WnCvecArgs* a, wn_stream_t st) {
+    WN_LAUNCH(k_cvec, dim3((unsigned)a->L), dim3(WN_TPB), 0, st, *a);
+    return 0;
+}
+
+__global__ __launch_bounds__(WN_TPB) void k_sum_layers(const float* __restrict__ params, long off, long ls, int L, int n,
+                                                       float* __restrict__ out) {
+    const int i = blockIdx.x * WN_TPB + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.0f;
+    for (int l = 0; l < L; ++l) s += params[off + (long)l * ls + i];
+    out[i] = s;
+}
+
+int wn_sum_layers(const float* params, long off, long ls, int L, int n, float* out, wn_stream_t st) {
+    WN_LAUNCH(k_sum_layers, dim3((unsigned)((n + WN_TPB - 1) / WN_TPB)), dim3(WN_TPB), 0, st, params, off, ls, L, n, out);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WN_TPB) void k_aux_bwd(const float* __restrict__ dP, const float* __restrict__ G, long g_bstride,
+                                                    const float* __restrict__ upw, float* __restrict__ dG,
+                                                    float* __restrict__ dw_partial, int T, int R2, int U, int F) {
+    const int o = blockIdx.x, b = blockIdx.y;
+    const float* row = dP + ((long)b * R2 + o) * T;
+    const float* grow = G + (long)b * g_bstride + (long)o * F;
+    // pass 1: dw[j] partial, lanes along j (coalesced)
+    for (int j = threadIdx.x; j < U; j += WN_TPB) {
+        float acc = 0.0f;
+        for (int f = 0; f < F; ++f) acc += row[(long)f * U + j] * grow[f];
+        dw_partial[((long)b * R2 + o) * U + j] = acc;
+    }
+    // pass 2: dG[f] = sum_j w[j] dP[fU+j]
+    for (int f = threadIdx.x; f < F; f += WN_TPB) {
+        float acc = 0.0f;
+        const float* p = row + (long)f * U;
+        for (int j = 0; j < U; ++j) acc += upw[j] * p[j];
+        dG[((long)b * R2 + o) * F + f] = acc;
+    }
+}
+
+int wn_aux_bwd(const float* dP, const float* G, long g_bstride, const float* upw, float* dG, float* dw_partial, int B, int T,
+               int R2, int U, int F, wn_stream_t st) {
+    if ((long)U * F != T) return 1;
+    WN_LAUNCH(k_aux_bwd, dim3((unsigned)R2, (unsigned)B), dim3(WN_TPB), 0, st, dP, G, g_bstride, upw, dG, dw_partial, T, R2, U,
+              F);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WN_TPB) void k_reduce(WnReduceArgs a) {
+    const long mn = (long)a.M * a.N;
+    const long i = (long)blockIdx.x * WN_TPB + threadIdx.x;
+    if (i >= mn) return;
+    float s = 0.0f;
+    for (int z = 0; z < a.nz; ++z) s += a.partial[(long)z * mn + i];
+    s *= a.scale;
+    const int m = (int)(i / a.N), n = (int)(i % a.N);
+    if (a.addend_m != nullptr) {
+        const float sc = a.addend_scale_ptr ? a.addend_scale_ptr[0] : 1.0f;
+        s += a.addend_m[m] * sc;
+    }
+    const long o = (long)(m / a.m_seg) * a.m_seg_stride + (long)(m % a.m_seg) * a.m_stride +
+                   (long)(n / a.n_seg) * a.n_seg_stride + (long)(n % a.n_seg) * a.n_stride;
+    if (a.accumulate) s += a.out[o];
+    a.out[o] = s;
+}
+
+int wn_reduce(const WnReduceArgs* a, wn_stream_t st) {
+    const long mn = (long)a->M * a->N;
+    if (mn <= 0 || a->m_seg <= 0 || a->n_seg <= 0) return 1;
+    WN_LAUNCH(k_reduce, dim3((unsigned)((mn + WN_TPB - 1) / WN_TPB)), dim3(WN_TPB), 0, st, *a);
+    return 0;
+}
+
+__global__ __launch_bounds__(WN_TPB) void k_dot(const float* __restrict__ a, const float* __restrict__ b, long n,
+                                                float* __restrict__ out, int accumulate) {
+    __shared__ float red[4];
+    float s = 0.0f;
+    for (long i = threadIdx.x; i < n; i += WN_TPB) s += a[i] * b[i];
+    const float tot = block_reduce_sum(s, red);
+    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + tot : tot;
+}
+
+int wn_dot(const float* a, const float* b, long n, float* out, int accumulate, wn_stream_t st) {
+    WN_LAUNCH(k_dot, dim3(1), dim3(WN_TPB), 0, st, a, b, n, out, accumulate);
+    return 0;
+}
+
+__global__ __launch_bounds__(WN_TPB) void k_fill(float* __restrict__ p, float v, long n) {
+    const long i = (long)blockIdx.x * WN_TPB + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+int wn_fill(float* p, float v, long n, wn_stream_t st) {
+    if (n <= 0) return 0;
+    WN_LAUNCH(k_fill, dim3((unsigned)((n + WN_TPB - 1) / WN_TPB)), dim3(WN_TPB), 0, st, p, v, n);
+    return 0;
+}

@@ -1,0 +1,210 @@
+// wn_gemm.hip -- generic fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Why f32-input MFMA: the parity gate is 1e-4 on fp32 logits after 30 residual layers; the
+// f32 MFMA is bit-for-bit a k-ordered fmaf chain (exact f32) and runs at the f32 vector peak
+// (157 TFLOP/s) while leaving the VALU free for loaders/epilogues.  This kernel is the
+// work-horse for everything on the path that is a plain contraction:
+//   * skip-sum   (reference wavenet.py:533,238):  [S x L*R] . [L*R x T]      (segment = layer)
+//   * post-net   (wavenet.py:518-523):            [S x S].[S x T], [Q x S].[S x T]
+//   * weight gradients (contraction over time)    dW[o][i] = sum_t dY[o][t] X[i][t-shift]
+//   * the any-size "layered" path (R != 64): dilated taps as K-segments with per-segment shift.
+//
+// Tiling: 256 threads = 4 waves (2x2), block tile (64*TM) x (64*TN), BK = 32; each wave owns
+// TM x TN 32x32 MFMA tiles.  Global -> registers -> LDS with the next tile's loads in flight
+// during the MFMAs of the current one.  All LDS traffic is ds_read/write_b32 and conflict free:
+//   k-minor tiles  [kk][mn]      : lanes read 32 consecutive floats of one row
+//   k-major tiles  [mn][kk + 1]  : row stride 33 dwords -> bank = (mn + kk) mod 32
+// Lane l of a wave feeds A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; accumulator register r
+// of lane l is D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]  (see wn_device.h).
+#include "wn_gemm.h"
+
+#define WN_BK 32
+#define WN_GEMM_THREADS 256
+
+template <int BMN, int KMAJ>
+struct TileGeom {
+    static constexpr int LD = KMAJ ? (WN_BK + 1) : BMN;
+    static constexpr int SIZE = KMAJ ? BMN * (WN_BK + 1) : WN_BK * BMN;
+    static constexpr int NE = BMN * WN_BK / WN_GEMM_THREADS;
+    static __device__ __forceinline__ void coord(int e, int tid, int& kk, int& mn) {
+        int idx = e * WN_GEMM_THREADS + tid;
+        if (KMAJ) {
+            mn = idx / WN_BK;
+            kk = idx % WN_BK;
+        } else {
+            kk = idx / BMN;
+            mn = idx % BMN;
+        }
+    }
+    static __device__ __forceinline__ int soff(int kk, int mn) { return KMAJ ? mn * LD + kk : kk * LD + mn; }
+};
+
+template <int TM, int TN, int KMAJ>
+__global__ __launch_bounds__(WN_GEMM_THREADS) void wn_gemm_kernel(WnGemmArgs g) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    typedef TileGeom<BM, KMAJ> GA;
+    typedef TileGeom<BN, KMAJ> GB;
+    __shared__ float As[GA::SIZE];
+    __shared__ float Bs[GB::SIZE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int z = blockIdx.z;
+    const int b = z / g.ksplit;
+    const int ks = z - b * g.ksplit;
+    const int kbeg = ks * g.kchunk;
+    const int kend = (g.K - kbeg > g.kchunk) ? (kbeg + g.kchunk) : g.K;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const float* __restrict__ Az = g.A + (long)b * g.a_zstride;
+    const float* __restrict__ Bz = g.B + (long)b * g.b_zstride;
+    const bool one_seg = (g.b_seg_len >= (KMAJ ? g.N : g.K));
+
+    float ra[GA::NE], rb[GB::NE];
+    f32x16 acc[TM][TN];
+    WN_UNROLL
+    for (int i = 0; i < TM; ++i) {
+        WN_UNROLL
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x16_zero();
+    }
+    float rowsum = 0.0f;
+
+    auto fetch = [&](int k0) {
+        WN_UNROLL
+        for (int e = 0; e < GA::NE; ++e) {
+            int kk, mn;
+            GA::coord(e, tid, kk, mn);
+            const int k = k0 + kk, m = m0 + mn;
+            const bool ok = (k < kend) && (m < g.M);
+            const long addr = KMAJ ? ((long)m * g.lda + k) : ((long)k * g.lda + m);
+            ra[e] = ok ? Az[addr] : 0.0f;
+        }
+        WN_UNROLL
+        for (int e = 0; e < GB::NE; ++e) {
+            int kk, mn;
+            GB::coord(e, tid, kk, mn);
+            const int k = k0 + kk, n = n0 + mn;
+            bool ok = (k < kend) && (n < g.N);
+            const int r = KMAJ ? n : k;
+            const int c = KMAJ ? k : n;
+            int seg = 0, rr = r;
+            if (!one_seg) {
+                seg = r / g.b_seg_len;
+                rr = r - seg * g.b_seg_len;
+            }
+            const int cc = c - (g.b_shift0 + seg * g.b_shift_step);
+            ok = ok && (cc >= 0) && (cc < g.b_clen);
+            float v = 0.0f;
+            if (g.b_index != nullptr) {
+                if (ok) {
+                    long long q = g.b_index[(long)b * g.b_index_zstride + cc] % g.b_index_mod;
+                    if (q < 0) q += g.b_index_mod;
+                    v = ((int)q == rr) ? 1.0f : 0.0f;
+                }
+            } else {
+                const long addr = (long)seg * g.b_seg_stride + (long)rr * g.ldb + cc;
+                v = ok ? Bz[addr] : 0.0f;
+                if (g.b_relu) v = fmaxf(v, 0.0f);
+            }
+            rb[e] = v;
+        }
+    };
+
+    const int nk = (kend > kbeg) ? (kend - kbeg + WN_BK - 1) / WN_BK : 0;
+    if (nk > 0) fetch(kbeg);
+    for (int kt = 0; kt < nk; ++kt) {
+        WN_UNROLL
+        for (int e = 0; e < GA::NE; ++e) {
+            int kk, mn;
+            GA::coord(e, tid, kk, mn);
+            As[GA::soff(kk, mn)] = ra[e];
+        }
+        WN_UNROLL
+        for (int e = 0; e < GB::NE; ++e) {
+            int kk, mn;
+            GB::coord(e, tid, kk, mn);
+            Bs[GB::soff(kk, mn)] = rb[e];
+        }
+        __syncthreads();
+        if (kt + 1 < nk) fetch(kbeg + (kt + 1) * WN_BK);
+
+        WN_UNROLL_N(4)
+        for (int s = 0; s < WN_BK / 2; ++s) {
+            const int kk = 2 * s + hi;
+            float a[TM], bb[TN];
+            WN_UNROLL
+            for (int i = 0; i < TM; ++i) a[i] = As[GA::soff(kk, (wm * TM + i) * 32 + li)];
+            WN_UNROLL
+            for (int j = 0; j < TN; ++j) bb[j] = Bs[GB::soff(kk, (wn * TN + j) * 32 + li)];
+            WN_UNROLL
+            for (int i = 0; i < TM; ++i) {
+                WN_UNROLL
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(a[i], bb[j], acc[i][j]);
+            }
+        }
+        if (KMAJ && g.a_rowsum != nullptr && tid < BM) {
+            float s = 0.0f;
+            for (int kk = 0; kk < WN_BK; ++kk) s += As[GA::soff(kk, tid)];
+            rowsum += s;
+        }
+        __syncthreads();
+    }
+
+    if (KMAJ && g.a_rowsum != nullptr && blockIdx.x == 0 && tid < BM && (m0 + tid) < g.M)
+        g.a_rowsum[(long)z * g.M + m0 + tid] = rowsum;
+
+    // epilogue: lane (col = li, hi) holds rows mfma32_row(r, hi) of each 32x32 tile
+    float* __restrict__ Cz = g.C + (long)z * g.c_zstride;
+    const float* __restrict__ Dz = g.D ? g.D + (long)b * g.d_zstride : nullptr;
+    const float* __restrict__ Ez = g.E ? g.E + (long)b * g.e_zstride : nullptr;
+    WN_UNROLL
+    for (int i = 0; i < TM; ++i) {
+        WN_UNROLL
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + li;
+            WN_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + mfma32_row(r, hi);
+                if (m < g.M && n < g.N) {
+                    float v = acc[i][j][r];
+                    if (g.bias) v += g.bias[m];
+                    if (Dz) v += Dz[(long)m * g.ldd + n];
+                    if (g.relu) v = fmaxf(v, 0.0f);
+                    if (Ez) v = (Ez[(long)m * g.lde + n] > 0.0f) ? v : 0.0f;
+                    float* p = Cz + (long)m * g.ldc + n;
+                    if (g.accumulate) v += *p;
+                    *p = v;
+                }
+            }
+        }
+    }
+}
+
+template <int TM, int TN, int KMAJ>
+static void launch_variant(const WnGemmArgs& g, wn_stream_t stream) {
+    dim3 grid((unsigned)((g.N + 64 * TN - 1) / (64 * TN)), (unsigned)((g.M + 64 * TM - 1) / (64 * TM)),
+              (unsigned)(g.nbatch * g.ksplit));
+    dim3 block(WN_GEMM_THREADS);
+    WN_LAUNCH((wn_gemm_kernel<TM, TN, KMAJ>), grid, block, 0, stream, g);
+}
+
+int wn_gemm_launch(const WnGemmArgs* gp, wn_stream_t stream) {
+    const WnGemmArgs& g = *gp;
+    if (g.M <= 0 || g.N <= 0 || g.K < 0 || g.nbatch <= 0 || g.ksplit <= 0) return 1;
+    if (g.a_kmajor != g.b_kmajor) return 2;
+    if (g.b_seg_len <= 0 || g.kchunk <= 0) return 3;
+    const int tm = g.M > 64 ? 2 : 1, tn = g.N > 64 ? 2 : 1;
+    const int key = (g.a_kmajor ? 4 : 0) | (tm == 2 ? 2 : 0) | (tn == 2 ? 1 : 0);
+    switch (key) {
+        case 0: launch_variant<1, 1, 0>(g, stream); break;
+        case 1: launch_variant<1, 2, 0>(g, stream); break;
+        case 2: launch_variant<2, 1, 0>(g, stream); break;
+        case 3: launch_variant<2, 2, 0>(g, stream); break;
+        case 4: launch_variant<1, 1, 1>(g, stream); break;
+        case 5: launch_variant<1, 2, 1>(g, stream); break;
+        case 6: launch_variant<2, 1, 1>(g, stream); break;
+        default: launch_variant<2, 2, 1>(g, stream); break;
+    }
+    return 0;
+}

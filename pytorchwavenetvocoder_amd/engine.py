@@ -1,0 +1,246 @@
+# -*- coding: utf-8 -*-
+"""Device-side state of one WaveNet replica: flat parameter / gradient / Adam buffers and the
+workspace the HIP library needs, plus thin wrappers around the C-ABI calls.
+
+PyTorch is used here only for device memory, streams and (in ``DataParallelReducer``)
+``torch.distributed``; every FLOP of the path runs in libwavenet_hip.so.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream_handle(device):
+    if device.type == "cuda":
+        return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return None
+
+
+class WaveNetEngine(object):
+    """Owns the flat buffers of one model replica.
+
+    Args mirror ``WaveNet.__init__`` (reference wavenet.py:172-173).
+    """
+
+    def __init__(self, n_quantize=256, n_aux=28, n_resch=512, n_skipch=256, dilation_depth=10,
+                 dilation_repeat=3, kernel_size=2, upsampling_factor=0, device="cpu", library=None):
+        self.lib = library if library is not None else _lib.load_library()
+        self.cfg = _lib.WnConfig(n_quantize, n_aux, n_resch, n_skipch, dilation_depth, dilation_repeat,
+                                 kernel_size, upsampling_factor)
+        self.device = torch.device(device)
+        n = self.lib.wn_param_count(ctypes.byref(self.cfg))
+        if n <= 0:
+            raise _lib.WnError("invalid WaveNet configuration: %s" % self.lib.wn_last_error().decode())
+        self.n_params = int(n)
+        self.n_layers = self.lib.wn_num_layers(ctypes.byref(self.cfg))
+        self.receptive_field = self.lib.wn_receptive_field(ctypes.byref(self.cfg))
+        self.flat_params = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+        self.flat_grads = None
+        self._ws = None
+        self._ws_key = None
+        self._last_shape = None
+        lo, hi = ctypes.c_int64(), ctypes.c_int64()
+        self.lib.check(self.lib.wn_dead_param_range(ctypes.byref(self.cfg), ctypes.byref(lo), ctypes.byref(hi)),
+                       "wn_dead_param_range")
+        self.dead_range = (lo.value, hi.value)
+        self.flags = 0
+
+    # ---- layout ---------------------------------------------------------------------------
+    def param_slice(self, kind, layer=0):
+        off, n = ctypes.c_int64(), ctypes.c_int64()
+        self.lib.check(self.lib.wn_param_offset(ctypes.byref(self.cfg), kind, layer, ctypes.byref(off), ctypes.byref(n)),
+                       "wn_param_offset")
+        return off.value, n.value
+
+    def bucket_ranges(self, layers_per_bucket):
+        nb = self.lib.wn_num_buckets(ctypes.byref(self.cfg), layers_per_bucket)
+        out = []
+        lo, hi = ctypes.c_int64(), ctypes.c_int64()
+        for i in range(nb):
+            self.lib.check(self.lib.wn_bucket_range(ctypes.byref(self.cfg), layers_per_bucket, i, ctypes.byref(lo),
+                                                    ctypes.byref(hi)), "wn_bucket_range")
+            out.append((lo.value, hi.value))
+        return out
+
+    # ---- device management ----------------------------------------------------------------
+    def to(self, device):
+        device = torch.device(device)
+        if device != self.device:
+            self.flat_params = self.flat_params.to(device)
+            self.flat_grads = None if self.flat_grads is None else self.flat_grads.to(device)
+            self._ws = None
+            self._ws_key = None
+            self.device = device
+        return self
+
+    def _check_device(self, *tensors):
+        if self.lib.is_emulator:
+            for t in tensors:
+                if t is not None and t.device.type != "cpu":
+                    raise _lib.WnError("emulator binding takes CPU tensors")
+            return
+        if self.device.type != "cuda":
+            raise _lib.WnError("the WaveNet HIP path runs on an MI355X: move the model to a GPU "
+                               "(model.cuda()); there is no CPU fallback")
+        for t in tensors:
+            if t is not None and t.device != self.device:
+                raise _lib.WnError("tensor on %s but the model lives on %s" % (t.device, self.device))
+
+    def workspace(self, B, T):
+        key = (B, T)
+        if self._ws_key != key:
+            nbytes = self.lib.wn_workspace_bytes(ctypes.byref(self.cfg), B, T)
+            if nbytes == 0:
+                raise _lib.WnError("wn_workspace_bytes: %s" % self.lib.wn_last_error().decode())
+            self._ws = None  # free first
+            self._ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.device)
+            self._ws_key = key
+        return self._ws
+
+    def grads(self):
+        if self.flat_grads is None:
+            self.flat_grads = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+        return self.flat_grads
+
+    # ---- C-ABI calls ------------------------------------------------------------------------
+    def forward(self, x, h):
+        """x (B,T) int64, h (B,A,T/U | T) fp32 -> logits (B,Q,T) fp32 (physical layout)."""
+        self._check_device(x, h)
+        if x.dtype != torch.int64 or x.dim() != 2:
+            raise ValueError("x must be a LongTensor of shape (B, T)")
+        B, T = x.shape
+        U = self.cfg.upsampling_factor
+        want = (B, self.cfg.n_aux, T // U if U > 0 else T)
+        if U > 0 and T % U != 0:
+            raise ValueError("T=%d is not a multiple of upsampling_factor=%d" % (T, U))
+        if tuple(h.shape) != want:
+            raise ValueError("h must have shape %s, got %s" % (want, tuple(h.shape)))
+        x = x.contiguous()
+        h = h.contiguous().float()
+        ws = self.workspace(B, T)
+        logits = torch.empty((B, self.cfg.n_quantize, T), dtype=torch.float32, device=self.device)
+        rc = self.lib.wn_forward(ctypes.byref(self.cfg), B, T, _ptr(self.flat_params), _ptr(x), _ptr(h), _ptr(logits),
+                                 _ptr(ws), ws.numel() * 4, self.flags, _stream_handle(self.device))
+        self.lib.check(rc, "wn_forward")
+        self._last_shape = (B, T)
+        self._last_inputs = (x, h)
+        return logits
+
+    def loss(self, logits, target, t_start=None, grad_scale=1.0, loss_scale=1.0, want_grad=True):
+        """Softmax-CE over positions >= t_start (default: receptive field).  Returns (loss, dlogits)."""
+        self._check_device(logits, target)
+        B, Q, T = logits.shape
+        if t_start is None:
+            t_start = self.receptive_field
+        target = target.contiguous()
+        ws = self.workspace(B, T)
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        dlogits = torch.empty_like(logits) if want_grad else None
+        rc = self.lib.wn_softmax_ce_loss(ctypes.byref(self.cfg), B, T, _ptr(logits), _ptr(target), int(t_start),
+                                         float(grad_scale), float(loss_scale), _ptr(loss), _ptr(dlogits), _ptr(ws),
+                                         ws.numel() * 4, _stream_handle(self.device))
+        self.lib.check(rc, "wn_softmax_ce_loss")
+        return loss, dlogits
+
+    def backward(self, dlogits, events=None, layers_per_bucket=0):
+        """Backward of the last ``forward`` call; fills ``self.grads()`` completely."""
+        if self._last_shape is None:
+            raise _lib.WnError("backward() without a preceding forward()")
+        B, T = self._last_shape
+        x, h = self._last_inputs
+        self._check_device(dlogits)
+        if tuple(dlogits.shape) != (B, self.cfg.n_quantize, T) or not dlogits.is_contiguous():
+            raise ValueError("dlogits must be a contiguous (B,Q,T) tensor")
+        g = self.grads()
+        ws = self.workspace(B, T)
+        if events:
+            arr = (ctypes.c_void_p * len(events))(*[ctypes.c_void_p(e) for e in events])
+            n_ev = len(events)
+        else:
+            arr, n_ev = None, 0
+        rc = self.lib.wn_backward(ctypes.byref(self.cfg), B, T, _ptr(self.flat_params), _ptr(x), _ptr(h), _ptr(dlogits),
+                                  _ptr(g), _ptr(ws), ws.numel() * 4, arr, n_ev, int(layers_per_bucket), self.flags,
+                                  _stream_handle(self.device))
+        self.lib.check(rc, "wn_backward")
+        return g
+
+    def adam_step(self, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self._check_device(exp_avg, exp_avg_sq)
+        rc = self.lib.wn_adam_step(_ptr(self.flat_params), _ptr(self.grads()), _ptr(exp_avg), _ptr(exp_avg_sq),
+                                   self.n_params, int(step), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                   float(weight_decay), self.dead_range[0], self.dead_range[1],
+                                   _stream_handle(self.device))
+        self.lib.check(rc, "wn_adam_step")
+
+
+# ---- reference state_dict keys <-> flat buffer ------------------------------------------------
+_LIST_KINDS = {
+    "dil_sigmoid": (_lib.P_DSIG_W, _lib.P_DSIG_B, True),
+    "dil_tanh": (_lib.P_DTANH_W, _lib.P_DTANH_B, True),
+    "aux_1x1_sigmoid": (_lib.P_ASIG_W, _lib.P_ASIG_B, False),
+    "aux_1x1_tanh": (_lib.P_ATANH_W, _lib.P_ATANH_B, False),
+    "skip_1x1": (_lib.P_SKIP_W, _lib.P_SKIP_B, False),
+    "res_1x1": (_lib.P_RES_W, _lib.P_RES_B, False),
+}
+_SINGLE_KINDS = {
+    "causal.conv.weight": _lib.P_CAUSAL_W, "causal.conv.bias": _lib.P_CAUSAL_B,
+    "upsampling.conv.weight": _lib.P_UP_W, "upsampling.conv.bias": _lib.P_UP_B,
+    "conv_post_1.weight": _lib.P_POST1_W, "conv_post_1.bias": _lib.P_POST1_B,
+    "conv_post_2.weight": _lib.P_POST2_W, "conv_post_2.bias": _lib.P_POST2_B,
+}
+
+
+def key_to_kind(key):
+    """Reference state_dict key (wavenet.py:187-210) -> (tensor kind, layer)."""
+    if key in _SINGLE_KINDS:
+        return _SINGLE_KINDS[key], 0
+    parts = key.split(".")
+    name, layer = parts[0], int(parts[1])
+    wk, bk, has_conv = _LIST_KINDS[name]
+    expect = 4 if has_conv else 3
+    if len(parts) != expect or (has_conv and parts[2] != "conv"):
+        raise KeyError(key)
+    return (wk if parts[-1] == "weight" else bk), layer
+
+
+def state_keys(cfg):
+    """All state_dict keys in the reference's registration order."""
+    L = cfg.dilation_depth * cfg.dilation_repeat
+    keys = ["causal.conv.weight", "causal.conv.bias"]
+    if cfg.upsampling_factor > 0:
+        keys += ["upsampling.conv.weight", "upsampling.conv.bias"]
+    for name in ("dil_sigmoid", "dil_tanh"):
+        for l in range(L):
+            keys += ["%s.%d.conv.weight" % (name, l), "%s.%d.conv.bias" % (name, l)]
+    for name in ("aux_1x1_sigmoid", "aux_1x1_tanh", "skip_1x1", "res_1x1"):
+        for l in range(L):
+            keys += ["%s.%d.weight" % (name, l), "%s.%d.bias" % (name, l)]
+    keys += ["conv_post_1.weight", "conv_post_1.bias", "conv_post_2.weight", "conv_post_2.bias"]
+    return keys
+
+
+def load_state_into_flat(engine, state):
+    """Copy a reference-layout state dict {key: tensor} into the engine's flat parameter buffer."""
+    for k in state_keys(engine.cfg):
+        kind, layer = key_to_kind(k)
+        off, n = engine.param_slice(kind, layer)
+        v = state[k]
+        if v.numel() != n:
+            raise ValueError("%s: expected %d elements, got %s" % (k, n, tuple(v.shape)))
+        engine.flat_params[off:off + n].copy_(v.reshape(-1).to(engine.flat_params.dtype))
+
+
+def flat_to_state(engine, flat, shapes):
+    """Views of a flat buffer keyed like the reference state dict (shapes: {key: shape})."""
+    out = {}
+    for k in state_keys(engine.cfg):
+        kind, layer = key_to_kind(k)
+        off, n = engine.param_slice(kind, layer)
+        out[k] = flat[off:off + n].view(shapes[k])
+    return out
