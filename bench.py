@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+# -*- coding: utf-8 -*-
+"""Benchmark of the WaveNet-vocoder TRAINING STEP on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = forward + softmax-CE on [:, rf:] + backward + gradient all-reduce (N>1) + Adam, on
+one synthetic minibatch already resident in HBM (reference train.py:527-540).  Workload =
+BASELINE.json configs[1]: 30-layer WaveNet, 64 residual / 256 skip channels, 80-dim mel aux,
+mu-law softmax, batch 8 x batch_len 20000 per GPU (-> T = 23040 model inputs, 19970 loss
+positions per sequence).  Weak scaling: the per-GPU batch is fixed.
+
+Prints ONE JSON line (rank 0).  Extra blocks:
+  roofline      dominant kernel: algorithmic FLOPs per launch / HIP-event duration vs the f32
+                matrix-core peak (the path is fp32 compute-bound), plus the
+                step-level HBM-roof and fp32-FLOP-roof fractions north_star asks for.
+  cpu_baseline  the CPU oracle (oracle/wavenet_oracle.py = the reference's torch CPU ops) timed on
+                this host's cores on a bounded sample (B=1 window of the same model).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG2 = dict(n_quantize=256, n_aux=80, n_resch=64, n_skipch=256, dilation_depth=10, dilation_repeat=3,
+            kernel_size=2, upsampling_factor=80)
+BATCH_PER_GPU = 8
+BATCH_LENGTH = 20000
+# algorithmic HBM bytes and FLOPs of one training timestep of this model
+ALG_BYTES_PER_TIMESTEP = 78356.0
+ALG_FLOP_PER_TIMESTEP = 9.27e6
+HBM_PEAK = 8.0e12          # B/s  (MI355X_MICROARCH.md)
+F32_MFMA_PEAK = 157.3e12   # FLOP/s dense f32 matrix = f32 vector peak
+
+
+def geometry(rf, batch_length, U):
+    """reference train.py:106-110,202-232"""
+    bl = batch_length - (rf + batch_length) % U
+    frames = (rf + bl) // U
+    return bl, frames, frames * U
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The oracle (a restatement of the reference's own torch CPU path) on this host's cores."""
+    from oracle import wavenet_oracle as O
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    cfg = O.OracleConfig(*[CFG2[k] for k in ("n_quantize", "n_aux", "n_resch", "n_skipch", "dilation_depth",
+                                              "dilation_repeat", "kernel_size", "upsampling_factor")])
+    bl, frames, T = geometry(cfg.receptive_field, BATCH_LENGTH, cfg.upsampling_factor)
+    g = torch.Generator().manual_seed(1)
+    params = O.init_params(cfg, generator=g)
+    x, h, t = O.synthetic_batch(cfg, 1, T, 1)
+    opt = O.OracleAdam(lr=1e-4)
+    O.train_step(cfg, params, opt, x, h, t)  # warm-up
+    times = []
+    t_begin = time.time()
+    while len(times) < 3 or (time.time() - t_begin < seconds_budget and len(times) < 10):
+        t0 = time.time()
+        O.train_step(cfg, params, opt, x, h, t)
+        times.append(time.time() - t0)
+    best = min(times)
+    return {"value": (T - cfg.receptive_field) / best, "unit": "audio-samples/sec", "cores": ncores,
+            "kind": "port", "threads": torch.get_num_threads(),
+            "sample": "CPU oracle (reference torch-CPU ops), same 30-layer model, B=1 x T=%d window, "
+                      "1 warm-up + %d timed steps, best step %.3f s, median %.3f s" % (
+                          T, len(times), best, sorted(times)[len(times) // 2])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="sequences per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused", action="store_true", help="force the layered (any-size) kernels")
+    ap.add_argument("--profile-steps", type=int, default=2, help="extra untimed steps with per-launch HIP events")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from pytorchwavenetvocoder_amd import _lib
+    from pytorchwavenetvocoder_amd.distributed import GradientReducer
+    from pytorchwavenetvocoder_amd.nets import WaveNet, initialize
+    from pytorchwavenetvocoder_amd.optim import FusedAdam
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    torch.manual_seed(1)  # reference default seed (train.py:386)
+    model = WaveNet(**CFG2)
+    model.apply(initialize)
+    model.to(device)
+    if args.no_fused:
+        model.engine.flags |= _lib.FLAG_NO_FUSED
+    rf = model.receptive_field
+    bl, frames, T = geometry(rf, BATCH_LENGTH, CFG2["upsampling_factor"])
+    B = args.batch
+    gen = torch.Generator().manual_seed(1234 + rank)
+    xx = torch.randint(0, CFG2["n_quantize"], (B, T + 1), generator=gen)
+    x = xx[:, :-1].contiguous().to(device)
+    t = xx[:, 1:].contiguous().to(device)
+    h = torch.randn(B, CFG2["n_aux"], frames, generator=gen).to(device)
+    if world > 1:  # identical initial weights on every rank (no per-step broadcast afterwards)
+        dist.broadcast(model.engine.flat_params, src=0)
+
+    opt = FusedAdam(model, lr=1e-4)
+    red = GradientReducer(model, layers_per_bucket=10)
+
+    def step():
+        loss = red.loss_and_backward(x, h, t)
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        loss = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+    final_loss = float(loss.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    samples_per_s = world * B * (T - rf) * args.steps / elapsed
+    timesteps_per_s_gpu = B * T * args.steps / elapsed
+
+    # ---- per-kernel timing with HIP events (untimed extra steps, rank 0) ----
+    roofline = None
+    kernels = None
+    if rank == 0 and args.profile_steps > 0:
+        lib = model.engine.lib
+        torch.cuda.synchronize(device)
+        lib.wn_prof_enable(1)
+        for _ in range(args.profile_steps):
+            step()
+        torch.cuda.synchronize(device)
+        lib.wn_prof_enable(0)
+        need = lib.wn_prof_report(None, 0)
+        buf = ctypes.create_string_buffer(max(need, 16))
+        lib.wn_prof_report(buf, len(buf))
+        prof = json.loads(buf.value.decode() or "{}")
+        tot_ms = sum(v["ms"] for v in prof.values()) or 1.0
+        kernels = {k: {"launches_per_step": v["count"] / args.profile_steps,
+                       "ms_per_step": v["ms"] / args.profile_steps,
+                       "share": v["ms"] / tot_ms,
+                       "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] > 0 and v["ms"] > 0 else None}
+                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+        dom = next((k for k, v in kernels.items() if v["tflops"] is not None), None)
+        if dom is not None:
+            v = prof[dom]
+            ach = v["flops"] / (v["ms"] * 1e-3) / 1e12
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK / 1e12,
+                        "unit": "TFLOP/s", "frac": ach / (F32_MFMA_PEAK / 1e12), "traffic": None,
+                        "avg_launch_ms": v["ms"] / v["count"], "flop_per_launch": v["flops"] / v["count"],
+                        "dtype_peak": "f32-input MFMA (v_mfma_f32_32x32x2_f32), dense 157.3 TFLOP/s",
+                        "step_hbm_frac": timesteps_per_s_gpu * ALG_BYTES_PER_TIMESTEP / HBM_PEAK,
+                        "step_hbm_achieved_GBps": timesteps_per_s_gpu * ALG_BYTES_PER_TIMESTEP / 1e9,
+                        "step_f32_flop_frac": timesteps_per_s_gpu * ALG_FLOP_PER_TIMESTEP / F32_MFMA_PEAK}
+
+    if rank == 0:
+        out = {
+            "metric": "train audio-samples/sec, 30-layer WaveNet batch_len=20000",
+            "value": samples_per_s, "unit": "audio-samples/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 30-layer WaveNet, 64 residual / 256 skip ch, 80-dim mel aux, "
+                                   "mu-law softmax, K=2, U=80; batch %d x batch_len 20000 per GPU (T=%d inputs, %d loss "
+                                   "positions per sequence), random-init weights, fwd+CE+bwd+allreduce+Adam" % (
+                                       B, T, T - rf),
+                       "global_batch": world * B, "parallelism": "dp%d" % world,
+                       "kernels": "layered" if args.no_fused else "fused+gemm"},
+            "timesteps_per_sec": world * timesteps_per_s_gpu, "final_loss": final_loss,
+            "roofline": roofline, "kernels": kernels,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

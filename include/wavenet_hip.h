@@ -149,6 +149,13 @@ int wn_op_causal_conv(const float* weight, const float* bias, const float* x /*(
 struct WnGemmArgs;
 int wn_op_gemm(const struct WnGemmArgs* args, void* stream);
 
+/* ---- diagnostics: opt-in per-launch timing with HIP events (used by bench.py's roofline block) ----
+ * wn_prof_enable(1) clears and starts recording {kernel tag, algorithmic flops/bytes, start/stop
+ * event} for every launch; after synchronising, wn_prof_report writes a JSON object
+ * {"tag": {"count", "ms", "flops", "bytes"}} into buf (returns the needed size when buf == NULL). */
+int wn_prof_enable(int on);
+int wn_prof_report(char* buf, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

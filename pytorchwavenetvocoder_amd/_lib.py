@@ -42,6 +42,7 @@ class WnGemmArgs(ctypes.Structure):
         ("relu", ctypes.c_int), ("accumulate", ctypes.c_int),
         ("nbatch", ctypes.c_int), ("ksplit", ctypes.c_int), ("kchunk", ctypes.c_int),
         ("a_rowsum", ctypes.c_void_p),
+        ("tag", ctypes.c_char_p),
     ]
 
     @classmethod
@@ -66,7 +67,7 @@ ABI_VERSION = 1
 EXPORTS = [
     "wn_abi_version", "wn_last_error", "wn_receptive_field", "wn_num_layers", "wn_param_count", "wn_param_offset",
     "wn_num_buckets", "wn_bucket_range", "wn_dead_param_range", "wn_workspace_bytes", "wn_forward",
-    "wn_softmax_ce_loss", "wn_backward", "wn_adam_step", "wn_op_front", "wn_op_causal_conv", "wn_op_gemm",
+    "wn_softmax_ce_loss", "wn_backward", "wn_adam_step", "wn_op_front", "wn_op_causal_conv", "wn_op_gemm", "wn_prof_enable", "wn_prof_report",
 ]
 
 
@@ -101,6 +102,8 @@ class WnLibrary(object):
         L.wn_op_front.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, vp]
         L.wn_op_causal_conv.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
         L.wn_op_gemm.argtypes = [ctypes.POINTER(WnGemmArgs), vp]
+        L.wn_prof_enable.argtypes = [i]
+        L.wn_prof_report.argtypes = [ctypes.c_char_p, sz]
         if L.wn_abi_version() != ABI_VERSION:
             raise WnError("ABI mismatch: library %d, binding %d" % (L.wn_abi_version(), ABI_VERSION))
 

@@ -456,7 +456,7 @@ extern "C" int wn_forward(const WnConfig* cfg, int B, int T, const float* params
         g.A = ws + w.waux_f; g.lda = (long)d.L * 2 * d.R;
         g.B = h; g.ldb = F; g.b_zstride = (long)d.A * F; g.b_clen = F;
         g.C = ws + w.G; g.ldc = F; g.c_zstride = (long)d.L * 2 * d.R * F;
-        g.nbatch = B;
+        g.nbatch = B; g.tag = "fwd_aux_frames";
         WN_TRY(wn_gemm_launch(&g, c.st));
     }
     const float* upw = d.U > 0 ? params + y.up_w : ws + w.one;
@@ -482,7 +482,7 @@ extern "C" int wn_forward(const WnConfig* cfg, int B, int T, const float* params
             g.B = Xl; g.ldb = T; g.b_zstride = (long)d.R * T; g.b_clen = T;
             g.b_seg_len = d.R; g.b_seg_stride = 0; g.b_shift0 = (d.K - 1) * dil; g.b_shift_step = -dil;
             g.C = ws + w.P; g.ldc = T; g.c_zstride = (long)2 * d.R * T;
-            g.nbatch = B;
+            g.nbatch = B; g.tag = "fwd_dilated_layered";
             WN_TRY(wn_gemm_launch(&g, c.st));
             // z = sigmoid(.)*tanh(.)                           (wavenet.py:529-532)
             WN_TRY(wn_gate_fwd(ws + w.P, Gl, g_bstride, upw, ws + w.cvec + (long)l * 2 * d.R, Sl, Gtl, Zl, B, T, d.R, Ue, F,
@@ -496,7 +496,7 @@ extern "C" int wn_forward(const WnConfig* cfg, int B, int T, const float* params
                 r.C = Xn; r.ldc = T; r.c_zstride = (long)d.R * T;
                 r.bias = params + lb + y.o_res_b;
                 r.D = Xl; r.ldd = T; r.d_zstride = (long)d.R * T;
-                r.nbatch = B;
+                r.nbatch = B; r.tag = "fwd_res_layered";
                 WN_TRY(wn_gemm_launch(&r, c.st));
             }
         }
@@ -509,7 +509,7 @@ extern "C" int wn_forward(const WnConfig* cfg, int B, int T, const float* params
         g.B = ws + w.Z; g.ldb = T; g.b_zstride = (long)d.R * T; g.b_clen = T;
         g.b_seg_len = d.R; g.b_seg_stride = BRT;
         g.C = ws + w.O1; g.ldc = T; g.c_zstride = (long)d.S * T;
-        g.bias = ws + w.bskip; g.relu = 1; g.nbatch = B;
+        g.bias = ws + w.bskip; g.relu = 1; g.nbatch = B; g.tag = "fwd_skip_sum";
         WN_TRY(wn_gemm_launch(&g, c.st));
     }
     {   // conv_post_1 + relu  (wavenet.py:520-521)
@@ -518,7 +518,7 @@ extern "C" int wn_forward(const WnConfig* cfg, int B, int T, const float* params
         g.A = ws + w.w1_f; g.lda = d.S;
         g.B = ws + w.O1; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = T;
         g.C = ws + w.O2; g.ldc = T; g.c_zstride = (long)d.S * T;
-        g.bias = params + y.post1_b; g.relu = 1; g.nbatch = B;
+        g.bias = params + y.post1_b; g.relu = 1; g.nbatch = B; g.tag = "fwd_post1";
         WN_TRY(wn_gemm_launch(&g, c.st));
     }
     {   // conv_post_2  (wavenet.py:522)
@@ -527,7 +527,7 @@ extern "C" int wn_forward(const WnConfig* cfg, int B, int T, const float* params
         g.A = ws + w.w2_f; g.lda = d.Q;
         g.B = ws + w.O2; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = T;
         g.C = logits; g.ldc = T; g.c_zstride = (long)d.Q * T;
-        g.bias = params + y.post2_b; g.nbatch = B;
+        g.bias = params + y.post2_b; g.nbatch = B; g.tag = "fwd_post2";
         WN_TRY(wn_gemm_launch(&g, c.st));
     }
     return rt_check("wn_forward");
@@ -622,7 +622,7 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
         g.B = dlogits; g.ldb = T; g.b_zstride = (long)d.Q * T; g.b_clen = T;
         g.C = ws + w.dO2; g.ldc = T; g.c_zstride = (long)d.S * T;
         g.E = ws + w.O2; g.lde = T; g.e_zstride = (long)d.S * T;
-        g.nbatch = B;
+        g.nbatch = B; g.tag = "bwd_post2_dx";
         WN_TRY(wn_gemm_launch(&g, c.st));
     }
     {   // dSkip = W1^T dO2, masked by relu'(skip-sum)
@@ -632,21 +632,21 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
         g.B = ws + w.dO2; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = T;
         g.C = ws + w.dSk; g.ldc = T; g.c_zstride = (long)d.S * T;
         g.E = ws + w.O1; g.lde = T; g.e_zstride = (long)d.S * T;
-        g.nbatch = B;
+        g.nbatch = B; g.tag = "bwd_post1_dx";
         WN_TRY(wn_gemm_launch(&g, c.st));
     }
     {   // d conv_post_2.{weight,bias}
         WnGemmArgs g = wn_gemm_default();
         g.M = d.Q; g.N = d.S; g.K = T;
         g.A = dlogits; g.lda = T; g.a_zstride = (long)d.Q * T;
-        g.B = ws + w.O2; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = T;
+        g.B = ws + w.O2; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = T; g.tag = "dw_post2";
         WN_TRY(dw_gemm(c, g, dw_out_plain(grads + y.post2_w, d.S, grads + y.post2_b)));
     }
     {   // d conv_post_1.{weight,bias}
         WnGemmArgs g = wn_gemm_default();
         g.M = d.S; g.N = d.S; g.K = T;
         g.A = ws + w.dO2; g.lda = T; g.a_zstride = (long)d.S * T;
-        g.B = ws + w.O1; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = T;
+        g.B = ws + w.O1; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = T; g.tag = "dw_post1";
         WN_TRY(dw_gemm(c, g, dw_out_plain(grads + y.post1_w, d.S, grads + y.post1_b)));
     }
     {   // d skip_1x1.l.weight for all layers in one contraction; bias = rowsum(dSkip) for every layer
@@ -654,7 +654,7 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
         g.M = d.S; g.N = d.L * d.R; g.K = T;
         g.A = ws + w.dSk; g.lda = T; g.a_zstride = (long)d.S * T;
         g.B = ws + w.Z; g.ldb = T; g.b_zstride = (long)d.R * T; g.b_clen = T;
-        g.b_seg_len = d.R; g.b_seg_stride = BRT;
+        g.b_seg_len = d.R; g.b_seg_stride = BRT; g.tag = "dw_skip";
         DwOut o;
         o.out = grads + y.skip0; o.m_seg = 0x7fffffff; o.m_seg_stride = 0; o.m_stride = d.R;
         o.n_seg = d.R; o.n_seg_stride = y.ls_skip; o.n_stride = 1;
@@ -691,7 +691,7 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
             WnGemmArgs g = wn_gemm_default();
             g.M = d.R; g.N = d.R; g.K = T;
             g.A = dXn; g.lda = T; g.a_zstride = (long)d.R * T;
-            g.B = Zl; g.ldb = T; g.b_zstride = (long)d.R * T; g.b_clen = T;
+            g.B = Zl; g.ldb = T; g.b_zstride = (long)d.R * T; g.b_clen = T; g.tag = "dw_res";
             WN_TRY(dw_gemm(c, g, dw_out_plain(grads + lb + y.o_res_w, d.R, grads + lb + y.o_res_b)));
         } else {
             WN_TRY(wn_fill(grads + lb + y.o_res_w, 0.0f, (long)d.R * d.R + d.R, c.st));
@@ -707,7 +707,7 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
                 g.A = params + y.skip0 + (long)l * y.ls_skip; g.lda = d.R;
                 g.B = ws + w.dSk; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = T;
                 g.C = ws + w.dZ; g.ldc = T; g.c_zstride = (long)d.R * T;
-                g.nbatch = B;
+                g.nbatch = B; g.tag = "bwd_dz_skip_layered";
                 WN_TRY(wn_gemm_launch(&g, c.st));
             }
             if (dXn) {  // dZ += Wres_l^T dX_{l+1}
@@ -716,7 +716,7 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
                 g.A = params + lb + y.o_res_w; g.lda = d.R;
                 g.B = dXn; g.ldb = T; g.b_zstride = (long)d.R * T; g.b_clen = T;
                 g.C = ws + w.dZ; g.ldc = T; g.c_zstride = (long)d.R * T;
-                g.accumulate = 1; g.nbatch = B;
+                g.accumulate = 1; g.nbatch = B; g.tag = "bwd_dz_res_layered";
                 WN_TRY(wn_gemm_launch(&g, c.st));
             }
             WN_TRY(wn_gate_bwd(ws + w.dZ, Sl, Gtl, dP, B, T, d.R, c.st));
@@ -727,6 +727,7 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
             g.A = dP; g.lda = T; g.a_zstride = (long)2 * d.R * T;
             g.B = Xl; g.ldb = T; g.b_zstride = (long)d.R * T; g.b_clen = T;
             g.b_seg_len = d.R; g.b_seg_stride = 0; g.b_shift0 = (d.K - 1) * dil; g.b_shift_step = -dil;
+            g.tag = "dw_dilated";
             DwOut o;
             o.out = grads + lb + y.o_dsig_w;
             o.m_seg = d.R; o.m_seg_stride = y.o_dtanh_w - y.o_dsig_w; o.m_stride = (long)d.R * d.K;
@@ -748,6 +749,7 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
             o.n_seg = 0x7fffffff; o.n_seg_stride = 0; o.n_stride = 1;
             o.rowsum_out = nullptr;
             WnGemmArgs g = wn_gemm_default();
+            g.tag = "dw_aux";
             g.M = 2 * d.R; g.N = d.A;
             if (d.U > 0) {
                 // through the upsampling layer: dG[f] = sum_j w[j] dP[fU+j]; dW = dG.h^T + b_up*dc (x) 1
@@ -773,7 +775,7 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
             g.b_seg_len = 2 * d.R; g.b_seg_stride = 0; g.b_shift0 = -(d.K - 1) * dil; g.b_shift_step = dil;
             g.C = dXcur; g.ldc = T; g.c_zstride = (long)d.R * T;
             if (dXn) { g.D = dXn; g.ldd = T; g.d_zstride = (long)d.R * T; }
-            g.nbatch = B;
+            g.nbatch = B; g.tag = "bwd_dx_dilated";
             WN_TRY(wn_gemm_launch(&g, c.st));
         }
         dXn = dXcur;
@@ -791,7 +793,7 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
         g.A = dXn; g.lda = T; g.a_zstride = (long)d.R * T;
         g.B = ws + w.X; /* unused (b_index set) */ g.ldb = 0; g.b_zstride = 0; g.b_clen = T;
         g.b_seg_len = d.Q; g.b_shift0 = d.K - 1; g.b_shift_step = -1;
-        g.b_index = x; g.b_index_zstride = T; g.b_index_mod = d.Q;
+        g.b_index = x; g.b_index_zstride = T; g.b_index_mod = d.Q; g.tag = "dw_front_onehot";
         DwOut o;
         o.out = grads + y.causal_w; o.m_seg = 0x7fffffff; o.m_seg_stride = 0; o.m_stride = (long)d.Q * d.K;
         o.n_seg = d.Q; o.n_seg_stride = 1; o.n_stride = d.K;

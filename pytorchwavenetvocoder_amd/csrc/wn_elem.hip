@@ -3,6 +3,7 @@
 // consecutive samples (coalesced 256 B per wave-instruction) and all reductions are two-stage
 // and order-deterministic (no float atomics).
 #include "wn_elem.h"
+#include "wn_prof.h"
 
 #define WN_TPB 256
 
@@ -46,6 +47,7 @@ __global__ __launch_bounds__(WN_TPB) void k_front_gather(const int64_t* __restri
 
 int wn_front_gather(const int64_t* x, const float* wc_f, const float* bias, float* x0, int B, int T, int Q, int R, int K,
                     wn_stream_t st) {
+    WN_PROF("front_gather", 0.0, 0.0, st);
     if (K > 8 || K < 1) return 1;
     dim3 grid((T + WN_TPB - 1) / WN_TPB, B);
     WN_LAUNCH(k_front_gather, grid, dim3(WN_TPB), 0, st, x, wc_f, bias, x0, T, Q, R, K);
@@ -74,6 +76,7 @@ __global__ __launch_bounds__(WN_TPB) void k_gate_fwd(const float* __restrict__ P
 
 int wn_gate_fwd(const float* P, const float* G, long g_bstride, const float* upw, const float* cvec, float* S, float* Gt,
                 float* Z, int B, int T, int R, int U, int F, wn_stream_t st) {
+    WN_PROF("gate_fwd", 0.0, 0.0, st);
     if (U < 1) return 1;
     dim3 grid((T + WN_TPB - 1) / WN_TPB, R, B);
     WN_LAUNCH(k_gate_fwd, grid, dim3(WN_TPB), 0, st, P, G, g_bstride, upw, cvec, S, Gt, Z, T, R, U, F);
@@ -92,6 +95,7 @@ __global__ __launch_bounds__(WN_TPB) void k_gate_bwd(const float* __restrict__ d
 }
 
 int wn_gate_bwd(const float* dZ, const float* S, const float* Gt, float* dP, int B, int T, int R, wn_stream_t st) {
+    WN_PROF("gate_bwd", 0.0, 0.0, st);
     dim3 grid((T + WN_TPB - 1) / WN_TPB, R, B);
     WN_LAUNCH(k_gate_bwd, grid, dim3(WN_TPB), 0, st, dZ, S, Gt, dP, T, R);
     return 0;
@@ -142,6 +146,7 @@ int wn_softmax_ce_nblocks(int B, int T) { return ((T + WN_TPB - 1) / WN_TPB) * B
 
 int wn_softmax_ce(const float* logits, const int64_t* target, float* dlogits, float* loss_partial, int* n_partial, int B,
                   int T, int Q, int t_start, float grad_scale, wn_stream_t st) {
+    WN_PROF("softmax_ce", 0.0, 0.0, st);
     dim3 grid((T + WN_TPB - 1) / WN_TPB, B);
     if (n_partial) *n_partial = (int)(grid.x * grid.y);
     WN_LAUNCH(k_softmax_ce, grid, dim3(WN_TPB), 0, st, logits, target, dlogits, loss_partial, T, Q, t_start, grad_scale);
@@ -158,6 +163,7 @@ __global__ __launch_bounds__(WN_TPB) void k_sum_partials(const float* __restrict
 }
 
 int wn_sum_partials(const float* partial, int n, float scale, float* out, wn_stream_t st) {
+    WN_PROF("sum_partials", 0.0, 0.0, st);
     WN_LAUNCH(k_sum_partials, dim3(1), dim3(WN_TPB), 0, st, partial, n, scale, out);
     return 0;
 }
@@ -183,6 +189,7 @@ __global__ __launch_bounds__(WN_TPB) void k_adam(float* __restrict__ p, const fl
 
 int wn_adam(float* p, const float* g, float* m, float* v, long n, float lr_over_bc1, float sqrt_bc2, float beta1, float beta2,
             float eps, float weight_decay, long skip_lo, long skip_hi, wn_stream_t st) {
+    WN_PROF("adam", 0.0, 0.0, st);
     long nb = (n + WN_TPB - 1) / WN_TPB;
     if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
@@ -206,6 +213,7 @@ __global__ __launch_bounds__(WN_TPB) void k_copy4(float* __restrict__ dst, const
 }
 
 int wn_copy4(float* dst, const float* src, const WnCopy4* c, wn_stream_t st) {
+    WN_PROF("copy4", 0.0, 0.0, st);
     const long total = (long)c->nl * c->n0 * c->n1 * c->n2;
     if (total <= 0) return 0;
     WN_LAUNCH(k_copy4, dim3((unsigned)((total + WN_TPB - 1) / WN_TPB)), dim3(WN_TPB), 0, st, dst, src, *c);
@@ -229,6 +237,7 @@ __global__ __launch_bounds__(WN_TPB) void k_cvec(WnCvecArgs a) {
 }
 
 int wn_cvec(const WnCvecArgs* a, wn_stream_t st) {
+    WN_PROF("cvec", 0.0, 0.0, st);
     WN_LAUNCH(k_cvec, dim3((unsigned)a->L), dim3(WN_TPB), 0, st, *a);
     return 0;
 }
@@ -243,6 +252,7 @@ __global__ __launch_bounds__(WN_TPB) void k_sum_layers(const float* __restrict__
 }
 
 int wn_sum_layers(const float* params, long off, long ls, int L, int n, float* out, wn_stream_t st) {
+    WN_PROF("sum_layers", 0.0, 0.0, st);
     WN_LAUNCH(k_sum_layers, dim3((unsigned)((n + WN_TPB - 1) / WN_TPB)), dim3(WN_TPB), 0, st, params, off, ls, L, n, out);
     return 0;
 }
@@ -271,6 +281,7 @@ __global__ __launch_bounds__(WN_TPB) void k_aux_bwd(const float* __restrict__ dP
 
 int wn_aux_bwd(const float* dP, const float* G, long g_bstride, const float* upw, float* dG, float* dw_partial, int B, int T,
                int R2, int U, int F, wn_stream_t st) {
+    WN_PROF("aux_bwd", 0.0, 0.0, st);
     if ((long)U * F != T) return 1;
     WN_LAUNCH(k_aux_bwd, dim3((unsigned)R2, (unsigned)B), dim3(WN_TPB), 0, st, dP, G, g_bstride, upw, dG, dw_partial, T, R2, U,
               F);
@@ -297,6 +308,7 @@ __global__ __launch_bounds__(WN_TPB) void k_reduce(WnReduceArgs a) {
 }
 
 int wn_reduce(const WnReduceArgs* a, wn_stream_t st) {
+    WN_PROF("reduce_partials", 0.0, 0.0, st);
     const long mn = (long)a->M * a->N;
     if (mn <= 0 || a->m_seg <= 0 || a->n_seg <= 0) return 1;
     WN_LAUNCH(k_reduce, dim3((unsigned)((mn + WN_TPB - 1) / WN_TPB)), dim3(WN_TPB), 0, st, *a);
@@ -313,6 +325,7 @@ __global__ __launch_bounds__(WN_TPB) void k_dot(const float* __restrict__ a, con
 }
 
 int wn_dot(const float* a, const float* b, long n, float* out, int accumulate, wn_stream_t st) {
+    WN_PROF("dot", 0.0, 0.0, st);
     WN_LAUNCH(k_dot, dim3(1), dim3(WN_TPB), 0, st, a, b, n, out, accumulate);
     return 0;
 }
@@ -323,6 +336,7 @@ __global__ __launch_bounds__(WN_TPB) void k_fill(float* __restrict__ p, float v,
 }
 
 int wn_fill(float* p, float v, long n, wn_stream_t st) {
+    WN_PROF("fill", 0.0, 0.0, st);
     if (n <= 0) return 0;
     WN_LAUNCH(k_fill, dim3((unsigned)((n + WN_TPB - 1) / WN_TPB)), dim3(WN_TPB), 0, st, p, v, n);
     return 0;

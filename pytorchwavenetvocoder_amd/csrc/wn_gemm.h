@@ -54,6 +54,7 @@ typedef struct WnGemmArgs {
     int ksplit;
     int kchunk;       // k range of split ks: [ks*kchunk, min(K, (ks+1)*kchunk))
     float* a_rowsum;  // optional [nz][M]: sum_k A(m,k) over this z's k range (a_kmajor=1 only)
+    const char* tag;  // static string naming the call site (profiling); may be null
 } WnGemmArgs;
 
 static inline WnGemmArgs wn_gemm_default() {
@@ -68,6 +69,7 @@ static inline WnGemmArgs wn_gemm_default() {
     g.relu = 0; g.accumulate = 0;
     g.nbatch = 1; g.ksplit = 1; g.kchunk = 0x7fffffff;
     g.a_rowsum = 0;
+    g.tag = 0;
     return g;
 }
 

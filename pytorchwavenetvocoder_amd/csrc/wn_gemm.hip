@@ -17,6 +17,7 @@
 // Lane l of a wave feeds A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; accumulator register r
 // of lane l is D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]  (see wn_device.h).
 #include "wn_gemm.h"
+#include "wn_prof.h"
 
 #define WN_BK 32
 #define WN_GEMM_THREADS 256
@@ -195,6 +196,7 @@ int wn_gemm_launch(const WnGemmArgs* gp, wn_stream_t stream) {
     if (g.a_kmajor != g.b_kmajor) return 2;
     if (g.b_seg_len <= 0 || g.kchunk <= 0) return 3;
     const int tm = g.M > 64 ? 2 : 1, tn = g.N > 64 ? 2 : 1;
+    WN_PROF(g.tag ? g.tag : "gemm", 2.0 * g.M * g.N * (double)g.K * g.nbatch, 0.0, stream);
     const int key = (g.a_kmajor ? 4 : 0) | (tm == 2 ? 2 : 0) | (tn == 2 ? 1 : 0);
     switch (key) {
         case 0: launch_variant<1, 1, 0>(g, stream); break;

@@ -1,0 +1,104 @@
+// wn_prof.hip -- see wn_prof.h
+#include "wn_prof.h"
+
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/wavenet_hip.h"
+
+#ifdef WN_EMU
+void wn_prof_scope_begin(const char*, double, double, wn_stream_t) {}
+void wn_prof_scope_end(wn_stream_t) {}
+extern "C" int wn_prof_enable(int) { return 0; }
+extern "C" int wn_prof_report(char* buf, size_t n) {
+    if (buf && n) buf[0] = 0;
+    return 0;
+}
+#else
+namespace {
+struct Rec {
+    const char* name;
+    double flops, bytes;
+    hipEvent_t e0, e1;
+};
+bool g_on = false;
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_pool;
+hipEvent_t get_event() {
+    if (!g_pool.empty()) {
+        hipEvent_t e = g_pool.back();
+        g_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+void wn_prof_scope_begin(const char* name, double flops, double bytes, wn_stream_t st) {
+    if (!g_on) return;
+    Rec r;
+    r.name = name;
+    r.flops = flops;
+    r.bytes = bytes;
+    r.e0 = get_event();
+    r.e1 = get_event();
+    (void)hipEventRecord(r.e0, st);
+    g_recs.push_back(r);
+}
+
+void wn_prof_scope_end(wn_stream_t st) {
+    if (!g_on || g_recs.empty()) return;
+    (void)hipEventRecord(g_recs.back().e1, st);
+}
+
+extern "C" int wn_prof_enable(int on) {
+    g_on = on != 0;
+    if (g_on) {
+        for (auto& r : g_recs) {
+            g_pool.push_back(r.e0);
+            g_pool.push_back(r.e1);
+        }
+        g_recs.clear();
+    }
+    return 0;
+}
+
+// JSON object {"name": {"count": n, "ms": total, "flops": total, "bytes": total}, ...}.  The caller
+// must have synchronised the stream(s).
+extern "C" int wn_prof_report(char* buf, size_t n) {
+    struct Agg {
+        long count = 0;
+        double ms = 0, flops = 0, bytes = 0;
+    };
+    std::map<std::string, Agg> agg;
+    for (auto& r : g_recs) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+        Agg& a = agg[r.name];
+        a.count++;
+        a.ms += ms;
+        a.flops += r.flops;
+        a.bytes += r.bytes;
+    }
+    std::string s = "{";
+    bool first = true;
+    for (auto& kv : agg) {
+        char tmp[512];
+        snprintf(tmp, sizeof(tmp), "%s\"%s\": {\"count\": %ld, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}", first ? "" : ", ",
+                 kv.first.c_str(), kv.second.count, kv.second.ms, kv.second.flops, kv.second.bytes);
+        s += tmp;
+        first = false;
+    }
+    s += "}";
+    if (!buf || n == 0) return (int)s.size() + 1;
+    if (s.size() + 1 > n) return -1;
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return 0;
+}
+#endif

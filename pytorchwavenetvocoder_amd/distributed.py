@@ -1,0 +1,58 @@
+# -*- coding: utf-8 -*-
+"""Data-parallel gradient reduction: one process per GPU, RCCL all-reduce over xGMI.
+
+Replaces the reference's single-process ``torch.nn.DataParallel`` (train.py:449-454: per-step
+parameter broadcast, logits gather to GPU0, gradient reduce to GPU0) with the minimum exchange the
+path needs: every rank computes its own loss on its own shard of the minibatch and ONE flat fp32
+gradient buffer is summed across ranks (gradients are pre-scaled by 1/world_size inside the loss
+kernel, so the sum is the global-batch mean the reference's loss produces).  The buffer is laid
+out in backward-completion order, so buckets are contiguous ranges: ``wn_backward`` records a HIP
+event after each bucket and the all-reduce of bucket i runs on a side stream while the backward
+kernels of the following layers are still executing.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradientReducer(object):
+    def __init__(self, model, process_group=None, layers_per_bucket=10):
+        self.model = model
+        self.group = process_group
+        self.lpb = layers_per_bucket
+        self.eng = model.engine
+        self.ranges = self.eng.bucket_ranges(layers_per_bucket)
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.cuda = self.eng.device.type == "cuda"
+        if self.cuda:
+            self.side = torch.cuda.Stream(device=self.eng.device)
+            self.events = [torch.cuda.Event() for _ in self.ranges]
+            for e in self.events:  # create the underlying hipEvent_t handles
+                e.record(torch.cuda.current_stream(self.eng.device))
+        else:
+            self.side, self.events = None, None
+
+    @property
+    def grad_scale(self):
+        return 1.0 / self.world
+
+    def loss_and_backward(self, x, h, t, t_start=None):
+        """forward + loss + backward with the bucketed all-reduce overlapped; returns the local
+        mean loss (device tensor)."""
+        if self.world == 1:
+            return self.model.loss_and_backward(x, h, t, t_start=t_start)
+        if not self.cuda:
+            loss = self.model.loss_and_backward(x, h, t, t_start=t_start, grad_scale=self.grad_scale)
+            flat = self.eng.grads()
+            for lo, hi in self.ranges:
+                dist.all_reduce(flat[lo:hi], group=self.group)
+            return loss
+        handles = [e.cuda_event for e in self.events]
+        loss = self.model.loss_and_backward(x, h, t, t_start=t_start, grad_scale=self.grad_scale,
+                                            events=handles, layers_per_bucket=self.lpb)
+        flat = self.eng.grads()
+        with torch.cuda.stream(self.side):
+            for (lo, hi), ev in zip(self.ranges, self.events):
+                self.side.wait_event(ev)
+                dist.all_reduce(flat[lo:hi], group=self.group)
+        torch.cuda.current_stream(self.eng.device).wait_stream(self.side)
+        return loss

@@ -1,0 +1,382 @@
+# -*- coding: utf-8 -*-
+"""MI355X-native drop-in for ``wavenet_vocoder.nets.wavenet`` (reference wavenet.py).
+
+Same public surface as the reference module -- ``encode_mu_law``, ``decode_mu_law``,
+``initialize``, ``OneHot``, ``CausalConv1d``, ``UpSampling``, ``WaveNet`` with the reference's
+constructor, ``forward(x, h)`` contract and ``state_dict`` keys/shapes -- but ``WaveNet.forward``
+and its backward run in the hand-written HIP kernels of ``libwavenet_hip.so`` (C ABI:
+include/wavenet_hip.h).  The ``nn.Conv1d`` / ``nn.ConvTranspose2d`` sub-modules are parameter
+containers only (so ``model.apply(initialize)``, ``load_state_dict`` and checkpoints behave like
+the reference's, wavenet.py:57-63, train.py:325-331): their tensors are views into ONE flat fp32
+buffer that the kernels, the fused Adam and the RCCL all-reduce operate on.
+
+There is no CPU path: calling the model with CPU tensors raises.
+"""
+import logging
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import _lib
+from ..engine import WaveNetEngine, key_to_kind
+
+
+def encode_mu_law(x, mu=256):
+    """Mu-law encoding (reference wavenet.py:17-30).
+
+    Args:
+        x (ndarray): Audio signal with the range from -1 to 1.
+        mu (int): Quantized level.
+
+    Returns:
+        ndarray: Quantized audio signal with the range from 0 to mu - 1.
+    """
+    mu = mu - 1
+    fx = np.sign(x) * np.log(1 + mu * np.abs(x)) / np.log(1 + mu)
+    return np.floor((fx + 1) / 2 * mu + 0.5).astype(np.int64)
+
+
+def decode_mu_law(y, mu=256):
+    """Mu-law decoding (reference wavenet.py:33-47)."""
+    mu = mu - 1
+    fx = (y - 0.5) / mu * 2 - 1
+    x = np.sign(fx) / mu * ((1 + mu) ** np.abs(fx) - 1)
+    return x
+
+
+def initialize(m):
+    """Xavier init for Conv1d, ones/zeros for ConvTranspose2d (reference wavenet.py:50-63).
+
+    In-place, so it writes straight through the parameter views into the flat buffer.
+    """
+    if isinstance(m, nn.Conv1d):
+        nn.init.xavier_uniform_(m.weight)
+        nn.init.constant_(m.bias, 0.0)
+    if isinstance(m, nn.ConvTranspose2d):
+        nn.init.constant_(m.weight, 1.0)
+        nn.init.constant_(m.bias, 0.0)
+
+
+class OneHot(nn.Module):
+    """One-hot conversion (reference wavenet.py:66-92).  Kept for API compatibility; the WaveNet
+    forward never materialises it (the front convolution is a gather, csrc/wn_elem.hip)."""
+
+    def __init__(self, depth):
+        super(OneHot, self).__init__()
+        self.depth = depth
+
+    def forward(self, x):
+        x = x % self.depth
+        x = torch.unsqueeze(x, 2)
+        x_onehot = x.new_zeros(x.size(0), x.size(1), self.depth).float()
+        return x_onehot.scatter_(2, x, 1)
+
+
+class CausalConv1d(nn.Module):
+    """1D dilated causal convolution (reference wavenet.py:95-121).
+
+    Stand-alone ``forward`` runs the HIP causal-conv op (taps as K-segments of one f32-MFMA
+    contraction); inside ``WaveNet`` the module only holds the parameters.
+    """
+
+    def __init__(self, in_channels, out_channels, kernel_size, dilation=1, bias=True):
+        super(CausalConv1d, self).__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = kernel_size
+        self.dilation = dilation
+        self.padding = (kernel_size - 1) * dilation
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size,
+                              padding=self.padding, dilation=dilation, bias=bias)
+
+    def forward(self, x):
+        """x (B, C, T) float -> (B, C', T).  Inference-only op (no autograd)."""
+        import ctypes
+        lib = _lib.load_library()
+        if not x.is_cuda:
+            raise _lib.WnError("CausalConv1d runs on the GPU HIP path only (no CPU fallback)")
+        x = x.contiguous().float()
+        B, C, T = x.shape
+        w = self.conv.weight.detach().contiguous()
+        b = self.conv.bias.detach().contiguous() if self.conv.bias is not None else \
+            torch.zeros(self.out_channels, device=x.device)
+        y = torch.empty(B, self.out_channels, T, device=x.device, dtype=torch.float32)
+        scratch = torch.empty(w.numel(), device=x.device, dtype=torch.float32)
+        st = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        rc = lib.wn_op_causal_conv(w.data_ptr(), b.data_ptr(), x.data_ptr(), y.data_ptr(), scratch.data_ptr(),
+                                   B, T, C, self.out_channels, self.kernel_size, self.dilation, st)
+        lib.check(rc, "wn_op_causal_conv")
+        return y
+
+
+class UpSampling(nn.Module):
+    """Upsampling with a (1, U) transposed convolution (reference wavenet.py:124-154).
+
+    ``out[b, c, f*U + j] = h[b, c, f] * w[j] + bias`` -- inside ``WaveNet`` this is never
+    materialised (applied at frame rate inside the gate, csrc/wn_elem.hip / wn_fused.hip).
+    """
+
+    def __init__(self, upsampling_factor, bias=True):
+        super(UpSampling, self).__init__()
+        self.upsampling_factor = upsampling_factor
+        self.bias = bias
+        self.conv = nn.ConvTranspose2d(1, 1, kernel_size=(1, self.upsampling_factor),
+                                       stride=(1, self.upsampling_factor), bias=self.bias)
+
+    def forward(self, x):
+        """x (B, C, T) -> (B, C, T * upsampling_factor)  (closed form, device-agnostic glue)."""
+        w = self.conv.weight.view(-1)
+        y = x.unsqueeze(-1) * w
+        if self.conv.bias is not None:
+            y = y + self.conv.bias
+        return y.reshape(x.size(0), x.size(1), -1)
+
+
+class _WaveNetFunction(torch.autograd.Function):
+    """autograd bridge: forward = wn_forward, backward = wn_backward (one flat gradient buffer)."""
+
+    @staticmethod
+    def forward(ctx, model, x, h, *params):
+        eng = model._engine
+        logits = eng.forward(x, h)
+        model._fwd_serial += 1
+        ctx.model = model
+        ctx.serial = model._fwd_serial
+        return logits.transpose(1, 2)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        model = ctx.model
+        if ctx.serial != model._fwd_serial:
+            raise _lib.WnError("WaveNet backward after a newer forward: the HIP path keeps the activations "
+                               "of the latest forward only")
+        dl = grad_out.transpose(1, 2).contiguous()
+        flat = model._engine.backward(dl).clone()
+        grads = []
+        for (off, n, shape, dead) in model._param_slices:
+            grads.append(None if dead else flat[off:off + n].view(shape))
+        return (None, None, None) + tuple(grads)
+
+
+class WaveNet(nn.Module):
+    """Conditional WaveNet (reference wavenet.py:157-210) on the MI355X HIP path.
+
+    Args:
+        n_quantize (int): Number of quantization.
+        n_aux (int): Number of aux feature dimension.
+        n_resch (int): Number of filter channels for residual block.
+        n_skipch (int): Number of filter channels for skip connection.
+        dilation_depth (int): Number of dilation depth (e.g. if set 10, max dilation = 2^(10-1)).
+        dilation_repeat (int): Number of dilation repeat.
+        kernel_size (int): Filter size of dilated causal convolution.
+        upsampling_factor (int): Upsampling factor.
+    """
+
+    def __init__(self, n_quantize=256, n_aux=28, n_resch=512, n_skipch=256,
+                 dilation_depth=10, dilation_repeat=3, kernel_size=2, upsampling_factor=0, _library=None):
+        super(WaveNet, self).__init__()
+        self.n_aux = n_aux
+        self.n_quantize = n_quantize
+        self.n_resch = n_resch
+        self.n_skipch = n_skipch
+        self.kernel_size = kernel_size
+        self.dilation_depth = dilation_depth
+        self.dilation_repeat = dilation_repeat
+        self.upsampling_factor = upsampling_factor
+
+        self.dilations = [2 ** i for i in range(self.dilation_depth)] * self.dilation_repeat
+        self.receptive_field = (self.kernel_size - 1) * sum(self.dilations) + 1
+
+        # parameter containers, registered in the reference's order (wavenet.py:187-210)
+        self.onehot = OneHot(self.n_quantize)
+        self.causal = CausalConv1d(self.n_quantize, self.n_resch, self.kernel_size)
+        if self.upsampling_factor > 0:
+            self.upsampling = UpSampling(self.upsampling_factor)
+        self.dil_sigmoid = nn.ModuleList()
+        self.dil_tanh = nn.ModuleList()
+        self.aux_1x1_sigmoid = nn.ModuleList()
+        self.aux_1x1_tanh = nn.ModuleList()
+        self.skip_1x1 = nn.ModuleList()
+        self.res_1x1 = nn.ModuleList()
+        for d in self.dilations:
+            self.dil_sigmoid += [CausalConv1d(self.n_resch, self.n_resch, self.kernel_size, d)]
+            self.dil_tanh += [CausalConv1d(self.n_resch, self.n_resch, self.kernel_size, d)]
+            self.aux_1x1_sigmoid += [nn.Conv1d(self.n_aux, self.n_resch, 1)]
+            self.aux_1x1_tanh += [nn.Conv1d(self.n_aux, self.n_resch, 1)]
+            self.skip_1x1 += [nn.Conv1d(self.n_resch, self.n_skipch, 1)]
+            self.res_1x1 += [nn.Conv1d(self.n_resch, self.n_resch, 1)]
+        self.conv_post_1 = nn.Conv1d(self.n_skipch, self.n_skipch, 1)
+        self.conv_post_2 = nn.Conv1d(self.n_skipch, self.n_quantize, 1)
+
+        # the HIP engine (loads libwavenet_hip.so; raises when the extension is unavailable)
+        object.__setattr__(self, "_engine", WaveNetEngine(
+            n_quantize, n_aux, n_resch, n_skipch, dilation_depth, dilation_repeat, kernel_size,
+            upsampling_factor, device="cpu", library=_library))
+        assert self._engine.receptive_field == self.receptive_field
+        self._fwd_serial = 0
+        self._param_slices = []
+        self._flatten()
+
+    # ---- flat storage -------------------------------------------------------------------------
+    def _flatten(self):
+        """(Re)build the flat parameter buffer on the parameters' device and point every
+        nn.Parameter at its slice."""
+        eng = self._engine
+        named = list(self.named_parameters())
+        device = named[0][1].device
+        for _, p in named:
+            if p.dtype != torch.float32:
+                raise _lib.WnError("the HIP WaveNet path is fp32 (parity gate 1e-4); got %s" % p.dtype)
+            if p.device != device:
+                raise _lib.WnError("all WaveNet parameters must live on one device")
+        flat = torch.empty(eng.n_params, dtype=torch.float32, device=device)
+        slices = []
+        with torch.no_grad():
+            for k, p in named:
+                kind, layer = key_to_kind(k)
+                off, n = eng.param_slice(kind, layer)
+                assert n == p.numel(), k
+                flat[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = flat[off:off + n].view(p.shape)
+                dead = (eng.dead_range[0] <= off < eng.dead_range[1])
+                slices.append((off, n, tuple(p.shape), dead))
+        eng.device = device
+        eng.flat_params = flat
+        eng.flat_grads = None
+        eng._ws = None
+        eng._ws_key = None
+        self._param_slices = slices
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super(WaveNet, self)._apply(fn, *args, **kwargs)
+        self._flatten()
+        return out
+
+    @property
+    def engine(self):
+        return self._engine
+
+    # ---- forward ------------------------------------------------------------------------------
+    def forward(self, x, h):
+        """Forward calculation (reference wavenet.py:212-241).
+
+        Args:
+            x (Tensor): Long tensor variable with the shape (B, T).
+            h (Tensor): Float tensor variable with the shape (B, n_aux, T)
+                (or (B, n_aux, T / upsampling_factor) with the upsampling layer).
+
+        Returns:
+            Tensor: Float tensor variable with the shape (B, T, n_quantize)
+                (a transposed view of a (B, n_quantize, T) buffer, like the reference's result).
+        """
+        params = tuple(self.parameters())
+        return _WaveNetFunction.apply(self, x, h, *params)
+
+    def loss_and_backward(self, x, h, t, t_start=None, grad_scale=1.0, events=None, layers_per_bucket=0):
+        """Fused training half-step: forward -> CrossEntropy on ``[:, t_start:]`` -> backward
+        (reference train.py:533-538) without an autograd graph.
+
+        Leaves the gradients in the flat buffer (``p.grad`` of every parameter is a view of it;
+        ``None`` for the dead last ``res_1x1``) and returns the mean loss as a 1-element device
+        tensor (no host sync).  ``grad_scale`` multiplies the gradients (1/world_size for DP)."""
+        eng = self._engine
+        logits = eng.forward(x, h)
+        self._fwd_serial += 1
+        loss, dlogits = eng.loss(logits, t, t_start=t_start, grad_scale=grad_scale)
+        flat = eng.backward(dlogits, events=events, layers_per_bucket=layers_per_bucket)
+        for p, (off, n, shape, dead) in zip(self.parameters(), self._param_slices):
+            p.grad = None if dead else flat[off:off + n].view(shape)
+        return loss
+
+    # ---- generation (reference wavenet.py:243-511) --------------------------------------------
+    def _window_logits(self, x, h_up):
+        """Logits (T, Q) for ONE window with the aux features already at sample rate."""
+        eng = self._gen_engine()
+        logits = eng.forward(x, h_up)
+        return logits[0].transpose(0, 1)
+
+    def _gen_engine(self):
+        """Engine that treats h as already up-sampled (the reference bypasses the upsampling layer
+        inside generate(), wavenet.py:258-259,273-283).  The flat layout keeps the upsampling
+        tensors at the very end, so the U=0 layout is a prefix of this model's buffer."""
+        if self.upsampling_factor == 0:
+            return self._engine
+        eng = getattr(self, "_gen_eng", None)
+        if eng is None or eng.device != self._engine.device or \
+                eng.flat_params.data_ptr() != self._engine.flat_params.data_ptr():
+            eng = WaveNetEngine(self.n_quantize, self.n_aux, self.n_resch, self.n_skipch, self.dilation_depth,
+                                self.dilation_repeat, self.kernel_size, 0, device=self._engine.device,
+                                library=self._engine.lib)
+            eng.flat_params = self._engine.flat_params[:eng.n_params]
+            object.__setattr__(self, "_gen_eng", eng)
+        return eng
+
+    def generate(self, x, h, n_samples, intervals=None, mode="sampling"):
+        """Generate a waveform sample by sample with full-window forwards (reference
+        wavenet.py:243-307).  Every window runs through the HIP forward.
+
+        Args:
+            x (Tensor): Long tensor variable with the shape (1, T).
+            h (Tensor): Float tensor variable with the shape (1, n_aux, n_samples + T).
+            n_samples (int): Number of samples to be generated.
+            intervals (int): Log interval.
+            mode (str): "sampling" or "argmax".
+
+        Returns:
+            ndarray: Generated quantized waveform (n_samples,).
+        """
+        with torch.no_grad():
+            if self.upsampling_factor > 0:
+                h = self.upsampling(h)
+            n_pad = self.receptive_field - x.size(1)
+            if n_pad > 0:
+                x = F.pad(x, (n_pad, 0), "constant", self.n_quantize // 2)
+                h = F.pad(h, (n_pad, 0), "replicate")
+            samples = x[0].tolist()
+            start = time.time()
+            for i in range(n_samples):
+                current_idx = len(samples)
+                xw = torch.tensor(samples[-self.receptive_field:], device=h.device).long().view(1, -1)
+                h_ = h[:, :, current_idx - self.receptive_field: current_idx].contiguous()
+                output = self._window_logits(xw, h_)
+                if mode == "sampling":
+                    posterior = F.softmax(output[-1], dim=0)
+                    dist = torch.distributions.Categorical(posterior)
+                    sample = int(dist.sample())
+                elif mode == "argmax":
+                    sample = int(output[-1].argmax())
+                else:
+                    logging.error("mode should be sampling or argmax")
+                    sys.exit(1)
+                samples.append(sample)
+                if intervals is not None and (i + 1) % intervals == 0:
+                    logging.info("%d/%d estimated time = %.3f sec (%.3f sec / sample)" % (
+                        i + 1, n_samples,
+                        (n_samples - i - 1) * ((time.time() - start) / intervals),
+                        (time.time() - start) / intervals))
+                    start = time.time()
+            return np.array(samples[-n_samples:])
+
+    def fast_generate(self, x, h, n_samples, intervals=None, mode="sampling"):
+        """Reference wavenet.py:309-395.  Round 1: same results as ``generate`` (the reference's own
+        tests assert argmax equality of the two, test/test_wavenet.py:93-222); the cached
+        dilation-queue decode kernel is the next hot-path row."""
+        return self.generate(x, h, n_samples, intervals, mode)
+
+    def batch_fast_generate(self, x, h, n_samples_list, intervals=None, mode="sampling"):
+        """Reference wavenet.py:397-511: per-utterance lengths; returned in order of completion
+        (shortest first), like the reference."""
+        order = sorted(range(len(n_samples_list)), key=lambda i: (n_samples_list[i], i))
+        T = x.size(1)
+        out = []
+        for i in order:
+            n = n_samples_list[i]
+            hi = h[i:i + 1, :, :]
+            if self.upsampling_factor == 0:
+                hi = hi[:, :, :n + T]
+            out.append(self.generate(x[i:i + 1], hi, n, intervals, mode))
+        return out

@@ -1,0 +1,52 @@
+# -*- coding: utf-8 -*-
+"""CPU-only: the HIP kernel SOURCES compiled for the host (tests/emu) against the reference's
+golden vectors and the oracle.  Validates index arithmetic / LDS layouts / MFMA lane maps of the
+exact code that hipcc builds for gfx950; the same checks run on the real GPU in test_gpu_parity.py."""
+import pytest
+import torch
+
+from tests import parity_common as PC
+from tests.emu_util import emu_library
+from tests.golden_util import CASES, GoldenCase
+
+pytestmark = pytest.mark.emu
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_engine_vs_golden(name):
+    PC.check_golden_case(GoldenCase(name), emu_library(), "cpu")
+
+
+@pytest.mark.parametrize("name", ["tiny_k2_up", "tiny_k3_noup"])
+def test_module_training_vs_golden(name):
+    PC.check_module_training(GoldenCase(name), emu_library(), "cpu")
+
+
+@pytest.mark.parametrize("name", ["r64_k2_up", "r64_k3_up"])
+def test_layered_path_vs_golden_r64(name):
+    from pytorchwavenetvocoder_amd import _lib
+    PC.check_golden_case(GoldenCase(name), emu_library(), "cpu", flags=_lib.FLAG_NO_FUSED)
+
+
+def test_ragged_T_and_odd_channels():
+    # T not a multiple of any tile, channel counts not multiples of 32, B=3
+    PC.run_oracle_vs_engine((37, 7, 12, 20, 2, 2, 2, 0), 3, 77, 5, emu_library(), "cpu")
+    PC.run_oracle_vs_engine((37, 7, 12, 20, 3, 1, 3, 7), 2, 91, 6, emu_library(), "cpu")
+
+
+def test_wide_channels_multi_tile():
+    # R > 64 exercises the 128-wide tiles and multi-tile M
+    PC.run_oracle_vs_engine((48, 9, 96, 160, 2, 1, 2, 4), 1, 72, 7, emu_library(), "cpu")
+
+
+def test_cpu_tensors_rejected_by_product_binding():
+    """The product binding must refuse CPU tensors (no CPU fallback)."""
+    from pytorchwavenetvocoder_amd import _lib
+    from pytorchwavenetvocoder_amd.nets import WaveNet
+    lib = _lib.load_library()  # the real gfx950 library (cross-compiled; loads without a GPU)
+    assert not lib.is_emulator
+    model = WaveNet(16, 4, 4, 4, 2, 1, 2, 0)
+    x = torch.zeros(1, 8, dtype=torch.long)
+    h = torch.zeros(1, 4, 8)
+    with pytest.raises(_lib.WnError):
+        model(x, h)

@@ -1,0 +1,151 @@
+# -*- coding: utf-8 -*-
+"""GPU parity tests proper: the gfx950 library called through the C-ABI on a real MI355X against
+(a) the committed golden vectors produced by the reference itself, (b) the live CPU oracle on
+seeded inputs at sizes it finishes in seconds, and (c) size-independent properties at
+BASELINE.json's full size (config 2: B=8, T=23040)."""
+import ctypes
+
+import pytest
+import torch
+
+from tests import parity_common as PC
+from tests.golden_util import CASES, GoldenCase
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _lib():
+    from pytorchwavenetvocoder_amd import _lib as L
+    lib = L.load_library()
+    assert not lib.is_emulator
+    return lib
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_engine_vs_golden(name):
+    PC.check_golden_case(GoldenCase(name), _lib(), DEV)
+
+
+@pytest.mark.parametrize("name", ["r64_k2_up", "r64_k3_up"])
+def test_layered_kernels_vs_golden_r64(name):
+    from pytorchwavenetvocoder_amd import _lib as L
+    PC.check_golden_case(GoldenCase(name), _lib(), DEV, flags=L.FLAG_NO_FUSED)
+
+
+@pytest.mark.parametrize("name", ["tiny_k2_up", "tiny_k3_noup", "r64_k2_up"])
+def test_module_training_vs_golden(name):
+    PC.check_module_training(GoldenCase(name), _lib(), DEV)
+
+
+def test_ragged_and_odd_shapes_vs_oracle():
+    PC.run_oracle_vs_engine((37, 7, 12, 20, 2, 2, 2, 0), 3, 77, 5, _lib(), DEV)
+    PC.run_oracle_vs_engine((37, 7, 12, 20, 3, 1, 3, 7), 2, 91, 6, _lib(), DEV)
+    PC.run_oracle_vs_engine((48, 9, 96, 160, 2, 1, 2, 4), 1, 72, 7, _lib(), DEV)
+
+
+def test_reference_test_shapes():
+    """The model shapes of the reference's own test/test_wavenet.py:31-71 (shape assertions)."""
+    from pytorchwavenetvocoder_amd.nets import WaveNet, initialize
+    for args, hlen in [((256, 28, 32, 128, 10, 1, 2), 100), ((256, 28, 32, 128, 10, 1, 2, 10), 10),
+                       ((256, 28, 32, 128, 10, 1, 3, 10), 10)]:
+        net = WaveNet(*args)
+        net.apply(initialize)
+        net.eval()
+        net.to(DEV)
+        x = torch.randint(0, 256, (1, 100), device=DEV)
+        h = torch.rand(1, 28, hlen, device=DEV)
+        y = net(x, h)[0]
+        assert y.size(0) == 100 and y.size(1) == 256
+
+
+def test_cfg2_model_midsize_vs_oracle():
+    """The BASELINE config-2 MODEL (30 layers, 64/256 ch, A=80, U=80) on a window the CPU oracle
+    finishes in seconds (T=4000 > rf=3070), trained-scale weights and init-scale weights."""
+    cfg_t = (256, 80, 64, 256, 10, 3, 2, 80)
+    e1, g1 = PC.run_oracle_vs_engine(cfg_t, 1, 4000, 21, _lib(), DEV, scale=0.05)
+    e2, g2 = PC.run_oracle_vs_engine(cfg_t, 2, 3200, 22, _lib(), DEV, scale=0.02)
+    print("cfg2-model logits err %.3g / %.3g, worst grad rel err %.3g / %.3g" % (e1, e2, g1, g2))
+
+
+def test_cfg2_fused_equals_layered_midsize():
+    """Fused R=64 kernels and the layered any-size kernels are two implementations of the same
+    math; they must agree to fp32 round-off."""
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd import _lib as L
+    from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat
+    cfg_t = (256, 80, 64, 256, 10, 3, 2, 80)
+    cfg = O.OracleConfig(*cfg_t)
+    params = O.random_params(cfg, 31, scale=0.05)
+    x, h, t = O.synthetic_batch(cfg, 2, 4000, 32)
+    outs = []
+    for flags in (0, L.FLAG_NO_FUSED):
+        eng = WaveNetEngine(*cfg_t, device=DEV, library=_lib())
+        eng.flags = flags
+        load_state_into_flat(eng, params)
+        logits = eng.forward(x.to(DEV), h.to(DEV))
+        loss, dl = eng.loss(logits, t.to(DEV))
+        g = eng.backward(dl).clone()
+        outs.append((logits.clone(), float(loss.cpu()), g))
+    assert float((outs[0][0] - outs[1][0]).abs().max()) <= 2e-5
+    assert abs(outs[0][1] - outs[1][1]) <= 1e-6
+    assert float((outs[0][2] - outs[1][2]).abs().max()) <= 1e-5 * float(outs[1][2].abs().max())
+
+
+def test_cfg2_full_size_properties():
+    """BASELINE config 2 at FULL size (B=8, T=23040): properties that need no oracle run.
+      * finite loss close to ln(256) for random-init weights and random targets;
+      * batch independence: sequence b computed alone (B=1) gives the same logits;
+      * causality: changing x[t0:] / h frames from t0 on leaves logits before t0 bit-identical;
+      * zero loss-gradient region: dlogits is zero for t < rf;
+      * directional derivative of the loss along the gradient matches |g|^2.
+    """
+    import math
+    from pytorchwavenetvocoder_amd.nets import WaveNet, initialize
+    torch.manual_seed(1)
+    cfg = dict(n_quantize=256, n_aux=80, n_resch=64, n_skipch=256, dilation_depth=10, dilation_repeat=3,
+               kernel_size=2, upsampling_factor=80)
+    model = WaveNet(**cfg)
+    model.apply(initialize)
+    model.to(DEV)
+    rf = model.receptive_field
+    assert rf == 3070
+    B, T, U = 8, 23040, 80
+    g = torch.Generator().manual_seed(5)
+    xx = torch.randint(0, 256, (B, T + 1), generator=g)
+    x, t = xx[:, :-1].contiguous().to(DEV), xx[:, 1:].contiguous().to(DEV)
+    h = torch.randn(B, 80, T // U, generator=g).to(DEV)
+    eng = model.engine
+    logits = eng.forward(x, h).clone()
+    assert torch.isfinite(logits).all()
+    loss, dl = eng.loss(logits, t)
+    assert abs(float(loss.cpu()) - math.log(256)) < 0.5
+    assert float(dl[:, :, :rf].abs().max()) == 0.0
+    flat = eng.backward(dl).clone()
+    assert torch.isfinite(flat).all()
+    lo, hi = eng.dead_range
+    assert float(flat[lo:hi].abs().max()) == 0.0
+    # batch independence
+    one = eng.forward(x[3:4].contiguous(), h[3:4].contiguous())
+    assert float((one[0] - logits[3]).abs().max()) <= 2e-5
+    # causality (t0 on a frame boundary so the aux features before t0 are unchanged)
+    t0 = 80 * 150
+    x2, h2 = x.clone(), h.clone()
+    x2[:, t0:] = (x2[:, t0:] + 17) % 256
+    h2[:, :, t0 // U:] += 1.0
+    l2 = eng.forward(x2, h2)
+    assert torch.equal(l2[:, :, :t0], logits[:, :, :t0])
+    assert not torch.equal(l2[:, :, t0:], logits[:, :, t0:])
+    # directional derivative along the gradient:  L(p - eps g) - L(p) ~= -eps |g|^2
+    p0 = eng.flat_params.clone()
+    gnorm2 = float((flat.double() ** 2).sum())
+    eps = 0.05 / max(gnorm2 ** 0.5, 1e-12)
+    base = float(loss.cpu())
+    eng.flat_params.copy_(p0 - eps * flat)
+    lm, _ = eng.loss(eng.forward(x, h), t, want_grad=False)
+    eng.flat_params.copy_(p0 + eps * flat)
+    lp, _ = eng.loss(eng.forward(x, h), t, want_grad=False)
+    eng.flat_params.copy_(p0)
+    fd = (float(lp.cpu()) - float(lm.cpu())) / (2 * eps)
+    assert abs(fd - gnorm2) <= 0.05 * gnorm2 + 1e-6, (fd, gnorm2, base)
