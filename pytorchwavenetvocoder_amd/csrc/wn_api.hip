@@ -250,12 +250,11 @@ static DwPlan dw_plan(int M, int N, int Kdim, int nbatch) {
 struct Ws {
     // packed weights
     long wc_f, wd_f, waux_f, cvec, rowsum_aux, wres_f, wskip_f, bskip, w1_f, w2_f, wd_b, one;
-    // fused-kernel weight images
-    long fw_fwd, fw_bwd;
     // saved activations
     long X, G, Sg, Gt, Z, O1, O2;
     // scratch
-    long P, dO2, dSk, dZ, dXa, dXb, dG, dw_partial, dc, tmpS, partial, rs_partial, loss_partial;
+    long P, dO2, dSk, dZ, dXa, dXb, dG, dw_partial, dc, tmpS, partial, rs_partial, red_scratch, loss_partial;
+    long red_scratch_floats;
     long total;
     int F;  // frames (T/U, or T without upsampling)
 };
@@ -285,8 +284,6 @@ static int make_ws(const Dims& d, int B, int T, Ws* w) {
     CARVE(w2_f, (long)d.S * d.Q);
     CARVE(wd_b, (long)d.L * d.K * 2 * d.R * d.R);
     CARVE(one, 64);
-    CARVE(fw_fwd, wn_fused_fwd_weight_floats(d.R, d.K) * (long)d.L);
-    CARVE(fw_bwd, wn_fused_bwd_weight_floats(d.R, d.K, d.S) * (long)d.L);
     CARVE(X, (long)d.L * BRT);
     CARVE(G, (long)B * d.L * 2 * d.R * F);
     CARVE(Sg, (long)d.L * BRT);
@@ -320,6 +317,8 @@ static int make_ws(const Dims& d, int B, int T, Ws* w) {
     }
     CARVE(partial, pmax);
     CARVE(rs_partial, rmax);
+    w->red_scratch_floats = 1 << 20;
+    CARVE(red_scratch, w->red_scratch_floats);
     CARVE(loss_partial, wn_softmax_ce_nblocks(B, T) + 64);
 #undef CARVE
     w->total = o;
@@ -357,7 +356,7 @@ static int make_ctx(Ctx* c, const WnConfig* cfg, int B, int T, void* ws, size_t 
     c->T = T;
     c->ws = (float*)ws;
     c->st = (wn_stream_t)stream;
-    c->fused = wn_fused_supported(c->d.R, c->d.K) && !(flags & WN_FLAG_NO_FUSED);
+    c->fused = wn_fused_supported(c->d.R, c->d.K, c->d.S) && !(flags & WN_FLAG_NO_FUSED);
     return 0;
 }
 
@@ -423,10 +422,6 @@ static int pack_weights(const Ctx& c, const float* params) {
     WN_TRY(wn_cvec(&ca, c.st));
     WN_TRY(wn_sum_layers(params, y.skip0 + (long)d.S * d.R, y.ls_skip, d.L, d.S, ws + w.bskip, c.st));
     WN_TRY(wn_fill(ws + w.one, 1.0f, 64, c.st));
-    if (c.fused) {
-        WN_TRY(wn_fused_pack_weights(params, lb0 + y.o_dsig_w, lb0 + y.o_dtanh_w, lb0 + y.o_res_w, lstep, y.skip0, y.ls_skip,
-                                     d.L, d.R, d.K, d.S, ws + w.fw_fwd, ws + w.fw_bwd, c.st));
-    }
     return rt_check("pack_weights");
 }
 
@@ -471,9 +466,9 @@ extern "C" int wn_forward(const WnConfig* cfg, int B, int T, const float* params
         float* Zl = ws + w.Z + (long)l * BRT;
         const long lb = layer_base(y, d, l);
         if (c.fused) {
-            WN_TRY(wn_fused_resblock_fwd(ws + w.fw_fwd + (long)l * wn_fused_fwd_weight_floats(d.R, d.K), Xl, Gl, g_bstride, upw,
-                                         ws + w.cvec + (long)l * 2 * d.R, params + lb + y.o_res_b, Xn, Sl, Gtl, Zl, B, T, d.R,
-                                         d.K, dil, Ue, F, c.st));
+            WN_TRY(wn_fused_resblock_fwd(ws + w.wd_f + (long)l * d.K * d.R * 2 * d.R, ws + w.wres_f + (long)l * d.R * d.R,
+                                         ws + w.cvec + (long)l * 2 * d.R, params + lb + y.o_res_b, Xl, Gl, g_bstride, upw, Xn,
+                                         Sl, Gtl, Zl, B, T, d.K, dil, Ue, F, c.st));
         } else {
             // P = sum_tap W_tap . x[t-(K-1-tap)d]            (wavenet.py:527-528)
             WnGemmArgs g = wn_gemm_default();
@@ -576,6 +571,7 @@ static int dw_gemm(const Ctx& c, WnGemmArgs g, const DwOut& o) {
     r.out = o.out; r.m_seg = o.m_seg; r.n_seg = o.n_seg;
     r.m_seg_stride = o.m_seg_stride; r.m_stride = o.m_stride; r.n_seg_stride = o.n_seg_stride; r.n_stride = o.n_stride;
     r.scale = 1.0f; r.accumulate = 0; r.addend_m = o.addend_m; r.addend_scale_ptr = o.addend_scale_ptr;
+    r.scratch = c.ws + c.w.red_scratch; r.scratch_floats = c.w.red_scratch_floats;
     WN_TRY(wn_reduce(&r, c.st));
     if (o.rowsum_out) {
         WnReduceArgs q;
@@ -583,6 +579,7 @@ static int dw_gemm(const Ctx& c, WnGemmArgs g, const DwOut& o) {
         q.out = o.rowsum_out; q.m_seg = 0x7fffffff; q.n_seg = 0x7fffffff;
         q.m_seg_stride = 0; q.m_stride = 1; q.n_seg_stride = 0; q.n_stride = 0;
         q.scale = 1.0f; q.accumulate = 0; q.addend_m = nullptr; q.addend_scale_ptr = nullptr;
+        q.scratch = c.ws + c.w.red_scratch; q.scratch_floats = c.w.red_scratch_floats;
         WN_TRY(wn_reduce(&q, c.st));
     }
     return 0;
@@ -698,8 +695,8 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
         }
         if (c.fused) {
             // dZ = Wskip^T dSk (+ Wres^T dXn) -> gate' -> dP
-            WN_TRY(wn_fused_resblock_bwd_gate(ws + w.fw_bwd + (long)l * wn_fused_bwd_weight_floats(d.R, d.K, d.S), ws + w.dSk, dXn,
-                                              Sl, Gtl, dP, B, T, d.R, d.S, c.st));
+            WN_TRY(wn_fused_bwd_gate(params + y.skip0 + (long)l * y.ls_skip, params + lb + y.o_res_w, ws + w.dSk, dXn, Sl, Gtl,
+                                     dP, B, T, d.S, c.st));
         } else {
             {   // dZ = Wskip_l^T dSkip
                 WnGemmArgs g = wn_gemm_default();
@@ -767,7 +764,9 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
             }
             WN_TRY(dw_gemm(c, g, o));
         }
-        {   // dX_l = dX_{l+1} + sum_tap W_tap^T dP[t + (K-1-tap) d]
+        if (c.fused) {
+            WN_TRY(wn_fused_bwd_dx(ws + w.wd_b + (long)l * d.K * 2 * d.R * d.R, dP, dXn, dXcur, B, T, d.K, dil, c.st));
+        } else {  // dX_l = dX_{l+1} + sum_tap W_tap^T dP[t + (K-1-tap) d]
             WnGemmArgs g = wn_gemm_default();
             g.M = d.R; g.N = T; g.K = d.K * 2 * d.R;
             g.A = ws + w.wd_b + (long)l * d.K * 2 * d.R * d.R; g.lda = d.R;
@@ -807,6 +806,7 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
         r.out = grads + y.up_w; r.m_seg = 0x7fffffff; r.n_seg = 0x7fffffff;
         r.m_seg_stride = 0; r.m_stride = 0; r.n_seg_stride = 0; r.n_stride = 1;
         r.scale = 1.0f; r.accumulate = 0; r.addend_m = nullptr; r.addend_scale_ptr = nullptr;
+        r.scratch = ws + w.red_scratch; r.scratch_floats = w.red_scratch_floats;
         WN_TRY(wn_reduce(&r, c.st));
         // d b_up = sum_{l,o'} rowsum(Waux_l)[o'] * dc_l[o']
         WN_TRY(wn_dot(ws + w.rowsum_aux, ws + w.dc, (long)d.L * 2 * d.R, grads + y.up_b, 0, c.st));

@@ -22,6 +22,14 @@ typedef void* wn_stream_t;
 static inline f32x16 mfma32(float a, float b, f32x16 c) { return emu::mfma_f32_32x32x2f32(a, b, c); }
 #define WN_UNROLL
 #define WN_UNROLL_N(n)
+// buffer access: base (wave-uniform) + per-lane byte offset (voff) + wave-uniform byte offset (soff)
+struct wn_rsrc_t {
+    const char* base;
+};
+static inline wn_rsrc_t wn_make_buf(const void* p, unsigned) { return wn_rsrc_t{(const char*)p}; }
+static inline float wn_buf_load(wn_rsrc_t r, int voff, int soff) { return *(const float*)(r.base + (long)voff + (long)soff); }
+static inline void wn_buf_store(wn_rsrc_t r, float v, int voff, int soff) { *(float*)(r.base + (long)voff + (long)soff) = v; }
+#define WN_UNIFORM(x) (x)
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -32,6 +40,22 @@ typedef hipStream_t wn_stream_t;
 static __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+// Buffer access (CDNA "MUBUF"): the 128-bit resource descriptor and the scalar offset live in SGPRs,
+// only the per-lane byte offset needs a VGPR -> a tile's 32 channel rows cost ONE address VGPR
+// (voff = time) plus an SGPR per row (soff = channel * T * 4) instead of 32 64-bit address pairs.
+// Correctness never relies on the hardware range check: callers clamp voff to 0 for dead lanes.
+typedef __amdgpu_buffer_rsrc_t wn_rsrc_t;
+static __device__ __forceinline__ wn_rsrc_t wn_make_buf(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+static __device__ __forceinline__ float wn_buf_load(wn_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+static __device__ __forceinline__ void wn_buf_store(wn_rsrc_t r, float v, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voff, soff, 0);
+}
+// make a value the compiler can prove wave-uniform (it IS uniform: derived from the wave id)
+#define WN_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #define WN_UNROLL _Pragma("unroll")
 #define WN_PRAGMA(x) _Pragma(#x)
 #define WN_UNROLL_N(n) WN_PRAGMA(unroll n)

@@ -73,6 +73,8 @@ typedef struct WnReduceArgs {
     int accumulate;
     const float* addend_m;  // nullable, [M]
     const float* addend_scale_ptr;  // nullable device scalar multiplied onto addend_m
+    float* scratch;        // nullable: second-level buffer for two-level reductions
+    long scratch_floats;
 } WnReduceArgs;
 int wn_reduce(const WnReduceArgs* a, wn_stream_t st);
 

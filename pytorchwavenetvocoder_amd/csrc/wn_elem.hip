@@ -258,43 +258,97 @@ int wn_sum_layers(const float* params, long off, long ls, int L, int n, float* o
 }
 
 // ---------------------------------------------------------------------------------------------
+#define WN_AUX_FC 32        // frames per LDS chunk
+#define WN_AUX_MAXF 8192    // LDS floats per chunk (FC * U <= MAXF)
+#define WN_AUX_JMAX 4       // dw accumulators per thread: U <= 4 * 256
 __global__ __launch_bounds__(WN_TPB) void k_aux_bwd(const float* __restrict__ dP, const float* __restrict__ G, long g_bstride,
                                                     const float* __restrict__ upw, float* __restrict__ dG,
-                                                    float* __restrict__ dw_partial, int T, int R2, int U, int F) {
+                                                    float* __restrict__ dw_partial, int T, int R2, int U, int F, int fc) {
+    // One workgroup per (row o', batch b): the row of dP is streamed once, coalesced, through LDS
+    // in chunks of fc frames; both reductions (over frames for dw[j], over j for dG[f]) read LDS.
+    __shared__ float tile[WN_AUX_MAXF];
     const int o = blockIdx.x, b = blockIdx.y;
     const float* row = dP + ((long)b * R2 + o) * T;
     const float* grow = G + (long)b * g_bstride + (long)o * F;
-    // pass 1: dw[j] partial, lanes along j (coalesced)
-    for (int j = threadIdx.x; j < U; j += WN_TPB) {
-        float acc = 0.0f;
-        for (int f = 0; f < F; ++f) acc += row[(long)f * U + j] * grow[f];
-        dw_partial[((long)b * R2 + o) * U + j] = acc;
+    float accw[WN_AUX_JMAX];
+    WN_UNROLL
+    for (int i = 0; i < WN_AUX_JMAX; ++i) accw[i] = 0.0f;
+    const int fsub = threadIdx.x >> 3, jp = threadIdx.x & 7;  // pass 2: 32 frames x 8 partial sums
+    for (int f0 = 0; f0 < F; f0 += fc) {
+        const int nf = (F - f0 < fc) ? (F - f0) : fc;
+        const int n = nf * U;
+        const float* src = row + (long)f0 * U;
+        for (int i = threadIdx.x; i < n; i += WN_TPB) tile[i] = src[i];
+        __syncthreads();
+        // pass 1: dw[j] += sum_f dP[f*U + j] * G[f]
+        WN_UNROLL
+        for (int i = 0; i < WN_AUX_JMAX; ++i) {
+            const int j = threadIdx.x + i * WN_TPB;
+            if (j < U) {
+                float a = accw[i];
+                for (int f = 0; f < nf; ++f) a += tile[f * U + j] * grow[f0 + f];
+                accw[i] = a;
+            }
+        }
+        // pass 2: dG[f] = sum_j w[j] dP[f*U + j]   (8 lanes per frame, xor-shuffle tree)
+        for (int fb = 0; fb < nf; fb += 32) {
+            const int f = fb + fsub;
+            float a = 0.0f;
+            if (f < nf)
+                for (int j = jp; j < U; j += 8) a += upw[j] * tile[f * U + j];
+            a += __shfl_xor(a, 1, 64);
+            a += __shfl_xor(a, 2, 64);
+            a += __shfl_xor(a, 4, 64);
+            if (jp == 0 && f < nf) dG[((long)b * R2 + o) * F + f0 + f] = a;
+        }
+        __syncthreads();
     }
-    // pass 2: dG[f] = sum_j w[j] dP[fU+j]
-    for (int f = threadIdx.x; f < F; f += WN_TPB) {
-        float acc = 0.0f;
-        const float* p = row + (long)f * U;
-        for (int j = 0; j < U; ++j) acc += upw[j] * p[j];
-        dG[((long)b * R2 + o) * F + f] = acc;
+    WN_UNROLL
+    for (int i = 0; i < WN_AUX_JMAX; ++i) {
+        const int j = threadIdx.x + i * WN_TPB;
+        if (j < U) dw_partial[((long)b * R2 + o) * U + j] = accw[i];
     }
 }
 
 int wn_aux_bwd(const float* dP, const float* G, long g_bstride, const float* upw, float* dG, float* dw_partial, int B, int T,
                int R2, int U, int F, wn_stream_t st) {
-    WN_PROF("aux_bwd", 0.0, 0.0, st);
+    WN_PROF("aux_bwd", 0.0, (double)B * R2 * T * 4.0, st);
     if ((long)U * F != T) return 1;
+    if (U > WN_AUX_JMAX * WN_TPB || U > WN_AUX_MAXF) return 2;
+    int fc = WN_AUX_MAXF / U;
+    if (fc > WN_AUX_FC) fc = WN_AUX_FC;
+    if (fc < 1) fc = 1;
     WN_LAUNCH(k_aux_bwd, dim3((unsigned)R2, (unsigned)B), dim3(WN_TPB), 0, st, dP, G, g_bstride, upw, dG, dw_partial, T, R2, U,
-              F);
+              F, fc);
     return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WN_TPB) void k_reduce(WnReduceArgs a) {
+// 32 outputs x 8 z-lanes per workgroup; the 8 partial sums are combined in a fixed order, so the
+// result is deterministic.  grid.y > 1 = first level of a two-level reduction (raw sums of one
+// z-chunk each into scratch[chunk][MN]); the mapped/scaled write happens in the last level.
+__global__ __launch_bounds__(WN_TPB) void k_reduce(WnReduceArgs a, const float* __restrict__ src, int nz, int zchunk,
+                                                   float* __restrict__ raw_out) {
+    __shared__ float red[8][33];
     const long mn = (long)a.M * a.N;
-    const long i = (long)blockIdx.x * WN_TPB + threadIdx.x;
-    if (i >= mn) return;
+    const int il = threadIdx.x & 31, zg = threadIdx.x >> 5;
+    const long i = (long)blockIdx.x * 32 + il;
+    const int zbeg = blockIdx.y * zchunk;
+    int zend = zbeg + zchunk;
+    if (zend > nz) zend = nz;
     float s = 0.0f;
-    for (int z = 0; z < a.nz; ++z) s += a.partial[(long)z * mn + i];
+    if (i < mn)
+        for (int z = zbeg + zg; z < zend; z += 8) s += src[(long)z * mn + i];
+    red[zg][il] = s;
+    __syncthreads();
+    if (zg != 0 || i >= mn) return;
+    s = 0.0f;
+    WN_UNROLL
+    for (int q = 0; q < 8; ++q) s += red[q][il];
+    if (raw_out != nullptr) {
+        raw_out[(long)blockIdx.y * mn + i] = s;
+        return;
+    }
     s *= a.scale;
     const int m = (int)(i / a.N), n = (int)(i % a.N);
     if (a.addend_m != nullptr) {
@@ -308,10 +362,21 @@ __global__ __launch_bounds__(WN_TPB) void k_reduce(WnReduceArgs a) {
 }
 
 int wn_reduce(const WnReduceArgs* a, wn_stream_t st) {
-    WN_PROF("reduce_partials", 0.0, 0.0, st);
+    WN_PROF("reduce_partials", 0.0, (double)a->nz * a->M * a->N * 4.0, st);
     const long mn = (long)a->M * a->N;
     if (mn <= 0 || a->m_seg <= 0 || a->n_seg <= 0) return 1;
-    WN_LAUNCH(k_reduce, dim3((unsigned)((mn + WN_TPB - 1) / WN_TPB)), dim3(WN_TPB), 0, st, *a);
+    const unsigned gx = (unsigned)((mn + 31) / 32);
+    // two levels when there are few outputs but very many partials (keeps the machine busy)
+    if (a->scratch != nullptr && a->nz >= 512 && gx < 512) {
+        int zchunk = 128;
+        const int nchunk = (a->nz + zchunk - 1) / zchunk;
+        if ((long)nchunk * mn <= a->scratch_floats) {
+            WN_LAUNCH(k_reduce, dim3(gx, (unsigned)nchunk), dim3(WN_TPB), 0, st, *a, a->partial, a->nz, zchunk, a->scratch);
+            WN_LAUNCH(k_reduce, dim3(gx, 1), dim3(WN_TPB), 0, st, *a, (const float*)a->scratch, nchunk, nchunk, (float*)nullptr);
+            return 0;
+        }
+    }
+    WN_LAUNCH(k_reduce, dim3(gx, 1), dim3(WN_TPB), 0, st, *a, a->partial, a->nz, a->nz, (float*)nullptr);
     return 0;
 }
 

@@ -1,10 +1,363 @@
-// wn_fused.hip -- placeholder until the fused R=64 kernels land (generic path is complete without it).
+// wn_fused.hip -- fused residual-block kernels for n_resch == 64 on CDNA4 (gfx950).
+//
+// Design (MI355X-first, not a translation of the reference's conv calls):
+//   * time runs across the 32 columns of a v_mfma_f32_32x32x2_f32 tile, channels down its rows;
+//     activations stay channel-major (B, C, T), so every B-operand load and every store of a wave
+//     is 32 consecutive samples of one channel (128 B segments, two per instruction);
+//   * the whole weight set of one residual block (dilated taps 2R x K*R, res 1x1, biases) is staged
+//     ONCE per workgroup into LDS (80 KB of the 160 KB) and re-used by all tiles the persistent
+//     workgroup walks; the A operand is a conflict-free ds_read_b32 (32 consecutive floats);
+//   * one wave owns one 32-sample tile end to end: dilated conv (256 MFMAs) -> gate in registers
+//     -> the gate output z is fed STRAIGHT from the accumulator registers into the res 1x1 MFMAs
+//     (64 MFMAs): the contraction order k of an MFMA is free, so k-step (tile, r) takes channel
+//     kappa = 32*tile + (r&3) + 8*(r>>2) + 4*(lane>>5) -- exactly the channel accumulator
+//     register r of that lane already holds.  No LDS round trip, no shuffles;
+//   * the upsampled aux features are never materialised: the accumulators are initialised with
+//     w[t%U] * G[:, t/U] + c, G = Waux.h at FRAME rate (computed once per step for all layers);
+//   * 512 threads = 8 waves = 2 per SIMD so one wave's loads/gate math overlap the other's MFMAs.
+// The f32-input MFMA is an exact fp32 fma chain, so parity with the fp32 reference is kept.
 #include "wn_fused.h"
-int wn_fused_supported(int, int) { return 0; }
-long wn_fused_fwd_weight_floats(int, int) { return 0; }
-long wn_fused_bwd_weight_floats(int, int, int) { return 0; }
-int wn_fused_pack_weights(const float*, long, long, long, long, long, long, int, int, int, int, float*, float*, wn_stream_t) { return 0; }
-int wn_fused_resblock_fwd(const float*, const float*, const float*, long, const float*, const float*, const float*, float*,
-                          float*, float*, float*, int, int, int, int, int, int, int, wn_stream_t) { return 1; }
-int wn_fused_resblock_bwd_gate(const float*, const float*, const float*, const float*, const float*, float*, int, int, int, int,
-                               wn_stream_t) { return 1; }
+
+#include "wn_prof.h"
+
+#define WN_FT 512  // threads per workgroup (8 waves)
+
+// channel handled by k-step s (0..31 within a 64-channel group) for lane-half hi
+static __device__ __forceinline__ int kappa64(int s, int hi) {
+    return 32 * (s >> 4) + ((s & 15) & 3) + 8 * ((s & 15) >> 2) + 4 * hi;
+}
+
+int wn_fused_supported(int R, int K, int S) {
+    if (R != 64 || K < 1 || K > 3 || S % 32 != 0) return 0;
+    const long fwd = ((long)K * 64 * 128 + 64 * 64 + 192) * 4;
+    const long gate = ((long)S * 64 + 64 * 64) * 4;
+    const long dx = ((long)K * 128 * 64) * 4;
+    const long lim = 160 * 1024;
+    return fwd <= lim && gate <= lim && dx <= lim;
+}
+
+#ifndef WN_EMU
+template <class Kern>
+static int set_lds(Kern kern, size_t bytes) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return e == hipSuccess ? 0 : 1;
+}
+#else
+template <class Kern>
+static int set_lds(Kern, size_t) { return 0; }
+#endif
+
+static __device__ __forceinline__ void stage_copy(float* dst, const float* __restrict__ src, int n) {
+    // n is a multiple of 4; dst is 16-byte aligned; src usually is (checked, block-uniform branch)
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        for (int i = threadIdx.x; i < n / 4; i += WN_FT) d4[i] = s4[i];
+    } else {
+        for (int i = threadIdx.x; i < n; i += WN_FT) dst[i] = src[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct FwdArgs {
+    const float* wd_f;
+    const float* wres_f;
+    const float* cvec;
+    const float* res_bias;
+    const float* X;
+    const float* G;
+    long g_bstride;
+    const float* upw;
+    float* Xnext;
+    float* S;
+    float* Gt;
+    float* Z;
+    int B, T, K, dil, U, F;
+};
+
+__global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
+    WN_DYN_SMEM(smem_raw);
+    float* Wd = reinterpret_cast<float*>(smem_raw);  // [K*64][128]
+    float* Wr = Wd + a.K * 64 * 128;                 // [64][64]
+    float* cv = Wr + 64 * 64;                        // [128]
+    float* rb = cv + 128;                            // [64]
+    stage_copy(Wd, a.wd_f, a.K * 64 * 128);
+    stage_copy(Wr, a.wres_f, 64 * 64);
+    if (threadIdx.x < 128) cv[threadIdx.x] = a.cvec[threadIdx.x];
+    if (threadIdx.x < 64) rb[threadIdx.x] = a.res_bias[threadIdx.x];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int T = a.T;
+    const int T4 = T * 4;  // bytes per channel row
+    const int tiles_per_b = (T + 31) >> 5;
+    const int ntiles = a.B * tiles_per_b;
+    const unsigned slab = (unsigned)(64 * T4);
+    for (int tile_v = blockIdx.x * 8 + wave; tile_v < ntiles; tile_v += gridDim.x * 8) {
+        const int tile = WN_UNIFORM(tile_v);
+        const int b = tile / tiles_per_b;
+        const int t = (tile - b * tiles_per_b) * 32 + li;
+        const bool inb = t < T;
+        const int tc = inb ? t : T - 1;
+        const wn_rsrc_t Xr = wn_make_buf(a.X + (long)b * 64 * T, slab);
+        // per-lane byte offset of (channel 4*hi, time t); channel c(s)/row constants go to soffset
+        const int vcur = inb ? (4 * hi * T + t) * 4 : 0;
+
+        f32x16 acc[4];
+        WN_UNROLL
+        for (int q = 0; q < 4; ++q) acc[q] = f32x16_zero();
+
+        // dilated taps with history (shift > 0)
+        for (int tap = 0; tap + 1 < a.K; ++tap) {
+            const int ts = t - (a.K - 1 - tap) * a.dil;
+            const bool ok = inb && ts >= 0;
+            const int vt = ok ? (4 * hi * T + ts) * 4 : 0;
+            float xt[32];
+            WN_UNROLL
+            for (int s = 0; s < 32; ++s) {
+                const float v = wn_buf_load(Xr, vt, kappa64(s, 0) * T4);
+                xt[s] = ok ? v : 0.0f;
+            }
+            const float* Wt = Wd + tap * 64 * 128 + 4 * hi * 128 + li;
+            WN_UNROLL
+            for (int s = 0; s < 32; ++s) {
+                const float* wrow = Wt + kappa64(s, 0) * 128;
+                WN_UNROLL
+                for (int q = 0; q < 4; ++q) acc[q] = mfma32(wrow[32 * q], xt[s], acc[q]);
+            }
+        }
+        // current tap (shift 0); its registers are also the residual input, already in D layout
+        float xc[32];
+        {
+            WN_UNROLL
+            for (int s = 0; s < 32; ++s) {
+                const float v = wn_buf_load(Xr, vcur, kappa64(s, 0) * T4);
+                xc[s] = inb ? v : 0.0f;
+            }
+            const float* Wt = Wd + (a.K - 1) * 64 * 128 + 4 * hi * 128 + li;
+            WN_UNROLL
+            for (int s = 0; s < 32; ++s) {
+                const float* wrow = Wt + kappa64(s, 0) * 128;
+                WN_UNROLL
+                for (int q = 0; q < 4; ++q) acc[q] = mfma32(wrow[32 * q], xc[s], acc[q]);
+            }
+        }
+        // gate (reference wavenet.py:529-532): P = conv + w[j]*G[row][f] + c[row]; saved for backward
+        const int fr = tc / a.U;
+        const float upw_j = a.upw[tc - fr * a.U];
+        const int F4 = a.F * 4;
+        const wn_rsrc_t Gr = wn_make_buf(a.G + (long)b * a.g_bstride, (unsigned)(128 * F4));
+        const int vg = (4 * hi * a.F + fr) * 4;
+        const wn_rsrc_t Sr = wn_make_buf(a.S + (long)b * 64 * T, slab);
+        const wn_rsrc_t Gtr = wn_make_buf(a.Gt + (long)b * 64 * T, slab);
+        const wn_rsrc_t Zr = wn_make_buf(a.Z + (long)b * 64 * T, slab);
+        const float* cvl = cv + 4 * hi;
+        f32x16 z[2];
+        WN_UNROLL
+        for (int q = 0; q < 2; ++q) {
+            WN_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int row0 = 32 * q + mfma32_row(r, 0);  // + 4*hi is in the per-lane offsets
+                const float pa = acc[q][r] + (upw_j * wn_buf_load(Gr, vg, row0 * F4) + cvl[row0]);
+                const float pg = acc[q + 2][r] + (upw_j * wn_buf_load(Gr, vg, (row0 + 64) * F4) + cvl[row0 + 64]);
+                const float s = wn_sigmoid(pa);
+                const float g = wn_tanh(pg);
+                const float zz = s * g;
+                z[q][r] = zz;
+                if (inb) {
+                    wn_buf_store(Sr, s, vcur, row0 * T4);
+                    wn_buf_store(Gtr, g, vcur, row0 * T4);
+                    wn_buf_store(Zr, zz, vcur, row0 * T4);
+                }
+            }
+        }
+        // res 1x1 + residual; z is consumed straight from the accumulator registers
+        if (a.Xnext != nullptr) {
+            const float* rbl = rb + 4 * hi;
+            f32x16 racc[2];
+            WN_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) racc[q][r] = xc[16 * q + r] + rbl[32 * q + mfma32_row(r, 0)];
+            }
+            const float* Wrl = Wr + 4 * hi * 64 + li;
+            WN_UNROLL
+            for (int s = 0; s < 32; ++s) {
+                const float* wrow = Wrl + kappa64(s, 0) * 64;
+                const float bz = z[s >> 4][s & 15];
+                WN_UNROLL
+                for (int q = 0; q < 2; ++q) racc[q] = mfma32(wrow[32 * q], bz, racc[q]);
+            }
+            if (inb) {
+                const wn_rsrc_t Xn = wn_make_buf(a.Xnext + (long)b * 64 * T, slab);
+                WN_UNROLL
+                for (int q = 0; q < 2; ++q) {
+                    WN_UNROLL
+                    for (int r = 0; r < 16; ++r) wn_buf_store(Xn, racc[q][r], vcur, (32 * q + mfma32_row(r, 0)) * T4);
+                }
+            }
+        }
+    }
+}
+
+int wn_fused_resblock_fwd(const float* wd_f, const float* wres_f, const float* cvec, const float* res_bias, const float* X,
+                          const float* G, long g_bstride, const float* upw, float* Xnext, float* S, float* Gt, float* Z, int B,
+                          int T, int K, int dilation, int U, int F, wn_stream_t st) {
+    WN_PROF("fused_resblock_fwd", 2.0 * (double)B * T * (K * 64.0 * 128.0 + (Xnext ? 64.0 * 64.0 : 0.0)), 0.0, st);
+    FwdArgs a;
+    a.wd_f = wd_f; a.wres_f = wres_f; a.cvec = cvec; a.res_bias = res_bias;
+    a.X = X; a.G = G; a.g_bstride = g_bstride; a.upw = upw;
+    a.Xnext = Xnext; a.S = S; a.Gt = Gt; a.Z = Z;
+    a.B = B; a.T = T; a.K = K; a.dil = dilation; a.U = U; a.F = F;
+    const size_t lds = ((size_t)K * 64 * 128 + 64 * 64 + 192) * sizeof(float);
+    if (set_lds(k_resblock_fwd, lds)) return 1;
+    const long ntiles = (long)B * ((T + 31) / 32);
+    long nblk = (ntiles + 7) / 8;
+    if (nblk > 256) nblk = 256;
+    WN_LAUNCH(k_resblock_fwd, dim3((unsigned)nblk), dim3(WN_FT), lds, st, a);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv64: out[64][t] = sum over segments, channels k:  W_seg[k][0..63] * src_seg[k][t - shift_seg]
+// ---------------------------------------------------------------------------------------------
+struct ConvSeg {
+    const float* src;  // (B, nch, T)
+    const float* w;    // [nch][64] (global); staged to LDS at float offset woff
+    int nch;           // multiple of 32
+    int shift;
+    int woff;
+};
+struct ConvArgs {
+    ConvSeg seg[3];
+    int nseg;
+    int wfloats;  // total LDS floats
+    int B, T;
+    const float* S;      // MODE 0
+    const float* Gt;     // MODE 0
+    const float* resid;  // MODE 1 (nullable)
+    float* out;          // MODE 0: dP (B,128,T) ; MODE 1: dX (B,64,T)
+};
+
+template <int MODE>
+__global__ __launch_bounds__(WN_FT) void k_conv64(ConvArgs a) {
+    WN_DYN_SMEM(smem_raw);
+    float* W = reinterpret_cast<float*>(smem_raw);
+    for (int sg = 0; sg < a.nseg; ++sg) stage_copy(W + a.seg[sg].woff, a.seg[sg].w, a.seg[sg].nch * 64);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int T = a.T;
+    const int T4 = T * 4;
+    const int tiles_per_b = (T + 31) >> 5;
+    const int ntiles = a.B * tiles_per_b;
+    for (int tile_v = blockIdx.x * 8 + wave; tile_v < ntiles; tile_v += gridDim.x * 8) {
+        const int tile = WN_UNIFORM(tile_v);
+        const int b = tile / tiles_per_b;
+        const int t = (tile - b * tiles_per_b) * 32 + li;
+        const bool inb = t < T;
+        f32x16 acc[2];
+        acc[0] = f32x16_zero();
+        acc[1] = f32x16_zero();
+        for (int sg = 0; sg < a.nseg; ++sg) {
+            const ConvSeg& g = a.seg[sg];
+            const int ts = t - g.shift;
+            const bool ok = inb && ts >= 0 && ts < T;
+            const wn_rsrc_t Sr = wn_make_buf(g.src + (long)b * g.nch * T, (unsigned)(g.nch * T4));
+            const int vt = ok ? (hi * T + ts) * 4 : 0;
+            const float* Wl = W + g.woff + hi * 64 + li;
+            for (int c0 = 0; c0 < g.nch; c0 += 32) {
+                float xv[16];
+                WN_UNROLL
+                for (int s = 0; s < 16; ++s) {
+                    const float v = wn_buf_load(Sr, vt, (c0 + 2 * s) * T4);
+                    xv[s] = ok ? v : 0.0f;
+                }
+                WN_UNROLL
+                for (int s = 0; s < 16; ++s) {
+                    const float* wrow = Wl + (c0 + 2 * s) * 64;
+                    acc[0] = mfma32(wrow[0], xv[s], acc[0]);
+                    acc[1] = mfma32(wrow[32], xv[s], acc[1]);
+                }
+            }
+        }
+        if (!inb) continue;
+        const int vcur = (4 * hi * T + t) * 4;
+        if (MODE == 0) {
+            // gate backward: dP = [dZ*g*s*(1-s) ; dZ*s*(1-g^2)]
+            const wn_rsrc_t Sr = wn_make_buf(a.S + (long)b * 64 * T, (unsigned)(64 * T4));
+            const wn_rsrc_t Gr = wn_make_buf(a.Gt + (long)b * 64 * T, (unsigned)(64 * T4));
+            const wn_rsrc_t Or = wn_make_buf(a.out + (long)b * 128 * T, (unsigned)(128 * T4));
+            WN_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int so = (32 * q + mfma32_row(r, 0)) * T4;
+                    const float s = wn_buf_load(Sr, vcur, so), g = wn_buf_load(Gr, vcur, so), dz = acc[q][r];
+                    wn_buf_store(Or, dz * g * (s * (1.0f - s)), vcur, so);
+                    wn_buf_store(Or, dz * s * (1.0f - g * g), vcur, so + 64 * T4);
+                }
+            }
+        } else {
+            const wn_rsrc_t Or = wn_make_buf(a.out + (long)b * 64 * T, (unsigned)(64 * T4));
+            const wn_rsrc_t Rr = wn_make_buf((a.resid ? a.resid : a.out) + (long)b * 64 * T, (unsigned)(64 * T4));
+            WN_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int so = (32 * q + mfma32_row(r, 0)) * T4;
+                    float v = acc[q][r];
+                    if (a.resid != nullptr) v += wn_buf_load(Rr, vcur, so);
+                    wn_buf_store(Or, v, vcur, so);
+                }
+            }
+        }
+    }
+}
+
+template <int MODE>
+static int launch_conv64(const ConvArgs& a, wn_stream_t st) {
+    const size_t lds = (size_t)a.wfloats * sizeof(float);
+    if (set_lds(k_conv64<MODE>, lds)) return 1;
+    const long ntiles = (long)a.B * ((a.T + 31) / 32);
+    long nblk = (ntiles + 7) / 8;
+    if (nblk > 256) nblk = 256;
+    WN_LAUNCH((k_conv64<MODE>), dim3((unsigned)nblk), dim3(WN_FT), lds, st, a);
+    return 0;
+}
+
+int wn_fused_bwd_gate(const float* wskip, const float* wres, const float* dSk, const float* dXn, const float* S, const float* Gt,
+                      float* dP, int B, int T, int Sch, wn_stream_t st) {
+    WN_PROF("fused_bwd_gate", 2.0 * (double)B * T * 64.0 * (Sch + (dXn ? 64.0 : 0.0)), 0.0, st);
+    ConvArgs a;
+    a.nseg = 1;
+    a.seg[0].src = dSk; a.seg[0].w = wskip; a.seg[0].nch = Sch; a.seg[0].shift = 0; a.seg[0].woff = 0;
+    a.wfloats = Sch * 64;
+    if (dXn) {
+        a.seg[1].src = dXn; a.seg[1].w = wres; a.seg[1].nch = 64; a.seg[1].shift = 0; a.seg[1].woff = Sch * 64;
+        a.nseg = 2;
+        a.wfloats += 64 * 64;
+    }
+    a.B = B; a.T = T; a.S = S; a.Gt = Gt; a.resid = nullptr; a.out = dP;
+    return launch_conv64<0>(a, st);
+}
+
+int wn_fused_bwd_dx(const float* wd_b, const float* dP, const float* dXn, float* dX, int B, int T, int K, int dilation,
+                    wn_stream_t st) {
+    WN_PROF("fused_bwd_dx", 2.0 * (double)B * T * 64.0 * K * 128.0, 0.0, st);
+    if (K > 3) return 1;
+    ConvArgs a;
+    a.nseg = K;
+    for (int tap = 0; tap < K; ++tap) {
+        a.seg[tap].src = dP;
+        a.seg[tap].w = wd_b + (long)tap * 128 * 64;
+        a.seg[tap].nch = 128;
+        a.seg[tap].shift = -(K - 1 - tap) * dilation;
+        a.seg[tap].woff = tap * 128 * 64;
+    }
+    a.wfloats = K * 128 * 64;
+    a.B = B; a.T = T; a.S = nullptr; a.Gt = nullptr; a.resid = dXn; a.out = dX;
+    return launch_conv64<1>(a, st);
+}

@@ -71,44 +71,119 @@ __global__ __launch_bounds__(WN_GEMM_THREADS) void wn_gemm_kernel(WnGemmArgs g) 
     }
     float rowsum = 0.0f;
 
-    auto fetch = [&](int k0) {
-        WN_UNROLL
-        for (int e = 0; e < GA::NE; ++e) {
-            int kk, mn;
-            GA::coord(e, tid, kk, mn);
-            const int k = k0 + kk, m = m0 + mn;
-            const bool ok = (k < kend) && (m < g.M);
-            const long addr = KMAJ ? ((long)m * g.lda + k) : ((long)k * g.lda + m);
-            ra[e] = ok ? Az[addr] : 0.0f;
-        }
-        WN_UNROLL
-        for (int e = 0; e < GB::NE; ++e) {
-            int kk, mn;
-            GB::coord(e, tid, kk, mn);
-            const int k = k0 + kk, n = n0 + mn;
-            bool ok = (k < kend) && (n < g.N);
-            const int r = KMAJ ? n : k;
-            const int c = KMAJ ? k : n;
-            int seg = 0, rr = r;
+    // ---- operand loaders -----------------------------------------------------------------
+    // All per-row work (segment lookup = integer division, shifts, 64-bit row offsets) is hoisted
+    // out of the per-element path: the loaders are VALU work that competes with the MFMA issue of
+    // the co-resident waves.
+    //   k-minor tiles: a thread owns ONE column (m or n) and walks the tile's k rows; when segments
+    //     are BK-aligned a whole tile lies in one segment (block-uniform scalar math);
+    //   k-major tiles: a thread owns ONE k column and walks rows that never change across k-tiles;
+    //     their (offset, shift, index) are computed once per block into an LDS table.
+    __shared__ long b_rowoff[KMAJ ? BN : 1];
+    __shared__ int b_rowshift[KMAJ ? BN : 1];
+    __shared__ int b_rowrr[KMAJ ? BN : 1];
+    if (KMAJ) {
+        for (int i = tid; i < BN; i += WN_GEMM_THREADS) {
+            const int n = n0 + i;
+            int seg = 0, rr = n;
             if (!one_seg) {
-                seg = r / g.b_seg_len;
-                rr = r - seg * g.b_seg_len;
+                seg = n / g.b_seg_len;
+                rr = n - seg * g.b_seg_len;
             }
-            const int cc = c - (g.b_shift0 + seg * g.b_shift_step);
-            ok = ok && (cc >= 0) && (cc < g.b_clen);
-            float v = 0.0f;
-            if (g.b_index != nullptr) {
-                if (ok) {
-                    long long q = g.b_index[(long)b * g.b_index_zstride + cc] % g.b_index_mod;
-                    if (q < 0) q += g.b_index_mod;
-                    v = ((int)q == rr) ? 1.0f : 0.0f;
+            b_rowoff[i] = (n < g.N) ? ((long)seg * g.b_seg_stride + (long)rr * g.ldb) : -1;
+            b_rowshift[i] = g.b_shift0 + seg * g.b_shift_step;
+            b_rowrr[i] = rr;
+        }
+        __syncthreads();
+    }
+    const bool seg_aligned = one_seg || (g.b_seg_len % WN_BK == 0 && kbeg % WN_BK == 0);
+    constexpr int A_RPP = KMAJ ? (WN_GEMM_THREADS / WN_BK) : (WN_GEMM_THREADS / BM);  // rows per pass
+    constexpr int B_RPP = KMAJ ? (WN_GEMM_THREADS / WN_BK) : (WN_GEMM_THREADS / BN);
+    const int a_col = KMAJ ? (tid % WN_BK) : (tid % BM);  // fixed column of this thread
+    const int a_row0 = KMAJ ? (tid / WN_BK) : (tid / BM);
+    const int b_col = KMAJ ? (tid % WN_BK) : (tid % BN);
+    const int b_row0 = KMAJ ? (tid / WN_BK) : (tid / BN);
+
+    auto fetch = [&](int k0) {
+        if (KMAJ) {
+            // A[m][k]: column = k (fixed), rows = m
+            const int k = k0 + a_col;
+            const bool kok = k < kend;
+            const float* pa = Az + (long)(m0 + a_row0) * g.lda + k;
+            const long astep = (long)A_RPP * g.lda;
+            WN_UNROLL
+            for (int e = 0; e < GA::NE; ++e) {
+                const bool ok = kok && (m0 + a_row0 + e * A_RPP) < g.M;
+                ra[e] = ok ? *pa : 0.0f;
+                pa += astep;
+            }
+            // B[n][k]: column = k (fixed), rows = n (table)
+            const int kb = k0 + b_col;
+            const bool kbok = kb < kend;
+            WN_UNROLL
+            for (int e = 0; e < GB::NE; ++e) {
+                const int i = b_row0 + e * B_RPP;
+                const long off = b_rowoff[i];
+                const int cc = kb - b_rowshift[i];
+                const bool ok = kbok && off >= 0 && cc >= 0 && cc < g.b_clen;
+                float v = 0.0f;
+                if (g.b_index != nullptr) {
+                    if (ok) {
+                        long long q = g.b_index[(long)b * g.b_index_zstride + cc] % g.b_index_mod;
+                        if (q < 0) q += g.b_index_mod;
+                        v = ((int)q == b_rowrr[i]) ? 1.0f : 0.0f;
+                    }
+                } else {
+                    v = ok ? Bz[off + cc] : 0.0f;
+                    if (g.b_relu) v = fmaxf(v, 0.0f);
+                }
+                rb[e] = v;
+            }
+        } else {
+            // A[k][m]: column = m (fixed), rows = k
+            const bool mok = (m0 + a_col) < g.M;
+            const float* pa = Az + (long)(k0 + a_row0) * g.lda + (m0 + a_col);
+            const long astep = (long)A_RPP * g.lda;
+            WN_UNROLL
+            for (int e = 0; e < GA::NE; ++e) {
+                const bool ok = mok && (k0 + a_row0 + e * A_RPP) < kend;
+                ra[e] = ok ? *pa : 0.0f;
+                pa += astep;
+            }
+            // B[k][n]: column = n (fixed), rows = k
+            const int n = n0 + b_col;
+            const bool nok = n < g.N;
+            if (seg_aligned) {
+                int seg = 0, rr0 = k0;
+                if (!one_seg) {
+                    seg = k0 / g.b_seg_len;
+                    rr0 = k0 - seg * g.b_seg_len;
+                }
+                const int cc = n - (g.b_shift0 + seg * g.b_shift_step);
+                const bool cok = nok && cc >= 0 && cc < g.b_clen;
+                const float* pb = Bz + (long)seg * g.b_seg_stride + (long)(rr0 + b_row0) * g.ldb + cc;
+                const long bstep = (long)B_RPP * g.ldb;
+                WN_UNROLL
+                for (int e = 0; e < GB::NE; ++e) {
+                    const bool ok = cok && (k0 + b_row0 + e * B_RPP) < kend;
+                    float v = ok ? *pb : 0.0f;
+                    if (g.b_relu) v = fmaxf(v, 0.0f);
+                    rb[e] = v;
+                    pb += bstep;
                 }
             } else {
-                const long addr = (long)seg * g.b_seg_stride + (long)rr * g.ldb + cc;
-                v = ok ? Bz[addr] : 0.0f;
-                if (g.b_relu) v = fmaxf(v, 0.0f);
+                WN_UNROLL
+                for (int e = 0; e < GB::NE; ++e) {
+                    const int k = k0 + b_row0 + e * B_RPP;
+                    const int seg = k / g.b_seg_len;
+                    const int rr = k - seg * g.b_seg_len;
+                    const int cc = n - (g.b_shift0 + seg * g.b_shift_step);
+                    const bool ok = nok && k < kend && cc >= 0 && cc < g.b_clen;
+                    float v = ok ? Bz[(long)seg * g.b_seg_stride + (long)rr * g.ldb + cc] : 0.0f;
+                    if (g.b_relu) v = fmaxf(v, 0.0f);
+                    rb[e] = v;
+                }
             }
-            rb[e] = v;
         }
     };
 

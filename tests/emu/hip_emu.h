@@ -307,3 +307,6 @@ inline unsigned atomicAdd(unsigned* p, unsigned v) {
     return o;
 }
 inline float __frcp_rn(float x) { return 1.0f / x; }
+struct float4 {
+    float x, y, z, w;
+};
