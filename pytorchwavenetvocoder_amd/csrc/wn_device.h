@@ -30,6 +30,7 @@ static inline wn_rsrc_t wn_make_buf(const void* p, unsigned) { return wn_rsrc_t{
 static inline float wn_buf_load(wn_rsrc_t r, int voff, int soff) { return *(const float*)(r.base + (long)voff + (long)soff); }
 static inline void wn_buf_store(wn_rsrc_t r, float v, int voff, int soff) { *(float*)(r.base + (long)voff + (long)soff) = v; }
 #define WN_UNIFORM(x) (x)
+#define WN_SCHED_BARRIER()
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -56,6 +57,8 @@ static __device__ __forceinline__ void wn_buf_store(wn_rsrc_t r, float v, int vo
 }
 // make a value the compiler can prove wave-uniform (it IS uniform: derived from the wave id)
 #define WN_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+// scheduling fence: hipcc may not move instructions across it (pins software-pipeline issue order)
+#define WN_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #define WN_UNROLL _Pragma("unroll")
 #define WN_PRAGMA(x) _Pragma(#x)
 #define WN_UNROLL_N(n) WN_PRAGMA(unroll n)
@@ -71,10 +74,28 @@ static __device__ __forceinline__ f32x16 f32x16_zero() {
     return z;
 }
 
-// Accurate logistic / tanh built on expf (ocml expf is ~1 ulp).  tanh via expm1-free form:
-// tanh(x) = sign(x) * (1 - 2/(exp(2|x|)+1)).
-static __device__ __forceinline__ float wn_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
-static __device__ __forceinline__ float wn_tanh(float x) { return tanhf(x); }
+// Logistic / tanh on the hardware transcendental units: v_exp_f32 (2^x) and v_rcp_f32 are 1-ulp
+// instructions, so sigmoid = rcp(1 + 2^(-x log2 e)) and tanh = sign(x) (1 - e)/(1 + e) with
+// e = 2^(-2|x| log2 e) carry an ABSOLUTE error of a few 1e-7 -- far inside the 1e-4 parity gate --
+// at ~1/4 of the instruction count of ocml expf/tanhf + IEEE division (the gate math is the
+// VALU-heavy part of the fused residual-block kernels).
+#ifdef WN_EMU
+static inline float wn_exp2(float x) { return exp2f(x); }
+static inline float wn_rcp(float x) { return 1.0f / x; }
+#else
+static __device__ __forceinline__ float wn_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+static __device__ __forceinline__ float wn_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
+static __device__ __forceinline__ float wn_sigmoid(float x) {
+    const float xc = fminf(fmaxf(x, -80.0f), 80.0f);  // keeps 2^(...) finite; sigmoid(+-80) is 1/0 in fp32
+    return wn_rcp(1.0f + wn_exp2(-1.4426950408889634f * xc));
+}
+static __device__ __forceinline__ float wn_tanh(float x) {
+    const float ax = fminf(fabsf(x), 40.0f);
+    const float e = wn_exp2(-2.8853900817779268f * ax);
+    const float t = (1.0f - e) * wn_rcp(1.0f + e);
+    return copysignf(t, x);
+}
 
 static __device__ __forceinline__ float wave_reduce_sum(float v) {
     WN_UNROLL

@@ -12,9 +12,15 @@
 //     (64 MFMAs): the contraction order k of an MFMA is free, so k-step (tile, r) takes channel
 //     kappa = 32*tile + (r&3) + 8*(r>>2) + 4*(lane>>5) -- exactly the channel accumulator
 //     register r of that lane already holds.  No LDS round trip, no shuffles;
-//   * the upsampled aux features are never materialised: the accumulators are initialised with
-//     w[t%U] * G[:, t/U] + c, G = Waux.h at FRAME rate (computed once per step for all layers);
-//   * 512 threads = 8 waves = 2 per SIMD so one wave's loads/gate math overlap the other's MFMAs.
+//   * the upsampled aux features are never materialised: P = conv + w[t%U] * G[:, t/U] + c with
+//     G = Waux.h at FRAME rate (computed once per step for all layers);
+//   * all global traffic goes through buffer instructions: one per-lane byte offset (time) in a
+//     VGPR, the channel row offset in an SGPR -> no per-access 64-bit address registers;
+//   * memory latency is hidden by explicit software pipelining, not by occupancy (80 KB of LDS
+//     weights allow 2 waves per SIMD): the operands of the NEXT tile are issued before the res
+//     MFMAs of the current one, the aux/gate inputs before the current-tap MFMAs, and
+//     sched_barrier pins that issue order (hipcc otherwise sinks every load to its first use and
+//     waits vmcnt(0) on each, and both waves of a SIMD stall in lock step).
 // The f32-input MFMA is an exact fp32 fma chain, so parity with the fp32 reference is kept.
 #include "wn_fused.h"
 
@@ -72,16 +78,17 @@ struct FwdArgs {
     float* S;
     float* Gt;
     float* Z;
-    int B, T, K, dil, U, F;
+    int B, T, dil, U, F;
 };
 
+template <int K>
 __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
     WN_DYN_SMEM(smem_raw);
     float* Wd = reinterpret_cast<float*>(smem_raw);  // [K*64][128]
-    float* Wr = Wd + a.K * 64 * 128;                 // [64][64]
+    float* Wr = Wd + K * 64 * 128;                   // [64][64]
     float* cv = Wr + 64 * 64;                        // [128]
     float* rb = cv + 128;                            // [64]
-    stage_copy(Wd, a.wd_f, a.K * 64 * 128);
+    stage_copy(Wd, a.wd_f, K * 64 * 128);
     stage_copy(Wr, a.wres_f, 64 * 64);
     if (threadIdx.x < 128) cv[threadIdx.x] = a.cvec[threadIdx.x];
     if (threadIdx.x < 64) rb[threadIdx.x] = a.res_bias[threadIdx.x];
@@ -91,64 +98,100 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
     const int li = lane & 31, hi = lane >> 5;
     const int T = a.T;
     const int T4 = T * 4;  // bytes per channel row
+    const int F4 = a.F * 4;
     const int tiles_per_b = (T + 31) >> 5;
     const int ntiles = a.B * tiles_per_b;
     const unsigned slab = (unsigned)(64 * T4);
-    for (int tile_v = blockIdx.x * 8 + wave; tile_v < ntiles; tile_v += gridDim.x * 8) {
+    const int step = gridDim.x * 8;
+    constexpr int KH = (K > 1) ? (K - 1) : 1;  // history taps (shift > 0)
+
+    // Software pipeline (per wave, per 32-sample tile):
+    //   history-tap operands xh : issued before the res MFMAs of the PREVIOUS tile (cross-tile prefetch)
+    //   current-tap operands xc : issued at tile start, land under the history-tap MFMAs
+    //   aux/gate inputs         : first half issued before the current-tap MFMAs, second half
+    //                             before the gate math of the first half
+    // Operands are consumed in place (zero history / dead lanes selected at use).
+    float xh[KH][32];
+    bool okh[KH];
+    auto issue_hist = [&](int tl_v) {
+        const int tl = WN_UNIFORM(tl_v);
+        const int b = tl / tiles_per_b;
+        const int t = (tl - b * tiles_per_b) * 32 + li;
+        const wn_rsrc_t Xr = wn_make_buf(a.X + (long)b * 64 * T, slab);
+        WN_UNROLL
+        for (int tap = 0; tap + 1 < K; ++tap) {
+            const int ts = t - (K - 1 - tap) * a.dil;
+            const bool ok = (t < T) && ts >= 0;
+            okh[tap] = ok;
+            const int vt = ok ? (4 * hi * T + ts) * 4 : 0;  // dead lanes read a valid dummy address
+            WN_UNROLL
+            for (int s = 0; s < 32; ++s) xh[tap][s] = wn_buf_load(Xr, vt, kappa64(s, 0) * T4);
+        }
+    };
+
+    int tile_v = blockIdx.x * 8 + wave;
+    if (K > 1 && tile_v < ntiles) issue_hist(tile_v);
+    while (tile_v < ntiles) {
         const int tile = WN_UNIFORM(tile_v);
         const int b = tile / tiles_per_b;
         const int t = (tile - b * tiles_per_b) * 32 + li;
         const bool inb = t < T;
         const int tc = inb ? t : T - 1;
-        const wn_rsrc_t Xr = wn_make_buf(a.X + (long)b * 64 * T, slab);
-        // per-lane byte offset of (channel 4*hi, time t); channel c(s)/row constants go to soffset
         const int vcur = inb ? (4 * hi * T + t) * 4 : 0;
 
+        // current tap (shift 0): raw loads now, consumed after the history taps
+        float xc[32];
+        {
+            const wn_rsrc_t Xr = wn_make_buf(a.X + (long)b * 64 * T, slab);
+            WN_UNROLL
+            for (int s = 0; s < 32; ++s) xc[s] = wn_buf_load(Xr, vcur, kappa64(s, 0) * T4);
+        }
+        WN_SCHED_BARRIER();
         f32x16 acc[4];
         WN_UNROLL
         for (int q = 0; q < 4; ++q) acc[q] = f32x16_zero();
-
         // dilated taps with history (shift > 0)
-        for (int tap = 0; tap + 1 < a.K; ++tap) {
-            const int ts = t - (a.K - 1 - tap) * a.dil;
-            const bool ok = inb && ts >= 0;
-            const int vt = ok ? (4 * hi * T + ts) * 4 : 0;
-            float xt[32];
-            WN_UNROLL
-            for (int s = 0; s < 32; ++s) {
-                const float v = wn_buf_load(Xr, vt, kappa64(s, 0) * T4);
-                xt[s] = ok ? v : 0.0f;
-            }
+        WN_UNROLL
+        for (int tap = 0; tap + 1 < K; ++tap) {
             const float* Wt = Wd + tap * 64 * 128 + 4 * hi * 128 + li;
             WN_UNROLL
             for (int s = 0; s < 32; ++s) {
                 const float* wrow = Wt + kappa64(s, 0) * 128;
+                const float xv = okh[tap] ? xh[tap][s] : 0.0f;
                 WN_UNROLL
-                for (int q = 0; q < 4; ++q) acc[q] = mfma32(wrow[32 * q], xt[s], acc[q]);
+                for (int q = 0; q < 4; ++q) acc[q] = mfma32(wrow[32 * q], xv, acc[q]);
             }
         }
-        // current tap (shift 0); its registers are also the residual input, already in D layout
-        float xc[32];
+        // aux / gate inputs (frame rate, L2 resident), first 32 gate channels
+        const int fr = tc / a.U;
+        const float upw_j = a.upw[tc - fr * a.U];
+        const wn_rsrc_t Gr = wn_make_buf(a.G + (long)b * a.g_bstride, (unsigned)(128 * F4));
+        const int vg = (4 * hi * a.F + fr) * 4;
+        float ga[2][16], gg[2][16];
+        WN_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            ga[0][r] = wn_buf_load(Gr, vg, mfma32_row(r, 0) * F4);
+            gg[0][r] = wn_buf_load(Gr, vg, (mfma32_row(r, 0) + 64) * F4);
+        }
+        WN_SCHED_BARRIER();
+        // current tap; xc is also the residual input, already in D layout
         {
-            WN_UNROLL
-            for (int s = 0; s < 32; ++s) {
-                const float v = wn_buf_load(Xr, vcur, kappa64(s, 0) * T4);
-                xc[s] = inb ? v : 0.0f;
-            }
-            const float* Wt = Wd + (a.K - 1) * 64 * 128 + 4 * hi * 128 + li;
+            const float* Wt = Wd + (K - 1) * 64 * 128 + 4 * hi * 128 + li;
             WN_UNROLL
             for (int s = 0; s < 32; ++s) {
                 const float* wrow = Wt + kappa64(s, 0) * 128;
+                const float xv = inb ? xc[s] : 0.0f;
                 WN_UNROLL
-                for (int q = 0; q < 4; ++q) acc[q] = mfma32(wrow[32 * q], xc[s], acc[q]);
+                for (int q = 0; q < 4; ++q) acc[q] = mfma32(wrow[32 * q], xv, acc[q]);
             }
         }
+        WN_SCHED_BARRIER();
+        WN_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            ga[1][r] = wn_buf_load(Gr, vg, (32 + mfma32_row(r, 0)) * F4);
+            gg[1][r] = wn_buf_load(Gr, vg, (96 + mfma32_row(r, 0)) * F4);
+        }
         // gate (reference wavenet.py:529-532): P = conv + w[j]*G[row][f] + c[row]; saved for backward
-        const int fr = tc / a.U;
-        const float upw_j = a.upw[tc - fr * a.U];
-        const int F4 = a.F * 4;
-        const wn_rsrc_t Gr = wn_make_buf(a.G + (long)b * a.g_bstride, (unsigned)(128 * F4));
-        const int vg = (4 * hi * a.F + fr) * 4;
         const wn_rsrc_t Sr = wn_make_buf(a.S + (long)b * 64 * T, slab);
         const wn_rsrc_t Gtr = wn_make_buf(a.Gt + (long)b * 64 * T, slab);
         const wn_rsrc_t Zr = wn_make_buf(a.Z + (long)b * 64 * T, slab);
@@ -159,8 +202,8 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
             WN_UNROLL
             for (int r = 0; r < 16; ++r) {
                 const int row0 = 32 * q + mfma32_row(r, 0);  // + 4*hi is in the per-lane offsets
-                const float pa = acc[q][r] + (upw_j * wn_buf_load(Gr, vg, row0 * F4) + cvl[row0]);
-                const float pg = acc[q + 2][r] + (upw_j * wn_buf_load(Gr, vg, (row0 + 64) * F4) + cvl[row0 + 64]);
+                const float pa = acc[q][r] + (upw_j * ga[q][r] + cvl[row0]);
+                const float pg = acc[q + 2][r] + (upw_j * gg[q][r] + cvl[row0 + 64]);
                 const float s = wn_sigmoid(pa);
                 const float g = wn_tanh(pg);
                 const float zz = s * g;
@@ -172,15 +215,22 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
                 }
             }
         }
-        // res 1x1 + residual; z is consumed straight from the accumulator registers
+        f32x16 racc[2];
         if (a.Xnext != nullptr) {
             const float* rbl = rb + 4 * hi;
-            f32x16 racc[2];
             WN_UNROLL
             for (int q = 0; q < 2; ++q) {
                 WN_UNROLL
-                for (int r = 0; r < 16; ++r) racc[q][r] = xc[16 * q + r] + rbl[32 * q + mfma32_row(r, 0)];
+                for (int r = 0; r < 16; ++r)
+                    racc[q][r] = (inb ? xc[16 * q + r] : 0.0f) + rbl[32 * q + mfma32_row(r, 0)];
             }
+        }
+        // prefetch the history-tap operands of this wave's next tile; they land under the res MFMAs
+        const int next_v = tile_v + step;
+        if (K > 1 && next_v < ntiles) issue_hist(next_v);
+        WN_SCHED_BARRIER();
+        // res 1x1 + residual; z is consumed straight from the accumulator registers
+        if (a.Xnext != nullptr) {
             const float* Wrl = Wr + 4 * hi * 64 + li;
             WN_UNROLL
             for (int s = 0; s < 32; ++s) {
@@ -198,7 +248,19 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
                 }
             }
         }
+        tile_v = next_v;
     }
+}
+
+template <int K>
+static int launch_fwd(const FwdArgs& a, wn_stream_t st) {
+    const size_t lds = ((size_t)K * 64 * 128 + 64 * 64 + 192) * sizeof(float);
+    if (set_lds(k_resblock_fwd<K>, lds)) return 1;
+    const long ntiles = (long)a.B * ((a.T + 31) / 32);
+    long nblk = (ntiles + 7) / 8;
+    if (nblk > 256) nblk = 256;
+    WN_LAUNCH((k_resblock_fwd<K>), dim3((unsigned)nblk), dim3(WN_FT), lds, st, a);
+    return 0;
 }
 
 int wn_fused_resblock_fwd(const float* wd_f, const float* wres_f, const float* cvec, const float* res_bias, const float* X,
@@ -209,14 +271,13 @@ int wn_fused_resblock_fwd(const float* wd_f, const float* wres_f, const float* c
     a.wd_f = wd_f; a.wres_f = wres_f; a.cvec = cvec; a.res_bias = res_bias;
     a.X = X; a.G = G; a.g_bstride = g_bstride; a.upw = upw;
     a.Xnext = Xnext; a.S = S; a.Gt = Gt; a.Z = Z;
-    a.B = B; a.T = T; a.K = K; a.dil = dilation; a.U = U; a.F = F;
-    const size_t lds = ((size_t)K * 64 * 128 + 64 * 64 + 192) * sizeof(float);
-    if (set_lds(k_resblock_fwd, lds)) return 1;
-    const long ntiles = (long)B * ((T + 31) / 32);
-    long nblk = (ntiles + 7) / 8;
-    if (nblk > 256) nblk = 256;
-    WN_LAUNCH(k_resblock_fwd, dim3((unsigned)nblk), dim3(WN_FT), lds, st, a);
-    return 0;
+    a.B = B; a.T = T; a.dil = dilation; a.U = U; a.F = F;
+    switch (K) {
+        case 1: return launch_fwd<1>(a, st);
+        case 2: return launch_fwd<2>(a, st);
+        case 3: return launch_fwd<3>(a, st);
+        default: return 1;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -232,6 +293,7 @@ struct ConvSeg {
 struct ConvArgs {
     ConvSeg seg[3];
     int nseg;
+    int nchunks;  // sum of nch/32
     int wfloats;  // total LDS floats
     int B, T;
     const float* S;      // MODE 0
@@ -253,67 +315,128 @@ __global__ __launch_bounds__(WN_FT) void k_conv64(ConvArgs a) {
     const int T4 = T * 4;
     const int tiles_per_b = (T + 31) >> 5;
     const int ntiles = a.B * tiles_per_b;
-    for (int tile_v = blockIdx.x * 8 + wave; tile_v < ntiles; tile_v += gridDim.x * 8) {
+    const int step = gridDim.x * 8;
+    const int NCH = a.nchunks;
+
+    // Operand chunks (32 channels = 16 k-steps) are double buffered in registers: chunk q+2 is in
+    // flight while the 32 MFMAs of chunks q and q+1 run.
+    float xa[16], xb[16];
+    bool oka = false, okb = false;
+    auto locate = [&](int q, int& sg, int& c0) {
+        sg = 0;
+        c0 = q * 32;
+        while (sg + 1 < a.nseg && c0 >= a.seg[sg].nch) {
+            c0 -= a.seg[sg].nch;
+            ++sg;
+        }
+    };
+    auto issue = [&](int tl_v, int q, float (&xr)[16], bool& okr) {
+        const int tl = WN_UNIFORM(tl_v);
+        const int b = tl / tiles_per_b;
+        const int t = (tl - b * tiles_per_b) * 32 + li;
+        int sg, c0;
+        locate(q, sg, c0);
+        const ConvSeg& g = a.seg[sg];
+        const int ts = t - g.shift;
+        const bool ok = (t < T) && ts >= 0 && ts < T;
+        okr = ok;
+        const wn_rsrc_t Sr = wn_make_buf(g.src + (long)b * g.nch * T, (unsigned)(g.nch * T4));
+        const int vt = ok ? (hi * T + ts) * 4 : 0;
+        WN_UNROLL
+        for (int s = 0; s < 16; ++s) xr[s] = wn_buf_load(Sr, vt, (c0 + 2 * s) * T4);
+    };
+    f32x16 acc[2];
+    auto consume = [&](int q, const float (&xr)[16], bool okr) {
+        int sg, c0;
+        locate(q, sg, c0);
+        const float* Wl = W + a.seg[sg].woff + (c0 + hi) * 64 + li;
+        WN_UNROLL
+        for (int s = 0; s < 16; ++s) {
+            const float xv = okr ? xr[s] : 0.0f;
+            const float* wrow = Wl + (2 * s) * 64;
+            acc[0] = mfma32(wrow[0], xv, acc[0]);
+            acc[1] = mfma32(wrow[32], xv, acc[1]);
+        }
+    };
+
+    int tile_v = blockIdx.x * 8 + wave;
+    if (tile_v < ntiles) {
+        issue(tile_v, 0, xa, oka);
+        if (NCH > 1) issue(tile_v, 1, xb, okb);
+    }
+    while (tile_v < ntiles) {
         const int tile = WN_UNIFORM(tile_v);
         const int b = tile / tiles_per_b;
         const int t = (tile - b * tiles_per_b) * 32 + li;
         const bool inb = t < T;
-        f32x16 acc[2];
-        acc[0] = f32x16_zero();
-        acc[1] = f32x16_zero();
-        for (int sg = 0; sg < a.nseg; ++sg) {
-            const ConvSeg& g = a.seg[sg];
-            const int ts = t - g.shift;
-            const bool ok = inb && ts >= 0 && ts < T;
-            const wn_rsrc_t Sr = wn_make_buf(g.src + (long)b * g.nch * T, (unsigned)(g.nch * T4));
-            const int vt = ok ? (hi * T + ts) * 4 : 0;
-            const float* Wl = W + g.woff + hi * 64 + li;
-            for (int c0 = 0; c0 < g.nch; c0 += 32) {
-                float xv[16];
-                WN_UNROLL
-                for (int s = 0; s < 16; ++s) {
-                    const float v = wn_buf_load(Sr, vt, (c0 + 2 * s) * T4);
-                    xv[s] = ok ? v : 0.0f;
-                }
-                WN_UNROLL
-                for (int s = 0; s < 16; ++s) {
-                    const float* wrow = Wl + (c0 + 2 * s) * 64;
-                    acc[0] = mfma32(wrow[0], xv[s], acc[0]);
-                    acc[1] = mfma32(wrow[32], xv[s], acc[1]);
-                }
-            }
-        }
-        if (!inb) continue;
-        const int vcur = (4 * hi * T + t) * 4;
+        const int vcur = inb ? (4 * hi * T + t) * 4 : 0;
+        const int next_v = tile_v + step;
+
+        // epilogue inputs: issued now, consumed after all MFMAs of the tile
+        float e0[2][16], e1[2][16];
         if (MODE == 0) {
-            // gate backward: dP = [dZ*g*s*(1-s) ; dZ*s*(1-g^2)]
             const wn_rsrc_t Sr = wn_make_buf(a.S + (long)b * 64 * T, (unsigned)(64 * T4));
             const wn_rsrc_t Gr = wn_make_buf(a.Gt + (long)b * 64 * T, (unsigned)(64 * T4));
-            const wn_rsrc_t Or = wn_make_buf(a.out + (long)b * 128 * T, (unsigned)(128 * T4));
             WN_UNROLL
             for (int q = 0; q < 2; ++q) {
                 WN_UNROLL
                 for (int r = 0; r < 16; ++r) {
                     const int so = (32 * q + mfma32_row(r, 0)) * T4;
-                    const float s = wn_buf_load(Sr, vcur, so), g = wn_buf_load(Gr, vcur, so), dz = acc[q][r];
-                    wn_buf_store(Or, dz * g * (s * (1.0f - s)), vcur, so);
-                    wn_buf_store(Or, dz * s * (1.0f - g * g), vcur, so + 64 * T4);
+                    e0[q][r] = wn_buf_load(Sr, vcur, so);
+                    e1[q][r] = wn_buf_load(Gr, vcur, so);
                 }
             }
-        } else {
-            const wn_rsrc_t Or = wn_make_buf(a.out + (long)b * 64 * T, (unsigned)(64 * T4));
-            const wn_rsrc_t Rr = wn_make_buf((a.resid ? a.resid : a.out) + (long)b * 64 * T, (unsigned)(64 * T4));
+        } else if (a.resid != nullptr) {
+            const wn_rsrc_t Rr = wn_make_buf(a.resid + (long)b * 64 * T, (unsigned)(64 * T4));
             WN_UNROLL
             for (int q = 0; q < 2; ++q) {
                 WN_UNROLL
-                for (int r = 0; r < 16; ++r) {
-                    const int so = (32 * q + mfma32_row(r, 0)) * T4;
-                    float v = acc[q][r];
-                    if (a.resid != nullptr) v += wn_buf_load(Rr, vcur, so);
-                    wn_buf_store(Or, v, vcur, so);
+                for (int r = 0; r < 16; ++r) e0[q][r] = wn_buf_load(Rr, vcur, (32 * q + mfma32_row(r, 0)) * T4);
+            }
+        }
+        WN_SCHED_BARRIER();
+        acc[0] = f32x16_zero();
+        acc[1] = f32x16_zero();
+        for (int q = 0; q < NCH; q += 2) {
+            consume(q, xa, oka);
+            if (q + 2 < NCH) issue(tile_v, q + 2, xa, oka);
+            else if (next_v < ntiles) issue(next_v, 0, xa, oka);
+            WN_SCHED_BARRIER();
+            if (q + 1 < NCH) {
+                consume(q + 1, xb, okb);
+                if (q + 3 < NCH) issue(tile_v, q + 3, xb, okb);
+                else if (next_v < ntiles && NCH > 1) issue(next_v, 1, xb, okb);
+                WN_SCHED_BARRIER();
+            }
+        }
+        if (inb) {
+            if (MODE == 0) {
+                // gate backward: dP = [dZ*g*s*(1-s) ; dZ*s*(1-g^2)]
+                const wn_rsrc_t Or = wn_make_buf(a.out + (long)b * 128 * T, (unsigned)(128 * T4));
+                WN_UNROLL
+                for (int q = 0; q < 2; ++q) {
+                    WN_UNROLL
+                    for (int r = 0; r < 16; ++r) {
+                        const int so = (32 * q + mfma32_row(r, 0)) * T4;
+                        const float s = e0[q][r], g = e1[q][r], dz = acc[q][r];
+                        wn_buf_store(Or, dz * g * (s * (1.0f - s)), vcur, so);
+                        wn_buf_store(Or, dz * s * (1.0f - g * g), vcur, so + 64 * T4);
+                    }
+                }
+            } else {
+                const wn_rsrc_t Or = wn_make_buf(a.out + (long)b * 64 * T, (unsigned)(64 * T4));
+                WN_UNROLL
+                for (int q = 0; q < 2; ++q) {
+                    WN_UNROLL
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[q][r];
+                        if (a.resid != nullptr) v += e0[q][r];
+                        wn_buf_store(Or, v, vcur, (32 * q + mfma32_row(r, 0)) * T4);
+                    }
                 }
             }
         }
+        tile_v = next_v;
     }
 }
 
@@ -335,10 +458,12 @@ int wn_fused_bwd_gate(const float* wskip, const float* wres, const float* dSk, c
     a.nseg = 1;
     a.seg[0].src = dSk; a.seg[0].w = wskip; a.seg[0].nch = Sch; a.seg[0].shift = 0; a.seg[0].woff = 0;
     a.wfloats = Sch * 64;
+    a.nchunks = Sch / 32;
     if (dXn) {
         a.seg[1].src = dXn; a.seg[1].w = wres; a.seg[1].nch = 64; a.seg[1].shift = 0; a.seg[1].woff = Sch * 64;
         a.nseg = 2;
         a.wfloats += 64 * 64;
+        a.nchunks += 2;
     }
     a.B = B; a.T = T; a.S = S; a.Gt = Gt; a.resid = nullptr; a.out = dP;
     return launch_conv64<0>(a, st);
@@ -358,6 +483,7 @@ int wn_fused_bwd_dx(const float* wd_b, const float* dP, const float* dXn, float*
         a.seg[tap].woff = tap * 128 * 64;
     }
     a.wfloats = K * 128 * 64;
+    a.nchunks = K * 4;
     a.B = B; a.T = T; a.S = nullptr; a.Gt = nullptr; a.resid = dXn; a.out = dX;
     return launch_conv64<1>(a, st);
 }

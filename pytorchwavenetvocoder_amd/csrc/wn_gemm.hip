@@ -40,8 +40,8 @@ struct TileGeom {
     static __device__ __forceinline__ int soff(int kk, int mn) { return KMAJ ? mn * LD + kk : kk * LD + mn; }
 };
 
-template <int TM, int TN, int KMAJ>
-__global__ __launch_bounds__(WN_GEMM_THREADS) void wn_gemm_kernel(WnGemmArgs g) {
+template <int TM, int TN, int KMAJ, int ONEHOT>
+__global__ __launch_bounds__(WN_GEMM_THREADS, 3) void wn_gemm_kernel(WnGemmArgs g) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     typedef TileGeom<BM, KMAJ> GA;
     typedef TileGeom<BN, KMAJ> GB;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(WN_GEMM_THREADS) void wn_gemm_kernel(WnGemmArgs g) 
                 const int cc = kb - b_rowshift[i];
                 const bool ok = kbok && off >= 0 && cc >= 0 && cc < g.b_clen;
                 float v = 0.0f;
-                if (g.b_index != nullptr) {
+                if (ONEHOT) {
                     if (ok) {
                         long long q = g.b_index[(long)b * g.b_index_zstride + cc] % g.b_index_mod;
                         if (q < 0) q += g.b_index_mod;
@@ -230,7 +230,9 @@ __global__ __launch_bounds__(WN_GEMM_THREADS) void wn_gemm_kernel(WnGemmArgs g) 
     if (KMAJ && g.a_rowsum != nullptr && blockIdx.x == 0 && tid < BM && (m0 + tid) < g.M)
         g.a_rowsum[(long)z * g.M + m0 + tid] = rowsum;
 
-    // epilogue: lane (col = li, hi) holds rows mfma32_row(r, hi) of each 32x32 tile
+    // epilogue: lane (col = li, hi) holds rows mfma32_row(r, hi) of each 32x32 tile.  All side inputs
+    // of a tile (bias, residual D, mask E, old C) are loaded first with clamped (always valid)
+    // indices, so the loads are issued back to back instead of one wait per element.
     float* __restrict__ Cz = g.C + (long)z * g.c_zstride;
     const float* __restrict__ Dz = g.D ? g.D + (long)b * g.d_zstride : nullptr;
     const float* __restrict__ Ez = g.E ? g.E + (long)b * g.e_zstride : nullptr;
@@ -239,30 +241,41 @@ __global__ __launch_bounds__(WN_GEMM_THREADS) void wn_gemm_kernel(WnGemmArgs g) 
         WN_UNROLL
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + (wn * TN + j) * 32 + li;
+            const int nc = n < g.N ? n : g.N - 1;
             WN_UNROLL
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * TM + i) * 32 + mfma32_row(r, hi);
-                if (m < g.M && n < g.N) {
-                    float v = acc[i][j][r];
-                    if (g.bias) v += g.bias[m];
-                    if (Dz) v += Dz[(long)m * g.ldd + n];
-                    if (g.relu) v = fmaxf(v, 0.0f);
-                    if (Ez) v = (Ez[(long)m * g.lde + n] > 0.0f) ? v : 0.0f;
-                    float* p = Cz + (long)m * g.ldc + n;
-                    if (g.accumulate) v += *p;
-                    *p = v;
+            for (int h8 = 0; h8 < 4; ++h8) {  // 4 rows at a time keeps the register peak of the epilogue low
+                float bv[4], dv[4], ev[4], cv[4];
+                WN_UNROLL
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int m = m0 + (wm * TM + i) * 32 + mfma32_row(4 * h8 + rr, hi);
+                    const int mc = m < g.M ? m : g.M - 1;
+                    bv[rr] = g.bias ? g.bias[mc] : 0.0f;
+                    // 32-bit element offsets from block-uniform bases (a per-batch slab is < 2^32 elements)
+                    dv[rr] = Dz ? Dz[(unsigned)mc * (unsigned)g.ldd + (unsigned)nc] : 0.0f;
+                    ev[rr] = Ez ? Ez[(unsigned)mc * (unsigned)g.lde + (unsigned)nc] : 1.0f;
+                    cv[rr] = g.accumulate ? Cz[(unsigned)mc * (unsigned)g.ldc + (unsigned)nc] : 0.0f;
                 }
+                WN_UNROLL
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int m = m0 + (wm * TM + i) * 32 + mfma32_row(4 * h8 + rr, hi);
+                    float v = acc[i][j][4 * h8 + rr] + bv[rr] + dv[rr];
+                    if (g.relu) v = fmaxf(v, 0.0f);
+                    v = (ev[rr] > 0.0f) ? v : 0.0f;
+                    v += cv[rr];
+                    if (m < g.M && n < g.N) Cz[(unsigned)m * (unsigned)g.ldc + (unsigned)n] = v;
+                }
+                WN_SCHED_BARRIER();  // keep the next chunk's loads from being hoisted above these stores
             }
         }
     }
 }
 
-template <int TM, int TN, int KMAJ>
+template <int TM, int TN, int KMAJ, int ONEHOT>
 static void launch_variant(const WnGemmArgs& g, wn_stream_t stream) {
     dim3 grid((unsigned)((g.N + 64 * TN - 1) / (64 * TN)), (unsigned)((g.M + 64 * TM - 1) / (64 * TM)),
               (unsigned)(g.nbatch * g.ksplit));
     dim3 block(WN_GEMM_THREADS);
-    WN_LAUNCH((wn_gemm_kernel<TM, TN, KMAJ>), grid, block, 0, stream, g);
+    WN_LAUNCH((wn_gemm_kernel<TM, TN, KMAJ, ONEHOT>), grid, block, 0, stream, g);
 }
 
 int wn_gemm_launch(const WnGemmArgs* gp, wn_stream_t stream) {
@@ -272,16 +285,24 @@ int wn_gemm_launch(const WnGemmArgs* gp, wn_stream_t stream) {
     if (g.b_seg_len <= 0 || g.kchunk <= 0) return 3;
     const int tm = g.M > 64 ? 2 : 1, tn = g.N > 64 ? 2 : 1;
     WN_PROF(g.tag ? g.tag : "gemm", 2.0 * g.M * g.N * (double)g.K * g.nbatch, 0.0, stream);
+    if (g.b_index != nullptr) {
+        if (!g.a_kmajor) return 4;  // the one-hot operand exists for the dW (k = time) mode only
+        if (tm == 2 && tn == 2) launch_variant<2, 2, 1, 1>(g, stream);
+        else if (tm == 2) launch_variant<2, 1, 1, 1>(g, stream);
+        else if (tn == 2) launch_variant<1, 2, 1, 1>(g, stream);
+        else launch_variant<1, 1, 1, 1>(g, stream);
+        return 0;
+    }
     const int key = (g.a_kmajor ? 4 : 0) | (tm == 2 ? 2 : 0) | (tn == 2 ? 1 : 0);
     switch (key) {
-        case 0: launch_variant<1, 1, 0>(g, stream); break;
-        case 1: launch_variant<1, 2, 0>(g, stream); break;
-        case 2: launch_variant<2, 1, 0>(g, stream); break;
-        case 3: launch_variant<2, 2, 0>(g, stream); break;
-        case 4: launch_variant<1, 1, 1>(g, stream); break;
-        case 5: launch_variant<1, 2, 1>(g, stream); break;
-        case 6: launch_variant<2, 1, 1>(g, stream); break;
-        default: launch_variant<2, 2, 1>(g, stream); break;
+        case 0: launch_variant<1, 1, 0, 0>(g, stream); break;
+        case 1: launch_variant<1, 2, 0, 0>(g, stream); break;
+        case 2: launch_variant<2, 1, 0, 0>(g, stream); break;
+        case 3: launch_variant<2, 2, 0, 0>(g, stream); break;
+        case 4: launch_variant<1, 1, 1, 0>(g, stream); break;
+        case 5: launch_variant<1, 2, 1, 0>(g, stream); break;
+        case 6: launch_variant<2, 1, 1, 0>(g, stream); break;
+        default: launch_variant<2, 2, 1, 0>(g, stream); break;
     }
     return 0;
 }

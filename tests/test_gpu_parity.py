@@ -62,9 +62,10 @@ def test_reference_test_shapes():
 
 def test_cfg2_model_midsize_vs_oracle():
     """The BASELINE config-2 MODEL (30 layers, 64/256 ch, A=80, U=80) on a window the CPU oracle
-    finishes in seconds (T=4000 > rf=3070), trained-scale weights and init-scale weights."""
+    finishes in seconds (T=3200/3280 > rf=3070), trained-scale weights, instances with a verified
+    ReLU-kink margin (parity_common.pick_instance)."""
     cfg_t = (256, 80, 64, 256, 10, 3, 2, 80)
-    e1, g1 = PC.run_oracle_vs_engine(cfg_t, 1, 4000, 21, _lib(), DEV, scale=0.05)
+    e1, g1 = PC.run_oracle_vs_engine(cfg_t, 1, 3280, 21, _lib(), DEV, scale=0.05)
     e2, g2 = PC.run_oracle_vs_engine(cfg_t, 2, 3200, 22, _lib(), DEV, scale=0.02)
     print("cfg2-model logits err %.3g / %.3g, worst grad rel err %.3g / %.3g" % (e1, e2, g1, g2))
 
@@ -77,8 +78,7 @@ def test_cfg2_fused_equals_layered_midsize():
     from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat
     cfg_t = (256, 80, 64, 256, 10, 3, 2, 80)
     cfg = O.OracleConfig(*cfg_t)
-    params = O.random_params(cfg, 31, scale=0.05)
-    x, h, t = O.synthetic_batch(cfg, 2, 4000, 32)
+    params, x, h, t, margin, sd = PC.pick_instance(cfg, 2, 3200, 31, 0.05)
     outs = []
     for flags in (0, L.FLAG_NO_FUSED):
         eng = WaveNetEngine(*cfg_t, device=DEV, library=_lib())
