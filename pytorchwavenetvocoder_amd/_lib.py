@@ -43,6 +43,8 @@ class WnGemmArgs(ctypes.Structure):
         ("nbatch", ctypes.c_int), ("ksplit", ctypes.c_int), ("kchunk", ctypes.c_int),
         ("a_rowsum", ctypes.c_void_p),
         ("tag", ctypes.c_char_p),
+        ("nlayer", ctypes.c_int), ("a_lstride", ctypes.c_long), ("b_lstride", ctypes.c_long),
+        ("b_dil_depth", ctypes.c_int), ("b_layer0", ctypes.c_int),
     ]
 
     @classmethod
@@ -53,6 +55,7 @@ class WnGemmArgs(ctypes.Structure):
         g.nbatch = 1
         g.ksplit = 1
         g.kchunk = 0x7fffffff
+        g.nlayer = 1
         return g
 
 

@@ -253,7 +253,7 @@ struct Ws {
     // saved activations
     long X, G, Sg, Gt, Z, O1, O2;
     // scratch
-    long P, dO2, dSk, dZ, dXa, dXb, dG, dw_partial, dc, tmpS, partial, rs_partial, red_scratch, loss_partial;
+    long P, dO2, dSk, dZ, dXall, dG, dw_partial, dc, tmpS, partial, rs_partial, red_scratch, loss_partial;
     long red_scratch_floats;
     long total;
     int F;  // frames (T/U, or T without upsampling)
@@ -291,13 +291,12 @@ static int make_ws(const Dims& d, int B, int T, Ws* w) {
     CARVE(Z, (long)d.L * BRT);
     CARVE(O1, BST);
     CARVE(O2, BST);
-    CARVE(P, 2 * BRT);
+    CARVE(P, (long)d.L * 2 * BRT);  // forward scratch (layered path) / dP of every layer (backward)
     CARVE(dO2, BST);
     CARVE(dSk, BST);
     CARVE(dZ, BRT);
-    CARVE(dXa, BRT);
-    CARVE(dXb, BRT);
-    CARVE(dG, (long)B * 2 * d.R * F);
+    CARVE(dXall, (long)d.L * BRT);  // dL/dx_l of every layer
+    CARVE(dG, (long)d.L * B * 2 * d.R * F);
     CARVE(dw_partial, (long)d.L * B * 2 * d.R * Ue);
     CARVE(dc, (long)d.L * 2 * d.R);
     CARVE(tmpS, d.S > d.Q ? d.S : d.Q);
@@ -308,11 +307,13 @@ static int make_ws(const Dims& d, int B, int T, Ws* w) {
             {d.Q, d.S, T}, {d.S, d.S, T}, {d.S, d.L * d.R, T}, {2 * d.R, d.K * d.R, T},
             {d.R, d.R, T}, {2 * d.R, d.A, F}, {2 * d.R, d.A, T}, {d.R, d.K * d.Q, T}};
         for (unsigned i = 0; i < sizeof(gs) / sizeof(gs[0]); ++i) {
-            DwPlan p = dw_plan(gs[i].M, gs[i].N, gs[i].K, B);
-            long need = (long)p.nz * gs[i].M * gs[i].N;
-            if (need > pmax) pmax = need;
-            long rneed = (long)p.nz * gs[i].M;
-            if (rneed > rmax) rmax = rneed;
+            for (int nl = 1; nl <= d.L; ++nl) {  // layer-batched launches: any bucket size
+                DwPlan p = dw_plan(gs[i].M, gs[i].N, gs[i].K, B * nl);
+                long need = (long)p.nz * gs[i].M * gs[i].N;
+                if (need > pmax) pmax = need;
+                long rneed = (long)p.nz * gs[i].M;
+                if (rneed > rmax) rmax = rneed;
+            }
         }
     }
     CARVE(partial, pmax);
@@ -556,30 +557,35 @@ struct DwOut {          // destination mapping of a weight-gradient (see WnReduc
     const float* addend_m;
     const float* addend_scale_ptr;
     float* rowsum_out;  // nullable: [M] contiguous destination of sum_k A(m,k)
+    long out_lstride, addend_lstride, rowsum_lstride;  // per layer of a batched launch
 };
 
-// dW[m][n] = sum_{b, k} A_b(m,k) * B_b(n,k)   (k = time), split over (b, k-chunks), reduced in order.
-static int dw_gemm(const Ctx& c, WnGemmArgs g, const DwOut& o) {
-    const DwPlan p = dw_plan(g.M, g.N, g.K, c.B);
+// dW[l][m][n] = sum_{b, k} A_{l,b}(m,k) * B_{l,b}(n,k)   (k = time) for nl layers in ONE launch,
+// split over (layer, b, k-chunks) and reduced in a fixed order.
+static int dw_gemm(const Ctx& c, WnGemmArgs g, const DwOut& o, int nl = 1) {
+    const DwPlan p = dw_plan(g.M, g.N, g.K, c.B * nl);
+    const int nz_layer = p.ksplit * c.B;
     g.a_kmajor = 1; g.b_kmajor = 1;
-    g.nbatch = c.B; g.ksplit = p.ksplit; g.kchunk = p.kchunk;
+    g.nlayer = nl; g.nbatch = c.B; g.ksplit = p.ksplit; g.kchunk = p.kchunk;
     g.C = c.ws + c.w.partial; g.ldc = g.N; g.c_zstride = (long)g.M * g.N;
     g.a_rowsum = o.rowsum_out ? c.ws + c.w.rs_partial : nullptr;
     WN_TRY(wn_gemm_launch(&g, c.st));
     WnReduceArgs r;
-    r.partial = c.ws + c.w.partial; r.nz = p.nz; r.M = g.M; r.N = g.N;
+    r.partial = c.ws + c.w.partial; r.nz = nz_layer; r.M = g.M; r.N = g.N;
     r.out = o.out; r.m_seg = o.m_seg; r.n_seg = o.n_seg;
     r.m_seg_stride = o.m_seg_stride; r.m_stride = o.m_stride; r.n_seg_stride = o.n_seg_stride; r.n_stride = o.n_stride;
     r.scale = 1.0f; r.accumulate = 0; r.addend_m = o.addend_m; r.addend_scale_ptr = o.addend_scale_ptr;
     r.scratch = c.ws + c.w.red_scratch; r.scratch_floats = c.w.red_scratch_floats;
+    r.nl = nl; r.out_lstride = o.out_lstride; r.addend_lstride = o.addend_lstride;
     WN_TRY(wn_reduce(&r, c.st));
     if (o.rowsum_out) {
         WnReduceArgs q;
-        q.partial = c.ws + c.w.rs_partial; q.nz = p.nz; q.M = g.M; q.N = 1;
+        q.partial = c.ws + c.w.rs_partial; q.nz = nz_layer; q.M = g.M; q.N = 1;
         q.out = o.rowsum_out; q.m_seg = 0x7fffffff; q.n_seg = 0x7fffffff;
         q.m_seg_stride = 0; q.m_stride = 1; q.n_seg_stride = 0; q.n_stride = 0;
         q.scale = 1.0f; q.accumulate = 0; q.addend_m = nullptr; q.addend_scale_ptr = nullptr;
         q.scratch = c.ws + c.w.red_scratch; q.scratch_floats = c.w.red_scratch_floats;
+        q.nl = nl; q.out_lstride = o.rowsum_lstride; q.addend_lstride = 0;
         WN_TRY(wn_reduce(&q, c.st));
     }
     return 0;
@@ -590,6 +596,7 @@ static DwOut dw_out_plain(float* out, long ld, float* rowsum_out) {
     o.out = out; o.m_seg = 0x7fffffff; o.n_seg = 0x7fffffff;
     o.m_seg_stride = 0; o.m_stride = ld; o.n_seg_stride = 0; o.n_stride = 1;
     o.addend_m = nullptr; o.addend_scale_ptr = nullptr; o.rowsum_out = rowsum_out;
+    o.out_lstride = 0; o.addend_lstride = 0; o.rowsum_lstride = 0;
     return o;
 }
 
@@ -656,6 +663,7 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
         o.out = grads + y.skip0; o.m_seg = 0x7fffffff; o.m_seg_stride = 0; o.m_stride = d.R;
         o.n_seg = d.R; o.n_seg_stride = y.ls_skip; o.n_stride = 1;
         o.addend_m = nullptr; o.addend_scale_ptr = nullptr; o.rowsum_out = ws + w.tmpS;
+        o.out_lstride = 0; o.addend_lstride = 0; o.rowsum_lstride = 0;
         WN_TRY(dw_gemm(c, g, o));
         WnCopy4 cp;
         cp.n0 = 1; cp.n1 = 1; cp.n2 = d.S; cp.nl = d.L;
@@ -667,36 +675,95 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
     bucket++;
 
     // ---- residual stack, last layer first (wavenet.py:525-536 reversed) ----
+    // The data chain (gate', dX) runs layer by layer; dP_l and dX_l of every layer are kept so that
+    // the weight gradients of a whole bucket of layers are produced by ONE launch per tensor kind
+    // (layer = outermost z dimension of the dW contraction), then reduced in a fixed order.
     const float* upw = d.U > 0 ? params + y.up_w : ws + w.one;
     const long g_bstride = (long)d.L * 2 * d.R * F;
-    float* dXn = nullptr;            // gradient w.r.t. the output of layer l (null: dead, last layer)
-    float* dXcur = ws + w.dXa;
-    float* dXother = ws + w.dXb;
+    const long P_L = 2 * BRT;
+    auto flush_bucket = [&](int lo, int hi) -> int {
+        const int nl = hi - lo;
+        const long lb_lo = layer_base(y, d, lo);
+        float* dc = ws + w.dc + (long)lo * 2 * d.R;
+        {   // d dil_{sigmoid,tanh}.l.conv.weight ; dc_l = rowsum(dP_l) -> conv + aux biases
+            WnGemmArgs g = wn_gemm_default();
+            g.M = 2 * d.R; g.N = d.K * d.R; g.K = T;
+            g.A = ws + w.P + (long)lo * P_L; g.lda = T; g.a_zstride = (long)2 * d.R * T; g.a_lstride = P_L;
+            g.B = ws + w.X + (long)lo * BRT; g.ldb = T; g.b_zstride = (long)d.R * T; g.b_lstride = BRT; g.b_clen = T;
+            g.b_seg_len = d.R; g.b_seg_stride = 0; g.b_shift0 = d.K - 1; g.b_shift_step = -1;
+            g.b_dil_depth = cfg->dilation_depth; g.b_layer0 = lo;
+            g.tag = "dw_dilated";
+            DwOut o;
+            o.out = grads + lb_lo + y.o_dsig_w;
+            o.m_seg = d.R; o.m_seg_stride = y.o_dtanh_w - y.o_dsig_w; o.m_stride = (long)d.R * d.K;
+            o.n_seg = d.R; o.n_seg_stride = 1; o.n_stride = d.K;
+            o.addend_m = nullptr; o.addend_scale_ptr = nullptr; o.rowsum_out = dc;
+            o.out_lstride = -y.LB; o.addend_lstride = 0; o.rowsum_lstride = 2 * d.R;
+            WN_TRY(dw_gemm(c, g, o, nl));
+            WnCopy4 cp;  // biases: dil_{sig,tanh}.bias = dc ; aux_{sig,tanh}.bias = dc
+            cp.n0 = 1; cp.n1 = 2; cp.n2 = d.R; cp.nl = nl;
+            cp.s0 = 0; cp.s1 = d.R; cp.s2 = 1; cp.sl = 2 * d.R;
+            cp.d0 = 0; cp.d1 = y.o_dtanh_b - y.o_dsig_b; cp.d2 = 1; cp.dl = -y.LB;
+            WN_TRY(wn_copy4(grads + lb_lo + y.o_dsig_b, dc, &cp, c.st));
+            cp.d1 = y.o_atanh_b - y.o_asig_b;
+            WN_TRY(wn_copy4(grads + lb_lo + y.o_asig_b, dc, &cp, c.st));
+        }
+        {   // d res_1x1.l = dX_{l+1} . z_l^T ; the last layer's res_1x1 is dead -> zeros
+            const int hi_res = hi < d.L ? hi : d.L - 1;
+            if (hi == d.L) WN_TRY(wn_fill(grads + layer_base(y, d, d.L - 1) + y.o_res_w, 0.0f, (long)d.R * d.R + d.R, c.st));
+            if (hi_res > lo) {
+                WnGemmArgs g = wn_gemm_default();
+                g.M = d.R; g.N = d.R; g.K = T;
+                g.A = ws + w.dXall + (long)(lo + 1) * BRT; g.lda = T; g.a_zstride = (long)d.R * T; g.a_lstride = BRT;
+                g.B = ws + w.Z + (long)lo * BRT; g.ldb = T; g.b_zstride = (long)d.R * T; g.b_lstride = BRT; g.b_clen = T;
+                g.tag = "dw_res";
+                DwOut o = dw_out_plain(grads + lb_lo + y.o_res_w, d.R, grads + lb_lo + y.o_res_b);
+                o.out_lstride = -y.LB; o.rowsum_lstride = -y.LB;
+                WN_TRY(dw_gemm(c, g, o, hi_res - lo));
+            }
+        }
+        {   // d aux_1x1_{sigmoid,tanh}.l.weight
+            DwOut o;
+            o.out = grads + lb_lo + y.o_asig_w;
+            o.m_seg = d.R; o.m_seg_stride = y.o_atanh_w - y.o_asig_w; o.m_stride = d.A;
+            o.n_seg = 0x7fffffff; o.n_seg_stride = 0; o.n_stride = 1;
+            o.rowsum_out = nullptr; o.out_lstride = -y.LB; o.rowsum_lstride = 0;
+            WnGemmArgs g = wn_gemm_default();
+            g.tag = "dw_aux";
+            g.M = 2 * d.R; g.N = d.A;
+            if (d.U > 0) {
+                // through the upsampling layer: dG[f] = sum_j w[j] dP[fU+j]; dW = dG.h^T + b_up*dc (x) 1
+                WN_TRY(wn_aux_bwd(ws + w.P + (long)lo * P_L, P_L, ws + w.G + (long)lo * 2 * d.R * F, g_bstride, upw, ws + w.dG,
+                                  ws + w.dw_partial + (long)lo * B * 2 * d.R * Ue, B, T, 2 * d.R, Ue, F, nl, c.st));
+                g.K = F;
+                g.A = ws + w.dG; g.lda = F; g.a_zstride = (long)2 * d.R * F; g.a_lstride = (long)B * 2 * d.R * F;
+                g.B = h; g.ldb = F; g.b_zstride = (long)d.A * F; g.b_lstride = 0; g.b_clen = F;
+                o.addend_m = dc; o.addend_scale_ptr = params + y.up_b; o.addend_lstride = 2 * d.R;
+            } else {
+                g.K = T;
+                g.A = ws + w.P + (long)lo * P_L; g.lda = T; g.a_zstride = (long)2 * d.R * T; g.a_lstride = P_L;
+                g.B = h; g.ldb = T; g.b_zstride = (long)d.A * T; g.b_lstride = 0; g.b_clen = T;
+                o.addend_m = nullptr; o.addend_scale_ptr = nullptr; o.addend_lstride = 0;
+            }
+            WN_TRY(dw_gemm(c, g, o, nl));
+        }
+        return 0;
+    };
+
+    int bucket_hi = d.L;  // layers [l, bucket_hi) have been walked but not flushed yet
     for (int l = d.L - 1; l >= 0; --l) {
         const int dil = dilation_of(cfg, l);
         const long lb = layer_base(y, d, l);
-        const float* Xl = ws + w.X + (long)l * BRT;
         const float* Sl = ws + w.Sg + (long)l * BRT;
         const float* Gtl = ws + w.Gt + (long)l * BRT;
-        const float* Zl = ws + w.Z + (long)l * BRT;
-        const float* Gl = ws + w.G + (long)l * 2 * d.R * F;
-        float* dP = ws + w.P;
-        float* dc = ws + w.dc + (long)l * 2 * d.R;
-
-        // d res_1x1.l (needs dX_{l+1} and z_l); dead for the last layer -> zeros
-        if (dXn) {
-            WnGemmArgs g = wn_gemm_default();
-            g.M = d.R; g.N = d.R; g.K = T;
-            g.A = dXn; g.lda = T; g.a_zstride = (long)d.R * T;
-            g.B = Zl; g.ldb = T; g.b_zstride = (long)d.R * T; g.b_clen = T; g.tag = "dw_res";
-            WN_TRY(dw_gemm(c, g, dw_out_plain(grads + lb + y.o_res_w, d.R, grads + lb + y.o_res_b)));
-        } else {
-            WN_TRY(wn_fill(grads + lb + y.o_res_w, 0.0f, (long)d.R * d.R + d.R, c.st));
-        }
+        float* dP = ws + w.P + (long)l * P_L;
+        const float* dXn = (l + 1 < d.L) ? ws + w.dXall + (long)(l + 1) * BRT : nullptr;  // null: dead (last layer)
+        float* dXl = ws + w.dXall + (long)l * BRT;
         if (c.fused) {
             // dZ = Wskip^T dSk (+ Wres^T dXn) -> gate' -> dP
             WN_TRY(wn_fused_bwd_gate(params + y.skip0 + (long)l * y.ls_skip, params + lb + y.o_res_w, ws + w.dSk, dXn, Sl, Gtl,
                                      dP, B, T, d.S, c.st));
+            WN_TRY(wn_fused_bwd_dx(ws + w.wd_b + (long)l * d.K * 2 * d.R * d.R, dP, dXn, dXl, B, T, d.K, dil, c.st));
         } else {
             {   // dZ = Wskip_l^T dSkip
                 WnGemmArgs g = wn_gemm_default();
@@ -717,74 +784,27 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
                 WN_TRY(wn_gemm_launch(&g, c.st));
             }
             WN_TRY(wn_gate_bwd(ws + w.dZ, Sl, Gtl, dP, B, T, d.R, c.st));
-        }
-        {   // d dil_{sigmoid,tanh}.l.conv.weight ; dc = rowsum(dP) -> conv + aux biases
-            WnGemmArgs g = wn_gemm_default();
-            g.M = 2 * d.R; g.N = d.K * d.R; g.K = T;
-            g.A = dP; g.lda = T; g.a_zstride = (long)2 * d.R * T;
-            g.B = Xl; g.ldb = T; g.b_zstride = (long)d.R * T; g.b_clen = T;
-            g.b_seg_len = d.R; g.b_seg_stride = 0; g.b_shift0 = (d.K - 1) * dil; g.b_shift_step = -dil;
-            g.tag = "dw_dilated";
-            DwOut o;
-            o.out = grads + lb + y.o_dsig_w;
-            o.m_seg = d.R; o.m_seg_stride = y.o_dtanh_w - y.o_dsig_w; o.m_stride = (long)d.R * d.K;
-            o.n_seg = d.R; o.n_seg_stride = 1; o.n_stride = d.K;
-            o.addend_m = nullptr; o.addend_scale_ptr = nullptr; o.rowsum_out = dc;
-            WN_TRY(dw_gemm(c, g, o));
-            WnCopy4 cp;  // biases: dil_{sig,tanh}.bias = dc ; aux_{sig,tanh}.bias = dc
-            cp.n0 = 1; cp.n1 = 2; cp.n2 = d.R; cp.nl = 1;
-            cp.s0 = 0; cp.s1 = d.R; cp.s2 = 1; cp.sl = 0;
-            cp.d0 = 0; cp.d1 = y.o_dtanh_b - y.o_dsig_b; cp.d2 = 1; cp.dl = 0;
-            WN_TRY(wn_copy4(grads + lb + y.o_dsig_b, dc, &cp, c.st));
-            cp.d1 = y.o_atanh_b - y.o_asig_b;
-            WN_TRY(wn_copy4(grads + lb + y.o_asig_b, dc, &cp, c.st));
-        }
-        {   // d aux_1x1_{sigmoid,tanh}.l.weight
-            DwOut o;
-            o.out = grads + lb + y.o_asig_w;
-            o.m_seg = d.R; o.m_seg_stride = y.o_atanh_w - y.o_asig_w; o.m_stride = d.A;
-            o.n_seg = 0x7fffffff; o.n_seg_stride = 0; o.n_stride = 1;
-            o.rowsum_out = nullptr;
-            WnGemmArgs g = wn_gemm_default();
-            g.tag = "dw_aux";
-            g.M = 2 * d.R; g.N = d.A;
-            if (d.U > 0) {
-                // through the upsampling layer: dG[f] = sum_j w[j] dP[fU+j]; dW = dG.h^T + b_up*dc (x) 1
-                WN_TRY(wn_aux_bwd(dP, Gl, g_bstride, upw, ws + w.dG, ws + w.dw_partial + (long)l * B * 2 * d.R * Ue, B, T,
-                                  2 * d.R, Ue, F, c.st));
-                g.K = F;
-                g.A = ws + w.dG; g.lda = F; g.a_zstride = (long)2 * d.R * F;
-                g.B = h; g.ldb = F; g.b_zstride = (long)d.A * F; g.b_clen = F;
-                o.addend_m = dc; o.addend_scale_ptr = params + y.up_b;
-            } else {
-                g.K = T;
-                g.A = dP; g.lda = T; g.a_zstride = (long)2 * d.R * T;
-                g.B = h; g.ldb = T; g.b_zstride = (long)d.A * T; g.b_clen = T;
-                o.addend_m = nullptr; o.addend_scale_ptr = nullptr;
+            {   // dX_l = dX_{l+1} + sum_tap W_tap^T dP[t + (K-1-tap) d]
+                WnGemmArgs g = wn_gemm_default();
+                g.M = d.R; g.N = T; g.K = d.K * 2 * d.R;
+                g.A = ws + w.wd_b + (long)l * d.K * 2 * d.R * d.R; g.lda = d.R;
+                g.B = dP; g.ldb = T; g.b_zstride = (long)2 * d.R * T; g.b_clen = T;
+                g.b_seg_len = 2 * d.R; g.b_seg_stride = 0; g.b_shift0 = -(d.K - 1) * dil; g.b_shift_step = dil;
+                g.C = dXl; g.ldc = T; g.c_zstride = (long)d.R * T;
+                if (dXn) { g.D = dXn; g.ldd = T; g.d_zstride = (long)d.R * T; }
+                g.nbatch = B; g.tag = "bwd_dx_dilated";
+                WN_TRY(wn_gemm_launch(&g, c.st));
             }
-            WN_TRY(dw_gemm(c, g, o));
         }
-        if (c.fused) {
-            WN_TRY(wn_fused_bwd_dx(ws + w.wd_b + (long)l * d.K * 2 * d.R * d.R, dP, dXn, dXcur, B, T, d.K, dil, c.st));
-        } else {  // dX_l = dX_{l+1} + sum_tap W_tap^T dP[t + (K-1-tap) d]
-            WnGemmArgs g = wn_gemm_default();
-            g.M = d.R; g.N = T; g.K = d.K * 2 * d.R;
-            g.A = ws + w.wd_b + (long)l * d.K * 2 * d.R * d.R; g.lda = d.R;
-            g.B = dP; g.ldb = T; g.b_zstride = (long)2 * d.R * T; g.b_clen = T;
-            g.b_seg_len = 2 * d.R; g.b_seg_stride = 0; g.b_shift0 = -(d.K - 1) * dil; g.b_shift_step = dil;
-            g.C = dXcur; g.ldc = T; g.c_zstride = (long)d.R * T;
-            if (dXn) { g.D = dXn; g.ldd = T; g.d_zstride = (long)d.R * T; }
-            g.nbatch = B; g.tag = "bwd_dx_dilated";
-            WN_TRY(wn_gemm_launch(&g, c.st));
-        }
-        dXn = dXcur;
-        float* t = dXcur; dXcur = dXother; dXother = t;
-        const int done = d.L - l;  // layers finished
+        const int done = d.L - l;  // layers walked
         if (done % lpb == 0 || l == 0) {
+            WN_TRY(flush_bucket(l, bucket_hi));
+            bucket_hi = l;
             if (events) rt_event_record(events[bucket], c.st);
             bucket++;
         }
     }
+    const float* dXn = ws + w.dXall;  // dL/dx_0
     // ---- front conv (one-hot as an implicit operand) ----
     {
         WnGemmArgs g = wn_gemm_default();
@@ -797,6 +817,7 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
         o.out = grads + y.causal_w; o.m_seg = 0x7fffffff; o.m_seg_stride = 0; o.m_stride = (long)d.Q * d.K;
         o.n_seg = d.Q; o.n_seg_stride = 1; o.n_stride = d.K;
         o.addend_m = nullptr; o.addend_scale_ptr = nullptr; o.rowsum_out = grads + y.causal_b;
+        o.out_lstride = 0; o.addend_lstride = 0; o.rowsum_lstride = 0;
         WN_TRY(dw_gemm(c, g, o));
     }
     // ---- upsampling layer parameters ----
@@ -807,6 +828,7 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
         r.m_seg_stride = 0; r.m_stride = 0; r.n_seg_stride = 0; r.n_stride = 1;
         r.scale = 1.0f; r.accumulate = 0; r.addend_m = nullptr; r.addend_scale_ptr = nullptr;
         r.scratch = ws + w.red_scratch; r.scratch_floats = w.red_scratch_floats;
+        r.nl = 1; r.out_lstride = 0; r.addend_lstride = 0;
         WN_TRY(wn_reduce(&r, c.st));
         // d b_up = sum_{l,o'} rowsum(Waux_l)[o'] * dc_l[o']
         WN_TRY(wn_dot(ws + w.rowsum_aux, ws + w.dc, (long)d.L * 2 * d.R, grads + y.up_b, 0, c.st));

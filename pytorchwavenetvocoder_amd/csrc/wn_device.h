@@ -31,6 +31,7 @@ static inline float wn_buf_load(wn_rsrc_t r, int voff, int soff) { return *(cons
 static inline void wn_buf_store(wn_rsrc_t r, float v, int voff, int soff) { *(float*)(r.base + (long)voff + (long)soff) = v; }
 #define WN_UNIFORM(x) (x)
 #define WN_SCHED_BARRIER()
+#define WN_SLEEP(n)
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -59,6 +60,7 @@ static __device__ __forceinline__ void wn_buf_store(wn_rsrc_t r, float v, int vo
 #define WN_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 // scheduling fence: hipcc may not move instructions across it (pins software-pipeline issue order)
 #define WN_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#define WN_SLEEP(n) __builtin_amdgcn_s_sleep(n)
 #define WN_UNROLL _Pragma("unroll")
 #define WN_PRAGMA(x) _Pragma(#x)
 #define WN_UNROLL_N(n) WN_PRAGMA(unroll n)

@@ -58,8 +58,10 @@ int wn_sum_layers(const float* params, long off, long ls, int L, int n, float* o
 
 // Aux backward for one layer (upsampling layer present):
 //   dG[b][o'][f] = sum_j w[j] dP[b][o'][fU+j];   dw_partial[(b*2R+o')][j] = sum_f dP[b][o'][fU+j] G[b][o'][f]
-int wn_aux_bwd(const float* dP, const float* G, long g_bstride, const float* upw, float* dG, float* dw_partial,
-               int B, int T, int R2, int U, int F, wn_stream_t st);
+// Batched over nl layers (grid.z): dP += l*dp_lstride, G += l*R2*F (layer rows inside the per-batch G
+// block), dG += l*B*R2*F, dw_partial += l*B*R2*U.
+int wn_aux_bwd(const float* dP, long dp_lstride, const float* G, long g_bstride, const float* upw, float* dG,
+               float* dw_partial, int B, int T, int R2, int U, int F, int nl, wn_stream_t st);
 
 // out[map(m,n)] (=|+=) scale * sum_z partial[z][m*N+n] (+ addend_m[m]*addend_scale)
 // map(m,n) = (m/m_seg)*m_seg_stride + (m%m_seg)*m_stride + (n/n_seg)*n_seg_stride + (n%n_seg)*n_stride
@@ -75,6 +77,9 @@ typedef struct WnReduceArgs {
     const float* addend_scale_ptr;  // nullable device scalar multiplied onto addend_m
     float* scratch;        // nullable: second-level buffer for two-level reductions
     long scratch_floats;
+    int nl;                // layers (grid.z): partial += l*nz*M*N, out += l*out_lstride, addend_m += l*addend_lstride
+    long out_lstride;
+    long addend_lstride;
 } WnReduceArgs;
 int wn_reduce(const WnReduceArgs* a, wn_stream_t st);
 

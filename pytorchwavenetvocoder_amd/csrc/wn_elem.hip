@@ -261,15 +261,17 @@ int wn_sum_layers(const float* params, long off, long ls, int L, int n, float* o
 #define WN_AUX_FC 32        // frames per LDS chunk
 #define WN_AUX_MAXF 8192    // LDS floats per chunk (FC * U <= MAXF)
 #define WN_AUX_JMAX 4       // dw accumulators per thread: U <= 4 * 256
-__global__ __launch_bounds__(WN_TPB) void k_aux_bwd(const float* __restrict__ dP, const float* __restrict__ G, long g_bstride,
-                                                    const float* __restrict__ upw, float* __restrict__ dG,
+__global__ __launch_bounds__(WN_TPB) void k_aux_bwd(const float* __restrict__ dP, long dp_lstride, const float* __restrict__ G,
+                                                    long g_bstride, const float* __restrict__ upw, float* __restrict__ dG,
                                                     float* __restrict__ dw_partial, int T, int R2, int U, int F, int fc) {
     // One workgroup per (row o', batch b): the row of dP is streamed once, coalesced, through LDS
     // in chunks of fc frames; both reductions (over frames for dw[j], over j for dG[f]) read LDS.
     __shared__ float tile[WN_AUX_MAXF];
-    const int o = blockIdx.x, b = blockIdx.y;
-    const float* row = dP + ((long)b * R2 + o) * T;
-    const float* grow = G + (long)b * g_bstride + (long)o * F;
+    const int o = blockIdx.x, b = blockIdx.y, l = blockIdx.z, nb = gridDim.y;
+    const float* row = dP + (long)l * dp_lstride + ((long)b * R2 + o) * T;
+    const float* grow = G + (long)b * g_bstride + ((long)l * R2 + o) * F;
+    dG += (long)l * nb * R2 * F;
+    dw_partial += (long)l * nb * R2 * U;
     float accw[WN_AUX_JMAX];
     WN_UNROLL
     for (int i = 0; i < WN_AUX_JMAX; ++i) accw[i] = 0.0f;
@@ -310,16 +312,16 @@ __global__ __launch_bounds__(WN_TPB) void k_aux_bwd(const float* __restrict__ dP
     }
 }
 
-int wn_aux_bwd(const float* dP, const float* G, long g_bstride, const float* upw, float* dG, float* dw_partial, int B, int T,
-               int R2, int U, int F, wn_stream_t st) {
-    WN_PROF("aux_bwd", 0.0, (double)B * R2 * T * 4.0, st);
+int wn_aux_bwd(const float* dP, long dp_lstride, const float* G, long g_bstride, const float* upw, float* dG, float* dw_partial,
+               int B, int T, int R2, int U, int F, int nl, wn_stream_t st) {
+    WN_PROF("aux_bwd", 0.0, (double)nl * B * R2 * T * 4.0, st);
     if ((long)U * F != T) return 1;
     if (U > WN_AUX_JMAX * WN_TPB || U > WN_AUX_MAXF) return 2;
     int fc = WN_AUX_MAXF / U;
     if (fc > WN_AUX_FC) fc = WN_AUX_FC;
     if (fc < 1) fc = 1;
-    WN_LAUNCH(k_aux_bwd, dim3((unsigned)R2, (unsigned)B), dim3(WN_TPB), 0, st, dP, G, g_bstride, upw, dG, dw_partial, T, R2, U,
-              F, fc);
+    WN_LAUNCH(k_aux_bwd, dim3((unsigned)R2, (unsigned)B, (unsigned)nl), dim3(WN_TPB), 0, st, dP, dp_lstride, G, g_bstride, upw,
+              dG, dw_partial, T, R2, U, F, fc);
     return 0;
 }
 
@@ -332,6 +334,8 @@ __global__ __launch_bounds__(WN_TPB) void k_reduce(WnReduceArgs a, const float* 
     __shared__ float red[8][33];
     const long mn = (long)a.M * a.N;
     const int il = threadIdx.x & 31, zg = threadIdx.x >> 5;
+    const int l = blockIdx.z;
+    src += (long)l * nz * mn;
     const long i = (long)blockIdx.x * 32 + il;
     const int zbeg = blockIdx.y * zchunk;
     int zend = zbeg + zchunk;
@@ -353,21 +357,22 @@ __global__ __launch_bounds__(WN_TPB) void k_reduce(WnReduceArgs a, const float* 
     const int m = (int)(i / a.N), n = (int)(i % a.N);
     if (a.addend_m != nullptr) {
         const float sc = a.addend_scale_ptr ? a.addend_scale_ptr[0] : 1.0f;
-        s += a.addend_m[m] * sc;
+        s += a.addend_m[(long)l * a.addend_lstride + m] * sc;
     }
-    const long o = (long)(m / a.m_seg) * a.m_seg_stride + (long)(m % a.m_seg) * a.m_stride +
+    const long o = (long)l * a.out_lstride + (long)(m / a.m_seg) * a.m_seg_stride + (long)(m % a.m_seg) * a.m_stride +
                    (long)(n / a.n_seg) * a.n_seg_stride + (long)(n % a.n_seg) * a.n_stride;
     if (a.accumulate) s += a.out[o];
     a.out[o] = s;
 }
 
 int wn_reduce(const WnReduceArgs* a, wn_stream_t st) {
-    WN_PROF("reduce_partials", 0.0, (double)a->nz * a->M * a->N * 4.0, st);
+    WN_PROF("reduce_partials", 0.0, (double)(a->nl > 0 ? a->nl : 1) * a->nz * a->M * a->N * 4.0, st);
     const long mn = (long)a->M * a->N;
     if (mn <= 0 || a->m_seg <= 0 || a->n_seg <= 0) return 1;
     const unsigned gx = (unsigned)((mn + 31) / 32);
     // two levels when there are few outputs but very many partials (keeps the machine busy)
-    if (a->scratch != nullptr && a->nz >= 512 && gx < 512) {
+    const int nl = a->nl > 0 ? a->nl : 1;
+    if (nl == 1 && a->scratch != nullptr && a->nz >= 512 && gx < 512) {
         int zchunk = 128;
         const int nchunk = (a->nz + zchunk - 1) / zchunk;
         if ((long)nchunk * mn <= a->scratch_floats) {
@@ -376,7 +381,7 @@ int wn_reduce(const WnReduceArgs* a, wn_stream_t st) {
             return 0;
         }
     }
-    WN_LAUNCH(k_reduce, dim3(gx, 1), dim3(WN_TPB), 0, st, *a, a->partial, a->nz, a->nz, (float*)nullptr);
+    WN_LAUNCH(k_reduce, dim3(gx, 1, (unsigned)nl), dim3(WN_TPB), 0, st, *a, a->partial, a->nz, a->nz, (float*)nullptr);
     return 0;
 }
 

@@ -26,6 +26,14 @@
 
 #include "wn_prof.h"
 
+#include <stdlib.h>
+
+// tuning knob (A/B on hardware): WN_STAGGER=<n> delays the second wave of every SIMD by n x 8128 cycles
+static int stagger_setting() {
+    const char* e = getenv("WN_STAGGER");
+    return e ? atoi(e) : 3;
+}
+
 #define WN_FT 512  // threads per workgroup (8 waves)
 
 // channel handled by k-step s (0..31 within a 64-channel group) for lane-half hi
@@ -79,6 +87,7 @@ struct FwdArgs {
     float* Gt;
     float* Z;
     int B, T, dil, U, F;
+    int stagger;  // waves 4..7 (the second wave of each SIMD) start `stagger` x 8K cycles late
 };
 
 template <int K>
@@ -93,6 +102,12 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
     if (threadIdx.x < 128) cv[threadIdx.x] = a.cvec[threadIdx.x];
     if (threadIdx.x < 64) rb[threadIdx.x] = a.res_bias[threadIdx.x];
     __syncthreads();
+    // De-phase the two waves that share a SIMD (waves w and w+4): started together they would run
+    // their MFMA phases and their gate/store phases in lock step and leave the matrix pipe idle
+    // during the latter; half a tile of head start makes one wave's VALU/VMEM phase coincide with
+    // the other's MFMA phase.
+    if (WN_UNIFORM((int)(threadIdx.x >> 8)) != 0)
+        for (int i = 0; i < a.stagger; ++i) WN_SLEEP(127);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, hi = lane >> 5;
@@ -272,6 +287,7 @@ int wn_fused_resblock_fwd(const float* wd_f, const float* wres_f, const float* c
     a.X = X; a.G = G; a.g_bstride = g_bstride; a.upw = upw;
     a.Xnext = Xnext; a.S = S; a.Gt = Gt; a.Z = Z;
     a.B = B; a.T = T; a.dil = dilation; a.U = U; a.F = F;
+    a.stagger = stagger_setting();
     switch (K) {
         case 1: return launch_fwd<1>(a, st);
         case 2: return launch_fwd<2>(a, st);
@@ -300,6 +316,7 @@ struct ConvArgs {
     const float* Gt;     // MODE 0
     const float* resid;  // MODE 1 (nullable)
     float* out;          // MODE 0: dP (B,128,T) ; MODE 1: dX (B,64,T)
+    int stagger;
 };
 
 template <int MODE>
@@ -308,6 +325,12 @@ __global__ __launch_bounds__(WN_FT) void k_conv64(ConvArgs a) {
     float* W = reinterpret_cast<float*>(smem_raw);
     for (int sg = 0; sg < a.nseg; ++sg) stage_copy(W + a.seg[sg].woff, a.seg[sg].w, a.seg[sg].nch * 64);
     __syncthreads();
+    // De-phase the two waves that share a SIMD (waves w and w+4): started together they would run
+    // their MFMA phases and their gate/store phases in lock step and leave the matrix pipe idle
+    // during the latter; half a tile of head start makes one wave's VALU/VMEM phase coincide with
+    // the other's MFMA phase.
+    if (WN_UNIFORM((int)(threadIdx.x >> 8)) != 0)
+        for (int i = 0; i < a.stagger; ++i) WN_SLEEP(127);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, hi = lane >> 5;
@@ -466,6 +489,7 @@ int wn_fused_bwd_gate(const float* wskip, const float* wres, const float* dSk, c
         a.nchunks += 2;
     }
     a.B = B; a.T = T; a.S = S; a.Gt = Gt; a.resid = nullptr; a.out = dP;
+    a.stagger = stagger_setting();
     return launch_conv64<0>(a, st);
 }
 
@@ -485,5 +509,6 @@ int wn_fused_bwd_dx(const float* wd_b, const float* dP, const float* dXn, float*
     a.wfloats = K * 128 * 64;
     a.nchunks = K * 4;
     a.B = B; a.T = T; a.S = nullptr; a.Gt = nullptr; a.resid = dXn; a.out = dX;
+    a.stagger = stagger_setting();
     return launch_conv64<1>(a, st);
 }

@@ -55,6 +55,14 @@ typedef struct WnGemmArgs {
     int kchunk;       // k range of split ks: [ks*kchunk, min(K, (ks+1)*kchunk))
     float* a_rowsum;  // optional [nz][M]: sum_k A(m,k) over this z's k range (a_kmajor=1 only)
     const char* tag;  // static string naming the call site (profiling); may be null
+    // optional outer "layer" dimension: z = (layer*nbatch + b)*ksplit + ks.  Layer li adds
+    // li*a_lstride / li*b_lstride to the operand bases; if b_dil_depth > 0 the shifts are scaled by
+    // the layer's dilation 2^((b_layer0 + li) % b_dil_depth)  (reference wavenet.py:184).
+    int nlayer;
+    long a_lstride;
+    long b_lstride;
+    int b_dil_depth;
+    int b_layer0;
 } WnGemmArgs;
 
 static inline WnGemmArgs wn_gemm_default() {
@@ -70,6 +78,7 @@ static inline WnGemmArgs wn_gemm_default() {
     g.nbatch = 1; g.ksplit = 1; g.kchunk = 0x7fffffff;
     g.a_rowsum = 0;
     g.tag = 0;
+    g.nlayer = 1; g.a_lstride = 0; g.b_lstride = 0; g.b_dil_depth = 0; g.b_layer0 = 0;
     return g;
 }
 

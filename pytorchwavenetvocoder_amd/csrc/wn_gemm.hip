@@ -53,13 +53,17 @@ __global__ __launch_bounds__(WN_GEMM_THREADS, 3) void wn_gemm_kernel(WnGemmArgs 
     const int li = lane & 31, hi = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int z = blockIdx.z;
-    const int b = z / g.ksplit;
-    const int ks = z - b * g.ksplit;
+    const int zl = z / (g.nbatch * g.ksplit);            // layer (outermost)
+    const int zr = z - zl * (g.nbatch * g.ksplit);
+    const int b = zr / g.ksplit;
+    const int ks = zr - b * g.ksplit;
+    const int dmul = (g.b_dil_depth > 0) ? (1 << ((g.b_layer0 + zl) % g.b_dil_depth)) : 1;
+    const int sh0 = g.b_shift0 * dmul, shstep = g.b_shift_step * dmul;
     const int kbeg = ks * g.kchunk;
     const int kend = (g.K - kbeg > g.kchunk) ? (kbeg + g.kchunk) : g.K;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const float* __restrict__ Az = g.A + (long)b * g.a_zstride;
-    const float* __restrict__ Bz = g.B + (long)b * g.b_zstride;
+    const float* __restrict__ Az = g.A + (long)zl * g.a_lstride + (long)b * g.a_zstride;
+    const float* __restrict__ Bz = g.B + (long)zl * g.b_lstride + (long)b * g.b_zstride;
     const bool one_seg = (g.b_seg_len >= (KMAJ ? g.N : g.K));
 
     float ra[GA::NE], rb[GB::NE];
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(WN_GEMM_THREADS, 3) void wn_gemm_kernel(WnGemmArgs 
                 rr = n - seg * g.b_seg_len;
             }
             b_rowoff[i] = (n < g.N) ? ((long)seg * g.b_seg_stride + (long)rr * g.ldb) : -1;
-            b_rowshift[i] = g.b_shift0 + seg * g.b_shift_step;
+            b_rowshift[i] = sh0 + seg * shstep;
             b_rowrr[i] = rr;
         }
         __syncthreads();
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(WN_GEMM_THREADS, 3) void wn_gemm_kernel(WnGemmArgs 
                     seg = k0 / g.b_seg_len;
                     rr0 = k0 - seg * g.b_seg_len;
                 }
-                const int cc = n - (g.b_shift0 + seg * g.b_shift_step);
+                const int cc = n - (sh0 + seg * shstep);
                 const bool cok = nok && cc >= 0 && cc < g.b_clen;
                 const float* pb = Bz + (long)seg * g.b_seg_stride + (long)(rr0 + b_row0) * g.ldb + cc;
                 const long bstep = (long)B_RPP * g.ldb;
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(WN_GEMM_THREADS, 3) void wn_gemm_kernel(WnGemmArgs 
                     const int k = k0 + b_row0 + e * B_RPP;
                     const int seg = k / g.b_seg_len;
                     const int rr = k - seg * g.b_seg_len;
-                    const int cc = n - (g.b_shift0 + seg * g.b_shift_step);
+                    const int cc = n - (sh0 + seg * shstep);
                     const bool ok = nok && k < kend && cc >= 0 && cc < g.b_clen;
                     float v = ok ? Bz[(long)seg * g.b_seg_stride + (long)rr * g.ldb + cc] : 0.0f;
                     if (g.b_relu) v = fmaxf(v, 0.0f);
@@ -273,18 +277,18 @@ __global__ __launch_bounds__(WN_GEMM_THREADS, 3) void wn_gemm_kernel(WnGemmArgs 
 template <int TM, int TN, int KMAJ, int ONEHOT>
 static void launch_variant(const WnGemmArgs& g, wn_stream_t stream) {
     dim3 grid((unsigned)((g.N + 64 * TN - 1) / (64 * TN)), (unsigned)((g.M + 64 * TM - 1) / (64 * TM)),
-              (unsigned)(g.nbatch * g.ksplit));
+              (unsigned)(g.nlayer * g.nbatch * g.ksplit));
     dim3 block(WN_GEMM_THREADS);
     WN_LAUNCH((wn_gemm_kernel<TM, TN, KMAJ, ONEHOT>), grid, block, 0, stream, g);
 }
 
 int wn_gemm_launch(const WnGemmArgs* gp, wn_stream_t stream) {
     const WnGemmArgs& g = *gp;
-    if (g.M <= 0 || g.N <= 0 || g.K < 0 || g.nbatch <= 0 || g.ksplit <= 0) return 1;
+    if (g.M <= 0 || g.N <= 0 || g.K < 0 || g.nbatch <= 0 || g.ksplit <= 0 || g.nlayer <= 0) return 1;
     if (g.a_kmajor != g.b_kmajor) return 2;
     if (g.b_seg_len <= 0 || g.kchunk <= 0) return 3;
     const int tm = g.M > 64 ? 2 : 1, tn = g.N > 64 ? 2 : 1;
-    WN_PROF(g.tag ? g.tag : "gemm", 2.0 * g.M * g.N * (double)g.K * g.nbatch, 0.0, stream);
+    WN_PROF(g.tag ? g.tag : "gemm", 2.0 * g.M * g.N * (double)g.K * g.nbatch * g.nlayer, 0.0, stream);
     if (g.b_index != nullptr) {
         if (!g.a_kmajor) return 4;  // the one-hot operand exists for the dW (k = time) mode only
         if (tm == 2 && tn == 2) launch_variant<2, 2, 1, 1>(g, stream);

@@ -23,7 +23,7 @@ TOL_GRAD = 1e-4
 TOL_ADAM_REL_LR = 1e-2  # |w - w_ref| <= 1e-2 * lr  (= SURVEY's 1e-6 at the reference's lr=1e-4)
 
 
-def check_golden_case(g, lib, device, flags=0):
+def check_golden_case(g, lib, device, flags=0, layers_per_bucket=0):
     """Engine-level (C-ABI) forward / loss / backward against a golden case."""
     eng = WaveNetEngine(*g.cfg.as_tuple(), device=device, library=lib)
     eng.flags = flags
@@ -36,7 +36,7 @@ def check_golden_case(g, lib, device, flags=0):
     assert err <= TOL_LOGITS, "logits max-abs err %g" % err
     loss, dl = eng.loss(logits, t)
     assert abs(float(loss.cpu()) - g.loss) <= TOL_LOSS
-    grads = flat_to_state(eng, eng.backward(dl).cpu(), O.param_shapes(g.cfg))
+    grads = flat_to_state(eng, eng.backward(dl, layers_per_bucket=layers_per_bucket).cpu(), O.param_shapes(g.cfg))
     for k, ref in g.grads.items():
         if ref is None:
             assert float(grads[k].abs().max()) == 0.0, k

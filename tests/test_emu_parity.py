@@ -28,6 +28,12 @@ def test_layered_path_vs_golden_r64(name):
     PC.check_golden_case(GoldenCase(name), emu_library(), "cpu", flags=_lib.FLAG_NO_FUSED)
 
 
+@pytest.mark.parametrize("name,lpb", [("tiny_k2_up", 4), ("tiny_k2_up", 1), ("r64_k2_up", 3), ("tiny_k3_noup", 2)])
+def test_bucketed_backward(name, lpb):
+    """Gradient buckets (layer-batched weight-gradient launches) of any size give the same result."""
+    PC.check_golden_case(GoldenCase(name), emu_library(), "cpu", layers_per_bucket=lpb)
+
+
 def test_ragged_T_and_odd_channels():
     # T not a multiple of any tile, channel counts not multiples of 32, B=3
     PC.run_oracle_vs_engine((37, 7, 12, 20, 2, 2, 2, 0), 3, 77, 5, emu_library(), "cpu")
