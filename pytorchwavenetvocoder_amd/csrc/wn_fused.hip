@@ -31,7 +31,7 @@
 // tuning knob (A/B on hardware): WN_STAGGER=<n> delays the second wave of every SIMD by n x 8128 cycles
 static int stagger_setting() {
     const char* e = getenv("WN_STAGGER");
-    return e ? atoi(e) : 3;
+    return e ? atoi(e) : 0;  // measured on MI355X (profiles/r01): 0 -> 19.8 ms, 1 -> 20.0, 3 -> 20.1, 5 -> 20.5 ms per step
 }
 
 #define WN_FT 512  // threads per workgroup (8 waves)
