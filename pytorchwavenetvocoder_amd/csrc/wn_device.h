@@ -32,6 +32,8 @@ static inline void wn_buf_store(wn_rsrc_t r, float v, int voff, int soff) { *(fl
 #define WN_UNIFORM(x) (x)
 #define WN_SCHED_BARRIER()
 #define WN_SLEEP(n)
+#define WN_SGB_DS(n)
+#define WN_SGB_MFMA(n)
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -61,6 +63,9 @@ static __device__ __forceinline__ void wn_buf_store(wn_rsrc_t r, float v, int vo
 // scheduling fence: hipcc may not move instructions across it (pins software-pipeline issue order)
 #define WN_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #define WN_SLEEP(n) __builtin_amdgcn_s_sleep(n)
+// scheduling groups: "the next n DS reads" / "the next n MFMAs" are emitted as a block in this order
+#define WN_SGB_DS(n) __builtin_amdgcn_sched_group_barrier(0x100, (n), 0)
+#define WN_SGB_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, (n), 0)
 #define WN_UNROLL _Pragma("unroll")
 #define WN_PRAGMA(x) _Pragma(#x)
 #define WN_UNROLL_N(n) WN_PRAGMA(unroll n)

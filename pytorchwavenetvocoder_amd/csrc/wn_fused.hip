@@ -169,12 +169,33 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
         WN_UNROLL
         for (int tap = 0; tap + 1 < K; ++tap) {
             const float* Wt = Wd + tap * 64 * 128 + 4 * hi * 128 + li;
+            // ping-pong LDS operand sets: the reads of k-step s+1 are in flight during the MFMAs of step s
+            float a0[4], a1[4];
             WN_UNROLL
-            for (int s = 0; s < 32; ++s) {
-                const float* wrow = Wt + kappa64(s, 0) * 128;
-                const float xv = okh[tap] ? xh[tap][s] : 0.0f;
+            for (int q = 0; q < 4; ++q) a0[q] = Wt[kappa64(0, 0) * 128 + 32 * q];
+            WN_SGB_DS(2);  // prologue group: from here on every [DS][MFMA] pair = (next operands, current MFMAs)
+            WN_UNROLL
+            for (int s = 0; s < 32; s += 2) {
                 WN_UNROLL
-                for (int q = 0; q < 4; ++q) acc[q] = mfma32(wrow[32 * q], xv, acc[q]);
+                for (int q = 0; q < 4; ++q) a1[q] = Wt[kappa64(s + 1, 0) * 128 + 32 * q];
+                {
+                    const float xv = okh[tap] ? xh[tap][s] : 0.0f;
+                    WN_UNROLL
+                    for (int q = 0; q < 4; ++q) acc[q] = mfma32(a0[q], xv, acc[q]);
+                }
+                WN_SGB_DS(2);
+                WN_SGB_MFMA(4);
+                if (s + 2 < 32) {
+                    WN_UNROLL
+                    for (int q = 0; q < 4; ++q) a0[q] = Wt[kappa64(s + 2, 0) * 128 + 32 * q];
+                }
+                {
+                    const float xv = okh[tap] ? xh[tap][s + 1] : 0.0f;
+                    WN_UNROLL
+                    for (int q = 0; q < 4; ++q) acc[q] = mfma32(a1[q], xv, acc[q]);
+                }
+                WN_SGB_DS(2);
+                WN_SGB_MFMA(4);
             }
         }
         // aux / gate inputs (frame rate, L2 resident), first 32 gate channels
@@ -192,12 +213,33 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
         // current tap; xc is also the residual input, already in D layout
         {
             const float* Wt = Wd + (K - 1) * 64 * 128 + 4 * hi * 128 + li;
+            // ping-pong LDS operand sets: the reads of k-step s+1 are in flight during the MFMAs of step s
+            float a0[4], a1[4];
             WN_UNROLL
-            for (int s = 0; s < 32; ++s) {
-                const float* wrow = Wt + kappa64(s, 0) * 128;
-                const float xv = inb ? xc[s] : 0.0f;
+            for (int q = 0; q < 4; ++q) a0[q] = Wt[kappa64(0, 0) * 128 + 32 * q];
+            WN_SGB_DS(2);  // prologue group: from here on every [DS][MFMA] pair = (next operands, current MFMAs)
+            WN_UNROLL
+            for (int s = 0; s < 32; s += 2) {
                 WN_UNROLL
-                for (int q = 0; q < 4; ++q) acc[q] = mfma32(wrow[32 * q], xv, acc[q]);
+                for (int q = 0; q < 4; ++q) a1[q] = Wt[kappa64(s + 1, 0) * 128 + 32 * q];
+                {
+                    const float xv = inb ? xc[s] : 0.0f;
+                    WN_UNROLL
+                    for (int q = 0; q < 4; ++q) acc[q] = mfma32(a0[q], xv, acc[q]);
+                }
+                WN_SGB_DS(2);
+                WN_SGB_MFMA(4);
+                if (s + 2 < 32) {
+                    WN_UNROLL
+                    for (int q = 0; q < 4; ++q) a0[q] = Wt[kappa64(s + 2, 0) * 128 + 32 * q];
+                }
+                {
+                    const float xv = inb ? xc[s + 1] : 0.0f;
+                    WN_UNROLL
+                    for (int q = 0; q < 4; ++q) acc[q] = mfma32(a1[q], xv, acc[q]);
+                }
+                WN_SGB_DS(2);
+                WN_SGB_MFMA(4);
             }
         }
         WN_SCHED_BARRIER();
@@ -247,12 +289,31 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
         // res 1x1 + residual; z is consumed straight from the accumulator registers
         if (a.Xnext != nullptr) {
             const float* Wrl = Wr + 4 * hi * 64 + li;
+            // stage = two k-steps (4 LDS operands, 4 MFMAs); ping-pong operand sets as above
+            float a0[4], a1[4];
             WN_UNROLL
-            for (int s = 0; s < 32; ++s) {
-                const float* wrow = Wrl + kappa64(s, 0) * 64;
-                const float bz = z[s >> 4][s & 15];
+            for (int q = 0; q < 4; ++q) a0[q] = Wrl[kappa64(q >> 1, 0) * 64 + 32 * (q & 1)];
+            WN_SGB_DS(2);
+            WN_UNROLL
+            for (int s = 0; s < 32; s += 4) {
                 WN_UNROLL
-                for (int q = 0; q < 2; ++q) racc[q] = mfma32(wrow[32 * q], bz, racc[q]);
+                for (int q = 0; q < 4; ++q) a1[q] = Wrl[kappa64(s + 2 + (q >> 1), 0) * 64 + 32 * (q & 1)];
+                racc[0] = mfma32(a0[0], z[s >> 4][s & 15], racc[0]);
+                racc[1] = mfma32(a0[1], z[s >> 4][s & 15], racc[1]);
+                racc[0] = mfma32(a0[2], z[(s + 1) >> 4][(s + 1) & 15], racc[0]);
+                racc[1] = mfma32(a0[3], z[(s + 1) >> 4][(s + 1) & 15], racc[1]);
+                WN_SGB_DS(2);
+                WN_SGB_MFMA(4);
+                if (s + 4 < 32) {
+                    WN_UNROLL
+                    for (int q = 0; q < 4; ++q) a0[q] = Wrl[kappa64(s + 4 + (q >> 1), 0) * 64 + 32 * (q & 1)];
+                }
+                racc[0] = mfma32(a1[0], z[(s + 2) >> 4][(s + 2) & 15], racc[0]);
+                racc[1] = mfma32(a1[1], z[(s + 2) >> 4][(s + 2) & 15], racc[1]);
+                racc[0] = mfma32(a1[2], z[(s + 3) >> 4][(s + 3) & 15], racc[0]);
+                racc[1] = mfma32(a1[3], z[(s + 3) >> 4][(s + 3) & 15], racc[1]);
+                WN_SGB_DS(2);
+                WN_SGB_MFMA(4);
             }
             if (inb) {
                 const wn_rsrc_t Xn = wn_make_buf(a.Xnext + (long)b * 64 * T, slab);
@@ -373,12 +434,38 @@ __global__ __launch_bounds__(WN_FT) void k_conv64(ConvArgs a) {
         int sg, c0;
         locate(q, sg, c0);
         const float* Wl = W + a.seg[sg].woff + (c0 + hi) * 64 + li;
+        // stage = two k-steps (4 LDS operands, 4 MFMAs); ping-pong operand sets: the reads of the next
+        // stage are in flight during the MFMAs of the current one
+        float a0[4], a1[4];
         WN_UNROLL
-        for (int s = 0; s < 16; ++s) {
-            const float xv = okr ? xr[s] : 0.0f;
-            const float* wrow = Wl + (2 * s) * 64;
-            acc[0] = mfma32(wrow[0], xv, acc[0]);
-            acc[1] = mfma32(wrow[32], xv, acc[1]);
+        for (int q = 0; q < 4; ++q) a0[q] = Wl[(2 * (q >> 1)) * 64 + 32 * (q & 1)];
+        WN_SGB_DS(2);
+        WN_UNROLL
+        for (int s = 0; s < 16; s += 4) {
+            WN_UNROLL
+            for (int q = 0; q < 4; ++q) a1[q] = Wl[(2 * (s + 2 + (q >> 1))) * 64 + 32 * (q & 1)];
+            {
+                const float xv0 = okr ? xr[s] : 0.0f, xv1 = okr ? xr[s + 1] : 0.0f;
+                acc[0] = mfma32(a0[0], xv0, acc[0]);
+                acc[1] = mfma32(a0[1], xv0, acc[1]);
+                acc[0] = mfma32(a0[2], xv1, acc[0]);
+                acc[1] = mfma32(a0[3], xv1, acc[1]);
+            }
+            WN_SGB_DS(2);
+            WN_SGB_MFMA(4);
+            if (s + 4 < 16) {
+                WN_UNROLL
+                for (int q = 0; q < 4; ++q) a0[q] = Wl[(2 * (s + 4 + (q >> 1))) * 64 + 32 * (q & 1)];
+            }
+            {
+                const float xv0 = okr ? xr[s + 2] : 0.0f, xv1 = okr ? xr[s + 3] : 0.0f;
+                acc[0] = mfma32(a1[0], xv0, acc[0]);
+                acc[1] = mfma32(a1[1], xv0, acc[1]);
+                acc[0] = mfma32(a1[2], xv1, acc[0]);
+                acc[1] = mfma32(a1[3], xv1, acc[1]);
+            }
+            WN_SGB_DS(2);
+            WN_SGB_MFMA(4);
         }
     };
 
