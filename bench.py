@@ -201,8 +201,15 @@ def main():
         if dom is not None:
             v = prof[dom]
             ach = v["flops"] / (v["ms"] * 1e-3) / 1e12
+            traffic = None  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/pmc_traffic.json)
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as fh:
+                    traffic = json.load(fh).get(dom, {}).get("hbm_bytes_per_launch")
+            except (OSError, ValueError):
+                pass
             roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK / 1e12,
-                        "unit": "TFLOP/s", "frac": ach / (F32_MFMA_PEAK / 1e12), "traffic": None,
+                        "unit": "TFLOP/s", "frac": ach / (F32_MFMA_PEAK / 1e12), "traffic": traffic,
+                        "traffic_note": "bytes/launch, (2*FETCH_SIZE+WRITE_SIZE)*1024 from separate --pmc passes",
                         "avg_launch_ms": v["ms"] / v["count"], "flop_per_launch": v["flops"] / v["count"],
                         "dtype_peak": "f32-input MFMA (v_mfma_f32_32x32x2_f32), dense 157.3 TFLOP/s",
                         "step_hbm_frac": timesteps_per_s_gpu * ALG_BYTES_PER_TIMESTEP / HBM_PEAK,
