@@ -258,57 +258,63 @@ int wn_sum_layers(const float* params, long off, long ls, int L, int n, float* o
 }
 
 // ---------------------------------------------------------------------------------------------
-#define WN_AUX_FC 32        // frames per LDS chunk
-#define WN_AUX_MAXF 8192    // LDS floats per chunk (FC * U <= MAXF)
-#define WN_AUX_JMAX 4       // dw accumulators per thread: U <= 4 * 256
+// NJ = phases per lane (U <= 64*NJ), UNR = frames in flight per wave
+template <int NJ, int UNR>
 __global__ __launch_bounds__(WN_TPB) void k_aux_bwd(const float* __restrict__ dP, long dp_lstride, const float* __restrict__ G,
                                                     long g_bstride, const float* __restrict__ upw, float* __restrict__ dG,
-                                                    float* __restrict__ dw_partial, int T, int R2, int U, int F, int fc) {
-    // One workgroup per (row o', batch b): the row of dP is streamed once, coalesced, through LDS
-    // in chunks of fc frames; both reductions (over frames for dw[j], over j for dG[f]) read LDS.
-    __shared__ float tile[WN_AUX_MAXF];
-    const int o = blockIdx.x, b = blockIdx.y, l = blockIdx.z, nb = gridDim.y;
+                                                    float* __restrict__ dw_partial, int T, int R2, int U, int F) {
+    constexpr int nj = NJ;
+    // One WAVE per (row o', batch b, layer l): lanes run along the phase j = t % U (coalesced row
+    // segments of U floats per frame), UNR frames are in flight at a time.  Per frame the wave
+    // reduces sum_j w[j] dP[fU+j] (-> dG[f]); per lane it accumulates dP[fU+j] * G[f] over the frames
+    // (-> dw[j]).  No LDS, no block barriers: the kernel is a pure HBM stream of dP.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int o = blockIdx.x * 4 + wave;
+    const int b = blockIdx.y, l = blockIdx.z, nb = gridDim.y;
+    if (o >= R2) return;  // whole wave leaves together (o is wave-uniform)
     const float* row = dP + (long)l * dp_lstride + ((long)b * R2 + o) * T;
     const float* grow = G + (long)b * g_bstride + ((long)l * R2 + o) * F;
-    dG += (long)l * nb * R2 * F;
-    dw_partial += (long)l * nb * R2 * U;
-    float accw[WN_AUX_JMAX];
+    float* dgrow = dG + (long)l * nb * R2 * F + ((long)b * R2 + o) * F;
+    float* dwrow = dw_partial + (long)l * nb * R2 * U + ((long)b * R2 + o) * U;
+    float wj[NJ], accw[NJ];
     WN_UNROLL
-    for (int i = 0; i < WN_AUX_JMAX; ++i) accw[i] = 0.0f;
-    const int fsub = threadIdx.x >> 3, jp = threadIdx.x & 7;  // pass 2: 32 frames x 8 partial sums
-    for (int f0 = 0; f0 < F; f0 += fc) {
-        const int nf = (F - f0 < fc) ? (F - f0) : fc;
-        const int n = nf * U;
-        const float* src = row + (long)f0 * U;
-        for (int i = threadIdx.x; i < n; i += WN_TPB) tile[i] = src[i];
-        __syncthreads();
-        // pass 1: dw[j] += sum_f dP[f*U + j] * G[f]
+    for (int i = 0; i < NJ; ++i) {
+        const int j = lane + 64 * i;
+        wj[i] = (i < nj && j < U) ? upw[j] : 0.0f;
+        accw[i] = 0.0f;
+    }
+    for (int f0 = 0; f0 < F; f0 += UNR) {
+        float v[UNR][NJ];
+        float gf[UNR];
         WN_UNROLL
-        for (int i = 0; i < WN_AUX_JMAX; ++i) {
-            const int j = threadIdx.x + i * WN_TPB;
-            if (j < U) {
-                float a = accw[i];
-                for (int f = 0; f < nf; ++f) a += tile[f * U + j] * grow[f0 + f];
-                accw[i] = a;
+        for (int u = 0; u < UNR; ++u) {
+            const int f = f0 + u;
+            const bool fok = f < F;
+            gf[u] = fok ? grow[f] : 0.0f;
+            WN_UNROLL
+            for (int i = 0; i < NJ; ++i) {
+                const int j = lane + 64 * i;
+                v[u][i] = (i < nj && fok && j < U) ? row[(long)f * U + j] : 0.0f;
             }
         }
-        // pass 2: dG[f] = sum_j w[j] dP[f*U + j]   (8 lanes per frame, xor-shuffle tree)
-        for (int fb = 0; fb < nf; fb += 32) {
-            const int f = fb + fsub;
-            float a = 0.0f;
-            if (f < nf)
-                for (int j = jp; j < U; j += 8) a += upw[j] * tile[f * U + j];
-            a += __shfl_xor(a, 1, 64);
-            a += __shfl_xor(a, 2, 64);
-            a += __shfl_xor(a, 4, 64);
-            if (jp == 0 && f < nf) dG[((long)b * R2 + o) * F + f0 + f] = a;
+        WN_UNROLL
+        for (int u = 0; u < UNR; ++u) {
+            float sdot = 0.0f;
+            WN_UNROLL
+            for (int i = 0; i < NJ; ++i) {
+                if (i < nj) {
+                    accw[i] += v[u][i] * gf[u];
+                    sdot += wj[i] * v[u][i];
+                }
+            }
+            sdot = wave_reduce_sum(sdot);
+            if (lane == 0 && f0 + u < F) dgrow[f0 + u] = sdot;
         }
-        __syncthreads();
     }
     WN_UNROLL
-    for (int i = 0; i < WN_AUX_JMAX; ++i) {
-        const int j = threadIdx.x + i * WN_TPB;
-        if (j < U) dw_partial[((long)b * R2 + o) * U + j] = accw[i];
+    for (int i = 0; i < NJ; ++i) {
+        const int j = lane + 64 * i;
+        if (i < nj && j < U) dwrow[j] = accw[i];
     }
 }
 
@@ -316,16 +322,21 @@ int wn_aux_bwd(const float* dP, long dp_lstride, const float* G, long g_bstride,
                int B, int T, int R2, int U, int F, int nl, wn_stream_t st) {
     WN_PROF("aux_bwd", 0.0, (double)nl * B * R2 * T * 4.0, st);
     if ((long)U * F != T) return 1;
-    if (U > WN_AUX_JMAX * WN_TPB || U > WN_AUX_MAXF) return 2;
-    int fc = WN_AUX_MAXF / U;
-    if (fc > WN_AUX_FC) fc = WN_AUX_FC;
-    if (fc < 1) fc = 1;
-    WN_LAUNCH(k_aux_bwd, dim3((unsigned)R2, (unsigned)B, (unsigned)nl), dim3(WN_TPB), 0, st, dP, dp_lstride, G, g_bstride, upw,
-              dG, dw_partial, T, R2, U, F, fc);
+    const int nj = (U + 63) / 64;
+    if (nj > 16) return 2;
+    const dim3 grid((unsigned)((R2 + 3) / 4), (unsigned)B, (unsigned)nl), block(WN_TPB);
+    if (nj <= 1) {
+        WN_LAUNCH((k_aux_bwd<1, 16>), grid, block, 0, st, dP, dp_lstride, G, g_bstride, upw, dG, dw_partial, T, R2, U, F);
+    } else if (nj <= 2) {
+        WN_LAUNCH((k_aux_bwd<2, 8>), grid, block, 0, st, dP, dp_lstride, G, g_bstride, upw, dG, dw_partial, T, R2, U, F);
+    } else if (nj <= 4) {
+        WN_LAUNCH((k_aux_bwd<4, 4>), grid, block, 0, st, dP, dp_lstride, G, g_bstride, upw, dG, dw_partial, T, R2, U, F);
+    } else {
+        WN_LAUNCH((k_aux_bwd<16, 2>), grid, block, 0, st, dP, dp_lstride, G, g_bstride, upw, dG, dw_partial, T, R2, U, F);
+    }
     return 0;
 }
 
-// ---------------------------------------------------------------------------------------------
 // 32 outputs x 8 z-lanes per workgroup; the 8 partial sums are combined in a fixed order, so the
 // result is deterministic.  grid.y > 1 = first level of a two-level reduction (raw sums of one
 // z-chunk each into scratch[chunk][MN]); the mapped/scaled write happens in the last level.

@@ -45,8 +45,8 @@ __global__ __launch_bounds__(WN_GEMM_THREADS, 3) void wn_gemm_kernel(WnGemmArgs 
     constexpr int BM = 64 * TM, BN = 64 * TN;
     typedef TileGeom<BM, KMAJ> GA;
     typedef TileGeom<BN, KMAJ> GB;
-    __shared__ float As[GA::SIZE];
-    __shared__ float Bs[GB::SIZE];
+    __shared__ __attribute__((aligned(16))) float As[GA::SIZE];
+    __shared__ __attribute__((aligned(16))) float Bs[GB::SIZE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -108,7 +108,55 @@ __global__ __launch_bounds__(WN_GEMM_THREADS, 3) void wn_gemm_kernel(WnGemmArgs 
     const int b_col = KMAJ ? (tid % WN_BK) : (tid % BN);
     const int b_row0 = KMAJ ? (tid / WN_BK) : (tid / BN);
 
+    // 16-byte staging path for k-minor tiles (forward / dX type): a thread owns 4 consecutive columns,
+    // loads them with one global_load_dwordx4 and stores them with one ds_write_b128 -> 4x fewer VMEM,
+    // LDS-write and address instructions than the scalar path.  Used when the tile is interior and
+    // 16-byte aligned (block-uniform decisions), otherwise the scalar path below handles edges/shifts.
+    constexpr int A_TPR = BM / 4, B_TPR = BN / 4;                          // threads per tile row
+    constexpr int A_VRPP = WN_GEMM_THREADS / A_TPR, B_VRPP = WN_GEMM_THREADS / B_TPR;  // rows per pass
+    const bool a_vec = !KMAJ && (g.lda % 4 == 0) && (m0 + BM <= g.M) &&
+                       ((reinterpret_cast<uintptr_t>(Az) & 15) == 0);
+    const bool b_vec_static = !KMAJ && !ONEHOT && seg_aligned && (g.ldb % 4 == 0) && (g.b_seg_stride % 4 == 0) &&
+                              (n0 + BN <= g.N) && ((reinterpret_cast<uintptr_t>(Bz) & 15) == 0);
+    bool rb_vec = false;  // layout of the B registers currently held (set by fetch, used by the LDS store)
+
     auto fetch = [&](int k0) {
+        if (!KMAJ && a_vec) {
+            const int c4 = (tid % A_TPR) * 4, r0 = tid / A_TPR;
+            WN_UNROLL
+            for (int p4 = 0; p4 < GA::NE / 4; ++p4) {
+                const int k = k0 + r0 + p4 * A_VRPP;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < kend) v = *reinterpret_cast<const float4*>(Az + (long)k * g.lda + m0 + c4);
+                ra[4 * p4 + 0] = v.x; ra[4 * p4 + 1] = v.y; ra[4 * p4 + 2] = v.z; ra[4 * p4 + 3] = v.w;
+            }
+        }
+        if (!KMAJ) {
+            rb_vec = false;
+            if (b_vec_static) {
+                int seg = 0, rr0 = k0;
+                if (!one_seg) {
+                    seg = k0 / g.b_seg_len;
+                    rr0 = k0 - seg * g.b_seg_len;
+                }
+                const int cc0 = n0 - (sh0 + seg * shstep);
+                if ((cc0 % 4 == 0) && cc0 >= 0 && cc0 + BN <= g.b_clen) {
+                    rb_vec = true;
+                    const int c4 = (tid % B_TPR) * 4, r0 = tid / B_TPR;
+                    const float* base = Bz + (long)seg * g.b_seg_stride + cc0 + c4;
+                    WN_UNROLL
+                    for (int p4 = 0; p4 < GB::NE / 4; ++p4) {
+                        const int kr = r0 + p4 * B_VRPP;
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (k0 + kr < kend) v = *reinterpret_cast<const float4*>(base + (long)(rr0 + kr) * g.ldb);
+                        if (g.b_relu) {
+                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                        }
+                        rb[4 * p4 + 0] = v.x; rb[4 * p4 + 1] = v.y; rb[4 * p4 + 2] = v.z; rb[4 * p4 + 3] = v.w;
+                    }
+                }
+            }
+        }
         if (KMAJ) {
             // A[m][k]: column = k (fixed), rows = m
             const int k = k0 + a_col;
@@ -144,6 +192,7 @@ __global__ __launch_bounds__(WN_GEMM_THREADS, 3) void wn_gemm_kernel(WnGemmArgs 
                 rb[e] = v;
             }
         } else {
+          if (!a_vec) {
             // A[k][m]: column = m (fixed), rows = k
             const bool mok = (m0 + a_col) < g.M;
             const float* pa = Az + (long)(k0 + a_row0) * g.lda + (m0 + a_col);
@@ -154,6 +203,8 @@ __global__ __launch_bounds__(WN_GEMM_THREADS, 3) void wn_gemm_kernel(WnGemmArgs 
                 ra[e] = ok ? *pa : 0.0f;
                 pa += astep;
             }
+          }
+          if (!rb_vec) {
             // B[k][n]: column = n (fixed), rows = k
             const int n = n0 + b_col;
             const bool nok = n < g.N;
@@ -188,23 +239,40 @@ __global__ __launch_bounds__(WN_GEMM_THREADS, 3) void wn_gemm_kernel(WnGemmArgs 
                     rb[e] = v;
                 }
             }
+          }
         }
     };
 
     const int nk = (kend > kbeg) ? (kend - kbeg + WN_BK - 1) / WN_BK : 0;
     if (nk > 0) fetch(kbeg);
     for (int kt = 0; kt < nk; ++kt) {
-        WN_UNROLL
-        for (int e = 0; e < GA::NE; ++e) {
-            int kk, mn;
-            GA::coord(e, tid, kk, mn);
-            As[GA::soff(kk, mn)] = ra[e];
+        if (!KMAJ && a_vec) {
+            const int c4 = (tid % A_TPR) * 4, r0 = tid / A_TPR;
+            WN_UNROLL
+            for (int p4 = 0; p4 < GA::NE / 4; ++p4)
+                *reinterpret_cast<float4*>(&As[(r0 + p4 * A_VRPP) * BM + c4]) =
+                    make_float4(ra[4 * p4 + 0], ra[4 * p4 + 1], ra[4 * p4 + 2], ra[4 * p4 + 3]);
+        } else {
+            WN_UNROLL
+            for (int e = 0; e < GA::NE; ++e) {
+                int kk, mn;
+                GA::coord(e, tid, kk, mn);
+                As[GA::soff(kk, mn)] = ra[e];
+            }
         }
-        WN_UNROLL
-        for (int e = 0; e < GB::NE; ++e) {
-            int kk, mn;
-            GB::coord(e, tid, kk, mn);
-            Bs[GB::soff(kk, mn)] = rb[e];
+        if (!KMAJ && rb_vec) {
+            const int c4 = (tid % B_TPR) * 4, r0 = tid / B_TPR;
+            WN_UNROLL
+            for (int p4 = 0; p4 < GB::NE / 4; ++p4)
+                *reinterpret_cast<float4*>(&Bs[(r0 + p4 * B_VRPP) * BN + c4]) =
+                    make_float4(rb[4 * p4 + 0], rb[4 * p4 + 1], rb[4 * p4 + 2], rb[4 * p4 + 3]);
+        } else {
+            WN_UNROLL
+            for (int e = 0; e < GB::NE; ++e) {
+                int kk, mn;
+                GB::coord(e, tid, kk, mn);
+                Bs[GB::soff(kk, mn)] = rb[e];
+            }
         }
         __syncthreads();
         if (kt + 1 < nk) fetch(kbeg + (kt + 1) * WN_BK);

@@ -310,3 +310,4 @@ inline float __frcp_rn(float x) { return 1.0f / x; }
 struct float4 {
     float x, y, z, w;
 };
+inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }

@@ -40,6 +40,14 @@ def test_ragged_T_and_odd_channels():
     PC.run_oracle_vs_engine((37, 7, 12, 20, 3, 1, 3, 7), 2, 91, 6, emu_library(), "cpu")
 
 
+def test_vector_staging_paths():
+    """T large enough for interior 128-wide tiles: exercises the 16-byte staging path of the GEMM (and its
+    per-tile fallback to scalar loads for taps whose shift is not a multiple of 4)."""
+    from pytorchwavenetvocoder_amd import _lib
+    PC.run_oracle_vs_engine((64, 8, 64, 64, 3, 1, 2, 8), 1, 256, 9, emu_library(), "cpu")
+    PC.run_oracle_vs_engine((64, 8, 64, 64, 3, 1, 2, 8), 1, 256, 9, emu_library(), "cpu", flags=_lib.FLAG_NO_FUSED)
+
+
 def test_wide_channels_multi_tile():
     # R > 64 exercises the 128-wide tiles and multi-tile M
     PC.run_oracle_vs_engine((48, 9, 96, 160, 2, 1, 2, 4), 1, 72, 7, emu_library(), "cpu")

@@ -50,6 +50,12 @@ def test_ragged_and_odd_shapes_vs_oracle():
     PC.run_oracle_vs_engine((48, 9, 96, 160, 2, 1, 2, 4), 1, 72, 7, _lib(), DEV)
 
 
+def test_vector_staging_paths():
+    from pytorchwavenetvocoder_amd import _lib as L
+    PC.run_oracle_vs_engine((64, 8, 64, 64, 3, 1, 2, 8), 1, 256, 9, _lib(), DEV)
+    PC.run_oracle_vs_engine((64, 8, 64, 64, 3, 1, 2, 8), 1, 256, 9, _lib(), DEV, flags=L.FLAG_NO_FUSED)
+
+
 def test_reference_test_shapes():
     """The model shapes of the reference's own test/test_wavenet.py:31-71 (shape assertions)."""
     from pytorchwavenetvocoder_amd.nets import WaveNet, initialize
