@@ -86,7 +86,10 @@ __global__ __launch_bounds__(WN_GEMM_THREADS, 3) void wn_gemm_kernel(WnGemmArgs 
     __shared__ long b_rowoff[KMAJ ? BN : 1];
     __shared__ int b_rowshift[KMAJ ? BN : 1];
     __shared__ int b_rowrr[KMAJ ? BN : 1];
+    __shared__ int b_kvec_flag;
     if (KMAJ) {
+        if (tid == 0) b_kvec_flag = 1;
+        __syncthreads();
         for (int i = tid; i < BN; i += WN_GEMM_THREADS) {
             const int n = n0 + i;
             int seg = 0, rr = n;
@@ -94,12 +97,19 @@ __global__ __launch_bounds__(WN_GEMM_THREADS, 3) void wn_gemm_kernel(WnGemmArgs 
                 seg = n / g.b_seg_len;
                 rr = n - seg * g.b_seg_len;
             }
-            b_rowoff[i] = (n < g.N) ? ((long)seg * g.b_seg_stride + (long)rr * g.ldb) : -1;
-            b_rowshift[i] = sh0 + seg * shstep;
+            const long off = (n < g.N) ? ((long)seg * g.b_seg_stride + (long)rr * g.ldb) : -1;
+            const int sh = sh0 + seg * shstep;
+            b_rowoff[i] = off;
+            b_rowshift[i] = sh;
             b_rowrr[i] = rr;
+            if ((sh & 3) != 0 || (off >= 0 && (off & 3) != 0)) b_kvec_flag = 0;  // benign race: only 0 is ever written
         }
         __syncthreads();
     }
+    // 16-byte loads along k (time) for the k-major (dW type) tiles: block-uniform eligibility
+    const bool k_base_ok = KMAJ && !ONEHOT && (kbeg % 4 == 0) && (kend % 4 == 0);
+    const bool a_kvec = k_base_ok && (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(Az) & 15) == 0);
+    const bool b_kvec = k_base_ok && (b_kvec_flag != 0) && ((reinterpret_cast<uintptr_t>(Bz) & 15) == 0);
     const bool seg_aligned = one_seg || (g.b_seg_len % WN_BK == 0 && kbeg % WN_BK == 0);
     constexpr int A_RPP = KMAJ ? (WN_GEMM_THREADS / WN_BK) : (WN_GEMM_THREADS / BM);  // rows per pass
     constexpr int B_RPP = KMAJ ? (WN_GEMM_THREADS / WN_BK) : (WN_GEMM_THREADS / BN);
@@ -157,7 +167,44 @@ __global__ __launch_bounds__(WN_GEMM_THREADS, 3) void wn_gemm_kernel(WnGemmArgs 
                 }
             }
         }
+        if (KMAJ && a_kvec) {
+            // A[m][k..k+3]: 8 threads per row, 32 rows per pass
+            const int kq = (tid & 7) * 4, r0 = tid >> 3;
+            WN_UNROLL
+            for (int p4 = 0; p4 < GA::NE / 4; ++p4) {
+                const int m = m0 + r0 + 32 * p4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < g.M && k0 + kq < kend) v = *reinterpret_cast<const float4*>(Az + (long)m * g.lda + k0 + kq);
+                ra[4 * p4 + 0] = v.x; ra[4 * p4 + 1] = v.y; ra[4 * p4 + 2] = v.z; ra[4 * p4 + 3] = v.w;
+            }
+        }
+        if (KMAJ && b_kvec) {
+            const int kq = (tid & 7) * 4, r0 = tid >> 3;
+            WN_UNROLL
+            for (int p4 = 0; p4 < GB::NE / 4; ++p4) {
+                const int i = r0 + 32 * p4;
+                const long off = b_rowoff[i];
+                const int cc = k0 + kq - b_rowshift[i];
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (off >= 0 && k0 + kq < kend) {
+                    if (cc >= 0 && cc + 3 < g.b_clen) {
+                        v = *reinterpret_cast<const float4*>(Bz + off + cc);
+                    } else {  // window edge (zero history / end of the sequence): element-wise
+                        const float* pr = Bz + off;
+                        if (cc + 0 >= 0 && cc + 0 < g.b_clen) v.x = pr[cc + 0];
+                        if (cc + 1 >= 0 && cc + 1 < g.b_clen) v.y = pr[cc + 1];
+                        if (cc + 2 >= 0 && cc + 2 < g.b_clen) v.z = pr[cc + 2];
+                        if (cc + 3 >= 0 && cc + 3 < g.b_clen) v.w = pr[cc + 3];
+                    }
+                }
+                if (g.b_relu) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                rb[4 * p4 + 0] = v.x; rb[4 * p4 + 1] = v.y; rb[4 * p4 + 2] = v.z; rb[4 * p4 + 3] = v.w;
+            }
+        }
         if (KMAJ) {
+          if (!a_kvec) {
             // A[m][k]: column = k (fixed), rows = m
             const int k = k0 + a_col;
             const bool kok = k < kend;
@@ -169,6 +216,8 @@ __global__ __launch_bounds__(WN_GEMM_THREADS, 3) void wn_gemm_kernel(WnGemmArgs 
                 ra[e] = ok ? *pa : 0.0f;
                 pa += astep;
             }
+          }
+          if (!b_kvec) {
             // B[n][k]: column = k (fixed), rows = n (table)
             const int kb = k0 + b_col;
             const bool kbok = kb < kend;
@@ -191,6 +240,7 @@ __global__ __launch_bounds__(WN_GEMM_THREADS, 3) void wn_gemm_kernel(WnGemmArgs 
                 }
                 rb[e] = v;
             }
+          }
         } else {
           if (!a_vec) {
             // A[k][m]: column = m (fixed), rows = k
@@ -246,7 +296,14 @@ __global__ __launch_bounds__(WN_GEMM_THREADS, 3) void wn_gemm_kernel(WnGemmArgs 
     const int nk = (kend > kbeg) ? (kend - kbeg + WN_BK - 1) / WN_BK : 0;
     if (nk > 0) fetch(kbeg);
     for (int kt = 0; kt < nk; ++kt) {
-        if (!KMAJ && a_vec) {
+        if (KMAJ && a_kvec) {
+            const int kq = (tid & 7) * 4, r0 = tid >> 3;
+            WN_UNROLL
+            for (int p4 = 0; p4 < GA::NE / 4; ++p4) {
+                WN_UNROLL
+                for (int i = 0; i < 4; ++i) As[GA::soff(kq + i, r0 + 32 * p4)] = ra[4 * p4 + i];
+            }
+        } else if (!KMAJ && a_vec) {
             const int c4 = (tid % A_TPR) * 4, r0 = tid / A_TPR;
             WN_UNROLL
             for (int p4 = 0; p4 < GA::NE / 4; ++p4)
@@ -260,7 +317,14 @@ __global__ __launch_bounds__(WN_GEMM_THREADS, 3) void wn_gemm_kernel(WnGemmArgs 
                 As[GA::soff(kk, mn)] = ra[e];
             }
         }
-        if (!KMAJ && rb_vec) {
+        if (KMAJ && b_kvec) {
+            const int kq = (tid & 7) * 4, r0 = tid >> 3;
+            WN_UNROLL
+            for (int p4 = 0; p4 < GB::NE / 4; ++p4) {
+                WN_UNROLL
+                for (int i = 0; i < 4; ++i) Bs[GB::soff(kq + i, r0 + 32 * p4)] = rb[4 * p4 + i];
+            }
+        } else if (!KMAJ && rb_vec) {
             const int c4 = (tid % B_TPR) * 4, r0 = tid / B_TPR;
             WN_UNROLL
             for (int p4 = 0; p4 < GB::NE / 4; ++p4)
