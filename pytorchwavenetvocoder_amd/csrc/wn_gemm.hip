@@ -108,8 +108,16 @@ __global__ __launch_bounds__(WN_GEMM_THREADS, 3) void wn_gemm_kernel(WnGemmArgs 
     }
     // 16-byte loads along k (time) for the k-major (dW type) tiles: block-uniform eligibility
     const bool k_base_ok = KMAJ && !ONEHOT && (kbeg % 4 == 0) && (kend % 4 == 0);
-    const bool a_kvec = k_base_ok && (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(Az) & 15) == 0);
-    const bool b_kvec = k_base_ok && (b_kvec_flag != 0) && ((reinterpret_cast<uintptr_t>(Bz) & 15) == 0);
+    const bool a_kvec = k_base_ok && (g.lda % 4 == 0) && (m0 + BM <= g.M) && ((reinterpret_cast<uintptr_t>(Az) & 15) == 0);
+    const bool b_kvec_static = k_base_ok && (b_kvec_flag != 0) && (n0 + BN <= g.N) &&
+                               ((reinterpret_cast<uintptr_t>(Bz) & 15) == 0);
+    // shift range over the rows of this B tile (shift is affine in the segment index)
+    int b_shmin = sh0, b_shmax = sh0;
+    if (KMAJ && !one_seg) {
+        const int s_lo = sh0 + (n0 / g.b_seg_len) * shstep, s_hi = sh0 + ((n0 + BN - 1) / g.b_seg_len) * shstep;
+        b_shmin = s_lo < s_hi ? s_lo : s_hi;
+        b_shmax = s_lo < s_hi ? s_hi : s_lo;
+    }
     const bool seg_aligned = one_seg || (g.b_seg_len % WN_BK == 0 && kbeg % WN_BK == 0);
     constexpr int A_RPP = KMAJ ? (WN_GEMM_THREADS / WN_BK) : (WN_GEMM_THREADS / BM);  // rows per pass
     constexpr int B_RPP = KMAJ ? (WN_GEMM_THREADS / WN_BK) : (WN_GEMM_THREADS / BN);
@@ -174,29 +182,21 @@ __global__ __launch_bounds__(WN_GEMM_THREADS, 3) void wn_gemm_kernel(WnGemmArgs 
             for (int p4 = 0; p4 < GA::NE / 4; ++p4) {
                 const int m = m0 + r0 + 32 * p4;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (m < g.M && k0 + kq < kend) v = *reinterpret_cast<const float4*>(Az + (long)m * g.lda + k0 + kq);
+                if (k0 + kq < kend) v = *reinterpret_cast<const float4*>(Az + (long)m * g.lda + k0 + kq);  // (kend % 4 == 0)
                 ra[4 * p4 + 0] = v.x; ra[4 * p4 + 1] = v.y; ra[4 * p4 + 2] = v.z; ra[4 * p4 + 3] = v.w;
             }
         }
-        if (KMAJ && b_kvec) {
+        if (KMAJ) {
+            // interior tile (every row's shifted window lies inside [0, clen) and the k-tile is full):
+            // unconditional 16-byte loads; any other tile takes the scalar path
+            rb_vec = b_kvec_static && (k0 - b_shmax >= 0) && (k0 + WN_BK - b_shmin <= g.b_clen) && (k0 + WN_BK <= kend);
+        }
+        if (KMAJ && rb_vec) {
             const int kq = (tid & 7) * 4, r0 = tid >> 3;
             WN_UNROLL
             for (int p4 = 0; p4 < GB::NE / 4; ++p4) {
                 const int i = r0 + 32 * p4;
-                const long off = b_rowoff[i];
-                const int cc = k0 + kq - b_rowshift[i];
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (off >= 0 && k0 + kq < kend) {
-                    if (cc >= 0 && cc + 3 < g.b_clen) {
-                        v = *reinterpret_cast<const float4*>(Bz + off + cc);
-                    } else {  // window edge (zero history / end of the sequence): element-wise
-                        const float* pr = Bz + off;
-                        if (cc + 0 >= 0 && cc + 0 < g.b_clen) v.x = pr[cc + 0];
-                        if (cc + 1 >= 0 && cc + 1 < g.b_clen) v.y = pr[cc + 1];
-                        if (cc + 2 >= 0 && cc + 2 < g.b_clen) v.z = pr[cc + 2];
-                        if (cc + 3 >= 0 && cc + 3 < g.b_clen) v.w = pr[cc + 3];
-                    }
-                }
+                float4 v = *reinterpret_cast<const float4*>(Bz + b_rowoff[i] + (k0 + kq - b_rowshift[i]));
                 if (g.b_relu) {
                     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                 }
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(WN_GEMM_THREADS, 3) void wn_gemm_kernel(WnGemmArgs 
                 pa += astep;
             }
           }
-          if (!b_kvec) {
+          if (!rb_vec) {
             // B[n][k]: column = k (fixed), rows = n (table)
             const int kb = k0 + b_col;
             const bool kbok = kb < kend;
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(WN_GEMM_THREADS, 3) void wn_gemm_kernel(WnGemmArgs 
                 As[GA::soff(kk, mn)] = ra[e];
             }
         }
-        if (KMAJ && b_kvec) {
+        if (KMAJ && rb_vec) {
             const int kq = (tid & 7) * 4, r0 = tid >> 3;
             WN_UNROLL
             for (int p4 = 0; p4 < GB::NE / 4; ++p4) {
