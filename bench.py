@@ -197,24 +197,41 @@ def main():
                        "share": v["ms"] / tot_ms,
                        "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] > 0 and v["ms"] > 0 else None}
                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+        for k, v in prof.items():
+            kernels[k]["GBps_compulsory"] = (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["bytes"] > 0 and v["ms"] > 0 else None
+        # Dominant kernel = largest share of the step.  Its roofline is whichever bound is the
+        # binding one for that launch: t_mfma = flop / f32-MFMA peak vs t_hbm = compulsory bytes /
+        # HBM peak (compulsory = every input/output tensor of the launch once).
         dom = next((k for k, v in kernels.items() if v["tflops"] is not None), None)
         if dom is not None:
             v = prof[dom]
-            ach = v["flops"] / (v["ms"] * 1e-3) / 1e12
+            sec = v["ms"] * 1e-3
+            ach_f = v["flops"] / sec / 1e12
+            ach_b = v["bytes"] / sec / 1e9
+            t_mfma = v["flops"] / F32_MFMA_PEAK
+            t_hbm = v["bytes"] / HBM_PEAK
             traffic = None  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/pmc_traffic.json)
             try:
                 with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as fh:
                     traffic = json.load(fh).get(dom, {}).get("hbm_bytes_per_launch")
             except (OSError, ValueError):
                 pass
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK / 1e12,
-                        "unit": "TFLOP/s", "frac": ach / (F32_MFMA_PEAK / 1e12), "traffic": traffic,
-                        "traffic_note": "bytes/launch, (2*FETCH_SIZE+WRITE_SIZE)*1024 from separate --pmc passes",
-                        "avg_launch_ms": v["ms"] / v["count"], "flop_per_launch": v["flops"] / v["count"],
-                        "dtype_peak": "f32-input MFMA (v_mfma_f32_32x32x2_f32), dense 157.3 TFLOP/s",
-                        "step_hbm_frac": timesteps_per_s_gpu * ALG_BYTES_PER_TIMESTEP / HBM_PEAK,
-                        "step_hbm_achieved_GBps": timesteps_per_s_gpu * ALG_BYTES_PER_TIMESTEP / 1e9,
-                        "step_f32_flop_frac": timesteps_per_s_gpu * ALG_FLOP_PER_TIMESTEP / F32_MFMA_PEAK}
+            if t_hbm >= t_mfma:
+                roofline = {"kernel": dom, "bound": "hbm", "achieved": ach_b, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                            "frac": ach_b / (HBM_PEAK / 1e9)}
+            else:
+                roofline = {"kernel": dom, "bound": "mfma", "achieved": ach_f, "peak": F32_MFMA_PEAK / 1e12,
+                            "unit": "TFLOP/s", "frac": ach_f / (F32_MFMA_PEAK / 1e12)}
+            roofline.update({
+                "traffic": traffic,
+                "traffic_note": "bytes/launch, (2*FETCH_SIZE+WRITE_SIZE)*1024 from separate --pmc passes",
+                "avg_launch_ms": v["ms"] / v["count"], "flop_per_launch": v["flops"] / v["count"],
+                "compulsory_bytes_per_launch": v["bytes"] / v["count"],
+                "mfma_frac": ach_f / (F32_MFMA_PEAK / 1e12), "hbm_frac": ach_b / (HBM_PEAK / 1e9),
+                "dtype_peak": "f32-input MFMA (v_mfma_f32_32x32x2_f32), dense 157.3 TFLOP/s; HBM3E 8 TB/s",
+                "step_hbm_frac": timesteps_per_s_gpu * ALG_BYTES_PER_TIMESTEP / HBM_PEAK,
+                "step_hbm_achieved_GBps": timesteps_per_s_gpu * ALG_BYTES_PER_TIMESTEP / 1e9,
+                "step_f32_flop_frac": timesteps_per_s_gpu * ALG_FLOP_PER_TIMESTEP / F32_MFMA_PEAK})
 
     if rank == 0:
         out = {

@@ -126,6 +126,8 @@ _cached = None
 def load_library(path=None, _test_emulator=False):
     """Load (building if necessary) the gfx950 library.  Raises if that is impossible."""
     global _cached
+    if path is None and os.environ.get("WN_LIB_PATH"):  # tuning experiments: an alternative gfx950 build
+        return WnLibrary(os.environ["WN_LIB_PATH"])
     if path is not None:
         return WnLibrary(path, is_emulator=_test_emulator)
     with _lock:

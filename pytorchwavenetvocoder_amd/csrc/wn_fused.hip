@@ -28,13 +28,25 @@
 
 #include <stdlib.h>
 
+#ifdef WN_TIMING
+// Experimental build only (tools/exp): per-phase cycle stamps of block 0, lane 0 of every wave.
+static long long* g_dbg = nullptr;
+extern "C" void wn_debug_set_buffer(void* p) { g_dbg = (long long*)p; }
+#define WN_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && lane == 0 && tcount < 4) a.dbg[(wave * 4 + tcount) * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define WN_STAMP(i)
+#endif
+
 // tuning knob (A/B on hardware): WN_STAGGER=<n> delays the second wave of every SIMD by n x 8128 cycles
 static int stagger_setting() {
     const char* e = getenv("WN_STAGGER");
     return e ? atoi(e) : 0;  // measured on MI355X (profiles/r01): 0 -> 19.8 ms, 1 -> 20.0, 3 -> 20.1, 5 -> 20.5 ms per step
 }
 
-#define WN_FT 512  // threads per workgroup (8 waves)
+#ifndef WN_FT
+#define WN_FT 512  // threads per workgroup (8 waves = 2 per SIMD)
+#endif
+#define WN_FW (WN_FT / 64)  // waves per workgroup
 
 // channel handled by k-step s (0..31 within a 64-channel group) for lane-half hi
 static __device__ __forceinline__ int kappa64(int s, int hi) {
@@ -88,6 +100,9 @@ struct FwdArgs {
     float* Z;
     int B, T, dil, U, F;
     int stagger;  // waves 4..7 (the second wave of each SIMD) start `stagger` x 8K cycles late
+#ifdef WN_TIMING
+    long long* dbg;
+#endif
 };
 
 template <int K>
@@ -97,16 +112,27 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
     float* Wr = Wd + K * 64 * 128;                   // [64][64]
     float* cv = Wr + 64 * 64;                        // [128]
     float* rb = cv + 128;                            // [64]
+#ifdef WN_TIMING
+    if (a.dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
+        a.dbg[((threadIdx.x >> 6) * 4) * 16 + 5] = (long long)__builtin_readcyclecounter();
+        a.dbg[((threadIdx.x >> 6) * 4) * 16 + 7] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+    if (a.dbg && threadIdx.x == 0) a.dbg[512 + blockIdx.x * 4 + 0] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
     stage_copy(Wd, a.wd_f, K * 64 * 128);
     stage_copy(Wr, a.wres_f, 64 * 64);
     if (threadIdx.x < 128) cv[threadIdx.x] = a.cvec[threadIdx.x];
     if (threadIdx.x < 64) rb[threadIdx.x] = a.res_bias[threadIdx.x];
     __syncthreads();
+#ifdef WN_TIMING
+    if (a.dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0)
+        a.dbg[((threadIdx.x >> 6) * 4) * 16 + 6] = (long long)__builtin_readcyclecounter();
+#endif
     // De-phase the two waves that share a SIMD (waves w and w+4): started together they would run
     // their MFMA phases and their gate/store phases in lock step and leave the matrix pipe idle
     // during the latter; half a tile of head start makes one wave's VALU/VMEM phase coincide with
     // the other's MFMA phase.
-    if (WN_UNIFORM((int)(threadIdx.x >> 8)) != 0)
+    if (WN_UNIFORM((int)(threadIdx.x / (WN_FT / 2))) != 0)
         for (int i = 0; i < a.stagger; ++i) WN_SLEEP(127);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -117,7 +143,7 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
     const int tiles_per_b = (T + 31) >> 5;
     const int ntiles = a.B * tiles_per_b;
     const unsigned slab = (unsigned)(64 * T4);
-    const int step = gridDim.x * 8;
+    const int step = gridDim.x * WN_FW;
     constexpr int KH = (K > 1) ? (K - 1) : 1;  // history taps (shift > 0)
 
     // Software pipeline (per wave, per 32-sample tile):
@@ -144,9 +170,12 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
         }
     };
 
-    int tile_v = blockIdx.x * 8 + wave;
+    int tile_v = blockIdx.x * WN_FW + wave;
+    int tcount = 0;
+    (void)tcount;
     if (K > 1 && tile_v < ntiles) issue_hist(tile_v);
     while (tile_v < ntiles) {
+        WN_STAMP(0);
         const int tile = WN_UNIFORM(tile_v);
         const int b = tile / tiles_per_b;
         const int t = (tile - b * tiles_per_b) * 32 + li;
@@ -198,6 +227,7 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
                 WN_SGB_MFMA(4);
             }
         }
+        WN_STAMP(1);  // after history-tap MFMAs
         // aux / gate inputs (frame rate, L2 resident), first 32 gate channels
         const int fr = tc / a.U;
         const float upw_j = a.upw[tc - fr * a.U];
@@ -243,6 +273,12 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
             }
         }
         WN_SCHED_BARRIER();
+        WN_STAMP(2);  // after current-tap MFMAs
+        // Prefetch the history-tap operands of this wave's next tile NOW, i.e. before the stores of the
+        // gate phase: vmcnt is one in-order counter for loads AND stores, so loads issued behind the
+        // 96 S/Gt/Z stores could only be waited for together with those stores' acknowledgements.
+        const int next_v = tile_v + step;
+        if (K > 1 && next_v < ntiles) issue_hist(next_v);
         WN_UNROLL
         for (int r = 0; r < 16; ++r) {
             ga[1][r] = wn_buf_load(Gr, vg, (32 + mfma32_row(r, 0)) * F4);
@@ -272,6 +308,7 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
                 }
             }
         }
+        WN_STAMP(3);  // after gate math + S/Gt/Z stores issued
         f32x16 racc[2];
         if (a.Xnext != nullptr) {
             const float* rbl = rb + 4 * hi;
@@ -282,9 +319,6 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
                     racc[q][r] = (inb ? xc[16 * q + r] : 0.0f) + rbl[32 * q + mfma32_row(r, 0)];
             }
         }
-        // prefetch the history-tap operands of this wave's next tile; they land under the res MFMAs
-        const int next_v = tile_v + step;
-        if (K > 1 && next_v < ntiles) issue_hist(next_v);
         WN_SCHED_BARRIER();
         // res 1x1 + residual; z is consumed straight from the accumulator registers
         if (a.Xnext != nullptr) {
@@ -324,8 +358,23 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
                 }
             }
         }
+        WN_STAMP(4);  // tile done
+        ++tcount;
         tile_v = next_v;
     }
+#ifdef WN_TIMING
+    if (a.dbg && blockIdx.x == 0 && lane == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        a.dbg[(wave * 4) * 16 + 8] = (long long)__builtin_amdgcn_s_memrealtime();
+        a.dbg[(wave * 4) * 16 + 9] = (long long)__builtin_readcyclecounter();
+    }
+    if (a.dbg && lane == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        if (wave == 0) a.dbg[512 + blockIdx.x * 4 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+        if (wave == 7) a.dbg[512 + blockIdx.x * 4 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
+        if (wave == 0) a.dbg[512 + blockIdx.x * 4 + 3] = tcount;
+    }
+#endif
 }
 
 template <int K>
@@ -333,7 +382,7 @@ static int launch_fwd(const FwdArgs& a, wn_stream_t st) {
     const size_t lds = ((size_t)K * 64 * 128 + 64 * 64 + 192) * sizeof(float);
     if (set_lds(k_resblock_fwd<K>, lds)) return 1;
     const long ntiles = (long)a.B * ((a.T + 31) / 32);
-    long nblk = (ntiles + 7) / 8;
+    long nblk = (ntiles + WN_FW - 1) / WN_FW;
     if (nblk > 256) nblk = 256;
     WN_LAUNCH((k_resblock_fwd<K>), dim3((unsigned)nblk), dim3(WN_FT), lds, st, a);
     return 0;
@@ -342,13 +391,17 @@ static int launch_fwd(const FwdArgs& a, wn_stream_t st) {
 int wn_fused_resblock_fwd(const float* wd_f, const float* wres_f, const float* cvec, const float* res_bias, const float* X,
                           const float* G, long g_bstride, const float* upw, float* Xnext, float* S, float* Gt, float* Z, int B,
                           int T, int K, int dilation, int U, int F, wn_stream_t st) {
-    WN_PROF("fused_resblock_fwd", 2.0 * (double)B * T * (K * 64.0 * 128.0 + (Xnext ? 64.0 * 64.0 : 0.0)), 0.0, st);
+    WN_PROF("fused_resblock_fwd", 2.0 * (double)B * T * (K * 64.0 * 128.0 + (Xnext ? 64.0 * 64.0 : 0.0)),
+            4.0 * (double)B * T * 64.0 * (Xnext ? 5.0 : 4.0), st);  // X in; S, Gt, Z (, Xnext) out
     FwdArgs a;
     a.wd_f = wd_f; a.wres_f = wres_f; a.cvec = cvec; a.res_bias = res_bias;
     a.X = X; a.G = G; a.g_bstride = g_bstride; a.upw = upw;
     a.Xnext = Xnext; a.S = S; a.Gt = Gt; a.Z = Z;
     a.B = B; a.T = T; a.dil = dilation; a.U = U; a.F = F;
     a.stagger = stagger_setting();
+#ifdef WN_TIMING
+    a.dbg = g_dbg;
+#endif
     switch (K) {
         case 1: return launch_fwd<1>(a, st);
         case 2: return launch_fwd<2>(a, st);
@@ -390,7 +443,7 @@ __global__ __launch_bounds__(WN_FT) void k_conv64(ConvArgs a) {
     // their MFMA phases and their gate/store phases in lock step and leave the matrix pipe idle
     // during the latter; half a tile of head start makes one wave's VALU/VMEM phase coincide with
     // the other's MFMA phase.
-    if (WN_UNIFORM((int)(threadIdx.x >> 8)) != 0)
+    if (WN_UNIFORM((int)(threadIdx.x / (WN_FT / 2))) != 0)
         for (int i = 0; i < a.stagger; ++i) WN_SLEEP(127);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -399,7 +452,7 @@ __global__ __launch_bounds__(WN_FT) void k_conv64(ConvArgs a) {
     const int T4 = T * 4;
     const int tiles_per_b = (T + 31) >> 5;
     const int ntiles = a.B * tiles_per_b;
-    const int step = gridDim.x * 8;
+    const int step = gridDim.x * WN_FW;
     const int NCH = a.nchunks;
 
     // Operand chunks (32 channels = 16 k-steps) are double buffered in registers: chunk q+2 is in
@@ -469,7 +522,7 @@ __global__ __launch_bounds__(WN_FT) void k_conv64(ConvArgs a) {
         }
     };
 
-    int tile_v = blockIdx.x * 8 + wave;
+    int tile_v = blockIdx.x * WN_FW + wave;
     if (tile_v < ntiles) {
         issue(tile_v, 0, xa, oka);
         if (NCH > 1) issue(tile_v, 1, xb, okb);
@@ -555,7 +608,7 @@ static int launch_conv64(const ConvArgs& a, wn_stream_t st) {
     const size_t lds = (size_t)a.wfloats * sizeof(float);
     if (set_lds(k_conv64<MODE>, lds)) return 1;
     const long ntiles = (long)a.B * ((a.T + 31) / 32);
-    long nblk = (ntiles + 7) / 8;
+    long nblk = (ntiles + WN_FW - 1) / WN_FW;
     if (nblk > 256) nblk = 256;
     WN_LAUNCH((k_conv64<MODE>), dim3((unsigned)nblk), dim3(WN_FT), lds, st, a);
     return 0;
@@ -563,7 +616,8 @@ static int launch_conv64(const ConvArgs& a, wn_stream_t st) {
 
 int wn_fused_bwd_gate(const float* wskip, const float* wres, const float* dSk, const float* dXn, const float* S, const float* Gt,
                       float* dP, int B, int T, int Sch, wn_stream_t st) {
-    WN_PROF("fused_bwd_gate", 2.0 * (double)B * T * 64.0 * (Sch + (dXn ? 64.0 : 0.0)), 0.0, st);
+    WN_PROF("fused_bwd_gate", 2.0 * (double)B * T * 64.0 * (Sch + (dXn ? 64.0 : 0.0)),
+            4.0 * (double)B * T * (Sch + (dXn ? 64.0 : 0.0) + 4.0 * 64.0), st);  // dSk (, dXn), S, Gt in; dP out
     ConvArgs a;
     a.nseg = 1;
     a.seg[0].src = dSk; a.seg[0].w = wskip; a.seg[0].nch = Sch; a.seg[0].shift = 0; a.seg[0].woff = 0;
@@ -582,7 +636,8 @@ int wn_fused_bwd_gate(const float* wskip, const float* wres, const float* dSk, c
 
 int wn_fused_bwd_dx(const float* wd_b, const float* dP, const float* dXn, float* dX, int B, int T, int K, int dilation,
                     wn_stream_t st) {
-    WN_PROF("fused_bwd_dx", 2.0 * (double)B * T * 64.0 * K * 128.0, 0.0, st);
+    WN_PROF("fused_bwd_dx", 2.0 * (double)B * T * 64.0 * K * 128.0,
+            4.0 * (double)B * T * 64.0 * (dXn ? 4.0 : 3.0), st);  // dP (, dXn) in; dX out
     if (K > 3) return 1;
     ConvArgs a;
     a.nseg = K;

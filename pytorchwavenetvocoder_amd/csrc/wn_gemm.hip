@@ -435,7 +435,10 @@ int wn_gemm_launch(const WnGemmArgs* gp, wn_stream_t stream) {
     if (g.a_kmajor != g.b_kmajor) return 2;
     if (g.b_seg_len <= 0 || g.kchunk <= 0) return 3;
     const int tm = g.M > 64 ? 2 : 1, tn = g.N > 64 ? 2 : 1;
-    WN_PROF(g.tag ? g.tag : "gemm", 2.0 * g.M * g.N * (double)g.K * g.nbatch * g.nlayer, 0.0, stream);
+    // compulsory bytes: both operands and the result once (a one-hot operand is 8-byte indices)
+    WN_PROF(g.tag ? g.tag : "gemm", 2.0 * g.M * g.N * (double)g.K * g.nbatch * g.nlayer,
+            ((double)g.M * g.K * 4.0 + (double)g.K * (g.b_index ? 8.0 : 4.0 * g.N) + (double)g.M * g.N * 4.0) * g.nbatch * g.nlayer,
+            stream);
     if (g.b_index != nullptr) {
         if (!g.a_kmajor) return 4;  // the one-hot operand exists for the dW (k = time) mode only
         if (tm == 2 && tn == 2) launch_variant<2, 2, 1, 1>(g, stream);
