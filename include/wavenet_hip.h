@@ -149,6 +149,37 @@ int wn_op_causal_conv(const float* weight, const float* bias, const float* x /*(
 struct WnGemmArgs;
 int wn_op_gemm(const struct WnGemmArgs* args, void* stream);
 
+/* ---- autoregressive decode (BASELINE config 5) -------------------------------------------------
+ * Replaces WaveNet.fast_generate / batch_fast_generate / _generate_residual_forward
+ * (wavenet_vocoder/nets/wavenet.py:309-395, 397-511, 538-549): one persistent workgroup per
+ * utterance, the dilation queues in a caller-owned state buffer, tokens chosen on-chip.
+ *
+ * Positions index the left-padded token buffer `samples` (B, Ttot) (wavenet.py:331-336: the
+ * context is padded with n_quantize/2 up to the receptive field, the aux features by replicating
+ * their first column: pass the pad length as n_pad).  Step p reads the tokens at p-K+1..p and the
+ * aux column of position p and produces the logits of position p+1.  Positions below t_forced[b]
+ * are the context (teacher forced; running them from step 0 over a zeroed state IS the reference's
+ * "prepare buffer" pass, wavenet.py:338-349); from t_forced[b] on, step p writes samples[b][p+1].
+ * Utterance b stops at t_end[b] positions.  All pointers are device pointers; nothing is allocated;
+ * asynchronous on `stream`.  The compiled kernel classes cover n_resch <= 64, n_skipch <= 256,
+ * n_quantize <= 256, kernel_size <= 3: wn_decode_supported() tells, everything else returns an
+ * error (callers fall back to full-window forwards, wavenet.py:243-307). */
+int wn_decode_supported(const WnConfig* cfg);
+int64_t wn_decode_pack_floats(const WnConfig* cfg);   /* floats of the packed decode weights, <0: unsupported */
+int64_t wn_decode_state_floats(const WnConfig* cfg);  /* floats of queue state per utterance */
+/* Re-pack the flat parameter buffer into the per-thread weight stream + side tables. */
+int wn_decode_pack(const WnConfig* cfg, const float* params, float* wpack, void* stream);
+/* Aux projections of all layers at the aux rate: G[b][f][l*2R+o'] = Waux_l h[b][:, f] (wavenet.py:541-542).
+ * h is (B, n_aux, F): frames if upsampling_factor > 0 (the kernel applies the transposed-conv taps
+ * of wavenet.py:136 per sample), samples otherwise. */
+int wn_decode_aux(const WnConfig* cfg, int B, int F, const float* wpack, const float* h, float* G, void* stream);
+/* mode: 0 argmax, 1 categorical sampling with the caller's uniform draws `uniforms` (B, Ttot)
+ * (draw [b][p+1] picks the token of position p+1).  logits_out (B, Ttot, Q) is optional (row p =
+ * the logits computed by step p).  `state` (B, wn_decode_state_floats) must be zero before step 0. */
+int wn_decode_steps(const WnConfig* cfg, int B, const float* params, const float* wpack, const float* G, int F, int n_pad,
+                    int64_t* samples, int64_t Ttot, const int32_t* t_forced, const int32_t* t_end, int p0, int p1,
+                    float* state, const float* uniforms, float* logits_out, int mode, void* stream);
+
 /* ---- diagnostics: opt-in per-launch timing with HIP events (used by bench.py's roofline block) ----
  * wn_prof_enable(1) clears and starts recording {kernel tag, algorithmic flops/bytes, start/stop
  * event} for every launch; after synchronising, wn_prof_report writes a JSON object

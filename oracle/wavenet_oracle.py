@@ -325,3 +325,142 @@ def batch_geometry(receptive_field: int, batch_length: int, upsampling_factor: i
     h_bs = (receptive_field + bl) // upsampling_factor
     T = h_bs * upsampling_factor
     return {"batch_length": bl, "frames": h_bs, "T": T, "loss_positions": T - receptive_field}
+
+
+# --------------------------------------------------------------------------
+# generation  (wavenet.py:243-511, 538-549) -- BASELINE config 5
+# --------------------------------------------------------------------------
+def _pad_context(cfg: OracleConfig, p, x, h):
+    """Shared prologue of generate / fast_generate / batch_fast_generate (wavenet.py:258-266,
+    328-336, 417-425): up-sample h, then left-pad x with n_quantize//2 and h by replication up to
+    the receptive field."""
+    if cfg.upsampling_factor > 0:
+        h = upsampling(h, p["upsampling.conv.weight"], p["upsampling.conv.bias"])
+    n_pad = cfg.receptive_field - x.size(1)
+    if n_pad > 0:
+        x = F.pad(x, (n_pad, 0), "constant", cfg.n_quantize // 2)
+        h = F.pad(h, (n_pad, 0), "replicate")
+    return x, h
+
+
+def _pick(logits_row, mode, generator=None):
+    """wavenet.py:289-298 / 370-378: categorical sample of softmax, or argmax."""
+    if mode == "argmax":
+        return int(logits_row.argmax())
+    if mode == "sampling":
+        post = F.softmax(logits_row, dim=0)
+        return int(torch.multinomial(post, 1, generator=generator))
+    raise ValueError("mode should be sampling or argmax")
+
+
+def generate(cfg: OracleConfig, p, x, h, n_samples, mode="argmax", return_logits=False):
+    """WaveNet.generate, wavenet.py:243-307: every new sample is the last output of a full forward
+    over the last receptive_field samples.  x (1,T) int64, h (1,A,(n_samples+T)[/U])."""
+    x, h = _pad_context(cfg, p, x, h)
+    rf = cfg.receptive_field
+    samples = x[0].tolist()
+    rows = []
+    sub = OracleConfig(*cfg.as_tuple()[:7], 0)  # h is at sample rate from here on
+    for _ in range(n_samples):
+        n = len(samples)
+        xw = torch.tensor(samples[-rf:]).long().view(1, -1)
+        hw = h[:, :, n - rf:n]
+        row = forward(sub, p, xw, hw)[0, -1]
+        rows.append(row)
+        samples.append(_pick(row, mode))
+    out = np.array(samples[-n_samples:])
+    return (out, torch.stack(rows)) if return_logits else out
+
+
+def _one_step(cfg: OracleConfig, p, prev_tokens, h_col, queues):
+    """One autoregressive step of the queue algorithm (wavenet.py:350-366, 538-549).
+
+    prev_tokens: (B, >=K) last tokens (the newest last); h_col: (B,A,1) aux at this position;
+    queues[l]: (B,R,(K-1)*d_l) = the input history of layer l (newest last).  Returns the logits
+    (B,Q) and the updated queues.  The reference keeps the *outputs* of layer l with length
+    (K-1)*d_{l+1} (buffer_size, wavenet.py:346-349); that is the same data indexed from the
+    consumer's side."""
+    K = cfg.kernel_size
+    dtype = p["causal.conv.weight"].dtype
+    # _preprocess on the last 2K-1 tokens, keep the newest column (wavenet.py:355-356)
+    win = prev_tokens[:, -(2 * K - 1):]
+    out = causal_conv1d(onehot(win, cfg.n_quantize, dtype).transpose(1, 2),
+                        p["causal.conv.weight"], p["causal.conv.bias"], 1)[:, :, -1:]
+    skips = None
+    new_queues = []
+    for l, d in enumerate(cfg.dilations):
+        hist = torch.cat([queues[l], out], dim=2)                # (B,R,(K-1)d+1)
+        new_queues.append(hist[:, :, 1:] if K > 1 else hist[:, :, :0])
+        # _generate_residual_forward (wavenet.py:538-549): dilated conv, newest column only
+        o_s = causal_conv1d(hist, p["dil_sigmoid.%d.conv.weight" % l], p["dil_sigmoid.%d.conv.bias" % l], d)[:, :, -1:]
+        o_t = causal_conv1d(hist, p["dil_tanh.%d.conv.weight" % l], p["dil_tanh.%d.conv.bias" % l], d)[:, :, -1:]
+        a_s = F.conv1d(h_col, p["aux_1x1_sigmoid.%d.weight" % l], p["aux_1x1_sigmoid.%d.bias" % l])
+        a_t = F.conv1d(h_col, p["aux_1x1_tanh.%d.weight" % l], p["aux_1x1_tanh.%d.bias" % l])
+        z = torch.sigmoid(o_s + a_s) * torch.tanh(o_t + a_t)
+        skip = F.conv1d(z, p["skip_1x1.%d.weight" % l], p["skip_1x1.%d.bias" % l])
+        out = F.conv1d(z, p["res_1x1.%d.weight" % l], p["res_1x1.%d.bias" % l]) + out
+        skips = skip if skips is None else skips + skip
+    o = F.relu(skips)
+    o = F.relu(F.conv1d(o, p["conv_post_1.weight"], p["conv_post_1.bias"]))
+    o = F.conv1d(o, p["conv_post_2.weight"], p["conv_post_2.bias"])
+    return o[:, :, 0], new_queues
+
+
+def _prefill_queues(cfg: OracleConfig, p, x, h):
+    """'prepare buffer' (wavenet.py:338-349): a full forward over the context; queue l keeps the
+    inputs of layer l at the last (K-1)*d_l positions BEFORE the newest one."""
+    dtype = p["causal.conv.weight"].dtype
+    K = cfg.kernel_size
+    out = causal_conv1d(onehot(x, cfg.n_quantize, dtype).transpose(1, 2),
+                        p["causal.conv.weight"], p["causal.conv.bias"], 1)
+    hh = h[:, :, :x.size(1)]
+    queues = []
+    for l, d in enumerate(cfg.dilations):
+        n = (K - 1) * d
+        q = out[:, :, -n - 1:-1]
+        if q.size(2) < n:   # context shorter than this queue: zero history (the conv's own padding)
+            q = F.pad(q, (n - q.size(2), 0))
+        queues.append(q)
+        out, _ = residual_forward(out, hh, p, l, d)
+    return queues
+
+
+def batch_fast_generate(cfg: OracleConfig, p, x, h, n_samples_list, mode="argmax", return_logits=False):
+    """WaveNet.batch_fast_generate, wavenet.py:397-511.  x (B,T), h (B,A,(max_n+T)[/U]).  Returns
+    the list of generated token arrays in the reference's order (shortest first, ties by index)."""
+    n_samples_list = list(n_samples_list)
+    x, h = _pad_context(cfg, p, x, h)
+    queues = _prefill_queues(cfg, p, x, h)
+    samples = x
+    B = x.size(0)
+    alive = list(range(B))
+    done = {}
+    rows = [[] for _ in range(B)]
+    for i in range(max(n_samples_list)):
+        h_col = h[alive, :, samples.size(1) - 1].unsqueeze(-1)
+        logits, queues = _one_step(cfg, p, samples, h_col, queues)
+        new = torch.tensor([_pick(logits[j], mode) for j in range(len(alive))]).long().view(-1, 1)
+        for j, b in enumerate(alive):
+            rows[b].append(logits[j])
+        samples = torch.cat([samples, new], dim=1)
+        keep = [j for j, b in enumerate(alive) if n_samples_list[b] > i + 1]
+        for j, b in enumerate(alive):
+            if n_samples_list[b] == i + 1:
+                done[b] = samples[j, -n_samples_list[b]:].numpy().copy()
+        if len(keep) != len(alive):
+            samples = samples[keep]
+            queues = [q[keep] for q in queues]
+            alive = [alive[j] for j in keep]
+        if not alive:
+            break
+    order = sorted(range(B), key=lambda b: (n_samples_list[b], b))
+    toks = [done[b] for b in order]
+    if return_logits:
+        return toks, [torch.stack(rows[b]) for b in order]
+    return toks
+
+
+def fast_generate(cfg: OracleConfig, p, x, h, n_samples, mode="argmax", return_logits=False):
+    """WaveNet.fast_generate, wavenet.py:309-395 (the B=1 case of the queue algorithm)."""
+    r = batch_fast_generate(cfg, p, x, h, [n_samples], mode, return_logits)
+    return (r[0][0], r[1][0]) if return_logits else r[0]

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include "../../include/wavenet_hip.h"
+#include "wn_decode.h"
 #include "wn_elem.h"
 #include "wn_fused.h"
 #include "wn_gemm.h"
@@ -883,6 +884,140 @@ extern "C" int wn_op_causal_conv(const float* weight, const float* bias, const f
     g.bias = bias; g.nbatch = B;
     WN_TRY(wn_gemm_launch(&g, (wn_stream_t)stream));
     return rt_check("wn_op_causal_conv");
+}
+
+// ------------------------------------------------------------------------------------------
+// autoregressive decode (wavenet.py:309-511, 538-549)
+// ------------------------------------------------------------------------------------------
+static int decode_plan(const WnConfig* cfg, Dims* d, WnDecodePlan* pl) {
+    WN_TRY(check_cfg(cfg, d));
+    wn_decode_make_plan(d->Q, d->A, d->R, d->S, d->L, d->K, cfg->dilation_depth, pl);
+    if (!pl->ok)
+        return fail(3, "decode kernel: configuration not covered (needs n_resch<=64, n_skipch<=256, n_quantize<=256, "
+                       "kernel_size<=3); use full-window forwards");
+    return 0;
+}
+
+extern "C" int wn_decode_supported(const WnConfig* cfg) {
+    Dims d;
+    WnDecodePlan pl;
+    const int rc = decode_plan(cfg, &d, &pl);
+    g_err[0] = 0;
+    return rc == 0 ? 1 : 0;
+}
+
+extern "C" int64_t wn_decode_pack_floats(const WnConfig* cfg) {
+    Dims d;
+    WnDecodePlan pl;
+    if (decode_plan(cfg, &d, &pl)) return -1;
+    return pl.total_floats;
+}
+
+extern "C" int64_t wn_decode_state_floats(const WnConfig* cfg) {
+    Dims d;
+    WnDecodePlan pl;
+    if (decode_plan(cfg, &d, &pl)) return -1;
+    return pl.queue_floats > 0 ? pl.queue_floats : 4;
+}
+
+extern "C" int wn_decode_pack(const WnConfig* cfg, const float* params, float* wpack, void* stream) {
+    g_err[0] = 0;
+    Dims d;
+    WnDecodePlan pl;
+    WN_TRY(decode_plan(cfg, &d, &pl));
+    if (!params || !wpack) return fail(1, "NULL argument");
+    const Lay y = make_lay(d);
+    wn_stream_t st = (wn_stream_t)stream;
+    const long lb0 = layer_base(y, d, 0), lstep = -y.LB;
+    WnDecodePackArgs pa;
+    pa.Q = d.Q; pa.R = d.R; pa.S = d.S; pa.L = d.L; pa.K = d.K;
+    pa.plan = pl;
+    pa.params = params;
+    pa.lb0 = lb0; pa.lstep = lstep;
+    pa.o_dsig_w = y.o_dsig_w; pa.o_dtanh_w = y.o_dtanh_w; pa.o_res_w = y.o_res_w;
+    pa.skip0 = y.skip0; pa.ls_skip = y.ls_skip; pa.post1_w = y.post1_w; pa.post2_w = y.post2_w;
+    pa.stream = wpack;
+    WN_TRY(wn_decode_pack_stream(&pa, st));
+    // side tables: cvec (all constant terms of the gate pre-activation), summed skip bias, the aux
+    // weights as the [a][l*2R+o'] operand of the aux-rate GEMM, a vector of ones (U == 0)
+    WnCvecArgs ca;
+    ca.params = params;
+    ca.off_dsig_b = lb0 + y.o_dsig_b; ca.off_dtanh_b = lb0 + y.o_dtanh_b;
+    ca.off_asig_w = lb0 + y.o_asig_w; ca.off_atanh_w = lb0 + y.o_atanh_w;
+    ca.off_asig_b = lb0 + y.o_asig_b; ca.off_atanh_b = lb0 + y.o_atanh_b;
+    ca.ls_dil = lstep; ca.ls_aux = lstep;
+    ca.off_up_b = y.up_b;
+    ca.L = d.L; ca.R = d.R; ca.A = d.A;
+    ca.cvec = wpack + pl.off_cvec;
+    ca.rowsum_aux = wpack + pl.off_wauxf;  // scratch: overwritten by the aux weights below
+    WN_TRY(wn_cvec(&ca, st));
+    WN_TRY(wn_sum_layers(params, y.skip0 + (long)d.S * d.R, y.ls_skip, d.L, d.S, wpack + pl.off_bskip, st));
+    WnCopy4 cp;
+    for (int half = 0; half < 2; ++half) {
+        const long asrc = lb0 + (half ? y.o_atanh_w : y.o_asig_w);
+        cp.n0 = 1; cp.n1 = d.A; cp.n2 = d.R; cp.nl = d.L;
+        cp.s0 = 0; cp.s1 = 1; cp.s2 = d.A; cp.sl = lstep;
+        cp.d0 = 0; cp.d1 = (long)d.L * 2 * d.R; cp.d2 = 1; cp.dl = 2 * d.R;
+        WN_TRY(wn_copy4(wpack + pl.off_wauxf + (long)half * d.R, params + asrc, &cp, st));
+    }
+    WN_TRY(wn_fill(wpack + pl.off_one, 1.0f, 64, st));
+    return rt_check("wn_decode_pack");
+}
+
+extern "C" int wn_decode_aux(const WnConfig* cfg, int B, int F, const float* wpack, const float* h, float* G,
+                             void* stream) {
+    g_err[0] = 0;
+    Dims d;
+    WnDecodePlan pl;
+    WN_TRY(decode_plan(cfg, &d, &pl));
+    if (!wpack || !h || !G || B <= 0 || F <= 0) return fail(1, "bad argument");
+    const int nG = d.L * 2 * d.R;
+    // G[b] (F x nG) = h[b]^T (F x A) . waux_f (A x nG)
+    WnGemmArgs g = wn_gemm_default();
+    g.M = F; g.N = nG; g.K = d.A;
+    g.A = h; g.lda = F; g.a_zstride = (long)d.A * F;
+    g.B = wpack + pl.off_wauxf; g.ldb = nG; g.b_zstride = 0; g.b_clen = nG;
+    g.C = G; g.ldc = nG; g.c_zstride = (long)F * nG;
+    g.nbatch = B; g.tag = "decode_aux_frames";
+    WN_TRY(wn_gemm_launch(&g, (wn_stream_t)stream));
+    return rt_check("wn_decode_aux");
+}
+
+extern "C" int wn_decode_steps(const WnConfig* cfg, int B, const float* params, const float* wpack, const float* G, int F,
+                               int n_pad, int64_t* samples, int64_t Ttot, const int32_t* t_forced, const int32_t* t_end,
+                               int p0, int p1, float* state, const float* uniforms, float* logits_out, int mode,
+                               void* stream) {
+    g_err[0] = 0;
+    Dims d;
+    WnDecodePlan pl;
+    WN_TRY(decode_plan(cfg, &d, &pl));
+    if (!params || !wpack || !G || !samples || !t_forced || !t_end || !state) return fail(1, "NULL argument");
+    if (B <= 0 || F <= 0 || n_pad < 0 || p0 < 0 || p1 < p0 || Ttot <= 0 || p1 > Ttot - 1)
+        return fail(1, "bad decode range: B=%d F=%d n_pad=%d steps [%d,%d) Ttot=%ld", B, F, n_pad, p0, p1, (long)Ttot);
+    if (mode != 0 && mode != 1) return fail(1, "mode should be 0 (argmax) or 1 (sampling)");
+    if (mode == 1 && !uniforms) return fail(1, "sampling mode needs the uniform draws");
+    if (p1 == p0) return 0;
+    const Lay y = make_lay(d);
+    WnDecodeArgs a;
+    a.Q = d.Q; a.A = d.A; a.R = d.R; a.S = d.S; a.L = d.L; a.K = d.K; a.depth = cfg->dilation_depth;
+    a.plan = pl;
+    a.wpack = wpack;
+    a.params = params;
+    a.off_causal_w = y.causal_w; a.off_causal_b = y.causal_b;
+    a.off_res_b0 = layer_base(y, d, 0) + y.o_res_b; a.res_b_lstride = -y.LB;
+    a.off_post1_b = y.post1_b; a.off_post2_b = y.post2_b;
+    a.upw = d.U > 0 ? params + y.up_w : wpack + pl.off_one;
+    a.Ue = d.U > 0 ? d.U : 1;
+    a.G = G; a.g_bstride = (long)F * d.L * 2 * d.R; a.F = F; a.n_pad = n_pad;
+    a.samples = samples; a.s_bstride = Ttot;
+    a.t_forced = t_forced; a.t_end = t_end;
+    a.p0 = p0; a.p1 = p1;
+    a.queues = state; a.q_bstride = pl.queue_floats > 0 ? pl.queue_floats : 4;
+    a.uniforms = uniforms; a.u_bstride = Ttot;
+    a.logits_out = logits_out; a.lo_bstride = Ttot * d.Q;
+    a.mode = mode;
+    WN_TRY(wn_decode_launch(&a, B, (wn_stream_t)stream));
+    return rt_check("wn_decode_steps");
 }
 
 extern "C" int wn_op_gemm(const struct WnGemmArgs* args, void* stream) {

@@ -29,11 +29,23 @@ struct wn_rsrc_t {
 static inline wn_rsrc_t wn_make_buf(const void* p, unsigned) { return wn_rsrc_t{(const char*)p}; }
 static inline float wn_buf_load(wn_rsrc_t r, int voff, int soff) { return *(const float*)(r.base + (long)voff + (long)soff); }
 static inline void wn_buf_store(wn_rsrc_t r, float v, int voff, int soff) { *(float*)(r.base + (long)voff + (long)soff) = v; }
+static inline float4 wn_buf_load4(wn_rsrc_t r, int voff, unsigned soff) { return *(const float4*)(r.base + (long)voff + (long)soff); }
 #define WN_UNIFORM(x) (x)
 #define WN_SCHED_BARRIER()
 #define WN_SLEEP(n)
 #define WN_SGB_DS(n)
 #define WN_SGB_MFMA(n)
+// workgroup barrier that orders LDS traffic only (outstanding global loads stay in flight)
+#define WN_LDS_BARRIER() __syncthreads()
+// load that must observe earlier stores of other waves of the same workgroup (bypasses the L1)
+static inline float wn_ld_coherent(const float* p) { return *p; }
+// v + the value of lane (l ^ m); all lanes of an aligned group of 2m hold the same partial sums
+static inline float wn_xor_add(float v, int m) { return v + __shfl_xor(v, m, 64); }
+// two-lane fp32 vector for v_pk_fma_f32
+struct f32x2 {
+    float x, y;
+};
+static inline f32x2 wn_pk_fma(f32x2 a, f32x2 b, f32x2 c) { return f32x2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -58,6 +70,11 @@ static __device__ __forceinline__ float wn_buf_load(wn_rsrc_t r, int voff, int s
 static __device__ __forceinline__ void wn_buf_store(wn_rsrc_t r, float v, int voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voff, soff, 0);
 }
+// 16-byte load: per-lane byte offset in a VGPR, wave-uniform byte offset in an SGPR (no 64-bit
+// per-lane address registers -- a register ring of weights needs none)
+static __device__ __forceinline__ float4 wn_buf_load4(wn_rsrc_t r, int voff, unsigned soff) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, (int)soff, 0));
+}
 // make a value the compiler can prove wave-uniform (it IS uniform: derived from the wave id)
 #define WN_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 // scheduling fence: hipcc may not move instructions across it (pins software-pipeline issue order)
@@ -66,6 +83,30 @@ static __device__ __forceinline__ void wn_buf_store(wn_rsrc_t r, float v, int vo
 // scheduling groups: "the next n DS reads" / "the next n MFMAs" are emitted as a block in this order
 #define WN_SGB_DS(n) __builtin_amdgcn_sched_group_barrier(0x100, (n), 0)
 #define WN_SGB_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, (n), 0)
+// s_barrier preceded by lgkmcnt(0) only: LDS writes are visible afterwards, while prefetched
+// global loads stay outstanding (a __syncthreads() would also wait for vmcnt(0)).
+#define WN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+static __device__ __forceinline__ float wn_ld_coherent(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// v + partner value, partner in the other half of the aligned 2m-lane group.  m = 1,2,4,8 are DPP
+// moves (quad_perm / row_half_mirror / row_mirror: valid because after the previous steps every
+// lane of an m-lane group holds the same partial sum); larger m goes through ds_bpermute.
+static __device__ __forceinline__ float wn_xor_add(float v, int m) {
+    const int iv = __builtin_bit_cast(int, v);
+    int o;
+    switch (m) {
+        case 1: o = __builtin_amdgcn_update_dpp(0, iv, 0xB1, 0xF, 0xF, true); break;   // quad_perm [1,0,3,2]
+        case 2: o = __builtin_amdgcn_update_dpp(0, iv, 0x4E, 0xF, 0xF, true); break;   // quad_perm [2,3,0,1]
+        case 4: o = __builtin_amdgcn_update_dpp(0, iv, 0x141, 0xF, 0xF, true); break;  // row_half_mirror
+        case 8: o = __builtin_amdgcn_update_dpp(0, iv, 0x140, 0xF, 0xF, true); break;  // row_mirror
+        default: return v + __shfl_xor(v, m, 64);
+    }
+    return v + __builtin_bit_cast(float, o);
+}
+// two-lane fp32 vector: fma on it is one v_pk_fma_f32
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ f32x2 wn_pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 #define WN_UNROLL _Pragma("unroll")
 #define WN_PRAGMA(x) _Pragma(#x)
 #define WN_UNROLL_N(n) WN_PRAGMA(unroll n)

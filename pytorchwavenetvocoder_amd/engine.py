@@ -178,6 +178,70 @@ class WaveNetEngine(object):
                                    _stream_handle(self.device))
         self.lib.check(rc, "wn_adam_step")
 
+    # ---- autoregressive decode (reference wavenet.py:309-511) ---------------------------------
+    def decode_supported(self):
+        return bool(self.lib.wn_decode_supported(ctypes.byref(self.cfg)))
+
+    def decode(self, x, h, n_samples_list, mode="argmax", chunk=4096, return_logits=False, progress=None):
+        """Queue-based sample-by-sample generation on the HIP decode kernel.
+
+        x (B,T0) int64 context, h (B, n_aux, frames | samples) aux features covering T0 + max(n)
+        samples, n_samples_list: samples to generate per utterance.  Follows the reference's prologue
+        (wavenet.py:328-336, 417-425): the context is left-padded with n_quantize//2 up to the
+        receptive field and the aux features by replicating their first column.  Returns the
+        generated tokens as a list of LongTensors (utterance order) [and the per-step logits].
+        """
+        self._check_device(x, h)
+        if x.dtype != torch.int64 or x.dim() != 2 or h.dim() != 3:
+            raise ValueError("x must be a LongTensor (B, T) and h a FloatTensor (B, n_aux, F)")
+        if mode not in ("argmax", "sampling"):
+            raise ValueError("mode should be sampling or argmax")
+        cfg = ctypes.byref(self.cfg)
+        B, T0 = x.shape
+        if len(n_samples_list) != B or h.size(0) != B or h.size(1) != self.cfg.n_aux:
+            raise ValueError("batch mismatch between x, h and n_samples_list")
+        U = self.cfg.upsampling_factor
+        n_max = int(max(n_samples_list))
+        need = T0 + n_max - 1   # last aux column read: sample index T0 + n_max - 2
+        F = h.size(2)
+        if (F * U if U > 0 else F) < need:
+            raise ValueError("h covers %d samples, %d needed" % (F * U if U > 0 else F, need))
+        n_pad = max(self.receptive_field - T0, 0)
+        Tctx = T0 + n_pad
+        Ttot = Tctx + n_max
+        npk = self.lib.wn_decode_pack_floats(cfg)
+        if npk <= 0:
+            raise _lib.WnError("wn_decode_pack_floats: %s" % self.lib.wn_last_error().decode())
+        st = _stream_handle(self.device)
+        dev = self.device
+        wpack = torch.empty(npk, dtype=torch.float32, device=dev)
+        self.lib.check(self.lib.wn_decode_pack(cfg, _ptr(self.flat_params), _ptr(wpack), st), "wn_decode_pack")
+        h = h.contiguous().float()
+        G = torch.empty((B, F, self.n_layers * 2 * self.cfg.n_resch), dtype=torch.float32, device=dev)
+        self.lib.check(self.lib.wn_decode_aux(cfg, B, F, _ptr(wpack), _ptr(h), _ptr(G), st), "wn_decode_aux")
+        samples = torch.full((B, Ttot), self.cfg.n_quantize // 2, dtype=torch.int64, device=dev)
+        samples[:, n_pad:Tctx] = x
+        t_forced = torch.full((B,), Tctx, dtype=torch.int32, device=dev)
+        t_end = torch.tensor([Tctx + int(n) for n in n_samples_list], dtype=torch.int32, device=dev)
+        state = torch.zeros((B, self.lib.wn_decode_state_floats(cfg)), dtype=torch.float32, device=dev)
+        uniforms = torch.rand((B, Ttot), dtype=torch.float32, device=dev) if mode == "sampling" else None
+        logits = torch.zeros((B, Ttot, self.cfg.n_quantize), dtype=torch.float32, device=dev) if return_logits else None
+        p = 0
+        while p < Ttot - 1:
+            p1 = min(p + chunk, Ttot - 1)
+            rc = self.lib.wn_decode_steps(cfg, B, _ptr(self.flat_params), _ptr(wpack), _ptr(G), F, n_pad, _ptr(samples),
+                                          Ttot, _ptr(t_forced), _ptr(t_end), p, p1, _ptr(state), _ptr(uniforms),
+                                          _ptr(logits), 1 if mode == "sampling" else 0, st)
+            self.lib.check(rc, "wn_decode_steps")
+            p = p1
+            if progress is not None:
+                progress(max(p + 1 - Tctx, 0), n_max)
+        out = [samples[b, Tctx:Tctx + int(n)] for b, n in enumerate(n_samples_list)]
+        if return_logits:   # row Tctx-1+i holds the logits that chose generated sample i
+            return out, [logits[b, Tctx - 1:Tctx - 1 + int(n)] for b, n in enumerate(n_samples_list)]
+        return out
+
+
 
 # ---- reference state_dict keys <-> flat buffer ------------------------------------------------
 _LIST_KINDS = {

@@ -361,22 +361,68 @@ class WaveNet(nn.Module):
                     start = time.time()
             return np.array(samples[-n_samples:])
 
+    def _decode(self, x, h, n_samples_list, intervals, mode):
+        """Run the HIP decode kernel (csrc/wn_decode.hip); returns per-utterance LongTensors."""
+        if mode not in ("sampling", "argmax"):
+            logging.error("mode should be sampling or argmax")
+            sys.exit(1)
+        start = [time.time(), 0]
+
+        def progress(done, total):
+            if intervals is not None and done > start[1]:
+                dt = (time.time() - start[0]) / (done - start[1])
+                logging.info("%d/%d estimated time = %.3f sec (%.3f sec / sample)" % (
+                    done, total, (total - done) * dt, dt))
+                start[0], start[1] = time.time(), done
+
+        with torch.no_grad():
+            return self.engine.decode(x, h, list(n_samples_list), mode=mode,
+                                      chunk=intervals if intervals else 4096, progress=progress)
+
     def fast_generate(self, x, h, n_samples, intervals=None, mode="sampling"):
-        """Reference wavenet.py:309-395.  Round 1: same results as ``generate`` (the reference's own
-        tests assert argmax equality of the two, test/test_wavenet.py:93-222); the cached
-        dilation-queue decode kernel is the next hot-path row (SURVEY.md 8f #1)."""
-        return self.generate(x, h, n_samples, intervals, mode)
+        """Generate a waveform with the queue algorithm (reference wavenet.py:309-395) on the HIP
+        decode kernel: one persistent workgroup walks the context (which fills the dilation
+        queues) and then emits ``n_samples`` tokens; nothing but the result leaves the GPU.
+
+        Args:
+            x (tensor): Long tensor variable with the shape  (1, T).
+            h (tensor): Float tensor variable with the shape  (1, n_aux, n_samples + T)
+                (frames if the model up-samples).
+            n_samples (int): Number of samples to be generated.
+            intervals (int): Log interval.
+            mode (str): "sampling" or "argmax".
+
+        Returns:
+            ndarray: Generated quantized waveform (n_samples,).
+        """
+        if not self.engine.decode_supported():
+            logging.warning("decode kernel does not cover this model size; using full-window forwards")
+            return self.generate(x, h, n_samples, intervals, mode)
+        return self._decode(x, h, [n_samples], intervals, mode)[0].cpu().numpy()
 
     def batch_fast_generate(self, x, h, n_samples_list, intervals=None, mode="sampling"):
-        """Reference wavenet.py:397-511: per-utterance lengths; returned in order of completion
-        (shortest first), like the reference."""
+        """Batched queue-algorithm generation (reference wavenet.py:397-511): one workgroup per
+        utterance, each stops at its own length.  Returns the list of generated waveforms in order
+        of completion (shortest first), like the reference.
+
+        Args:
+            x (tensor): Long tensor variable with the shape (B, T).
+            h (tensor): Float tensor variable with the shape (B, n_aux, max(n_samples_list) + T).
+            n_samples_list (list): List of number of samples to be generated (B,).
+            intervals (int): Log interval.
+            mode (str): "sampling" or "argmax".
+        """
         order = sorted(range(len(n_samples_list)), key=lambda i: (n_samples_list[i], i))
-        T = x.size(1)
-        out = []
-        for i in order:
-            n = n_samples_list[i]
-            hi = h[i:i + 1, :, :]
-            if self.upsampling_factor == 0:
-                hi = hi[:, :, :n + T]
-            out.append(self.generate(x[i:i + 1], hi, n, intervals, mode))
-        return out
+        if not self.engine.decode_supported():
+            logging.warning("decode kernel does not cover this model size; using full-window forwards")
+            T = x.size(1)
+            out = []
+            for i in order:
+                n = n_samples_list[i]
+                hi = h[i:i + 1, :, :]
+                if self.upsampling_factor == 0:
+                    hi = hi[:, :, :n + T]
+                out.append(self.generate(x[i:i + 1], hi, n, intervals, mode))
+            return out
+        toks = self._decode(x, h, n_samples_list, intervals, mode)
+        return [toks[i].cpu().numpy() for i in order]

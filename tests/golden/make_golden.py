@@ -131,9 +131,66 @@ def model_facts():
     print("cfg2: rf=%d n_params=%d n_keys=%d" % (m.receptive_field, n, len(keys)))
 
 
+# ---- generation (BASELINE config 5): reference generate / fast_generate / batch_fast_generate ----
+DECODE_CASES = {
+    # name: (cfg tuple, context length T0, n_samples list (batch), seed, param scale)
+    "decode_tiny_k2_up": ((32, 5, 8, 12, 3, 2, 2, 4), 1, [24, 17], 21, 0.5),
+    "decode_tiny_k3_noup": ((32, 5, 8, 12, 3, 1, 3, 0), 7, [20, 20, 9], 22, 0.5),
+    "decode_r64_k2_up": ((256, 12, 64, 96, 4, 2, 2, 8), 1, [40, 33], 23, 0.2),
+    "decode_r64_longctx": ((64, 6, 64, 32, 3, 1, 2, 0), 30, [25], 24, 0.3),
+}
+
+
+def decode_inputs(cfg, T0, n_list, seed):
+    """Machine-independent inputs of a decode case (numpy RandomState)."""
+    rs = np.random.RandomState(seed + 2000)
+    B = len(n_list)
+    x = torch.from_numpy(rs.randint(0, cfg.n_quantize, (B, T0))).long()
+    U = cfg.upsampling_factor
+    tot = max(n_list) + T0
+    nf = (tot + U - 1) // U if U > 0 else tot
+    h = torch.from_numpy(rs.standard_normal((B, cfg.n_aux, nf)).astype(np.float32))
+    return x, h
+
+
+def run_decode_case(name, spec):
+    cfg_t, T0, n_list, seed, scale = spec
+    cfg = O.OracleConfig(*cfg_t)
+    params = O.random_params(cfg, seed, scale=scale)
+    model = WaveNet(*cfg_t)
+    model.load_state_dict(params)
+    model.eval()
+    x, h = decode_inputs(cfg, T0, n_list, seed)
+    out = {"cfg": np.array(cfg_t), "T0": np.array(T0), "n_list": np.array(n_list), "seed": np.array(seed),
+           "scale": np.array(scale)}
+    margins = []
+    with torch.no_grad():
+        for b, n in enumerate(n_list):
+            hb = h[b:b + 1]
+            fast = model.fast_generate(x[b:b + 1], hb, n, mode="argmax")          # REFERENCE
+            naive = model.generate(x[b:b + 1], hb, n, mode="argmax")              # REFERENCE
+            out["fast/%d" % b] = np.asarray(fast)
+            out["naive/%d" % b] = np.asarray(naive)
+            # top-2 logit margin along the generated path (oracle logits; tokens are checked equal)
+            tok, lg = O.fast_generate(cfg, params, x[b:b + 1], hb, n, return_logits=True)
+            assert (tok == np.asarray(fast)).all(), name
+            top2 = lg.topk(2, dim=1).values
+            margins.append(float((top2[:, 0] - top2[:, 1]).min()))
+            out["logits/%d" % b] = lg.numpy()
+        batch = model.batch_fast_generate(x, h, list(n_list), mode="argmax")       # REFERENCE
+        for i, a in enumerate(batch):
+            out["batch/%d" % i] = np.asarray(a)
+    out["min_margin"] = np.array(min(margins))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote %s: min top-2 margin %.3e, distinct tokens %d" % (
+        name, min(margins), len(set(np.concatenate([out["fast/%d" % b] for b in range(len(n_list))]).tolist()))))
+
+
 if __name__ == "__main__":
     for name, spec in CASES.items():
         run_case(name, spec)
+    for name, spec in DECODE_CASES.items():
+        run_decode_case(name, spec)
     mulaw_vectors()
     upsampling_vectors()
     model_facts()

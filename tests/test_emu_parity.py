@@ -8,6 +8,7 @@ import torch
 from tests import parity_common as PC
 from tests.emu_util import emu_library
 from tests.golden_util import CASES, GoldenCase
+from tests.decode_common import DECODE_CASES, check_decode_case
 
 pytestmark = pytest.mark.emu
 
@@ -51,6 +52,12 @@ def test_vector_staging_paths():
 def test_wide_channels_multi_tile():
     # R > 64 exercises the 128-wide tiles and multi-tile M
     PC.run_oracle_vs_engine((48, 9, 96, 160, 2, 1, 2, 4), 1, 72, 7, emu_library(), "cpu")
+
+
+@pytest.mark.parametrize("name", DECODE_CASES)
+def test_decode_vs_reference_generation(name):
+    """Decode kernel (wn_decode.hip) == the reference's fast_generate / batch_fast_generate outputs."""
+    check_decode_case(name, emu_library(), "cpu")
 
 
 def test_cpu_tensors_rejected_by_product_binding():

@@ -160,3 +160,58 @@ def test_cfg2_full_size_properties():
     eng.flat_params.copy_(p0)
     fd = (float(lp.cpu()) - float(lm.cpu())) / (2 * eps)
     assert abs(fd - gnorm2) <= 0.05 * gnorm2 + 1e-6, (fd, gnorm2, base)
+
+
+# ---- autoregressive decode (BASELINE config 5, wn_decode.hip) -----------------------------------
+import numpy as np  # noqa: E402
+
+from oracle import wavenet_oracle as O  # noqa: E402
+from tests.decode_common import DECODE_CASES, check_decode_case  # noqa: E402
+
+
+@pytest.mark.parametrize("name", DECODE_CASES)
+def test_decode_vs_reference_generation(name):
+    """Decode kernel == the reference's fast_generate / batch_fast_generate golden outputs."""
+    check_decode_case(name, _lib(), DEV)
+
+
+def test_decode_cfg2_teacher_forced_equals_training_forward():
+    """Full-size model (30 layers, 64/256 channels, U=80): the logits the decode kernel computes
+    while it walks a context longer than the receptive field must equal the training forward's
+    logits at the same positions (same HIP library, two very different kernels), and the generated
+    continuation must be the argmax path of the training forward."""
+    from pytorchwavenetvocoder_amd.nets import WaveNet
+    cfg = O.OracleConfig(256, 80, 64, 256, 10, 3, 2, 80)
+    params = O.random_params(cfg, 77, scale=0.1)
+    model = WaveNet(*cfg.as_tuple())
+    model.load_state_dict(params)
+    model.to(DEV)
+    B, T0, n = 2, 3360, 80          # T0 > rf = 3070, multiple of U
+    rs = np.random.RandomState(78)
+    x = torch.from_numpy(rs.randint(0, 256, (B, T0))).long().to(DEV)
+    h = torch.from_numpy(rs.standard_normal((B, 80, (T0 + n) // 80)).astype(np.float32)).to(DEV)
+    toks, lg = model.engine.decode(x, h, [n, n - 17], mode="argmax", return_logits=True, chunk=1000)
+    full = torch.cat([x, torch.stack([toks[0], torch.cat([toks[1], toks[1].new_zeros(17)])])], dim=1)
+    logits = model.engine.forward(full, h)          # (B, Q, T0+n)
+    for b, nb in enumerate([n, n - 17]):
+        # generated sample i was chosen from the logits of position T0-1+i
+        ref = logits[b, :, T0 - 1:T0 - 1 + nb].transpose(0, 1)
+        assert float((lg[b] - ref).abs().max()) <= 1e-4
+        top2 = ref.topk(2, dim=1).values
+        safe = (top2[:, 0] - top2[:, 1]) > 1e-3
+        assert bool((ref.argmax(1)[safe] == toks[b][safe]).all())
+        assert int(safe.sum()) > nb // 2
+
+
+def test_decode_unsupported_size_falls_back_to_window_forwards():
+    from pytorchwavenetvocoder_amd.nets import WaveNet
+    cfg = O.OracleConfig(32, 4, 128, 32, 2, 1, 2, 0)   # n_resch=128: outside the compiled decode classes
+    model = WaveNet(*cfg.as_tuple())
+    model.load_state_dict(O.random_params(cfg, 3, scale=0.3))
+    model.to(DEV)
+    assert not model.engine.decode_supported()
+    x = torch.tensor([[5, 9, 1, 30]]).long().to(DEV)
+    h = torch.from_numpy(np.random.RandomState(4).standard_normal((1, 4, 16)).astype(np.float32)).to(DEV)
+    a = model.fast_generate(x, h, 10, mode="argmax")
+    b = O.generate(cfg, O.random_params(cfg, 3, scale=0.3), x.cpu(), h.cpu(), 10)
+    assert (a == b).all()

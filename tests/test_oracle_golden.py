@@ -72,3 +72,21 @@ def test_cfg2_facts():
     assert sum(int(np.prod(s)) for s in shapes.values()) == int(z["n_params"]) == 1594897
     geo = O.batch_geometry(cfg.receptive_field, 20000, 80)
     assert geo == {"batch_length": 19970, "frames": 288, "T": 23040, "loss_positions": 19970}
+
+
+# ---- generation (BASELINE config 5): oracle restatement vs the reference's own outputs ----------
+from tests.decode_common import DECODE_CASES, DecodeCase  # noqa: E402
+
+
+@pytest.mark.parametrize("name", DECODE_CASES)
+def test_oracle_generation_vs_reference(name):
+    g = DecodeCase(name)
+    for b, n in enumerate(g.n_list):
+        xb, hb = g.x[b:b + 1], g.h[b:b + 1]
+        fast, lg = O.fast_generate(g.cfg, g.params, xb, hb, n, return_logits=True)
+        assert (fast == g.fast[b]).all()
+        assert float((lg - g.logits[b]).abs().max()) <= 1e-5
+        assert (O.generate(g.cfg, g.params, xb, hb, n) == g.naive[b]).all()
+    batch = O.batch_fast_generate(g.cfg, g.params, g.x, g.h, g.n_list)
+    for a, r in zip(batch, g.batch):
+        assert (a == r).all()
