@@ -97,6 +97,43 @@ def cpu_baseline(seconds_budget=25.0):
                           T, cands, best_thr, len(times), best, sorted(times)[len(times) // 2])}
 
 
+def decode_report(model, device, with_cpu):
+    """BASELINE configs[4]: sample-by-sample generation on the same 30-layer model (argmax mode, seed
+    token 128), the decode kernel of csrc/wn_decode.hip; beside it the oracle's queue algorithm
+    (reference wavenet.py:309-395 restated) on the host cores for a few samples."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import decode_bench
+    out = {"workload": "BASELINE configs[4]: fast_generate / batch_fast_generate on the configs[1] model, argmax, "
+                       "context = receptive field (3070 teacher-forced steps, reported separately)"}
+    for B, n in ((1, 2000), (256, 2000)):
+        m = decode_bench.measure(model, B, n, device)
+        out["batch%d" % B] = {k: m[k] for k in ("us_per_step", "samples_per_sec_per_utt", "samples_per_sec", "context_s")}
+    # per step one workgroup streams the packed weights once: compulsory bytes = the stream
+    eng = model.engine
+    stream_bytes = float(eng.lib.wn_decode_stream_bytes(ctypes.byref(eng.cfg)))
+    out["stream_bytes_per_step"] = stream_bytes
+    out["stream_GBps_per_workgroup"] = stream_bytes / (out["batch1"]["us_per_step"] * 1e-6) / 1e9
+    out["stream_note"] = "one CU sustains ~112 GB/s on a 5 MB cyclic read (tools/stream_probe.hip, profiles/r01/stream_probe.txt)"
+    if with_cpu:
+        from oracle import wavenet_oracle as O
+        cfg = O.OracleConfig(*[CFG2[k] for k in ("n_quantize", "n_aux", "n_resch", "n_skipch", "dilation_depth",
+                                                  "dilation_repeat", "kernel_size", "upsampling_factor")])
+        params = O.init_params(cfg, generator=torch.Generator().manual_seed(1))
+        x = torch.full((1, 1), 128, dtype=torch.int64)
+        n = 40
+        h = torch.randn(1, cfg.n_aux, (n + 1 + 79) // 80)
+        torch.set_num_threads(8)
+        t0 = time.time()
+        O.fast_generate(cfg, params, x, h, 1)
+        t_ctx = time.time() - t0
+        t0 = time.time()
+        O.fast_generate(cfg, params, x, h, n)
+        t_all = time.time() - t0
+        out["cpu_baseline"] = {"value": (n - 1) / max(t_all - t_ctx, 1e-9), "unit": "audio-samples/sec", "cores": 8,
+                               "kind": "port", "sample": "oracle fast_generate, B=1, %d samples after the context" % n}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,6 +141,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="sequences per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the configs[4] generation measurement")
     ap.add_argument("--no-fused", action="store_true", help="force the layered (any-size) kernels")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra untimed steps with per-launch HIP events")
     args = ap.parse_args()
@@ -252,6 +290,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         else:
             out["cpu_baseline"] = None
+        if not args.no_decode and world == 1:
+            out["decode"] = decode_report(model, device, not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -167,6 +167,7 @@ int wn_op_gemm(const struct WnGemmArgs* args, void* stream);
 int wn_decode_supported(const WnConfig* cfg);
 int64_t wn_decode_pack_floats(const WnConfig* cfg);   /* floats of the packed decode weights, <0: unsupported */
 int64_t wn_decode_state_floats(const WnConfig* cfg);  /* floats of queue state per utterance */
+int64_t wn_decode_stream_bytes(const WnConfig* cfg);  /* weight bytes one workgroup streams per step */
 /* Re-pack the flat parameter buffer into the per-thread weight stream + side tables. */
 int wn_decode_pack(const WnConfig* cfg, const float* params, float* wpack, void* stream);
 /* Aux projections of all layers at the aux rate: G[b][f][l*2R+o'] = Waux_l h[b][:, f] (wavenet.py:541-542).

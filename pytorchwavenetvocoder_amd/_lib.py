@@ -72,7 +72,7 @@ EXPORTS = [
     "wn_num_buckets", "wn_bucket_range", "wn_dead_param_range", "wn_workspace_bytes", "wn_forward",
     "wn_softmax_ce_loss", "wn_backward", "wn_adam_step", "wn_op_front", "wn_op_causal_conv", "wn_op_gemm", "wn_prof_enable", "wn_prof_report",
     "wn_decode_supported", "wn_decode_pack_floats", "wn_decode_state_floats", "wn_decode_pack", "wn_decode_aux",
-    "wn_decode_steps",
+    "wn_decode_steps", "wn_decode_stream_bytes",
 ]
 
 
@@ -114,6 +114,8 @@ class WnLibrary(object):
         L.wn_decode_pack_floats.restype = i64
         L.wn_decode_state_floats.argtypes = [cfgp]
         L.wn_decode_state_floats.restype = i64
+        L.wn_decode_stream_bytes.argtypes = [cfgp]
+        L.wn_decode_stream_bytes.restype = i64
         L.wn_decode_pack.argtypes = [cfgp, vp, vp, vp]
         L.wn_decode_aux.argtypes = [cfgp, i, i, vp, vp, vp, vp]
         L.wn_decode_steps.argtypes = [cfgp, i, vp, vp, vp, i, i, vp, i64, vp, vp, i, i, vp, vp, vp, i, vp]

@@ -920,6 +920,13 @@ extern "C" int64_t wn_decode_state_floats(const WnConfig* cfg) {
     return pl.queue_floats > 0 ? pl.queue_floats : 4;
 }
 
+extern "C" int64_t wn_decode_stream_bytes(const WnConfig* cfg) {
+    Dims d;
+    WnDecodePlan pl;
+    if (decode_plan(cfg, &d, &pl)) return -1;
+    return pl.stream_f4 * 16;
+}
+
 extern "C" int wn_decode_pack(const WnConfig* cfg, const float* params, float* wpack, void* stream) {
     g_err[0] = 0;
     Dims d;
