@@ -29,6 +29,7 @@ struct wn_rsrc_t {
 static inline wn_rsrc_t wn_make_buf(const void* p, unsigned) { return wn_rsrc_t{(const char*)p}; }
 static inline float wn_buf_load(wn_rsrc_t r, int voff, int soff) { return *(const float*)(r.base + (long)voff + (long)soff); }
 static inline void wn_buf_store(wn_rsrc_t r, float v, int voff, int soff) { *(float*)(r.base + (long)voff + (long)soff) = v; }
+static inline void wn_buf_store_nt(wn_rsrc_t r, float v, int voff, int soff) { wn_buf_store(r, v, voff, soff); }
 static inline float4 wn_buf_load4(wn_rsrc_t r, int voff, unsigned soff) { return *(const float4*)(r.base + (long)voff + (long)soff); }
 #define WN_UNIFORM(x) (x)
 #define WN_SCHED_BARRIER()
@@ -69,6 +70,13 @@ static __device__ __forceinline__ float wn_buf_load(wn_rsrc_t r, int voff, int s
 }
 static __device__ __forceinline__ void wn_buf_store(wn_rsrc_t r, float v, int voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voff, soff, 0);
+}
+#ifndef WN_NT_AUX
+#define WN_NT_AUX 2  // aux bit 1 = nt on gfx94x/gfx950
+#endif
+// streaming store (nt): the line is not kept in L2 -- for tensors whose next reader is a later kernel
+static __device__ __forceinline__ void wn_buf_store_nt(wn_rsrc_t r, float v, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voff, soff, WN_NT_AUX);
 }
 // 16-byte load: per-lane byte offset in a VGPR, wave-uniform byte offset in an SGPR (no 64-bit
 // per-lane address registers -- a register ring of weights needs none)
