@@ -75,6 +75,9 @@ enum {
 
 /* flags for wn_forward */
 #define WN_FLAG_NO_FUSED 1 /* force the any-size layered path even when the fused R=64 kernels apply */
+#define WN_FLAG_EXACT_MFMA 2 /* every contraction on the exact f32-input MFMA (default: the skip-sum / post-net
+                              * contractions run on the bf16 matrix cores with a 3-way operand split whose six
+                              * products reproduce fp32 to round-off; csrc/wn_gemm6.hip) */
 
 int wn_abi_version(void);
 const char* wn_last_error(void);

@@ -64,6 +64,7 @@ class WnGemmArgs(ctypes.Structure):
  P_ATANH_W, P_ATANH_B, P_SKIP_W, P_SKIP_B, P_RES_W, P_RES_B, P_POST1_W, P_POST1_B, P_POST2_W, P_POST2_B) = range(20)
 
 FLAG_NO_FUSED = 1
+FLAG_EXACT_MFMA = 2
 ABI_VERSION = 1
 
 # every symbol include/wavenet_hip.h declares

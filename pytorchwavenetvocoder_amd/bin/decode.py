@@ -127,8 +127,12 @@ def build_model(config):
 
 
 def _worker(gpu, feat_list, args, config, mean, scale):
+    with torch.no_grad():
+        _decode_files(gpu, feat_list, args, config, mean, scale)
+
+
+def _decode_files(gpu, feat_list, args, config, mean, scale):
     torch.cuda.set_device(gpu)
-    torch.set_grad_enabled(False)
     device = torch.device("cuda", gpu)
     model = build_model(config)
     model.load_state_dict(torch.load(args.checkpoint, map_location="cpu", weights_only=False)["model"])

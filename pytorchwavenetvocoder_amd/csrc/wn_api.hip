@@ -12,6 +12,7 @@
 #include "wn_elem.h"
 #include "wn_fused.h"
 #include "wn_gemm.h"
+#include "wn_gemm6.h"
 
 // ------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -250,7 +251,7 @@ static DwPlan dw_plan(int M, int N, int Kdim, int nbatch) {
 // ------------------------------------------------------------------------------------------
 struct Ws {
     // packed weights
-    long wc_f, wd_f, waux_f, cvec, rowsum_aux, wres_f, wskip_f, bskip, w1_f, w2_f, wd_b, one;
+    long wc_f, wd_f, waux_f, cvec, rowsum_aux, wres_f, wskip_f, bskip, w1_f, w2_f, wd_b, one, apk;
     // saved activations
     long X, G, Sg, Gt, Z, O1, O2;
     // scratch
@@ -322,6 +323,12 @@ static int make_ws(const Dims& d, int B, int T, Ws* w) {
     w->red_scratch_floats = 1 << 20;
     CARVE(red_scratch, w->red_scratch_floats);
     CARVE(loss_partial, wn_softmax_ce_nblocks(B, T) + 64);
+    {   // split-bf16 weights of the forward-type contractions (wn_gemm6): one buffer, re-packed before each use
+        long e = wn_gemm6_apk_elems(d.S, d.L * d.R);
+        const long e1 = wn_gemm6_apk_elems(d.S > d.Q ? d.S : d.Q, d.S > d.Q ? d.S : d.Q);
+        if (e1 > e) e = e1;
+        CARVE(apk, (e + 1) / 2);
+    }
 #undef CARVE
     w->total = o;
     return 0;
@@ -344,6 +351,7 @@ struct Ctx {
     float* ws;
     wn_stream_t st;
     bool fused;
+    bool split_bf16;  // forward-type contractions on the bf16 matrix cores (3-way split, fp32-equivalent)
 };
 
 static int make_ctx(Ctx* c, const WnConfig* cfg, int B, int T, void* ws, size_t ws_bytes, int flags, void* stream) {
@@ -359,12 +367,32 @@ static int make_ctx(Ctx* c, const WnConfig* cfg, int B, int T, void* ws, size_t 
     c->ws = (float*)ws;
     c->st = (wn_stream_t)stream;
     c->fused = wn_fused_supported(c->d.R, c->d.K, c->d.S) && !(flags & WN_FLAG_NO_FUSED);
+    c->split_bf16 = !(flags & WN_FLAG_EXACT_MFMA);
     return 0;
 }
 
 // ------------------------------------------------------------------------------------------
 // weight packing (once per forward; weights change every optimizer step)
 // ------------------------------------------------------------------------------------------
+// Weights x activations contraction: split-bf16 matrix-core kernel when the launch has its shape
+// (>= 128 output rows, k-minor operands, no shifts), the exact-f32 MFMA kernel otherwise.
+static int fw_gemm(const Ctx& c, const WnGemmArgs& g) {
+    const bool ok = c.split_bf16 && g.M >= 128 && !g.a_kmajor && !g.b_kmajor && g.b_shift0 == 0 && g.b_shift_step == 0 &&
+                    (g.b_seg_len >= g.K || g.b_seg_len % 16 == 0) && !g.D && !g.accumulate && g.ksplit == 1 &&
+                    g.nlayer == 1 && !g.b_relu && !g.b_index && g.a_zstride == 0 && !g.a_rowsum && g.b_clen >= g.N;
+    if (!ok) return wn_gemm_launch(&g, c.st);
+    unsigned short* apk = reinterpret_cast<unsigned short*>(c.ws + c.w.apk);
+    WN_TRY(wn_gemm6_pack(g.A, g.lda, g.M, g.K, apk, c.st));
+    WnGemm6Args a;
+    a.M = g.M; a.N = g.N; a.K = g.K;
+    a.Apk = apk; a.Mpad = (g.M + WN_G6_BM - 1) / WN_G6_BM * WN_G6_BM;
+    a.B = g.B; a.ldb = g.ldb; a.b_zstride = g.b_zstride; a.b_seg_len = g.b_seg_len; a.b_seg_stride = g.b_seg_stride;
+    a.C = g.C; a.ldc = g.ldc; a.c_zstride = g.c_zstride;
+    a.bias = g.bias; a.E = g.E; a.lde = g.lde; a.e_zstride = g.e_zstride; a.relu = g.relu;
+    a.nbatch = g.nbatch; a.tag = g.tag;
+    return wn_gemm6_launch(&a, c.st);
+}
+
 static int pack_weights(const Ctx& c, const float* params) {
     const Dims& d = c.d;
     const Lay& y = c.y;
@@ -507,7 +535,7 @@ extern "C" int wn_forward(const WnConfig* cfg, int B, int T, const float* params
         g.b_seg_len = d.R; g.b_seg_stride = BRT;
         g.C = ws + w.O1; g.ldc = T; g.c_zstride = (long)d.S * T;
         g.bias = ws + w.bskip; g.relu = 1; g.nbatch = B; g.tag = "fwd_skip_sum";
-        WN_TRY(wn_gemm_launch(&g, c.st));
+        WN_TRY(fw_gemm(c, g));
     }
     {   // conv_post_1 + relu  (wavenet.py:520-521)
         WnGemmArgs g = wn_gemm_default();
@@ -516,7 +544,7 @@ extern "C" int wn_forward(const WnConfig* cfg, int B, int T, const float* params
         g.B = ws + w.O1; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = T;
         g.C = ws + w.O2; g.ldc = T; g.c_zstride = (long)d.S * T;
         g.bias = params + y.post1_b; g.relu = 1; g.nbatch = B; g.tag = "fwd_post1";
-        WN_TRY(wn_gemm_launch(&g, c.st));
+        WN_TRY(fw_gemm(c, g));
     }
     {   // conv_post_2  (wavenet.py:522)
         WnGemmArgs g = wn_gemm_default();
@@ -525,7 +553,7 @@ extern "C" int wn_forward(const WnConfig* cfg, int B, int T, const float* params
         g.B = ws + w.O2; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = T;
         g.C = logits; g.ldc = T; g.c_zstride = (long)d.Q * T;
         g.bias = params + y.post2_b; g.nbatch = B; g.tag = "fwd_post2";
-        WN_TRY(wn_gemm_launch(&g, c.st));
+        WN_TRY(fw_gemm(c, g));
     }
     return rt_check("wn_forward");
 }
@@ -628,7 +656,7 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
         g.C = ws + w.dO2; g.ldc = T; g.c_zstride = (long)d.S * T;
         g.E = ws + w.O2; g.lde = T; g.e_zstride = (long)d.S * T;
         g.nbatch = B; g.tag = "bwd_post2_dx";
-        WN_TRY(wn_gemm_launch(&g, c.st));
+        WN_TRY(fw_gemm(c, g));
     }
     {   // dSkip = W1^T dO2, masked by relu'(skip-sum)
         WnGemmArgs g = wn_gemm_default();
@@ -638,7 +666,7 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
         g.C = ws + w.dSk; g.ldc = T; g.c_zstride = (long)d.S * T;
         g.E = ws + w.O1; g.lde = T; g.e_zstride = (long)d.S * T;
         g.nbatch = B; g.tag = "bwd_post1_dx";
-        WN_TRY(wn_gemm_launch(&g, c.st));
+        WN_TRY(fw_gemm(c, g));
     }
     {   // d conv_post_2.{weight,bias}
         WnGemmArgs g = wn_gemm_default();

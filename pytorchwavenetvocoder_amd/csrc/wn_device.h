@@ -23,14 +23,26 @@ static inline f32x16 mfma32(float a, float b, f32x16 c) { return emu::mfma_f32_3
 #define WN_UNROLL
 #define WN_UNROLL_N(n)
 // buffer access: base (wave-uniform) + per-lane byte offset (voff) + wave-uniform byte offset (soff)
+// like the hardware, accesses beyond num_records read 0 / are dropped
 struct wn_rsrc_t {
     const char* base;
+    unsigned bytes;
 };
-static inline wn_rsrc_t wn_make_buf(const void* p, unsigned) { return wn_rsrc_t{(const char*)p}; }
-static inline float wn_buf_load(wn_rsrc_t r, int voff, int soff) { return *(const float*)(r.base + (long)voff + (long)soff); }
-static inline void wn_buf_store(wn_rsrc_t r, float v, int voff, int soff) { *(float*)(r.base + (long)voff + (long)soff) = v; }
+static inline wn_rsrc_t wn_make_buf(const void* p, unsigned bytes) { return wn_rsrc_t{(const char*)p, bytes}; }
+static inline float wn_buf_load(wn_rsrc_t r, int voff, int soff) {
+    const unsigned long off = (unsigned long)(unsigned)voff + (unsigned long)(unsigned)soff;
+    return off + 4 <= r.bytes ? *(const float*)(r.base + off) : 0.0f;
+}
+static inline void wn_buf_store(wn_rsrc_t r, float v, int voff, int soff) {
+    const unsigned long off = (unsigned long)(unsigned)voff + (unsigned long)(unsigned)soff;
+    if (off + 4 <= r.bytes) *(float*)(r.base + off) = v;
+}
 static inline void wn_buf_store_nt(wn_rsrc_t r, float v, int voff, int soff) { wn_buf_store(r, v, voff, soff); }
-static inline float4 wn_buf_load4(wn_rsrc_t r, int voff, unsigned soff) { return *(const float4*)(r.base + (long)voff + (long)soff); }
+static inline float4 wn_buf_load4(wn_rsrc_t r, int voff, unsigned soff) {
+    const unsigned long off = (unsigned long)(unsigned)voff + (unsigned long)soff;
+    return off + 16 <= r.bytes ? *(const float4*)(r.base + off) : float4{0.f, 0.f, 0.f, 0.f};
+}
+static inline float4 wn_buf_load4_nt(wn_rsrc_t r, int voff, unsigned soff) { return wn_buf_load4(r, voff, soff); }
 #define WN_UNIFORM(x) (x)
 #define WN_SCHED_BARRIER()
 #define WN_SLEEP(n)
@@ -42,6 +54,25 @@ static inline float4 wn_buf_load4(wn_rsrc_t r, int voff, unsigned soff) { return
 static inline float wn_ld_coherent(const float* p) { return *p; }
 // v + the value of lane (l ^ m); all lanes of an aligned group of 2m hold the same partial sums
 static inline float wn_xor_add(float v, int m) { return v + __shfl_xor(v, m, 64); }
+// bf16 matrix-core step (v_mfma_f32_32x32x16_bf16): a / b = 8 bf16 per lane packed in a float4
+typedef float4 wn_f4;  // 16-byte register quad
+static inline f32x16 mfma_bf16(const wn_f4& a, const wn_f4& b, f32x16 c) {
+    return emu::mfma_f32_32x32x16bf16(reinterpret_cast<const uint16_t*>(&a), reinterpret_cast<const uint16_t*>(&b), c);
+}
+// two fp32 -> two bf16 (round to nearest even) packed lo | hi << 16
+static inline unsigned wn_pk_bf16(float a, float b) {
+    auto one = [](float x) -> unsigned {
+        unsigned u;
+        memcpy(&u, &x, 4);
+        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    };
+    return one(a) | (one(b) << 16);
+}
+static inline float wn_bits_f32(unsigned u) {
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
 // two-lane fp32 vector for v_pk_fma_f32
 struct f32x2 {
     float x, y;
@@ -70,6 +101,10 @@ static __device__ __forceinline__ float wn_buf_load(wn_rsrc_t r, int voff, int s
 }
 static __device__ __forceinline__ void wn_buf_store(wn_rsrc_t r, float v, int voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voff, soff, 0);
+}
+// the same with the nt hint: the line is the first candidate for eviction (streamed-once data)
+static __device__ __forceinline__ float4 wn_buf_load4_nt(wn_rsrc_t r, int voff, unsigned soff) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, (int)soff, 2));
 }
 #ifndef WN_NT_AUX
 #define WN_NT_AUX 2  // aux bit 1 = nt on gfx94x/gfx950
@@ -112,6 +147,20 @@ static __device__ __forceinline__ float wn_xor_add(float v, int m) {
     }
     return v + __builtin_bit_cast(float, o);
 }
+// bf16 matrix-core step (v_mfma_f32_32x32x16_bf16, 16x the f32 MFMA rate): a / b = 8 bf16 per lane
+typedef __bf16 wn_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wn_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float wn_f4 __attribute__((ext_vector_type(4)));  // 16-byte register quad (first-class vector: stays in VGPRs)
+static __device__ __forceinline__ f32x16 mfma_bf16(wn_f4 a, wn_f4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wn_bf16x8, a), __builtin_bit_cast(wn_bf16x8, b), c, 0, 0, 0);
+}
+// two fp32 -> two bf16 (round to nearest even) packed lo | hi << 16: one v_cvt_pk_bf16_f32
+static __device__ __forceinline__ unsigned wn_pk_bf16(float a, float b) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, wn_bf16x2));
+}
+static __device__ __forceinline__ float wn_bits_f32(unsigned u) { return __builtin_bit_cast(float, u); }
 // two-lane fp32 vector: fma on it is one v_pk_fma_f32
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ f32x2 wn_pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }

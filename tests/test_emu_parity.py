@@ -49,6 +49,16 @@ def test_vector_staging_paths():
     PC.run_oracle_vs_engine((64, 8, 64, 64, 3, 1, 2, 8), 1, 256, 9, emu_library(), "cpu", flags=_lib.FLAG_NO_FUSED)
 
 
+def test_split_bf16_contractions_vs_exact_mfma():
+    """Skip-sum / post-net contractions with >= 128 output rows run on the bf16 matrix cores with a 3-way
+    operand split (wn_gemm6.hip); they must meet the same gates as the exact-f32 MFMA path
+    (WN_FLAG_EXACT_MFMA), including a ragged T, K not a multiple of 16 and M not a multiple of 256."""
+    from pytorchwavenetvocoder_amd import _lib
+    for flags in (0, _lib.FLAG_EXACT_MFMA):
+        PC.run_oracle_vs_engine((200, 6, 16, 136, 2, 2, 2, 0), 1, 45, 21, emu_library(), "cpu", flags=flags, scale=0.2)
+    PC.run_oracle_vs_engine((256, 5, 64, 256, 2, 1, 2, 4), 1, 36, 22, emu_library(), "cpu", scale=0.2)
+
+
 def test_wide_channels_multi_tile():
     # R > 64 exercises the 128-wide tiles and multi-tile M
     PC.run_oracle_vs_engine((48, 9, 96, 160, 2, 1, 2, 4), 1, 72, 7, emu_library(), "cpu")

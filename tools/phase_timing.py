@@ -22,7 +22,7 @@ def build():
     os.makedirs(EXP, exist_ok=True)
     csrc = os.path.join(ROOT, "pytorchwavenetvocoder_amd", "csrc")
     objs = []
-    for name in ("wn_gemm", "wn_elem", "wn_fused", "wn_decode", "wn_prof", "wn_api"):
+    for name in ("wn_gemm", "wn_gemm6", "wn_elem", "wn_fused", "wn_decode", "wn_prof", "wn_api"):
         obj = os.path.join(EXP, name + ".timing.o")
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DWN_TIMING", "-c",
                                os.path.join(csrc, name + ".hip"), "-o", obj])
