@@ -598,7 +598,10 @@ static int dw_gemm(const Ctx& c, WnGemmArgs g, const DwOut& o, int nl = 1) {
     g.nlayer = nl; g.nbatch = c.B; g.ksplit = p.ksplit; g.kchunk = p.kchunk;
     g.C = c.ws + c.w.partial; g.ldc = g.N; g.c_zstride = (long)g.M * g.N;
     g.a_rowsum = o.rowsum_out ? c.ws + c.w.rs_partial : nullptr;
-    WN_TRY(wn_gemm_launch(&g, c.st));
+    if (c.split_bf16 && wn_gemm6_dw_eligible(&g))
+        WN_TRY(wn_gemm6_dw_launch(&g, c.st));
+    else
+        WN_TRY(wn_gemm_launch(&g, c.st));
     WnReduceArgs r;
     r.partial = c.ws + c.w.partial; r.nz = nz_layer; r.M = g.M; r.N = g.N;
     r.out = o.out; r.m_seg = o.m_seg; r.n_seg = o.n_seg;

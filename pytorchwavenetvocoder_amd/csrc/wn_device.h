@@ -56,6 +56,7 @@ static inline float wn_ld_coherent(const float* p) { return *p; }
 static inline float wn_xor_add(float v, int m) { return v + __shfl_xor(v, m, 64); }
 // bf16 matrix-core step (v_mfma_f32_32x32x16_bf16): a / b = 8 bf16 per lane packed in a float4
 typedef float4 wn_f4;  // 16-byte register quad
+static inline wn_f4 wn_ld4_unaligned(const float* p) { return wn_f4{p[0], p[1], p[2], p[3]}; }
 static inline f32x16 mfma_bf16(const wn_f4& a, const wn_f4& b, f32x16 c) {
     return emu::mfma_f32_32x32x16bf16(reinterpret_cast<const uint16_t*>(&a), reinterpret_cast<const uint16_t*>(&b), c);
 }
@@ -151,6 +152,11 @@ static __device__ __forceinline__ float wn_xor_add(float v, int m) {
 typedef __bf16 wn_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 wn_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float wn_f4 __attribute__((ext_vector_type(4)));  // 16-byte register quad (first-class vector: stays in VGPRs)
+// one global_load_dwordx4 from a 4-byte aligned address (shifted conv taps)
+static __device__ __forceinline__ wn_f4 wn_ld4_unaligned(const float* p) {
+    typedef float v4u __attribute__((ext_vector_type(4), aligned(4)));
+    return *reinterpret_cast<const v4u*>(p);
+}
 static __device__ __forceinline__ f32x16 mfma_bf16(wn_f4 a, wn_f4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wn_bf16x8, a), __builtin_bit_cast(wn_bf16x8, b), c, 0, 0, 0);
 }

@@ -35,3 +35,9 @@ static inline long wn_gemm6_apk_elems(int M, int K) {
 // src holds A(m,k) = src[k*lda + m] (fp32) -> Apk
 int wn_gemm6_pack(const float* src, long lda, int M, int K, unsigned short* Apk, wn_stream_t st);
 int wn_gemm6_launch(const WnGemm6Args* g, wn_stream_t st);
+
+// Weight-gradient type contraction (both operands k-major, k = time; csrc/wn_gemm.h semantics of the
+// a_kmajor = b_kmajor = 1 mode incl. segments, shifts, split-K, layers, a_rowsum) on the same 3-way split.
+struct WnGemmArgs;
+int wn_gemm6_dw_eligible(const struct WnGemmArgs* g);
+int wn_gemm6_dw_launch(const struct WnGemmArgs* g, wn_stream_t st);

@@ -21,6 +21,7 @@
 // loads of step s+1 are in flight during the 48 MFMAs of step s.
 #include "wn_gemm6.h"
 
+#include "wn_gemm.h"
 #include "wn_prof.h"
 
 #define G6_T 256
@@ -225,4 +226,234 @@ int wn_gemm6_launch(const WnGemm6Args* gp, wn_stream_t st) {
     dim3 grid((unsigned)((g.N + WN_G6_BN - 1) / WN_G6_BN), (unsigned)(g.Mpad / WN_G6_BM), (unsigned)g.nbatch);
     WN_LAUNCH(k_gemm6, grid, dim3(G6_T), lds, st, g);
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight-gradient type: C[z][m][n] = sum_k A(m,k) B(n, k - shift_n), k = time (contiguous in both)
+// ---------------------------------------------------------------------------------------------
+// Block tile (64 TM) x (64 TN), 16 k per step, 4 waves (2 x 2).  A thread owns 8 (or 4) consecutive
+// k of one operand row: one or two 16-byte global loads (the shifted taps only need 4-byte
+// alignment), split into the three bf16 pieces in registers, one 16 (8) byte LDS write per piece
+// into the fragment layout [piece][row][16 k].  The loads run two steps ahead of the MFMAs (two
+// register sets), LDS is double buffered.
+template <int TM, int TN>
+__global__ __launch_bounds__(G6_T, 2) void k_gemm6_dw(WnGemmArgs g) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int AE = BM / 16, BE = BN / 16;            // fp32 elements per thread and step
+    constexpr int A_BYTES = 3 * BM * 32, B_BYTES = 3 * BN * 32, ST_BYTES = A_BYTES + B_BYTES;
+    WN_DYN_SMEM(smem_raw);
+    __shared__ long b_rowoff[BN];
+    __shared__ int b_rowshift[BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int z = blockIdx.z;
+    const int zl = z / (g.nbatch * g.ksplit);
+    const int zr = z - zl * (g.nbatch * g.ksplit);
+    const int b = zr / g.ksplit;
+    const int ks = zr - b * g.ksplit;
+    const int dmul = (g.b_dil_depth > 0) ? (1 << ((g.b_layer0 + zl) % g.b_dil_depth)) : 1;
+    const int sh0 = g.b_shift0 * dmul, shstep = g.b_shift_step * dmul;
+    const int kbeg = ks * g.kchunk;
+    const int kend = (g.K - kbeg > g.kchunk) ? (kbeg + g.kchunk) : g.K;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const float* __restrict__ Az = g.A + (long)zl * g.a_lstride + (long)b * g.a_zstride;
+    const float* __restrict__ Bz = g.B + (long)zl * g.b_lstride + (long)b * g.b_zstride;
+    const bool one_seg = g.b_seg_len >= g.N;
+
+    for (int i = tid; i < BN; i += G6_T) {
+        const int n = n0 + i;
+        int seg = 0, rr = n;
+        if (!one_seg) {
+            seg = n / g.b_seg_len;
+            rr = n - seg * g.b_seg_len;
+        }
+        b_rowoff[i] = (n < g.N) ? ((long)seg * g.b_seg_stride + (long)rr * g.ldb) : -1;
+        b_rowshift[i] = sh0 + seg * shstep;
+    }
+    int b_shmin = sh0, b_shmax = sh0;
+    if (!one_seg) {
+        const int s_lo = sh0 + (n0 / g.b_seg_len) * shstep, s_hi = sh0 + ((n0 + BN - 1) / g.b_seg_len) * shstep;
+        b_shmin = s_lo < s_hi ? s_lo : s_hi;
+        b_shmax = s_lo < s_hi ? s_hi : s_lo;
+    }
+    __syncthreads();
+
+    // this thread's slice of the operand tiles
+    const int a_row = tid / (16 / AE), a_k = (tid % (16 / AE)) * AE;
+    const int b_row = tid / (16 / BE), b_k = (tid % (16 / BE)) * BE;
+    const long a_off = (long)(m0 + a_row) * g.lda;
+    const bool a_row_ok = (m0 + a_row) < g.M;
+    const long b_off = b_rowoff[b_row];
+    const int b_sh = b_rowshift[b_row];
+    const bool a_tile_ok = (m0 + BM) <= g.M, b_tile_ok = (n0 + BN) <= g.N;
+    float rowsum = 0.f;
+
+    auto fetch = [&](int k0, float (&ra)[AE], float (&rb)[BE]) {
+        const bool full = (k0 + 16) <= kend;
+        if (a_tile_ok && full) {
+            WN_UNROLL
+            for (int q = 0; q < AE / 4; ++q) {
+                const wn_f4 v = wn_ld4_unaligned(Az + a_off + k0 + a_k + 4 * q);
+                ra[4 * q] = v.x; ra[4 * q + 1] = v.y; ra[4 * q + 2] = v.z; ra[4 * q + 3] = v.w;
+            }
+        } else {
+            WN_UNROLL
+            for (int e = 0; e < AE; ++e) {
+                const int k = k0 + a_k + e;
+                ra[e] = (a_row_ok && k < kend) ? Az[a_off + k] : 0.f;
+            }
+        }
+        if (b_tile_ok && full && (k0 - b_shmax) >= 0 && (k0 + 16 - b_shmin) <= g.b_clen) {
+            WN_UNROLL
+            for (int q = 0; q < BE / 4; ++q) {
+                const wn_f4 v = wn_ld4_unaligned(Bz + b_off + (k0 + b_k + 4 * q - b_sh));
+                rb[4 * q] = v.x; rb[4 * q + 1] = v.y; rb[4 * q + 2] = v.z; rb[4 * q + 3] = v.w;
+            }
+        } else {
+            WN_UNROLL
+            for (int e = 0; e < BE; ++e) {
+                const int k = k0 + b_k + e, cc = k - b_sh;
+                rb[e] = (b_off >= 0 && k < kend && cc >= 0 && cc < g.b_clen) ? Bz[b_off + cc] : 0.f;
+            }
+        }
+        if (g.b_relu) {
+            WN_UNROLL
+            for (int e = 0; e < BE; ++e) rb[e] = fmaxf(rb[e], 0.f);
+        }
+    };
+    // split E consecutive-k values and write the three pieces of row `row` at k offset `kofs`
+    auto split_store = [&](char* base, int rows, int row, int kofs, const float* v, int E) {
+        unsigned h[4], md[4], lo[4];
+        for (int q = 0; q < E / 2; ++q) {
+            const float x0 = v[2 * q], x1 = v[2 * q + 1];
+            h[q] = wn_pk_bf16(x0, x1);
+            const float r0 = x0 - wn_bits_f32(h[q] << 16), r1 = x1 - wn_bits_f32(h[q] & 0xffff0000u);
+            md[q] = wn_pk_bf16(r0, r1);
+            lo[q] = wn_pk_bf16(r0 - wn_bits_f32(md[q] << 16), r1 - wn_bits_f32(md[q] & 0xffff0000u));
+        }
+        char* d = base + row * 32 + kofs * 2;
+        const unsigned* src[3] = {h, md, lo};
+        for (int p = 0; p < 3; ++p) {
+            unsigned* o = reinterpret_cast<unsigned*>(d + p * rows * 32);
+            for (int q = 0; q < E / 2; ++q) o[q] = src[p][q];
+        }
+    };
+    auto stage = [&](int st, const float (&ra)[AE], const float (&rb)[BE]) {
+        char* sa = smem_raw + st * ST_BYTES;
+        if (g.a_rowsum != nullptr) {
+            WN_UNROLL
+            for (int e = 0; e < AE; ++e) rowsum += ra[e];
+        }
+        split_store(sa, BM, a_row, a_k, ra, AE);
+        split_store(sa + A_BYTES, BN, b_row, b_k, rb, BE);
+    };
+
+    f32x16 acc[TM][TN];
+    WN_UNROLL
+    for (int i = 0; i < TM; ++i) {
+        WN_UNROLL
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x16_zero();
+    }
+    auto compute = [&](int st) {
+        const char* sa = smem_raw + st * ST_BYTES;
+        const char* sb = sa + A_BYTES;
+        wn_f4 bf[3][TN];
+        WN_UNROLL
+        for (int p = 0; p < 3; ++p) {
+            WN_UNROLL
+            for (int j = 0; j < TN; ++j)
+                bf[p][j] = *reinterpret_cast<const wn_f4*>(sb + p * (BN * 32) + ((wn * TN + j) * 32 + li) * 32 + hi * 16);
+        }
+        WN_UNROLL
+        for (int i = 0; i < TM; ++i) {
+            wn_f4 af[3];
+            WN_UNROLL
+            for (int p = 0; p < 3; ++p)
+                af[p] = *reinterpret_cast<const wn_f4*>(sa + p * (BM * 32) + ((wm * TM + i) * 32 + li) * 32 + hi * 16);
+            WN_UNROLL
+            for (int j = 0; j < TN; ++j) {
+                f32x16 c = acc[i][j];
+                c = mfma_bf16(af[0], bf[2][j], c);
+                c = mfma_bf16(af[2], bf[0][j], c);
+                c = mfma_bf16(af[1], bf[1][j], c);
+                c = mfma_bf16(af[0], bf[1][j], c);
+                c = mfma_bf16(af[1], bf[0][j], c);
+                c = mfma_bf16(af[0], bf[0][j], c);
+                acc[i][j] = c;
+            }
+        }
+    };
+
+    const int nk = (kend > kbeg) ? (kend - kbeg + 15) / 16 : 0;
+    float ra0[AE], rb0[BE], ra1[AE], rb1[BE];
+    if (nk > 0) fetch(kbeg, ra0, rb0);
+    if (nk > 1) fetch(kbeg + 16, ra1, rb1);
+    if (nk > 0) stage(0, ra0, rb0);
+    __syncthreads();
+    for (int kb = 0; kb < nk; kb += 2) {
+        // even step: registers set 0 is free, set 1 holds step kb+1
+        if (kb + 2 < nk) fetch(kbeg + (kb + 2) * 16, ra0, rb0);
+        WN_SCHED_BARRIER();
+        compute(0);
+        WN_SCHED_BARRIER();
+        if (kb + 1 < nk) stage(1, ra1, rb1);
+        __syncthreads();
+        if (kb + 1 >= nk) break;
+        // odd step
+        if (kb + 3 < nk) fetch(kbeg + (kb + 3) * 16, ra1, rb1);
+        WN_SCHED_BARRIER();
+        compute(1);
+        WN_SCHED_BARRIER();
+        if (kb + 2 < nk) stage(0, ra0, rb0);
+        __syncthreads();
+    }
+
+    if (g.a_rowsum != nullptr) {
+        // the 16/AE threads of a row are adjacent lanes
+        for (int m = 1; m < 16 / AE; m <<= 1) rowsum += __shfl_xor(rowsum, m, 64);
+        if (blockIdx.x == 0 && a_k == 0 && a_row_ok) g.a_rowsum[(long)z * g.M + m0 + a_row] = rowsum;
+    }
+    const wn_rsrc_t Cr = wn_make_buf(g.C + (long)z * g.c_zstride, (unsigned)((long)g.M * g.ldc * 4));
+    WN_UNROLL
+    for (int i = 0; i < TM; ++i) {
+        WN_UNROLL
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + li;
+            WN_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + mfma32_row(r, hi);
+                wn_buf_store(Cr, acc[i][j][r], (m < g.M && n < g.N) ? (m * (int)g.ldc + n) * 4 : 0x7ffffff0, 0);
+            }
+        }
+    }
+}
+
+int wn_gemm6_dw_eligible(const WnGemmArgs* g) {
+    return g->a_kmajor && g->b_kmajor && !g->b_index && !g->bias && !g->D && !g->E && !g->relu && !g->accumulate &&
+           (long)g->M * g->ldc * 4 < 0x7ffffff0L && g->M > 0 && g->N > 0;
+}
+
+template <int TM, int TN>
+static int launch_dw(const WnGemmArgs& g, wn_stream_t st) {
+    constexpr int lds = 2 * (3 * 64 * TM * 32 + 3 * 64 * TN * 32);
+    dim3 grid((unsigned)((g.N + 64 * TN - 1) / (64 * TN)), (unsigned)((g.M + 64 * TM - 1) / (64 * TM)),
+              (unsigned)(g.nlayer * g.nbatch * g.ksplit));
+    WN_LAUNCH((k_gemm6_dw<TM, TN>), grid, dim3(G6_T), lds, st, g);
+    return 0;
+}
+
+int wn_gemm6_dw_launch(const WnGemmArgs* gp, wn_stream_t st) {
+    const WnGemmArgs& g = *gp;
+    if (!wn_gemm6_dw_eligible(gp)) return 1;
+    if (g.K < 0 || g.nbatch <= 0 || g.ksplit <= 0 || g.nlayer <= 0 || g.b_seg_len <= 0 || g.kchunk <= 0) return 2;
+    WN_PROF(g.tag ? g.tag : "gemm6_dw", 2.0 * g.M * g.N * (double)g.K * g.nbatch * g.nlayer,
+            ((double)g.M * g.K * 4.0 + (double)g.K * 4.0 * g.N + (double)g.M * g.N * 4.0) * g.nbatch * g.nlayer, st);
+    const int tm = g.M > 64 ? 2 : 1, tn = g.N > 64 ? 2 : 1;
+    if (tm == 2 && tn == 2) return launch_dw<2, 2>(g, st);
+    if (tm == 2) return launch_dw<2, 1>(g, st);
+    if (tn == 2) return launch_dw<1, 2>(g, st);
+    return launch_dw<1, 1>(g, st);
 }
