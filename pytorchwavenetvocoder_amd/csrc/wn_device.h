@@ -43,6 +43,12 @@ static inline float4 wn_buf_load4(wn_rsrc_t r, int voff, unsigned soff) {
     return off + 16 <= r.bytes ? *(const float4*)(r.base + off) : float4{0.f, 0.f, 0.f, 0.f};
 }
 static inline float4 wn_buf_load4_nt(wn_rsrc_t r, int voff, unsigned soff) { return wn_buf_load4(r, voff, soff); }
+// global -> LDS without registers: lane l of the wave writes 16 bytes at lds_wave_base + 16*l
+static inline void wn_buf_load_lds16(wn_rsrc_t r, char* lds_wave_base, int voff, unsigned soff) {
+    const float4 v = wn_buf_load4(r, voff, soff);
+    memcpy(lds_wave_base + 16 * (threadIdx.x & 63), &v, 16);
+}
+#define WN_WAIT_VMCNT(n)
 #define WN_UNIFORM(x) (x)
 #define WN_SCHED_BARRIER()
 #define WN_SLEEP(n)
@@ -107,6 +113,13 @@ static __device__ __forceinline__ void wn_buf_store(wn_rsrc_t r, float v, int vo
 static __device__ __forceinline__ float4 wn_buf_load4_nt(wn_rsrc_t r, int voff, unsigned soff) {
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, (int)soff, 2));
 }
+// global -> LDS without registers (buffer_load_dwordx4 ... lds): lane l of the wave writes 16 bytes at
+// lds_wave_base + 16*l; lds_wave_base must be wave-uniform.  Completion is counted by vmcnt.
+static __device__ __forceinline__ void wn_buf_load_lds16(wn_rsrc_t r, char* lds_wave_base, int voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, (int)soff, 0, 0);
+}
+// s_waitcnt vmcnt(n) only (n <= 15)
+#define WN_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | (n))
 #ifndef WN_NT_AUX
 #define WN_NT_AUX 2  // aux bit 1 = nt on gfx94x/gfx950
 #endif

@@ -68,22 +68,25 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g) {
     const int b = blockIdx.z;
     const int m0 = blockIdx.y * WN_G6_BM, n0 = blockIdx.x * WN_G6_BN;
     const float* __restrict__ Bz = g.B + (long)b * g.b_zstride;
-    const char* Ab = reinterpret_cast<const char*>(g.Apk);
     const int nk = (g.K + 15) / 16;
     const bool one_seg = g.b_seg_len >= g.K;
 
-    // staging registers
-    wn_f4 ra[6];
-    float rb[8];
+    // the split weights go global -> LDS directly (their packed layout IS the LDS layout)
+    const wn_rsrc_t Ar = wn_make_buf(g.Apk, (unsigned)((long)nk * 3 * g.Mpad * 32));
+    const int wave_u = WN_UNIFORM(wave);
+    float rb0[8], rb1[8];  // activations are fetched two steps ahead (HBM latency), weights one (L2)
     const int bn = tid & 127, bkh = tid >> 7;  // this thread's B column and k half (8 k values)
     const bool n_ok = (n0 + bn) < g.N;
-    auto fetch = [&](int kb) {
+    auto fetch_a = [&](int kb, int st) {
+        char* sa = smem_raw + st * ST_BYTES + wave_u * 1024;
         WN_UNROLL
         for (int p = 0; p < 3; ++p) {
-            const char* src = Ab + (((long)kb * 3 + p) * g.Mpad + m0) * 32 + tid * 16;
-            ra[2 * p] = *reinterpret_cast<const wn_f4*>(src);
-            ra[2 * p + 1] = *reinterpret_cast<const wn_f4*>(src + 4096);
+            const unsigned src = kb < nk ? (unsigned)((kb * 3 + p) * g.Mpad + m0) * 32u : 0xfffff000u;  // past the end: zeros
+            wn_buf_load_lds16(Ar, sa + p * (WN_G6_BM * 32), tid * 16, src);
+            wn_buf_load_lds16(Ar, sa + p * (WN_G6_BM * 32) + 4096, tid * 16, src + 4096u);
         }
+    };
+    auto fetch_b = [&](int kb, float (&rb)[8]) {
         const int k0 = kb * 16;
         int seg = 0, rr0 = k0;
         if (!one_seg) {
@@ -99,13 +102,8 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g) {
         WN_UNROLL
         for (int e = 0; e < 8; ++e) rb[e] = wn_buf_load(Br, (n_ok && e < krem) ? base + e * (int)g.ldb * 4 : 0x7ffffff0, 0);
     };
-    auto stage = [&](int st) {
+    auto stage = [&](int st, const float (&rb)[8]) {
         char* sa = smem_raw + st * ST_BYTES;
-        WN_UNROLL
-        for (int p = 0; p < 3; ++p) {
-            *reinterpret_cast<wn_f4*>(sa + p * (WN_G6_BM * 32) + tid * 16) = ra[2 * p];
-            *reinterpret_cast<wn_f4*>(sa + p * (WN_G6_BM * 32) + 4096 + tid * 16) = ra[2 * p + 1];
-        }
         unsigned h[4], md[4], lo[4];
         WN_UNROLL
         for (int q = 0; q < 4; ++q) {
@@ -131,16 +129,8 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g) {
         acc[i][0] = f32x16_zero();
         acc[i][1] = f32x16_zero();
     }
-    if (nk > 0) {
-        fetch(0);
-        stage(0);
-    }
-    __syncthreads();
-    for (int kb = 0; kb < nk; ++kb) {
-        const bool more = kb + 1 < nk;
-        if (more) fetch(kb + 1);
-        WN_SCHED_BARRIER();  // the loads of the next step stay in flight during the MFMAs of this one
-        const char* sa = smem_raw + (kb & 1) * ST_BYTES;
+    auto compute = [&](int st) {
+        const char* sa = smem_raw + st * ST_BYTES;
         const char* sb = sa + A_BYTES;
         wn_f4 bf[3][2];
         WN_UNROLL
@@ -155,22 +145,48 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g) {
             WN_UNROLL
             for (int p = 0; p < 3; ++p)
                 af[p] = *reinterpret_cast<const wn_f4*>(sa + p * (WN_G6_BM * 32) + (128 * wm + 32 * i + li) * 32 + hi * 16);
+            // small terms first; the two column tiles alternate so that back-to-back MFMAs never
+            // depend on each other (a dependent 32x32x16 issues ~25% slower)
+            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
             WN_UNROLL
-            for (int j = 0; j < 2; ++j) {
-                f32x16 c = acc[i][j];
-                c = mfma_bf16(af[0], bf[2][j], c);  // small terms first
-                c = mfma_bf16(af[2], bf[0][j], c);
-                c = mfma_bf16(af[1], bf[1][j], c);
-                c = mfma_bf16(af[0], bf[1][j], c);
-                c = mfma_bf16(af[1], bf[0][j], c);
-                c = mfma_bf16(af[0], bf[0][j], c);
-                acc[i][j] = c;
+            for (int t = 0; t < 6; ++t) {
+                WN_UNROLL
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(af[PA[t]], bf[PB[t]][j], acc[i][j]);
             }
         }
+    };
+    // The weight slab of step s+1 is issued FIRST in step s, the activation loads of step s+2 after it,
+    // so "at most 8 loads outstanding" == "the weight slab has landed in LDS" (vmcnt retires in order).
+    // Steps are processed in pairs with the two register sets swapping roles; steps past the end read
+    // out-of-range offsets (zeros) and add nothing, which keeps the loop body branch-free.
+    const int nk2 = (nk + 1) & ~1;
+    fetch_a(0, 0);
+    fetch_b(0, rb0);
+    fetch_b(1, rb1);
+    stage(0, rb0);
+    WN_WAIT_VMCNT(8);
+    __syncthreads();
+    for (int kb = 0; kb < nk2; kb += 2) {
+        // even step: LDS stage 0 holds step kb, rb1 holds step kb+1, rb0 is free
+        fetch_a(kb + 1, 1);
+        fetch_b(kb + 2, rb0);
+        WN_SCHED_BARRIER();  // the loads stay in flight during the MFMAs
+        compute(0);
         WN_SCHED_BARRIER();
-        if (more) stage((kb + 1) & 1);
+        stage(1, rb1);
+        WN_WAIT_VMCNT(8);
+        __syncthreads();
+        // odd step
+        fetch_a(kb + 2, 0);
+        fetch_b(kb + 3, rb1);
+        WN_SCHED_BARRIER();
+        compute(1);
+        WN_SCHED_BARRIER();
+        stage(0, rb0);
+        WN_WAIT_VMCNT(8);
         __syncthreads();
     }
+    WN_WAIT_VMCNT(0);
 
     // epilogue: bias, mask, relu; rows of a lane are (r&3) + 8*(r>>2) + 4*hi, its column is li.
     // Buffer accesses with out-of-range offsets for the ragged edges (reads give 0, writes are dropped).
@@ -236,8 +252,11 @@ int wn_gemm6_launch(const WnGemm6Args* gp, wn_stream_t st) {
 // alignment), split into the three bf16 pieces in registers, one 16 (8) byte LDS write per piece
 // into the fragment layout [piece][row][16 k].  The loads run two steps ahead of the MFMAs (two
 // register sets), LDS is double buffered.
+#ifndef WN_G6_DW_OCC
+#define WN_G6_DW_OCC 2
+#endif
 template <int TM, int TN>
-__global__ __launch_bounds__(G6_T, 2) void k_gemm6_dw(WnGemmArgs g) {
+__global__ __launch_bounds__(G6_T, WN_G6_DW_OCC) void k_gemm6_dw(WnGemmArgs g) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int AE = BM / 16, BE = BN / 16;            // fp32 elements per thread and step
     constexpr int A_BYTES = 3 * BM * 32, B_BYTES = 3 * BN * 32, ST_BYTES = A_BYTES + B_BYTES;
@@ -373,16 +392,11 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6_dw(WnGemmArgs g) {
             WN_UNROLL
             for (int p = 0; p < 3; ++p)
                 af[p] = *reinterpret_cast<const wn_f4*>(sa + p * (BM * 32) + ((wm * TM + i) * 32 + li) * 32 + hi * 16);
+            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
             WN_UNROLL
-            for (int j = 0; j < TN; ++j) {
-                f32x16 c = acc[i][j];
-                c = mfma_bf16(af[0], bf[2][j], c);
-                c = mfma_bf16(af[2], bf[0][j], c);
-                c = mfma_bf16(af[1], bf[1][j], c);
-                c = mfma_bf16(af[0], bf[1][j], c);
-                c = mfma_bf16(af[1], bf[0][j], c);
-                c = mfma_bf16(af[0], bf[0][j], c);
-                acc[i][j] = c;
+            for (int t = 0; t < 6; ++t) {
+                WN_UNROLL
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(af[PA[t]], bf[PB[t]][j], acc[i][j]);
             }
         }
     };
