@@ -794,8 +794,8 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
         if (c.fused) {
             // dZ = Wskip^T dSk (+ Wres^T dXn) -> gate' -> dP
             WN_TRY(wn_fused_bwd_gate(params + y.skip0 + (long)l * y.ls_skip, params + lb + y.o_res_w, ws + w.dSk, dXn, Sl, Gtl,
-                                     dP, B, T, d.S, c.st));
-            WN_TRY(wn_fused_bwd_dx(ws + w.wd_b + (long)l * d.K * 2 * d.R * d.R, dP, dXn, dXl, B, T, d.K, dil, c.st));
+                                     dP, B, T, d.S, c.split_bf16 ? 1 : 0, c.st));
+            WN_TRY(wn_fused_bwd_dx(ws + w.wd_b + (long)l * d.K * 2 * d.R * d.R, dP, dXn, dXl, B, T, d.K, dil, c.split_bf16 ? 1 : 0, c.st));
         } else {
             {   // dZ = Wskip_l^T dSkip
                 WnGemmArgs g = wn_gemm_default();

@@ -18,9 +18,10 @@ int wn_fused_resblock_fwd(const float* wd_f, const float* wres_f, const float* c
 // dZ = Wskip^T dSkip (+ Wres^T dXn) ; dP = [dZ*g*s*(1-s) ; dZ*s*(1-g^2)]
 // wskip : natural skip_1x1 weight [S][R] ; wres : natural res_1x1 weight [R][R] ; dXn may be NULL.
 int wn_fused_bwd_gate(const float* wskip, const float* wres, const float* dSk, const float* dXn, const float* S,
-                      const float* Gt, float* dP, int B, int T, int Sch, wn_stream_t st);
+                      const float* Gt, float* dP, int B, int T, int Sch, int split, wn_stream_t st);
 
 // dX[t] = (dXn[t]) + sum_tap Wd_tap^T dP[t + (K-1-tap) d]
 // wd_b : [(tap*2R + o')*R + i] packed weights ; dXn may be NULL.
+// split != 0: bf16 matrix cores with the 3-way operand split (fp32-equivalent), else the exact f32 MFMA
 int wn_fused_bwd_dx(const float* wd_b, const float* dP, const float* dXn, float* dX, int B, int T, int K, int dilation,
-                    wn_stream_t st);
+                    int split, wn_stream_t st);

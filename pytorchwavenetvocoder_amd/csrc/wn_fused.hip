@@ -613,19 +613,217 @@ __global__ __launch_bounds__(WN_FT) void k_conv64(ConvArgs a) {
     }
 }
 
+// Same tile loop on the bf16 matrix cores: every fp32 operand is split into three bf16 pieces and the
+// six significant cross products are accumulated in fp32 (see wn_gemm6.hip for the error analysis).
+// Weights are split once per launch into LDS in fragment layout [16-k block][piece][64 rows][16 k];
+// the activation chunk of a lane (2 x 8 consecutive channels of its time step) is split in registers.
+// 24 bf16 MFMAs (768 cycles) replace the 32 f32 MFMAs (2048 cycles) of a 32-channel chunk.
 template <int MODE>
-static int launch_conv64(const ConvArgs& a, wn_stream_t st) {
-    const size_t lds = (size_t)a.wfloats * sizeof(float);
-    if (set_lds(k_conv64<MODE>, lds)) return 1;
+__global__ __launch_bounds__(WN_FT) void k_conv64s(ConvArgs a) {
+    WN_DYN_SMEM(smem_raw);
+    char* W = smem_raw;  // 6 KB per 16-k block: [piece][row][16 k] bf16
+    for (int idx = threadIdx.x; idx < a.nchunks * 2 * 128; idx += WN_FT) {
+        const int o = idx & 63, h = (idx >> 6) & 1, kbg = idx >> 7;
+        int sg = 0, c = kbg * 16 + 8 * h;
+        while (sg + 1 < a.nseg && c >= a.seg[sg].nch) {
+            c -= a.seg[sg].nch;
+            ++sg;
+        }
+        const float* src = a.seg[sg].w + (long)c * 64 + o;
+        unsigned hq[4], mq[4], lq[4];
+        WN_UNROLL
+        for (int q = 0; q < 4; ++q) {
+            const float x0 = src[(2 * q) * 64], x1 = src[(2 * q + 1) * 64];
+            hq[q] = wn_pk_bf16(x0, x1);
+            const float r0 = x0 - wn_bits_f32(hq[q] << 16), r1 = x1 - wn_bits_f32(hq[q] & 0xffff0000u);
+            mq[q] = wn_pk_bf16(r0, r1);
+            lq[q] = wn_pk_bf16(r0 - wn_bits_f32(mq[q] << 16), r1 - wn_bits_f32(mq[q] & 0xffff0000u));
+        }
+        unsigned* d = reinterpret_cast<unsigned*>(W + kbg * 6144 + o * 32 + h * 16);
+        WN_UNROLL
+        for (int q = 0; q < 4; ++q) {
+            d[q] = hq[q];
+            d[512 + q] = mq[q];
+            d[1024 + q] = lq[q];
+        }
+    }
+    __syncthreads();
+    // De-phase the two waves that share a SIMD (waves w and w+4): started together they would run
+    // their MFMA phases and their gate/store phases in lock step and leave the matrix pipe idle
+    // during the latter; half a tile of head start makes one wave's VALU/VMEM phase coincide with
+    // the other's MFMA phase.
+    if (WN_UNIFORM((int)(threadIdx.x / (WN_FT / 2))) != 0)
+        for (int i = 0; i < a.stagger; ++i) WN_SLEEP(127);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int T = a.T;
+    const int T4 = T * 4;
+    const int tiles_per_b = (T + 31) >> 5;
+    const int ntiles = a.B * tiles_per_b;
+    const int step = gridDim.x * WN_FW;
+    const int NCH = a.nchunks;
+
+    // Operand chunks (32 channels = 16 k-steps) are double buffered in registers: chunk q+2 is in
+    // flight while the 32 MFMAs of chunks q and q+1 run.
+    float xa[16], xb[16];
+    bool oka = false, okb = false;
+    auto locate = [&](int q, int& sg, int& c0) {
+        sg = 0;
+        c0 = q * 32;
+        while (sg + 1 < a.nseg && c0 >= a.seg[sg].nch) {
+            c0 -= a.seg[sg].nch;
+            ++sg;
+        }
+    };
+    auto issue = [&](int tl_v, int q, float (&xr)[16], bool& okr) {
+        const int tl = WN_UNIFORM(tl_v);
+        const int b = tl / tiles_per_b;
+        const int t = (tl - b * tiles_per_b) * 32 + li;
+        int sg, c0;
+        locate(q, sg, c0);
+        const ConvSeg& g = a.seg[sg];
+        const int ts = t - g.shift;
+        const bool ok = (t < T) && ts >= 0 && ts < T;
+        okr = ok;
+        const wn_rsrc_t Sr = wn_make_buf(g.src + (long)b * g.nch * T, (unsigned)(g.nch * T4));
+        const int vt = ok ? (8 * hi * T + ts) * 4 : 0;  // lane half hi owns channels 8*hi .. 8*hi+7 of each 16-k block
+        WN_UNROLL
+        for (int s = 0; s < 16; ++s) xr[s] = wn_buf_load(Sr, vt, (c0 + 16 * (s >> 3) + (s & 7)) * T4);
+    };
+    f32x16 acc[2];
+    auto consume = [&](int q, const float (&xr)[16], bool okr) {
+        WN_UNROLL
+        for (int blk = 0; blk < 2; ++blk) {
+            unsigned hq[4], mq[4], lq[4];
+            WN_UNROLL
+            for (int e = 0; e < 4; ++e) {
+                const float x0 = okr ? xr[8 * blk + 2 * e] : 0.0f, x1 = okr ? xr[8 * blk + 2 * e + 1] : 0.0f;
+                hq[e] = wn_pk_bf16(x0, x1);
+                const float r0 = x0 - wn_bits_f32(hq[e] << 16), r1 = x1 - wn_bits_f32(hq[e] & 0xffff0000u);
+                mq[e] = wn_pk_bf16(r0, r1);
+                lq[e] = wn_pk_bf16(r0 - wn_bits_f32(mq[e] << 16), r1 - wn_bits_f32(mq[e] & 0xffff0000u));
+            }
+            wn_f4 bf[3];
+            bf[0].x = wn_bits_f32(hq[0]); bf[0].y = wn_bits_f32(hq[1]); bf[0].z = wn_bits_f32(hq[2]); bf[0].w = wn_bits_f32(hq[3]);
+            bf[1].x = wn_bits_f32(mq[0]); bf[1].y = wn_bits_f32(mq[1]); bf[1].z = wn_bits_f32(mq[2]); bf[1].w = wn_bits_f32(mq[3]);
+            bf[2].x = wn_bits_f32(lq[0]); bf[2].y = wn_bits_f32(lq[1]); bf[2].z = wn_bits_f32(lq[2]); bf[2].w = wn_bits_f32(lq[3]);
+            const char* Wl = W + (2 * q + blk) * 6144 + li * 32 + hi * 16;
+            wn_f4 af[2][3];
+            WN_UNROLL
+            for (int rt = 0; rt < 2; ++rt) {
+                WN_UNROLL
+                for (int p = 0; p < 3; ++p) af[rt][p] = *reinterpret_cast<const wn_f4*>(Wl + p * 2048 + rt * 1024);
+            }
+            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};  // small terms first
+            WN_UNROLL
+            for (int t = 0; t < 6; ++t) {
+                acc[0] = mfma_bf16(af[0][PA[t]], bf[PB[t]], acc[0]);
+                acc[1] = mfma_bf16(af[1][PA[t]], bf[PB[t]], acc[1]);
+            }
+        }
+    };
+
+    int tile_v = blockIdx.x * WN_FW + wave;
+    if (tile_v < ntiles) {
+        issue(tile_v, 0, xa, oka);
+        if (NCH > 1) issue(tile_v, 1, xb, okb);
+    }
+    while (tile_v < ntiles) {
+        const int tile = WN_UNIFORM(tile_v);
+        const int b = tile / tiles_per_b;
+        const int t = (tile - b * tiles_per_b) * 32 + li;
+        const bool inb = t < T;
+        const int vcur = inb ? (4 * hi * T + t) * 4 : 0;
+        const int next_v = tile_v + step;
+
+        // epilogue inputs: issued now, consumed after all MFMAs of the tile
+        float e0[2][16], e1[2][16];
+        if (MODE == 0) {
+            const wn_rsrc_t Sr = wn_make_buf(a.S + (long)b * 64 * T, (unsigned)(64 * T4));
+            const wn_rsrc_t Gr = wn_make_buf(a.Gt + (long)b * 64 * T, (unsigned)(64 * T4));
+            WN_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int so = (32 * q + mfma32_row(r, 0)) * T4;
+                    e0[q][r] = wn_buf_load(Sr, vcur, so);
+                    e1[q][r] = wn_buf_load(Gr, vcur, so);
+                }
+            }
+        } else if (a.resid != nullptr) {
+            const wn_rsrc_t Rr = wn_make_buf(a.resid + (long)b * 64 * T, (unsigned)(64 * T4));
+            WN_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) e0[q][r] = wn_buf_load(Rr, vcur, (32 * q + mfma32_row(r, 0)) * T4);
+            }
+        }
+        WN_SCHED_BARRIER();
+        acc[0] = f32x16_zero();
+        acc[1] = f32x16_zero();
+        for (int q = 0; q < NCH; q += 2) {
+            consume(q, xa, oka);
+            if (q + 2 < NCH) issue(tile_v, q + 2, xa, oka);
+            else if (next_v < ntiles) issue(next_v, 0, xa, oka);
+            WN_SCHED_BARRIER();
+            if (q + 1 < NCH) {
+                consume(q + 1, xb, okb);
+                if (q + 3 < NCH) issue(tile_v, q + 3, xb, okb);
+                else if (next_v < ntiles && NCH > 1) issue(next_v, 1, xb, okb);
+                WN_SCHED_BARRIER();
+            }
+        }
+        if (inb) {
+            if (MODE == 0) {
+                // gate backward: dP = [dZ*g*s*(1-s) ; dZ*s*(1-g^2)]
+                const wn_rsrc_t Or = wn_make_buf(a.out + (long)b * 128 * T, (unsigned)(128 * T4));
+                WN_UNROLL
+                for (int q = 0; q < 2; ++q) {
+                    WN_UNROLL
+                    for (int r = 0; r < 16; ++r) {
+                        const int so = (32 * q + mfma32_row(r, 0)) * T4;
+                        const float s = e0[q][r], g = e1[q][r], dz = acc[q][r];
+                        WN_ST_DP(Or, dz * g * (s * (1.0f - s)), vcur, so);
+                        WN_ST_DP(Or, dz * s * (1.0f - g * g), vcur, so + 64 * T4);
+                    }
+                }
+            } else {
+                const wn_rsrc_t Or = wn_make_buf(a.out + (long)b * 64 * T, (unsigned)(64 * T4));
+                WN_UNROLL
+                for (int q = 0; q < 2; ++q) {
+                    WN_UNROLL
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[q][r];
+                        if (a.resid != nullptr) v += e0[q][r];
+                        WN_ST_DX(Or, v, vcur, (32 * q + mfma32_row(r, 0)) * T4);
+                    }
+                }
+            }
+        }
+        tile_v = next_v;
+    }
+}
+
+template <int MODE>
+static int launch_conv64(const ConvArgs& a, int split, wn_stream_t st) {
     const long ntiles = (long)a.B * ((a.T + 31) / 32);
     long nblk = (ntiles + WN_FW - 1) / WN_FW;
     if (nblk > 256) nblk = 256;
+    if (split) {
+        const size_t lds = (size_t)a.nchunks * 2 * 6144;
+        if (lds > 160 * 1024 || set_lds(k_conv64s<MODE>, lds)) return 1;
+        WN_LAUNCH((k_conv64s<MODE>), dim3((unsigned)nblk), dim3(WN_FT), lds, st, a);
+        return 0;
+    }
+    const size_t lds = (size_t)a.wfloats * sizeof(float);
+    if (set_lds(k_conv64<MODE>, lds)) return 1;
     WN_LAUNCH((k_conv64<MODE>), dim3((unsigned)nblk), dim3(WN_FT), lds, st, a);
     return 0;
 }
 
 int wn_fused_bwd_gate(const float* wskip, const float* wres, const float* dSk, const float* dXn, const float* S, const float* Gt,
-                      float* dP, int B, int T, int Sch, wn_stream_t st) {
+                      float* dP, int B, int T, int Sch, int split, wn_stream_t st) {
     WN_PROF("fused_bwd_gate", 2.0 * (double)B * T * 64.0 * (Sch + (dXn ? 64.0 : 0.0)),
             4.0 * (double)B * T * (Sch + (dXn ? 64.0 : 0.0) + 4.0 * 64.0), st);  // dSk (, dXn), S, Gt in; dP out
     ConvArgs a;
@@ -641,11 +839,11 @@ int wn_fused_bwd_gate(const float* wskip, const float* wres, const float* dSk, c
     }
     a.B = B; a.T = T; a.S = S; a.Gt = Gt; a.resid = nullptr; a.out = dP;
     a.stagger = stagger_setting();
-    return launch_conv64<0>(a, st);
+    return launch_conv64<0>(a, split, st);
 }
 
 int wn_fused_bwd_dx(const float* wd_b, const float* dP, const float* dXn, float* dX, int B, int T, int K, int dilation,
-                    wn_stream_t st) {
+                    int split, wn_stream_t st) {
     WN_PROF("fused_bwd_dx", 2.0 * (double)B * T * 64.0 * K * 128.0,
             4.0 * (double)B * T * 64.0 * (dXn ? 4.0 : 3.0), st);  // dP (, dXn) in; dX out
     if (K > 3) return 1;
@@ -662,5 +860,5 @@ int wn_fused_bwd_dx(const float* wd_b, const float* dP, const float* dXn, float*
     a.nchunks = K * 4;
     a.B = B; a.T = T; a.S = nullptr; a.Gt = nullptr; a.resid = dXn; a.out = dX;
     a.stagger = stagger_setting();
-    return launch_conv64<1>(a, st);
+    return launch_conv64<1>(a, split, st);
 }
