@@ -498,7 +498,7 @@ extern "C" int wn_forward(const WnConfig* cfg, int B, int T, const float* params
         if (c.fused) {
             WN_TRY(wn_fused_resblock_fwd(ws + w.wd_f + (long)l * d.K * d.R * 2 * d.R, ws + w.wres_f + (long)l * d.R * d.R,
                                          ws + w.cvec + (long)l * 2 * d.R, params + lb + y.o_res_b, Xl, Gl, g_bstride, upw, Xn,
-                                         Sl, Gtl, Zl, B, T, d.K, dil, Ue, F, c.st));
+                                         Sl, Gtl, Zl, B, T, d.K, dil, Ue, F, c.split_bf16 ? 1 : 0, c.st));
         } else {
             // P = sum_tap W_tap . x[t-(K-1-tap)d]            (wavenet.py:527-528)
             WnGemmArgs g = wn_gemm_default();

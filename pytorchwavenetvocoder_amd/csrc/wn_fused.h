@@ -13,7 +13,7 @@ int wn_fused_supported(int R, int K, int S);
 // wres_f: [i*R + o]               packed (transposed) res_1x1 weight
 int wn_fused_resblock_fwd(const float* wd_f, const float* wres_f, const float* cvec, const float* res_bias,
                           const float* X, const float* G, long g_bstride, const float* upw, float* Xnext, float* S,
-                          float* Gt, float* Z, int B, int T, int K, int dilation, int U, int F, wn_stream_t st);
+                          float* Gt, float* Z, int B, int T, int K, int dilation, int U, int F, int split, wn_stream_t st);
 
 // dZ = Wskip^T dSkip (+ Wres^T dXn) ; dP = [dZ*g*s*(1-s) ; dZ*s*(1-g^2)]
 // wskip : natural skip_1x1 weight [S][R] ; wres : natural res_1x1 weight [R][R] ; dXn may be NULL.

@@ -387,20 +387,324 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
 #endif
 }
 
+// The same residual block on the bf16 matrix cores (3-way operand split, six products, fp32
+// accumulate: fp32-equivalent, see wn_gemm6.hip).  The register layouts of the activation operands
+// (xh, xc, z: k-step s of lane half hi = channel kappa64(s, hi)) are unchanged; 8 consecutive steps
+// form the lane's share of one 16-k block, i.e. block kb holds channels 16 kb .. 16 kb + 15 and
+// position (hi, e) of the block is channel 16 kb + (e&3) + 8 (e>>2) + 4 hi.  The weights are split
+// once per launch into LDS with exactly that k order: [block][piece][row][hi*8 + e].
+static __device__ __forceinline__ void split8(const float (&x)[8], wn_f4 (&bf)[3]) {
+    unsigned hq[4], mq[4], lq[4];
+    WN_UNROLL
+    for (int e = 0; e < 4; ++e) {
+        const float x0 = x[2 * e], x1 = x[2 * e + 1];
+        hq[e] = wn_pk_bf16(x0, x1);
+        const float r0 = x0 - wn_bits_f32(hq[e] << 16), r1 = x1 - wn_bits_f32(hq[e] & 0xffff0000u);
+        mq[e] = wn_pk_bf16(r0, r1);
+        lq[e] = wn_pk_bf16(r0 - wn_bits_f32(mq[e] << 16), r1 - wn_bits_f32(mq[e] & 0xffff0000u));
+    }
+    bf[0].x = wn_bits_f32(hq[0]); bf[0].y = wn_bits_f32(hq[1]); bf[0].z = wn_bits_f32(hq[2]); bf[0].w = wn_bits_f32(hq[3]);
+    bf[1].x = wn_bits_f32(mq[0]); bf[1].y = wn_bits_f32(mq[1]); bf[1].z = wn_bits_f32(mq[2]); bf[1].w = wn_bits_f32(mq[3]);
+    bf[2].x = wn_bits_f32(lq[0]); bf[2].y = wn_bits_f32(lq[1]); bf[2].z = wn_bits_f32(lq[2]); bf[2].w = wn_bits_f32(lq[3]);
+}
+// 8 source values (stride `st` floats) of one (row, block half) -> the three LDS pieces
+static __device__ __forceinline__ void split_to_lds(const float* src, int st, char* dst, int piece_bytes) {
+    float x[8];
+    WN_UNROLL
+    for (int e = 0; e < 8; ++e) x[e] = src[((e & 3) + 8 * (e >> 2)) * st];
+    wn_f4 bf[3];
+    split8(x, bf);
+    WN_UNROLL
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<wn_f4*>(dst + p * piece_bytes) = bf[p];
+}
+
 template <int K>
-static int launch_fwd(const FwdArgs& a, wn_stream_t st) {
-    const size_t lds = ((size_t)K * 64 * 128 + 64 * 64 + 192) * sizeof(float);
-    if (set_lds(k_resblock_fwd<K>, lds)) return 1;
+__global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
+    WN_DYN_SMEM(smem_raw);
+    constexpr int WD_BLK = 3 * 128 * 32, WR_BLK = 3 * 64 * 32;  // bytes of one 16-k block
+    char* Wd = smem_raw;                                         // [K*4 blocks][piece][128 rows][16 k] bf16
+    char* Wr = Wd + K * 4 * WD_BLK;                              // [4 blocks][piece][64 rows][16 k] bf16
+    float* cv = reinterpret_cast<float*>(Wr + 4 * WR_BLK);       // [128]
+    float* rb = cv + 128;                                        // [64]
+#ifdef WN_TIMING
+    if (a.dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
+        a.dbg[((threadIdx.x >> 6) * 4) * 16 + 5] = (long long)__builtin_readcyclecounter();
+        a.dbg[((threadIdx.x >> 6) * 4) * 16 + 7] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+    if (a.dbg && threadIdx.x == 0) a.dbg[512 + blockIdx.x * 4 + 0] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+    // wd_f[(tap*64 + i)*128 + o'] , wres_f[i*64 + o]: channel i of (block kb, half h, e) = 16 kb + 4 h + (e&3) + 8 (e>>2)
+    for (int idx = threadIdx.x; idx < K * 4 * 2 * 128; idx += WN_FT) {
+        const int o = idx & 127, h = (idx >> 7) & 1, blk = idx >> 8;  // blk = tap*4 + kb
+        const int tap = blk >> 2, kb = blk & 3;
+        split_to_lds(a.wd_f + (long)(tap * 64 + 16 * kb + 4 * h) * 128 + o, 128, Wd + blk * WD_BLK + o * 32 + h * 16, 128 * 32);
+    }
+    for (int idx = threadIdx.x; idx < 4 * 2 * 64; idx += WN_FT) {
+        const int o = idx & 63, h = (idx >> 6) & 1, kb = idx >> 7;
+        split_to_lds(a.wres_f + (long)(16 * kb + 4 * h) * 64 + o, 64, Wr + kb * WR_BLK + o * 32 + h * 16, 64 * 32);
+    }
+    if (threadIdx.x < 128) cv[threadIdx.x] = a.cvec[threadIdx.x];
+    if (threadIdx.x < 64) rb[threadIdx.x] = a.res_bias[threadIdx.x];
+    __syncthreads();
+#ifdef WN_TIMING
+    if (a.dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0)
+        a.dbg[((threadIdx.x >> 6) * 4) * 16 + 6] = (long long)__builtin_readcyclecounter();
+#endif
+    // De-phase the two waves that share a SIMD (waves w and w+4): started together they would run
+    // their MFMA phases and their gate/store phases in lock step and leave the matrix pipe idle
+    // during the latter; half a tile of head start makes one wave's VALU/VMEM phase coincide with
+    // the other's MFMA phase.
+    if (WN_UNIFORM((int)(threadIdx.x / (WN_FT / 2))) != 0)
+        for (int i = 0; i < a.stagger; ++i) WN_SLEEP(127);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int T = a.T;
+    const int T4 = T * 4;  // bytes per channel row
+    const int F4 = a.F * 4;
+    const int tiles_per_b = (T + 31) >> 5;
+    const int ntiles = a.B * tiles_per_b;
+    const unsigned slab = (unsigned)(64 * T4);
+    const int step = gridDim.x * WN_FW;
+    constexpr int KH = (K > 1) ? (K - 1) : 1;  // history taps (shift > 0)
+
+    // Software pipeline (per wave, per 32-sample tile):
+    //   history-tap operands xh : issued before the res MFMAs of the PREVIOUS tile (cross-tile prefetch)
+    //   current-tap operands xc : issued at tile start, land under the history-tap MFMAs
+    //   aux/gate inputs         : first half issued before the current-tap MFMAs, second half
+    //                             before the gate math of the first half
+    // Operands are consumed in place (zero history / dead lanes selected at use).
+    float xh[KH][32];
+    bool okh[KH];
+    auto issue_hist = [&](int tl_v) {
+        const int tl = WN_UNIFORM(tl_v);
+        const int b = tl / tiles_per_b;
+        const int t = (tl - b * tiles_per_b) * 32 + li;
+        const wn_rsrc_t Xr = wn_make_buf(a.X + (long)b * 64 * T, slab);
+        WN_UNROLL
+        for (int tap = 0; tap + 1 < K; ++tap) {
+            const int ts = t - (K - 1 - tap) * a.dil;
+            const bool ok = (t < T) && ts >= 0;
+            okh[tap] = ok;
+            const int vt = ok ? (4 * hi * T + ts) * 4 : 0;  // dead lanes read a valid dummy address
+            WN_UNROLL
+            for (int s = 0; s < 32; ++s) xh[tap][s] = wn_buf_load(Xr, vt, kappa64(s, 0) * T4);
+        }
+    };
+
+    int tile_v = blockIdx.x * WN_FW + wave;
+    int tcount = 0;
+    (void)tcount;
+    if (K > 1 && tile_v < ntiles) issue_hist(tile_v);
+    while (tile_v < ntiles) {
+        WN_STAMP(0);
+        const int tile = WN_UNIFORM(tile_v);
+        const int b = tile / tiles_per_b;
+        const int t = (tile - b * tiles_per_b) * 32 + li;
+        const bool inb = t < T;
+        const int tc = inb ? t : T - 1;
+        const int vcur = inb ? (4 * hi * T + t) * 4 : 0;
+
+        // current tap (shift 0): raw loads now, consumed after the history taps
+        float xc[32];
+        {
+            const wn_rsrc_t Xr = wn_make_buf(a.X + (long)b * 64 * T, slab);
+            WN_UNROLL
+            for (int s = 0; s < 32; ++s) xc[s] = wn_buf_load(Xr, vcur, kappa64(s, 0) * T4);
+        }
+        WN_SCHED_BARRIER();
+        f32x16 acc[4];
+        WN_UNROLL
+        for (int q = 0; q < 4; ++q) acc[q] = f32x16_zero();
+        // dilated taps with history (shift > 0)
+        WN_UNROLL
+        for (int tap = 0; tap + 1 < K; ++tap) {
+            WN_UNROLL
+            for (int kb = 0; kb < 4; ++kb) {
+                float x8[8];
+                WN_UNROLL
+                for (int e = 0; e < 8; ++e) x8[e] = okh[tap] ? xh[tap][8 * kb + e] : 0.0f;
+                wn_f4 bf[3];
+                split8(x8, bf);
+                const char* Wl = Wd + (tap * 4 + kb) * WD_BLK + li * 32 + hi * 16;
+                constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};  // small terms first
+                WN_UNROLL
+                for (int qh = 0; qh < 4; qh += 2) {  // two row tiles at a time (register budget)
+                    wn_f4 af[2][3];
+                    WN_UNROLL
+                    for (int q = 0; q < 2; ++q) {
+                        WN_UNROLL
+                        for (int p = 0; p < 3; ++p)
+                            af[q][p] = *reinterpret_cast<const wn_f4*>(Wl + p * (128 * 32) + (qh + q) * 1024);
+                    }
+                    WN_UNROLL
+                    for (int t6 = 0; t6 < 6; ++t6) {
+                        acc[qh] = mfma_bf16(af[0][PA[t6]], bf[PB[t6]], acc[qh]);
+                        acc[qh + 1] = mfma_bf16(af[1][PA[t6]], bf[PB[t6]], acc[qh + 1]);
+                    }
+                }
+            }
+        }
+        WN_STAMP(1);  // after history-tap MFMAs
+        // aux / gate inputs (frame rate, L2 resident), first 32 gate channels
+        const int fr = tc / a.U;
+        const float upw_j = a.upw[tc - fr * a.U];
+        const wn_rsrc_t Gr = wn_make_buf(a.G + (long)b * a.g_bstride, (unsigned)(128 * F4));
+        const int vg = (4 * hi * a.F + fr) * 4;
+        float ga[2][16], gg[2][16];
+        WN_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            ga[0][r] = wn_buf_load(Gr, vg, mfma32_row(r, 0) * F4);
+            gg[0][r] = wn_buf_load(Gr, vg, (mfma32_row(r, 0) + 64) * F4);
+        }
+        WN_SCHED_BARRIER();
+        // current tap; xc is also the residual input, already in D layout
+        {
+            WN_UNROLL
+            for (int kb = 0; kb < 4; ++kb) {
+                float x8[8];
+                WN_UNROLL
+                for (int e = 0; e < 8; ++e) x8[e] = inb ? xc[8 * kb + e] : 0.0f;
+                wn_f4 bf[3];
+                split8(x8, bf);
+                const char* Wl = Wd + ((K - 1) * 4 + kb) * WD_BLK + li * 32 + hi * 16;
+                constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+                WN_UNROLL
+                for (int qh = 0; qh < 4; qh += 2) {  // two row tiles at a time (register budget)
+                    wn_f4 af[2][3];
+                    WN_UNROLL
+                    for (int q = 0; q < 2; ++q) {
+                        WN_UNROLL
+                        for (int p = 0; p < 3; ++p)
+                            af[q][p] = *reinterpret_cast<const wn_f4*>(Wl + p * (128 * 32) + (qh + q) * 1024);
+                    }
+                    WN_UNROLL
+                    for (int t6 = 0; t6 < 6; ++t6) {
+                        acc[qh] = mfma_bf16(af[0][PA[t6]], bf[PB[t6]], acc[qh]);
+                        acc[qh + 1] = mfma_bf16(af[1][PA[t6]], bf[PB[t6]], acc[qh + 1]);
+                    }
+                }
+            }
+        }
+        WN_SCHED_BARRIER();
+        WN_STAMP(2);  // after current-tap MFMAs
+        // Prefetch the history-tap operands of this wave's next tile NOW, i.e. before the stores of the
+        // gate phase: vmcnt is one in-order counter for loads AND stores, so loads issued behind the
+        // 96 S/Gt/Z stores could only be waited for together with those stores' acknowledgements.
+        const int next_v = tile_v + step;
+        if (K > 1 && next_v < ntiles) issue_hist(next_v);
+        WN_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            ga[1][r] = wn_buf_load(Gr, vg, (32 + mfma32_row(r, 0)) * F4);
+            gg[1][r] = wn_buf_load(Gr, vg, (96 + mfma32_row(r, 0)) * F4);
+        }
+        // gate (reference wavenet.py:529-532): P = conv + w[j]*G[row][f] + c[row]; saved for backward
+        const wn_rsrc_t Sr = wn_make_buf(a.S + (long)b * 64 * T, slab);
+        const wn_rsrc_t Gtr = wn_make_buf(a.Gt + (long)b * 64 * T, slab);
+        const wn_rsrc_t Zr = wn_make_buf(a.Z + (long)b * 64 * T, slab);
+        const float* cvl = cv + 4 * hi;
+        f32x16 z[2];
+        WN_UNROLL
+        for (int q = 0; q < 2; ++q) {
+            WN_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int row0 = 32 * q + mfma32_row(r, 0);  // + 4*hi is in the per-lane offsets
+                const float pa = acc[q][r] + (upw_j * ga[q][r] + cvl[row0]);
+                const float pg = acc[q + 2][r] + (upw_j * gg[q][r] + cvl[row0 + 64]);
+                const float s = wn_sigmoid(pa);
+                const float g = wn_tanh(pg);
+                const float zz = s * g;
+                z[q][r] = zz;
+                if (inb) {
+                    WN_ST_SGZ(Sr, s, vcur, row0 * T4);
+                    WN_ST_SGZ(Gtr, g, vcur, row0 * T4);
+                    WN_ST_SGZ(Zr, zz, vcur, row0 * T4);
+                }
+            }
+        }
+        WN_STAMP(3);  // after gate math + S/Gt/Z stores issued
+        f32x16 racc[2];
+        if (a.Xnext != nullptr) {
+            const float* rbl = rb + 4 * hi;
+            WN_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r)
+                    racc[q][r] = (inb ? xc[16 * q + r] : 0.0f) + rbl[32 * q + mfma32_row(r, 0)];
+            }
+        }
+        WN_SCHED_BARRIER();
+        // res 1x1 + residual; z is consumed straight from the accumulator registers
+        if (a.Xnext != nullptr) {
+            WN_UNROLL
+            for (int kb = 0; kb < 4; ++kb) {
+                float x8[8];
+                WN_UNROLL
+                for (int e = 0; e < 8; ++e) x8[e] = z[(8 * kb + e) >> 4][(8 * kb + e) & 15];
+                wn_f4 bf[3];
+                split8(x8, bf);
+                const char* Wl = Wr + kb * WR_BLK + li * 32 + hi * 16;
+                wn_f4 af[2][3];
+                WN_UNROLL
+                for (int q = 0; q < 2; ++q) {
+                    WN_UNROLL
+                    for (int p = 0; p < 3; ++p) af[q][p] = *reinterpret_cast<const wn_f4*>(Wl + p * (64 * 32) + q * 1024);
+                }
+                constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+                WN_UNROLL
+                for (int t6 = 0; t6 < 6; ++t6) {
+                    racc[0] = mfma_bf16(af[0][PA[t6]], bf[PB[t6]], racc[0]);
+                    racc[1] = mfma_bf16(af[1][PA[t6]], bf[PB[t6]], racc[1]);
+                }
+            }
+            if (inb) {
+                const wn_rsrc_t Xn = wn_make_buf(a.Xnext + (long)b * 64 * T, slab);
+                WN_UNROLL
+                for (int q = 0; q < 2; ++q) {
+                    WN_UNROLL
+                    for (int r = 0; r < 16; ++r) WN_ST_X(Xn, racc[q][r], vcur, (32 * q + mfma32_row(r, 0)) * T4);
+                }
+            }
+        }
+        WN_STAMP(4);  // tile done
+        ++tcount;
+        tile_v = next_v;
+    }
+#ifdef WN_TIMING
+    if (a.dbg && blockIdx.x == 0 && lane == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        a.dbg[(wave * 4) * 16 + 8] = (long long)__builtin_amdgcn_s_memrealtime();
+        a.dbg[(wave * 4) * 16 + 9] = (long long)__builtin_readcyclecounter();
+    }
+    if (a.dbg && lane == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        if (wave == 0) a.dbg[512 + blockIdx.x * 4 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+        if (wave == 7) a.dbg[512 + blockIdx.x * 4 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
+        if (wave == 0) a.dbg[512 + blockIdx.x * 4 + 3] = tcount;
+    }
+#endif
+}
+
+template <int K>
+static int launch_fwd(const FwdArgs& a, int split, wn_stream_t st) {
     const long ntiles = (long)a.B * ((a.T + 31) / 32);
     long nblk = (ntiles + WN_FW - 1) / WN_FW;
     if (nblk > 256) nblk = 256;
+    const size_t lds_s = (size_t)K * 4 * (3 * 128 * 32) + 4 * (3 * 64 * 32) + 192 * sizeof(float);
+    if (split && lds_s <= 160 * 1024) {  // K = 3 does not fit split: stays on the f32 MFMA
+        if (set_lds(k_resblock_fwd_s<K>, lds_s)) return 1;
+        WN_LAUNCH((k_resblock_fwd_s<K>), dim3((unsigned)nblk), dim3(WN_FT), lds_s, st, a);
+        return 0;
+    }
+    const size_t lds = ((size_t)K * 64 * 128 + 64 * 64 + 192) * sizeof(float);
+    if (set_lds(k_resblock_fwd<K>, lds)) return 1;
     WN_LAUNCH((k_resblock_fwd<K>), dim3((unsigned)nblk), dim3(WN_FT), lds, st, a);
     return 0;
 }
 
 int wn_fused_resblock_fwd(const float* wd_f, const float* wres_f, const float* cvec, const float* res_bias, const float* X,
                           const float* G, long g_bstride, const float* upw, float* Xnext, float* S, float* Gt, float* Z, int B,
-                          int T, int K, int dilation, int U, int F, wn_stream_t st) {
+                          int T, int K, int dilation, int U, int F, int split, wn_stream_t st) {
     WN_PROF("fused_resblock_fwd", 2.0 * (double)B * T * (K * 64.0 * 128.0 + (Xnext ? 64.0 * 64.0 : 0.0)),
             4.0 * (double)B * T * 64.0 * (Xnext ? 5.0 : 4.0), st);  // X in; S, Gt, Z (, Xnext) out
     FwdArgs a;
@@ -413,9 +717,9 @@ int wn_fused_resblock_fwd(const float* wd_f, const float* wres_f, const float* c
     a.dbg = g_dbg;
 #endif
     switch (K) {
-        case 1: return launch_fwd<1>(a, st);
-        case 2: return launch_fwd<2>(a, st);
-        case 3: return launch_fwd<3>(a, st);
+        case 1: return launch_fwd<1>(a, split, st);
+        case 2: return launch_fwd<2>(a, split, st);
+        case 3: return launch_fwd<3>(a, split, st);
         default: return 1;
     }
 }
