@@ -40,6 +40,8 @@ ALG_BYTES_PER_TIMESTEP = 78356.0
 ALG_FLOP_PER_TIMESTEP = 9.27e6
 HBM_PEAK = 8.0e12          # B/s  (MI355X_MICROARCH.md)
 F32_MFMA_PEAK = 157.3e12   # FLOP/s dense f32 matrix = f32 vector peak
+BF16_MFMA_PEAK = 2.5e15     # FLOP/s dense bf16 matrix (MI355X_MICROARCH.md); the 3-way split spends 6 bf16
+SPLIT_PRODUCTS = 6.0        # MFMAs per fp32-equivalent product -> 417 TFLOP/s of fp32-equivalent work
 
 
 def geometry(rf, batch_length, U):
@@ -143,6 +145,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the configs[4] generation measurement")
     ap.add_argument("--no-fused", action="store_true", help="force the layered (any-size) kernels")
+    ap.add_argument("--exact-mfma", action="store_true", help="every contraction on the exact f32-input MFMA")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra untimed steps with per-launch HIP events")
     args = ap.parse_args()
 
@@ -172,6 +175,8 @@ def main():
     model.to(device)
     if args.no_fused:
         model.engine.flags |= _lib.FLAG_NO_FUSED
+    if args.exact_mfma:
+        model.engine.flags |= _lib.FLAG_EXACT_MFMA
     rf = model.receptive_field
     bl, frames, T = geometry(rf, BATCH_LENGTH, CFG2["upsampling_factor"])
     B = args.batch
@@ -246,7 +251,8 @@ def main():
             sec = v["ms"] * 1e-3
             ach_f = v["flops"] / sec / 1e12
             ach_b = v["bytes"] / sec / 1e9
-            t_mfma = v["flops"] / F32_MFMA_PEAK
+            mfma_peak = F32_MFMA_PEAK if args.exact_mfma else BF16_MFMA_PEAK / SPLIT_PRODUCTS
+            t_mfma = v["flops"] / mfma_peak
             t_hbm = v["bytes"] / HBM_PEAK
             traffic = None  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/pmc_traffic.json)
             try:
@@ -258,15 +264,17 @@ def main():
                 roofline = {"kernel": dom, "bound": "hbm", "achieved": ach_b, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                             "frac": ach_b / (HBM_PEAK / 1e9)}
             else:
-                roofline = {"kernel": dom, "bound": "mfma", "achieved": ach_f, "peak": F32_MFMA_PEAK / 1e12,
-                            "unit": "TFLOP/s", "frac": ach_f / (F32_MFMA_PEAK / 1e12)}
+                roofline = {"kernel": dom, "bound": "mfma", "achieved": ach_f, "peak": mfma_peak / 1e12,
+                            "unit": "TFLOP/s", "frac": ach_f / (mfma_peak / 1e12)}
             roofline.update({
                 "traffic": traffic,
                 "traffic_note": "bytes/launch, (2*FETCH_SIZE+WRITE_SIZE)*1024 from separate --pmc passes",
                 "avg_launch_ms": v["ms"] / v["count"], "flop_per_launch": v["flops"] / v["count"],
                 "compulsory_bytes_per_launch": v["bytes"] / v["count"],
-                "mfma_frac": ach_f / (F32_MFMA_PEAK / 1e12), "hbm_frac": ach_b / (HBM_PEAK / 1e9),
-                "dtype_peak": "f32-input MFMA (v_mfma_f32_32x32x2_f32), dense 157.3 TFLOP/s; HBM3E 8 TB/s",
+                "mfma_frac": ach_f / (mfma_peak / 1e12), "hbm_frac": ach_b / (HBM_PEAK / 1e9),
+                "dtype_peak": ("f32-input MFMA (v_mfma_f32_32x32x2_f32), dense 157.3 TFLOP/s" if args.exact_mfma else
+                               "fp32-equivalent work on v_mfma_f32_32x32x16_bf16: 2.5 PFLOP/s dense bf16 / 6 products "
+                               "= 417 TFLOP/s") + "; HBM3E 8 TB/s",
                 "step_hbm_frac": timesteps_per_s_gpu * ALG_BYTES_PER_TIMESTEP / HBM_PEAK,
                 "step_hbm_achieved_GBps": timesteps_per_s_gpu * ALG_BYTES_PER_TIMESTEP / 1e9,
                 "step_f32_flop_frac": timesteps_per_s_gpu * ALG_FLOP_PER_TIMESTEP / F32_MFMA_PEAK})
@@ -282,7 +290,11 @@ def main():
                                    "positions per sequence), random-init weights, fwd+CE+bwd+allreduce+Adam" % (
                                        B, T, T - rf),
                        "global_batch": world * B, "parallelism": "dp%d" % world,
-                       "kernels": "layered" if args.no_fused else "fused+gemm"},
+                       "kernels": "layered" if args.no_fused else "fused+gemm",
+                       "arithmetic": "fp32 storage and accumulation; contractions on the bf16 matrix cores with a 3-way "
+                                     "operand split (6 products, fp32-equivalent to round-off) except the one-hot front "
+                                     "weight gradient and K=3 forward blocks (exact f32 MFMA); WN_FLAG_EXACT_MFMA "
+                                     "selects the f32 MFMA everywhere"},
             "timesteps_per_sec": world * timesteps_per_s_gpu, "final_loss": final_loss,
             "roofline": roofline, "kernels": kernels,
         }
