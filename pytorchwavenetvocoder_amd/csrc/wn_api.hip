@@ -257,6 +257,7 @@ struct Ws {
     // scratch
     long P, dO2, dSk, dZ, dXall, dG, dw_partial, dc, tmpS, partial, rs_partial, red_scratch, loss_partial;
     long red_scratch_floats;
+    long apk_floats;
     long total;
     int F;  // frames (T/U, or T without upsampling)
 };
@@ -324,10 +325,15 @@ static int make_ws(const Dims& d, int B, int T, Ws* w) {
     CARVE(red_scratch, w->red_scratch_floats);
     CARVE(loss_partial, wn_softmax_ce_nblocks(B, T) + 64);
     {   // split-bf16 weights of the forward-type contractions (wn_gemm6): one buffer, re-packed before each use
-        long e = wn_gemm6_apk_elems(d.S, d.L * d.R);
-        const long e1 = wn_gemm6_apk_elems(d.S > d.Q ? d.S : d.Q, d.S > d.Q ? d.S : d.Q);
-        if (e1 > e) e = e1;
-        CARVE(apk, (e + 1) / 2);
+        const int mk[][2] = {{d.S, d.L * d.R}, {d.S, d.S}, {d.Q, d.S}, {d.S, d.Q}, {2 * d.R, d.K * d.R},
+                             {d.R, d.R}, {d.R, d.S}, {d.R, d.K * 2 * d.R}};
+        long e = 0;
+        for (unsigned i = 0; i < sizeof(mk) / sizeof(mk[0]); ++i) {
+            const long ei = wn_gemm6_apk_elems(mk[i][0], mk[i][1]);
+            if (ei > e) e = ei;
+        }
+        w->apk_floats = (e + 1) / 2;
+        CARVE(apk, w->apk_floats);
     }
 #undef CARVE
     w->total = o;
@@ -377,9 +383,10 @@ static int make_ctx(Ctx* c, const WnConfig* cfg, int B, int T, void* ws, size_t 
 // Weights x activations contraction: split-bf16 matrix-core kernel when the launch has its shape
 // (>= 128 output rows, k-minor operands, no shifts), the exact-f32 MFMA kernel otherwise.
 static int fw_gemm(const Ctx& c, const WnGemmArgs& g) {
-    const bool ok = c.split_bf16 && g.M >= 128 && !g.a_kmajor && !g.b_kmajor && g.b_shift0 == 0 && g.b_shift_step == 0 &&
-                    (g.b_seg_len >= g.K || g.b_seg_len % 16 == 0) && !g.D && !g.accumulate && g.ksplit == 1 &&
-                    g.nlayer == 1 && !g.b_relu && !g.b_index && g.a_zstride == 0 && !g.a_rowsum && g.b_clen >= g.N;
+    const bool ok = c.split_bf16 && g.M >= 128 && !g.a_kmajor && !g.b_kmajor &&
+                    (g.b_seg_len >= g.K || g.b_seg_len % 16 == 0) && g.ksplit == 1 && g.nlayer == 1 && !g.b_relu &&
+                    !g.b_index && g.a_zstride == 0 && !g.a_rowsum &&
+                    wn_gemm6_apk_elems(g.M, g.K) <= 2 * c.w.apk_floats && (long)g.M * g.ldc * 4 < 0x7ffffff0L;
     if (!ok) return wn_gemm_launch(&g, c.st);
     unsigned short* apk = reinterpret_cast<unsigned short*>(c.ws + c.w.apk);
     WN_TRY(wn_gemm6_pack(g.A, g.lda, g.M, g.K, apk, c.st));
@@ -387,6 +394,8 @@ static int fw_gemm(const Ctx& c, const WnGemmArgs& g) {
     a.M = g.M; a.N = g.N; a.K = g.K;
     a.Apk = apk; a.Mpad = (g.M + WN_G6_BM - 1) / WN_G6_BM * WN_G6_BM;
     a.B = g.B; a.ldb = g.ldb; a.b_zstride = g.b_zstride; a.b_seg_len = g.b_seg_len; a.b_seg_stride = g.b_seg_stride;
+    a.b_shift0 = g.b_shift0; a.b_shift_step = g.b_shift_step; a.b_clen = g.b_clen;
+    a.D = g.D; a.ldd = g.ldd; a.d_zstride = g.d_zstride; a.accumulate = g.accumulate;
     a.C = g.C; a.ldc = g.ldc; a.c_zstride = g.c_zstride;
     a.bias = g.bias; a.E = g.E; a.lde = g.lde; a.e_zstride = g.e_zstride; a.relu = g.relu;
     a.nbatch = g.nbatch; a.tag = g.tag;
@@ -508,7 +517,7 @@ extern "C" int wn_forward(const WnConfig* cfg, int B, int T, const float* params
             g.b_seg_len = d.R; g.b_seg_stride = 0; g.b_shift0 = (d.K - 1) * dil; g.b_shift_step = -dil;
             g.C = ws + w.P; g.ldc = T; g.c_zstride = (long)2 * d.R * T;
             g.nbatch = B; g.tag = "fwd_dilated_layered";
-            WN_TRY(wn_gemm_launch(&g, c.st));
+            WN_TRY(fw_gemm(c, g));
             // z = sigmoid(.)*tanh(.)                           (wavenet.py:529-532)
             WN_TRY(wn_gate_fwd(ws + w.P, Gl, g_bstride, upw, ws + w.cvec + (long)l * 2 * d.R, Sl, Gtl, Zl, B, T, d.R, Ue, F,
                                c.st));
@@ -522,7 +531,7 @@ extern "C" int wn_forward(const WnConfig* cfg, int B, int T, const float* params
                 r.bias = params + lb + y.o_res_b;
                 r.D = Xl; r.ldd = T; r.d_zstride = (long)d.R * T;
                 r.nbatch = B; r.tag = "fwd_res_layered";
-                WN_TRY(wn_gemm_launch(&r, c.st));
+                WN_TRY(fw_gemm(c, r));
             }
         }
     }
@@ -804,7 +813,7 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
                 g.B = ws + w.dSk; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = T;
                 g.C = ws + w.dZ; g.ldc = T; g.c_zstride = (long)d.R * T;
                 g.nbatch = B; g.tag = "bwd_dz_skip_layered";
-                WN_TRY(wn_gemm_launch(&g, c.st));
+                WN_TRY(fw_gemm(c, g));
             }
             if (dXn) {  // dZ += Wres_l^T dX_{l+1}
                 WnGemmArgs g = wn_gemm_default();
@@ -813,7 +822,7 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
                 g.B = dXn; g.ldb = T; g.b_zstride = (long)d.R * T; g.b_clen = T;
                 g.C = ws + w.dZ; g.ldc = T; g.c_zstride = (long)d.R * T;
                 g.accumulate = 1; g.nbatch = B; g.tag = "bwd_dz_res_layered";
-                WN_TRY(wn_gemm_launch(&g, c.st));
+                WN_TRY(fw_gemm(c, g));
             }
             WN_TRY(wn_gate_bwd(ws + w.dZ, Sl, Gtl, dP, B, T, d.R, c.st));
             {   // dX_l = dX_{l+1} + sum_tap W_tap^T dP[t + (K-1-tap) d]
@@ -825,7 +834,7 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
                 g.C = dXl; g.ldc = T; g.c_zstride = (long)d.R * T;
                 if (dXn) { g.D = dXn; g.ldd = T; g.d_zstride = (long)d.R * T; }
                 g.nbatch = B; g.tag = "bwd_dx_dilated";
-                WN_TRY(wn_gemm_launch(&g, c.st));
+                WN_TRY(fw_gemm(c, g));
             }
         }
         const int done = d.L - l;  // layers walked

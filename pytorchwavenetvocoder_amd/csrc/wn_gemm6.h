@@ -16,6 +16,8 @@ typedef struct WnGemm6Args {
     long b_zstride;
     int b_seg_len;              // multiple of 16, or >= K
     long b_seg_stride;
+    int b_shift0, b_shift_step; // element (k, n) reads column n - (b_shift0 + seg*b_shift_step), 0 outside [0, b_clen)
+    int b_clen;
     float* C;                   // C[z][m][n]
     long ldc;
     long c_zstride;
@@ -23,7 +25,11 @@ typedef struct WnGemm6Args {
     const float* E;             // mask source: result *= (E > 0), indexed like C, or null
     long lde;
     long e_zstride;
+    const float* D;             // residual added before relu/mask, indexed like C, or null
+    long ldd;
+    long d_zstride;
     int relu;
+    int accumulate;             // C += result
     int nbatch;
     const char* tag;
 } WnGemm6Args;

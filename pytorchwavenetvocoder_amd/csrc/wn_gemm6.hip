@@ -98,9 +98,11 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g) {
         const int rows = one_seg ? g.K : g.b_seg_len;
         const wn_rsrc_t Br = wn_make_buf(Bz + (long)seg * g.b_seg_stride, (unsigned)((long)rows * g.ldb * 4));
         const int krem = g.K - (k0 + 8 * bkh);  // valid rows of this thread's 8
-        const int base = ((rr0 + 8 * bkh) * (int)g.ldb + n0 + bn) * 4;
+        const int cc = n0 + bn - (g.b_shift0 + seg * g.b_shift_step);  // shifted column: zero history outside [0, clen)
+        const bool c_ok = n_ok && cc >= 0 && cc < g.b_clen;
+        const int base = ((rr0 + 8 * bkh) * (int)g.ldb + cc) * 4;
         WN_UNROLL
-        for (int e = 0; e < 8; ++e) rb[e] = wn_buf_load(Br, (n_ok && e < krem) ? base + e * (int)g.ldb * 4 : 0x7ffffff0, 0);
+        for (int e = 0; e < 8; ++e) rb[e] = wn_buf_load(Br, (c_ok && e < krem) ? base + e * (int)g.ldb * 4 : 0x7ffffff0, 0);
     };
     auto stage = [&](int st, const float (&rb)[8]) {
         char* sa = smem_raw + st * ST_BYTES;
@@ -192,6 +194,7 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g) {
     // Buffer accesses with out-of-range offsets for the ragged edges (reads give 0, writes are dropped).
     const wn_rsrc_t Cr = wn_make_buf(g.C + (long)b * g.c_zstride, (unsigned)((long)g.M * g.ldc * 4));
     const wn_rsrc_t Er = wn_make_buf(g.E ? g.E + (long)b * g.e_zstride : g.C, g.E ? (unsigned)((long)g.M * g.lde * 4) : 0u);
+    const wn_rsrc_t Dr = wn_make_buf(g.D ? g.D + (long)b * g.d_zstride : g.C, g.D ? (unsigned)((long)g.M * g.ldd * 4) : 0u);
     const wn_rsrc_t Biasr = wn_make_buf(g.bias ? g.bias : g.C, g.bias ? (unsigned)(g.M * 4) : 0u);
     WN_UNROLL
     for (int i = 0; i < 4; ++i) {
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g) {
         WN_UNROLL
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + 64 * wn + 32 * j + li;
-            float ev[16];
+            float ev[16], dv[16];
             if (g.E) {
                 WN_UNROLL
                 for (int r = 0; r < 16; ++r) {
@@ -209,15 +212,26 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g) {
                     ev[r] = wn_buf_load(Er, (row < g.M && col < g.N) ? (row * (int)g.lde + col) * 4 : 0x7ffffff0, 0);
                 }
             }
+            WN_UNROLL
+            for (int r = 0; r < 16; ++r) dv[r] = 0.f;
+            if (g.D) {
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + 128 * wm + 32 * i + mfma32_row(r, hi);
+                    dv[r] = wn_buf_load(Dr, (row < g.M && col < g.N) ? (row * (int)g.ldd + col) * 4 : 0x7ffffff0, 0);
+                }
+            }
             WN_SCHED_BARRIER();
             WN_UNROLL
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + 128 * wm + 32 * i + mfma32_row(r, hi);
                 float v = acc[i][j][r];
-                v += bv[r];
-                if (g.E) v = (ev[r] > 0.f) ? v : 0.f;
+                v += bv[r] + dv[r];
                 if (g.relu) v = fmaxf(v, 0.f);
-                wn_buf_store(Cr, v, (row < g.M && col < g.N) ? (row * (int)g.ldc + col) * 4 : 0x7ffffff0, 0);
+                if (g.E) v = (ev[r] > 0.f) ? v : 0.f;
+                const int coff = (row < g.M && col < g.N) ? (row * (int)g.ldc + col) * 4 : 0x7ffffff0;
+                if (g.accumulate) v += wn_buf_load(Cr, coff, 0);
+                wn_buf_store(Cr, v, coff, 0);
             }
         }
     }

@@ -57,6 +57,8 @@ def test_split_bf16_contractions_vs_exact_mfma():
     for flags in (0, _lib.FLAG_EXACT_MFMA):
         PC.run_oracle_vs_engine((200, 6, 16, 136, 2, 2, 2, 0), 1, 45, 21, emu_library(), "cpu", flags=flags, scale=0.2)
     PC.run_oracle_vs_engine((256, 5, 64, 256, 2, 1, 2, 4), 1, 36, 22, emu_library(), "cpu", scale=0.2)
+    # any-size layered path (n_resch = 128): dilated taps with shifts, residual and accumulate epilogues
+    PC.run_oracle_vs_engine((40, 5, 128, 144, 3, 1, 3, 0), 1, 40, 23, emu_library(), "cpu", scale=0.1)
 
 
 def test_wide_channels_multi_tile():
