@@ -112,15 +112,22 @@ __global__ __launch_bounds__(WN_TPB) void k_softmax_ce(const float* __restrict__
     const bool live = (t < T) && (t >= t_start);
     const float* lg = logits + (long)b * Q * T + t;
     if (live) {
-        float mx = lg[0], sum = 1.0f;
-        for (int q = 1; q < Q; ++q) {
-            const float v = lg[(long)q * T];
-            if (v > mx) {
-                sum = sum * expf(mx - v) + 1.0f;
-                mx = v;
-            } else {
-                sum += expf(v - mx);
+        // online softmax in chunks of 8 channels: the 8 strided loads of a chunk are independent and in
+        // flight together (one dependent load per iteration made this kernel latency bound)
+        float mx = -3.0e38f, sum = 0.0f;
+        for (int q0 = 0; q0 < Q; q0 += 8) {
+            float v[8];
+            WN_UNROLL
+            for (int u = 0; u < 8; ++u) v[u] = (q0 + u < Q) ? lg[(long)(q0 + u) * T] : -3.0e38f;
+            float cm = v[0];
+            WN_UNROLL
+            for (int u = 1; u < 8; ++u) cm = fmaxf(cm, v[u]);
+            if (cm > mx) {
+                sum *= expf(mx - cm);
+                mx = cm;
             }
+            WN_UNROLL
+            for (int u = 0; u < 8; ++u) sum += expf(v[u] - mx);
         }
         long long tg = target[(long)b * T + t] % Q;
         if (tg < 0) tg += Q;
@@ -128,10 +135,18 @@ __global__ __launch_bounds__(WN_TPB) void k_softmax_ce(const float* __restrict__
         my_loss = lse - lg[(long)tg * T];
         if (dlogits != nullptr) {
             float* dl = dlogits + (long)b * Q * T + t;
-            for (int q = 0; q < Q; ++q) {
-                float p = expf(lg[(long)q * T] - lse);
-                if (q == (int)tg) p -= 1.0f;
-                dl[(long)q * T] = p * grad_scale;
+            for (int q0 = 0; q0 < Q; q0 += 8) {
+                float v[8];
+                WN_UNROLL
+                for (int u = 0; u < 8; ++u) v[u] = (q0 + u < Q) ? lg[(long)(q0 + u) * T] : 0.0f;
+                WN_UNROLL
+                for (int u = 0; u < 8; ++u) {
+                    if (q0 + u < Q) {
+                        float pq = expf(v[u] - lse);
+                        if (q0 + u == (int)tg) pq -= 1.0f;
+                        dl[(long)(q0 + u) * T] = pq * grad_scale;
+                    }
+                }
             }
         }
     } else if (t < T && dlogits != nullptr) {
