@@ -258,6 +258,7 @@ struct Ws {
     long P, dO2, dSk, dZ, dXall, dG, dw_partial, dc, tmpS, partial, rs_partial, red_scratch, loss_partial;
     long red_scratch_floats;
     long apk_floats;
+    long front_partial, front_partial_floats;
     long total;
     int F;  // frames (T/U, or T without upsampling)
 };
@@ -324,6 +325,8 @@ static int make_ws(const Dims& d, int B, int T, Ws* w) {
     w->red_scratch_floats = 1 << 20;
     CARVE(red_scratch, w->red_scratch_floats);
     CARVE(loss_partial, wn_softmax_ce_nblocks(B, T) + 64);
+    w->front_partial_floats = wn_front_dw_supported(d.R, d.K, d.Q) ? wn_front_dw_partial_floats(B, T, d.R, d.K, d.Q) : 0;
+    CARVE(front_partial, w->front_partial_floats);
     {   // split-bf16 weights of the forward-type contractions (wn_gemm6): one buffer, re-packed before each use
         const int mk[][2] = {{d.S, d.L * d.R}, {d.S, d.S}, {d.Q, d.S}, {d.S, d.Q}, {2 * d.R, d.K * d.R},
                              {d.R, d.R}, {d.R, d.S}, {d.R, d.K * 2 * d.R}};
@@ -846,8 +849,11 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
         }
     }
     const float* dXn = ws + w.dXall;  // dL/dx_0
-    // ---- front conv (one-hot as an implicit operand) ----
-    {
+    // ---- front conv: scatter over the token indices, or (large tables) the one-hot contraction ----
+    if (wn_front_dw_supported(d.R, d.K, d.Q) &&
+        wn_front_dw_partial_floats(B, T, d.R, d.K, d.Q) <= w.front_partial_floats) {
+        WN_TRY(wn_front_dw(dXn, x, ws + w.front_partial, grads + y.causal_w, grads + y.causal_b, B, T, d.R, d.K, d.Q, c.st));
+    } else {
         WnGemmArgs g = wn_gemm_default();
         g.M = d.R; g.N = d.K * d.Q; g.K = T;
         g.A = dXn; g.lda = T; g.a_zstride = (long)d.R * T;

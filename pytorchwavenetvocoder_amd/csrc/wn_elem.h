@@ -86,3 +86,13 @@ int wn_reduce(const WnReduceArgs* a, wn_stream_t st);
 // out[0] (=|+=) sum_i a[i]*b[i]
 int wn_dot(const float* a, const float* b, long n, float* out, int accumulate, wn_stream_t st);
 int wn_fill(float* p, float v, long n, wn_stream_t st);
+
+// Front-conv weight / bias gradient as a scatter (reference: autograd of OneHot + CausalConv1d,
+// wavenet.py:78-92,513-516): dW[c][q][k] = sum_{b,t} dX0[b][c][t] * [x[b][t-(K-1-k)] mod Q == q]  (zero history),
+// db[c] = sum_{b,t} dX0[b][c][t].  One LDS table [R][K*Q] per workgroup, every wave owns its own channel
+// rows and walks time 64 steps at a time (lane = time step: coalesced loads, in-order LDS adds), per-block
+// tables are summed in block order -> deterministic.  Needs R*K*Q*4 <= 150 KB of LDS.
+int wn_front_dw_supported(int R, int K, int Q);
+long wn_front_dw_partial_floats(int B, int T, int R, int K, int Q);
+int wn_front_dw(const float* dX0, const int64_t* x, float* partial, float* dW, float* db, int B, int T, int R, int K, int Q,
+                wn_stream_t st);

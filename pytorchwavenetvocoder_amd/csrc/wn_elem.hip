@@ -437,3 +437,140 @@ int wn_fill(float* p, float v, long n, wn_stream_t st) {
     WN_LAUNCH(k_fill, dim3((unsigned)((n + WN_TPB - 1) / WN_TPB)), dim3(WN_TPB), 0, st, p, v, n);
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// front-conv weight gradient as a scatter (see wn_elem.h)
+// ---------------------------------------------------------------------------------------------
+static void front_dw_grid(int B, int T, int* nchunk, int* chunk) {
+    int nc = 256 / (B > 0 ? B : 1);  // one workgroup per CU (the table fills its LDS)
+    if (nc < 1) nc = 1;
+    int ch = (T + nc - 1) / nc;
+    ch = (ch + 63) / 64 * 64;
+    if (ch < 64) ch = 64;
+    *chunk = ch;
+    *nchunk = (T + ch - 1) / ch;
+}
+
+int wn_front_dw_supported(int R, int K, int Q) { return ((long)R * K * Q + R) * 4 <= 150 * 1024 && K <= 8; }
+
+long wn_front_dw_partial_floats(int B, int T, int R, int K, int Q) {
+    int nc, ch;
+    front_dw_grid(B, T, &nc, &ch);
+    return (long)B * nc * ((long)R * K * Q + R);
+}
+
+__global__ __launch_bounds__(256) void k_front_dw_scatter(const float* __restrict__ dX0, const int64_t* __restrict__ x,
+                                                          float* __restrict__ partial, int T, int R, int K, int Q, int chunk) {
+    WN_DYN_SMEM(smem_raw);
+    float* acc = reinterpret_cast<float*>(smem_raw);  // [R][K*Q]
+    const int KQ = K * Q;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, t0 = blockIdx.x * chunk;
+    const int t1 = (t0 + chunk < T) ? t0 + chunk : T;
+    const int ntab = R * KQ + R, ntab4 = ntab >> 2;
+    for (int i = tid; i < ntab4; i += 256) reinterpret_cast<float4*>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 4 * ntab4 + tid; i < ntab; i += 256) acc[i] = 0.0f;
+    __syncthreads();
+    const int64_t* xb = x + (long)b * T;
+    const float* db = dX0 + (long)b * R * T;
+    float* out = partial + ((long)b * gridDim.x + blockIdx.x) * ((long)R * KQ + R);
+    // wave w owns channels w, w+4, w+8, ...: no two waves ever touch the same table row.  The token
+    // columns of a 64-step strip are looked up once and reused for all channels of the wave.
+    float* rsum = acc + R * KQ;  // [R] row sums (bias gradient)
+    for (int ts = t0; ts < t1; ts += 64) {
+        const int t = ts + lane;
+        const bool ok = t < t1;
+        int col[8];
+        WN_UNROLL
+        for (int k = 0; k < 8; ++k) {
+            col[k] = -1;
+            const int tq = t - (K - 1 - k);
+            if (k < K && ok && tq >= 0) {
+                long long q = xb[tq] % Q;
+                if (q < 0) q += Q;
+                col[k] = k * Q + (int)q;
+            }
+        }
+        for (int c0 = wave; c0 < R; c0 += 32) {  // 8 channels of this wave per step: 8 loads in flight
+            float v[8];
+            WN_UNROLL
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + 4 * u;
+                v[u] = (ok && c < R) ? db[(long)c * T + t] : 0.0f;
+            }
+            WN_UNROLL
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + 4 * u;
+                if (c < R) {
+                    WN_UNROLL
+                    for (int k = 0; k < 8; ++k)
+                        if (col[k] >= 0) atomicAdd(&acc[c * KQ + col[k]], v[u]);
+                }
+            }
+        }
+    }
+    // bias gradient: row sums of this block's time range (second, cheap pass over the same cache lines)
+    for (int c = wave; c < R; c += 4) {
+        float rs = 0.0f;
+        for (int ts = t0; ts < t1; ts += 256) {
+            float v[4];
+            WN_UNROLL
+            for (int u = 0; u < 4; ++u) {
+                const int t = ts + 64 * u + lane;
+                v[u] = t < t1 ? db[(long)c * T + t] : 0.0f;
+            }
+            rs += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        rs = wave_reduce_sum(rs);
+        if (lane == 0) rsum[c] = rs;
+    }
+    __syncthreads();
+    if ((((long)R * KQ + R) & 3) == 0) {  // per-block slabs stay 16-byte aligned
+        for (int i = tid; i < ntab4; i += 256) reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(acc)[i];
+    } else {
+        for (int i = tid; i < ntab; i += 256) out[i] = acc[i];
+    }
+}
+
+// dW[c][q][k] = sum_blk partial[blk][c][k*Q+q] ; db[c] = sum_blk partial[blk][R*KQ + c]
+__global__ __launch_bounds__(256) void k_front_dw_reduce(const float* __restrict__ partial, int nblk, float* __restrict__ dW,
+                                                         float* __restrict__ db, int R, int K, int Q) {
+    const int KQ = K * Q;
+    const long per = (long)R * KQ + R;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= per) return;
+    float s = 0.0f;
+    for (int b0 = 0; b0 < nblk; b0 += 8) {  // 8 independent loads in flight, summed in block order
+        float v[8];
+        WN_UNROLL
+        for (int u = 0; u < 8; ++u) v[u] = (b0 + u < nblk) ? partial[(long)(b0 + u) * per + i] : 0.0f;
+        WN_UNROLL
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    if (i < (long)R * KQ) {
+        const int c = (int)(i / KQ), r = (int)(i % KQ);
+        const int k = r / Q, q = r % Q;
+        dW[((long)c * Q + q) * K + k] = s;
+    } else {
+        db[i - (long)R * KQ] = s;
+    }
+}
+
+int wn_front_dw(const float* dX0, const int64_t* x, float* partial, float* dW, float* db, int B, int T, int R, int K, int Q,
+                wn_stream_t st) {
+    WN_PROF("dw_front_scatter", 0.0, (double)B * R * T * 4.0, st);
+    if (!wn_front_dw_supported(R, K, Q)) return 1;
+    int nc, ch;
+    front_dw_grid(B, T, &nc, &ch);
+    const size_t lds = ((size_t)R * K * Q + R) * 4;
+#ifndef WN_EMU
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_dw_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+        return 2;
+#endif
+    WN_LAUNCH(k_front_dw_scatter, dim3((unsigned)nc, (unsigned)B), dim3(256), lds, st, dX0, x, partial, T, R, K, Q, ch);
+    const long per = (long)R * K * Q + R;
+    WN_LAUNCH(k_front_dw_reduce, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, partial, nc * B, dW, db, R, K, Q);
+    return 0;
+}
