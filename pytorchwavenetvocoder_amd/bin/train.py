@@ -77,8 +77,20 @@ def validate_length(x, y, upsampling_factor=None):
 def _to_batch(xs, hs, ts, device):
     bx, bh, bt = torch.stack(xs), torch.stack(hs), torch.stack(ts)
     if device is not None:
-        bx, bh, bt = bx.to(device), bh.to(device), bt.to(device)
+        if torch.device(device).type == "cuda":  # pinned staging: the copies overlap the step that is running
+            bx, bh, bt = bx.pin_memory(), bh.pin_memory(), bt.pin_memory()
+        bx, bh, bt = bx.to(device, non_blocking=True), bh.to(device, non_blocking=True), bt.to(device, non_blocking=True)
     return (bx, bh), bt
+
+
+def _shard_range(batch_size, shard):
+    """Window indices [lo, hi) of a minibatch owned by rank ``shard[0]`` of ``shard[1]`` -- the chunks
+    ``nn.DataParallel`` scatters (reference train.py:449-454)."""
+    if shard is None:
+        return 0, batch_size
+    rank, world = shard
+    per = (batch_size + world - 1) // world
+    return min(rank * per, batch_size), min((rank + 1) * per, batch_size)
 
 
 @background(max_prefetch=16)
@@ -92,13 +104,18 @@ def train_generator(wav_list, feat_list, receptive_field,
                     upsampling_factor=80,
                     use_upsampling_layer=True,
                     use_speaker_code=False,
-                    device="auto"):
+                    device="auto",
+                    shard=None):
     """Minibatch generator with the reference's four batching modes (train.py:67-312).
 
     Yields ``((batch_x, batch_h), batch_t)``: x/t int64 (B, T) with t the next sample of x, h float
     (B, D, T) -- or (B, D, T / upsampling_factor) with the upsampling layer.  Windows hold
     ``receptive_field + batch_length`` samples and advance by ``batch_length`` (the first
     receptive_field outputs of every window carry no loss, train.py:535).
+
+    ``shard=(rank, world)``: yield only this rank's windows of every minibatch (same minibatch
+    composition as the unsharded generator; the mu-law / scaling work of the other ranks' windows is
+    skipped instead of being done ``world`` times).
     """
     if device == "auto":
         device = torch.device("cuda") if torch.cuda.is_available() else None
@@ -122,9 +139,11 @@ def train_generator(wav_list, feat_list, receptive_field,
             h_ = feat_transform(h_)
         return torch.from_numpy(np.asarray(x_)).long(), torch.from_numpy(np.asarray(h_)).float()
 
+    my_lo, my_hi = _shard_range(batch_size, shard)
     x_buffer = h_buffer = None
     while True:
         batch_x, batch_h, batch_t = [], [], []
+        n_in_batch = 0
         for wavfile, featfile in zip(wav_list, feat_list):
             x, _fs = read_wav(wavfile)
             h = read_hdf5(featfile, "/" + feature_type)
@@ -153,20 +172,27 @@ def train_generator(wav_list, feat_list, receptive_field,
                     x_ss = h_ss = batch_length
                     more = lambda: len(x_buffer) > x_bs                            # noqa: E731
                 while more():
-                    x_, h_ = prep(x_buffer[:x_bs], h_buffer[:h_bs])
-                    if use_upsampling_layer:
-                        batch_h += [h_.transpose(0, 1)]
-                    else:
-                        batch_h += [h_[:-1].transpose(0, 1)]
-                    batch_x += [x_[:-1]]
-                    batch_t += [x_[1:]]
+                    if my_lo <= n_in_batch < my_hi:   # windows of other ranks are only skipped over
+                        x_, h_ = prep(x_buffer[:x_bs], h_buffer[:h_bs])
+                        if use_upsampling_layer:
+                            batch_h += [h_.transpose(0, 1)]
+                        else:
+                            batch_h += [h_[:-1].transpose(0, 1)]
+                        batch_x += [x_[:-1]]
+                        batch_t += [x_[1:]]
+                    n_in_batch += 1
                     h_buffer = h_buffer[h_ss:]
                     x_buffer = x_buffer[x_ss:]
-                    if len(batch_x) == batch_size:
-                        yield _to_batch(batch_x, batch_h, batch_t, device)
+                    if n_in_batch == batch_size:
+                        if batch_x:
+                            yield _to_batch(batch_x, batch_h, batch_t, device)
                         batch_x, batch_h, batch_t = [], [], []
+                        n_in_batch = 0
             else:
-                # one utterance per batch
+                # one utterance per batch; with several ranks utterance i goes to rank i mod world
+                n_in_batch += 1
+                if shard is not None and (n_in_batch - 1) % shard[1] != shard[0]:
+                    continue
                 if use_upsampling_layer:
                     h = h[:-1]
                     x = x[:-upsampling_factor + 1]
@@ -315,6 +341,7 @@ def _worker(rank, world, args, port):
         shuffle=True,
         upsampling_factor=args.upsampling_factor,
         use_upsampling_layer=args.use_upsampling_layer,
+        shard=(rank, world) if world > 1 else None,
         use_speaker_code=args.use_speaker_code,
         device=device)
 
@@ -337,10 +364,6 @@ def _worker(rank, world, args, port):
     for i in range(iterations, args.iters):
         start = time.time()
         (batch_x, batch_h), batch_t = generator.next()
-        if world > 1:  # this rank's chunk of the minibatch (DataParallel scatters the same chunks)
-            per = (batch_x.size(0) + world - 1) // world
-            sl = slice(rank * per, min((rank + 1) * per, batch_x.size(0)))
-            batch_x, batch_h, batch_t = batch_x[sl].contiguous(), batch_h[sl].contiguous(), batch_t[sl].contiguous()
         batch_loss = reducer.loss_and_backward(batch_x, batch_h, batch_t)
         optimizer.step()
         loss_acc += batch_loss.detach()

@@ -83,6 +83,27 @@ def test_generator_modes(tmp_path, batch_length, upsample):
     gen.close()
 
 
+def test_sharded_generator_is_a_partition_of_the_unsharded_one(tmp_path):
+    """shard=(rank, world): every rank yields its DataParallel chunk of the same minibatches."""
+    wavs, feats, _ = make_corpus(str(tmp_path), n=4)
+    kw = dict(receptive_field=15, batch_length=400, batch_size=5, feature_type="melspc", shuffle=False,
+              wav_transform=lambda x: encode_mu_law(x, 256), upsampling_factor=U, use_upsampling_layer=True, device=None)
+    full = T.train_generator(wavs, feats, **kw)
+    parts = [T.train_generator(wavs, feats, shard=(r, 2), **kw) for r in range(2)]
+    try:
+        for _ in range(3):
+            (fx, fh), ft = full.next()
+            got = [p.next() for p in parts]
+            assert [g[0][0].size(0) for g in got] == [3, 2]
+            assert torch.equal(torch.cat([g[0][0] for g in got]), fx)
+            assert torch.equal(torch.cat([g[0][1] for g in got]), fh)
+            assert torch.equal(torch.cat([g[1] for g in got]), ft)
+    finally:
+        full.close()
+        for p in parts:
+            p.close()
+
+
 def test_validate_length():
     x, y = T.validate_length(np.zeros(1000), np.zeros((12, 3)), 80)
     assert len(x) == len(y) * 80
