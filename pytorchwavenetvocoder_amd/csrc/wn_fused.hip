@@ -83,6 +83,29 @@ template <class Kern>
 static int set_lds(Kern, size_t) { return 0; }
 #endif
 
+// XCD-aware tile mapping.  Workgroup b is dispatched to XCD b % 8 (each XCD has its own 4 MB L2): the tile
+// space is cut into 8 contiguous time ranges, one per XCD, and the 256 waves of an XCD walk their range
+// together, so the shifted taps of a tile (up to 512 samples = 16 tiles back / ahead) were just read by a
+// neighbouring wave of the SAME XCD and hit its L2 instead of going out to the fabric.
+struct TileWalk {
+    int first, end, step;
+};
+static __device__ __forceinline__ TileWalk tile_walk(int ntiles, int wave) {
+    TileWalk w;
+    if ((gridDim.x & 7) == 0) {
+        const int per = (ntiles + 7) >> 3, x = blockIdx.x & 7;
+        const int lo = x * per;
+        w.end = lo + per < ntiles ? lo + per : ntiles;
+        w.first = lo + (blockIdx.x >> 3) * WN_FW + wave;
+        w.step = (gridDim.x >> 3) * WN_FW;
+    } else {
+        w.end = ntiles;
+        w.first = blockIdx.x * WN_FW + wave;
+        w.step = gridDim.x * WN_FW;
+    }
+    return w;
+}
+
 static __device__ __forceinline__ void stage_copy(float* dst, const float* __restrict__ src, int n) {
     // n is a multiple of 4; dst is 16-byte aligned; src usually is (checked, block-uniform branch)
     if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
@@ -153,7 +176,8 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
     const int tiles_per_b = (T + 31) >> 5;
     const int ntiles = a.B * tiles_per_b;
     const unsigned slab = (unsigned)(64 * T4);
-    const int step = gridDim.x * WN_FW;
+    const TileWalk walk = tile_walk(ntiles, threadIdx.x >> 6);
+    const int step = walk.step, tile_end = walk.end;
     constexpr int KH = (K > 1) ? (K - 1) : 1;  // history taps (shift > 0)
 
     // Software pipeline (per wave, per 32-sample tile):
@@ -180,11 +204,11 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
         }
     };
 
-    int tile_v = blockIdx.x * WN_FW + wave;
+    int tile_v = walk.first;
     int tcount = 0;
     (void)tcount;
-    if (K > 1 && tile_v < ntiles) issue_hist(tile_v);
-    while (tile_v < ntiles) {
+    if (K > 1 && tile_v < tile_end) issue_hist(tile_v);
+    while (tile_v < tile_end) {
         WN_STAMP(0);
         const int tile = WN_UNIFORM(tile_v);
         const int b = tile / tiles_per_b;
@@ -288,7 +312,7 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
         // gate phase: vmcnt is one in-order counter for loads AND stores, so loads issued behind the
         // 96 S/Gt/Z stores could only be waited for together with those stores' acknowledgements.
         const int next_v = tile_v + step;
-        if (K > 1 && next_v < ntiles) issue_hist(next_v);
+        if (K > 1 && next_v < tile_end) issue_hist(next_v);
         WN_UNROLL
         for (int r = 0; r < 16; ++r) {
             ga[1][r] = wn_buf_load(Gr, vg, (32 + mfma32_row(r, 0)) * F4);
@@ -465,7 +489,8 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
     const int tiles_per_b = (T + 31) >> 5;
     const int ntiles = a.B * tiles_per_b;
     const unsigned slab = (unsigned)(64 * T4);
-    const int step = gridDim.x * WN_FW;
+    const TileWalk walk = tile_walk(ntiles, threadIdx.x >> 6);
+    const int step = walk.step, tile_end = walk.end;
     constexpr int KH = (K > 1) ? (K - 1) : 1;  // history taps (shift > 0)
 
     // Software pipeline (per wave, per 32-sample tile):
@@ -492,11 +517,11 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
         }
     };
 
-    int tile_v = blockIdx.x * WN_FW + wave;
+    int tile_v = walk.first;
     int tcount = 0;
     (void)tcount;
-    if (K > 1 && tile_v < ntiles) issue_hist(tile_v);
-    while (tile_v < ntiles) {
+    if (K > 1 && tile_v < tile_end) issue_hist(tile_v);
+    while (tile_v < tile_end) {
         WN_STAMP(0);
         const int tile = WN_UNIFORM(tile_v);
         const int b = tile / tiles_per_b;
@@ -592,7 +617,7 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
         // gate phase: vmcnt is one in-order counter for loads AND stores, so loads issued behind the
         // 96 S/Gt/Z stores could only be waited for together with those stores' acknowledgements.
         const int next_v = tile_v + step;
-        if (K > 1 && next_v < ntiles) issue_hist(next_v);
+        if (K > 1 && next_v < tile_end) issue_hist(next_v);
         WN_UNROLL
         for (int r = 0; r < 16; ++r) {
             ga[1][r] = wn_buf_load(Gr, vg, (32 + mfma32_row(r, 0)) * F4);
@@ -766,7 +791,8 @@ __global__ __launch_bounds__(WN_FT) void k_conv64(ConvArgs a) {
     const int T4 = T * 4;
     const int tiles_per_b = (T + 31) >> 5;
     const int ntiles = a.B * tiles_per_b;
-    const int step = gridDim.x * WN_FW;
+    const TileWalk walk = tile_walk(ntiles, threadIdx.x >> 6);
+    const int step = walk.step, tile_end = walk.end;
     const int NCH = a.nchunks;
 
     // Operand chunks (32 channels = 16 k-steps) are double buffered in registers: chunk q+2 is in
@@ -836,12 +862,12 @@ __global__ __launch_bounds__(WN_FT) void k_conv64(ConvArgs a) {
         }
     };
 
-    int tile_v = blockIdx.x * WN_FW + wave;
-    if (tile_v < ntiles) {
+    int tile_v = walk.first;
+    if (tile_v < tile_end) {
         issue(tile_v, 0, xa, oka);
         if (NCH > 1) issue(tile_v, 1, xb, okb);
     }
-    while (tile_v < ntiles) {
+    while (tile_v < tile_end) {
         const int tile = WN_UNIFORM(tile_v);
         const int b = tile / tiles_per_b;
         const int t = (tile - b * tiles_per_b) * 32 + li;
@@ -877,12 +903,12 @@ __global__ __launch_bounds__(WN_FT) void k_conv64(ConvArgs a) {
         for (int q = 0; q < NCH; q += 2) {
             consume(q, xa, oka);
             if (q + 2 < NCH) issue(tile_v, q + 2, xa, oka);
-            else if (next_v < ntiles) issue(next_v, 0, xa, oka);
+            else if (next_v < tile_end) issue(next_v, 0, xa, oka);
             WN_SCHED_BARRIER();
             if (q + 1 < NCH) {
                 consume(q + 1, xb, okb);
                 if (q + 3 < NCH) issue(tile_v, q + 3, xb, okb);
-                else if (next_v < ntiles && NCH > 1) issue(next_v, 1, xb, okb);
+                else if (next_v < tile_end && NCH > 1) issue(next_v, 1, xb, okb);
                 WN_SCHED_BARRIER();
             }
         }
@@ -965,7 +991,8 @@ __global__ __launch_bounds__(WN_FT) void k_conv64s(ConvArgs a) {
     const int T4 = T * 4;
     const int tiles_per_b = (T + 31) >> 5;
     const int ntiles = a.B * tiles_per_b;
-    const int step = gridDim.x * WN_FW;
+    const TileWalk walk = tile_walk(ntiles, threadIdx.x >> 6);
+    const int step = walk.step, tile_end = walk.end;
     const int NCH = a.nchunks;
 
     // Operand chunks (32 channels = 16 k-steps) are double buffered in registers: chunk q+2 is in
@@ -1028,12 +1055,12 @@ __global__ __launch_bounds__(WN_FT) void k_conv64s(ConvArgs a) {
         }
     };
 
-    int tile_v = blockIdx.x * WN_FW + wave;
-    if (tile_v < ntiles) {
+    int tile_v = walk.first;
+    if (tile_v < tile_end) {
         issue(tile_v, 0, xa, oka);
         if (NCH > 1) issue(tile_v, 1, xb, okb);
     }
-    while (tile_v < ntiles) {
+    while (tile_v < tile_end) {
         const int tile = WN_UNIFORM(tile_v);
         const int b = tile / tiles_per_b;
         const int t = (tile - b * tiles_per_b) * 32 + li;
@@ -1069,12 +1096,12 @@ __global__ __launch_bounds__(WN_FT) void k_conv64s(ConvArgs a) {
         for (int q = 0; q < NCH; q += 2) {
             consume(q, xa, oka);
             if (q + 2 < NCH) issue(tile_v, q + 2, xa, oka);
-            else if (next_v < ntiles) issue(next_v, 0, xa, oka);
+            else if (next_v < tile_end) issue(next_v, 0, xa, oka);
             WN_SCHED_BARRIER();
             if (q + 1 < NCH) {
                 consume(q + 1, xb, okb);
                 if (q + 3 < NCH) issue(tile_v, q + 3, xb, okb);
-                else if (next_v < ntiles && NCH > 1) issue(next_v, 1, xb, okb);
+                else if (next_v < tile_end && NCH > 1) issue(next_v, 1, xb, okb);
                 WN_SCHED_BARRIER();
             }
         }
