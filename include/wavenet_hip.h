@@ -184,6 +184,19 @@ int wn_decode_steps(const WnConfig* cfg, int B, const float* params, const float
                     int64_t* samples, int64_t Ttot, const int32_t* t_forced, const int32_t* t_end, int p0, int p1,
                     float* state, const float* uniforms, float* logits_out, int mode, void* stream);
 
+/* Any-size variant of the same decode (layer-wise launches of the contraction kernels on [channels x B]
+ * operands: one pass over the weights per step serves the whole batch).  Same positions / teacher forcing
+ * / mode / uniforms / logits_out conventions as wn_decode_steps.  `state` is ONE caller-owned buffer of
+ * wn_decode_layered_state_floats(cfg, B) floats, zero-filled before wn_decode_layered_prepare, which packs
+ * the weights into it and computes G (B, F, L*2R) from h (B, n_aux, F). */
+int64_t wn_decode_layered_state_floats(const WnConfig* cfg, int B);
+int wn_decode_layered_prepare(const WnConfig* cfg, int B, int F, const float* params, const float* h, float* G, float* state,
+                              int64_t state_floats, void* stream);
+int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* params, const float* G, int F, int n_pad,
+                            int64_t* samples, int64_t Ttot, const int32_t* t_forced, const int32_t* t_end, int p0, int p1,
+                            float* state, int64_t state_floats, const float* uniforms, float* logits_out, int mode,
+                            void* stream);
+
 /* ---- diagnostics: opt-in per-launch timing with HIP events (used by bench.py's roofline block) ----
  * wn_prof_enable(1) clears and starts recording {kernel tag, algorithmic flops/bytes, start/stop
  * event} for every launch; after synchronising, wn_prof_report writes a JSON object

@@ -74,6 +74,7 @@ EXPORTS = [
     "wn_softmax_ce_loss", "wn_backward", "wn_adam_step", "wn_op_front", "wn_op_causal_conv", "wn_op_gemm", "wn_prof_enable", "wn_prof_report",
     "wn_decode_supported", "wn_decode_pack_floats", "wn_decode_state_floats", "wn_decode_pack", "wn_decode_aux",
     "wn_decode_steps", "wn_decode_stream_bytes",
+    "wn_decode_layered_state_floats", "wn_decode_layered_prepare", "wn_decode_layered_steps",
 ]
 
 
@@ -120,6 +121,10 @@ class WnLibrary(object):
         L.wn_decode_pack.argtypes = [cfgp, vp, vp, vp]
         L.wn_decode_aux.argtypes = [cfgp, i, i, vp, vp, vp, vp]
         L.wn_decode_steps.argtypes = [cfgp, i, vp, vp, vp, i, i, vp, i64, vp, vp, i, i, vp, vp, vp, i, vp]
+        L.wn_decode_layered_state_floats.argtypes = [cfgp, i]
+        L.wn_decode_layered_state_floats.restype = i64
+        L.wn_decode_layered_prepare.argtypes = [cfgp, i, i, vp, vp, vp, vp, i64, vp]
+        L.wn_decode_layered_steps.argtypes = [cfgp, i, vp, vp, i, i, vp, i64, vp, vp, i, i, vp, i64, vp, vp, i, vp]
         if L.wn_abi_version() != ABI_VERSION:
             raise WnError("ABI mismatch: library %d, binding %d" % (L.wn_abi_version(), ABI_VERSION))
 

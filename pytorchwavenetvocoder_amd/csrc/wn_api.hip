@@ -1073,6 +1073,186 @@ extern "C" int wn_decode_steps(const WnConfig* cfg, int B, const float* params, 
     return rt_check("wn_decode_steps");
 }
 
+// ------------------------------------------------------------------------------------------
+// any-size decode: the queue algorithm (wavenet.py:397-511) as layer-wise launches.  Utterances are the
+// contiguous axis of every matrix ("time" of the contraction kernels = utterance index), so one step
+// of all utterances is ~100 launches of the training kernels on [channels x B] operands: weights are
+// read once per step for the whole batch.  Used when the persistent decode kernel does not cover the
+// model size (e.g. the n_resch = 512 recipe default).
+// ------------------------------------------------------------------------------------------
+struct DlLay {
+    Ws w;  // packed-weight region of a (B=1, T=Ue) training workspace
+    long queues, xin, P, Sg, Gt, Zcat, gstep, skpart, O1, O2, logits, total;
+    long qfloats_per_utt;
+};
+
+static int dl_layout(const WnConfig* cfg, const Dims& d, int nb, DlLay* y) {
+    const int Ue = d.U > 0 ? d.U : 1;
+    WN_TRY(make_ws(d, 1, Ue, &y->w));
+    long sumd = 0;
+    for (int l = 0; l < d.L; ++l) sumd += dilation_of(cfg, l);
+    y->qfloats_per_utt = (long)(d.K - 1) * sumd * d.R;
+    long o = y->w.total;
+#define DCARVE(field, n) \
+    y->field = o;        \
+    o += al64((long)(n));
+    DCARVE(queues, y->qfloats_per_utt * nb + 64);
+    DCARVE(xin, (long)d.L * d.K * d.R * nb);
+    DCARVE(P, (long)2 * d.R * nb);
+    DCARVE(Sg, (long)d.R * nb);
+    DCARVE(Gt, (long)d.R * nb);
+    DCARVE(Zcat, (long)d.L * d.R * nb);
+    DCARVE(gstep, (long)d.L * 2 * d.R * nb);
+    DCARVE(skpart, (long)d.L * d.S * nb);
+    DCARVE(O1, (long)d.S * nb);
+    DCARVE(O2, (long)d.S * nb);
+    DCARVE(logits, (long)d.Q * nb);
+#undef DCARVE
+    y->total = o;
+    return 0;
+}
+
+static void dl_ctx(Ctx* c, const WnConfig* cfg, const Dims& d, const DlLay& y, int nb, float* state, void* stream) {
+    c->cfg = cfg;
+    c->d = d;
+    c->y = make_lay(d);
+    c->w = y.w;
+    c->B = 1;
+    c->T = nb;
+    c->ws = state;
+    c->st = (wn_stream_t)stream;
+    c->fused = false;
+    // exact f32 MFMA here: with a handful of utterance columns the contractions are weight-streaming bound and
+    // the split path would re-split (or stream 1.5x the bytes of) the weights on every step
+    c->split_bf16 = false;
+}
+
+extern "C" int64_t wn_decode_layered_state_floats(const WnConfig* cfg, int B) {
+    Dims d;
+    if (check_cfg(cfg, &d) || B < 1) return -1;
+    DlLay y;
+    if (dl_layout(cfg, d, B, &y)) return -1;
+    return y.total;
+}
+
+// Packs the weights into `state` (which must be zero-filled first: the queues start from zero history) and
+// computes the aux projections G (B, F, L*2R) of all layers at the aux rate.
+extern "C" int wn_decode_layered_prepare(const WnConfig* cfg, int B, int F, const float* params, const float* h, float* G,
+                                         float* state, int64_t state_floats, void* stream) {
+    g_err[0] = 0;
+    Dims d;
+    WN_TRY(check_cfg(cfg, &d));
+    if (!params || !h || !G || !state || B < 1 || F < 1) return fail(1, "bad argument");
+    DlLay y;
+    WN_TRY(dl_layout(cfg, d, B, &y));
+    if (state_floats < y.total) return fail(1, "decode state too small: %ld < %ld floats", (long)state_floats, y.total);
+    Ctx c;
+    dl_ctx(&c, cfg, d, y, B, state, stream);
+    WN_TRY(pack_weights(c, params));
+    const int nG = d.L * 2 * d.R;
+    WnGemmArgs g = wn_gemm_default();  // G[b] (F x nG) = h[b]^T (F x A) . waux_f (A x nG)
+    g.M = F; g.N = nG; g.K = d.A;
+    g.A = h; g.lda = F; g.a_zstride = (long)d.A * F;
+    g.B = state + y.w.waux_f; g.ldb = nG; g.b_zstride = 0; g.b_clen = nG;
+    g.C = G; g.ldc = nG; g.c_zstride = (long)F * nG;
+    g.nbatch = B; g.tag = "decode_aux_frames";
+    WN_TRY(wn_gemm_launch(&g, c.st));
+    return rt_check("wn_decode_layered_prepare");
+}
+
+extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* params, const float* G, int F, int n_pad,
+                                       int64_t* samples, int64_t Ttot, const int32_t* t_forced, const int32_t* t_end, int p0,
+                                       int p1, float* state, int64_t state_floats, const float* uniforms, float* logits_out,
+                                       int mode, void* stream) {
+    g_err[0] = 0;
+    Dims d;
+    WN_TRY(check_cfg(cfg, &d));
+    if (!params || !G || !samples || !t_forced || !t_end || !state) return fail(1, "NULL argument");
+    if (B <= 0 || F <= 0 || n_pad < 0 || p0 < 0 || p1 < p0 || Ttot <= 0 || p1 > Ttot - 1)
+        return fail(1, "bad decode range: B=%d F=%d n_pad=%d steps [%d,%d) Ttot=%ld", B, F, n_pad, p0, p1, (long)Ttot);
+    if (mode != 0 && mode != 1) return fail(1, "mode should be 0 (argmax) or 1 (sampling)");
+    if (mode == 1 && !uniforms) return fail(1, "sampling mode needs the uniform draws");
+    DlLay y;
+    WN_TRY(dl_layout(cfg, d, B, &y));
+    if (state_floats < y.total) return fail(1, "decode state too small: %ld < %ld floats", (long)state_floats, y.total);
+    Ctx c;
+    dl_ctx(&c, cfg, d, y, B, state, stream);
+    const Lay& lay = c.y;
+    const Ws& w = y.w;
+    float* ws = state;
+    const int nb = B;
+    WnDlArgs a;
+    a.nb = nb; a.L = d.L; a.K = d.K; a.R = d.R; a.Q = d.Q; a.depth = cfg->dilation_depth; a.nG = d.L * 2 * d.R;
+    a.n_pad = n_pad; a.Ue = d.U > 0 ? d.U : 1; a.F = F;
+    a.params = params; a.off_causal_w = lay.causal_w; a.off_causal_b = lay.causal_b;
+    a.upw = d.U > 0 ? params + lay.up_w : ws + w.one;
+    a.G = G; a.samples = samples; a.Ttot = Ttot;
+    a.queues = ws + y.queues; a.xin = ws + y.xin; a.gstep = ws + y.gstep;
+    const long RB = (long)d.R * nb;
+    for (int p = p0; p < p1; ++p) {
+        a.p = p;
+        WN_TRY(wn_dl_inputs(&a, c.st));
+        for (int l = 0; l < d.L; ++l) {
+            const long lb = layer_base(lay, d, l);
+            float* xin_l = ws + y.xin + (long)l * d.K * RB;
+            float* z_l = ws + y.Zcat + (long)l * RB;
+            {   // both rows of the gate: taps [history | newest] x packed dilated weights  (wavenet.py:540-541)
+                WnDlMmArgs g;
+                g.M = 2 * d.R; g.K = d.K * d.R; g.nb = nb;
+                g.A = ws + w.wd_f + (long)l * d.K * d.R * 2 * d.R; g.lda = 2 * d.R; g.a_zstride = 0;
+                g.B = xin_l; g.ldb = nb; g.b_zstride = 0;
+                g.C = ws + y.P; g.ldc = nb; g.c_zstride = 0;
+                g.bias = nullptr; g.D = nullptr; g.ldd = 0; g.relu = 0; g.nz = 1; g.tag = "dl_dilated";
+                WN_TRY(wn_dl_mm(&g, c.st));
+            }
+            WN_TRY(wn_gate_fwd(ws + y.P, ws + y.gstep + (long)l * 2 * RB, 0, ws + w.one, ws + w.cvec + (long)l * 2 * d.R,
+                               ws + y.Sg, ws + y.Gt, z_l, 1, nb, d.R, 1, nb, c.st));
+            if (l + 1 < d.L) {  // next layer input = res_1x1(z) + x  (wavenet.py:546-548)
+                WnDlMmArgs r;
+                r.M = d.R; r.K = d.R; r.nb = nb;
+                r.A = ws + w.wres_f + (long)l * d.R * d.R; r.lda = d.R; r.a_zstride = 0;
+                r.B = z_l; r.ldb = nb; r.b_zstride = 0;
+                r.C = xin_l + (long)d.K * RB + (long)(d.K - 1) * RB; r.ldc = nb; r.c_zstride = 0;
+                r.bias = params + lb + lay.o_res_b;
+                r.D = xin_l + (long)(d.K - 1) * RB; r.ldd = nb;
+                r.relu = 0; r.nz = 1; r.tag = "dl_res";
+                WN_TRY(wn_dl_mm(&r, c.st));
+            }
+        }
+        {   // skip-sum over all layers + relu (wavenet.py:545,365-366): one launch over the layers, then a fixed-order sum
+            WnDlMmArgs g;
+            g.M = d.S; g.K = d.R; g.nb = nb;
+            g.A = ws + w.wskip_f; g.lda = d.S; g.a_zstride = (long)d.R * d.S;
+            g.B = ws + y.Zcat; g.ldb = nb; g.b_zstride = RB;
+            g.C = ws + y.skpart; g.ldc = nb; g.c_zstride = (long)d.S * nb;
+            g.bias = nullptr; g.D = nullptr; g.ldd = 0; g.relu = 0; g.nz = d.L; g.tag = "dl_skip";
+            WN_TRY(wn_dl_mm(&g, c.st));
+            WN_TRY(wn_dl_sum(ws + y.skpart, d.L, (long)d.S * nb, d.S, nb, ws + w.bskip, 1, ws + y.O1, c.st));
+        }
+        {
+            WnDlMmArgs g;
+            g.M = d.S; g.K = d.S; g.nb = nb;
+            g.A = ws + w.w1_f; g.lda = d.S; g.a_zstride = 0;
+            g.B = ws + y.O1; g.ldb = nb; g.b_zstride = 0;
+            g.C = ws + y.O2; g.ldc = nb; g.c_zstride = 0;
+            g.bias = params + lay.post1_b; g.D = nullptr; g.ldd = 0; g.relu = 1; g.nz = 1; g.tag = "dl_post1";
+            WN_TRY(wn_dl_mm(&g, c.st));
+        }
+        {
+            WnDlMmArgs g;
+            g.M = d.Q; g.K = d.S; g.nb = nb;
+            g.A = ws + w.w2_f; g.lda = d.Q; g.a_zstride = 0;
+            g.B = ws + y.O2; g.ldb = nb; g.b_zstride = 0;
+            g.C = ws + y.logits; g.ldc = nb; g.c_zstride = 0;
+            g.bias = params + lay.post2_b; g.D = nullptr; g.ldd = 0; g.relu = 0; g.nz = 1; g.tag = "dl_post2";
+            WN_TRY(wn_dl_mm(&g, c.st));
+        }
+        WN_TRY(wn_dl_select(ws + y.logits, d.Q, nb, samples, Ttot, t_forced, t_end, p, uniforms, logits_out, mode, c.st));
+        WN_TRY(wn_dl_push(&a, c.st));
+    }
+    return rt_check("wn_decode_layered_steps");
+}
+
 extern "C" int wn_op_gemm(const struct WnGemmArgs* args, void* stream) {
     g_err[0] = 0;
     WN_TRY(wn_gemm_launch(args, (wn_stream_t)stream));

@@ -96,3 +96,47 @@ int wn_front_dw_supported(int R, int K, int Q);
 long wn_front_dw_partial_floats(int B, int T, int R, int K, int Q);
 int wn_front_dw(const float* dX0, const int64_t* x, float* partial, float* dW, float* db, int B, int T, int R, int K, int Q,
                 wn_stream_t st);
+
+// ---- any-size decode (layer-wise launches; utterances are the contiguous axis of every matrix) ----
+// Step inputs for all layers: history taps from the queue rings into the per-layer operand windows
+// xin[l][tap][R][nb], aux pre-activations Gstep[l*2R+o][u] = upw[j]*G[u][f][l*2R+o], and the front conv of
+// the newest tokens into xin[0][K-1] (reference wavenet.py:355-356, 513-516).
+typedef struct WnDlArgs {
+    int nb, L, K, R, Q, depth, nG;  // nG = L*2R
+    int p, n_pad, Ue, F;
+    const float* params;
+    long off_causal_w, off_causal_b;
+    const float* upw;
+    const float* G;       // (nb, F, nG)
+    const int64_t* samples;  // (nb, Ttot)
+    long Ttot;
+    float* queues;        // layer l at qoff(l)*nb: [slot][R][nb]
+    float* xin;           // [L][K][R][nb]
+    float* gstep;         // [nG][nb]
+} WnDlArgs;
+int wn_dl_inputs(const WnDlArgs* a, wn_stream_t st);
+// After the step: push the layer inputs of position p into the queue rings.
+int wn_dl_push(const WnDlArgs* a, wn_stream_t st);
+// Token choice per utterance from logits [Q][nb]: argmax or inverse-CDF draw; teacher forcing below t_forced.
+int wn_dl_select(const float* logits, int Q, int nb, int64_t* samples, long Ttot, const int* t_forced, const int* t_end,
+                 int p, const float* uniforms, float* logits_out, int mode, wn_stream_t st);
+
+// Skinny contraction of the any-size decode: C[z][m][u] = epi( sum_k A[z](m,k) * B[z][k][u] ), u < nb (tens of
+// utterances), A(m,k) = Az[k*lda + m] (the packed transposed weights).  One workgroup = 32 output rows x 32
+// columns; its 4 waves split K and stream their weight rows straight from global memory into the A operand of
+// the f32 MFMA (no LDS staging: every weight is used once), partial tiles are summed through LDS.
+// epi: + bias[m] + D[m][u], relu.
+typedef struct WnDlMmArgs {
+    int M, K, nb;
+    const float* A; long lda; long a_zstride;
+    const float* B; long ldb; long b_zstride;
+    float* C; long ldc; long c_zstride;
+    const float* bias;
+    const float* D; long ldd;
+    int relu;
+    int nz;
+    const char* tag;
+} WnDlMmArgs;
+int wn_dl_mm(const WnDlMmArgs* a, wn_stream_t st);
+// out[m][u] = relu?( sum_z part[z][m][u] + bias[m] )
+int wn_dl_sum(const float* part, int nz, long zstride, int M, int nb, const float* bias, int relu, float* out, wn_stream_t st);

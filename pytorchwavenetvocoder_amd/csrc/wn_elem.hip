@@ -574,3 +574,202 @@ int wn_front_dw(const float* dX0, const int64_t* x, float* partial, float* dW, f
     WN_LAUNCH(k_front_dw_reduce, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, partial, nc * B, dW, db, R, K, Q);
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// any-size decode helpers (see wn_elem.h)
+// ---------------------------------------------------------------------------------------------
+static __device__ __forceinline__ long dl_queue_off(int l, int depth, int K, int R) {
+    const long cyc = l / depth, in = l % depth;
+    return (long)R * (K - 1) * (cyc * ((1L << depth) - 1) + ((1L << in) - 1));
+}
+
+__global__ __launch_bounds__(WN_TPB) void k_dl_inputs(WnDlArgs a) {
+    const int nb = a.nb, R = a.R, K = a.K;
+    const long n_hist = (long)a.L * (K - 1) * R * nb, n_aux = (long)a.nG * nb, n_front = (long)R * nb;
+    const long i = (long)blockIdx.x * WN_TPB + threadIdx.x;
+    if (i < n_hist) {
+        const int u = (int)(i % nb);
+        long r = i / nb;
+        const int c = (int)(r % R);
+        r /= R;
+        const int j = (int)(r % (K - 1)), l = (int)(r / (K - 1));
+        const int d = 1 << (l % a.depth), Dq = (K - 1) * d;
+        int slot = (a.p - (K - 1 - j) * d) % Dq;
+        if (slot < 0) slot += Dq;  // not written yet in this run: zero history
+        a.xin[(((long)l * K + j) * R + c) * nb + u] = a.queues[(dl_queue_off(l, a.depth, K, R) + (long)slot * R + c) * nb + u];
+    } else if (i < n_hist + n_aux) {
+        const long q = i - n_hist;
+        const int u = (int)(q % nb), row = (int)(q / nb);
+        const int t = a.p > a.n_pad ? a.p - a.n_pad : 0;  // replicated first column inside the left padding
+        int f = t / a.Ue;
+        const float w = a.upw[t - f * a.Ue];
+        if (f > a.F - 1) f = a.F - 1;
+        a.gstep[q] = w * a.G[((long)u * a.F + f) * a.nG + row];
+    } else if (i < n_hist + n_aux + n_front) {
+        const long q = i - n_hist - n_aux;
+        const int u = (int)(q % nb), c = (int)(q / nb);
+        float x0 = a.params[a.off_causal_b + c];
+        for (int k = 0; k < K; ++k) {
+            const int tq = a.p - (K - 1 - k);
+            if (tq >= 0) {
+                long long tok = a.samples[(long)u * a.Ttot + tq] % a.Q;
+                if (tok < 0) tok += a.Q;
+                x0 += a.params[a.off_causal_w + ((long)c * a.Q + tok) * K + k];
+            }
+        }
+        a.xin[((long)(K - 1) * R + c) * nb + u] = x0;
+    }
+}
+
+int wn_dl_inputs(const WnDlArgs* a, wn_stream_t st) {
+    WN_PROF("dl_inputs", 0.0, 0.0, st);
+    const long n = (long)a->L * (a->K - 1) * a->R * a->nb + (long)a->nG * a->nb + (long)a->R * a->nb;
+    WN_LAUNCH(k_dl_inputs, dim3((unsigned)((n + WN_TPB - 1) / WN_TPB)), dim3(WN_TPB), 0, st, *a);
+    return 0;
+}
+
+__global__ __launch_bounds__(WN_TPB) void k_dl_push(WnDlArgs a) {
+    const int nb = a.nb, R = a.R, K = a.K;
+    const long n = (long)a.L * R * nb;
+    const long i = (long)blockIdx.x * WN_TPB + threadIdx.x;
+    if (i >= n || K < 2) return;
+    const int u = (int)(i % nb);
+    long r = i / nb;
+    const int c = (int)(r % R), l = (int)(r / R);
+    const int Dq = (K - 1) << (l % a.depth);
+    a.queues[(dl_queue_off(l, a.depth, K, R) + (long)(a.p % Dq) * R + c) * nb + u] = a.xin[(((long)l * K + (K - 1)) * R + c) * nb + u];
+}
+
+int wn_dl_push(const WnDlArgs* a, wn_stream_t st) {
+    WN_PROF("dl_push", 0.0, 0.0, st);
+    const long n = (long)a->L * a->R * a->nb;
+    WN_LAUNCH(k_dl_push, dim3((unsigned)((n + WN_TPB - 1) / WN_TPB)), dim3(WN_TPB), 0, st, *a);
+    return 0;
+}
+
+// one thread per utterance (Q <= a few hundred): first-max argmax or inverse-CDF draw
+__global__ __launch_bounds__(WN_TPB) void k_dl_select(const float* __restrict__ logits, int Q, int nb, int64_t* samples, long Ttot,
+                                                      const int* t_forced, const int* t_end, int p, const float* uniforms,
+                                                      float* logits_out, int mode) {
+    const int u = blockIdx.x * WN_TPB + threadIdx.x;
+    if (u >= nb) return;
+    float best = -3.0e38f;
+    int bi = 0;
+    for (int q = 0; q < Q; ++q) {
+        const float v = logits[(long)q * nb + u];
+        if (logits_out) logits_out[((long)u * Ttot + p) * Q + q] = v;
+        if (v > best) { best = v; bi = q; }
+    }
+    int chosen = bi;
+    if (mode == 1 && uniforms != nullptr) {
+        float total = 0.0f;
+        for (int q = 0; q < Q; ++q) total += expf(logits[(long)q * nb + u] - best);
+        const float target = uniforms[(long)u * Ttot + p + 1] * total;
+        float run = 0.0f;
+        int cand = -1;
+        for (int q = 0; q < Q; ++q) {
+            run += expf(logits[(long)q * nb + u] - best);
+            if (cand < 0 && run >= target) cand = q;
+        }
+        if (cand >= 0) chosen = cand;
+    }
+    if (p + 1 >= t_forced[u] && p + 1 < t_end[u]) samples[(long)u * Ttot + p + 1] = chosen;
+}
+
+int wn_dl_select(const float* logits, int Q, int nb, int64_t* samples, long Ttot, const int* t_forced, const int* t_end, int p,
+                 const float* uniforms, float* logits_out, int mode, wn_stream_t st) {
+    WN_PROF("dl_select", 0.0, 0.0, st);
+    WN_LAUNCH(k_dl_select, dim3((unsigned)((nb + WN_TPB - 1) / WN_TPB)), dim3(WN_TPB), 0, st, logits, Q, nb, samples, Ttot,
+              t_forced, t_end, p, uniforms, logits_out, mode);
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void k_dl_mm(WnDlMmArgs a) {
+    __shared__ float red[4][32 * 33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32, z = blockIdx.z;
+    const float* __restrict__ Az = a.A + (long)z * a.a_zstride;
+    const float* __restrict__ Bz = a.B + (long)z * a.b_zstride;
+    // this wave's k range (multiples of 2)
+    const int kq = ((a.K + 7) / 8) * 2;
+    const int k0 = wave * kq, k1 = (k0 + kq < a.K) ? k0 + kq : a.K;
+    const bool m_ok = (m0 + li) < a.M, u_ok = (n0 + li) < a.nb;
+    const float* pa = Az + (m_ok ? m0 + li : 0);
+    const float* pb = Bz + (u_ok ? n0 + li : 0);
+    f32x16 acc = f32x16_zero();
+    // 16 k per step; the 16 loads of step s+1 are issued before the 8 MFMAs of step s (two register sets)
+    auto fetch = [&](int k, float (&av)[8], float (&bv)[8]) {
+        WN_UNROLL
+        for (int s = 0; s < 8; ++s) {
+            const int kk = k + 2 * s + hi;
+            const bool ok = kk < k1;
+            av[s] = pa[(long)(ok ? kk : k0) * a.lda];
+            bv[s] = pb[(long)(ok ? kk : k0) * a.ldb];
+            if (!ok || !m_ok) av[s] = 0.0f;
+            if (!ok || !u_ok) bv[s] = 0.0f;
+        }
+    };
+    float a0[8], b0[8], a1[8], b1[8];
+    if (k0 < k1) fetch(k0, a0, b0);
+    for (int k = k0; k < k1; k += 32) {
+        if (k + 16 < k1) fetch(k + 16, a1, b1);
+        WN_SCHED_BARRIER();
+        WN_UNROLL
+        for (int s = 0; s < 8; ++s) acc = mfma32(a0[s], b0[s], acc);
+        WN_SCHED_BARRIER();
+        if (k + 16 >= k1) break;
+        if (k + 32 < k1) fetch(k + 32, a0, b0);
+        WN_SCHED_BARRIER();
+        WN_UNROLL
+        for (int s = 0; s < 8; ++s) acc = mfma32(a1[s], b1[s], acc);
+        WN_SCHED_BARRIER();
+    }
+    WN_UNROLL
+    for (int r = 0; r < 16; ++r) red[wave][mfma32_row(r, hi) * 33 + li] = acc[r];
+    __syncthreads();
+    float* Cz = a.C + (long)z * a.c_zstride;
+    for (int i = tid; i < 32 * 32; i += 256) {
+        const int row = i >> 5, col = i & 31;
+        const int m = m0 + row, u = n0 + col;
+        if (m < a.M && u < a.nb) {
+            float v = (red[0][row * 33 + col] + red[1][row * 33 + col]) + (red[2][row * 33 + col] + red[3][row * 33 + col]);
+            if (a.bias) v += a.bias[m];
+            if (a.D) v += a.D[(long)m * a.ldd + u];
+            if (a.relu) v = fmaxf(v, 0.0f);
+            Cz[(long)m * a.ldc + u] = v;
+        }
+    }
+}
+
+int wn_dl_mm(const WnDlMmArgs* a, wn_stream_t st) {
+    WN_PROF(a->tag ? a->tag : "dl_mm", 2.0 * a->M * (double)a->K * a->nb * a->nz, (double)a->M * a->K * 4.0 * a->nz, st);
+    if (a->M <= 0 || a->K <= 0 || a->nb <= 0 || a->nz <= 0) return 1;
+    dim3 grid((unsigned)((a->M + 31) / 32), (unsigned)((a->nb + 31) / 32), (unsigned)a->nz);
+    WN_LAUNCH(k_dl_mm, grid, dim3(256), 0, st, *a);
+    return 0;
+}
+
+__global__ __launch_bounds__(WN_TPB) void k_dl_sum(const float* __restrict__ part, int nz, long zstride, int M, int nb,
+                                                   const float* __restrict__ bias, int relu, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * WN_TPB + threadIdx.x;
+    if (i >= (long)M * nb) return;
+    float s = 0.0f;
+    for (int z0 = 0; z0 < nz; z0 += 8) {
+        float v[8];
+        WN_UNROLL
+        for (int u = 0; u < 8; ++u) v[u] = (z0 + u < nz) ? part[(long)(z0 + u) * zstride + i] : 0.0f;
+        WN_UNROLL
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    if (bias) s += bias[i / nb];
+    if (relu) s = fmaxf(s, 0.0f);
+    out[i] = s;
+}
+
+int wn_dl_sum(const float* part, int nz, long zstride, int M, int nb, const float* bias, int relu, float* out, wn_stream_t st) {
+    WN_PROF("dl_sum", 0.0, 0.0, st);
+    const long n = (long)M * nb;
+    WN_LAUNCH(k_dl_sum, dim3((unsigned)((n + WN_TPB - 1) / WN_TPB)), dim3(WN_TPB), 0, st, part, nz, zstride, M, nb, bias, relu, out);
+    return 0;
+}

@@ -182,7 +182,7 @@ class WaveNetEngine(object):
     def decode_supported(self):
         return bool(self.lib.wn_decode_supported(ctypes.byref(self.cfg)))
 
-    def decode(self, x, h, n_samples_list, mode="argmax", chunk=4096, return_logits=False, progress=None):
+    def decode(self, x, h, n_samples_list, mode="argmax", chunk=4096, return_logits=False, progress=None, layered=None):
         """Queue-based sample-by-sample generation on the HIP decode kernel.
 
         x (B,T0) int64 context, h (B, n_aux, frames | samples) aux features covering T0 + max(n)
@@ -190,6 +190,10 @@ class WaveNetEngine(object):
         (wavenet.py:328-336, 417-425): the context is left-padded with n_quantize//2 up to the
         receptive field and the aux features by replicating their first column.  Returns the
         generated tokens as a list of LongTensors (utterance order) [and the per-step logits].
+
+        Two kernels implement it: the persistent one-workgroup-per-utterance kernel (model sizes covered by
+        ``decode_supported()``) and the any-size layer-wise path (``layered=True``; chosen automatically
+        when the first does not apply, e.g. the n_resch = 512 recipe default).
         """
         self._check_device(x, h)
         if x.dtype != torch.int64 or x.dim() != 2 or h.dim() != 3:
@@ -209,30 +213,46 @@ class WaveNetEngine(object):
         n_pad = max(self.receptive_field - T0, 0)
         Tctx = T0 + n_pad
         Ttot = Tctx + n_max
-        npk = self.lib.wn_decode_pack_floats(cfg)
-        if npk <= 0:
-            raise _lib.WnError("wn_decode_pack_floats: %s" % self.lib.wn_last_error().decode())
+        if layered is None:
+            layered = not self.decode_supported()
         st = _stream_handle(self.device)
         dev = self.device
-        wpack = torch.empty(npk, dtype=torch.float32, device=dev)
-        self.lib.check(self.lib.wn_decode_pack(cfg, _ptr(self.flat_params), _ptr(wpack), st), "wn_decode_pack")
         h = h.contiguous().float()
         G = torch.empty((B, F, self.n_layers * 2 * self.cfg.n_resch), dtype=torch.float32, device=dev)
-        self.lib.check(self.lib.wn_decode_aux(cfg, B, F, _ptr(wpack), _ptr(h), _ptr(G), st), "wn_decode_aux")
+        if layered:
+            nst = self.lib.wn_decode_layered_state_floats(cfg, B)
+            if nst <= 0:
+                raise _lib.WnError("wn_decode_layered_state_floats: %s" % self.lib.wn_last_error().decode())
+            state = torch.zeros(nst, dtype=torch.float32, device=dev)
+            self.lib.check(self.lib.wn_decode_layered_prepare(cfg, B, F, _ptr(self.flat_params), _ptr(h), _ptr(G), _ptr(state),
+                                                              nst, st), "wn_decode_layered_prepare")
+        else:
+            npk = self.lib.wn_decode_pack_floats(cfg)
+            if npk <= 0:
+                raise _lib.WnError("wn_decode_pack_floats: %s" % self.lib.wn_last_error().decode())
+            wpack = torch.empty(npk, dtype=torch.float32, device=dev)
+            self.lib.check(self.lib.wn_decode_pack(cfg, _ptr(self.flat_params), _ptr(wpack), st), "wn_decode_pack")
+            self.lib.check(self.lib.wn_decode_aux(cfg, B, F, _ptr(wpack), _ptr(h), _ptr(G), st), "wn_decode_aux")
+            state = torch.zeros((B, self.lib.wn_decode_state_floats(cfg)), dtype=torch.float32, device=dev)
         samples = torch.full((B, Ttot), self.cfg.n_quantize // 2, dtype=torch.int64, device=dev)
         samples[:, n_pad:Tctx] = x
         t_forced = torch.full((B,), Tctx, dtype=torch.int32, device=dev)
         t_end = torch.tensor([Tctx + int(n) for n in n_samples_list], dtype=torch.int32, device=dev)
-        state = torch.zeros((B, self.lib.wn_decode_state_floats(cfg)), dtype=torch.float32, device=dev)
         uniforms = torch.rand((B, Ttot), dtype=torch.float32, device=dev) if mode == "sampling" else None
         logits = torch.zeros((B, Ttot, self.cfg.n_quantize), dtype=torch.float32, device=dev) if return_logits else None
         p = 0
         while p < Ttot - 1:
             p1 = min(p + chunk, Ttot - 1)
-            rc = self.lib.wn_decode_steps(cfg, B, _ptr(self.flat_params), _ptr(wpack), _ptr(G), F, n_pad, _ptr(samples),
-                                          Ttot, _ptr(t_forced), _ptr(t_end), p, p1, _ptr(state), _ptr(uniforms),
-                                          _ptr(logits), 1 if mode == "sampling" else 0, st)
-            self.lib.check(rc, "wn_decode_steps")
+            if layered:
+                rc = self.lib.wn_decode_layered_steps(cfg, B, _ptr(self.flat_params), _ptr(G), F, n_pad, _ptr(samples), Ttot,
+                                                      _ptr(t_forced), _ptr(t_end), p, p1, _ptr(state), state.numel(),
+                                                      _ptr(uniforms), _ptr(logits), 1 if mode == "sampling" else 0, st)
+                self.lib.check(rc, "wn_decode_layered_steps")
+            else:
+                rc = self.lib.wn_decode_steps(cfg, B, _ptr(self.flat_params), _ptr(wpack), _ptr(G), F, n_pad, _ptr(samples),
+                                              Ttot, _ptr(t_forced), _ptr(t_end), p, p1, _ptr(state), _ptr(uniforms),
+                                              _ptr(logits), 1 if mode == "sampling" else 0, st)
+                self.lib.check(rc, "wn_decode_steps")
             p = p1
             if progress is not None:
                 progress(max(p + 1 - Tctx, 0), n_max)

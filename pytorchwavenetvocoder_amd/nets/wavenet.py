@@ -381,8 +381,10 @@ class WaveNet(nn.Module):
 
     def fast_generate(self, x, h, n_samples, intervals=None, mode="sampling"):
         """Generate a waveform with the queue algorithm (reference wavenet.py:309-395) on the HIP
-        decode kernel: one persistent workgroup walks the context (which fills the dilation
-        queues) and then emits ``n_samples`` tokens; nothing but the result leaves the GPU.
+        decode path: one persistent workgroup per utterance for the model sizes the decode kernel
+        covers, layer-wise launches on [channels x batch] operands for any other size; the context
+        walk fills the dilation queues, then ``n_samples`` tokens are emitted; nothing but the result
+        leaves the GPU.
 
         Args:
             x (tensor): Long tensor variable with the shape  (1, T).
@@ -395,9 +397,6 @@ class WaveNet(nn.Module):
         Returns:
             ndarray: Generated quantized waveform (n_samples,).
         """
-        if not self.engine.decode_supported():
-            logging.warning("decode kernel does not cover this model size; using full-window forwards")
-            return self.generate(x, h, n_samples, intervals, mode)
         return self._decode(x, h, [n_samples], intervals, mode)[0].cpu().numpy()
 
     def batch_fast_generate(self, x, h, n_samples_list, intervals=None, mode="sampling"):
@@ -413,16 +412,5 @@ class WaveNet(nn.Module):
             mode (str): "sampling" or "argmax".
         """
         order = sorted(range(len(n_samples_list)), key=lambda i: (n_samples_list[i], i))
-        if not self.engine.decode_supported():
-            logging.warning("decode kernel does not cover this model size; using full-window forwards")
-            T = x.size(1)
-            out = []
-            for i in order:
-                n = n_samples_list[i]
-                hi = h[i:i + 1, :, :]
-                if self.upsampling_factor == 0:
-                    hi = hi[:, :, :n + T]
-                out.append(self.generate(x[i:i + 1], hi, n, intervals, mode))
-            return out
         toks = self._decode(x, h, n_samples_list, intervals, mode)
         return [toks[i].cpu().numpy() for i in order]

@@ -39,7 +39,7 @@ class DecodeCase(object):
         self.min_margin = float(z["min_margin"])
 
 
-def check_decode_case(name, lib, device):
+def check_decode_case(name, lib, device, layered_too=True):
     """Kernel tokens == the reference's fast_generate tokens, per-step logits within 1e-4, batch
     order as the reference, through both the engine call and the nn.Module API."""
     g = DecodeCase(name)
@@ -53,6 +53,12 @@ def check_decode_case(name, lib, device):
     for b, n in enumerate(g.n_list):
         assert float((lg[b].cpu() - g.logits[b]).abs().max()) <= TOL_LOGITS, (name, b)
         assert (toks[b].cpu().numpy() == g.fast[b]).all(), (name, b)
+    # the any-size layer-wise path must give the same tokens / logits
+    if layered_too:
+        toks2, lg2 = model.engine.decode(x, h, g.n_list, mode="argmax", chunk=11, return_logits=True, layered=True)
+        for b, n in enumerate(g.n_list):
+            assert float((lg2[b].cpu() - g.logits[b]).abs().max()) <= TOL_LOGITS, (name, b)
+            assert (toks2[b].cpu().numpy() == g.fast[b]).all(), (name, b)
     # module API: single utterances (wavenet.py:309) and the batch (wavenet.py:397)
     for b, n in enumerate(g.n_list):
         hb = h[b:b + 1]

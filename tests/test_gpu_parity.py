@@ -203,15 +203,24 @@ def test_decode_cfg2_teacher_forced_equals_training_forward():
         assert int(safe.sum()) > nb // 2
 
 
-def test_decode_unsupported_size_falls_back_to_window_forwards():
+def test_decode_any_size_model_uses_the_layered_path():
+    """n_resch = 128 is outside the compiled classes of the persistent decode kernel: fast_generate /
+    batch_fast_generate run the layer-wise path and must reproduce the queue algorithm (oracle)."""
     from pytorchwavenetvocoder_amd.nets import WaveNet
-    cfg = O.OracleConfig(32, 4, 128, 32, 2, 1, 2, 0)   # n_resch=128: outside the compiled decode classes
+    cfg = O.OracleConfig(32, 4, 128, 160, 3, 2, 2, 4)
+    params = O.random_params(cfg, 3, scale=0.1)
     model = WaveNet(*cfg.as_tuple())
-    model.load_state_dict(O.random_params(cfg, 3, scale=0.3))
+    model.load_state_dict(params)
     model.to(DEV)
     assert not model.engine.decode_supported()
-    x = torch.tensor([[5, 9, 1, 30]]).long().to(DEV)
-    h = torch.from_numpy(np.random.RandomState(4).standard_normal((1, 4, 16)).astype(np.float32)).to(DEV)
-    a = model.fast_generate(x, h, 10, mode="argmax")
-    b = O.generate(cfg, O.random_params(cfg, 3, scale=0.3), x.cpu(), h.cpu(), 10)
-    assert (a == b).all()
+    x = torch.tensor([[5, 9, 1, 30], [7, 7, 2, 0]]).long()
+    h = torch.from_numpy(np.random.RandomState(4).standard_normal((2, 4, 12)).astype(np.float32))
+    ref, ref_lg = O.batch_fast_generate(cfg, params, x, h, [30, 22], return_logits=True)
+    toks, lg = model.engine.decode(x.to(DEV), h.to(DEV), [30, 22], return_logits=True)
+    for b, i in enumerate([1, 0]):   # oracle order: shortest first
+        assert float((lg[i].cpu() - ref_lg[b]).abs().max()) <= 1e-4
+        top2 = ref_lg[b].topk(2, dim=1).values
+        safe = ((top2[:, 0] - top2[:, 1]) > 1e-3).numpy()
+        assert (toks[i].cpu().numpy()[safe] == ref[b][safe]).all()
+    out = model.batch_fast_generate(x.to(DEV), h.to(DEV), [30, 22], mode="argmax")
+    assert [len(o) for o in out] == [22, 30]
