@@ -163,11 +163,18 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # WN_BENCH_BACKEND=gloo lets the multi-rank control flow be exercised on a box with fewer GPUs than ranks
+    # (ranks then share devices); the driver's runs use nccl (= RCCL), one rank per GPU.
+    backend = os.environ.get("WN_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     torch.manual_seed(1)  # reference default seed (train.py:386)
     model = WaveNet(**CFG2)
@@ -222,14 +229,18 @@ def main():
     # ---- per-kernel timing with HIP events (untimed extra steps, rank 0) ----
     roofline = None
     kernels = None
-    if rank == 0 and args.profile_steps > 0:
+    if args.profile_steps > 0:
+        # every rank runs the extra steps (they contain the gradient all-reduce); only rank 0 records events
         lib = model.engine.lib
         torch.cuda.synchronize(device)
-        lib.wn_prof_enable(1)
+        if rank == 0:
+            lib.wn_prof_enable(1)
         for _ in range(args.profile_steps):
             step()
         torch.cuda.synchronize(device)
-        lib.wn_prof_enable(0)
+        if rank == 0:
+            lib.wn_prof_enable(0)
+    if rank == 0 and args.profile_steps > 0:
         need = lib.wn_prof_report(None, 0)
         buf = ctypes.create_string_buffer(max(need, 16))
         lib.wn_prof_report(buf, len(buf))
@@ -292,9 +303,8 @@ def main():
                        "global_batch": world * B, "parallelism": "dp%d" % world,
                        "kernels": "layered" if args.no_fused else "fused+gemm",
                        "arithmetic": "fp32 storage and accumulation; contractions on the bf16 matrix cores with a 3-way "
-                                     "operand split (6 products, fp32-equivalent to round-off) except the one-hot front "
-                                     "weight gradient and K=3 forward blocks (exact f32 MFMA); WN_FLAG_EXACT_MFMA "
-                                     "selects the f32 MFMA everywhere"},
+                                     "operand split (6 products, fp32-equivalent to round-off) except K=3 forward blocks "
+                                     "(exact f32 MFMA); WN_FLAG_EXACT_MFMA selects the f32 MFMA everywhere"},
             "timesteps_per_sec": world * timesteps_per_s_gpu, "final_loss": final_loss,
             "roofline": roofline, "kernels": kernels,
         }
