@@ -397,6 +397,11 @@ def main(argv=None):
     """RUN TRAINING."""
     args = get_parser().parse_args(argv)
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    n_ranks = world_env if world_env > 1 else args.n_gpus
+    if n_ranks > 1 and args.batch_length is not None and args.batch_size < n_ranks:
+        # every rank must own at least one window of each minibatch (the reference scatters the same way)
+        logging.error("--batch_size (%d) must be >= the number of GPUs (%d)." % (args.batch_size, n_ranks))
+        sys.exit(1)
     if world_env > 1:  # launched by torch.distributed.run: one process per GPU already
         _worker(int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0"))), world_env, args,
                 int(os.environ.get("MASTER_PORT", "29500")))
