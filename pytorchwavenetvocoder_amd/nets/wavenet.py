@@ -316,8 +316,10 @@ class WaveNet(nn.Module):
         return eng
 
     def generate(self, x, h, n_samples, intervals=None, mode="sampling"):
-        """Generate a waveform sample by sample with full-window forwards (reference
-        wavenet.py:243-307).  Every window runs through the HIP forward.
+        """Naive generation (reference wavenet.py:243-307): every new sample is the last output of
+        a full forward over the newest ``receptive_field`` samples (activations left of the window
+        count as zero, which is what distinguishes it from ``fast_generate``).  Every window runs
+        through the HIP forward; the token buffer stays on the device.
 
         Args:
             x (Tensor): Long tensor variable with the shape (1, T).
@@ -329,37 +331,33 @@ class WaveNet(nn.Module):
         Returns:
             ndarray: Generated quantized waveform (n_samples,).
         """
+        if mode not in ("sampling", "argmax"):
+            logging.error("mode should be sampling or argmax")
+            sys.exit(1)
+        rf = self.receptive_field
         with torch.no_grad():
             if self.upsampling_factor > 0:
                 h = self.upsampling(h)
-            n_pad = self.receptive_field - x.size(1)
+            n_pad = max(rf - x.size(1), 0)
+            n_ctx = x.size(1) + n_pad
+            tokens = torch.full((1, n_ctx + n_samples), self.n_quantize // 2, dtype=torch.long, device=h.device)
+            tokens[:, n_pad:n_ctx] = x
             if n_pad > 0:
-                x = F.pad(x, (n_pad, 0), "constant", self.n_quantize // 2)
                 h = F.pad(h, (n_pad, 0), "replicate")
-            samples = x[0].tolist()
-            start = time.time()
+            tick, done_at_tick = time.time(), 0
             for i in range(n_samples):
-                current_idx = len(samples)
-                xw = torch.tensor(samples[-self.receptive_field:], device=h.device).long().view(1, -1)
-                h_ = h[:, :, current_idx - self.receptive_field: current_idx].contiguous()
-                output = self._window_logits(xw, h_)
-                if mode == "sampling":
-                    posterior = F.softmax(output[-1], dim=0)
-                    dist = torch.distributions.Categorical(posterior)
-                    sample = int(dist.sample())
-                elif mode == "argmax":
-                    sample = int(output[-1].argmax())
+                end = n_ctx + i
+                logits = self._window_logits(tokens[:, end - rf:end].contiguous(), h[:, :, end - rf:end].contiguous())[-1]
+                if mode == "argmax":
+                    tokens[0, end] = logits.argmax()
                 else:
-                    logging.error("mode should be sampling or argmax")
-                    sys.exit(1)
-                samples.append(sample)
+                    tokens[0, end] = torch.distributions.Categorical(F.softmax(logits, dim=0)).sample()
                 if intervals is not None and (i + 1) % intervals == 0:
+                    per = (time.time() - tick) / (i + 1 - done_at_tick)
                     logging.info("%d/%d estimated time = %.3f sec (%.3f sec / sample)" % (
-                        i + 1, n_samples,
-                        (n_samples - i - 1) * ((time.time() - start) / intervals),
-                        (time.time() - start) / intervals))
-                    start = time.time()
-            return np.array(samples[-n_samples:])
+                        i + 1, n_samples, (n_samples - i - 1) * per, per))
+                    tick, done_at_tick = time.time(), i + 1
+            return tokens[0, n_ctx:].cpu().numpy()
 
     def _decode(self, x, h, n_samples_list, intervals, mode):
         """Run the HIP decode kernel (csrc/wn_decode.hip); returns per-utterance LongTensors."""

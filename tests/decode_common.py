@@ -69,6 +69,11 @@ def check_decode_case(name, lib, device, layered_too=True):
     assert len(outs) == len(g.batch)
     for a, r in zip(outs, g.batch):
         assert a.shape == r.shape and (a == r).all(), name
+    # naive generate() (window forwards; reference wavenet.py:243-307) against the reference's own naive tokens
+    if name.startswith("decode_tiny"):
+        b = len(g.n_list) - 1
+        out = model.generate(x[b:b + 1], h[b:b + 1], g.n_list[b], mode="argmax")
+        assert (out == g.naive[b]).all(), name
     # sampling mode: valid tokens, reproducible under the torch seed (uniforms come from torch.rand)
     torch.manual_seed(5)
     s1 = model.fast_generate(x[:1], h[:1], g.n_list[0], mode="sampling")
