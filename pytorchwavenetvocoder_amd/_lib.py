@@ -86,6 +86,11 @@ class WnLibrary(object):
     def __init__(self, path, is_emulator=False):
         self.path = path
         self.is_emulator = is_emulator
+        if not is_emulator:
+            # PyTorch-ROCm ships its own HIP runtime: it must be in the process BEFORE this library is loaded,
+            # otherwise libwavenet_hip.so binds the system runtime, the process ends up with two runtimes and
+            # every launch of ours fails with "no ROCm-capable device is detected".
+            import torch  # noqa: F401
         self.lib = ctypes.CDLL(path)
         L = self.lib
         vp, i, i64, f, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t

@@ -25,6 +25,18 @@ static int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// Every entry point starts from a clean slate: the error text is reset and an error some EARLIER runtime call of
+// the process left behind (hipGetLastError is sticky per thread: e.g. a device probe before the framework
+// initialised the runtime) is discarded, so rt_check only reports launches of this call.
+#ifdef WN_EMU
+static void api_enter() { g_err[0] = 0; }
+#else
+static void api_enter() {
+    g_err[0] = 0;
+    (void)hipGetLastError();
+}
+#endif
+
 #ifdef WN_EMU
 static int rt_check(const char*) { return 0; }
 static void rt_event_record(void*, wn_stream_t) {}
@@ -472,7 +484,7 @@ static int pack_weights(const Ctx& c, const float* params) {
 // ------------------------------------------------------------------------------------------
 extern "C" int wn_forward(const WnConfig* cfg, int B, int T, const float* params, const int64_t* x, const float* h,
                           float* logits, void* wsp, size_t ws_bytes, int flags, void* stream) {
-    g_err[0] = 0;
+    api_enter();
     Ctx c;
     WN_TRY(make_ctx(&c, cfg, B, T, wsp, ws_bytes, flags, stream));
     if (!params || !x || !h || !logits) return fail(1, "NULL argument");
@@ -576,7 +588,7 @@ extern "C" int wn_forward(const WnConfig* cfg, int B, int T, const float* params
 extern "C" int wn_softmax_ce_loss(const WnConfig* cfg, int B, int T, const float* logits, const int64_t* target, int t_start,
                                   float grad_scale, float loss_scale, float* loss, float* dlogits, void* wsp, size_t ws_bytes,
                                   void* stream) {
-    g_err[0] = 0;
+    api_enter();
     Ctx c;
     WN_TRY(make_ctx(&c, cfg, B, T, wsp, ws_bytes, 0, stream));
     if (!logits || !target || !loss) return fail(1, "NULL argument");
@@ -647,7 +659,7 @@ static DwOut dw_out_plain(float* out, long ld, float* rowsum_out) {
 extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* params, const int64_t* x, const float* h,
                            const float* dlogits, float* grads, void* wsp, size_t ws_bytes, void* const* events, int n_events,
                            int lpb, int flags, void* stream) {
-    g_err[0] = 0;
+    api_enter();
     Ctx c;
     WN_TRY(make_ctx(&c, cfg, B, T, wsp, ws_bytes, flags, stream));
     if (!params || !x || !h || !dlogits || !grads) return fail(1, "NULL argument");
@@ -889,7 +901,7 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
 extern "C" int wn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
                             float lr, float beta1, float beta2, float eps, float weight_decay, int64_t skip_lo,
                             int64_t skip_hi, void* stream) {
-    g_err[0] = 0;
+    api_enter();
     if (!params || !grads || !exp_avg || !exp_avg_sq || n <= 0 || step < 1) return fail(1, "bad wn_adam_step argument");
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
@@ -903,7 +915,7 @@ extern "C" int wn_adam_step(float* params, const float* grads, float* exp_avg, f
 // ------------------------------------------------------------------------------------------
 extern "C" int wn_op_front(const float* weight, const float* bias, const int64_t* x, float* out, float* scratch, int B, int T,
                            int Q, int R, int K, void* stream) {
-    g_err[0] = 0;
+    api_enter();
     WnCopy4 cp;
     cp.n0 = K; cp.n1 = Q; cp.n2 = R; cp.nl = 1;
     cp.d0 = (long)Q * R; cp.d1 = R; cp.d2 = 1; cp.dl = 0;
@@ -915,7 +927,7 @@ extern "C" int wn_op_front(const float* weight, const float* bias, const int64_t
 
 extern "C" int wn_op_causal_conv(const float* weight, const float* bias, const float* x, float* y, float* scratch, int B, int T,
                                  int Cin, int Cout, int K, int dilation, void* stream) {
-    g_err[0] = 0;
+    api_enter();
     WnCopy4 cp;  // scratch[(tap*Cin + i)*Cout + o] = W[o][i][tap]
     cp.n0 = K; cp.n1 = Cin; cp.n2 = Cout; cp.nl = 1;
     cp.s0 = 1; cp.s1 = K; cp.s2 = (long)Cin * K; cp.sl = 0;
@@ -948,7 +960,7 @@ extern "C" int wn_decode_supported(const WnConfig* cfg) {
     Dims d;
     WnDecodePlan pl;
     const int rc = decode_plan(cfg, &d, &pl);
-    g_err[0] = 0;
+    api_enter();
     return rc == 0 ? 1 : 0;
 }
 
@@ -974,7 +986,7 @@ extern "C" int64_t wn_decode_stream_bytes(const WnConfig* cfg) {
 }
 
 extern "C" int wn_decode_pack(const WnConfig* cfg, const float* params, float* wpack, void* stream) {
-    g_err[0] = 0;
+    api_enter();
     Dims d;
     WnDecodePlan pl;
     WN_TRY(decode_plan(cfg, &d, &pl));
@@ -1019,7 +1031,7 @@ extern "C" int wn_decode_pack(const WnConfig* cfg, const float* params, float* w
 
 extern "C" int wn_decode_aux(const WnConfig* cfg, int B, int F, const float* wpack, const float* h, float* G,
                              void* stream) {
-    g_err[0] = 0;
+    api_enter();
     Dims d;
     WnDecodePlan pl;
     WN_TRY(decode_plan(cfg, &d, &pl));
@@ -1040,7 +1052,7 @@ extern "C" int wn_decode_steps(const WnConfig* cfg, int B, const float* params, 
                                int n_pad, int64_t* samples, int64_t Ttot, const int32_t* t_forced, const int32_t* t_end,
                                int p0, int p1, float* state, const float* uniforms, float* logits_out, int mode,
                                void* stream) {
-    g_err[0] = 0;
+    api_enter();
     Dims d;
     WnDecodePlan pl;
     WN_TRY(decode_plan(cfg, &d, &pl));
@@ -1139,7 +1151,7 @@ extern "C" int64_t wn_decode_layered_state_floats(const WnConfig* cfg, int B) {
 // computes the aux projections G (B, F, L*2R) of all layers at the aux rate.
 extern "C" int wn_decode_layered_prepare(const WnConfig* cfg, int B, int F, const float* params, const float* h, float* G,
                                          float* state, int64_t state_floats, void* stream) {
-    g_err[0] = 0;
+    api_enter();
     Dims d;
     WN_TRY(check_cfg(cfg, &d));
     if (!params || !h || !G || !state || B < 1 || F < 1) return fail(1, "bad argument");
@@ -1164,7 +1176,7 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
                                        int64_t* samples, int64_t Ttot, const int32_t* t_forced, const int32_t* t_end, int p0,
                                        int p1, float* state, int64_t state_floats, const float* uniforms, float* logits_out,
                                        int mode, void* stream) {
-    g_err[0] = 0;
+    api_enter();
     Dims d;
     WN_TRY(check_cfg(cfg, &d));
     if (!params || !G || !samples || !t_forced || !t_end || !state) return fail(1, "NULL argument");
@@ -1254,7 +1266,7 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
 }
 
 extern "C" int wn_op_gemm(const struct WnGemmArgs* args, void* stream) {
-    g_err[0] = 0;
+    api_enter();
     WN_TRY(wn_gemm_launch(args, (wn_stream_t)stream));
     return rt_check("wn_op_gemm");
 }
