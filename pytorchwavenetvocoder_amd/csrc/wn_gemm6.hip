@@ -371,7 +371,7 @@ __global__ __launch_bounds__(G6_T, WN_G6_DW_OCC) void k_gemm6_dw(WnGemmArgs g) {
     };
     // split E consecutive-k values and write the three pieces of row `row` at k offset `kofs`
     auto split_store = [&](char* base, int rows, int row, int kofs, const float* v, int E) {
-        unsigned h[4], md[4], lo[4];
+        unsigned h[8], md[8], lo[8];  // E <= 16
         for (int q = 0; q < E / 2; ++q) {
             const float x0 = v[2 * q], x1 = v[2 * q + 1];
             h[q] = wn_pk_bf16(x0, x1);
