@@ -390,11 +390,7 @@ __global__ __launch_bounds__(WN_DT) void k_decode(WnDecodeArgs a) {
                 const int i4 = imin(part_s + ps * r, R4 - 1);
                 const float4 x = *reinterpret_cast<const float4*>(zbuf + 4 * i4);
                 acc_sk = dot4p(W[UD + UR + r], x, acc_sk);
-#ifdef WN_DEC_NT_SKIP
-                W[UD + UR + r] = wn_buf_load4_nt(stream, voff, nxt + (UD + UR + r) * UB);
-#else
                 W[UD + UR + r] = wn_buf_load4(stream, voff, nxt + (UD + UR + r) * UB);
-#endif
             }
             if (l == 3) DSTAMP(16);
             WN_LDS_BARRIER();

@@ -37,12 +37,10 @@ static inline void wn_buf_store(wn_rsrc_t r, float v, int voff, int soff) {
     const unsigned long off = (unsigned long)(unsigned)voff + (unsigned long)(unsigned)soff;
     if (off + 4 <= r.bytes) *(float*)(r.base + off) = v;
 }
-static inline void wn_buf_store_nt(wn_rsrc_t r, float v, int voff, int soff) { wn_buf_store(r, v, voff, soff); }
 static inline float4 wn_buf_load4(wn_rsrc_t r, int voff, unsigned soff) {
     const unsigned long off = (unsigned long)(unsigned)voff + (unsigned long)soff;
     return off + 16 <= r.bytes ? *(const float4*)(r.base + off) : float4{0.f, 0.f, 0.f, 0.f};
 }
-static inline float4 wn_buf_load4_nt(wn_rsrc_t r, int voff, unsigned soff) { return wn_buf_load4(r, voff, soff); }
 // global -> LDS without registers: lane l of the wave writes 16 bytes at lds_wave_base + 16*l
 static inline void wn_buf_load_lds16(wn_rsrc_t r, char* lds_wave_base, int voff, unsigned soff) {
     const float4 v = wn_buf_load4(r, voff, soff);
@@ -109,10 +107,6 @@ static __device__ __forceinline__ float wn_buf_load(wn_rsrc_t r, int voff, int s
 static __device__ __forceinline__ void wn_buf_store(wn_rsrc_t r, float v, int voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voff, soff, 0);
 }
-// the same with the nt hint: the line is the first candidate for eviction (streamed-once data)
-static __device__ __forceinline__ float4 wn_buf_load4_nt(wn_rsrc_t r, int voff, unsigned soff) {
-    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, (int)soff, 2));
-}
 // global -> LDS without registers (buffer_load_dwordx4 ... lds): lane l of the wave writes 16 bytes at
 // lds_wave_base + 16*l; lds_wave_base must be wave-uniform.  Completion is counted by vmcnt.
 static __device__ __forceinline__ void wn_buf_load_lds16(wn_rsrc_t r, char* lds_wave_base, int voff, unsigned soff) {
@@ -120,13 +114,6 @@ static __device__ __forceinline__ void wn_buf_load_lds16(wn_rsrc_t r, char* lds_
 }
 // s_waitcnt vmcnt(n) only (n <= 15)
 #define WN_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | (n))
-#ifndef WN_NT_AUX
-#define WN_NT_AUX 2  // aux bit 1 = nt on gfx94x/gfx950
-#endif
-// streaming store (nt): the line is not kept in L2 -- for tensors whose next reader is a later kernel
-static __device__ __forceinline__ void wn_buf_store_nt(wn_rsrc_t r, float v, int voff, int soff) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voff, soff, WN_NT_AUX);
-}
 // 16-byte load: per-lane byte offset in a VGPR, wave-uniform byte offset in an SGPR (no 64-bit
 // per-lane address registers -- a register ring of weights needs none)
 static __device__ __forceinline__ float4 wn_buf_load4(wn_rsrc_t r, int voff, unsigned soff) {

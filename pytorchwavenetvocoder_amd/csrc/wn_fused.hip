@@ -24,15 +24,6 @@
 // The f32-input MFMA is an exact fp32 fma chain, so parity with the fp32 reference is kept.
 #include "wn_fused.h"
 
-// store flavour per output tensor (A/B on hardware: -DWN_NT_MASK=bits, 1 S/Gt/Z, 2 Xnext, 4 dP, 8 dX)
-#ifndef WN_NT_MASK
-#define WN_NT_MASK 0
-#endif
-#define WN_ST_SEL(bit, ...) do { if ((WN_NT_MASK) & (bit)) wn_buf_store_nt(__VA_ARGS__); else wn_buf_store(__VA_ARGS__); } while (0)
-#define WN_ST_SGZ(...) WN_ST_SEL(1, __VA_ARGS__)
-#define WN_ST_X(...) WN_ST_SEL(2, __VA_ARGS__)
-#define WN_ST_DP(...) WN_ST_SEL(4, __VA_ARGS__)
-#define WN_ST_DX(...) WN_ST_SEL(8, __VA_ARGS__)
 
 #include "wn_prof.h"
 
@@ -336,9 +327,9 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
                 const float zz = s * g;
                 z[q][r] = zz;
                 if (inb) {
-                    WN_ST_SGZ(Sr, s, vcur, row0 * T4);
-                    WN_ST_SGZ(Gtr, g, vcur, row0 * T4);
-                    WN_ST_SGZ(Zr, zz, vcur, row0 * T4);
+                    wn_buf_store(Sr, s, vcur, row0 * T4);
+                    wn_buf_store(Gtr, g, vcur, row0 * T4);
+                    wn_buf_store(Zr, zz, vcur, row0 * T4);
                 }
             }
         }
@@ -388,7 +379,7 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
                 WN_UNROLL
                 for (int q = 0; q < 2; ++q) {
                     WN_UNROLL
-                    for (int r = 0; r < 16; ++r) WN_ST_X(Xn, racc[q][r], vcur, (32 * q + mfma32_row(r, 0)) * T4);
+                    for (int r = 0; r < 16; ++r) wn_buf_store(Xn, racc[q][r], vcur, (32 * q + mfma32_row(r, 0)) * T4);
                 }
             }
         }
@@ -641,9 +632,9 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
                 const float zz = s * g;
                 z[q][r] = zz;
                 if (inb) {
-                    WN_ST_SGZ(Sr, s, vcur, row0 * T4);
-                    WN_ST_SGZ(Gtr, g, vcur, row0 * T4);
-                    WN_ST_SGZ(Zr, zz, vcur, row0 * T4);
+                    wn_buf_store(Sr, s, vcur, row0 * T4);
+                    wn_buf_store(Gtr, g, vcur, row0 * T4);
+                    wn_buf_store(Zr, zz, vcur, row0 * T4);
                 }
             }
         }
@@ -687,7 +678,7 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
                 WN_UNROLL
                 for (int q = 0; q < 2; ++q) {
                     WN_UNROLL
-                    for (int r = 0; r < 16; ++r) WN_ST_X(Xn, racc[q][r], vcur, (32 * q + mfma32_row(r, 0)) * T4);
+                    for (int r = 0; r < 16; ++r) wn_buf_store(Xn, racc[q][r], vcur, (32 * q + mfma32_row(r, 0)) * T4);
                 }
             }
         }
@@ -922,8 +913,8 @@ __global__ __launch_bounds__(WN_FT) void k_conv64(ConvArgs a) {
                     for (int r = 0; r < 16; ++r) {
                         const int so = (32 * q + mfma32_row(r, 0)) * T4;
                         const float s = e0[q][r], g = e1[q][r], dz = acc[q][r];
-                        WN_ST_DP(Or, dz * g * (s * (1.0f - s)), vcur, so);
-                        WN_ST_DP(Or, dz * s * (1.0f - g * g), vcur, so + 64 * T4);
+                        wn_buf_store(Or, dz * g * (s * (1.0f - s)), vcur, so);
+                        wn_buf_store(Or, dz * s * (1.0f - g * g), vcur, so + 64 * T4);
                     }
                 }
             } else {
@@ -934,7 +925,7 @@ __global__ __launch_bounds__(WN_FT) void k_conv64(ConvArgs a) {
                     for (int r = 0; r < 16; ++r) {
                         float v = acc[q][r];
                         if (a.resid != nullptr) v += e0[q][r];
-                        WN_ST_DX(Or, v, vcur, (32 * q + mfma32_row(r, 0)) * T4);
+                        wn_buf_store(Or, v, vcur, (32 * q + mfma32_row(r, 0)) * T4);
                     }
                 }
             }
@@ -1115,8 +1106,8 @@ __global__ __launch_bounds__(WN_FT) void k_conv64s(ConvArgs a) {
                     for (int r = 0; r < 16; ++r) {
                         const int so = (32 * q + mfma32_row(r, 0)) * T4;
                         const float s = e0[q][r], g = e1[q][r], dz = acc[q][r];
-                        WN_ST_DP(Or, dz * g * (s * (1.0f - s)), vcur, so);
-                        WN_ST_DP(Or, dz * s * (1.0f - g * g), vcur, so + 64 * T4);
+                        wn_buf_store(Or, dz * g * (s * (1.0f - s)), vcur, so);
+                        wn_buf_store(Or, dz * s * (1.0f - g * g), vcur, so + 64 * T4);
                     }
                 }
             } else {
@@ -1127,7 +1118,7 @@ __global__ __launch_bounds__(WN_FT) void k_conv64s(ConvArgs a) {
                     for (int r = 0; r < 16; ++r) {
                         float v = acc[q][r];
                         if (a.resid != nullptr) v += e0[q][r];
-                        WN_ST_DX(Or, v, vcur, (32 * q + mfma32_row(r, 0)) * T4);
+                        wn_buf_store(Or, v, vcur, (32 * q + mfma32_row(r, 0)) * T4);
                     }
                 }
             }

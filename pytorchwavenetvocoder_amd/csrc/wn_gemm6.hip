@@ -25,9 +25,6 @@
 #include "wn_prof.h"
 
 #define G6_T 256
-#ifndef WN_G6_EXP
-#define WN_G6_EXP 0  // tuning experiments only (tools/build_variant.sh)
-#endif
 
 __global__ void k_gemm6_pack(const float* src, long lda, int M, int K, int Mpad, unsigned short* Apk) {
     // one thread per (kb, m): 16 k values -> 3 x 16 bf16
@@ -114,13 +111,9 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g) {
         for (int q = 0; q < 4; ++q) {
             const float x0 = rb[2 * q], x1 = rb[2 * q + 1];
             h[q] = wn_pk_bf16(x0, x1);
-#if WN_G6_EXP == 1
-            md[q] = h[q]; lo[q] = h[q];
-#else
             const float r0 = x0 - wn_bits_f32(h[q] << 16), r1 = x1 - wn_bits_f32(h[q] & 0xffff0000u);
             md[q] = wn_pk_bf16(r0, r1);
             lo[q] = wn_pk_bf16(r0 - wn_bits_f32(md[q] << 16), r1 - wn_bits_f32(md[q] & 0xffff0000u));
-#endif
         }
         char* sb = sa + A_BYTES + bn * 32 + bkh * 16;
         wn_f4 v;
@@ -157,13 +150,8 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g) {
             // small terms first; the two column tiles alternate so that back-to-back MFMAs never
             // depend on each other (a dependent 32x32x16 issues ~25% slower)
             constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
-#if WN_G6_EXP == 2
-            WN_UNROLL
-            for (int t = 0; t < 1; ++t) {
-#else
             WN_UNROLL
             for (int t = 0; t < 6; ++t) {
-#endif
                 WN_UNROLL
                 for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(af[PA[t]], bf[PB[t]][j], acc[i][j]);
             }
@@ -278,11 +266,8 @@ int wn_gemm6_launch(const WnGemm6Args* gp, wn_stream_t st) {
 // alignment), split into the three bf16 pieces in registers, one 16 (8) byte LDS write per piece
 // into the fragment layout [piece][row][16 k].  The loads run two steps ahead of the MFMAs (two
 // register sets), LDS is double buffered.
-#ifndef WN_G6_DW_OCC
-#define WN_G6_DW_OCC 2
-#endif
 template <int TM, int TN>
-__global__ __launch_bounds__(G6_T, WN_G6_DW_OCC) void k_gemm6_dw(WnGemmArgs g) {
+__global__ __launch_bounds__(G6_T, 2) void k_gemm6_dw(WnGemmArgs g) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int AE = BM / 16, BE = BN / 16;            // fp32 elements per thread and step
     constexpr int A_BYTES = 3 * BM * 32, B_BYTES = 3 * BN * 32, ST_BYTES = A_BYTES + B_BYTES;
