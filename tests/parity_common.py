@@ -77,6 +77,29 @@ def check_module_training(g, lib, device):
     return model, opt
 
 
+def check_reference_training_loop(g, lib, device):
+    """The reference's own loop (train.py:527-540): model(x, h) -> CrossEntropyLoss on [:, rf:] -> backward ->
+    torch.optim.Adam(model.parameters()).step(), i.e. autograd + a stock optimizer on the flat-buffer views,
+    must land on the reference's weights after the golden number of steps."""
+    model = WaveNet(*g.cfg.as_tuple(), _library=lib)
+    model.load_state_dict(g.params)
+    model.to(device)
+    x, h, t = g.x.to(device), g.h.to(device), g.t.to(device)
+    opt = torch.optim.Adam(model.parameters(), lr=g.adam_lr, weight_decay=g.wd)
+    crit = torch.nn.CrossEntropyLoss()
+    Q = g.cfg.n_quantize
+    for s in range(g.adam_steps):
+        out = model(x, h)
+        loss = crit(out[:, g.rf:].contiguous().view(-1, Q), t[:, g.rf:].contiguous().view(-1))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        assert abs(float(loss) - float(g.z["loss_step%d" % s])) <= TOL_LOSS
+    for k, v in model.state_dict().items():
+        e = float((v.cpu() - g.after[k]).abs().max())
+        assert e <= TOL_ADAM_REL_LR * g.adam_lr, "%s: |dw| err %g (lr %g)" % (k, e, g.adam_lr)
+
+
 KINK_MARGIN = 1e-5  # required min |pre-ReLU| on loss positions (10x the observed fp32 forward error)
 
 

@@ -23,6 +23,11 @@ def test_module_training_vs_golden(name):
     PC.check_module_training(GoldenCase(name), emu_library(), "cpu")
 
 
+@pytest.mark.parametrize("name", ["tiny_k3_noup", "tiny_init"])
+def test_reference_training_loop_with_stock_adam(name):
+    PC.check_reference_training_loop(GoldenCase(name), emu_library(), "cpu")
+
+
 @pytest.mark.parametrize("name", ["r64_k2_up", "r64_k3_up"])
 def test_layered_path_vs_golden_r64(name):
     from pytorchwavenetvocoder_amd import _lib

@@ -23,6 +23,12 @@ def _lib():
     return lib
 
 
+@pytest.mark.parametrize("name", ["tiny_k3_noup", "tiny_init", "r64_k2_up"])
+def test_reference_training_loop_with_stock_adam(name):
+    """autograd + torch.optim.Adam on the flat-buffer parameter views == the reference's weights."""
+    PC.check_reference_training_loop(GoldenCase(name), _lib(), DEV)
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_engine_vs_golden(name):
     PC.check_golden_case(GoldenCase(name), _lib(), DEV)
