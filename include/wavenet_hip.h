@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define WN_ABI_VERSION 1
+#define WN_ABI_VERSION 2
 
 /* Same fields as the constructor WaveNet(n_quantize, n_aux, n_resch, n_skipch, dilation_depth,
  * dilation_repeat, kernel_size, upsampling_factor)  -- reference wavenet.py:172-173. */
@@ -46,6 +46,9 @@ typedef struct WnConfig {
     int32_t dilation_repeat;
     int32_t kernel_size;
     int32_t upsampling_factor; /* 0 = no upsampling layer (h arrives at sample rate) */
+    int32_t out_channels;      /* channels of conv_post_2; 0 = n_quantize (the reference's softmax head).  A mixture-of-
+                                * logistics head uses 3 * n_mixture (BASELINE configs[3]); the front end stays the
+                                * n_quantize-class one-hot causal conv */
 } WnConfig;
 
 /* Tensor kinds for wn_param_offset (reference state_dict key in the comment). */
@@ -151,6 +154,15 @@ int wn_op_causal_conv(const float* weight, const float* bias, const float* x /*(
 /* Generic C[z] = A.B contraction on the f32 matrix cores; see csrc/wn_gemm.h for the argument block. */
 struct WnGemmArgs;
 int wn_op_gemm(const struct WnGemmArgs* args, void* stream);
+
+/* Mixture-of-logistics output head (BASELINE configs[3]).  NOT part of the reference (its WaveNet only has the
+ * softmax head, wavenet.py:209-210,518-523): parity is therefore pinned to this repo's own CPU restatement of
+ * the discretised mixture of logistics (PixelCNN++, Salimans et al. 2017) in oracle/, not to the reference.
+ * out (B, out_channels = 3*n_mix, T) from wn_forward; y (B, T) fp32 target waveform in [-1, 1];
+ * loss = mean negative log-likelihood over t >= t_start; dout goes to wn_backward as `dlogits`. */
+int wn_mol_loss(const WnConfig* cfg, int B, int T, const float* out, const float* y, int t_start, float grad_scale,
+                float loss_scale, int num_classes, float log_scale_min, float* loss, float* dout, void* workspace,
+                size_t workspace_bytes, void* stream);
 
 /* ---- autoregressive decode (BASELINE config 5) -------------------------------------------------
  * Replaces WaveNet.fast_generate / batch_fast_generate / _generate_residual_forward

@@ -464,3 +464,47 @@ def fast_generate(cfg: OracleConfig, p, x, h, n_samples, mode="argmax", return_l
     """WaveNet.fast_generate, wavenet.py:309-395 (the B=1 case of the queue algorithm)."""
     r = batch_fast_generate(cfg, p, x, h, [n_samples], mode, return_logits)
     return (r[0][0], r[1][0]) if return_logits else r[0]
+
+
+# --------------------------------------------------------------------------
+# mixture-of-logistics output head (BASELINE configs[3])
+#
+# NOT in the reference (its WaveNet has only the softmax head, wavenet.py:209-210,518-523): there is
+# no reference code to restate and no reference output to pin this against -- PARITY UNPINNED BY THE
+# REFERENCE.  What follows is the discretised mixture of logistics of PixelCNN++ (Salimans et al.,
+# 2017, eq. 2-3 and its edge cases) as WaveNet vocoders use it for 16-bit audio, written from the
+# published formulas; it is the checker of csrc/wn_elem.hip::k_mol_nll and of the decode sampler.
+# --------------------------------------------------------------------------
+def mol_nll(out, y, num_classes=65536, log_scale_min=-7.0, start=0):
+    """out (B,T,3*nm): [logits | means | log-scales]; y (B,T) in [-1,1].  Mean negative
+    log-likelihood over positions t >= start."""
+    nm = out.size(-1) // 3
+    out = out[:, start:]
+    y = y[:, start:].unsqueeze(-1)
+    logit, mean = out[..., :nm], out[..., nm:2 * nm]
+    ls = torch.clamp(out[..., 2 * nm:3 * nm], min=log_scale_min)
+    half = 1.0 / (num_classes - 1)
+    inv = torch.exp(-ls)
+    c = y - mean
+    plus_in, min_in, mid_in = inv * (c + half), inv * (c - half), inv * c
+    cdf_delta = torch.sigmoid(plus_in) - torch.sigmoid(min_in)
+    log_cdf_plus = plus_in - F.softplus(plus_in)               # log P(x < first bin edge)
+    log_one_minus_cdf_min = -F.softplus(min_in)                # log P(x > last bin edge)
+    log_pdf_mid = mid_in - ls - 2.0 * F.softplus(mid_in) - float(np.log((num_classes - 1) / 2.0))
+    inner = torch.where(cdf_delta > 1e-5, torch.log(torch.clamp(cdf_delta, min=1e-12)), log_pdf_mid)
+    ll = torch.where(y < -0.999, log_cdf_plus, torch.where(y > 0.999, log_one_minus_cdf_min, inner))
+    lp = ll + F.log_softmax(logit, dim=-1)
+    return -torch.logsumexp(lp, dim=-1).mean()
+
+
+def mol_sample(out_row, u, log_scale_min=-7.0):
+    """One draw from the mixture of a single position: out_row (3*nm,), u (nm+1,) uniforms in (0,1):
+    component = argmax(logit - log(-log u_i)) (Gumbel max), x = mean + scale*(log u - log(1-u)), clipped."""
+    nm = out_row.numel() // 3
+    g = out_row[:nm] - torch.log(-torch.log(u[:nm]))
+    k = int(g.argmax())
+    mean = out_row[nm + k]
+    ls = torch.clamp(out_row[2 * nm + k], min=log_scale_min)
+    uu = u[nm]
+    x = mean + torch.exp(ls) * (torch.log(uu) - torch.log(1.0 - uu))
+    return float(torch.clamp(x, -1.0, 1.0))

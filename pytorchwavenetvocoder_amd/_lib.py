@@ -23,7 +23,7 @@ class WnConfig(ctypes.Structure):
     _fields_ = [("n_quantize", ctypes.c_int32), ("n_aux", ctypes.c_int32), ("n_resch", ctypes.c_int32),
                 ("n_skipch", ctypes.c_int32), ("dilation_depth", ctypes.c_int32),
                 ("dilation_repeat", ctypes.c_int32), ("kernel_size", ctypes.c_int32),
-                ("upsampling_factor", ctypes.c_int32)]
+                ("upsampling_factor", ctypes.c_int32), ("out_channels", ctypes.c_int32)]
 
 
 class WnGemmArgs(ctypes.Structure):
@@ -65,7 +65,7 @@ class WnGemmArgs(ctypes.Structure):
 
 FLAG_NO_FUSED = 1
 FLAG_EXACT_MFMA = 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/wavenet_hip.h declares
 EXPORTS = [
@@ -74,7 +74,7 @@ EXPORTS = [
     "wn_softmax_ce_loss", "wn_backward", "wn_adam_step", "wn_op_front", "wn_op_causal_conv", "wn_op_gemm", "wn_prof_enable", "wn_prof_report",
     "wn_decode_supported", "wn_decode_pack_floats", "wn_decode_state_floats", "wn_decode_pack", "wn_decode_aux",
     "wn_decode_steps", "wn_decode_stream_bytes",
-    "wn_decode_layered_state_floats", "wn_decode_layered_prepare", "wn_decode_layered_steps",
+    "wn_decode_layered_state_floats", "wn_decode_layered_prepare", "wn_decode_layered_steps", "wn_mol_loss",
 ]
 
 
@@ -126,6 +126,7 @@ class WnLibrary(object):
         L.wn_decode_pack.argtypes = [cfgp, vp, vp, vp]
         L.wn_decode_aux.argtypes = [cfgp, i, i, vp, vp, vp, vp]
         L.wn_decode_steps.argtypes = [cfgp, i, vp, vp, vp, i, i, vp, i64, vp, vp, i, i, vp, vp, vp, i, vp]
+        L.wn_mol_loss.argtypes = [cfgp, i, i, vp, vp, i, f, f, i, f, vp, vp, vp, sz, vp]
         L.wn_decode_layered_state_floats.argtypes = [cfgp, i]
         L.wn_decode_layered_state_floats.restype = i64
         L.wn_decode_layered_prepare.argtypes = [cfgp, i, i, vp, vp, vp, vp, i64, vp]

@@ -63,15 +63,17 @@ extern "C" const char* wn_last_error(void) { return g_err; }
 // ------------------------------------------------------------------------------------------
 struct Dims {
     int Q, A, R, S, L, K, U;
+    int Qo;  // output channels of the post net (Q for the softmax head)
 };
 
 static int check_cfg(const WnConfig* c, Dims* d) {
     if (!c) return fail(1, "cfg is NULL");
     if (c->n_quantize < 2 || c->n_aux < 1 || c->n_resch < 1 || c->n_skipch < 1 || c->dilation_depth < 1 ||
         c->dilation_depth > 24 || c->dilation_repeat < 1 || c->kernel_size < 1 || c->kernel_size > 8 ||
-        c->upsampling_factor < 0)
+        c->upsampling_factor < 0 || c->out_channels < 0)
         return fail(1, "invalid WnConfig");
     d->Q = c->n_quantize;
+    d->Qo = c->out_channels > 0 ? c->out_channels : c->n_quantize;
     d->A = c->n_aux;
     d->R = c->n_resch;
     d->S = c->n_skipch;
@@ -95,8 +97,8 @@ struct Lay {
 static Lay make_lay(const Dims& d) {
     Lay y;
     long o = 0;
-    y.post2_w = o; o += (long)d.Q * d.S;
-    y.post2_b = o; o += d.Q;
+    y.post2_w = o; o += (long)d.Qo * d.S;
+    y.post2_b = o; o += d.Qo;
     y.post1_w = o; o += (long)d.S * d.S;
     y.post1_b = o; o += d.S;
     y.skip0 = o;
@@ -176,8 +178,8 @@ extern "C" int wn_param_offset(const WnConfig* cfg, int kind, int layer, int64_t
         case WN_P_RES_B: off = lb + y.o_res_b; n = d.R; break;
         case WN_P_POST1_W: off = y.post1_w; n = (long)d.S * d.S; break;
         case WN_P_POST1_B: off = y.post1_b; n = d.S; break;
-        case WN_P_POST2_W: off = y.post2_w; n = (long)d.Q * d.S; break;
-        case WN_P_POST2_B: off = y.post2_b; n = d.Q; break;
+        case WN_P_POST2_W: off = y.post2_w; n = (long)d.Qo * d.S; break;
+        case WN_P_POST2_B: off = y.post2_b; n = d.Qo; break;
         default: return fail(2, "unknown tensor kind %d", kind);
     }
     if ((kind == WN_P_SKIP_W || kind == WN_P_SKIP_B) && (layer < 0 || layer >= d.L))
@@ -297,7 +299,7 @@ static int make_ws(const Dims& d, int B, int T, Ws* w) {
     CARVE(wskip_f, (long)d.L * d.R * d.S);
     CARVE(bskip, d.S);
     CARVE(w1_f, (long)d.S * d.S);
-    CARVE(w2_f, (long)d.S * d.Q);
+    CARVE(w2_f, (long)d.S * d.Qo);
     CARVE(wd_b, (long)d.L * d.K * 2 * d.R * d.R);
     CARVE(one, 64);
     CARVE(X, (long)d.L * BRT);
@@ -315,12 +317,12 @@ static int make_ws(const Dims& d, int B, int T, Ws* w) {
     CARVE(dG, (long)d.L * B * 2 * d.R * F);
     CARVE(dw_partial, (long)d.L * B * 2 * d.R * Ue);
     CARVE(dc, (long)d.L * 2 * d.R);
-    CARVE(tmpS, d.S > d.Q ? d.S : d.Q);
+    CARVE(tmpS, d.S > d.Qo ? d.S : d.Qo);
     // partial buffers: max over the dW GEMMs issued by wn_backward
     long pmax = 0, rmax = 0;
     {
         struct { int M, N, K; } gs[] = {
-            {d.Q, d.S, T}, {d.S, d.S, T}, {d.S, d.L * d.R, T}, {2 * d.R, d.K * d.R, T},
+            {d.Qo, d.S, T}, {d.S, d.S, T}, {d.S, d.L * d.R, T}, {2 * d.R, d.K * d.R, T},
             {d.R, d.R, T}, {2 * d.R, d.A, F}, {2 * d.R, d.A, T}, {d.R, d.K * d.Q, T}};
         for (unsigned i = 0; i < sizeof(gs) / sizeof(gs[0]); ++i) {
             for (int nl = 1; nl <= d.L; ++nl) {  // layer-batched launches: any bucket size
@@ -340,7 +342,7 @@ static int make_ws(const Dims& d, int B, int T, Ws* w) {
     w->front_partial_floats = wn_front_dw_supported(d.R, d.K, d.Q) ? wn_front_dw_partial_floats(B, T, d.R, d.K, d.Q) : 0;
     CARVE(front_partial, w->front_partial_floats);
     {   // split-bf16 weights of the forward-type contractions (wn_gemm6): one buffer, re-packed before each use
-        const int mk[][2] = {{d.S, d.L * d.R}, {d.S, d.S}, {d.Q, d.S}, {d.S, d.Q}, {2 * d.R, d.K * d.R},
+        const int mk[][2] = {{d.S, d.L * d.R}, {d.S, d.S}, {d.Qo, d.S}, {d.S, d.Qo}, {2 * d.R, d.K * d.R},
                              {d.R, d.R}, {d.R, d.S}, {d.R, d.K * 2 * d.R}};
         long e = 0;
         for (unsigned i = 0; i < sizeof(mk) / sizeof(mk[0]); ++i) {
@@ -461,7 +463,7 @@ static int pack_weights(const Ctx& c, const float* params) {
     cp.s0 = 0; cp.s1 = 1; cp.s2 = d.S; cp.sl = 0;
     cp.d0 = 0; cp.d1 = d.S; cp.d2 = 1; cp.dl = 0;
     WN_TRY(wn_copy4(ws + w.w1_f, params + y.post1_w, &cp, c.st));
-    cp.n1 = d.S; cp.n2 = d.Q; cp.s1 = 1; cp.s2 = d.S; cp.d1 = d.Q; cp.d2 = 1;
+    cp.n1 = d.S; cp.n2 = d.Qo; cp.s1 = 1; cp.s2 = d.S; cp.d1 = d.Qo; cp.d2 = 1;
     WN_TRY(wn_copy4(ws + w.w2_f, params + y.post2_w, &cp, c.st));
     // cvec / rowsum_aux / bskip / one
     WnCvecArgs ca;
@@ -572,10 +574,10 @@ extern "C" int wn_forward(const WnConfig* cfg, int B, int T, const float* params
     }
     {   // conv_post_2  (wavenet.py:522)
         WnGemmArgs g = wn_gemm_default();
-        g.M = d.Q; g.N = T; g.K = d.S;
-        g.A = ws + w.w2_f; g.lda = d.Q;
+        g.M = d.Qo; g.N = T; g.K = d.S;
+        g.A = ws + w.w2_f; g.lda = d.Qo;
         g.B = ws + w.O2; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = T;
-        g.C = logits; g.ldc = T; g.c_zstride = (long)d.Q * T;
+        g.C = logits; g.ldc = T; g.c_zstride = (long)d.Qo * T;
         g.bias = params + y.post2_b; g.nbatch = B; g.tag = "fwd_post2";
         WN_TRY(fw_gemm(c, g));
     }
@@ -595,9 +597,28 @@ extern "C" int wn_softmax_ce_loss(const WnConfig* cfg, int B, int T, const float
     if (t_start < 0 || t_start >= T) return fail(1, "t_start=%d outside [0,%d)", t_start, T);
     int np = 0;
     const float gs = grad_scale / ((float)B * (float)(T - t_start));
-    WN_TRY(wn_softmax_ce(logits, target, dlogits, c.ws + c.w.loss_partial, &np, B, T, c.d.Q, t_start, gs, c.st));
+    WN_TRY(wn_softmax_ce(logits, target, dlogits, c.ws + c.w.loss_partial, &np, B, T, c.d.Qo, t_start, gs, c.st));
     WN_TRY(wn_sum_partials(c.ws + c.w.loss_partial, np, loss_scale / ((float)B * (float)(T - t_start)), loss, c.st));
     return rt_check("wn_softmax_ce_loss");
+}
+
+// Mixture-of-logistics head (BASELINE configs[3]; absent from the reference): mean negative log-likelihood of
+// the target waveform y (B,T) in [-1,1] under the 3*n_mix output channels, over positions t >= t_start,
+// and its gradient in the layout wn_backward takes.
+extern "C" int wn_mol_loss(const WnConfig* cfg, int B, int T, const float* out, const float* y, int t_start, float grad_scale,
+                           float loss_scale, int num_classes, float log_scale_min, float* loss, float* dout, void* wsp,
+                           size_t ws_bytes, void* stream) {
+    api_enter();
+    Ctx c;
+    WN_TRY(make_ctx(&c, cfg, B, T, wsp, ws_bytes, 0, stream));
+    if (!out || !y || !loss) return fail(1, "NULL argument");
+    if (c.d.Qo % 3 != 0) return fail(1, "out_channels=%d is not 3 * n_mixture", c.d.Qo);
+    if (t_start < 0 || t_start >= T) return fail(1, "t_start=%d outside [0,%d)", t_start, T);
+    int np = 0;
+    const float gs = grad_scale / ((float)B * (float)(T - t_start));
+    WN_TRY(wn_mol_nll(out, y, dout, c.ws + c.w.loss_partial, &np, B, T, c.d.Qo / 3, t_start, gs, num_classes, log_scale_min, c.st));
+    WN_TRY(wn_sum_partials(c.ws + c.w.loss_partial, np, loss_scale / ((float)B * (float)(T - t_start)), loss, c.st));
+    return rt_check("wn_mol_loss");
 }
 
 // ------------------------------------------------------------------------------------------
@@ -677,9 +698,9 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
     // ---- post-net backward (wavenet.py:518-523 reversed) ----
     {   // dO2 = W2^T dlogits, masked by relu'(O2)
         WnGemmArgs g = wn_gemm_default();
-        g.M = d.S; g.N = T; g.K = d.Q;
+        g.M = d.S; g.N = T; g.K = d.Qo;
         g.A = params + y.post2_w; g.lda = d.S;
-        g.B = dlogits; g.ldb = T; g.b_zstride = (long)d.Q * T; g.b_clen = T;
+        g.B = dlogits; g.ldb = T; g.b_zstride = (long)d.Qo * T; g.b_clen = T;
         g.C = ws + w.dO2; g.ldc = T; g.c_zstride = (long)d.S * T;
         g.E = ws + w.O2; g.lde = T; g.e_zstride = (long)d.S * T;
         g.nbatch = B; g.tag = "bwd_post2_dx";
@@ -697,8 +718,8 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
     }
     {   // d conv_post_2.{weight,bias}
         WnGemmArgs g = wn_gemm_default();
-        g.M = d.Q; g.N = d.S; g.K = T;
-        g.A = dlogits; g.lda = T; g.a_zstride = (long)d.Q * T;
+        g.M = d.Qo; g.N = d.S; g.K = T;
+        g.A = dlogits; g.lda = T; g.a_zstride = (long)d.Qo * T;
         g.B = ws + w.O2; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = T; g.tag = "dw_post2";
         WN_TRY(dw_gemm(c, g, dw_out_plain(grads + y.post2_w, d.S, grads + y.post2_b)));
     }
@@ -950,6 +971,7 @@ extern "C" int wn_op_causal_conv(const float* weight, const float* bias, const f
 static int decode_plan(const WnConfig* cfg, Dims* d, WnDecodePlan* pl) {
     WN_TRY(check_cfg(cfg, d));
     wn_decode_make_plan(d->Q, d->A, d->R, d->S, d->L, d->K, cfg->dilation_depth, pl);
+    if (d->Qo != d->Q) pl->ok = 0;  // other output heads generate through the layer-wise path
     if (!pl->ok)
         return fail(3, "decode kernel: configuration not covered (needs n_resch<=64, n_skipch<=256, n_quantize<=256, "
                        "kernel_size<=3); use full-window forwards");
@@ -1118,7 +1140,7 @@ static int dl_layout(const WnConfig* cfg, const Dims& d, int nb, DlLay* y) {
     DCARVE(skpart, (long)d.L * d.S * nb);
     DCARVE(O1, (long)d.S * nb);
     DCARVE(O2, (long)d.S * nb);
-    DCARVE(logits, (long)d.Q * nb);
+    DCARVE(logits, (long)d.Qo * nb);
 #undef DCARVE
     y->total = o;
     return 0;
@@ -1252,14 +1274,14 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
         }
         {
             WnDlMmArgs g;
-            g.M = d.Q; g.K = d.S; g.nb = nb;
-            g.A = ws + w.w2_f; g.lda = d.Q; g.a_zstride = 0;
+            g.M = d.Qo; g.K = d.S; g.nb = nb;
+            g.A = ws + w.w2_f; g.lda = d.Qo; g.a_zstride = 0;
             g.B = ws + y.O2; g.ldb = nb; g.b_zstride = 0;
             g.C = ws + y.logits; g.ldc = nb; g.c_zstride = 0;
             g.bias = params + lay.post2_b; g.D = nullptr; g.ldd = 0; g.relu = 0; g.nz = 1; g.tag = "dl_post2";
             WN_TRY(wn_dl_mm(&g, c.st));
         }
-        WN_TRY(wn_dl_select(ws + y.logits, d.Q, nb, samples, Ttot, t_forced, t_end, p, uniforms, logits_out, mode, c.st));
+        WN_TRY(wn_dl_select(ws + y.logits, d.Qo, nb, samples, Ttot, t_forced, t_end, p, uniforms, logits_out, mode, c.st));
         WN_TRY(wn_dl_push(&a, c.st));
     }
     return rt_check("wn_decode_layered_steps");

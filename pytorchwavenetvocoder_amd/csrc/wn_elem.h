@@ -140,3 +140,12 @@ typedef struct WnDlMmArgs {
 int wn_dl_mm(const WnDlMmArgs* a, wn_stream_t st);
 // out[m][u] = relu?( sum_z part[z][m][u] + bias[m] )
 int wn_dl_sum(const float* part, int nz, long zstride, int M, int nb, const float* bias, int relu, float* out, wn_stream_t st);
+
+// ---- mixture-of-logistics output head (BASELINE configs[3]; NOT in the reference: the formulas are the
+// discretised mixture of logistics of PixelCNN++, Salimans et al. 2017, as used by WaveNet vocoders) ----
+// out (B, 3*nm, T): rows [0,nm) mixture logits, [nm,2nm) means, [2nm,3nm) log-scales (clamped at log_scale_min);
+// y (B, T) target waveform in [-1, 1]; num_classes = quantisation levels of the waveform (65536 for 16 bit).
+// loss_partial gets one partial sum of the negative log-likelihood per block over t >= t_start; dout (nullable)
+// gets d(sum nll * grad_scale)/d(out), zero for t < t_start.
+int wn_mol_nll(const float* out, const float* y, float* dout, float* loss_partial, int* n_partial, int B, int T, int nm,
+               int t_start, float grad_scale, int num_classes, float log_scale_min, wn_stream_t st);

@@ -773,3 +773,109 @@ int wn_dl_sum(const float* part, int nz, long zstride, int M, int nb, const floa
     WN_LAUNCH(k_dl_sum, dim3((unsigned)((n + WN_TPB - 1) / WN_TPB)), dim3(WN_TPB), 0, st, part, nz, zstride, M, nb, bias, relu, out);
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// mixture-of-logistics negative log-likelihood, forward + gradient (see wn_elem.h)
+// ---------------------------------------------------------------------------------------------
+static __device__ __forceinline__ float mol_softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+static __device__ __forceinline__ float mol_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// log-likelihood of one mixture component and its derivatives w.r.t. mean and (clamped) log-scale
+static __device__ __forceinline__ float mol_component(float y, float mean, float ls, float half_bin, float log_half_classes,
+                                                      float* dll_dm, float* dll_dls) {
+    const float inv = expf(-ls), c = y - mean;
+    const float plus_in = inv * (c + half_bin), min_in = inv * (c - half_bin), mid_in = inv * c;
+    if (y < -0.999f) {  // left edge: everything below the first bin
+        const float sg = mol_sigmoid(-plus_in);
+        *dll_dm = -inv * sg;
+        *dll_dls = -plus_in * sg;
+        return plus_in - mol_softplus(plus_in);
+    }
+    if (y > 0.999f) {  // right edge
+        const float sg = mol_sigmoid(min_in);
+        *dll_dm = inv * sg;
+        *dll_dls = min_in * sg;
+        return -mol_softplus(min_in);
+    }
+    const float cp = mol_sigmoid(plus_in), cm = mol_sigmoid(min_in);
+    const float delta = cp - cm;
+    if (delta > 1e-5f) {
+        const float dp = cp * (1.0f - cp), dm = cm * (1.0f - cm);
+        *dll_dm = -inv * (dp - dm) / delta;
+        *dll_dls = -(plus_in * dp - min_in * dm) / delta;
+        return logf(fmaxf(delta, 1e-12f));
+    }
+    // extremely narrow component: density at the bin centre times the bin width
+    const float sm = mol_sigmoid(mid_in);
+    *dll_dm = -inv * (1.0f - 2.0f * sm);
+    *dll_dls = -mid_in * (1.0f - 2.0f * sm) - 1.0f;
+    return mid_in - ls - 2.0f * mol_softplus(mid_in) - log_half_classes;
+}
+
+__global__ __launch_bounds__(WN_TPB) void k_mol_nll(const float* __restrict__ out, const float* __restrict__ yv,
+                                                    float* __restrict__ dout, float* __restrict__ loss_partial, int T, int nm,
+                                                    int t_start, float grad_scale, float half_bin, float log_half_classes,
+                                                    float log_scale_min) {
+    __shared__ float red[4];
+    const int t = blockIdx.x * WN_TPB + threadIdx.x;
+    const int b = blockIdx.y;
+    float my = 0.0f;
+    const bool live = (t < T) && (t >= t_start);
+    const float* o = out + (long)b * 3 * nm * T + t;
+    float* d = dout ? dout + (long)b * 3 * nm * T + t : nullptr;
+    if (live) {
+        const float y = yv[(long)b * T + t];
+        // log-softmax of the mixture logits
+        float m1 = -3.0e38f;
+        for (int i = 0; i < nm; ++i) m1 = fmaxf(m1, o[(long)i * T]);
+        float s1 = 0.0f;
+        for (int i = 0; i < nm; ++i) s1 += expf(o[(long)i * T] - m1);
+        const float lse_p = m1 + logf(s1);
+        // log-sum-exp over components of (component log-likelihood + log prior)
+        float m2 = -3.0e38f;
+        for (int i = 0; i < nm; ++i) {
+            float a, c;
+            const float ls = fmaxf(o[(long)(2 * nm + i) * T], log_scale_min);
+            const float lp = mol_component(y, o[(long)(nm + i) * T], ls, half_bin, log_half_classes, &a, &c) + o[(long)i * T] - lse_p;
+            m2 = fmaxf(m2, lp);
+        }
+        float s2 = 0.0f;
+        for (int i = 0; i < nm; ++i) {
+            float a, c;
+            const float ls = fmaxf(o[(long)(2 * nm + i) * T], log_scale_min);
+            const float lp = mol_component(y, o[(long)(nm + i) * T], ls, half_bin, log_half_classes, &a, &c) + o[(long)i * T] - lse_p;
+            s2 += expf(lp - m2);
+        }
+        const float lse = m2 + logf(s2);
+        my = -lse;
+        if (d) {
+            for (int i = 0; i < nm; ++i) {
+                float dm, dls;
+                const float raw = o[(long)(2 * nm + i) * T];
+                const float ls = fmaxf(raw, log_scale_min);
+                const float logit = o[(long)i * T];
+                const float lp = mol_component(y, o[(long)(nm + i) * T], ls, half_bin, log_half_classes, &dm, &dls) + logit - lse_p;
+                const float r = expf(lp - lse);           // posterior responsibility
+                const float pi = expf(logit - lse_p);     // prior
+                d[(long)i * T] = (pi - r) * grad_scale;
+                d[(long)(nm + i) * T] = -r * dm * grad_scale;
+                d[(long)(2 * nm + i) * T] = raw >= log_scale_min ? -r * dls * grad_scale : 0.0f;
+            }
+        }
+    } else if (t < T && d) {
+        for (int i = 0; i < 3 * nm; ++i) d[(long)i * T] = 0.0f;
+    }
+    const float tot = block_reduce_sum(my, red);
+    if (threadIdx.x == 0) loss_partial[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+}
+
+int wn_mol_nll(const float* out, const float* y, float* dout, float* loss_partial, int* n_partial, int B, int T, int nm,
+               int t_start, float grad_scale, int num_classes, float log_scale_min, wn_stream_t st) {
+    WN_PROF("mol_nll", 0.0, 0.0, st);
+    if (nm < 1 || num_classes < 2) return 1;
+    dim3 grid((T + WN_TPB - 1) / WN_TPB, B);
+    if (n_partial) *n_partial = (int)(grid.x * grid.y);
+    WN_LAUNCH(k_mol_nll, grid, dim3(WN_TPB), 0, st, out, y, dout, loss_partial, T, nm, t_start, grad_scale,
+              1.0f / (float)(num_classes - 1), logf((float)(num_classes - 1) * 0.5f), log_scale_min);
+    return 0;
+}

@@ -29,10 +29,11 @@ class WaveNetEngine(object):
     """
 
     def __init__(self, n_quantize=256, n_aux=28, n_resch=512, n_skipch=256, dilation_depth=10,
-                 dilation_repeat=3, kernel_size=2, upsampling_factor=0, device="cpu", library=None):
+                 dilation_repeat=3, kernel_size=2, upsampling_factor=0, device="cpu", library=None, out_channels=0):
         self.lib = library if library is not None else _lib.load_library()
         self.cfg = _lib.WnConfig(n_quantize, n_aux, n_resch, n_skipch, dilation_depth, dilation_repeat,
-                                 kernel_size, upsampling_factor)
+                                 kernel_size, upsampling_factor, out_channels)
+        self.out_channels = out_channels if out_channels > 0 else n_quantize
         self.device = torch.device(device)
         n = self.lib.wn_param_count(ctypes.byref(self.cfg))
         if n <= 0:
@@ -124,7 +125,7 @@ class WaveNetEngine(object):
         x = x.contiguous()
         h = h.contiguous().float()
         ws = self.workspace(B, T)
-        logits = torch.empty((B, self.cfg.n_quantize, T), dtype=torch.float32, device=self.device)
+        logits = torch.empty((B, self.out_channels, T), dtype=torch.float32, device=self.device)
         rc = self.lib.wn_forward(ctypes.byref(self.cfg), B, T, _ptr(self.flat_params), _ptr(x), _ptr(h), _ptr(logits),
                                  _ptr(ws), ws.numel() * 4, self.flags, _stream_handle(self.device))
         self.lib.check(rc, "wn_forward")
@@ -148,6 +149,26 @@ class WaveNetEngine(object):
         self.lib.check(rc, "wn_softmax_ce_loss")
         return loss, dlogits
 
+    def mol_loss(self, out, y, t_start=None, grad_scale=1.0, loss_scale=1.0, want_grad=True, num_classes=65536,
+                 log_scale_min=-7.0):
+        """Mixture-of-logistics head: mean NLL of the waveform ``y`` (B,T) in [-1,1] under ``out`` (B, 3*n_mix, T)
+        over positions >= t_start, and d(loss)/d(out) for ``backward``.  Not in the reference (see include/)."""
+        self._check_device(out, y)
+        B, C, T = out.shape
+        if C != self.out_channels or C % 3 != 0:
+            raise ValueError("out must be (B, 3*n_mix = %d, T)" % self.out_channels)
+        if t_start is None:
+            t_start = self.receptive_field
+        y = y.contiguous().float()
+        ws = self.workspace(B, T)
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        dout = torch.empty_like(out) if want_grad else None
+        rc = self.lib.wn_mol_loss(ctypes.byref(self.cfg), B, T, _ptr(out), _ptr(y), int(t_start), float(grad_scale),
+                                  float(loss_scale), int(num_classes), float(log_scale_min), _ptr(loss), _ptr(dout),
+                                  _ptr(ws), ws.numel() * 4, _stream_handle(self.device))
+        self.lib.check(rc, "wn_mol_loss")
+        return loss, dout
+
     def backward(self, dlogits, events=None, layers_per_bucket=0):
         """Backward of the last ``forward`` call; fills ``self.grads()`` completely."""
         if self._last_shape is None:
@@ -155,7 +176,7 @@ class WaveNetEngine(object):
         B, T = self._last_shape
         x, h = self._last_inputs
         self._check_device(dlogits)
-        if tuple(dlogits.shape) != (B, self.cfg.n_quantize, T) or not dlogits.is_contiguous():
+        if tuple(dlogits.shape) != (B, self.out_channels, T) or not dlogits.is_contiguous():
             raise ValueError("dlogits must be a contiguous (B,Q,T) tensor")
         g = self.grads()
         ws = self.workspace(B, T)
@@ -239,7 +260,7 @@ class WaveNetEngine(object):
         t_forced = torch.full((B,), Tctx, dtype=torch.int32, device=dev)
         t_end = torch.tensor([Tctx + int(n) for n in n_samples_list], dtype=torch.int32, device=dev)
         uniforms = torch.rand((B, Ttot), dtype=torch.float32, device=dev) if mode == "sampling" else None
-        logits = torch.zeros((B, Ttot, self.cfg.n_quantize), dtype=torch.float32, device=dev) if return_logits else None
+        logits = torch.zeros((B, Ttot, self.out_channels), dtype=torch.float32, device=dev) if return_logits else None
         p = 0
         while p < Ttot - 1:
             p1 = min(p + chunk, Ttot - 1)
