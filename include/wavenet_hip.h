@@ -207,7 +207,9 @@ int wn_decode_layered_prepare(const WnConfig* cfg, int B, int F, const float* pa
 int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* params, const float* G, int F, int n_pad,
                             int64_t* samples, int64_t Ttot, const int32_t* t_forced, const int32_t* t_end, int p0, int p1,
                             float* state, int64_t state_floats, const float* uniforms, float* logits_out, int mode,
-                            void* stream);
+                            float* wave_out, void* stream);
+/* mode 2 (mixture-of-logistics head, out_channels = 3*n_mix): uniforms is (B, Ttot, n_mix+1); the drawn value is
+ * written to wave_out (B, Ttot) (nullable) and, mu-law encoded with n_quantize levels, to samples. */
 
 /* ---- diagnostics: opt-in per-launch timing with HIP events (used by bench.py's roofline block) ----
  * wn_prof_enable(1) clears and starts recording {kernel tag, algorithmic flops/bytes, start/stop

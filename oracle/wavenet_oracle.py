@@ -58,7 +58,9 @@ class OracleConfig(object):
     """Same constructor arguments as WaveNet.__init__ (wavenet.py:172-173)."""
 
     def __init__(self, n_quantize=256, n_aux=28, n_resch=512, n_skipch=256,
-                 dilation_depth=10, dilation_repeat=3, kernel_size=2, upsampling_factor=0):
+                 dilation_depth=10, dilation_repeat=3, kernel_size=2, upsampling_factor=0, out_channels=0):
+        # out_channels: NOT a reference argument; 3*n_mixture for the mixture-of-logistics head (0 = n_quantize)
+        self.out_channels = out_channels if out_channels > 0 else n_quantize
         self.n_quantize = n_quantize
         self.n_aux = n_aux
         self.n_resch = n_resch
@@ -112,8 +114,8 @@ def param_shapes(cfg: OracleConfig) -> "OrderedDict[str, Tuple[int, ...]]":
         d["res_1x1.%d.bias" % l] = (R,)
     d["conv_post_1.weight"] = (S, S, 1)
     d["conv_post_1.bias"] = (S,)
-    d["conv_post_2.weight"] = (Q, S, 1)
-    d["conv_post_2.bias"] = (Q,)
+    d["conv_post_2.weight"] = (cfg.out_channels, S, 1)
+    d["conv_post_2.bias"] = (cfg.out_channels,)
     return d
 
 

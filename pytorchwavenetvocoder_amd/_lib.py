@@ -130,7 +130,7 @@ class WnLibrary(object):
         L.wn_decode_layered_state_floats.argtypes = [cfgp, i]
         L.wn_decode_layered_state_floats.restype = i64
         L.wn_decode_layered_prepare.argtypes = [cfgp, i, i, vp, vp, vp, vp, i64, vp]
-        L.wn_decode_layered_steps.argtypes = [cfgp, i, vp, vp, i, i, vp, i64, vp, vp, i, i, vp, i64, vp, vp, i, vp]
+        L.wn_decode_layered_steps.argtypes = [cfgp, i, vp, vp, i, i, vp, i64, vp, vp, i, i, vp, i64, vp, vp, i, vp, vp]
         if L.wn_abi_version() != ABI_VERSION:
             raise WnError("ABI mismatch: library %d, binding %d" % (L.wn_abi_version(), ABI_VERSION))
 

@@ -1197,15 +1197,16 @@ extern "C" int wn_decode_layered_prepare(const WnConfig* cfg, int B, int F, cons
 extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* params, const float* G, int F, int n_pad,
                                        int64_t* samples, int64_t Ttot, const int32_t* t_forced, const int32_t* t_end, int p0,
                                        int p1, float* state, int64_t state_floats, const float* uniforms, float* logits_out,
-                                       int mode, void* stream) {
+                                       int mode, float* wave_out, void* stream) {
     api_enter();
     Dims d;
     WN_TRY(check_cfg(cfg, &d));
     if (!params || !G || !samples || !t_forced || !t_end || !state) return fail(1, "NULL argument");
     if (B <= 0 || F <= 0 || n_pad < 0 || p0 < 0 || p1 < p0 || Ttot <= 0 || p1 > Ttot - 1)
         return fail(1, "bad decode range: B=%d F=%d n_pad=%d steps [%d,%d) Ttot=%ld", B, F, n_pad, p0, p1, (long)Ttot);
-    if (mode != 0 && mode != 1) return fail(1, "mode should be 0 (argmax) or 1 (sampling)");
-    if (mode == 1 && !uniforms) return fail(1, "sampling mode needs the uniform draws");
+    if (mode != 0 && mode != 1 && mode != 2) return fail(1, "mode should be 0 (argmax), 1 (sampling) or 2 (mixture of logistics)");
+    if (mode != 0 && !uniforms) return fail(1, "sampling modes need the uniform draws");
+    if (mode == 2 && (d.Qo % 3 != 0 || d.Qo == d.Q)) return fail(1, "mode 2 needs out_channels = 3 * n_mixture");
     DlLay y;
     WN_TRY(dl_layout(cfg, d, B, &y));
     if (state_floats < y.total) return fail(1, "decode state too small: %ld < %ld floats", (long)state_floats, y.total);
@@ -1281,7 +1282,11 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
             g.bias = params + lay.post2_b; g.D = nullptr; g.ldd = 0; g.relu = 0; g.nz = 1; g.tag = "dl_post2";
             WN_TRY(wn_dl_mm(&g, c.st));
         }
-        WN_TRY(wn_dl_select(ws + y.logits, d.Qo, nb, samples, Ttot, t_forced, t_end, p, uniforms, logits_out, mode, c.st));
+        if (mode == 2)
+            WN_TRY(wn_dl_select_mol(ws + y.logits, d.Qo / 3, nb, d.Q, samples, wave_out, Ttot, t_forced, t_end, p, uniforms,
+                                    logits_out, -7.0f, c.st));
+        else
+            WN_TRY(wn_dl_select(ws + y.logits, d.Qo, nb, samples, Ttot, t_forced, t_end, p, uniforms, logits_out, mode, c.st));
         WN_TRY(wn_dl_push(&a, c.st));
     }
     return rt_check("wn_decode_layered_steps");

@@ -149,3 +149,9 @@ int wn_dl_sum(const float* part, int nz, long zstride, int M, int nb, const floa
 // gets d(sum nll * grad_scale)/d(out), zero for t < t_start.
 int wn_mol_nll(const float* out, const float* y, float* dout, float* loss_partial, int* n_partial, int B, int T, int nm,
                int t_start, float grad_scale, int num_classes, float log_scale_min, wn_stream_t st);
+// Decode-side draw of the MoL head for every utterance from out [3*nm][nb]: component by Gumbel max with the
+// uniforms u[0..nm), value = mean + scale*(log u_nm - log(1-u_nm)) clipped to [-1,1]; the value is mu-law
+// encoded (levels Q) into the token fed back to the one-hot front end; wave_out (nb, Ttot) keeps the float.
+int wn_dl_select_mol(const float* out, int nm, int nb, int Q, int64_t* samples, float* wave_out, long Ttot, const int* t_forced,
+                     const int* t_end, int p, const float* uniforms /* (nb, Ttot, nm+1) */, float* out_copy, float log_scale_min,
+                     wn_stream_t st);

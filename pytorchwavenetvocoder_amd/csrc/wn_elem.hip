@@ -879,3 +879,40 @@ int wn_mol_nll(const float* out, const float* y, float* dout, float* loss_partia
               1.0f / (float)(num_classes - 1), logf((float)(num_classes - 1) * 0.5f), log_scale_min);
     return 0;
 }
+
+__global__ __launch_bounds__(WN_TPB) void k_dl_select_mol(const float* __restrict__ out, int nm, int nb, int Q, int64_t* samples,
+                                                          float* wave_out, long Ttot, const int* t_forced, const int* t_end,
+                                                          int p, const float* __restrict__ uniforms, float* out_copy,
+                                                          float log_scale_min) {
+    const int u = blockIdx.x * WN_TPB + threadIdx.x;
+    if (u >= nb) return;
+    if (out_copy) {
+        for (int q = 0; q < 3 * nm; ++q) out_copy[((long)u * Ttot + p) * (3 * nm) + q] = out[(long)q * nb + u];
+    }
+    if (!(p + 1 >= t_forced[u] && p + 1 < t_end[u])) return;
+    const float* un = uniforms + ((long)u * Ttot + p + 1) * (nm + 1);
+    float best = -3.0e38f;
+    int k = 0;
+    for (int i = 0; i < nm; ++i) {
+        const float g = out[(long)i * nb + u] - logf(-logf(un[i]));
+        if (g > best) { best = g; k = i; }
+    }
+    const float mean = out[(long)(nm + k) * nb + u];
+    const float ls = fmaxf(out[(long)(2 * nm + k) * nb + u], log_scale_min);
+    const float uu = un[nm];
+    float x = mean + expf(ls) * (logf(uu) - logf(1.0f - uu));
+    x = fminf(fmaxf(x, -1.0f), 1.0f);
+    if (wave_out) wave_out[(long)u * Ttot + p + 1] = x;
+    // mu-law encode (reference wavenet.py:17-30): sign(x) ln(1+mu|x|)/ln(1+mu) -> floor((fx+1)/2*mu + 0.5)
+    const float mu = (float)(Q - 1);
+    const float fx = copysignf(logf(1.0f + mu * fabsf(x)) / logf(1.0f + mu), x);
+    samples[(long)u * Ttot + p + 1] = (int64_t)floorf((fx + 1.0f) * 0.5f * mu + 0.5f);
+}
+
+int wn_dl_select_mol(const float* out, int nm, int nb, int Q, int64_t* samples, float* wave_out, long Ttot, const int* t_forced,
+                     const int* t_end, int p, const float* uniforms, float* out_copy, float log_scale_min, wn_stream_t st) {
+    WN_PROF("dl_select_mol", 0.0, 0.0, st);
+    WN_LAUNCH(k_dl_select_mol, dim3((unsigned)((nb + WN_TPB - 1) / WN_TPB)), dim3(WN_TPB), 0, st, out, nm, nb, Q, samples, wave_out,
+              Ttot, t_forced, t_end, p, uniforms, out_copy, log_scale_min);
+    return 0;
+}

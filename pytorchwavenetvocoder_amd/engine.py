@@ -219,8 +219,9 @@ class WaveNetEngine(object):
         self._check_device(x, h)
         if x.dtype != torch.int64 or x.dim() != 2 or h.dim() != 3:
             raise ValueError("x must be a LongTensor (B, T) and h a FloatTensor (B, n_aux, F)")
-        if mode not in ("argmax", "sampling"):
-            raise ValueError("mode should be sampling or argmax")
+        if mode not in ("argmax", "sampling", "mol"):
+            raise ValueError("mode should be sampling, argmax or mol")
+        n_mix = self.out_channels // 3 if mode == "mol" else 0
         cfg = ctypes.byref(self.cfg)
         B, T0 = x.shape
         if len(n_samples_list) != B or h.size(0) != B or h.size(1) != self.cfg.n_aux:
@@ -236,6 +237,8 @@ class WaveNetEngine(object):
         Ttot = Tctx + n_max
         if layered is None:
             layered = not self.decode_supported()
+        if mode == "mol" and not layered:
+            raise ValueError("the mixture-of-logistics head generates through the layer-wise path")
         st = _stream_handle(self.device)
         dev = self.device
         h = h.contiguous().float()
@@ -259,7 +262,12 @@ class WaveNetEngine(object):
         samples[:, n_pad:Tctx] = x
         t_forced = torch.full((B,), Tctx, dtype=torch.int32, device=dev)
         t_end = torch.tensor([Tctx + int(n) for n in n_samples_list], dtype=torch.int32, device=dev)
-        uniforms = torch.rand((B, Ttot), dtype=torch.float32, device=dev) if mode == "sampling" else None
+        if mode == "mol":   # n_mix Gumbel draws + one logistic draw per position, kept away from 0 and 1
+            uniforms = torch.rand((B, Ttot, n_mix + 1), dtype=torch.float32, device=dev).clamp_(1e-5, 1.0 - 1e-5)
+            wave = torch.zeros((B, Ttot), dtype=torch.float32, device=dev)
+        else:
+            uniforms = torch.rand((B, Ttot), dtype=torch.float32, device=dev) if mode == "sampling" else None
+            wave = None
         logits = torch.zeros((B, Ttot, self.out_channels), dtype=torch.float32, device=dev) if return_logits else None
         p = 0
         while p < Ttot - 1:
@@ -267,7 +275,8 @@ class WaveNetEngine(object):
             if layered:
                 rc = self.lib.wn_decode_layered_steps(cfg, B, _ptr(self.flat_params), _ptr(G), F, n_pad, _ptr(samples), Ttot,
                                                       _ptr(t_forced), _ptr(t_end), p, p1, _ptr(state), state.numel(),
-                                                      _ptr(uniforms), _ptr(logits), 1 if mode == "sampling" else 0, st)
+                                                      _ptr(uniforms), _ptr(logits), {"argmax": 0, "sampling": 1, "mol": 2}[mode],
+                                                      _ptr(wave), st)
                 self.lib.check(rc, "wn_decode_layered_steps")
             else:
                 rc = self.lib.wn_decode_steps(cfg, B, _ptr(self.flat_params), _ptr(wpack), _ptr(G), F, n_pad, _ptr(samples),
@@ -278,6 +287,8 @@ class WaveNetEngine(object):
             if progress is not None:
                 progress(max(p + 1 - Tctx, 0), n_max)
         out = [samples[b, Tctx:Tctx + int(n)] for b, n in enumerate(n_samples_list)]
+        self.last_wave = None if wave is None else [wave[b, Tctx:Tctx + int(n)] for b, n in enumerate(n_samples_list)]
+        self.last_uniforms = uniforms
         if return_logits:   # row Tctx-1+i holds the logits that chose generated sample i
             return out, [logits[b, Tctx - 1:Tctx - 1 + int(n)] for b, n in enumerate(n_samples_list)]
         return out

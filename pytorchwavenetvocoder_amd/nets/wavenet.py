@@ -174,11 +174,17 @@ class WaveNet(nn.Module):
         dilation_repeat (int): Number of dilation repeat.
         kernel_size (int): Filter size of dilated causal convolution.
         upsampling_factor (int): Upsampling factor.
+        n_mixture (int): NOT a reference argument.  0 (default) = the reference's n_quantize-way softmax head;
+            > 0 = mixture-of-logistics head with that many components (BASELINE configs[3]): ``conv_post_2`` then
+            has 3 * n_mixture channels (mixture logits, means, log-scales), the input stays the mu-law one-hot
+            front end, the loss is ``mol_loss_and_backward`` and generation draws from the mixture.
     """
 
     def __init__(self, n_quantize=256, n_aux=28, n_resch=512, n_skipch=256,
-                 dilation_depth=10, dilation_repeat=3, kernel_size=2, upsampling_factor=0, _library=None):
+                 dilation_depth=10, dilation_repeat=3, kernel_size=2, upsampling_factor=0, n_mixture=0, _library=None):
         super(WaveNet, self).__init__()
+        self.n_mixture = n_mixture
+        self.out_channels = 3 * n_mixture if n_mixture > 0 else n_quantize
         self.n_aux = n_aux
         self.n_quantize = n_quantize
         self.n_resch = n_resch
@@ -210,12 +216,12 @@ class WaveNet(nn.Module):
             self.skip_1x1 += [nn.Conv1d(self.n_resch, self.n_skipch, 1)]
             self.res_1x1 += [nn.Conv1d(self.n_resch, self.n_resch, 1)]
         self.conv_post_1 = nn.Conv1d(self.n_skipch, self.n_skipch, 1)
-        self.conv_post_2 = nn.Conv1d(self.n_skipch, self.n_quantize, 1)
+        self.conv_post_2 = nn.Conv1d(self.n_skipch, self.out_channels, 1)
 
         # the HIP engine (loads libwavenet_hip.so; raises when the extension is unavailable)
         object.__setattr__(self, "_engine", WaveNetEngine(
             n_quantize, n_aux, n_resch, n_skipch, dilation_depth, dilation_repeat, kernel_size,
-            upsampling_factor, device="cpu", library=_library))
+            upsampling_factor, device="cpu", library=_library, out_channels=3 * n_mixture))
         assert self._engine.receptive_field == self.receptive_field
         self._fwd_serial = 0
         self._param_slices = []
@@ -292,6 +298,23 @@ class WaveNet(nn.Module):
             p.grad = None if dead else flat[off:off + n].view(shape)
         return loss
 
+    def mol_loss_and_backward(self, x, h, y, t_start=None, grad_scale=1.0, num_classes=65536, log_scale_min=-7.0):
+        """Training half-step of the mixture-of-logistics head (``n_mixture > 0``): forward -> mean negative
+        log-likelihood of the waveform ``y`` (B, T) in [-1, 1] (the value of the NEXT sample at every position,
+        like ``t`` of the softmax head) on ``[:, t_start:]`` -> backward.  Gradients land as in
+        ``loss_and_backward``."""
+        if self.n_mixture <= 0:
+            raise ValueError("this model has the softmax head (n_mixture = 0)")
+        eng = self._engine
+        out = eng.forward(x, h)
+        self._fwd_serial += 1
+        loss, dout = eng.mol_loss(out, y, t_start=t_start, grad_scale=grad_scale, num_classes=num_classes,
+                                  log_scale_min=log_scale_min)
+        flat = eng.backward(dout)
+        for p, (off, n, shape, dead) in zip(self.parameters(), self._param_slices):
+            p.grad = None if dead else flat[off:off + n].view(shape)
+        return loss
+
     # ---- generation (reference wavenet.py:243-511) --------------------------------------------
     def _window_logits(self, x, h_up):
         """Logits (T, Q) for ONE window with the aux features already at sample rate."""
@@ -310,7 +333,7 @@ class WaveNet(nn.Module):
                 eng.flat_params.data_ptr() != self._engine.flat_params.data_ptr():
             eng = WaveNetEngine(self.n_quantize, self.n_aux, self.n_resch, self.n_skipch, self.dilation_depth,
                                 self.dilation_repeat, self.kernel_size, 0, device=self._engine.device,
-                                library=self._engine.lib)
+                                library=self._engine.lib, out_channels=3 * self.n_mixture)
             eng.flat_params = self._engine.flat_params[:eng.n_params]
             object.__setattr__(self, "_gen_eng", eng)
         return eng
@@ -364,6 +387,8 @@ class WaveNet(nn.Module):
         if mode not in ("sampling", "argmax"):
             logging.error("mode should be sampling or argmax")
             sys.exit(1)
+        if self.n_mixture > 0:  # the mixture head has no argmax: both modes draw from the mixture
+            mode = "mol"
         start = [time.time(), 0]
 
         def progress(done, total):
