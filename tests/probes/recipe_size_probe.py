@@ -8,7 +8,7 @@ import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import wavenet_oracle as O  # noqa: E402  (checker only)
 from pytorchwavenetvocoder_amd.nets import WaveNet  # noqa: E402
