@@ -7,7 +7,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import wavenet_oracle as O  # noqa: E402
 from pytorchwavenetvocoder_amd import _lib  # noqa: E402
 from pytorchwavenetvocoder_amd.engine import WaveNetEngine, key_to_kind, load_state_into_flat, state_keys  # noqa: E402

@@ -11,7 +11,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import wavenet_oracle as O  # noqa: E402  (checker only)
 from pytorchwavenetvocoder_amd import _lib  # noqa: E402
 from pytorchwavenetvocoder_amd.engine import WaveNetEngine, flat_to_state, load_state_into_flat  # noqa: E402
