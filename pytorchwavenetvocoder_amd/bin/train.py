@@ -74,13 +74,15 @@ def validate_length(x, y, upsampling_factor=None):
     return x, y
 
 
-def _to_batch(xs, hs, ts, device):
-    bx, bh, bt = torch.stack(xs), torch.stack(hs), torch.stack(ts)
+def _to_batch(xs, hs, ts, device, ys=None):
+    tensors = [torch.stack(xs), torch.stack(hs), torch.stack(ts)] + ([torch.stack(ys)] if ys else [])
     if device is not None:
         if torch.device(device).type == "cuda":  # pinned staging: the copies overlap the step that is running
-            bx, bh, bt = bx.pin_memory(), bh.pin_memory(), bt.pin_memory()
-        bx, bh, bt = bx.to(device, non_blocking=True), bh.to(device, non_blocking=True), bt.to(device, non_blocking=True)
-    return (bx, bh), bt
+            tensors = [v.pin_memory() for v in tensors]
+        tensors = [v.to(device, non_blocking=True) for v in tensors]
+    if ys:
+        return (tensors[0], tensors[1]), tensors[2], tensors[3]
+    return (tensors[0], tensors[1]), tensors[2]
 
 
 def _shard_range(batch_size, shard):
@@ -105,7 +107,8 @@ def train_generator(wav_list, feat_list, receptive_field,
                     use_upsampling_layer=True,
                     use_speaker_code=False,
                     device="auto",
-                    shard=None):
+                    shard=None,
+                    with_wave=False):
     """Minibatch generator with the reference's four batching modes (train.py:67-312).
 
     Yields ``((batch_x, batch_h), batch_t)``: x/t int64 (B, T) with t the next sample of x, h float
@@ -116,6 +119,8 @@ def train_generator(wav_list, feat_list, receptive_field,
     ``shard=(rank, world)``: yield only this rank's windows of every minibatch (same minibatch
     composition as the unsharded generator; the mu-law / scaling work of the other ranks' windows is
     skipped instead of being done ``world`` times).
+    ``with_wave=True`` (mixture-of-logistics head): additionally yields ``batch_y`` float (B, T), the waveform
+    value of the next sample at every position (the un-quantised counterpart of ``batch_t``).
     """
     if device == "auto":
         device = torch.device("cuda") if torch.cuda.is_available() else None
@@ -133,6 +138,7 @@ def train_generator(wav_list, feat_list, receptive_field,
         logging.warning("in utterance batch mode, batchsize will be 1.")
 
     def prep(x_, h_):
+        raw.append(torch.from_numpy(np.asarray(x_, dtype=np.float32)))
         if wav_transform is not None:
             x_ = wav_transform(x_)
         if feat_transform is not None:
@@ -140,9 +146,10 @@ def train_generator(wav_list, feat_list, receptive_field,
         return torch.from_numpy(np.asarray(x_)).long(), torch.from_numpy(np.asarray(h_)).float()
 
     my_lo, my_hi = _shard_range(batch_size, shard)
+    raw = []  # un-quantised windows in the order of prep() calls
     x_buffer = h_buffer = None
     while True:
-        batch_x, batch_h, batch_t = [], [], []
+        batch_x, batch_h, batch_t, batch_y = [], [], [], []
         n_in_batch = 0
         for wavfile, featfile in zip(wav_list, feat_list):
             x, _fs = read_wav(wavfile)
@@ -180,13 +187,14 @@ def train_generator(wav_list, feat_list, receptive_field,
                             batch_h += [h_[:-1].transpose(0, 1)]
                         batch_x += [x_[:-1]]
                         batch_t += [x_[1:]]
+                        batch_y += [raw.pop()[1:]]
                     n_in_batch += 1
                     h_buffer = h_buffer[h_ss:]
                     x_buffer = x_buffer[x_ss:]
                     if n_in_batch == batch_size:
                         if batch_x:
-                            yield _to_batch(batch_x, batch_h, batch_t, device)
-                        batch_x, batch_h, batch_t = [], [], []
+                            yield _to_batch(batch_x, batch_h, batch_t, device, batch_y if with_wave else None)
+                        batch_x, batch_h, batch_t, batch_y = [], [], [], []
                         n_in_batch = 0
             else:
                 # one utterance per batch; with several ranks utterance i goes to rank i mod world
@@ -198,7 +206,7 @@ def train_generator(wav_list, feat_list, receptive_field,
                     x = x[:-upsampling_factor + 1]
                 x_, h_ = prep(x, h)
                 hh = h_.transpose(0, 1) if use_upsampling_layer else h_[:-1].transpose(0, 1)
-                yield _to_batch([x_[:-1]], [hh], [x_[1:]], device)
+                yield _to_batch([x_[:-1]], [hh], [x_[1:]], device, [raw.pop()[1:]] if with_wave else None)
         if shuffle:
             idx = np.random.permutation(n_files)
             wav_list = [wav_list[i] for i in idx]
@@ -255,6 +263,8 @@ def get_parser():
         else:
             parser.add_argument("--" + name, default=default, type=typ, help=text)
     parser.add_argument("--feature_type", default="world", choices=["world", "melspc"], type=str)
+    # extension (not a reference flag): mixture-of-logistics output head with N components, 0 = softmax head
+    parser.add_argument("--n_mixture", default=0, type=int, help="mixture-of-logistics components (0: softmax head)")
     parser.add_argument("--resume", default=None, nargs="?", type=str, help="checkpoint to continue from")
     return parser
 
@@ -304,7 +314,7 @@ def _worker(rank, world, args, port):
     upsampling_factor = args.upsampling_factor if args.use_upsampling_layer else 0
     model = WaveNet(n_quantize=args.n_quantize, n_aux=args.n_aux, n_resch=args.n_resch, n_skipch=args.n_skipch,
                     dilation_depth=args.dilation_depth, dilation_repeat=args.dilation_repeat,
-                    kernel_size=args.kernel_size, upsampling_factor=upsampling_factor)
+                    kernel_size=args.kernel_size, upsampling_factor=upsampling_factor, n_mixture=args.n_mixture)
     if is_main:
         logging.info(model)
     model.apply(initialize)
@@ -342,6 +352,7 @@ def _worker(rank, world, args, port):
         upsampling_factor=args.upsampling_factor,
         use_upsampling_layer=args.use_upsampling_layer,
         shard=(rank, world) if world > 1 else None,
+        with_wave=args.n_mixture > 0,
         use_speaker_code=args.use_speaker_code,
         device=device)
 
@@ -363,8 +374,9 @@ def _worker(rank, world, args, port):
     total = 0.0
     for i in range(iterations, args.iters):
         start = time.time()
-        (batch_x, batch_h), batch_t = generator.next()
-        batch_loss = reducer.loss_and_backward(batch_x, batch_h, batch_t)
+        item = generator.next()
+        (batch_x, batch_h), batch_t = item[0], item[1]
+        batch_loss = reducer.loss_and_backward(batch_x, batch_h, batch_t, y=item[2] if args.n_mixture > 0 else None)
         optimizer.step()
         loss_acc += batch_loss.detach()
         if args.verbose > 1:

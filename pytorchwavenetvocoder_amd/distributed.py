@@ -35,20 +35,25 @@ class GradientReducer(object):
     def grad_scale(self):
         return 1.0 / self.world
 
-    def loss_and_backward(self, x, h, t, t_start=None):
+    def _step(self, x, h, t, y, **kw):
+        if y is not None:   # mixture-of-logistics head: the target is the waveform value, not the token
+            return self.model.mol_loss_and_backward(x, h, y, **kw)
+        return self.model.loss_and_backward(x, h, t, **kw)
+
+    def loss_and_backward(self, x, h, t, t_start=None, y=None):
         """forward + loss + backward with the bucketed all-reduce overlapped; returns the local
-        mean loss (device tensor)."""
+        mean loss (device tensor).  ``y`` (B, T) float selects the mixture-of-logistics loss."""
         if self.world == 1:
-            return self.model.loss_and_backward(x, h, t, t_start=t_start)
+            return self._step(x, h, t, y, t_start=t_start)
         if not self.cuda:
-            loss = self.model.loss_and_backward(x, h, t, t_start=t_start, grad_scale=self.grad_scale)
+            loss = self._step(x, h, t, y, t_start=t_start, grad_scale=self.grad_scale)
             flat = self.eng.grads()
             for lo, hi in self.ranges:
                 dist.all_reduce(flat[lo:hi], group=self.group)
             return loss
         handles = [e.cuda_event for e in self.events]
-        loss = self.model.loss_and_backward(x, h, t, t_start=t_start, grad_scale=self.grad_scale,
-                                            events=handles, layers_per_bucket=self.lpb)
+        loss = self._step(x, h, t, y, t_start=t_start, grad_scale=self.grad_scale, events=handles,
+                          layers_per_bucket=self.lpb)
         flat = self.eng.grads()
         with torch.cuda.stream(self.side):
             for (lo, hi), ev in zip(self.ranges, self.events):

@@ -298,7 +298,8 @@ class WaveNet(nn.Module):
             p.grad = None if dead else flat[off:off + n].view(shape)
         return loss
 
-    def mol_loss_and_backward(self, x, h, y, t_start=None, grad_scale=1.0, num_classes=65536, log_scale_min=-7.0):
+    def mol_loss_and_backward(self, x, h, y, t_start=None, grad_scale=1.0, num_classes=65536, log_scale_min=-7.0,
+                              events=None, layers_per_bucket=0):
         """Training half-step of the mixture-of-logistics head (``n_mixture > 0``): forward -> mean negative
         log-likelihood of the waveform ``y`` (B, T) in [-1, 1] (the value of the NEXT sample at every position,
         like ``t`` of the softmax head) on ``[:, t_start:]`` -> backward.  Gradients land as in
@@ -310,7 +311,7 @@ class WaveNet(nn.Module):
         self._fwd_serial += 1
         loss, dout = eng.mol_loss(out, y, t_start=t_start, grad_scale=grad_scale, num_classes=num_classes,
                                   log_scale_min=log_scale_min)
-        flat = eng.backward(dout)
+        flat = eng.backward(dout, events=events, layers_per_bucket=layers_per_bucket)
         for p, (off, n, shape, dead) in zip(self.parameters(), self._param_slices):
             p.grad = None if dead else flat[off:off + n].view(shape)
         return loss

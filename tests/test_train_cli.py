@@ -104,6 +104,21 @@ def test_sharded_generator_is_a_partition_of_the_unsharded_one(tmp_path):
             p.close()
 
 
+def test_generator_yields_the_waveform_targets_of_the_mixture_head(tmp_path):
+    wavs, feats, _ = make_corpus(str(tmp_path), n=2)
+    gen = T.train_generator(wavs, feats, receptive_field=15, batch_length=400, batch_size=2, feature_type="melspc",
+                            shuffle=False, wav_transform=lambda x: encode_mu_law(x, 256), upsampling_factor=U,
+                            use_upsampling_layer=True, device=None, with_wave=True)
+    try:
+        (bx, bh), bt, by = gen.next()
+        assert by.dtype == torch.float32 and tuple(by.shape) == tuple(bt.shape)
+        assert float(by.abs().max()) <= 1.0
+        # the mu-law token of the waveform target is the token target
+        assert torch.equal(torch.from_numpy(encode_mu_law(by.numpy().astype(np.float64), 256)).long(), bt)
+    finally:
+        gen.close()
+
+
 def test_validate_length():
     x, y = T.validate_length(np.zeros(1000), np.zeros((12, 3)), 80)
     assert len(x) == len(y) * 80
