@@ -78,7 +78,11 @@ void wn_decode_make_plan(int Q, int A, int R, int S, int L, int K, int depth, Wn
     long sumd = 0;
     for (int l = 0; l < L; ++l) sumd += 1L << (l % depth);
     pl->queue_floats = (long)(K - 1) * sumd * R;
-    const long lds_f = (long)L * K * pl->R4 * 4 + round4((long)L * 2 * R) + pl->R4 * 4 + 2L * pl->S4 * 4 + Qpad + 16;
+    // step state (inputs, aux, gate, skip, post, logits, token history) + the bias tables (res_1x1 of every
+    // layer, summed skip, post 1, post 2): a bias read from global memory inside the layer loop would make the
+    // consumer wait for every weight unit in flight (vmcnt is in-order)
+    const long lds_f = (long)L * K * pl->R4 * 4 + round4((long)L * 2 * R) + pl->R4 * 4 + 2L * pl->S4 * 4 + Qpad + 16 +
+                       round4((long)L * R) + 2L * pl->S4 * 4 + Qpad;
     pl->lds_bytes = (size_t)lds_f * 4;
     pl->ok = pl->lds_bytes <= 160 * 1024 ? 1 : 0;
 }
@@ -236,6 +240,10 @@ __global__ __launch_bounds__(WN_DT) void k_decode(WnDecodeArgs a) {
     float* p1v = sk + S4 * 4;
     float* lgt = p1v + S4 * 4;
     int* tokh = reinterpret_cast<int*>(lgt + Qpad);
+    float* b_res = lgt + Qpad + 16;                 // [L][R] res_1x1 biases
+    float* b_sk = b_res + (((long)L * R + 3) & ~3L);  // [S] sum of the skip_1x1 biases
+    float* b_p1 = b_sk + S4 * 4;                    // [S] conv_post_1 bias
+    float* b_p2 = b_p1 + S4 * 4;                    // [Qpad] conv_post_2 bias
     const int lds_floats = (int)(pl.lds_bytes / 4);
     for (int i = tid; i < lds_floats; i += WN_DT) lds[i] = 0.f;
 
@@ -262,6 +270,12 @@ __global__ __launch_bounds__(WN_DT) void k_decode(WnDecodeArgs a) {
     float* qb = a.queues + (long)b * a.q_bstride;
 
     WN_LDS_BARRIER();
+    for (int i = tid; i < L * R; i += WN_DT) b_res[i] = P[a.off_res_b0 + (long)(i / R) * a.res_b_lstride + (i % R)];
+    for (int i = tid; i < S; i += WN_DT) {
+        b_sk[i] = bskip[i];
+        b_p1[i] = P[a.off_post1_b + i];
+    }
+    for (int i = tid; i < Q; i += WN_DT) b_p2[i] = P[a.off_post2_b + i];
     if (tid < 8) {
         const int q = a.p0 - tid;
         if (q >= 0) {
@@ -378,7 +392,7 @@ __global__ __launch_bounds__(WN_DT) void k_decode(WnDecodeArgs a) {
             ar = group_sum(ar, pl.lg_pr);
             if (l == 3) DSTAMP(15);
             if (part_r == 0 && o_r < R && l + 1 < L) {  // the last layer's residual output is dead
-                const float xn = ar + P[a.off_res_b0 + (long)l * a.res_b_lstride + o_r] + xl[CUR + o_r];
+                const float xn = ar + b_res[l * R + o_r] + xl[CUR + o_r];
                 xin[(l + 1) * XS + CUR + o_r] = xn;
                 if (K > 1) {
                     const int Dq = (K - 1) << ((l + 1) % depth);
@@ -403,7 +417,7 @@ __global__ __launch_bounds__(WN_DT) void k_decode(WnDecodeArgs a) {
         {
             const float v = group_sum(acc_sk.x + acc_sk.y, pl.lg_ps);
             acc_sk = f32x2{0.f, 0.f};
-            if (part_s == 0 && o_s < S) sk[o_s] = fmaxf(v + bskip[o_s], 0.f);
+            if (part_s == 0 && o_s < S) sk[o_s] = fmaxf(v + b_sk[o_s], 0.f);
         }
         WN_LDS_BARRIER();
         {
@@ -416,7 +430,7 @@ __global__ __launch_bounds__(WN_DT) void k_decode(WnDecodeArgs a) {
                 W[j % UL] = wn_buf_load4(stream, voff, ((j / UL + 1 < NPL) ? (unsigned)(L + j / UL + 1) * LB : 0u) + (j % UL) * UB);
             }
             const float acc = group_sum(acc2.x + acc2.y, pl.lg_p1);
-            if (part_1 == 0 && o_1 < S) p1v[o_1] = fmaxf(acc + P[a.off_post1_b + o_1], 0.f);
+            if (part_1 == 0 && o_1 < S) p1v[o_1] = fmaxf(acc + b_p1[o_1], 0.f);
         }
         WN_LDS_BARRIER();
         {
@@ -429,7 +443,7 @@ __global__ __launch_bounds__(WN_DT) void k_decode(WnDecodeArgs a) {
                 W[j % UL] = wn_buf_load4(stream, voff, ((j / UL + 1 < NPL) ? (unsigned)(L + j / UL + 1) * LB : 0u) + (j % UL) * UB);
             }
             const float acc = group_sum(acc2.x + acc2.y, pl.lg_p2);
-            if (part_2 == 0) lgt[o_2] = o_2 < Q ? acc + P[a.off_post2_b + o_2] : -3.0e38f;
+            if (part_2 == 0) lgt[o_2] = o_2 < Q ? acc + b_p2[o_2] : -3.0e38f;
             // slots of the padded tail are never consumed: refill them with layer 0 directly
             WN_UNROLL
             for (int j = UP; j < NPL * UL; ++j) W[j % UL] = wn_buf_load4(stream, voff, (j % UL) * UB);

@@ -143,6 +143,14 @@ def test_cfg2_full_size_properties():
     assert torch.isfinite(flat).all()
     lo, hi = eng.dead_range
     assert float(flat[lo:hi].abs().max()) == 0.0
+    # run-to-run reproducibility: every reduction in the path has a fixed order (no float atomics
+    # on global memory), so the same inputs give the same bits
+    logits_b = eng.forward(x, h).clone()
+    assert torch.equal(logits_b, logits)
+    loss_b, dl_b = eng.loss(logits_b, t)
+    assert torch.equal(loss_b, loss)
+    flat_b = eng.backward(dl_b)
+    assert torch.equal(flat_b, flat)
     # batch independence
     one = eng.forward(x[3:4].contiguous(), h[3:4].contiguous())
     assert float((one[0] - logits[3]).abs().max()) <= 2e-5
