@@ -82,7 +82,7 @@ void wn_decode_make_plan(int Q, int A, int R, int S, int L, int K, int depth, Wn
     // layer, summed skip, post 1, post 2): a bias read from global memory inside the layer loop would make the
     // consumer wait for every weight unit in flight (vmcnt is in-order)
     const long lds_f = (long)L * K * pl->R4 * 4 + round4((long)L * 2 * R) + pl->R4 * 4 + 2L * pl->S4 * 4 + Qpad + 16 +
-                       round4((long)L * R) + 2L * pl->S4 * 4 + Qpad;
+                       round4((long)L * R) + 2L * pl->S4 * 4 + Qpad + round4((long)L * 2 * R) /* cvec */ + pl->R4 * 4 /* causal bias */;
     pl->lds_bytes = (size_t)lds_f * 4;
     pl->ok = pl->lds_bytes <= 160 * 1024 ? 1 : 0;
 }
@@ -218,6 +218,19 @@ extern "C" void wn_decode_debug_set_buffer(void* p) { g_dec_dbg = (long long*)p;
 #define DSTAMP(i)
 #endif
 
+// The LDS addresses of the matrix-vector units are loop invariant; hoisted out of the step loop they would pin
+// ~90 registers next to the weight ring.  Passing the lane's role through an empty asm once per layer / per step
+// makes the compiler recompute them (two VALU ops each) where they are used.
+#ifdef WN_EMU
+#define WN_OPAQUE(x) (x)
+#else
+static __device__ __forceinline__ int wn_opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+#define WN_OPAQUE(x) wn_opaque(x)
+#endif
+
 template <int UD, int UR, int US, int UP1, int UP2>
 __global__ __launch_bounds__(WN_DT) void k_decode(WnDecodeArgs a) {
     constexpr int UL = UD + UR + US;
@@ -244,16 +257,18 @@ __global__ __launch_bounds__(WN_DT) void k_decode(WnDecodeArgs a) {
     float* b_sk = b_res + (((long)L * R + 3) & ~3L);  // [S] sum of the skip_1x1 biases
     float* b_p1 = b_sk + S4 * 4;                    // [S] conv_post_1 bias
     float* b_p2 = b_p1 + S4 * 4;                    // [Qpad] conv_post_2 bias
+    float* c_lds = b_p2 + Qpad;                     // [L][2R] constant part of the aux pre-activations
+    float* b_front = c_lds + ((nG + 3) & ~3);       // [R] causal conv bias
     const int lds_floats = (int)(pl.lds_bytes / 4);
     for (int i = tid; i < lds_floats; i += WN_DT) lds[i] = 0.f;
 
     // thread roles
     const int pd = 1 << pl.lg_pd, pr = 1 << pl.lg_pr, ps = 1 << pl.lg_ps, pp1 = 1 << pl.lg_p1, pp2 = 1 << pl.lg_p2;
-    const int c_d = tid >> pl.lg_pd, part_d = tid & (pd - 1);
-    const int o_r = tid >> pl.lg_pr, part_r = tid & (pr - 1);
-    const int o_s = tid >> pl.lg_ps, part_s = tid & (ps - 1);
-    const int o_1 = tid >> pl.lg_p1, part_1 = tid & (pp1 - 1);
-    const int o_2 = tid >> pl.lg_p2, part_2 = tid & (pp2 - 1);
+    const int c_d = tid >> pl.lg_pd, part_d0 = tid & (pd - 1);
+    const int o_r = tid >> pl.lg_pr, part_r0 = tid & (pr - 1);
+    const int o_s = tid >> pl.lg_ps, part_s0 = tid & (ps - 1);
+    const int o_1 = tid >> pl.lg_p1, part_10 = tid & (pp1 - 1);
+    const int o_2 = tid >> pl.lg_p2, part_20 = tid & (pp2 - 1);
 
     // weight stream: unit u of this thread sits at byte u*WN_DT*16 + tid*16
     const wn_rsrc_t stream = wn_make_buf(a.wpack, (unsigned)(pl.stream_f4 * 16));
@@ -276,6 +291,8 @@ __global__ __launch_bounds__(WN_DT) void k_decode(WnDecodeArgs a) {
         b_p1[i] = P[a.off_post1_b + i];
     }
     for (int i = tid; i < Q; i += WN_DT) b_p2[i] = P[a.off_post2_b + i];
+    for (int i = tid; i < nG; i += WN_DT) c_lds[i] = cvec[i];
+    for (int i = tid; i < R; i += WN_DT) b_front[i] = P[a.off_causal_b + i];
     if (tid < 8) {
         const int q = a.p0 - tid;
         if (q >= 0) {
@@ -326,24 +343,33 @@ __global__ __launch_bounds__(WN_DT) void k_decode(WnDecodeArgs a) {
             f = imin(f, a.F - 1);
             const float* g = a.G + (long)b * a.g_bstride + (long)f * nG;
             for (int i0 = tid; i0 < nG; i0 += 8 * WN_DT) {
-                float gv[8], cv[8];
+                float gv[8];
                 WN_UNROLL
                 for (int u = 0; u < 8; ++u) {
                     const int idx = i0 + u * WN_DT;
                     gv[u] = idx < nG ? g[idx] : 0.f;
-                    cv[u] = idx < nG ? cvec[idx] : 0.f;
                 }
                 WN_UNROLL
                 for (int u = 0; u < 8; ++u) {
                     const int idx = i0 + u * WN_DT;
-                    if (idx < nG) aux[idx] = fmaf(uw, gv[u], cv[u]);
+                    if (idx < nG) aux[idx] = fmaf(uw, gv[u], c_lds[idx]);
                 }
             }
         }
         float x0 = 0.f;
-        if (tid < R) {  // front conv as a gather (wavenet.py:513-516)
-            x0 = P[a.off_causal_b + tid];
-            for (int k = 0; k < K; ++k) {
+        if (tid < R) {  // front conv as a gather (wavenet.py:513-516); the taps are requested together
+            float wv[4];
+            WN_UNROLL
+            for (int k = 0; k < 4; ++k) {
+                const int kc = imin(k, K - 1);
+                const int q = p - (K - 1 - kc);
+                wv[k] = P[a.off_causal_w + ((long)tid * Q + tokh[q & 7]) * K + kc];
+            }
+            x0 = b_front[tid];
+            WN_UNROLL
+            for (int k = 0; k < 4; ++k)
+                if (k < K && p - (K - 1 - k) >= 0) x0 += wv[k];
+            for (int k = 4; k < K; ++k) {
                 const int q = p - (K - 1 - k);
                 if (q >= 0) x0 += P[a.off_causal_w + ((long)tid * Q + tokh[q & 7]) * K + k];
             }
@@ -357,6 +383,7 @@ __global__ __launch_bounds__(WN_DT) void k_decode(WnDecodeArgs a) {
         // ---- residual stack (wavenet.py:538-549) ------------------------------------------------
         for (int l = 0; l < L; ++l) {
             const float* xl = xin + l * XS;
+            const int part_d = WN_OPAQUE(part_d0), part_r = WN_OPAQUE(part_r0), part_s = WN_OPAQUE(part_s0);
             const unsigned nxt = (unsigned)(l + 1) * LB;  // after the last layer: post pseudo-layer 0
             f32x2 sg = f32x2{0.f, 0.f};  // (sigmoid row, tanh row) of channel c_d
             WN_UNROLL
@@ -414,6 +441,7 @@ __global__ __launch_bounds__(WN_DT) void k_decode(WnDecodeArgs a) {
         DSTAMP(3);
 
         // ---- post net (wavenet.py:518-523) -------------------------------------------------------
+        const int part_s = WN_OPAQUE(part_s0), part_1 = WN_OPAQUE(part_10), part_2 = WN_OPAQUE(part_20);
         {
             const float v = group_sum(acc_sk.x + acc_sk.y, pl.lg_ps);
             acc_sk = f32x2{0.f, 0.f};
