@@ -89,7 +89,8 @@ const char* wn_last_error(void);
 int wn_receptive_field(const WnConfig* cfg);
 int wn_num_layers(const WnConfig* cfg);
 
-/* Number of fp32 elements of the flat parameter buffer (== sum of numel of the reference state_dict). */
+/* Number of fp32 elements of the flat parameter buffer (== sum of numel of the reference state_dict);
+ * -1 for an invalid configuration (wn_last_error() says which field). */
 int64_t wn_param_count(const WnConfig* cfg);
 /* Offset (in floats) and numel of tensor `kind` of layer `layer` (ignored for non per-layer kinds)
  * inside the flat parameter / gradient buffers.  Returns non-zero if the tensor does not exist
@@ -105,7 +106,8 @@ int wn_bucket_range(const WnConfig* cfg, int layers_per_bucket, int bucket, int6
  * wavenet.py:231-238 leaves its output unused, so torch reports grad None and Adam skips it). */
 int wn_dead_param_range(const WnConfig* cfg, int64_t* lo, int64_t* hi);
 
-/* Bytes of caller-provided scratch for batch B x T model inputs (forward + backward). */
+/* Bytes of caller-provided scratch for batch B x T model inputs (forward + backward); 0 for an invalid
+ * configuration or shape (wn_last_error()). */
 size_t wn_workspace_bytes(const WnConfig* cfg, int B, int T);
 
 /* WaveNet.forward(x, h)  -- reference wavenet.py:212-241 (+ _preprocess :513-516, UpSampling

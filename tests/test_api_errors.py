@@ -1,0 +1,112 @@
+# -*- coding: utf-8 -*-
+"""Error behaviour of the host mirror and the C ABI: bad arguments must fail loudly (ValueError from
+the Python mirror, WnError carrying wn_last_error() from the library), never compute on garbage and
+never fall back to a CPU path.  Runs on the kernel emulator (test infrastructure), no GPU needed."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from pytorchwavenetvocoder_amd import _lib
+from pytorchwavenetvocoder_amd.nets import WaveNet
+from tests.emu_util import emu_library
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _model(**kw):
+    cfg = dict(n_quantize=16, n_aux=4, n_resch=8, n_skipch=8, dilation_depth=2, dilation_repeat=1, kernel_size=2,
+               upsampling_factor=4)
+    cfg.update(kw)
+    return WaveNet(_library=emu_library(), **cfg)
+
+
+def test_forward_argument_checks():
+    m = _model()
+    x = torch.zeros(1, 16, dtype=torch.long)
+    h = torch.zeros(1, 4, 4)
+    m(x, h)  # sanity: the valid call works
+    with pytest.raises(ValueError):
+        m.engine.forward(x.float(), h)                      # tokens must be int64
+    with pytest.raises(ValueError):
+        m.engine.forward(torch.zeros(1, 18, dtype=torch.long), torch.zeros(1, 4, 4))   # T % U != 0
+    with pytest.raises(ValueError):
+        m.engine.forward(x, torch.zeros(1, 4, 5))           # aux frames != T / U
+    with pytest.raises(ValueError):
+        m.engine.forward(x, torch.zeros(1, 3, 4))           # aux channels != n_aux
+    with pytest.raises(ValueError):
+        m.engine.forward(x[0], h)                           # (T,) instead of (B, T)
+
+
+def test_backward_needs_forward_and_matching_shape():
+    m = _model()
+    with pytest.raises(_lib.WnError):
+        m.engine.backward(torch.zeros(1, 16, 16))
+    x = torch.zeros(1, 16, dtype=torch.long)
+    h = torch.zeros(1, 4, 4)
+    m.engine.forward(x, h)
+    with pytest.raises((ValueError, _lib.WnError)):
+        m.engine.backward(torch.zeros(1, 16, 12))           # dlogits of another T
+
+
+def test_loss_window_checked_by_the_library():
+    m = _model()
+    x = torch.zeros(1, 16, dtype=torch.long)
+    h = torch.zeros(1, 4, 4)
+    logits = m.engine.forward(x, h)
+    t = torch.zeros(1, 16, dtype=torch.long)
+    for bad in (-1, 16, 100):
+        with pytest.raises(_lib.WnError) as e:
+            m.engine.loss(logits, t, t_start=bad)
+        assert "t_start" in str(e.value)                    # the library's message travels with the exception
+    with pytest.raises(ValueError):
+        m.engine.mol_loss(logits, torch.zeros(1, 16))       # softmax model: out_channels is not 3 * n_mix
+
+
+def test_c_abi_rejects_bad_configs_and_null_pointers():
+    lib = emu_library()
+    cfg = _lib.WnConfig(16, 4, 8, 8, 2, 1, 2, 4, 16)
+    assert lib.wn_param_count(ctypes.byref(cfg)) > 0
+    for field, val in (("n_quantize", 0), ("n_resch", 0), ("kernel_size", 0), ("dilation_depth", 0), ("n_skipch", -3)):
+        bad = _lib.WnConfig(16, 4, 8, 8, 2, 1, 2, 4, 16)
+        setattr(bad, field, val)
+        assert lib.wn_param_count(ctypes.byref(bad)) == -1, field
+        assert lib.wn_workspace_bytes(ctypes.byref(bad), 1, 16) == 0, field
+        assert lib.wn_last_error()                          # a message is left for the caller
+    ws = torch.zeros(lib.wn_workspace_bytes(ctypes.byref(cfg), 1, 16) // 4 + 1)
+    rc = lib.wn_forward(ctypes.byref(cfg), 1, 16, None, None, None, None, ws.data_ptr(), ws.numel() * 4, 0, None)
+    assert rc != 0 and b"NULL" in lib.wn_last_error()
+    p = torch.zeros(lib.wn_param_count(ctypes.byref(cfg)))
+    x = torch.zeros(1, 16, dtype=torch.long)
+    h = torch.zeros(1, 4, 4)
+    out = torch.zeros(1, 16, 16)
+    rc = lib.wn_forward(ctypes.byref(cfg), 1, 16, p.data_ptr(), x.data_ptr(), h.data_ptr(), out.data_ptr(), ws.data_ptr(),
+                        16, 0, None)                        # workspace far too small
+    assert rc != 0 and b"workspace" in lib.wn_last_error()
+
+
+def test_decode_argument_checks():
+    m = _model()
+    x = torch.zeros(2, 3, dtype=torch.long)
+    h = torch.zeros(2, 4, 4)
+    with pytest.raises(ValueError):
+        m.engine.decode(x, h, [4])                          # one length per utterance
+    with pytest.raises(ValueError):
+        m.engine.decode(x, h, [4, 4], mode="nucleus")       # unknown token choice
+    with pytest.raises(ValueError):
+        m.engine.decode(x, h, [4, 400])                     # aux features do not cover the request
+    with pytest.raises(ValueError):
+        m.engine.decode(x, h, [4, 4], mode="mol")           # softmax model
+
+
+def test_missing_library_fails_loudly():
+    """No HIP library -> import of the product path raises; nothing silently takes over."""
+    code = ("import os; os.environ['WN_LIB_PATH'] = '/nonexistent/libwavenet_hip.so'\n"
+            "from pytorchwavenetvocoder_amd.nets import WaveNet\n"
+            "WaveNet(16, 4, 8, 8, 2, 1, 2, 4)\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode != 0
+    assert "libwavenet_hip" in r.stderr
