@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define WN_ABI_VERSION 2
+#define WN_ABI_VERSION 3
 
 /* Same fields as the constructor WaveNet(n_quantize, n_aux, n_resch, n_skipch, dilation_depth,
  * dilation_repeat, kernel_size, upsampling_factor)  -- reference wavenet.py:172-173. */
@@ -212,6 +212,28 @@ int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* params, con
                             float* wave_out, void* stream);
 /* mode 2 (mixture-of-logistics head, out_channels = 3*n_mix): uniforms is (B, Ttot, n_mix+1); the drawn value is
  * written to wave_out (B, Ttot) (nullable) and, mu-law encoded with n_quantize levels, to samples. */
+
+/* Parallel context walk.  The reference builds the generation buffers with ONE full forward over the padded
+ * context (wavenet.py:338-349, 427-441); stepping the decode kernel through those >= receptive-field positions
+ * instead costs rf steps before the first new sample.  These three entry points do what the reference does:
+ *   wn_decode_ctx_aux   h (B, n_aux, F) -> h_ctx (B, n_aux, Tctx): the UPSAMPLED aux feature of every context
+ *                       position (ConvTranspose2d of wavenet.py:141-154), the n_pad left-padding positions
+ *                       replicating the first upsampled column (wavenet.py:336, 425);
+ *   wn_decode_prefill   runs the residual stack of the training forward on x_ctx (B, Tctx) / h_ctx and copies
+ *                       the newest (K-1)*d_l layer inputs of every layer into the dilation queues of `state`
+ *                       (layered = 0: the (B, wn_decode_state_floats) state of wn_decode_steps; 1: the state of
+ *                       wn_decode_layered_steps, after wn_decode_layered_prepare).  The B utterances of the call
+ *                       are utterances [state_b0, state_b0 + B) of a state built for state_B utterances, so a
+ *                       large batch can be walked in groups with a bounded workspace.  Decoding then resumes
+ *                       with p0 = Tctx-1, the last context position, whose logits choose the first new sample.
+ *                       `ws`: wn_decode_prefill_workspace_bytes(cfg, B, Tctx) bytes; flags as wn_forward.
+ * Tctx >= receptive field (the caller pads: wavenet.py:328-336). */
+int wn_decode_ctx_aux(const WnConfig* cfg, int B, int F, int Tctx, int n_pad, const float* params, const float* h,
+                      float* h_ctx, void* stream);
+size_t wn_decode_prefill_workspace_bytes(const WnConfig* cfg, int B, int Tctx);
+int wn_decode_prefill(const WnConfig* cfg, int B, int Tctx, const float* params, const int64_t* x_ctx, const float* h_ctx,
+                      void* ws, size_t ws_bytes, float* state, int64_t state_floats, int state_B, int state_b0, int layered,
+                      int flags, void* stream);
 
 /* ---- diagnostics: opt-in per-launch timing with HIP events (used by bench.py's roofline block) ----
  * wn_prof_enable(1) clears and starts recording {kernel tag, algorithmic flops/bytes, start/stop

@@ -65,7 +65,7 @@ class WnGemmArgs(ctypes.Structure):
 
 FLAG_NO_FUSED = 1
 FLAG_EXACT_MFMA = 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/wavenet_hip.h declares
 EXPORTS = [
@@ -75,6 +75,7 @@ EXPORTS = [
     "wn_decode_supported", "wn_decode_pack_floats", "wn_decode_state_floats", "wn_decode_pack", "wn_decode_aux",
     "wn_decode_steps", "wn_decode_stream_bytes",
     "wn_decode_layered_state_floats", "wn_decode_layered_prepare", "wn_decode_layered_steps", "wn_mol_loss",
+    "wn_decode_ctx_aux", "wn_decode_prefill_workspace_bytes", "wn_decode_prefill",
 ]
 
 
@@ -131,6 +132,10 @@ class WnLibrary(object):
         L.wn_decode_layered_state_floats.restype = i64
         L.wn_decode_layered_prepare.argtypes = [cfgp, i, i, vp, vp, vp, vp, i64, vp]
         L.wn_decode_layered_steps.argtypes = [cfgp, i, vp, vp, i, i, vp, i64, vp, vp, i, i, vp, i64, vp, vp, i, vp, vp]
+        L.wn_decode_ctx_aux.argtypes = [cfgp, i, i, i, i, vp, vp, vp, vp]
+        L.wn_decode_prefill_workspace_bytes.argtypes = [cfgp, i, i]
+        L.wn_decode_prefill_workspace_bytes.restype = ctypes.c_size_t
+        L.wn_decode_prefill.argtypes = [cfgp, i, i, vp, vp, vp, vp, ctypes.c_size_t, vp, i64, i, i, i, i, vp]
         if L.wn_abi_version() != ABI_VERSION:
             raise WnError("ABI mismatch: library %d, binding %d" % (L.wn_abi_version(), ABI_VERSION))
 

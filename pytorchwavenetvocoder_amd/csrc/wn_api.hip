@@ -484,12 +484,10 @@ static int pack_weights(const Ctx& c, const float* params) {
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-extern "C" int wn_forward(const WnConfig* cfg, int B, int T, const float* params, const int64_t* x, const float* h,
-                          float* logits, void* wsp, size_t ws_bytes, int flags, void* stream) {
-    api_enter();
-    Ctx c;
-    WN_TRY(make_ctx(&c, cfg, B, T, wsp, ws_bytes, flags, stream));
-    if (!params || !x || !h || !logits) return fail(1, "NULL argument");
+// front conv, aux projection and the residual stack: leaves X_l, s_l, g_l, z_l of every layer in the workspace
+static int forward_stack(const Ctx& c, const float* params, const int64_t* x, const float* h) {
+    const WnConfig* cfg = c.cfg;
+    const int B = c.B, T = c.T;
     const Dims& d = c.d;
     const Lay& y = c.y;
     const Ws& w = c.w;
@@ -552,6 +550,21 @@ extern "C" int wn_forward(const WnConfig* cfg, int B, int T, const float* params
             }
         }
     }
+    return 0;
+}
+
+extern "C" int wn_forward(const WnConfig* cfg, int B, int T, const float* params, const int64_t* x, const float* h,
+                          float* logits, void* wsp, size_t ws_bytes, int flags, void* stream) {
+    api_enter();
+    Ctx c;
+    WN_TRY(make_ctx(&c, cfg, B, T, wsp, ws_bytes, flags, stream));
+    if (!params || !x || !h || !logits) return fail(1, "NULL argument");
+    WN_TRY(forward_stack(c, params, x, h));
+    const Dims& d = c.d;
+    const Lay& y = c.y;
+    const Ws& w = c.w;
+    float* ws = c.ws;
+    const long BRT = (long)B * d.R * T;
     // skip-sum over layers as ONE contraction with K = L*R (wavenet.py:533,238), relu fused (:519)
     {
         WnGemmArgs g = wn_gemm_default();
@@ -1290,6 +1303,75 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
         WN_TRY(wn_dl_push(&a, c.st));
     }
     return rt_check("wn_decode_layered_steps");
+}
+
+// ---- parallel context walk (reference wavenet.py:338-349: the "prepare buffer" pass is a full forward) --------
+// The context of a generation call (left padding + given samples, >= receptive field positions) is known up
+// front, so its dilation queues need no sample-by-sample walk: the training forward's residual stack computes
+// the layer inputs of all positions at once and the newest (K-1)*d_l of every layer are copied into the queues.
+// The stack runs with the aux features at SAMPLE rate (configuration with upsampling_factor = 0, whose flat
+// parameter layout is a prefix of the model's: the upsampling layer's parameters are the last entries), because
+// the left padding replicates the first UPSAMPLED column (wavenet.py:336), which no frame-rate input can express.
+static WnConfig ctx_cfg(const WnConfig* cfg) {
+    WnConfig c0 = *cfg;
+    c0.upsampling_factor = 0;
+    return c0;
+}
+
+extern "C" int wn_decode_ctx_aux(const WnConfig* cfg, int B, int F, int Tctx, int n_pad, const float* params, const float* h,
+                                 float* h_ctx, void* stream) {
+    api_enter();
+    Dims d;
+    WN_TRY(check_cfg(cfg, &d));
+    if (!params || !h || !h_ctx || B < 1 || F < 1 || Tctx < 1 || n_pad < 0) return fail(1, "bad argument");
+    const Lay y = make_lay(d);
+    const float* upw = d.U > 0 ? params + y.up_w : nullptr;
+    const float* upb = d.U > 0 ? params + y.up_b : nullptr;
+    WN_TRY(wn_decode_ctx_aux_rows(h, upw, upb, h_ctx, B, d.A, F, d.U, Tctx, n_pad, (wn_stream_t)stream));
+    return rt_check("wn_decode_ctx_aux");
+}
+
+extern "C" size_t wn_decode_prefill_workspace_bytes(const WnConfig* cfg, int B, int Tctx) {
+    if (!cfg) return 0;
+    const WnConfig c0 = ctx_cfg(cfg);
+    return wn_workspace_bytes(&c0, B, Tctx);
+}
+
+extern "C" int wn_decode_prefill(const WnConfig* cfg, int B, int Tctx, const float* params, const int64_t* x_ctx,
+                                 const float* h_ctx, void* wsp, size_t ws_bytes, float* state, int64_t state_floats, int state_B,
+                                 int state_b0, int layered, int flags, void* stream) {
+    api_enter();
+    if (!cfg) return fail(1, "config is NULL");
+    const WnConfig c0 = ctx_cfg(cfg);
+    Ctx c;
+    WN_TRY(make_ctx(&c, &c0, B, Tctx, wsp, ws_bytes, flags, stream));
+    if (!params || !x_ctx || !h_ctx || !state) return fail(1, "NULL argument");
+    if (state_b0 < 0 || state_b0 + B > state_B) return fail(1, "utterances [%d, %d) outside a state of %d", state_b0, state_b0 + B, state_B);
+    const Dims& d = c.d;
+    if (Tctx < wn_receptive_field(cfg)) return fail(1, "context of %d positions is shorter than the receptive field", Tctx);
+    float* qdst;
+    long elem_stride, utt_stride;
+    if (layered) {
+        Dims dm;
+        WN_TRY(check_cfg(cfg, &dm));
+        DlLay y;
+        WN_TRY(dl_layout(cfg, dm, state_B, &y));
+        if (state_floats < y.total) return fail(1, "decode state too small: %ld < %ld floats", (long)state_floats, y.total);
+        qdst = state + y.queues + state_b0; elem_stride = state_B; utt_stride = 1;
+    } else {
+        Dims dm;
+        WnDecodePlan pl;
+        WN_TRY(decode_plan(cfg, &dm, &pl));
+        const long per = pl.queue_floats > 0 ? pl.queue_floats : 4;
+        if (state_floats < per * state_B)
+            return fail(1, "decode state too small: %ld < %ld floats", (long)state_floats, per * state_B);
+        qdst = state + per * state_b0; elem_stride = 1; utt_stride = per;
+    }
+    WN_TRY(forward_stack(c, params, x_ctx, h_ctx));
+    // decoding resumes at the last context position P0 = Tctx-1 (its logits choose the first new sample)
+    WN_TRY(wn_decode_fill_queues(c.ws + c.w.X, qdst, d.L, B, d.R, Tctx, d.K, cfg->dilation_depth, Tctx - 1, elem_stride,
+                                 utt_stride, c.st));
+    return rt_check("wn_decode_prefill");
 }
 
 extern "C" int wn_op_gemm(const struct WnGemmArgs* args, void* stream) {

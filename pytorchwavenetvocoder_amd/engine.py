@@ -203,7 +203,8 @@ class WaveNetEngine(object):
     def decode_supported(self):
         return bool(self.lib.wn_decode_supported(ctypes.byref(self.cfg)))
 
-    def decode(self, x, h, n_samples_list, mode="argmax", chunk=4096, return_logits=False, progress=None, layered=None):
+    def decode(self, x, h, n_samples_list, mode="argmax", chunk=4096, return_logits=False, progress=None, layered=None,
+               prefill="parallel", prefill_batch=32):
         """Queue-based sample-by-sample generation on the HIP decode kernel.
 
         x (B,T0) int64 context, h (B, n_aux, frames | samples) aux features covering T0 + max(n)
@@ -215,6 +216,12 @@ class WaveNetEngine(object):
         Two kernels implement it: the persistent one-workgroup-per-utterance kernel (model sizes covered by
         ``decode_supported()``) and the any-size layer-wise path (``layered=True``; chosen automatically
         when the first does not apply, e.g. the n_resch = 512 recipe default).
+
+        ``prefill``: how the dilation queues of the context are built.  "parallel" (default) does what the
+        reference does (wavenet.py:338-349): one forward of the residual stack over the whole padded context
+        (``prefill_batch`` utterances at a time), then decoding starts at the last context position.  "walk"
+        steps the decode kernel through the context sample by sample (teacher forced; receptive-field steps
+        before the first new sample) -- kept as the independent check of the former.
         """
         self._check_device(x, h)
         if x.dtype != torch.int64 or x.dim() != 2 or h.dim() != 3:
@@ -239,6 +246,8 @@ class WaveNetEngine(object):
             layered = not self.decode_supported()
         if mode == "mol" and not layered:
             raise ValueError("the mixture-of-logistics head generates through the layer-wise path")
+        if prefill not in ("parallel", "walk"):
+            raise ValueError("prefill should be parallel or walk")
         st = _stream_handle(self.device)
         dev = self.device
         h = h.contiguous().float()
@@ -270,6 +279,9 @@ class WaveNetEngine(object):
             wave = None
         logits = torch.zeros((B, Ttot, self.out_channels), dtype=torch.float32, device=dev) if return_logits else None
         p = 0
+        if prefill == "parallel" and Tctx >= 2:
+            self._decode_prefill(samples, h, F, Tctx, n_pad, state, layered, int(prefill_batch), st)
+            p = Tctx - 1
         while p < Ttot - 1:
             p1 = min(p + chunk, Ttot - 1)
             if layered:
@@ -292,6 +304,32 @@ class WaveNetEngine(object):
         if return_logits:   # row Tctx-1+i holds the logits that chose generated sample i
             return out, [logits[b, Tctx - 1:Tctx - 1 + int(n)] for b, n in enumerate(n_samples_list)]
         return out
+
+    def _decode_prefill(self, samples, h, F, Tctx, n_pad, state, layered, nbatch, st):
+        """Dilation queues of the context from one forward of the residual stack (wn_decode_prefill)."""
+        cfg = ctypes.byref(self.cfg)
+        B = samples.size(0)
+        dev = self.device
+        # groups of utterances with a bounded workspace (the training workspace of B x Tctx inputs)
+        per_utt = self.lib.wn_decode_prefill_workspace_bytes(cfg, 1, Tctx)
+        if per_utt == 0:
+            raise _lib.WnError("wn_decode_prefill_workspace_bytes: %s" % self.lib.wn_last_error().decode())
+        nbatch = max(1, min(nbatch, (8 << 30) // per_utt))
+        ws = None
+        for b0 in range(0, B, nbatch):
+            nb = min(nbatch, B - b0)
+            x_ctx = samples[b0:b0 + nb, :Tctx].contiguous()
+            h_ctx = torch.empty((nb, self.cfg.n_aux, Tctx), dtype=torch.float32, device=dev)
+            self.lib.check(self.lib.wn_decode_ctx_aux(cfg, nb, F, Tctx, n_pad, _ptr(self.flat_params), _ptr(h[b0:b0 + nb]),
+                                                      _ptr(h_ctx), st), "wn_decode_ctx_aux")
+            nbytes = self.lib.wn_decode_prefill_workspace_bytes(cfg, nb, Tctx)
+            if ws is None or ws.numel() * 4 < nbytes:
+                ws = None
+                ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+            rc = self.lib.wn_decode_prefill(cfg, nb, Tctx, _ptr(self.flat_params), _ptr(x_ctx), _ptr(h_ctx), _ptr(ws),
+                                            ws.numel() * 4, _ptr(state), state.numel(), B, b0, 1 if layered else 0, self.flags,
+                                            st)
+            self.lib.check(rc, "wn_decode_prefill")
 
 
 

@@ -59,6 +59,19 @@ def check_decode_case(name, lib, device, layered_too=True):
         for b, n in enumerate(g.n_list):
             assert float((lg2[b].cpu() - g.logits[b]).abs().max()) <= TOL_LOGITS, (name, b)
             assert (toks2[b].cpu().numpy() == g.fast[b]).all(), (name, b)
+    # the two ways of building the context's dilation queues -- one forward of the residual stack (default, as
+    # the reference does) and the teacher-forced walk of the decode kernel -- are independent kernels
+    for lay in ([False, True] if layered_too else [False]):
+        toks3, lg3 = model.engine.decode(x, h, g.n_list, mode="argmax", chunk=9, return_logits=True, layered=lay,
+                                         prefill="walk")
+        toks4, lg4 = model.engine.decode(x, h, g.n_list, mode="argmax", chunk=9, return_logits=True, layered=lay,
+                                         prefill="parallel", prefill_batch=1)   # one utterance per group
+        for b, n in enumerate(g.n_list):
+            assert float((lg3[b].cpu() - g.logits[b]).abs().max()) <= TOL_LOGITS, (name, b, lay)
+            assert (toks3[b].cpu().numpy() == g.fast[b]).all(), (name, b, lay)
+            assert float((lg4[b].cpu() - g.logits[b]).abs().max()) <= TOL_LOGITS, (name, b, lay)
+            assert float((lg3[b] - lg4[b]).abs().max()) <= TOL_LOGITS, (name, b, lay)
+            assert (toks4[b].cpu().numpy() == g.fast[b]).all(), (name, b, lay)
     # module API: single utterances (wavenet.py:309) and the batch (wavenet.py:397)
     for b, n in enumerate(g.n_list):
         hb = h[b:b + 1]

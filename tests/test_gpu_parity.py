@@ -204,17 +204,29 @@ def test_decode_cfg2_teacher_forced_equals_training_forward():
     rs = np.random.RandomState(78)
     x = torch.from_numpy(rs.randint(0, 256, (B, T0))).long().to(DEV)
     h = torch.from_numpy(rs.standard_normal((B, 80, (T0 + n) // 80)).astype(np.float32)).to(DEV)
-    toks, lg = model.engine.decode(x, h, [n, n - 17], mode="argmax", return_logits=True, chunk=1000)
-    full = torch.cat([x, torch.stack([toks[0], torch.cat([toks[1], toks[1].new_zeros(17)])])], dim=1)
-    logits = model.engine.forward(full, h)          # (B, Q, T0+n)
-    for b, nb in enumerate([n, n - 17]):
-        # generated sample i was chosen from the logits of position T0-1+i
-        ref = logits[b, :, T0 - 1:T0 - 1 + nb].transpose(0, 1)
-        assert float((lg[b] - ref).abs().max()) <= 1e-4
-        top2 = ref.topk(2, dim=1).values
+    # "walk": the decode kernel alone builds the queues (3360 teacher-forced steps); "parallel": the residual
+    # stack of the training forward builds them (what generation does by default)
+    for prefill in ("walk", "parallel"):
+        toks, lg = model.engine.decode(x, h, [n, n - 17], mode="argmax", return_logits=True, chunk=1000, prefill=prefill)
+        full = torch.cat([x, torch.stack([toks[0], torch.cat([toks[1], toks[1].new_zeros(17)])])], dim=1)
+        logits = model.engine.forward(full, h)          # (B, Q, T0+n)
+        for b, nb in enumerate([n, n - 17]):
+            # generated sample i was chosen from the logits of position T0-1+i
+            ref = logits[b, :, T0 - 1:T0 - 1 + nb].transpose(0, 1)
+            assert float((lg[b] - ref).abs().max()) <= 1e-4, prefill
+            top2 = ref.topk(2, dim=1).values
+            safe = (top2[:, 0] - top2[:, 1]) > 1e-3
+            assert bool((ref.argmax(1)[safe] == toks[b][safe]).all()), prefill
+            assert int(safe.sum()) > nb // 2
+    # a short context (one token, left padding of rf-1 positions with the first upsampled aux column replicated)
+    x1 = x[:, :1].contiguous()
+    tw, lw = model.engine.decode(x1, h, [40, 40], mode="argmax", return_logits=True, prefill="walk")
+    tp, lp = model.engine.decode(x1, h, [40, 40], mode="argmax", return_logits=True, prefill="parallel")
+    for b in range(B):
+        assert float((lw[b] - lp[b]).abs().max()) <= 1e-4
+        top2 = lw[b].topk(2, dim=1).values
         safe = (top2[:, 0] - top2[:, 1]) > 1e-3
-        assert bool((ref.argmax(1)[safe] == toks[b][safe]).all())
-        assert int(safe.sum()) > nb // 2
+        assert bool((tw[b][safe] == tp[b][safe]).all())
 
 
 def test_decode_any_size_model_uses_the_layered_path():
