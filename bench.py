@@ -106,7 +106,7 @@ def decode_report(model, device, with_cpu):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import decode_bench
     out = {"workload": "BASELINE configs[4]: fast_generate / batch_fast_generate on the configs[1] model, argmax, "
-                       "context = receptive field (3070 teacher-forced steps, reported separately)"}
+                       "context = receptive field (3070 positions, built by one forward of the residual stack; context_s reported separately)"}
     for B, n in ((1, 2000), (256, 2000)):
         m = decode_bench.measure(model, B, n, device)
         out["batch%d" % B] = {k: m[k] for k in ("us_per_step", "samples_per_sec_per_utt", "samples_per_sec", "context_s")}
