@@ -227,11 +227,15 @@ int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* params, con
  *                       large batch can be walked in groups with a bounded workspace.  Decoding then resumes
  *                       with p0 = Tctx-1, the last context position, whose logits choose the first new sample.
  *                       `ws`: wn_decode_prefill_workspace_bytes(cfg, B, Tctx) bytes; flags as wn_forward.
- * Tctx >= receptive field (the caller pads: wavenet.py:328-336). */
-int wn_decode_ctx_aux(const WnConfig* cfg, int B, int F, int Tctx, int n_pad, const float* params, const float* h,
+ * Tctx >= receptive field (the caller pads: wavenet.py:328-336).  Only the newest receptive field + kernel_size - 1
+ * positions of a context reach the queues (the dilated stack plus the causal front conv), so a long context may be
+ * passed as its tail of at least that many positions: x_ctx / h_ctx then hold positions [pos0, pos0 + Tctx) of
+ * the padded context and decoding resumes with p0 = pos0 + Tctx - 1. */
+int wn_decode_ctx_aux(const WnConfig* cfg, int B, int F, int Tctx, int n_pad, int pos0, const float* params, const float* h,
                       float* h_ctx, void* stream);
 size_t wn_decode_prefill_workspace_bytes(const WnConfig* cfg, int B, int Tctx);
-int wn_decode_prefill(const WnConfig* cfg, int B, int Tctx, const float* params, const int64_t* x_ctx, const float* h_ctx,
+int wn_decode_prefill(const WnConfig* cfg, int B, int Tctx, int pos0, const float* params, const int64_t* x_ctx,
+                      const float* h_ctx,
                       void* ws, size_t ws_bytes, float* state, int64_t state_floats, int state_B, int state_b0, int layered,
                       int flags, void* stream);
 

@@ -132,10 +132,10 @@ class WnLibrary(object):
         L.wn_decode_layered_state_floats.restype = i64
         L.wn_decode_layered_prepare.argtypes = [cfgp, i, i, vp, vp, vp, vp, i64, vp]
         L.wn_decode_layered_steps.argtypes = [cfgp, i, vp, vp, i, i, vp, i64, vp, vp, i, i, vp, i64, vp, vp, i, vp, vp]
-        L.wn_decode_ctx_aux.argtypes = [cfgp, i, i, i, i, vp, vp, vp, vp]
+        L.wn_decode_ctx_aux.argtypes = [cfgp, i, i, i, i, i, vp, vp, vp, vp]
         L.wn_decode_prefill_workspace_bytes.argtypes = [cfgp, i, i]
         L.wn_decode_prefill_workspace_bytes.restype = ctypes.c_size_t
-        L.wn_decode_prefill.argtypes = [cfgp, i, i, vp, vp, vp, vp, ctypes.c_size_t, vp, i64, i, i, i, i, vp]
+        L.wn_decode_prefill.argtypes = [cfgp, i, i, i, vp, vp, vp, vp, ctypes.c_size_t, vp, i64, i, i, i, i, vp]
         if L.wn_abi_version() != ABI_VERSION:
             raise WnError("ABI mismatch: library %d, binding %d" % (L.wn_abi_version(), ABI_VERSION))
 

@@ -1318,16 +1318,16 @@ static WnConfig ctx_cfg(const WnConfig* cfg) {
     return c0;
 }
 
-extern "C" int wn_decode_ctx_aux(const WnConfig* cfg, int B, int F, int Tctx, int n_pad, const float* params, const float* h,
-                                 float* h_ctx, void* stream) {
+extern "C" int wn_decode_ctx_aux(const WnConfig* cfg, int B, int F, int Tctx, int n_pad, int pos0, const float* params,
+                                 const float* h, float* h_ctx, void* stream) {
     api_enter();
     Dims d;
     WN_TRY(check_cfg(cfg, &d));
-    if (!params || !h || !h_ctx || B < 1 || F < 1 || Tctx < 1 || n_pad < 0) return fail(1, "bad argument");
+    if (!params || !h || !h_ctx || B < 1 || F < 1 || Tctx < 1 || n_pad < 0 || pos0 < 0) return fail(1, "bad argument");
     const Lay y = make_lay(d);
     const float* upw = d.U > 0 ? params + y.up_w : nullptr;
     const float* upb = d.U > 0 ? params + y.up_b : nullptr;
-    WN_TRY(wn_decode_ctx_aux_rows(h, upw, upb, h_ctx, B, d.A, F, d.U, Tctx, n_pad, (wn_stream_t)stream));
+    WN_TRY(wn_decode_ctx_aux_rows(h, upw, upb, h_ctx, B, d.A, F, d.U, Tctx, n_pad, pos0, (wn_stream_t)stream));
     return rt_check("wn_decode_ctx_aux");
 }
 
@@ -1337,7 +1337,7 @@ extern "C" size_t wn_decode_prefill_workspace_bytes(const WnConfig* cfg, int B, 
     return wn_workspace_bytes(&c0, B, Tctx);
 }
 
-extern "C" int wn_decode_prefill(const WnConfig* cfg, int B, int Tctx, const float* params, const int64_t* x_ctx,
+extern "C" int wn_decode_prefill(const WnConfig* cfg, int B, int Tctx, int pos0, const float* params, const int64_t* x_ctx,
                                  const float* h_ctx, void* wsp, size_t ws_bytes, float* state, int64_t state_floats, int state_B,
                                  int state_b0, int layered, int flags, void* stream) {
     api_enter();
@@ -1346,9 +1346,13 @@ extern "C" int wn_decode_prefill(const WnConfig* cfg, int B, int Tctx, const flo
     Ctx c;
     WN_TRY(make_ctx(&c, &c0, B, Tctx, wsp, ws_bytes, flags, stream));
     if (!params || !x_ctx || !h_ctx || !state) return fail(1, "NULL argument");
+    if (pos0 < 0) return fail(1, "pos0=%d", pos0);
     if (state_b0 < 0 || state_b0 + B > state_B) return fail(1, "utterances [%d, %d) outside a state of %d", state_b0, state_b0 + B, state_B);
     const Dims& d = c.d;
     if (Tctx < wn_receptive_field(cfg)) return fail(1, "context of %d positions is shorter than the receptive field", Tctx);
+    if (pos0 > 0 && Tctx < wn_receptive_field(cfg) + cfg->kernel_size - 1)
+        return fail(1, "a context tail needs receptive field + kernel_size - 1 = %d positions, got %d",
+                    wn_receptive_field(cfg) + cfg->kernel_size - 1, Tctx);
     float* qdst;
     long elem_stride, utt_stride;
     if (layered) {
@@ -1368,8 +1372,8 @@ extern "C" int wn_decode_prefill(const WnConfig* cfg, int B, int Tctx, const flo
         qdst = state + per * state_b0; elem_stride = 1; utt_stride = per;
     }
     WN_TRY(forward_stack(c, params, x_ctx, h_ctx));
-    // decoding resumes at the last context position P0 = Tctx-1 (its logits choose the first new sample)
-    WN_TRY(wn_decode_fill_queues(c.ws + c.w.X, qdst, d.L, B, d.R, Tctx, d.K, cfg->dilation_depth, Tctx - 1, elem_stride,
+    // decoding resumes at the last context position pos0 + Tctx-1 (its logits choose the first new sample)
+    WN_TRY(wn_decode_fill_queues(c.ws + c.w.X, qdst, d.L, B, d.R, Tctx, d.K, cfg->dilation_depth, Tctx - 1, pos0, elem_stride,
                                  utt_stride, c.st));
     return rt_check("wn_decode_prefill");
 }

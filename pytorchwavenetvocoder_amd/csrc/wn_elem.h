@@ -158,14 +158,14 @@ int wn_dl_select_mol(const float* out, int nm, int nb, int Q, int64_t* samples, 
 
 // ---- parallel context walk of the decode path (reference wavenet.py:338-349: the "prepare buffer" pass IS a
 // full forward over the padded context) ----
-// Sample-rate aux features of the padded context: out (B, A, T); position p reads the upsampled feature of
-// sample t = max(p - n_pad, 0) (the left padding replicates the first upsampled column, wavenet.py:336):
+// Sample-rate aux features of the padded context: out (B, A, T); column p is position pos0 + p of the padded
+// context and reads the upsampled feature of sample t = max(pos0 + p - n_pad, 0) (the left padding replicates the first upsampled column, wavenet.py:336):
 // U > 0: upw[t % U] * h[b][a][min(t / U, F-1)] + upb[0]  (ConvTranspose2d (1,U)/(1,U), wavenet.py:141-154);
 // U == 0: h[b][a][min(t, F-1)].
 int wn_decode_ctx_aux_rows(const float* h, const float* upw, const float* upb, float* out, int B, int A, int F, int U, int T,
-                           int n_pad, wn_stream_t st);
+                           int n_pad, int pos0, wn_stream_t st);
 // Dilation queues after a context of P0 positions from the layer inputs X [L][B][R][T] of a training forward:
-// for layer l the Dq = (K-1)*d_l newest positions q in [P0-Dq, P0) go to slot q % Dq,
-// dst[(queue_off(l) + slot*R + c) * elem_stride + b * utt_stride] = X[l][b][c][q].
-int wn_decode_fill_queues(const float* X, float* dst, int L, int B, int R, int T, int K, int depth, int P0, long elem_stride,
-                          long utt_stride, wn_stream_t st);
+// for layer l the Dq = (K-1)*d_l newest positions q in [P0-Dq, P0) go to slot (pos0 + q) % Dq (pos0 = absolute
+// position of column 0 of X), dst[(queue_off(l) + slot*R + c) * elem_stride + b * utt_stride] = X[l][b][c][q].
+int wn_decode_fill_queues(const float* X, float* dst, int L, int B, int R, int T, int K, int depth, int P0, int pos0,
+                          long elem_stride, long utt_stride, wn_stream_t st);

@@ -922,11 +922,11 @@ int wn_dl_select_mol(const float* out, int nm, int nb, int Q, int64_t* samples, 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WN_TPB) void k_decode_ctx_aux(const float* __restrict__ h, const float* __restrict__ upw,
                                                            const float* __restrict__ upb, float* __restrict__ out, int A, int F,
-                                                           int U, int T, int n_pad) {
+                                                           int U, int T, int n_pad, int pos0) {
     const int p = blockIdx.x * WN_TPB + threadIdx.x;
     const int a = blockIdx.y, b = blockIdx.z;
     if (p >= T) return;
-    const int t = p > n_pad ? p - n_pad : 0;
+    const int t = pos0 + p > n_pad ? pos0 + p - n_pad : 0;
     const float* hr = h + ((long)b * A + a) * F;
     float v;
     if (U > 0) {
@@ -941,16 +941,16 @@ __global__ __launch_bounds__(WN_TPB) void k_decode_ctx_aux(const float* __restri
 }
 
 int wn_decode_ctx_aux_rows(const float* h, const float* upw, const float* upb, float* out, int B, int A, int F, int U, int T,
-                           int n_pad, wn_stream_t st) {
+                           int n_pad, int pos0, wn_stream_t st) {
     WN_PROF("decode_ctx_aux", 0.0, 0.0, st);
-    if (B < 1 || A < 1 || F < 1 || T < 1 || A > 65535 || B > 65535) return 1;
+    if (B < 1 || A < 1 || F < 1 || T < 1 || A > 65535 || B > 65535 || pos0 < 0) return 1;
     WN_LAUNCH(k_decode_ctx_aux, dim3((unsigned)((T + WN_TPB - 1) / WN_TPB), (unsigned)A, (unsigned)B), dim3(WN_TPB), 0, st, h, upw,
-              upb, out, A, F, U, T, n_pad);
+              upb, out, A, F, U, T, n_pad, pos0);
     return 0;
 }
 
 __global__ __launch_bounds__(WN_TPB) void k_decode_fill_queues(const float* __restrict__ X, float* __restrict__ dst, int B, int R,
-                                                               int T, int K, int depth, int P0, long elem_stride,
+                                                               int T, int K, int depth, int P0, int pos0, long elem_stride,
                                                                long utt_stride) {
     const int l = blockIdx.x, b = blockIdx.y;
     const int Dq = (K - 1) << (l % depth);
@@ -959,16 +959,16 @@ __global__ __launch_bounds__(WN_TPB) void k_decode_fill_queues(const float* __re
     for (int i = threadIdx.x; i < Dq * R; i += WN_TPB) {  // consecutive threads read consecutive positions of one channel
         const int c = i / Dq, q = P0 - Dq + (i - c * Dq);
         if (q < 0) continue;  // zero history (the state buffer is zero initialised)
-        dst[(qoff + (long)(q % Dq) * R + c) * elem_stride + (long)b * utt_stride] = Xl[(long)c * T + q];
+        dst[(qoff + (long)((pos0 + q) % Dq) * R + c) * elem_stride + (long)b * utt_stride] = Xl[(long)c * T + q];
     }
 }
 
-int wn_decode_fill_queues(const float* X, float* dst, int L, int B, int R, int T, int K, int depth, int P0, long elem_stride,
-                          long utt_stride, wn_stream_t st) {
+int wn_decode_fill_queues(const float* X, float* dst, int L, int B, int R, int T, int K, int depth, int P0, int pos0,
+                          long elem_stride, long utt_stride, wn_stream_t st) {
     WN_PROF("decode_fill_queues", 0.0, 0.0, st);
     if (K < 2) return 0;  // no history taps, no queues
-    if (L < 1 || B < 1 || B > 65535 || P0 < 0 || P0 > T) return 1;
-    WN_LAUNCH(k_decode_fill_queues, dim3((unsigned)L, (unsigned)B), dim3(WN_TPB), 0, st, X, dst, B, R, T, K, depth, P0,
+    if (L < 1 || B < 1 || B > 65535 || P0 < 0 || P0 > T || pos0 < 0) return 1;
+    WN_LAUNCH(k_decode_fill_queues, dim3((unsigned)L, (unsigned)B), dim3(WN_TPB), 0, st, X, dst, B, R, T, K, depth, P0, pos0,
               elem_stride, utt_stride);
     return 0;
 }

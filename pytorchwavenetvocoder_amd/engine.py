@@ -310,23 +310,27 @@ class WaveNetEngine(object):
         cfg = ctypes.byref(self.cfg)
         B = samples.size(0)
         dev = self.device
-        # groups of utterances with a bounded workspace (the training workspace of B x Tctx inputs)
-        per_utt = self.lib.wn_decode_prefill_workspace_bytes(cfg, 1, Tctx)
+        # Only the newest rf + K - 1 positions reach the queues (rf - 1 through the dilated stack, K - 1 more
+        # through the causal front conv): a longer context is passed as its tail.
+        pos0 = max(0, Tctx - (self.receptive_field + self.cfg.kernel_size - 1))
+        Tpre = Tctx - pos0
+        # groups of utterances with a bounded workspace (the training workspace of nb x Tpre inputs)
+        per_utt = self.lib.wn_decode_prefill_workspace_bytes(cfg, 1, Tpre)
         if per_utt == 0:
             raise _lib.WnError("wn_decode_prefill_workspace_bytes: %s" % self.lib.wn_last_error().decode())
         nbatch = max(1, min(nbatch, (8 << 30) // per_utt))
         ws = None
         for b0 in range(0, B, nbatch):
             nb = min(nbatch, B - b0)
-            x_ctx = samples[b0:b0 + nb, :Tctx].contiguous()
-            h_ctx = torch.empty((nb, self.cfg.n_aux, Tctx), dtype=torch.float32, device=dev)
-            self.lib.check(self.lib.wn_decode_ctx_aux(cfg, nb, F, Tctx, n_pad, _ptr(self.flat_params), _ptr(h[b0:b0 + nb]),
-                                                      _ptr(h_ctx), st), "wn_decode_ctx_aux")
-            nbytes = self.lib.wn_decode_prefill_workspace_bytes(cfg, nb, Tctx)
+            x_ctx = samples[b0:b0 + nb, pos0:Tctx].contiguous()
+            h_ctx = torch.empty((nb, self.cfg.n_aux, Tpre), dtype=torch.float32, device=dev)
+            self.lib.check(self.lib.wn_decode_ctx_aux(cfg, nb, F, Tpre, n_pad, pos0, _ptr(self.flat_params),
+                                                      _ptr(h[b0:b0 + nb]), _ptr(h_ctx), st), "wn_decode_ctx_aux")
+            nbytes = self.lib.wn_decode_prefill_workspace_bytes(cfg, nb, Tpre)
             if ws is None or ws.numel() * 4 < nbytes:
                 ws = None
                 ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
-            rc = self.lib.wn_decode_prefill(cfg, nb, Tctx, _ptr(self.flat_params), _ptr(x_ctx), _ptr(h_ctx), _ptr(ws),
+            rc = self.lib.wn_decode_prefill(cfg, nb, Tpre, pos0, _ptr(self.flat_params), _ptr(x_ctx), _ptr(h_ctx), _ptr(ws),
                                             ws.numel() * 4, _ptr(state), state.numel(), B, b0, 1 if layered else 0, self.flags,
                                             st)
             self.lib.check(rc, "wn_decode_prefill")
