@@ -684,56 +684,59 @@ int wn_dl_select(const float* logits, int Q, int nb, int64_t* samples, long Ttot
     return 0;
 }
 
-__global__ __launch_bounds__(256) void k_dl_mm(WnDlMmArgs a) {
-    __shared__ float red[4][32 * 33];
+// NW waves split the K range of a 32 x 32 output tile; every wave requests the operands of up to four 16-k
+// steps before its first MFMA (a launch is a handful of dependent memory round trips, so what counts is how few
+// of them are exposed), partial tiles are summed through LDS in a fixed order.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_dl_mm(WnDlMmArgs a) {
+    __shared__ float red[NW][32 * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
     const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32, z = blockIdx.z;
     const float* __restrict__ Az = a.A + (long)z * a.a_zstride;
     const float* __restrict__ Bz = a.B + (long)z * a.b_zstride;
     // this wave's k range (multiples of 2)
-    const int kq = ((a.K + 7) / 8) * 2;
+    const int kq = ((a.K + 2 * NW - 1) / (2 * NW)) * 2;
     const int k0 = wave * kq, k1 = (k0 + kq < a.K) ? k0 + kq : a.K;
     const bool m_ok = (m0 + li) < a.M, u_ok = (n0 + li) < a.nb;
     const float* pa = Az + (m_ok ? m0 + li : 0);
     const float* pb = Bz + (u_ok ? n0 + li : 0);
     f32x16 acc = f32x16_zero();
-    // 16 k per step; the 16 loads of step s+1 are issued before the 8 MFMAs of step s (two register sets)
-    auto fetch = [&](int k, float (&av)[8], float (&bv)[8]) {
+    for (int kg = k0; kg < k1; kg += 64) {
+        float av[4][8], bv[4][8];
         WN_UNROLL
-        for (int s = 0; s < 8; ++s) {
-            const int kk = k + 2 * s + hi;
-            const bool ok = kk < k1;
-            av[s] = pa[(long)(ok ? kk : k0) * a.lda];
-            bv[s] = pb[(long)(ok ? kk : k0) * a.ldb];
-            if (!ok || !m_ok) av[s] = 0.0f;
-            if (!ok || !u_ok) bv[s] = 0.0f;
+        for (int g = 0; g < 4; ++g) {
+            WN_UNROLL
+            for (int s = 0; s < 8; ++s) {
+                const int kk = kg + 16 * g + 2 * s + hi;
+                const bool ok = kk < k1;
+                const int kc = ok ? kk : k0;   // k0 < k1 here: a valid address for the dead lanes
+                av[g][s] = pa[(long)kc * a.lda];
+                bv[g][s] = pb[(long)kc * a.ldb];
+                if (!ok || !m_ok) av[g][s] = 0.0f;
+                if (!ok || !u_ok) bv[g][s] = 0.0f;
+            }
         }
-    };
-    float a0[8], b0[8], a1[8], b1[8];
-    if (k0 < k1) fetch(k0, a0, b0);
-    for (int k = k0; k < k1; k += 32) {
-        if (k + 16 < k1) fetch(k + 16, a1, b1);
         WN_SCHED_BARRIER();
         WN_UNROLL
-        for (int s = 0; s < 8; ++s) acc = mfma32(a0[s], b0[s], acc);
-        WN_SCHED_BARRIER();
-        if (k + 16 >= k1) break;
-        if (k + 32 < k1) fetch(k + 32, a0, b0);
-        WN_SCHED_BARRIER();
-        WN_UNROLL
-        for (int s = 0; s < 8; ++s) acc = mfma32(a1[s], b1[s], acc);
-        WN_SCHED_BARRIER();
+        for (int g = 0; g < 4; ++g) {
+            if (kg + 16 * g < k1) {
+                WN_UNROLL
+                for (int s = 0; s < 8; ++s) acc = mfma32(av[g][s], bv[g][s], acc);
+            }
+        }
     }
     WN_UNROLL
-    for (int r = 0; r < 16; ++r) red[wave][mfma32_row(r, hi) * 33 + li] = acc[r];
+    for (int r = 0; r < 16; ++r) red[wave][mfma32_row(r, hi) * 32 + li] = acc[r];
     __syncthreads();
     float* Cz = a.C + (long)z * a.c_zstride;
-    for (int i = tid; i < 32 * 32; i += 256) {
+    for (int i = tid; i < 32 * 32; i += NW * 64) {
         const int row = i >> 5, col = i & 31;
         const int m = m0 + row, u = n0 + col;
         if (m < a.M && u < a.nb) {
-            float v = (red[0][row * 33 + col] + red[1][row * 33 + col]) + (red[2][row * 33 + col] + red[3][row * 33 + col]);
+            float v = 0.0f;
+            WN_UNROLL
+            for (int w = 0; w < NW; w += 4) v += (red[w][i] + red[w + 1][i]) + (red[w + 2][i] + red[w + 3][i]);
             if (a.bias) v += a.bias[m];
             if (a.D) v += a.D[(long)m * a.ldd + u];
             if (a.relu) v = fmaxf(v, 0.0f);
@@ -746,7 +749,13 @@ int wn_dl_mm(const WnDlMmArgs* a, wn_stream_t st) {
     WN_PROF(a->tag ? a->tag : "dl_mm", 2.0 * a->M * (double)a->K * a->nb * a->nz, (double)a->M * a->K * 4.0 * a->nz, st);
     if (a->M <= 0 || a->K <= 0 || a->nb <= 0 || a->nz <= 0) return 1;
     dim3 grid((unsigned)((a->M + 31) / 32), (unsigned)((a->nb + 31) / 32), (unsigned)a->nz);
-    WN_LAUNCH(k_dl_mm, grid, dim3(256), 0, st, *a);
+    // few tiles and a long K: 16 waves per tile keep every wave's range at one group of requests
+    const long tiles = (long)grid.x * grid.y * grid.z;
+    if (a->K >= 512 && tiles <= 512) {
+        WN_LAUNCH(k_dl_mm<16>, grid, dim3(1024), 0, st, *a);
+    } else {
+        WN_LAUNCH(k_dl_mm<4>, grid, dim3(256), 0, st, *a);
+    }
     return 0;
 }
 

@@ -229,6 +229,28 @@ def test_decode_cfg2_teacher_forced_equals_training_forward():
         assert bool((tw[b][safe] == tp[b][safe]).all())
 
 
+def test_decode_wide_model_layered_path_long_k():
+    """n_resch = 256: the layer-wise contractions have K = 512 and run the 16-wave variant of the skinny
+    matrix kernel; tokens / logits must still be the queue algorithm's (oracle)."""
+    from pytorchwavenetvocoder_amd.nets import WaveNet
+    cfg = O.OracleConfig(64, 6, 256, 288, 3, 2, 2, 4)
+    params = O.random_params(cfg, 11, scale=0.05)
+    model = WaveNet(*cfg.as_tuple())
+    model.load_state_dict(params)
+    model.to(DEV)
+    assert not model.engine.decode_supported()
+    x = torch.tensor([[5, 9, 1, 30], [7, 7, 2, 0], [1, 2, 3, 4]]).long()
+    h = torch.from_numpy(np.random.RandomState(12).standard_normal((3, 6, 10)).astype(np.float32))
+    ref, ref_lg = O.batch_fast_generate(cfg, params, x, h, [24, 24, 24], return_logits=True)
+    for prefill in ("parallel", "walk"):
+        toks, lg = model.engine.decode(x.to(DEV), h.to(DEV), [24, 24, 24], return_logits=True, prefill=prefill)
+        for b in range(3):
+            assert float((lg[b].cpu() - ref_lg[b]).abs().max()) <= 1e-4, (prefill, b)
+            top2 = ref_lg[b].topk(2, dim=1).values
+            safe = ((top2[:, 0] - top2[:, 1]) > 1e-3).numpy()
+            assert (toks[b].cpu().numpy()[safe] == ref[b][safe]).all(), (prefill, b)
+
+
 def test_decode_any_size_model_uses_the_layered_path():
     """n_resch = 128 is outside the compiled classes of the persistent decode kernel: fast_generate /
     batch_fast_generate run the layer-wise path and must reproduce the queue algorithm (oracle)."""
