@@ -1237,6 +1237,7 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
     a.G = G; a.samples = samples; a.Ttot = Ttot;
     a.queues = ws + y.queues; a.xin = ws + y.xin; a.gstep = ws + y.gstep;
     const long RB = (long)d.R * nb;
+    const bool gate_fused = d.R % 16 == 0;
     for (int p = p0; p < p1; ++p) {
         a.p = p;
         WN_TRY(wn_dl_inputs(&a, c.st));
@@ -1251,10 +1252,16 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
                 g.B = xin_l; g.ldb = nb; g.b_zstride = 0;
                 g.C = ws + y.P; g.ldc = nb; g.c_zstride = 0;
                 g.bias = nullptr; g.D = nullptr; g.ldd = 0; g.relu = 0; g.nz = 1; g.tag = "dl_dilated";
+                g.gate_R = 0; g.gate_g = nullptr; g.gate_c = nullptr;
+                if (gate_fused) {  // z = sigmoid(.)*tanh(.) in the epilogue (wavenet.py:542-544): one launch less per layer
+                    g.gate_R = d.R; g.gate_g = ws + y.gstep + (long)l * 2 * RB; g.gate_c = ws + w.cvec + (long)l * 2 * d.R;
+                    g.C = z_l;
+                }
                 WN_TRY(wn_dl_mm(&g, c.st));
             }
-            WN_TRY(wn_gate_fwd(ws + y.P, ws + y.gstep + (long)l * 2 * RB, 0, ws + w.one, ws + w.cvec + (long)l * 2 * d.R,
-                               ws + y.Sg, ws + y.Gt, z_l, 1, nb, d.R, 1, nb, c.st));
+            if (!gate_fused)
+                WN_TRY(wn_gate_fwd(ws + y.P, ws + y.gstep + (long)l * 2 * RB, 0, ws + w.one, ws + w.cvec + (long)l * 2 * d.R,
+                                   ws + y.Sg, ws + y.Gt, z_l, 1, nb, d.R, 1, nb, c.st));
             if (l + 1 < d.L) {  // next layer input = res_1x1(z) + x  (wavenet.py:546-548)
                 WnDlMmArgs r;
                 r.M = d.R; r.K = d.R; r.nb = nb;
@@ -1264,6 +1271,7 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
                 r.bias = params + lb + lay.o_res_b;
                 r.D = xin_l + (long)(d.K - 1) * RB; r.ldd = nb;
                 r.relu = 0; r.nz = 1; r.tag = "dl_res";
+                r.gate_R = 0; r.gate_g = nullptr; r.gate_c = nullptr;
                 WN_TRY(wn_dl_mm(&r, c.st));
             }
         }
@@ -1274,6 +1282,7 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
             g.B = ws + y.Zcat; g.ldb = nb; g.b_zstride = RB;
             g.C = ws + y.skpart; g.ldc = nb; g.c_zstride = (long)d.S * nb;
             g.bias = nullptr; g.D = nullptr; g.ldd = 0; g.relu = 0; g.nz = d.L; g.tag = "dl_skip";
+            g.gate_R = 0; g.gate_g = nullptr; g.gate_c = nullptr;
             WN_TRY(wn_dl_mm(&g, c.st));
             WN_TRY(wn_dl_sum(ws + y.skpart, d.L, (long)d.S * nb, d.S, nb, ws + w.bskip, 1, ws + y.O1, c.st));
         }
@@ -1284,6 +1293,7 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
             g.B = ws + y.O1; g.ldb = nb; g.b_zstride = 0;
             g.C = ws + y.O2; g.ldc = nb; g.c_zstride = 0;
             g.bias = params + lay.post1_b; g.D = nullptr; g.ldd = 0; g.relu = 1; g.nz = 1; g.tag = "dl_post1";
+            g.gate_R = 0; g.gate_g = nullptr; g.gate_c = nullptr;
             WN_TRY(wn_dl_mm(&g, c.st));
         }
         {
@@ -1293,6 +1303,7 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
             g.B = ws + y.O2; g.ldb = nb; g.b_zstride = 0;
             g.C = ws + y.logits; g.ldc = nb; g.c_zstride = 0;
             g.bias = params + lay.post2_b; g.D = nullptr; g.ldd = 0; g.relu = 0; g.nz = 1; g.tag = "dl_post2";
+            g.gate_R = 0; g.gate_g = nullptr; g.gate_c = nullptr;
             WN_TRY(wn_dl_mm(&g, c.st));
         }
         if (mode == 2)

@@ -136,6 +136,12 @@ typedef struct WnDlMmArgs {
     int relu;
     int nz;
     const char* tag;
+    // Gate epilogue (gate_R > 0, M = 2*gate_R, gate_R % 16 == 0): a tile holds rows c0..c0+15 (sigmoid half) and
+    // gate_R+c0.. (tanh half) of the same 16 channels and writes C[c][u] = sigmoid(acc_s + (gate_g[c][u] + gate_c[c])) *
+    // tanh(acc_t + (gate_g[R+c][u] + gate_c[R+c]))  (wavenet.py:542-544) instead of the 2R pre-activations.
+    int gate_R;
+    const float* gate_g;  // [2R][nb] aux pre-activations of this layer and step
+    const float* gate_c;  // [2R] constant part
 } WnDlMmArgs;
 int wn_dl_mm(const WnDlMmArgs* a, wn_stream_t st);
 // out[m][u] = relu?( sum_z part[z][m][u] + bias[m] )

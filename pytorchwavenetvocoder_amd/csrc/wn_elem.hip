@@ -698,8 +698,11 @@ __global__ __launch_bounds__(NW * 64) void k_dl_mm(WnDlMmArgs a) {
     // this wave's k range (multiples of 2)
     const int kq = ((a.K + 2 * NW - 1) / (2 * NW)) * 2;
     const int k0 = wave * kq, k1 = (k0 + kq < a.K) ? k0 + kq : a.K;
-    const bool m_ok = (m0 + li) < a.M, u_ok = (n0 + li) < a.nb;
-    const float* pa = Az + (m_ok ? m0 + li : 0);
+    // row of the weight matrix behind tile row li: plain tiles are 32 consecutive rows; gate tiles pair the
+    // sigmoid and the tanh row of 16 channels
+    const int mrow = a.gate_R > 0 ? ((li < 16) ? blockIdx.x * 16 + li : a.gate_R + blockIdx.x * 16 + (li - 16)) : m0 + li;
+    const bool m_ok = mrow < a.M, u_ok = (n0 + li) < a.nb;
+    const float* pa = Az + (m_ok ? mrow : 0);
     const float* pb = Bz + (u_ok ? n0 + li : 0);
     f32x16 acc = f32x16_zero();
     for (int kg = k0; kg < k1; kg += 64) {
@@ -730,6 +733,25 @@ __global__ __launch_bounds__(NW * 64) void k_dl_mm(WnDlMmArgs a) {
     for (int r = 0; r < 16; ++r) red[wave][mfma32_row(r, hi) * 32 + li] = acc[r];
     __syncthreads();
     float* Cz = a.C + (long)z * a.c_zstride;
+    if (a.gate_R > 0) {
+        const int R = a.gate_R;
+        for (int i = tid; i < 16 * 32; i += NW * 64) {
+            const int row = i >> 5, col = i & 31;
+            const int c = blockIdx.x * 16 + row, u = n0 + col;
+            if (c < R && u < a.nb) {
+                float vs = 0.0f, vt = 0.0f;
+                WN_UNROLL
+                for (int w = 0; w < NW; w += 4) {
+                    vs += (red[w][i] + red[w + 1][i]) + (red[w + 2][i] + red[w + 3][i]);
+                    vt += (red[w][i + 512] + red[w + 1][i + 512]) + (red[w + 2][i + 512] + red[w + 3][i + 512]);
+                }
+                const float ps = vs + (a.gate_g[(long)c * a.nb + u] + a.gate_c[c]);
+                const float pt = vt + (a.gate_g[(long)(R + c) * a.nb + u] + a.gate_c[R + c]);
+                Cz[(long)c * a.ldc + u] = wn_sigmoid(ps) * wn_tanh(pt);
+            }
+        }
+        return;
+    }
     for (int i = tid; i < 32 * 32; i += NW * 64) {
         const int row = i >> 5, col = i & 31;
         const int m = m0 + row, u = n0 + col;
@@ -748,7 +770,8 @@ __global__ __launch_bounds__(NW * 64) void k_dl_mm(WnDlMmArgs a) {
 int wn_dl_mm(const WnDlMmArgs* a, wn_stream_t st) {
     WN_PROF(a->tag ? a->tag : "dl_mm", 2.0 * a->M * (double)a->K * a->nb * a->nz, (double)a->M * a->K * 4.0 * a->nz, st);
     if (a->M <= 0 || a->K <= 0 || a->nb <= 0 || a->nz <= 0) return 1;
-    dim3 grid((unsigned)((a->M + 31) / 32), (unsigned)((a->nb + 31) / 32), (unsigned)a->nz);
+    if (a->gate_R > 0 && (a->gate_R % 16 != 0 || a->M != 2 * a->gate_R || !a->gate_g || !a->gate_c)) return 1;
+    dim3 grid((unsigned)(a->gate_R > 0 ? a->gate_R / 16 : (a->M + 31) / 32), (unsigned)((a->nb + 31) / 32), (unsigned)a->nz);
     // few tiles and a long K: 16 waves per tile keep every wave's range at one group of requests
     const long tiles = (long)grid.x * grid.y * grid.z;
     if (a->K >= 512 && tiles <= 512) {
