@@ -192,11 +192,13 @@ int wn_decode_pack(const WnConfig* cfg, const float* params, float* wpack, void*
  * of wavenet.py:136 per sample), samples otherwise. */
 int wn_decode_aux(const WnConfig* cfg, int B, int F, const float* wpack, const float* h, float* G, void* stream);
 /* mode: 0 argmax, 1 categorical sampling with the caller's uniform draws `uniforms` (B, Ttot)
- * (draw [b][p+1] picks the token of position p+1).  logits_out (B, Ttot, Q) is optional (row p =
- * the logits computed by step p).  `state` (B, wn_decode_state_floats) must be zero before step 0. */
+ * (draw [b][p+1] picks the token of position p+1), 2 mixture-of-logistics head (out_channels = 3*n_mix, n_mix <= 64;
+ * not in the reference): uniforms is (B, Ttot, n_mix+1), the drawn value goes to wave_out (B, Ttot) (nullable) and,
+ * mu-law encoded with n_quantize levels, to samples.  logits_out (B, Ttot, out_channels) is optional (row p = the
+ * network output computed by step p).  `state` (B, wn_decode_state_floats) must be zero before step 0. */
 int wn_decode_steps(const WnConfig* cfg, int B, const float* params, const float* wpack, const float* G, int F, int n_pad,
                     int64_t* samples, int64_t Ttot, const int32_t* t_forced, const int32_t* t_end, int p0, int p1,
-                    float* state, const float* uniforms, float* logits_out, int mode, void* stream);
+                    float* state, const float* uniforms, float* logits_out, int mode, float* wave_out, void* stream);
 
 /* Any-size variant of the same decode (layer-wise launches of the contraction kernels on [channels x B]
  * operands: one pass over the weights per step serves the whole batch).  Same positions / teacher forcing

@@ -126,7 +126,7 @@ class WnLibrary(object):
         L.wn_decode_stream_bytes.restype = i64
         L.wn_decode_pack.argtypes = [cfgp, vp, vp, vp]
         L.wn_decode_aux.argtypes = [cfgp, i, i, vp, vp, vp, vp]
-        L.wn_decode_steps.argtypes = [cfgp, i, vp, vp, vp, i, i, vp, i64, vp, vp, i, i, vp, vp, vp, i, vp]
+        L.wn_decode_steps.argtypes = [cfgp, i, vp, vp, vp, i, i, vp, i64, vp, vp, i, i, vp, vp, vp, i, vp, vp]
         L.wn_mol_loss.argtypes = [cfgp, i, i, vp, vp, i, f, f, i, f, vp, vp, vp, sz, vp]
         L.wn_decode_layered_state_floats.argtypes = [cfgp, i]
         L.wn_decode_layered_state_floats.restype = i64

@@ -983,11 +983,12 @@ extern "C" int wn_op_causal_conv(const float* weight, const float* bias, const f
 // ------------------------------------------------------------------------------------------
 static int decode_plan(const WnConfig* cfg, Dims* d, WnDecodePlan* pl) {
     WN_TRY(check_cfg(cfg, d));
-    wn_decode_make_plan(d->Q, d->A, d->R, d->S, d->L, d->K, cfg->dilation_depth, pl);
-    if (d->Qo != d->Q) pl->ok = 0;  // other output heads generate through the layer-wise path
+    wn_decode_make_plan(d->Qo, d->A, d->R, d->S, d->L, d->K, cfg->dilation_depth, pl);
+    if (d->Q > 256) pl->ok = 0;
+    if (d->Qo != d->Q && (d->Qo % 3 != 0 || d->Qo / 3 > 64)) pl->ok = 0;  // mixture head: one lane per component
     if (!pl->ok)
         return fail(3, "decode kernel: configuration not covered (needs n_resch<=64, n_skipch<=256, n_quantize<=256, "
-                       "kernel_size<=3); use full-window forwards");
+                       "out_channels<=256, kernel_size<=3); use the layer-wise path");
     return 0;
 }
 
@@ -1030,7 +1031,7 @@ extern "C" int wn_decode_pack(const WnConfig* cfg, const float* params, float* w
     wn_stream_t st = (wn_stream_t)stream;
     const long lb0 = layer_base(y, d, 0), lstep = -y.LB;
     WnDecodePackArgs pa;
-    pa.Q = d.Q; pa.R = d.R; pa.S = d.S; pa.L = d.L; pa.K = d.K;
+    pa.Q = d.Qo; pa.R = d.R; pa.S = d.S; pa.L = d.L; pa.K = d.K;  // Q of the packer = rows of conv_post_2
     pa.plan = pl;
     pa.params = params;
     pa.lb0 = lb0; pa.lstep = lstep;
@@ -1086,7 +1087,7 @@ extern "C" int wn_decode_aux(const WnConfig* cfg, int B, int F, const float* wpa
 extern "C" int wn_decode_steps(const WnConfig* cfg, int B, const float* params, const float* wpack, const float* G, int F,
                                int n_pad, int64_t* samples, int64_t Ttot, const int32_t* t_forced, const int32_t* t_end,
                                int p0, int p1, float* state, const float* uniforms, float* logits_out, int mode,
-                               void* stream) {
+                               float* wave_out, void* stream) {
     api_enter();
     Dims d;
     WnDecodePlan pl;
@@ -1094,12 +1095,13 @@ extern "C" int wn_decode_steps(const WnConfig* cfg, int B, const float* params, 
     if (!params || !wpack || !G || !samples || !t_forced || !t_end || !state) return fail(1, "NULL argument");
     if (B <= 0 || F <= 0 || n_pad < 0 || p0 < 0 || p1 < p0 || Ttot <= 0 || p1 > Ttot - 1)
         return fail(1, "bad decode range: B=%d F=%d n_pad=%d steps [%d,%d) Ttot=%ld", B, F, n_pad, p0, p1, (long)Ttot);
-    if (mode != 0 && mode != 1) return fail(1, "mode should be 0 (argmax) or 1 (sampling)");
-    if (mode == 1 && !uniforms) return fail(1, "sampling mode needs the uniform draws");
+    if (mode != 0 && mode != 1 && mode != 2) return fail(1, "mode should be 0 (argmax), 1 (sampling) or 2 (mixture of logistics)");
+    if (mode != 0 && !uniforms) return fail(1, "sampling modes need the uniform draws");
+    if (mode == 2 && (d.Qo % 3 != 0 || d.Qo == d.Q)) return fail(1, "mode 2 needs out_channels = 3 * n_mixture");
     if (p1 == p0) return 0;
     const Lay y = make_lay(d);
     WnDecodeArgs a;
-    a.Q = d.Q; a.A = d.A; a.R = d.R; a.S = d.S; a.L = d.L; a.K = d.K; a.depth = cfg->dilation_depth;
+    a.Q = d.Q; a.Qo = d.Qo; a.A = d.A; a.R = d.R; a.S = d.S; a.L = d.L; a.K = d.K; a.depth = cfg->dilation_depth;
     a.plan = pl;
     a.wpack = wpack;
     a.params = params;
@@ -1113,9 +1115,10 @@ extern "C" int wn_decode_steps(const WnConfig* cfg, int B, const float* params, 
     a.t_forced = t_forced; a.t_end = t_end;
     a.p0 = p0; a.p1 = p1;
     a.queues = state; a.q_bstride = pl.queue_floats > 0 ? pl.queue_floats : 4;
-    a.uniforms = uniforms; a.u_bstride = Ttot;
-    a.logits_out = logits_out; a.lo_bstride = Ttot * d.Q;
+    a.uniforms = uniforms; a.u_bstride = Ttot;   // mode 2: rows of nm+1 draws, indexed (b*Ttot + p+1)*(nm+1)
+    a.logits_out = logits_out; a.lo_bstride = Ttot * d.Qo;
     a.mode = mode;
+    a.wave_out = wave_out; a.w_bstride = Ttot;
     WN_TRY(wn_decode_launch(&a, B, (wn_stream_t)stream));
     return rt_check("wn_decode_steps");
 }

@@ -28,6 +28,7 @@ typedef struct WnDecodePlan {
 
 typedef struct WnDecodeArgs {
     int Q, A, R, S, L, K, depth;
+    int Qo;               // rows of conv_post_2: Q (softmax head) or 3*n_mix (mixture-of-logistics head)
     WnDecodePlan plan;
     const float* wpack;   // packed decode weights (stream + side tables)
     const float* params;  // flat parameter buffer (biases, front conv, upsampling weights)
@@ -44,17 +45,20 @@ typedef struct WnDecodeArgs {
     int p0, p1;           // steps [p0, p1)
     float* queues;        // (B, queue_floats), zero before step 0
     long q_bstride;
-    const float* uniforms;  // nullable (B, Ttot): uniform draw used for position p+1 at [p+1]
+    const float* uniforms;  // nullable (B, Ttot): uniform draw used for position p+1 at [p+1]; mode 2: (B, Ttot, nm+1)
     long u_bstride;
-    float* logits_out;    // nullable (B, Ttot, Q): row p = logits computed by step p
+    float* logits_out;    // nullable (B, Ttot, Qo): row p = network output computed by step p
     long lo_bstride;
-    int mode;             // 0 argmax, 1 sampling
+    int mode;             // 0 argmax, 1 sampling, 2 mixture of logistics (Qo = 3*nm, nm <= 64)
+    float* wave_out;      // mode 2, nullable (B, Ttot): the drawn waveform value of position p+1
+    long w_bstride;
 #ifdef WN_TIMING
     long long* dbg;
 #endif
 } WnDecodeArgs;
 
 // Fills the plan for the configuration; plan->ok == 0 if no compiled class covers it.
+// Q here = rows of conv_post_2 (out_channels)
 void wn_decode_make_plan(int Q, int A, int R, int S, int L, int K, int depth, WnDecodePlan* plan);
 
 struct WnDecodePackArgs {

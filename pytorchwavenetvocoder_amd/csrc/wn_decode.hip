@@ -239,7 +239,7 @@ __global__ __launch_bounds__(WN_DT) void k_decode(WnDecodeArgs a) {
     WN_DYN_SMEM(smem_raw);
     float* lds = reinterpret_cast<float*>(smem_raw);
     const int tid = threadIdx.x, b = blockIdx.x;
-    const int R = a.R, S = a.S, Q = a.Q, L = a.L, K = a.K, depth = a.depth;
+    const int R = a.R, S = a.S, Q = a.Q, Qo = a.Qo, L = a.L, K = a.K, depth = a.depth;
     const WnDecodePlan& pl = a.plan;
     const int R4 = pl.R4, S4 = pl.S4;
     const int XS = K * R4 * 4;         // floats of one layer's input window [tap][R4*4]
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(WN_DT) void k_decode(WnDecodeArgs a) {
         b_sk[i] = bskip[i];
         b_p1[i] = P[a.off_post1_b + i];
     }
-    for (int i = tid; i < Q; i += WN_DT) b_p2[i] = P[a.off_post2_b + i];
+    for (int i = tid; i < Qo; i += WN_DT) b_p2[i] = P[a.off_post2_b + i];
     for (int i = tid; i < nG; i += WN_DT) c_lds[i] = cvec[i];
     for (int i = tid; i < R; i += WN_DT) b_front[i] = P[a.off_causal_b + i];
     if (tid < 8) {
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(WN_DT) void k_decode(WnDecodeArgs a) {
                 W[j % UL] = wn_buf_load4(stream, voff, ((j / UL + 1 < NPL) ? (unsigned)(L + j / UL + 1) * LB : 0u) + (j % UL) * UB);
             }
             const float acc = group_sum(acc2.x + acc2.y, pl.lg_p2);
-            if (part_2 == 0) lgt[o_2] = o_2 < Q ? acc + b_p2[o_2] : -3.0e38f;
+            if (part_2 == 0) lgt[o_2] = o_2 < Qo ? acc + b_p2[o_2] : -3.0e38f;
             // slots of the padded tail are never consumed: refill them with layer 0 directly
             WN_UNROLL
             for (int j = UP; j < NPL * UL; ++j) W[j % UL] = wn_buf_load4(stream, voff, (j % UL) * UB);
@@ -481,17 +481,55 @@ __global__ __launch_bounds__(WN_DT) void k_decode(WnDecodeArgs a) {
         DSTAMP(4);
         // ---- next token: argmax or categorical draw (wavenet.py:370-378) -------------------------
         if (a.logits_out != nullptr) {
-            float* lo = a.logits_out + (long)b * a.lo_bstride + (long)p * Q;
-            for (int q = tid; q < Q; q += WN_DT) lo[q] = lgt[q];
+            float* lo = a.logits_out + (long)b * a.lo_bstride + (long)p * Qo;
+            for (int q = tid; q < Qo; q += WN_DT) lo[q] = lgt[q];
         }
-        if (tid < 64) {
+        if (a.mode == 2) {
+            // mixture-of-logistics head (not in the reference; same draw as k_dl_select_mol): component by Gumbel
+            // max over the nm mixture logits, value = mean + scale * logit(u), clipped, mu-law token for the front end
+            if (tid < 64) {
+                const int nm = Qo / 3;
+                const bool gen = p + 1 >= t_forced;
+                const float* un = a.uniforms + ((long)b * a.u_bstride + p + 1) * (nm + 1);
+                float best = -3.0e38f;
+                int bi = 0x7fffffff;
+                if (gen && tid < nm) {
+                    best = lgt[tid] - logf(-logf(un[tid]));
+                    bi = tid;
+                }
+                for (int m = 1; m < 64; m <<= 1) {
+                    const float ov = __shfl_xor(best, m, 64);
+                    const int oi = __shfl_xor(bi, m, 64);
+                    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+                }
+                if (tid == 0) {
+                    int next;
+                    if (!gen) {
+                        const long v = (long)(smp[p + 1] % Q);
+                        next = (int)(v < 0 ? v + Q : v);
+                    } else {
+                        const float mean = lgt[nm + bi];
+                        const float ls = fmaxf(lgt[2 * nm + bi], -7.0f);
+                        const float uu = un[nm];
+                        float xv = mean + expf(ls) * (logf(uu) - logf(1.0f - uu));
+                        xv = fminf(fmaxf(xv, -1.0f), 1.0f);
+                        if (a.wave_out) a.wave_out[(long)b * a.w_bstride + p + 1] = xv;
+                        const float mu = (float)(Q - 1);
+                        const float fx = copysignf(logf(1.0f + mu * fabsf(xv)) / logf(1.0f + mu), xv);
+                        next = (int)floorf((fx + 1.0f) * 0.5f * mu + 0.5f);
+                        smp[p + 1] = next;
+                    }
+                    tokh[(p + 1) & 7] = next;
+                }
+            }
+        } else if (tid < 64) {
             const int per = Qpad >= 64 ? (Qpad >> 6) : 1;
             const int q0 = tid * per;
             float best = -3.0e38f;
             int bi = 0x7fffffff;
             for (int i = 0; i < per; ++i) {
                 const int q = q0 + i;
-                if (q < Q) {
+                if (q < Qo) {
                     const float v = lgt[q];
                     if (v > best || bi == 0x7fffffff) { best = v; bi = q; }
                 }
@@ -506,7 +544,7 @@ __global__ __launch_bounds__(WN_DT) void k_decode(WnDecodeArgs a) {
                 float lsum = 0.f;
                 for (int i = 0; i < per; ++i) {
                     const int q = q0 + i;
-                    if (q < Q) lsum += expf(lgt[q] - best);
+                    if (q < Qo) lsum += expf(lgt[q] - best);
                 }
                 float incl = lsum;  // inclusive scan over lanes
                 for (int off = 1; off < 64; off <<= 1) {
@@ -519,7 +557,7 @@ __global__ __launch_bounds__(WN_DT) void k_decode(WnDecodeArgs a) {
                 float run = incl - lsum;
                 for (int i = 0; i < per; ++i) {
                     const int q = q0 + i;
-                    if (q < Q) {
+                    if (q < Qo) {
                         run += expf(lgt[q] - best);
                         if (cand == 0x7fffffff && run >= target) cand = q;
                     }

@@ -244,8 +244,6 @@ class WaveNetEngine(object):
         Ttot = Tctx + n_max
         if layered is None:
             layered = not self.decode_supported()
-        if mode == "mol" and not layered:
-            raise ValueError("the mixture-of-logistics head generates through the layer-wise path")
         if prefill not in ("parallel", "walk"):
             raise ValueError("prefill should be parallel or walk")
         st = _stream_handle(self.device)
@@ -293,7 +291,7 @@ class WaveNetEngine(object):
             else:
                 rc = self.lib.wn_decode_steps(cfg, B, _ptr(self.flat_params), _ptr(wpack), _ptr(G), F, n_pad, _ptr(samples),
                                               Ttot, _ptr(t_forced), _ptr(t_end), p, p1, _ptr(state), _ptr(uniforms),
-                                              _ptr(logits), 1 if mode == "sampling" else 0, st)
+                                              _ptr(logits), {"argmax": 0, "sampling": 1, "mol": 2}[mode], _ptr(wave), st)
                 self.lib.check(rc, "wn_decode_steps")
             p = p1
             if progress is not None:

@@ -93,7 +93,16 @@ def check_mol_generation(lib, device):
     xs = torch.tensor([[3, 17], [30, 1]]).long()
     hs = torch.from_numpy(np.random.RandomState(12).standard_normal((2, 4, 8)).astype(np.float32))
     n = 14
-    toks, outs = model.engine.decode(xs.to(device), hs.to(device), [n, n - 5], mode="mol", return_logits=True)
+    assert model.engine.decode_supported()   # the persistent kernel covers this size; both paths are checked
+    for layered in (False, True):
+        _check_mol_generation_path(model, cfg, params, xs, hs, n, device, layered)
+    # module API: fast_generate draws from the mixture, values in range
+    out = model.fast_generate(xs[:1].to(device), hs[:1].to(device), 10, mode="sampling")
+    assert out.shape == (10,) and out.min() >= 0 and out.max() < cfg.n_quantize
+
+
+def _check_mol_generation_path(model, cfg, params, xs, hs, n, device, layered):
+    toks, outs = model.engine.decode(xs.to(device), hs.to(device), [n, n - 5], mode="mol", return_logits=True, layered=layered)
     u = model.engine.last_uniforms.cpu()
     wave = [w.cpu() for w in model.engine.last_wave]
     rf = cfg.receptive_field
@@ -112,6 +121,3 @@ def check_mol_generation(lib, device):
             if abs(abs(xo) - 1.0) > 1e-3:   # away from the clip, the mu-law bin of the value
                 tok = int(encode_mu_law(np.array([float(wave[b][i])]), cfg.n_quantize)[0])
                 assert abs(tok - int(toks[b][i])) <= 1     # fp32 vs fp64 mu-law at a bin edge
-    # module API: fast_generate draws from the mixture, values in range
-    out = model.fast_generate(xs[:1].to(device), hs[:1].to(device), 10, mode="sampling")
-    assert out.shape == (10,) and out.min() >= 0 and out.max() < cfg.n_quantize
