@@ -228,6 +228,8 @@ class WaveNetEngine(object):
             raise ValueError("x must be a LongTensor (B, T) and h a FloatTensor (B, n_aux, F)")
         if mode not in ("argmax", "sampling", "mol"):
             raise ValueError("mode should be sampling, argmax or mol")
+        if mode == "mol" and (self.out_channels % 3 != 0 or self.out_channels == self.cfg.n_quantize):
+            raise ValueError("mode mol needs a model with the mixture-of-logistics head (n_mixture)")
         n_mix = self.out_channels // 3 if mode == "mol" else 0
         cfg = ctypes.byref(self.cfg)
         B, T0 = x.shape
