@@ -89,3 +89,38 @@ def test_cpu_tensors_rejected_by_product_binding():
     h = torch.zeros(1, 4, 8)
     with pytest.raises(_lib.WnError):
         model(x, h)
+
+
+def test_decode_context_lengths_and_ragged_requests():
+    """Contexts shorter than / equal to / longer than the receptive field (left padding, exact fit, the tail
+    passed to the one-pass context), zero-length and ragged requests, K = 3 and no upsampling layer, on both
+    decode paths: walking the context == one pass over it, and both == the queue algorithm (oracle)."""
+    import numpy as np
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd.nets import WaveNet
+    for cfg_t in [(16, 4, 8, 12, 3, 2, 2, 4), (16, 4, 8, 12, 2, 2, 3, 0)]:
+        cfg = O.OracleConfig(*cfg_t)
+        params = O.random_params(cfg, 5, scale=0.3)
+        m = WaveNet(*cfg_t, _library=emu_library())
+        m.load_state_dict(params)
+        rf = m.receptive_field
+        for T0 in (1, rf, rf + 1, 3 * rf):
+            rs = np.random.RandomState(T0)
+            x = torch.from_numpy(rs.randint(0, 16, (3, T0))).long()
+            U = cfg_t[7]
+            tot = T0 + 9
+            h = torch.from_numpy(rs.standard_normal((3, 4, (tot + U - 1) // U if U > 0 else tot)).astype(np.float32))
+            ns = [9, 0, 1]
+            for lay in (False, True):
+                a, la = m.engine.decode(x, h, ns, return_logits=True, layered=lay, prefill="walk")
+                b, lb = m.engine.decode(x, h, ns, return_logits=True, layered=lay, prefill="parallel")
+                for i, n in enumerate(ns):
+                    assert a[i].numel() == n and b[i].numel() == n
+                    if n:
+                        assert float((la[i] - lb[i]).abs().max()) < 1e-4, (cfg_t, T0, lay, i)
+                        assert (a[i] == b[i]).all(), (cfg_t, T0, lay, i)
+            ref, rl = O.batch_fast_generate(cfg, params, x, h, [9, 9, 9], return_logits=True)
+            c, lc = m.engine.decode(x, h, [9, 9, 9], return_logits=True)
+            for i in range(3):
+                assert float((lc[i] - rl[i]).abs().max()) < 1e-4, (cfg_t, T0, i)
+                assert (c[i].numpy() == ref[i]).all(), (cfg_t, T0, i)
