@@ -6,7 +6,9 @@
  *
  * Conventions
  *   - plain C types only: device pointers + sizes; the caller (PyTorch-ROCm, or any HIP program)
- *     owns every buffer, the library allocates nothing and keeps no state between calls;
+ *     owns every buffer, the library allocates no device memory and keeps no state between calls
+ *     (one exception: wn_backward creates ONE internal non-blocking stream and a few events per device
+ *     on first use, unless WN_FLAG_NO_OVERLAP);
  *   - activations are channel-major fp32 (B, C, T) exactly like the reference's tensors; sample
  *     indices are int64 (torch.long); logits are written physically as (B, Q, T) -- the
  *     reference's `(B, T, Q)` result is the `.transpose(1, 2)` view of that buffer
@@ -81,6 +83,12 @@ enum {
 #define WN_FLAG_EXACT_MFMA 2 /* every contraction on the exact f32-input MFMA (default: the skip-sum / post-net
                               * contractions run on the bf16 matrix cores with a 3-way operand split whose six
                               * products reproduce fp32 to round-off; csrc/wn_gemm6.hip) */
+#define WN_FLAG_FWD_OVERLAP 8 /* wn_forward (fused kernels): the skip-sum contraction is issued in three chunks of layers on
+                               * the internal side stream while the residual stack is still running (the partial sums
+                               * round differently from the single contraction: ~1e-7 relative on the logits) */
+#define WN_FLAG_NO_OVERLAP 4 /* wn_backward: keep the weight-gradient contractions on the caller's stream.  Default: they
+                              * run on an internal side stream beside the gate'/dX chain (fork/join with events inside
+                              * the call; results are bit-identical either way).  Also serial while wn_prof_enable(1) */
 
 int wn_abi_version(void);
 const char* wn_last_error(void);

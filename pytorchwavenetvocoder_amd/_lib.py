@@ -65,6 +65,8 @@ class WnGemmArgs(ctypes.Structure):
 
 FLAG_NO_FUSED = 1
 FLAG_EXACT_MFMA = 2
+FLAG_FWD_OVERLAP = 8  # wn_forward: chunked skip-sum beside the residual stack (side stream)
+FLAG_NO_OVERLAP = 4  # wn_backward: weight gradients on the caller stream (default: internal side stream)
 ABI_VERSION = 3
 
 # every symbol include/wavenet_hip.h declares

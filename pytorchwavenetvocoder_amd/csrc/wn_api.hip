@@ -13,6 +13,7 @@
 #include "wn_fused.h"
 #include "wn_gemm.h"
 #include "wn_gemm6.h"
+#include "wn_prof.h"
 
 // ------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -47,6 +48,83 @@ static int rt_check(const char* where) {
     return 0;
 }
 static void rt_event_record(void* ev, wn_stream_t st) { (void)hipEventRecord((hipEvent_t)ev, st); }
+#endif
+
+// ------------------------------------------------------------------------------------------
+// Internal side stream of wn_backward.  The data chain of the backward pass (gate', dX: 2 dependent launches per
+// layer, HBM-bound) and the weight-gradient contractions of the layers already walked (matrix-core-bound) do not
+// depend on each other, so the latter are enqueued on a second stream: they fill the drain/ramp gap between two
+// dependent chain launches and the partial last round of their tiles.  Fork/join with events; the caller sees
+// the usual stream semantics (everything is complete in `stream` order when the call's work retires).
+// One non-blocking stream + event pool per device, created on first use and kept (the only state of the library);
+// a mutex makes the record/wait pairs of concurrent callers atomic.  WN_FLAG_NO_OVERLAP, or per-launch profiling
+// (wn_prof_enable), keeps everything on the caller's stream.
+// ------------------------------------------------------------------------------------------
+#ifdef WN_EMU
+struct SideRt {
+    wn_stream_t st;
+};
+struct SideLock {   // emulator: one in-order "stream", but the overlap launch sequences (chunked skip-sum) still run
+    SideRt* rt;
+    explicit SideLock(bool want) : rt(nullptr) {
+        static SideRt one = {nullptr};
+        if (want) rt = &one;
+    }
+};
+static int side_link(SideRt*, wn_stream_t, wn_stream_t) { return 0; }
+#else
+#include <mutex>
+#include <vector>
+struct SideRt {
+    hipStream_t st = nullptr;
+    std::vector<hipEvent_t> ev;
+    size_t next = 0;
+    std::mutex mu;
+};
+static SideRt* side_get() {
+    static std::mutex g_mu;
+    static SideRt* g_rt[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_rt[dev]) {
+        SideRt* r = new SideRt();
+        if (hipStreamCreateWithFlags(&r->st, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            delete r;
+            return nullptr;
+        }
+        g_rt[dev] = r;
+    }
+    return g_rt[dev];
+}
+struct SideLock {   // holds the device's side runtime for one call (nullptr = run serially on the caller's stream)
+    SideRt* rt;
+    explicit SideLock(bool want) : rt(want ? side_get() : nullptr) {
+        if (rt) {
+            rt->mu.lock();
+            rt->next = 0;
+        }
+    }
+    ~SideLock() {
+        if (rt) rt->mu.unlock();
+    }
+    SideLock(const SideLock&) = delete;
+    SideLock& operator=(const SideLock&) = delete;
+};
+// work enqueued on `to` after this call waits for everything enqueued on `from` so far
+static int side_link(SideRt* rt, wn_stream_t from, wn_stream_t to) {
+    if (!rt || from == to) return 0;
+    if (rt->next == rt->ev.size()) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(100, "hipEventCreate failed");
+        rt->ev.push_back(e);
+    }
+    hipEvent_t e = rt->ev[rt->next++];
+    if (hipEventRecord(e, from) != hipSuccess || hipStreamWaitEvent(to, e, 0) != hipSuccess)
+        return fail(100, "stream fork/join failed: %s", hipGetErrorString(hipGetLastError()));
+    return 0;
+}
 #endif
 
 #define WN_TRY(expr)                                                                     \
@@ -485,7 +563,29 @@ static int pack_weights(const Ctx& c, const float* params) {
 // forward
 // ------------------------------------------------------------------------------------------
 // front conv, aux projection and the residual stack: leaves X_l, s_l, g_l, z_l of every layer in the workspace
-static int forward_stack(const Ctx& c, const float* params, const int64_t* x, const float* h) {
+// skip-sum of layers [lo, hi) into O1: O1 = (lo == 0 ? b_skip : O1) + sum_l Wskip_l z_l, relu when `last`
+// (wavenet.py:533,238,519).  One launch over all layers is the serial form; wn_forward's overlap mode issues it in
+// chunks on the side stream while the residual stack is still running.
+static int skip_sum(const Ctx& c, int lo, int hi, bool last) {
+    const Dims& d = c.d;
+    const Ws& w = c.w;
+    float* ws = c.ws;
+    const long BRT = (long)c.B * d.R * c.T;
+    WnGemmArgs g = wn_gemm_default();
+    g.M = d.S; g.N = c.T; g.K = (hi - lo) * d.R;
+    g.A = ws + w.wskip_f + (long)lo * d.R * d.S; g.lda = d.S;
+    g.B = ws + w.Z + (long)lo * BRT; g.ldb = c.T; g.b_zstride = (long)d.R * c.T; g.b_clen = c.T;
+    g.b_seg_len = d.R; g.b_seg_stride = BRT;
+    g.C = ws + w.O1; g.ldc = c.T; g.c_zstride = (long)d.S * c.T;
+    if (lo == 0) g.bias = ws + w.bskip;
+    else { g.D = ws + w.O1; g.ldd = c.T; g.d_zstride = (long)d.S * c.T; }  // in place: an element is read by the lane that writes it
+    g.relu = last ? 1 : 0; g.nbatch = c.B; g.tag = "fwd_skip_sum";
+    return fw_gemm(c, g);
+}
+
+// `side` != nullptr (fused path only): the skip-sum of every `chunk` finished layers is issued on cs->st
+static int forward_stack(const Ctx& c, const float* params, const int64_t* x, const float* h, SideRt* side = nullptr,
+                         const Ctx* cs = nullptr, int chunk = 0, int* skip_done = nullptr) {
     const WnConfig* cfg = c.cfg;
     const int B = c.B, T = c.T;
     const Dims& d = c.d;
@@ -523,6 +623,11 @@ static int forward_stack(const Ctx& c, const float* params, const int64_t* x, co
             WN_TRY(wn_fused_resblock_fwd(ws + w.wd_f + (long)l * d.K * d.R * 2 * d.R, ws + w.wres_f + (long)l * d.R * d.R,
                                          ws + w.cvec + (long)l * 2 * d.R, params + lb + y.o_res_b, Xl, Gl, g_bstride, upw, Xn,
                                          Sl, Gtl, Zl, B, T, d.K, dil, Ue, F, c.split_bf16 ? 1 : 0, c.st));
+            if (side && (l + 1) % chunk == 0 && l + 1 < d.L) {
+                WN_TRY(side_link(side, c.st, cs->st));  // z of layers [*skip_done, l] is enqueued
+                WN_TRY(skip_sum(*cs, *skip_done, l + 1, false));
+                *skip_done = l + 1;
+            }
         } else {
             // P = sum_tap W_tap . x[t-(K-1-tap)d]            (wavenet.py:527-528)
             WnGemmArgs g = wn_gemm_default();
@@ -559,23 +664,21 @@ extern "C" int wn_forward(const WnConfig* cfg, int B, int T, const float* params
     Ctx c;
     WN_TRY(make_ctx(&c, cfg, B, T, wsp, ws_bytes, flags, stream));
     if (!params || !x || !h || !logits) return fail(1, "NULL argument");
-    WN_TRY(forward_stack(c, params, x, h));
+    // overlap mode (opt-in, fused kernels): partial skip-sums run on the internal side stream beside the stack
+    SideLock side((flags & WN_FLAG_FWD_OVERLAP) && !(flags & WN_FLAG_NO_OVERLAP) && c.fused && !wn_prof_is_on());
+    Ctx cs = c;
+    int skip_done = 0;
+#ifndef WN_EMU
+    if (side.rt) cs.st = side.rt->st;
+#endif
     const Dims& d = c.d;
     const Lay& y = c.y;
     const Ws& w = c.w;
     float* ws = c.ws;
-    const long BRT = (long)B * d.R * T;
-    // skip-sum over layers as ONE contraction with K = L*R (wavenet.py:533,238), relu fused (:519)
-    {
-        WnGemmArgs g = wn_gemm_default();
-        g.M = d.S; g.N = T; g.K = d.L * d.R;
-        g.A = ws + w.wskip_f; g.lda = d.S;
-        g.B = ws + w.Z; g.ldb = T; g.b_zstride = (long)d.R * T; g.b_clen = T;
-        g.b_seg_len = d.R; g.b_seg_stride = BRT;
-        g.C = ws + w.O1; g.ldc = T; g.c_zstride = (long)d.S * T;
-        g.bias = ws + w.bskip; g.relu = 1; g.nbatch = B; g.tag = "fwd_skip_sum";
-        WN_TRY(fw_gemm(c, g));
-    }
+    WN_TRY(forward_stack(c, params, x, h, side.rt, &cs, (d.L + 2) / 3, &skip_done));
+    WN_TRY(side_link(side.rt, cs.st, c.st));  // join: O1 holds the sum of layers [0, skip_done)
+    // skip-sum over (the remaining) layers as ONE contraction with K = L*R (wavenet.py:533,238), relu fused (:519)
+    WN_TRY(skip_sum(c, skip_done, d.L, true));
     {   // conv_post_1 + relu  (wavenet.py:520-521)
         WnGemmArgs g = wn_gemm_default();
         g.M = d.S; g.N = T; g.K = d.S;
@@ -697,6 +800,12 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
     Ctx c;
     WN_TRY(make_ctx(&c, cfg, B, T, wsp, ws_bytes, flags, stream));
     if (!params || !x || !h || !dlogits || !grads) return fail(1, "NULL argument");
+    // c = the data chain on the caller's stream; cs = the weight gradients, on the side stream unless serial
+    SideLock side(!(flags & WN_FLAG_NO_OVERLAP) && !wn_prof_is_on());
+    Ctx cs = c;
+#ifndef WN_EMU
+    if (side.rt) cs.st = side.rt->st;
+#endif
     const Dims& d = c.d;
     const Lay& y = c.y;
     const Ws& w = c.w;
@@ -729,19 +838,20 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
         g.nbatch = B; g.tag = "bwd_post1_dx";
         WN_TRY(fw_gemm(c, g));
     }
+    WN_TRY(side_link(side.rt, c.st, cs.st));  // fork: dO2, dSkip (and everything before this call) are ready
     {   // d conv_post_2.{weight,bias}
         WnGemmArgs g = wn_gemm_default();
         g.M = d.Qo; g.N = d.S; g.K = T;
         g.A = dlogits; g.lda = T; g.a_zstride = (long)d.Qo * T;
         g.B = ws + w.O2; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = T; g.tag = "dw_post2";
-        WN_TRY(dw_gemm(c, g, dw_out_plain(grads + y.post2_w, d.S, grads + y.post2_b)));
+        WN_TRY(dw_gemm(cs, g, dw_out_plain(grads + y.post2_w, d.S, grads + y.post2_b)));
     }
     {   // d conv_post_1.{weight,bias}
         WnGemmArgs g = wn_gemm_default();
         g.M = d.S; g.N = d.S; g.K = T;
         g.A = ws + w.dO2; g.lda = T; g.a_zstride = (long)d.S * T;
         g.B = ws + w.O1; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = T; g.tag = "dw_post1";
-        WN_TRY(dw_gemm(c, g, dw_out_plain(grads + y.post1_w, d.S, grads + y.post1_b)));
+        WN_TRY(dw_gemm(cs, g, dw_out_plain(grads + y.post1_w, d.S, grads + y.post1_b)));
     }
     {   // d skip_1x1.l.weight for all layers in one contraction; bias = rowsum(dSkip) for every layer
         WnGemmArgs g = wn_gemm_default();
@@ -754,14 +864,14 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
         o.n_seg = d.R; o.n_seg_stride = y.ls_skip; o.n_stride = 1;
         o.addend_m = nullptr; o.addend_scale_ptr = nullptr; o.rowsum_out = ws + w.tmpS;
         o.out_lstride = 0; o.addend_lstride = 0; o.rowsum_lstride = 0;
-        WN_TRY(dw_gemm(c, g, o));
+        WN_TRY(dw_gemm(cs, g, o));
         WnCopy4 cp;
         cp.n0 = 1; cp.n1 = 1; cp.n2 = d.S; cp.nl = d.L;
         cp.s0 = 0; cp.s1 = 0; cp.s2 = 1; cp.sl = 0;
         cp.d0 = 0; cp.d1 = 0; cp.d2 = 1; cp.dl = y.ls_skip;
-        WN_TRY(wn_copy4(grads + y.skip0 + (long)d.S * d.R, ws + w.tmpS, &cp, c.st));
+        WN_TRY(wn_copy4(grads + y.skip0 + (long)d.S * d.R, ws + w.tmpS, &cp, cs.st));
     }
-    if (events) rt_event_record(events[bucket], c.st);
+    if (events) rt_event_record(events[bucket], cs.st);
     bucket++;
 
     // ---- residual stack, last layer first (wavenet.py:525-536 reversed) ----
@@ -772,6 +882,7 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
     const long g_bstride = (long)d.L * 2 * d.R * F;
     const long P_L = 2 * BRT;
     auto flush_bucket = [&](int lo, int hi) -> int {
+        const Ctx& c = cs;  // every launch of a flush is a weight gradient
         const int nl = hi - lo;
         const long lb_lo = layer_base(y, d, lo);
         float* dc = ws + w.dc + (long)lo * 2 * d.R;
@@ -888,9 +999,10 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
         }
         const int done = d.L - l;  // layers walked
         if (done % lpb == 0 || l == 0) {
+            WN_TRY(side_link(side.rt, c.st, cs.st));  // dP, dX of layers [l, bucket_hi) are enqueued
             WN_TRY(flush_bucket(l, bucket_hi));
             bucket_hi = l;
-            if (events) rt_event_record(events[bucket], c.st);
+            if (events) rt_event_record(events[bucket], cs.st);
             bucket++;
         }
     }
@@ -898,7 +1010,7 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
     // ---- front conv: scatter over the token indices, or (large tables) the one-hot contraction ----
     if (wn_front_dw_supported(d.R, d.K, d.Q) &&
         wn_front_dw_partial_floats(B, T, d.R, d.K, d.Q) <= w.front_partial_floats) {
-        WN_TRY(wn_front_dw(dXn, x, ws + w.front_partial, grads + y.causal_w, grads + y.causal_b, B, T, d.R, d.K, d.Q, c.st));
+        WN_TRY(wn_front_dw(dXn, x, ws + w.front_partial, grads + y.causal_w, grads + y.causal_b, B, T, d.R, d.K, d.Q, cs.st));
     } else {
         WnGemmArgs g = wn_gemm_default();
         g.M = d.R; g.N = d.K * d.Q; g.K = T;
@@ -911,7 +1023,7 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
         o.n_seg = d.Q; o.n_seg_stride = 1; o.n_stride = d.K;
         o.addend_m = nullptr; o.addend_scale_ptr = nullptr; o.rowsum_out = grads + y.causal_b;
         o.out_lstride = 0; o.addend_lstride = 0; o.rowsum_lstride = 0;
-        WN_TRY(dw_gemm(c, g, o));
+        WN_TRY(dw_gemm(cs, g, o));
     }
     // ---- upsampling layer parameters ----
     if (d.U > 0) {
@@ -922,12 +1034,13 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
         r.scale = 1.0f; r.accumulate = 0; r.addend_m = nullptr; r.addend_scale_ptr = nullptr;
         r.scratch = ws + w.red_scratch; r.scratch_floats = w.red_scratch_floats;
         r.nl = 1; r.out_lstride = 0; r.addend_lstride = 0;
-        WN_TRY(wn_reduce(&r, c.st));
+        WN_TRY(wn_reduce(&r, cs.st));
         // d b_up = sum_{l,o'} rowsum(Waux_l)[o'] * dc_l[o']
-        WN_TRY(wn_dot(ws + w.rowsum_aux, ws + w.dc, (long)d.L * 2 * d.R, grads + y.up_b, 0, c.st));
+        WN_TRY(wn_dot(ws + w.rowsum_aux, ws + w.dc, (long)d.L * 2 * d.R, grads + y.up_b, 0, cs.st));
     }
-    if (events) rt_event_record(events[bucket], c.st);
+    if (events) rt_event_record(events[bucket], cs.st);
     bucket++;
+    WN_TRY(side_link(side.rt, cs.st, c.st));  // join: the caller's stream continues after every gradient
     return rt_check("wn_backward");
 }
 

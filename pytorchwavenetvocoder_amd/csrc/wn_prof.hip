@@ -13,6 +13,7 @@
 #ifdef WN_EMU
 void wn_prof_scope_begin(const char*, double, double, wn_stream_t) {}
 void wn_prof_scope_end(wn_stream_t) {}
+bool wn_prof_is_on() { return false; }
 extern "C" int wn_prof_enable(int) { return 0; }
 extern "C" int wn_prof_report(char* buf, size_t n) {
     if (buf && n) buf[0] = 0;
@@ -56,6 +57,8 @@ void wn_prof_scope_end(wn_stream_t st) {
     if (!g_on || g_recs.empty()) return;
     (void)hipEventRecord(g_recs.back().e1, st);
 }
+
+bool wn_prof_is_on() { return g_on; }
 
 extern "C" int wn_prof_enable(int on) {
     g_on = on != 0;

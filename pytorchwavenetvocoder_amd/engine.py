@@ -6,10 +6,15 @@ PyTorch is used here only for device memory, streams and (in ``DataParallelReduc
 ``torch.distributed``; every FLOP of the path runs in libwavenet_hip.so.
 """
 import ctypes
+import os
 
 import torch
 
 from . import _lib
+
+# Launch modes every engine starts with: 0 = wn_backward's weight gradients on the library's side stream (the
+# library default).  Set from measurements on MI355X (profiles/r01/overlap_probe.txt).
+DEFAULT_FLAGS = 0
 
 
 def _ptr(t):
@@ -50,7 +55,9 @@ class WaveNetEngine(object):
         self.lib.check(self.lib.wn_dead_param_range(ctypes.byref(self.cfg), ctypes.byref(lo), ctypes.byref(hi)),
                        "wn_dead_param_range")
         self.dead_range = (lo.value, hi.value)
-        self.flags = 0
+        # launch-mode flags of wn_forward / wn_backward (include/wavenet_hip.h WN_FLAG_*); WN_ENGINE_FLAGS overrides
+        # the default for A/B measurements (tools/overlap_probe.py)
+        self.flags = int(os.environ.get("WN_ENGINE_FLAGS", str(DEFAULT_FLAGS)), 0)
 
     # ---- layout ---------------------------------------------------------------------------
     def param_slice(self, kind, layer=0):

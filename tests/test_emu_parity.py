@@ -40,6 +40,18 @@ def test_bucketed_backward(name, lpb):
     PC.check_golden_case(GoldenCase(name), emu_library(), "cpu", layers_per_bucket=lpb)
 
 
+@pytest.mark.parametrize("name", ["r64_k2_up", "r64_k3_up"])
+def test_overlap_launch_sequences(name):
+    """The overlap modes of wn_forward / wn_backward change the launch sequence (skip-sum in chunks of layers that
+    accumulate in place; weight gradients issued per bucket from a second context).  The emulator has one in-order
+    stream, so this checks the sequences' arithmetic; the stream fork/join itself is covered on the GPU."""
+    from pytorchwavenetvocoder_amd import _lib
+    PC.check_golden_case(GoldenCase(name), emu_library(), "cpu", flags=_lib.FLAG_FWD_OVERLAP)
+    PC.check_golden_case(GoldenCase(name), emu_library(), "cpu", flags=_lib.FLAG_FWD_OVERLAP | _lib.FLAG_EXACT_MFMA,
+                         layers_per_bucket=1)
+    PC.check_golden_case(GoldenCase(name), emu_library(), "cpu", flags=_lib.FLAG_NO_OVERLAP)
+
+
 def test_ragged_T_and_odd_channels():
     # T not a multiple of any tile, channel counts not multiples of 32, B=3
     PC.run_oracle_vs_engine((37, 7, 12, 20, 2, 2, 2, 0), 3, 77, 5, emu_library(), "cpu")
