@@ -86,6 +86,10 @@ enum {
 #define WN_FLAG_FWD_OVERLAP 8 /* wn_forward (fused kernels): the skip-sum contraction is issued in three chunks of layers on
                                * the internal side stream while the residual stack is still running (the partial sums
                                * round differently from the single contraction: ~1e-7 relative on the logits) */
+#define WN_FLAG_DW_FLUSH(n) (((n) & 0xff) << 8) /* wn_backward: issue the weight gradients of at most n walked layers per
+                               * launch group (0 = default: a whole gradient bucket in serial mode, 5 layers in
+                               * overlap mode).  Groups never straddle a bucket.  The split-K plan of a group depends
+                               * on its size, so different n round differently (~1e-7 relative) */
 #define WN_FLAG_NO_OVERLAP 4 /* wn_backward: keep the weight-gradient contractions on the caller's stream.  Default: they
                               * run on an internal side stream beside the gate'/dX chain (fork/join with events inside
                               * the call; results are bit-identical either way).  Also serial while wn_prof_enable(1) */

@@ -67,6 +67,13 @@ FLAG_NO_FUSED = 1
 FLAG_EXACT_MFMA = 2
 FLAG_FWD_OVERLAP = 8  # wn_forward: chunked skip-sum beside the residual stack (side stream)
 FLAG_NO_OVERLAP = 4  # wn_backward: weight gradients on the caller stream (default: internal side stream)
+
+
+def flag_dw_flush(n):
+    """WN_FLAG_DW_FLUSH(n): weight gradients of at most n walked layers per launch group (wn_backward)."""
+    return (int(n) & 0xff) << 8
+
+
 ABI_VERSION = 3
 
 # every symbol include/wavenet_hip.h declares

@@ -5,6 +5,7 @@
 // the HIP kernels of wn_gemm.hip, wn_elem.hip and wn_fused.hip.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/wavenet_hip.h"
@@ -60,13 +61,14 @@ static void rt_event_record(void* ev, wn_stream_t st) { (void)hipEventRecord((hi
 // a mutex makes the record/wait pairs of concurrent callers atomic.  WN_FLAG_NO_OVERLAP, or per-launch profiling
 // (wn_prof_enable), keeps everything on the caller's stream.
 // ------------------------------------------------------------------------------------------
+#define WN_DW_FLUSH_DEFAULT 5
 #ifdef WN_EMU
 struct SideRt {
     wn_stream_t st;
 };
 struct SideLock {   // emulator: one in-order "stream", but the overlap launch sequences (chunked skip-sum) still run
     SideRt* rt;
-    explicit SideLock(bool want) : rt(nullptr) {
+    SideLock(bool want, wn_stream_t) : rt(nullptr) {
         static SideRt one = {nullptr};
         if (want) rt = &one;
     }
@@ -81,15 +83,26 @@ struct SideRt {
     size_t next = 0;
     std::mutex mu;
 };
-static SideRt* side_get() {
+static SideRt* side_get(wn_stream_t caller) {
     static std::mutex g_mu;
     static SideRt* g_rt[64] = {nullptr};
-    int dev = 0;
+    int dev = 0, sdev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    // the launches follow the current device (as everywhere in this library); a caller stream of another device
+    // gets the serial mode instead of a cross-device fork
+    if (caller && (hipStreamGetDevice(caller, &sdev) != hipSuccess || sdev != dev)) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_rt[dev]) {
         SideRt* r = new SideRt();
-        if (hipStreamCreateWithFlags(&r->st, hipStreamNonBlocking) != hipSuccess) {
+        // lowest priority: the side stream carries filler work, the caller's stream carries the dependent chain
+        // (WN_SIDE_PRIORITY=normal, read once, for A/B measurements)
+        int least = 0, greatest = 0;
+        const char* pr = getenv("WN_SIDE_PRIORITY");
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || (pr && !strcmp(pr, "normal"))) least = 0;
+        if (hipStreamCreateWithPriority(&r->st, hipStreamNonBlocking, least) != hipSuccess) {
             (void)hipGetLastError();
             delete r;
             return nullptr;
@@ -100,7 +113,7 @@ static SideRt* side_get() {
 }
 struct SideLock {   // holds the device's side runtime for one call (nullptr = run serially on the caller's stream)
     SideRt* rt;
-    explicit SideLock(bool want) : rt(want ? side_get() : nullptr) {
+    SideLock(bool want, wn_stream_t caller) : rt(want ? side_get(caller) : nullptr) {
         if (rt) {
             rt->mu.lock();
             rt->next = 0;
@@ -665,7 +678,7 @@ extern "C" int wn_forward(const WnConfig* cfg, int B, int T, const float* params
     WN_TRY(make_ctx(&c, cfg, B, T, wsp, ws_bytes, flags, stream));
     if (!params || !x || !h || !logits) return fail(1, "NULL argument");
     // overlap mode (opt-in, fused kernels): partial skip-sums run on the internal side stream beside the stack
-    SideLock side((flags & WN_FLAG_FWD_OVERLAP) && !(flags & WN_FLAG_NO_OVERLAP) && c.fused && !wn_prof_is_on());
+    SideLock side((flags & WN_FLAG_FWD_OVERLAP) && !(flags & WN_FLAG_NO_OVERLAP) && c.fused && !wn_prof_is_on(), c.st);
     Ctx cs = c;
     int skip_done = 0;
 #ifndef WN_EMU
@@ -801,7 +814,7 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
     WN_TRY(make_ctx(&c, cfg, B, T, wsp, ws_bytes, flags, stream));
     if (!params || !x || !h || !dlogits || !grads) return fail(1, "NULL argument");
     // c = the data chain on the caller's stream; cs = the weight gradients, on the side stream unless serial
-    SideLock side(!(flags & WN_FLAG_NO_OVERLAP) && !wn_prof_is_on());
+    SideLock side(!(flags & WN_FLAG_NO_OVERLAP) && !wn_prof_is_on(), c.st);
     Ctx cs = c;
 #ifndef WN_EMU
     if (side.rt) cs.st = side.rt->st;
@@ -951,6 +964,11 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
         return 0;
     };
 
+    // Weight gradients are issued for groups of walked layers: a whole bucket in serial mode (largest launches), at
+    // most WN_DW_FLUSH_DEFAULT layers in overlap mode so that they start while the chain is still running; flags bits
+    // 8..15 override the group size.  (The split-K plan, hence the rounding, depends on the group size.)
+    int fmax = (flags >> 8) & 0xff;
+    if (fmax == 0) fmax = side.rt ? WN_DW_FLUSH_DEFAULT : d.L;
     int bucket_hi = d.L;  // layers [l, bucket_hi) have been walked but not flushed yet
     for (int l = d.L - 1; l >= 0; --l) {
         const int dil = dilation_of(cfg, l);
@@ -998,12 +1016,15 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
             }
         }
         const int done = d.L - l;  // layers walked
-        if (done % lpb == 0 || l == 0) {
+        const bool bucket_end = (done % lpb == 0 || l == 0);
+        if (bucket_end || bucket_hi - l >= fmax) {
             WN_TRY(side_link(side.rt, c.st, cs.st));  // dP, dX of layers [l, bucket_hi) are enqueued
             WN_TRY(flush_bucket(l, bucket_hi));
             bucket_hi = l;
-            if (events) rt_event_record(events[bucket], cs.st);
-            bucket++;
+            if (bucket_end) {
+                if (events) rt_event_record(events[bucket], cs.st);
+                bucket++;
+            }
         }
     }
     const float* dXn = ws + w.dXall;  // dL/dx_0

@@ -50,6 +50,9 @@ def test_overlap_launch_sequences(name):
     PC.check_golden_case(GoldenCase(name), emu_library(), "cpu", flags=_lib.FLAG_FWD_OVERLAP | _lib.FLAG_EXACT_MFMA,
                          layers_per_bucket=1)
     PC.check_golden_case(GoldenCase(name), emu_library(), "cpu", flags=_lib.FLAG_NO_OVERLAP)
+    # launch groups of 1 / 2 walked layers inside buckets of 2 / the whole stack
+    PC.check_golden_case(GoldenCase(name), emu_library(), "cpu", flags=_lib.flag_dw_flush(1), layers_per_bucket=2)
+    PC.check_golden_case(GoldenCase(name), emu_library(), "cpu", flags=_lib.flag_dw_flush(2))
 
 
 def test_ragged_T_and_odd_channels():

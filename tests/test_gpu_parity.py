@@ -112,35 +112,44 @@ def test_cfg2_fused_equals_layered_midsize():
 
 def test_stream_overlap_modes_midsize():
     """wn_backward's weight gradients run on the library's side stream beside the gate'/dX chain (default), serially
-    with WN_FLAG_NO_OVERLAP: same kernels, same reduction order -> bit-identical gradients, with and without bucket
-    events, repeated (the fork/join must leave nothing pending).  WN_FLAG_FWD_OVERLAP (skip-sum in chunks beside the
-    residual stack) re-associates the skip sum: logits to round-off, and still within the oracle gates."""
+    with WN_FLAG_NO_OVERLAP: same kernels and, for the same launch-group size (WN_FLAG_DW_FLUSH), the same reduction
+    order -> bit-identical gradients for every bucket size, run to run (the fork/join must leave nothing pending).
+    Different group sizes re-associate the split-K sums, and WN_FLAG_FWD_OVERLAP (skip-sum in chunks beside the
+    residual stack) re-associates the skip sum: equal to round-off, and still within the oracle gates."""
     from oracle import wavenet_oracle as O
     from pytorchwavenetvocoder_amd import _lib as L
     from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat
     cfg_t = (256, 80, 64, 256, 10, 3, 2, 80)
     cfg = O.OracleConfig(*cfg_t)
     params, x, h, t, margin, sd = PC.pick_instance(cfg, 2, 3120, 41, 0.05)
-    res = {}
-    for flags in (L.FLAG_NO_OVERLAP, 0, L.FLAG_FWD_OVERLAP):
+    x, h, t = x.to(DEV), h.to(DEV), t.to(DEV)
+
+    def run(flags, lpb):
         eng = WaveNetEngine(*cfg_t, device=DEV, library=_lib())
         eng.flags = flags
         load_state_into_flat(eng, params)
-        for rep in range(3):
-            logits = eng.forward(x.to(DEV), h.to(DEV))
-            loss, dl = eng.loss(logits, t.to(DEV))
-            g = eng.backward(dl, layers_per_bucket=(0, 10, 7)[rep]).clone()
+        out = []
+        for rep in range(2):
+            logits = eng.forward(x, h)
+            loss, dl = eng.loss(logits, t)
+            g = eng.backward(dl, layers_per_bucket=lpb).clone()
             torch.cuda.synchronize()
-            if rep == 0:
-                res[flags] = (logits.clone(), float(loss.cpu()), g)
-            else:  # run-to-run: bitwise
-                assert torch.equal(logits, res[flags][0]) and torch.equal(g, res[flags][2]), (flags, rep)
-    serial, over, fwd = res[L.FLAG_NO_OVERLAP], res[0], res[L.FLAG_FWD_OVERLAP]
-    assert torch.equal(serial[0], over[0]) and serial[1] == over[1]
-    assert torch.equal(serial[2], over[2]), "side-stream weight gradients differ from the serial ones"
-    assert float((fwd[0] - serial[0]).abs().max()) <= 2e-5
-    assert abs(fwd[1] - serial[1]) <= 1e-6
-    assert float((fwd[2] - serial[2]).abs().max()) <= 1e-5 * float(serial[2].abs().max())
+            out.append((logits.clone(), float(loss.cpu()), g))
+        assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][2], out[1][2]), (flags, lpb)
+        return out[0]
+
+    F5 = L.flag_dw_flush(5)
+    for lpb in (0, 10, 7):
+        serial = run(L.FLAG_NO_OVERLAP | F5, lpb)
+        over = run(F5, lpb)
+        assert torch.equal(serial[0], over[0]) and serial[1] == over[1]
+        assert torch.equal(serial[2], over[2]), "side-stream weight gradients differ from the serial ones (lpb %d)" % lpb
+    base = run(L.FLAG_NO_OVERLAP, 0)  # one launch group per bucket
+    for flags in (0, L.flag_dw_flush(3), L.FLAG_FWD_OVERLAP, L.FLAG_FWD_OVERLAP | L.flag_dw_flush(30)):
+        r = run(flags, 0)
+        assert float((r[0] - base[0]).abs().max()) <= 2e-5, flags
+        assert abs(r[1] - base[1]) <= 1e-6, flags
+        assert float((r[2] - base[2]).abs().max()) <= 1e-5 * float(base[2].abs().max()), flags
     e, gerr = PC.run_oracle_vs_engine(cfg_t, 1, 3120, 21, _lib(), DEV, scale=0.05, flags=L.FLAG_FWD_OVERLAP)
     print("fwd-overlap logits err %.3g, worst grad rel err %.3g" % (e, gerr))
 

@@ -2,13 +2,14 @@
 # -*- coding: utf-8 -*-
 """A/B of the stream-overlap launch modes on the BASELINE configs[1] training step (one process, one model):
 
-    serial        WN_FLAG_NO_OVERLAP           everything on the caller's stream
-    bwd           0                            weight gradients on the side stream beside the gate'/dX chain
-    bwd+fwd       WN_FLAG_FWD_OVERLAP          + skip-sum in three chunks beside the residual stack
-    fwd only      measured as forward-only time of the same modes
+    serial        WN_FLAG_NO_OVERLAP           everything on the caller's stream, one weight-gradient group per bucket
+    serial/5      ... | WN_FLAG_DW_FLUSH(5)    same, groups of 5 layers
+    bwd/n         WN_FLAG_DW_FLUSH(n)          weight gradients on the side stream beside the gate'/dX chain
+    bwd/n+fwd     ... | WN_FLAG_FWD_OVERLAP    + skip-sum in three chunks beside the residual stack
 
-Prints ms/step per mode (two interleaved rounds) and writes the flags of the fastest mode to
-gpurun_out/best_flags.txt.  Checks that the gradients of `serial` and `bwd` are bit-identical."""
+Prints ms/step and forward ms per mode (three interleaved rounds), writes gpurun_out/overlap_probe_<prio>.json and
+the flags of the fastest mode.  WN_SIDE_PRIORITY=normal|low (default low) is the priority of the library's side
+stream; run once per value.  Checks that gradients of serial/5 and bwd/5 are bit-identical."""
 import json
 import os
 import sys
@@ -38,7 +39,11 @@ def main():
     x, t = xx[:, :-1].contiguous().to(dev), xx[:, 1:].contiguous().to(dev)
     h = torch.randn(B, 80, frames, generator=gen).to(dev)
     opt = FusedAdam(model, lr=1e-4)
-    modes = [("serial", _lib.FLAG_NO_OVERLAP), ("bwd", 0), ("bwd+fwd", _lib.FLAG_FWD_OVERLAP)]
+    F = _lib.flag_dw_flush
+    modes = [("serial/5", _lib.FLAG_NO_OVERLAP | F(5)), ("bwd/5", F(5)), ("serial", _lib.FLAG_NO_OVERLAP),
+             ("bwd/3", F(3)), ("bwd/10", F(10)), ("bwd/30", F(30)), ("bwd/5+fwd", F(5) | _lib.FLAG_FWD_OVERLAP),
+             ("bwd/10+fwd", F(10) | _lib.FLAG_FWD_OVERLAP)]
+    prio = os.environ.get("WN_SIDE_PRIORITY", "low")
     eng = model.engine
 
     # bit-identity of the gradients (no optimizer step in between)
@@ -48,7 +53,7 @@ def main():
         model.loss_and_backward(x, h, t)
         torch.cuda.synchronize()
         grads[name] = eng.grads().clone()
-    same = bool(torch.equal(grads["serial"], grads["bwd"]))
+    same = bool(torch.equal(grads["serial/5"], grads["bwd/5"]))
     print("gradients serial == side-stream, bitwise:", same, flush=True)
 
     def timed(fn, n):
@@ -80,16 +85,17 @@ def main():
         r["flags"] = fl
         r["best_step_ms"] = min(r["step_ms"])
         r["best_fwd_ms"] = min(r["fwd_ms"])
-        print("%-8s flags %d  step ms %s  forward ms %s" % (
+        print("%-10s flags %4d  step ms %s  forward ms %s" % (
             name, fl, " ".join("%.3f" % v for v in r["step_ms"]), " ".join("%.3f" % v for v in r["fwd_ms"])), flush=True)
         if best is None or r["best_step_ms"] < res[best]["best_step_ms"]:
             best = name
-    print("fastest:", best, "flags", res[best]["flags"], flush=True)
+    print("side-stream priority %s: fastest %s (flags %d, %.3f ms/step)" % (prio, best, res[best]["flags"],
+                                                                             res[best]["best_step_ms"]), flush=True)
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "best_flags.txt"), "w") as fh:
-        fh.write("%d\n" % res[best]["flags"])
-    print(json.dumps({"bitwise_equal": same, "modes": res, "fastest": best}), flush=True)
+    with open(os.path.join(out, "overlap_probe_%s.json" % prio), "w") as fh:
+        json.dump({"priority": prio, "bitwise_equal": same, "modes": res, "fastest": best,
+                   "fastest_flags": res[best]["flags"], "fastest_ms": res[best]["best_step_ms"]}, fh)
     if not same:
         sys.exit(1)
 
