@@ -136,6 +136,19 @@ def decode_report(model, device, with_cpu):
     return out
 
 
+def stream_mode(flags):
+    """Launch mode of the timed steps (include/wavenet_hip.h WN_FLAG_*).  The per-launch HIP-event table of the
+    `kernels` / `roofline` blocks is always taken serially (wn_prof_enable keeps everything on one stream)."""
+    from pytorchwavenetvocoder_amd import _lib
+    if flags & _lib.FLAG_NO_OVERLAP:
+        return "serial (one stream)"
+    n = (flags >> 8) & 0xff
+    s = "weight gradients of every %d walked layers on the library's side stream beside the backward chain" % (n or 5)
+    if flags & _lib.FLAG_FWD_OVERLAP:
+        s += "; skip-sum in 3 chunks on the side stream beside the residual stack"
+    return s
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -302,6 +315,7 @@ def main():
                                        B, T, T - rf),
                        "global_batch": world * B, "parallelism": "dp%d" % world,
                        "kernels": "layered" if args.no_fused else "fused+gemm",
+                       "streams": stream_mode(model.engine.flags),
                        "arithmetic": "fp32 storage and accumulation; contractions on the bf16 matrix cores with a 3-way "
                                      "operand split (6 products, fp32-equivalent to round-off) except K=3 forward blocks "
                                      "(exact f32 MFMA); WN_FLAG_EXACT_MFMA selects the f32 MFMA everywhere"},
