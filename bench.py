@@ -140,13 +140,15 @@ def stream_mode(flags):
     """Launch mode of the timed steps (include/wavenet_hip.h WN_FLAG_*).  The per-launch HIP-event table of the
     `kernels` / `roofline` blocks is always taken serially (wn_prof_enable keeps everything on one stream)."""
     from pytorchwavenetvocoder_amd import _lib
-    if flags & _lib.FLAG_NO_OVERLAP:
-        return "serial (one stream)"
     n = (flags >> 8) & 0xff
-    s = "weight gradients of every %d walked layers on the library's side stream beside the backward chain" % (n or 5)
+    parts = []
+    if flags & _lib.FLAG_BWD_OVERLAP:
+        parts.append("weight gradients of every %d walked layers on the library's side stream beside the backward chain" % (n or 5))
+    elif n:
+        parts.append("weight gradients in groups of %d layers" % n)
     if flags & _lib.FLAG_FWD_OVERLAP:
-        s += "; skip-sum in 3 chunks on the side stream beside the residual stack"
-    return s
+        parts.append("skip-sum in 3 chunks on the side stream beside the residual stack")
+    return "; ".join(parts) if parts else "serial (one stream)"
 
 
 def main():

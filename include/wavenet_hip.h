@@ -7,8 +7,8 @@
  * Conventions
  *   - plain C types only: device pointers + sizes; the caller (PyTorch-ROCm, or any HIP program)
  *     owns every buffer, the library allocates no device memory and keeps no state between calls
- *     (one exception: wn_backward creates ONE internal non-blocking stream and a few events per device
- *     on first use, unless WN_FLAG_NO_OVERLAP);
+ *     (one exception: the opt-in overlap modes WN_FLAG_BWD_OVERLAP / WN_FLAG_FWD_OVERLAP create ONE internal
+ *     non-blocking stream and a few events per device on first use);
  *   - activations are channel-major fp32 (B, C, T) exactly like the reference's tensors; sample
  *     indices are int64 (torch.long); logits are written physically as (B, Q, T) -- the
  *     reference's `(B, T, Q)` result is the `.transpose(1, 2)` view of that buffer
@@ -83,16 +83,21 @@ enum {
 #define WN_FLAG_EXACT_MFMA 2 /* every contraction on the exact f32-input MFMA (default: the skip-sum / post-net
                               * contractions run on the bf16 matrix cores with a 3-way operand split whose six
                               * products reproduce fp32 to round-off; csrc/wn_gemm6.hip) */
+/* Opt-in stream-overlap modes (fused kernels' data chain on the caller's stream, independent contractions on an
+ * internal low-priority side stream, fork/join with events inside the call; the caller sees plain stream semantics).
+ * Measured on MI355X they do not pay today (the persistent chain kernels hold every wave slot, so a
+ * concurrent contraction either starves them or waits), hence not the default; per-launch profiling
+ * (wn_prof_enable) always runs serially. */
+#define WN_FLAG_BWD_OVERLAP 4 /* wn_backward: weight-gradient contractions on the side stream beside the gate'/dX chain;
+                               * same kernels, same reduction order: bit-identical to the serial mode for the same
+                               * launch-group size */
 #define WN_FLAG_FWD_OVERLAP 8 /* wn_forward (fused kernels): the skip-sum contraction is issued in three chunks of layers on
-                               * the internal side stream while the residual stack is still running (the partial sums
-                               * round differently from the single contraction: ~1e-7 relative on the logits) */
+                               * the side stream while the residual stack is still running (the partial sums round
+                               * differently from the single contraction: ~1e-7 relative on the logits) */
 #define WN_FLAG_DW_FLUSH(n) (((n) & 0xff) << 8) /* wn_backward: issue the weight gradients of at most n walked layers per
-                               * launch group (0 = default: a whole gradient bucket in serial mode, 5 layers in
-                               * overlap mode).  Groups never straddle a bucket.  The split-K plan of a group depends
-                               * on its size, so different n round differently (~1e-7 relative) */
-#define WN_FLAG_NO_OVERLAP 4 /* wn_backward: keep the weight-gradient contractions on the caller's stream.  Default: they
-                              * run on an internal side stream beside the gate'/dX chain (fork/join with events inside
-                              * the call; results are bit-identical either way).  Also serial while wn_prof_enable(1) */
+                               * launch group (0 = default: a whole gradient bucket; 5 layers with WN_FLAG_BWD_OVERLAP).
+                               * Groups never straddle a bucket.  The split-K plan of a group depends on its size, so
+                               * different n round differently (~1e-7 relative) */
 
 int wn_abi_version(void);
 const char* wn_last_error(void);

@@ -65,8 +65,8 @@ class WnGemmArgs(ctypes.Structure):
 
 FLAG_NO_FUSED = 1
 FLAG_EXACT_MFMA = 2
-FLAG_FWD_OVERLAP = 8  # wn_forward: chunked skip-sum beside the residual stack (side stream)
-FLAG_NO_OVERLAP = 4  # wn_backward: weight gradients on the caller stream (default: internal side stream)
+FLAG_BWD_OVERLAP = 4  # wn_backward: weight gradients on the library's side stream beside the gate'/dX chain (opt-in)
+FLAG_FWD_OVERLAP = 8  # wn_forward: chunked skip-sum on the side stream beside the residual stack (opt-in)
 
 
 def flag_dw_flush(n):

@@ -58,8 +58,8 @@ static void rt_event_record(void* ev, wn_stream_t st) { (void)hipEventRecord((hi
 // dependent chain launches and the partial last round of their tiles.  Fork/join with events; the caller sees
 // the usual stream semantics (everything is complete in `stream` order when the call's work retires).
 // One non-blocking stream + event pool per device, created on first use and kept (the only state of the library);
-// a mutex makes the record/wait pairs of concurrent callers atomic.  WN_FLAG_NO_OVERLAP, or per-launch profiling
-// (wn_prof_enable), keeps everything on the caller's stream.
+// a mutex makes the record/wait pairs of concurrent callers atomic.  Opt-in (WN_FLAG_BWD_OVERLAP / WN_FLAG_FWD_OVERLAP):
+// see DESIGN.md 5.1 for the measurement; per-launch profiling (wn_prof_enable) keeps everything on the caller's stream.
 // ------------------------------------------------------------------------------------------
 #define WN_DW_FLUSH_DEFAULT 5
 #ifdef WN_EMU
@@ -678,7 +678,7 @@ extern "C" int wn_forward(const WnConfig* cfg, int B, int T, const float* params
     WN_TRY(make_ctx(&c, cfg, B, T, wsp, ws_bytes, flags, stream));
     if (!params || !x || !h || !logits) return fail(1, "NULL argument");
     // overlap mode (opt-in, fused kernels): partial skip-sums run on the internal side stream beside the stack
-    SideLock side((flags & WN_FLAG_FWD_OVERLAP) && !(flags & WN_FLAG_NO_OVERLAP) && c.fused && !wn_prof_is_on(), c.st);
+    SideLock side((flags & WN_FLAG_FWD_OVERLAP) && c.fused && !wn_prof_is_on(), c.st);
     Ctx cs = c;
     int skip_done = 0;
 #ifndef WN_EMU
@@ -814,7 +814,7 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
     WN_TRY(make_ctx(&c, cfg, B, T, wsp, ws_bytes, flags, stream));
     if (!params || !x || !h || !dlogits || !grads) return fail(1, "NULL argument");
     // c = the data chain on the caller's stream; cs = the weight gradients, on the side stream unless serial
-    SideLock side(!(flags & WN_FLAG_NO_OVERLAP) && !wn_prof_is_on(), c.st);
+    SideLock side((flags & WN_FLAG_BWD_OVERLAP) && !wn_prof_is_on(), c.st);
     Ctx cs = c;
 #ifndef WN_EMU
     if (side.rt) cs.st = side.rt->st;

@@ -12,8 +12,8 @@ import torch
 
 from . import _lib
 
-# Launch modes every engine starts with: 0 = wn_backward's weight gradients on the library's side stream (the
-# library default).  Set from measurements on MI355X (profiles/r01/overlap_probe.txt).
+# Launch modes every engine starts with: 0 = everything on the caller's stream.  The opt-in overlap modes
+# (_lib.FLAG_BWD_OVERLAP / FLAG_FWD_OVERLAP) measured no faster on MI355X (profiles/r01/overlap_probe.txt).
 DEFAULT_FLAGS = 0
 
 

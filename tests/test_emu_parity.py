@@ -46,12 +46,12 @@ def test_overlap_launch_sequences(name):
     accumulate in place; weight gradients issued per bucket from a second context).  The emulator has one in-order
     stream, so this checks the sequences' arithmetic; the stream fork/join itself is covered on the GPU."""
     from pytorchwavenetvocoder_amd import _lib
-    PC.check_golden_case(GoldenCase(name), emu_library(), "cpu", flags=_lib.FLAG_FWD_OVERLAP)
+    PC.check_golden_case(GoldenCase(name), emu_library(), "cpu", flags=_lib.FLAG_FWD_OVERLAP | _lib.FLAG_BWD_OVERLAP)
     PC.check_golden_case(GoldenCase(name), emu_library(), "cpu", flags=_lib.FLAG_FWD_OVERLAP | _lib.FLAG_EXACT_MFMA,
                          layers_per_bucket=1)
-    PC.check_golden_case(GoldenCase(name), emu_library(), "cpu", flags=_lib.FLAG_NO_OVERLAP)
+    PC.check_golden_case(GoldenCase(name), emu_library(), "cpu", flags=_lib.FLAG_BWD_OVERLAP)
     # launch groups of 1 / 2 walked layers inside buckets of 2 / the whole stack
-    PC.check_golden_case(GoldenCase(name), emu_library(), "cpu", flags=_lib.flag_dw_flush(1), layers_per_bucket=2)
+    PC.check_golden_case(GoldenCase(name), emu_library(), "cpu", flags=_lib.FLAG_BWD_OVERLAP | _lib.flag_dw_flush(1), layers_per_bucket=2)
     PC.check_golden_case(GoldenCase(name), emu_library(), "cpu", flags=_lib.flag_dw_flush(2))
 
 

@@ -111,8 +111,8 @@ def test_cfg2_fused_equals_layered_midsize():
 
 
 def test_stream_overlap_modes_midsize():
-    """wn_backward's weight gradients run on the library's side stream beside the gate'/dX chain (default), serially
-    with WN_FLAG_NO_OVERLAP: same kernels and, for the same launch-group size (WN_FLAG_DW_FLUSH), the same reduction
+    """Opt-in overlap modes.  With WN_FLAG_BWD_OVERLAP wn_backward's weight gradients run on the library's side stream
+    beside the gate'/dX chain: same kernels and, for the same launch-group size (WN_FLAG_DW_FLUSH), the same reduction
     order -> bit-identical gradients for every bucket size, run to run (the fork/join must leave nothing pending).
     Different group sizes re-associate the split-K sums, and WN_FLAG_FWD_OVERLAP (skip-sum in chunks beside the
     residual stack) re-associates the skip sum: equal to round-off, and still within the oracle gates."""
@@ -140,12 +140,13 @@ def test_stream_overlap_modes_midsize():
 
     F5 = L.flag_dw_flush(5)
     for lpb in (0, 10, 7):
-        serial = run(L.FLAG_NO_OVERLAP | F5, lpb)
-        over = run(F5, lpb)
+        serial = run(F5, lpb)
+        over = run(L.FLAG_BWD_OVERLAP | F5, lpb)
         assert torch.equal(serial[0], over[0]) and serial[1] == over[1]
         assert torch.equal(serial[2], over[2]), "side-stream weight gradients differ from the serial ones (lpb %d)" % lpb
-    base = run(L.FLAG_NO_OVERLAP, 0)  # one launch group per bucket
-    for flags in (0, L.flag_dw_flush(3), L.FLAG_FWD_OVERLAP, L.FLAG_FWD_OVERLAP | L.flag_dw_flush(30)):
+    base = run(0, 0)  # serial, one launch group per bucket
+    for flags in (L.FLAG_BWD_OVERLAP, L.FLAG_BWD_OVERLAP | L.flag_dw_flush(3), L.FLAG_FWD_OVERLAP,
+                  L.FLAG_FWD_OVERLAP | L.FLAG_BWD_OVERLAP | L.flag_dw_flush(30)):
         r = run(flags, 0)
         assert float((r[0] - base[0]).abs().max()) <= 2e-5, flags
         assert abs(r[1] - base[1]) <= 1e-6, flags

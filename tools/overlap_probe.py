@@ -2,10 +2,11 @@
 # -*- coding: utf-8 -*-
 """A/B of the stream-overlap launch modes on the BASELINE configs[1] training step (one process, one model):
 
-    serial        WN_FLAG_NO_OVERLAP           everything on the caller's stream, one weight-gradient group per bucket
-    serial/5      ... | WN_FLAG_DW_FLUSH(5)    same, groups of 5 layers
-    bwd/n         WN_FLAG_DW_FLUSH(n)          weight gradients on the side stream beside the gate'/dX chain
-    bwd/n+fwd     ... | WN_FLAG_FWD_OVERLAP    + skip-sum in three chunks beside the residual stack
+    serial        0                                          everything on the caller's stream, one weight-gradient group per bucket
+    serial/5      WN_FLAG_DW_FLUSH(5)                        same, groups of 5 layers
+    bwd/n         WN_FLAG_BWD_OVERLAP | WN_FLAG_DW_FLUSH(n)  weight gradients on the side stream beside the gate'/dX chain
+    bwd/n+fwd     ... | WN_FLAG_FWD_OVERLAP                  + skip-sum in three chunks beside the residual stack
+    fwd           WN_FLAG_FWD_OVERLAP                        only the forward mode
 
 Prints ms/step and forward ms per mode (three interleaved rounds), writes gpurun_out/overlap_probe_<prio>.json and
 the flags of the fastest mode.  WN_SIDE_PRIORITY=normal|low (default low) is the priority of the library's side
@@ -40,9 +41,9 @@ def main():
     h = torch.randn(B, 80, frames, generator=gen).to(dev)
     opt = FusedAdam(model, lr=1e-4)
     F = _lib.flag_dw_flush
-    modes = [("serial/5", _lib.FLAG_NO_OVERLAP | F(5)), ("bwd/5", F(5)), ("serial", _lib.FLAG_NO_OVERLAP),
-             ("bwd/3", F(3)), ("bwd/10", F(10)), ("bwd/30", F(30)), ("bwd/5+fwd", F(5) | _lib.FLAG_FWD_OVERLAP),
-             ("bwd/10+fwd", F(10) | _lib.FLAG_FWD_OVERLAP)]
+    BW, FW = _lib.FLAG_BWD_OVERLAP, _lib.FLAG_FWD_OVERLAP
+    modes = [("serial/5", F(5)), ("bwd/5", BW | F(5)), ("serial", 0), ("bwd/3", BW | F(3)), ("bwd/10", BW | F(10)),
+             ("bwd/30", BW | F(30)), ("bwd/5+fwd", BW | FW | F(5)), ("bwd/10+fwd", BW | FW | F(10)), ("fwd", FW)]
     prio = os.environ.get("WN_SIDE_PRIORITY", "low")
     eng = model.engine
 
