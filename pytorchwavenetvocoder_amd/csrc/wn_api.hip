@@ -518,44 +518,47 @@ static int pack_weights(const Ctx& c, const float* params) {
     const long lb0 = layer_base(y, d, 0);
     const long lstep = -y.LB;  // layer l block = lb0 + l*lstep
     WnCopy4 cp;
+    WnCopy4Batch jobs;  // all re-layouts below (11 of them): one launch
+    jobs.njobs = 0;
     // wc_f[tap][q][r] = causal_w[r][q][tap]
     cp.n0 = d.K; cp.n1 = d.Q; cp.n2 = d.R; cp.nl = 1;
     cp.d0 = (long)d.Q * d.R; cp.d1 = d.R; cp.d2 = 1; cp.dl = 0;
     cp.s0 = 1; cp.s1 = d.K; cp.s2 = (long)d.Q * d.K; cp.sl = 0;
-    WN_TRY(wn_copy4(ws + w.wc_f, params + y.causal_w, &cp, c.st));
+    WN_TRY(wn_copy4_batch_add(&jobs, ws + w.wc_f, params + y.causal_w, &cp));
     // wd_f[l][(tap*R+i)*2R + o'] = W{sig,tanh}[o][i][tap] ;  wd_b[l][(tap*2R+o')*R + i] = same
     for (int half = 0; half < 2; ++half) {
         const long src = lb0 + (half ? y.o_dtanh_w : y.o_dsig_w);
         cp.n0 = d.K; cp.n1 = d.R /*i*/; cp.n2 = d.R /*o*/; cp.nl = d.L;
         cp.s0 = 1; cp.s1 = d.K; cp.s2 = (long)d.R * d.K; cp.sl = lstep;
         cp.d0 = (long)d.R * 2 * d.R; cp.d1 = 2 * d.R; cp.d2 = 1; cp.dl = (long)d.K * d.R * 2 * d.R;
-        WN_TRY(wn_copy4(ws + w.wd_f + (long)half * d.R, params + src, &cp, c.st));
+        WN_TRY(wn_copy4_batch_add(&jobs, ws + w.wd_f + (long)half * d.R, params + src, &cp));
         cp.d0 = (long)2 * d.R * d.R; cp.d1 = 1; cp.d2 = d.R; cp.dl = (long)d.K * 2 * d.R * d.R;
-        WN_TRY(wn_copy4(ws + w.wd_b + (long)half * d.R * d.R, params + src, &cp, c.st));
+        WN_TRY(wn_copy4_batch_add(&jobs, ws + w.wd_b + (long)half * d.R * d.R, params + src, &cp));
         // waux_f[a][l*2R + o'] = Waux{sig,tanh}_l[o][a]
         const long asrc = lb0 + (half ? y.o_atanh_w : y.o_asig_w);
         cp.n0 = 1; cp.n1 = d.A; cp.n2 = d.R; cp.nl = d.L;
         cp.s0 = 0; cp.s1 = 1; cp.s2 = d.A; cp.sl = lstep;
         cp.d0 = 0; cp.d1 = (long)d.L * 2 * d.R; cp.d2 = 1; cp.dl = 2 * d.R;
-        WN_TRY(wn_copy4(ws + w.waux_f + (long)half * d.R, params + asrc, &cp, c.st));
+        WN_TRY(wn_copy4_batch_add(&jobs, ws + w.waux_f + (long)half * d.R, params + asrc, &cp));
     }
     // wres_f[l][i*R + o] = Wres_l[o][i]
     cp.n0 = 1; cp.n1 = d.R; cp.n2 = d.R; cp.nl = d.L;
     cp.s0 = 0; cp.s1 = 1; cp.s2 = d.R; cp.sl = lstep;
     cp.d0 = 0; cp.d1 = d.R; cp.d2 = 1; cp.dl = (long)d.R * d.R;
-    WN_TRY(wn_copy4(ws + w.wres_f, params + lb0 + y.o_res_w, &cp, c.st));
+    WN_TRY(wn_copy4_batch_add(&jobs, ws + w.wres_f, params + lb0 + y.o_res_w, &cp));
     // wskip_f[(l*R + r)*S + s] = Wskip_l[s][r]
     cp.n0 = 1; cp.n1 = d.R; cp.n2 = d.S; cp.nl = d.L;
     cp.s0 = 0; cp.s1 = 1; cp.s2 = d.R; cp.sl = y.ls_skip;
     cp.d0 = 0; cp.d1 = d.S; cp.d2 = 1; cp.dl = (long)d.R * d.S;
-    WN_TRY(wn_copy4(ws + w.wskip_f, params + y.skip0, &cp, c.st));
+    WN_TRY(wn_copy4_batch_add(&jobs, ws + w.wskip_f, params + y.skip0, &cp));
     // w1_f[i*S + o] = W1[o][i] ; w2_f[i*Q + q] = W2[q][i]
     cp.n0 = 1; cp.n1 = d.S; cp.n2 = d.S; cp.nl = 1;
     cp.s0 = 0; cp.s1 = 1; cp.s2 = d.S; cp.sl = 0;
     cp.d0 = 0; cp.d1 = d.S; cp.d2 = 1; cp.dl = 0;
-    WN_TRY(wn_copy4(ws + w.w1_f, params + y.post1_w, &cp, c.st));
+    WN_TRY(wn_copy4_batch_add(&jobs, ws + w.w1_f, params + y.post1_w, &cp));
     cp.n1 = d.S; cp.n2 = d.Qo; cp.s1 = 1; cp.s2 = d.S; cp.d1 = d.Qo; cp.d2 = 1;
-    WN_TRY(wn_copy4(ws + w.w2_f, params + y.post2_w, &cp, c.st));
+    WN_TRY(wn_copy4_batch_add(&jobs, ws + w.w2_f, params + y.post2_w, &cp));
+    WN_TRY(wn_copy4_batch(&jobs, c.st));
     // cvec / rowsum_aux / bskip / one
     WnCvecArgs ca;
     ca.params = params;

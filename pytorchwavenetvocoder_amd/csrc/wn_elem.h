@@ -40,6 +40,22 @@ typedef struct WnCopy4 {
     long d0, d1, d2, dl, s0, s1, s2, sl;
 } WnCopy4;
 int wn_copy4(float* dst, const float* src, const WnCopy4* c, wn_stream_t st);
+// several independent copies in ONE launch (the weight packing of a forward is ten of them)
+#define WN_COPY4_MAXJOBS 12
+typedef struct WnCopy4Batch {
+    int njobs;
+    int blk0[WN_COPY4_MAXJOBS + 1];  // first block of job j (filled by wn_copy4_batch)
+    float* dst[WN_COPY4_MAXJOBS];
+    const float* src[WN_COPY4_MAXJOBS];
+    WnCopy4 c[WN_COPY4_MAXJOBS];
+} WnCopy4Batch;
+static inline int wn_copy4_batch_add(WnCopy4Batch* b, float* dst, const float* src, const WnCopy4* c) {
+    if (b->njobs >= WN_COPY4_MAXJOBS) return 1;
+    b->dst[b->njobs] = dst; b->src[b->njobs] = src; b->c[b->njobs] = *c;
+    b->njobs++;
+    return 0;
+}
+int wn_copy4_batch(WnCopy4Batch* b, wn_stream_t st);
 
 // cvec[l][o'] = b_dil[o'] + b_aux[o'] + b_up * sum_a Waux[o'][a]   (o' in [0,2R): sigmoid then tanh)
 // rowsum_aux[l][o'] = sum_a Waux[o'][a]

@@ -227,6 +227,39 @@ __global__ __launch_bounds__(WN_TPB) void k_copy4(float* __restrict__ dst, const
     dst[i0 * c.d0 + i1 * c.d1 + i2 * c.d2 + l * c.dl] = src[i0 * c.s0 + i1 * c.s1 + i2 * c.s2 + l * c.sl];
 }
 
+static __device__ __forceinline__ void copy4_elem(float* __restrict__ dst, const float* __restrict__ src, const WnCopy4& c, long i) {
+    const int i2 = (int)(i % c.n2);
+    long r = i / c.n2;
+    const int i1 = (int)(r % c.n1);
+    r /= c.n1;
+    const int i0 = (int)(r % c.n0);
+    const int l = (int)(r / c.n0);
+    dst[i0 * c.d0 + i1 * c.d1 + i2 * c.d2 + l * c.dl] = src[i0 * c.s0 + i1 * c.s1 + i2 * c.s2 + l * c.sl];
+}
+
+__global__ __launch_bounds__(WN_TPB) void k_copy4_batch(WnCopy4Batch a) {
+    int j = 0;
+    while (j + 1 < a.njobs && (int)blockIdx.x >= a.blk0[j + 1]) ++j;  // block-uniform
+    const WnCopy4& c = a.c[j];
+    const long total = (long)c.nl * c.n0 * c.n1 * c.n2;
+    const long i = (long)((int)blockIdx.x - a.blk0[j]) * WN_TPB + threadIdx.x;
+    if (i < total) copy4_elem(a.dst[j], a.src[j], c, i);
+}
+
+int wn_copy4_batch(WnCopy4Batch* b, wn_stream_t st) {
+    WN_PROF("copy4", 0.0, 0.0, st);
+    int nblk = 0;
+    for (int j = 0; j < b->njobs; ++j) {
+        const long total = (long)b->c[j].nl * b->c[j].n0 * b->c[j].n1 * b->c[j].n2;
+        b->blk0[j] = nblk;
+        nblk += (int)((total + WN_TPB - 1) / WN_TPB);
+    }
+    b->blk0[b->njobs] = nblk;
+    if (nblk <= 0) return 0;
+    WN_LAUNCH(k_copy4_batch, dim3((unsigned)nblk), dim3(WN_TPB), 0, st, *b);
+    return 0;
+}
+
 int wn_copy4(float* dst, const float* src, const WnCopy4* c, wn_stream_t st) {
     WN_PROF("copy4", 0.0, 0.0, st);
     const long total = (long)c->nl * c->n0 * c->n1 * c->n2;
