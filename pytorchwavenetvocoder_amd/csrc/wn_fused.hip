@@ -44,6 +44,18 @@ static int stagger_setting() {
     return e ? atoi(e) : 0;  // measured on MI355X (profiles/r01): 0 -> 19.8 ms, 1 -> 20.0, 3 -> 20.1, 5 -> 20.5 ms per step
 }
 
+// tuning knob (A/B on hardware): WN_CHAIN_BLOCKS=<n> caps the persistent grid of the fused kernels (default 256 = one
+// workgroup per CU); measures how many CUs the HBM-bound chain kernels need to keep their rate
+static long chain_blocks() {
+    static long v = -1;
+    if (v < 0) {
+        const char* e = getenv("WN_CHAIN_BLOCKS");
+        v = e ? atol(e) : 256;
+        if (v < 8) v = 256;
+    }
+    return v;
+}
+
 #ifndef WN_FT
 #define WN_FT 512  // threads per workgroup (8 waves = 2 per SIMD)
 #endif
@@ -705,7 +717,7 @@ template <int K>
 static int launch_fwd(const FwdArgs& a, int split, wn_stream_t st) {
     const long ntiles = (long)a.B * ((a.T + 31) / 32);
     long nblk = (ntiles + WN_FW - 1) / WN_FW;
-    if (nblk > 256) nblk = 256;
+    if (nblk > chain_blocks()) nblk = chain_blocks();
     const size_t lds_s = (size_t)K * 4 * (3 * 128 * 32) + 4 * (3 * 64 * 32) + 192 * sizeof(float);
     if (split && lds_s <= 160 * 1024) {  // K = 3 does not fit split: stays on the f32 MFMA
         if (set_lds(k_resblock_fwd_s<K>, lds_s)) return 1;
@@ -1131,7 +1143,7 @@ template <int MODE>
 static int launch_conv64(const ConvArgs& a, int split, wn_stream_t st) {
     const long ntiles = (long)a.B * ((a.T + 31) / 32);
     long nblk = (ntiles + WN_FW - 1) / WN_FW;
-    if (nblk > 256) nblk = 256;
+    if (nblk > chain_blocks()) nblk = chain_blocks();
     if (split) {
         const size_t lds = (size_t)a.nchunks * 2 * 6144;
         if (lds > 160 * 1024 || set_lds(k_conv64s<MODE>, lds)) return 1;
