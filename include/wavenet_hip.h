@@ -91,6 +91,8 @@ enum {
 #define WN_FLAG_BWD_OVERLAP 4 /* wn_backward: weight-gradient contractions on the side stream beside the gate'/dX chain;
                                * same kernels, same reduction order: bit-identical to the serial mode for the same
                                * launch-group size */
+#define WN_FLAG_BWD_OVERLAP_HEAD 16 /* with WN_FLAG_BWD_OVERLAP: only the post-net / skip weight gradients run on the side
+                               * stream; the per-layer groups stay on the caller's stream */
 #define WN_FLAG_FWD_OVERLAP 8 /* wn_forward (fused kernels): the skip-sum contraction is issued in three chunks of layers on
                                * the side stream while the residual stack is still running (the partial sums round
                                * differently from the single contraction: ~1e-7 relative on the logits) */

@@ -102,7 +102,20 @@ static SideRt* side_get(wn_stream_t caller) {
         int least = 0, greatest = 0;
         const char* pr = getenv("WN_SIDE_PRIORITY");
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || (pr && !strcmp(pr, "normal"))) least = 0;
-        if (hipStreamCreateWithPriority(&r->st, hipStreamNonBlocking, least) != hipSuccess) {
+        // WN_SIDE_CUS=<n> (A/B measurements): the side stream may only use n CUs (CU-mask bits interleave the XCDs, so
+        // the first n bits are n/8 CUs of every XCD).  Such a stream is a BLOCKING stream (hipExtStreamCreateWithCUMask
+        // has no flags): it only overlaps with a caller stream other than the NULL stream.
+        const char* cus = getenv("WN_SIDE_CUS");
+        const int ncu = cus ? atoi(cus) : 0;
+        hipError_t ce;
+        if (ncu > 0 && ncu < 1024) {
+            uint32_t mask[32] = {0};
+            for (int i = 0; i < ncu; ++i) mask[i >> 5] |= 1u << (i & 31);
+            ce = hipExtStreamCreateWithCUMask(&r->st, 32, mask);
+        } else {
+            ce = hipStreamCreateWithPriority(&r->st, hipStreamNonBlocking, least);
+        }
+        if (ce != hipSuccess) {
             (void)hipGetLastError();
             delete r;
             return nullptr;
@@ -897,8 +910,11 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
     const float* upw = d.U > 0 ? params + y.up_w : ws + w.one;
     const long g_bstride = (long)d.L * 2 * d.R * F;
     const long P_L = 2 * BRT;
+    // WN_FLAG_BWD_OVERLAP_HEAD: only the post-net / skip weight gradients (matrix-bound) go to the side stream, the
+    // per-layer groups (HBM-bound like the chain itself) follow the chain on the caller's stream
+    const Ctx& cl = (flags & WN_FLAG_BWD_OVERLAP_HEAD) ? c : cs;
     auto flush_bucket = [&](int lo, int hi) -> int {
-        const Ctx& c = cs;  // every launch of a flush is a weight gradient
+        const Ctx& c = cl;  // every launch of a flush is a weight gradient
         const int nl = hi - lo;
         const long lb_lo = layer_base(y, d, lo);
         float* dc = ws + w.dc + (long)lo * 2 * d.R;
@@ -971,7 +987,7 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
     // most WN_DW_FLUSH_DEFAULT layers in overlap mode so that they start while the chain is still running; flags bits
     // 8..15 override the group size.  (The split-K plan, hence the rounding, depends on the group size.)
     int fmax = (flags >> 8) & 0xff;
-    if (fmax == 0) fmax = side.rt ? WN_DW_FLUSH_DEFAULT : d.L;
+    if (fmax == 0) fmax = (side.rt && !(flags & WN_FLAG_BWD_OVERLAP_HEAD)) ? WN_DW_FLUSH_DEFAULT : d.L;
     int bucket_hi = d.L;  // layers [l, bucket_hi) have been walked but not flushed yet
     for (int l = d.L - 1; l >= 0; --l) {
         const int dil = dilation_of(cfg, l);
@@ -1021,11 +1037,13 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
         const int done = d.L - l;  // layers walked
         const bool bucket_end = (done % lpb == 0 || l == 0);
         if (bucket_end || bucket_hi - l >= fmax) {
-            WN_TRY(side_link(side.rt, c.st, cs.st));  // dP, dX of layers [l, bucket_hi) are enqueued
+            WN_TRY(side_link(side.rt, c.st, cl.st));  // dP, dX of layers [l, bucket_hi) are enqueued
+            if (flags & WN_FLAG_BWD_OVERLAP_HEAD)       // the split-K partial buffers are shared with the head's launches
+                WN_TRY(side_link(side.rt, cs.st, c.st));
             WN_TRY(flush_bucket(l, bucket_hi));
             bucket_hi = l;
             if (bucket_end) {
-                if (events) rt_event_record(events[bucket], cs.st);
+                if (events) rt_event_record(events[bucket], cl.st);
                 bucket++;
             }
         }
@@ -1034,7 +1052,7 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
     // ---- front conv: scatter over the token indices, or (large tables) the one-hot contraction ----
     if (wn_front_dw_supported(d.R, d.K, d.Q) &&
         wn_front_dw_partial_floats(B, T, d.R, d.K, d.Q) <= w.front_partial_floats) {
-        WN_TRY(wn_front_dw(dXn, x, ws + w.front_partial, grads + y.causal_w, grads + y.causal_b, B, T, d.R, d.K, d.Q, cs.st));
+        WN_TRY(wn_front_dw(dXn, x, ws + w.front_partial, grads + y.causal_w, grads + y.causal_b, B, T, d.R, d.K, d.Q, cl.st));
     } else {
         WnGemmArgs g = wn_gemm_default();
         g.M = d.R; g.N = d.K * d.Q; g.K = T;
@@ -1047,7 +1065,7 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
         o.n_seg = d.Q; o.n_seg_stride = 1; o.n_stride = d.K;
         o.addend_m = nullptr; o.addend_scale_ptr = nullptr; o.rowsum_out = grads + y.causal_b;
         o.out_lstride = 0; o.addend_lstride = 0; o.rowsum_lstride = 0;
-        WN_TRY(dw_gemm(cs, g, o));
+        WN_TRY(dw_gemm(cl, g, o));
     }
     // ---- upsampling layer parameters ----
     if (d.U > 0) {
@@ -1058,11 +1076,11 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
         r.scale = 1.0f; r.accumulate = 0; r.addend_m = nullptr; r.addend_scale_ptr = nullptr;
         r.scratch = ws + w.red_scratch; r.scratch_floats = w.red_scratch_floats;
         r.nl = 1; r.out_lstride = 0; r.addend_lstride = 0;
-        WN_TRY(wn_reduce(&r, cs.st));
+        WN_TRY(wn_reduce(&r, cl.st));
         // d b_up = sum_{l,o'} rowsum(Waux_l)[o'] * dc_l[o']
-        WN_TRY(wn_dot(ws + w.rowsum_aux, ws + w.dc, (long)d.L * 2 * d.R, grads + y.up_b, 0, cs.st));
+        WN_TRY(wn_dot(ws + w.rowsum_aux, ws + w.dc, (long)d.L * 2 * d.R, grads + y.up_b, 0, cl.st));
     }
-    if (events) rt_event_record(events[bucket], cs.st);
+    if (events) rt_event_record(events[bucket], cl.st);
     bucket++;
     WN_TRY(side_link(side.rt, cs.st, c.st));  // join: the caller's stream continues after every gradient
     return rt_check("wn_backward");

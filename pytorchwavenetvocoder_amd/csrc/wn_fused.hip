@@ -61,6 +61,27 @@ static long chain_blocks() {
 #endif
 #define WN_FW (WN_FT / 64)  // waves per workgroup
 
+// Persistent grid of the fused kernels: the smallest multiple of 8 workgroups (XCD-aware walk) that needs no more
+// rounds of tiles than one workgroup per CU would.  Config 2 has 5 760 tiles: 256 x 8 waves walk them in 2.81 -> 3
+// rounds, 240 x 8 in exactly 3 -- same time (12.95 vs 13.05 ms/step measured, profiles/r01/cosched_probe.txt), and 16
+// CUs stay free for whatever runs beside the chain (the RCCL kernels of the gradient all-reduce).  WN_CHAIN_BALANCE=0
+// restores one workgroup per CU.
+static long balanced_blocks(long ntiles) {
+    const long cap = chain_blocks();
+    long nblk = (ntiles + WN_FW - 1) / WN_FW;
+    if (nblk <= cap) return nblk;
+    static int balance = -1;
+    if (balance < 0) {
+        const char* e = getenv("WN_CHAIN_BALANCE");
+        balance = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    if (!balance) return cap;
+    const long rounds = (ntiles + cap * WN_FW - 1) / (cap * WN_FW);
+    long nb = (ntiles + rounds * WN_FW - 1) / (rounds * WN_FW);
+    nb = (nb + 7) / 8 * 8;
+    return nb < cap ? nb : cap;
+}
+
 // channel handled by k-step s (0..31 within a 64-channel group) for lane-half hi
 static __device__ __forceinline__ int kappa64(int s, int hi) {
     return 32 * (s >> 4) + ((s & 15) & 3) + 8 * ((s & 15) >> 2) + 4 * hi;
@@ -716,8 +737,7 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
 template <int K>
 static int launch_fwd(const FwdArgs& a, int split, wn_stream_t st) {
     const long ntiles = (long)a.B * ((a.T + 31) / 32);
-    long nblk = (ntiles + WN_FW - 1) / WN_FW;
-    if (nblk > chain_blocks()) nblk = chain_blocks();
+    const long nblk = balanced_blocks(ntiles);
     const size_t lds_s = (size_t)K * 4 * (3 * 128 * 32) + 4 * (3 * 64 * 32) + 192 * sizeof(float);
     if (split && lds_s <= 160 * 1024) {  // K = 3 does not fit split: stays on the f32 MFMA
         if (set_lds(k_resblock_fwd_s<K>, lds_s)) return 1;
@@ -1142,8 +1162,7 @@ __global__ __launch_bounds__(WN_FT) void k_conv64s(ConvArgs a) {
 template <int MODE>
 static int launch_conv64(const ConvArgs& a, int split, wn_stream_t st) {
     const long ntiles = (long)a.B * ((a.T + 31) / 32);
-    long nblk = (ntiles + WN_FW - 1) / WN_FW;
-    if (nblk > chain_blocks()) nblk = chain_blocks();
+    const long nblk = balanced_blocks(ntiles);
     if (split) {
         const size_t lds = (size_t)a.nchunks * 2 * 6144;
         if (lds > 160 * 1024 || set_lds(k_conv64s<MODE>, lds)) return 1;
