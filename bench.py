@@ -166,7 +166,7 @@ def main():
 
     import torch.distributed as dist
     from pytorchwavenetvocoder_amd import _lib
-    from pytorchwavenetvocoder_amd.distributed import GradientReducer
+    from pytorchwavenetvocoder_amd.distributed import GradientReducer, rccl_footprint_defaults
     from pytorchwavenetvocoder_amd.nets import WaveNet, initialize
     from pytorchwavenetvocoder_amd.optim import FusedAdam
 
@@ -187,6 +187,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
+            rccl_footprint_defaults()
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)

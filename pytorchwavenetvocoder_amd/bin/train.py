@@ -296,6 +296,8 @@ def _worker(rank, world, args, port):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(port))
+        from pytorchwavenetvocoder_amd.distributed import rccl_footprint_defaults
+        rccl_footprint_defaults()
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     is_main = rank == 0
     if is_main:

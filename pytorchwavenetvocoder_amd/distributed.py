@@ -10,8 +10,20 @@ out in backward-completion order, so buckets are contiguous ranges: ``wn_backwar
 event after each bucket and the all-reduce of bucket i runs on a side stream while the backward
 kernels of the following layers are still executing.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def rccl_footprint_defaults():
+    """Call before ``init_process_group("nccl")``.  The fused chain kernels are persistent grids that need a whole CU
+    per workgroup (120 KB LDS, every VGPR); for the benchmark geometry they use 240 of the 256 CUs.  An RCCL kernel
+    with more workgroups (= channels) than the 16 CUs left would take CUs a chain kernel is about to claim, and the
+    unplaced part of that grid only starts when the rest of it retires (measured with a side-stream contraction:
+    DESIGN.md 5.1).  The gradient buffer is 6.4 MB in 4 buckets -- latency-bound, so 16 channels cost nothing.
+    ``setdefault``: an explicit NCCL_MAX_NCHANNELS in the environment wins."""
+    os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
 
 
 class GradientReducer(object):
