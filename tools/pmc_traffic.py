@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+# -*- coding: utf-8 -*-
+"""HBM traffic per kernel launch from two rocprofv3 counter passes (tools/pmc_traffic.sh):
+
+    python tools/pmc_traffic.py <dir of the --pmc FETCH_SIZE pass> <dir of the --pmc WRITE_SIZE pass> <steps> > pmc_traffic.json
+
+bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KB; on gfx950 FETCH_SIZE tallies the 128-byte fabric
+requests at 64 bytes (MI355X_MICROARCH.md, section HBM) -- calibrated on this code's own dword buffer accesses: the
+fused forward kernel writes exactly 4 x B*R*T*4 = 188.7 MB (WRITE_SIZE 187.2 MB) and the fused gate kernel must read
+329.7 MB (2 * FETCH_SIZE = 329.6 MB).  `steps` = number of training steps the profiled command ran (warm-up + timed +
+profile steps), used for the whole-step total."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from pmc_summary import summarize  # noqa: E402
+
+TAGS = {"fused_bwd_gate": "void k_conv64s<0>(ConvArgs)", "fused_resblock_fwd": "void k_resblock_fwd_s<2>(FwdArgs)",
+        "fused_bwd_dx": "void k_conv64s<1>(ConvArgs)"}
+
+
+def main():
+    fetch, write, steps = summarize([sys.argv[1]]), summarize([sys.argv[2]]), float(sys.argv[3])
+    per, total = {}, 0.0
+    for k in sorted(set(fetch) | set(write)):
+        f = fetch.get(k, {}).get("FETCH_SIZE", 0.0)
+        w = write.get(k, {}).get("WRITE_SIZE", 0.0)
+        n = max(fetch.get(k, {}).get("launches", 0), write.get(k, {}).get("launches", 0))
+        b = (2.0 * f + w) * 1024.0
+        per[k[:80]] = b
+        total += b * n
+    out = {}
+    for tag, name in TAGS.items():
+        if name in fetch or name in write:
+            out[tag] = {"kernel": name, "fetch_size_kb": fetch.get(name, {}).get("FETCH_SIZE"),
+                        "write_size_kb": write.get(name, {}).get("WRITE_SIZE"),
+                        "hbm_bytes_per_launch": (2.0 * fetch.get(name, {}).get("FETCH_SIZE", 0.0) +
+                                                 write.get(name, {}).get("WRITE_SIZE", 0.0)) * 1024.0}
+    out["_step_total_bytes"] = total / steps
+    out["_per_kernel_bytes_per_launch"] = per
+    out["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/pmc_traffic.sh); bytes = "
+                    "(2*FETCH_SIZE + WRITE_SIZE)*1024, see tools/pmc_traffic.py; the step total includes the model "
+                    "set-up kernels of the run divided by the number of steps")
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
