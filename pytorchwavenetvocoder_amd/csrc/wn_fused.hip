@@ -793,6 +793,7 @@ struct ConvArgs {
     const float* resid;  // MODE 1 (nullable)
     float* out;          // MODE 0: dP (B,128,T) ; MODE 1: dX (B,64,T)
     int stagger;
+    int interleave;      // k_conv64s: chunk q -> segment q % nseg (equal-size segments): the taps of one channel group back to back
 };
 
 template <int MODE>
@@ -978,9 +979,15 @@ __global__ __launch_bounds__(WN_FT) void k_conv64s(ConvArgs a) {
     for (int idx = threadIdx.x; idx < a.nchunks * 2 * 128; idx += WN_FT) {
         const int o = idx & 63, h = (idx >> 6) & 1, kbg = idx >> 7;
         int sg = 0, c = kbg * 16 + 8 * h;
-        while (sg + 1 < a.nseg && c >= a.seg[sg].nch) {
-            c -= a.seg[sg].nch;
-            ++sg;
+        if (a.interleave) {
+            const int q = kbg >> 1;
+            sg = q % a.nseg;
+            c = (q / a.nseg) * 32 + (kbg & 1) * 16 + 8 * h;
+        } else {
+            while (sg + 1 < a.nseg && c >= a.seg[sg].nch) {
+                c -= a.seg[sg].nch;
+                ++sg;
+            }
         }
         const float* src = a.seg[sg].w + (long)c * 64 + o;
         unsigned hq[4], mq[4], lq[4];
@@ -1023,6 +1030,11 @@ __global__ __launch_bounds__(WN_FT) void k_conv64s(ConvArgs a) {
     float xa[16], xb[16];
     bool oka = false, okb = false;
     auto locate = [&](int q, int& sg, int& c0) {
+        if (a.interleave) {
+            sg = q % a.nseg;
+            c0 = (q / a.nseg) * 32;
+            return;
+        }
         sg = 0;
         c0 = q * 32;
         while (sg + 1 < a.nseg && c0 >= a.seg[sg].nch) {
@@ -1192,6 +1204,7 @@ int wn_fused_bwd_gate(const float* wskip, const float* wres, const float* dSk, c
     }
     a.B = B; a.T = T; a.S = S; a.Gt = Gt; a.resid = nullptr; a.out = dP;
     a.stagger = stagger_setting();
+    a.interleave = 0;
     return launch_conv64<0>(a, split, st);
 }
 
@@ -1213,5 +1226,15 @@ int wn_fused_bwd_dx(const float* wd_b, const float* dP, const float* dXn, float*
     a.nchunks = K * 4;
     a.B = B; a.T = T; a.S = nullptr; a.Gt = nullptr; a.resid = dXn; a.out = dX;
     a.stagger = stagger_setting();
+    // The taps of one 32-channel group are consumed back to back: position p is read as tap K-1 by the wave of its
+    // own tile and as an earlier tap by the wave d samples away, and with [tap][channel] order those two reads of the
+    // same lines were half a tile period apart -- longer than a line survives in the XCD's 4 MB L2 under the
+    // kernel's write stream, so the second tap came over the fabric again (PMC: 253 MB per launch for 189 compulsory).
+    static int il = -1;
+    if (il < 0) {
+        const char* e = getenv("WN_DX_INTERLEAVE");
+        il = e ? atoi(e) : 1;  // measured: 56.3 -> 53.0 us per launch (profiles/r01/tap_probe.txt); WN_DX_INTERLEAVE=0 for A/B
+    }
+    a.interleave = (K > 1 && il) ? 1 : 0;
     return launch_conv64<1>(a, split, st);
 }
