@@ -82,3 +82,24 @@ def test_two_rank_data_parallel_equals_single_process(tmp_path):
         O.train_step(cfg, oparams, oopt, x, h, t)
     for k, v in model.state_dict().items():
         assert float((v - oparams[k]).abs().max()) <= 1e-5, k
+
+
+def test_rccl_footprint_default_respects_the_environment(monkeypatch):
+    """bench.py / train.py cap RCCL at 16 channels before init_process_group("nccl") (the persistent chain kernels
+    leave 16 CUs); an explicit setting in the environment wins."""
+    from pytorchwavenetvocoder_amd.distributed import rccl_footprint_defaults
+    monkeypatch.delenv("NCCL_MAX_NCHANNELS", raising=False)
+    rccl_footprint_defaults()
+    assert os.environ["NCCL_MAX_NCHANNELS"] == "16"
+    monkeypatch.setenv("NCCL_MAX_NCHANNELS", "4")
+    rccl_footprint_defaults()
+    assert os.environ["NCCL_MAX_NCHANNELS"] == "4"
+
+
+def test_bench_reports_the_stream_mode():
+    import bench
+    from pytorchwavenetvocoder_amd import _lib
+    assert bench.stream_mode(0) == "serial (one stream)"
+    assert "side stream" in bench.stream_mode(_lib.FLAG_BWD_OVERLAP | _lib.flag_dw_flush(10))
+    assert "every 10 walked layers" in bench.stream_mode(_lib.FLAG_BWD_OVERLAP | _lib.flag_dw_flush(10))
+    assert "skip-sum" in bench.stream_mode(_lib.FLAG_FWD_OVERLAP)
