@@ -492,7 +492,9 @@ long wn_front_dw_partial_floats(int B, int T, int R, int K, int Q) {
     return (long)B * nc * ((long)R * K * Q + R);
 }
 
-__global__ __launch_bounds__(256) void k_front_dw_scatter(const float* __restrict__ dX0, const int64_t* __restrict__ x,
+#define FD_T 1024            // threads of k_front_dw_scatter
+#define FD_W (FD_T / 64)      // its waves
+__global__ __launch_bounds__(FD_T) void k_front_dw_scatter(const float* __restrict__ dX0, const int64_t* __restrict__ x,
                                                           float* __restrict__ partial, int T, int R, int K, int Q, int chunk) {
     WN_DYN_SMEM(smem_raw);
     float* acc = reinterpret_cast<float*>(smem_raw);  // [R][K*Q]
@@ -501,13 +503,15 @@ __global__ __launch_bounds__(256) void k_front_dw_scatter(const float* __restric
     const int b = blockIdx.y, t0 = blockIdx.x * chunk;
     const int t1 = (t0 + chunk < T) ? t0 + chunk : T;
     const int ntab = R * KQ + R, ntab4 = ntab >> 2;
-    for (int i = tid; i < ntab4; i += 256) reinterpret_cast<float4*>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = 4 * ntab4 + tid; i < ntab; i += 256) acc[i] = 0.0f;
+    for (int i = tid; i < ntab4; i += FD_T) reinterpret_cast<float4*>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 4 * ntab4 + tid; i < ntab; i += FD_T) acc[i] = 0.0f;
     __syncthreads();
     const int64_t* xb = x + (long)b * T;
     const float* db = dX0 + (long)b * R * T;
     float* out = partial + ((long)b * gridDim.x + blockIdx.x) * ((long)R * KQ + R);
-    // wave w owns channels w, w+4, w+8, ...: no two waves ever touch the same table row.  The token
+    // wave w owns channels w, w+FD_W, w+2 FD_W, ...: no two waves ever touch the same table row (and the order of the
+    // additions into one table entry -- time strips in sequence, lanes in hardware order -- does not depend on the
+    // number of waves).  16 waves per CU instead of 4 hide the LDS-atomic latency.  The token
     // columns of a 64-step strip are looked up once and reused for all channels of the wave.
     float* rsum = acc + R * KQ;  // [R] row sums (bias gradient)
     for (int ts = t0; ts < t1; ts += 64) {
@@ -524,16 +528,16 @@ __global__ __launch_bounds__(256) void k_front_dw_scatter(const float* __restric
                 col[k] = k * Q + (int)q;
             }
         }
-        for (int c0 = wave; c0 < R; c0 += 32) {  // 8 channels of this wave per step: 8 loads in flight
+        for (int c0 = wave; c0 < R; c0 += 8 * FD_W) {  // up to 8 channels of this wave per step: 8 loads in flight
             float v[8];
             WN_UNROLL
             for (int u = 0; u < 8; ++u) {
-                const int c = c0 + 4 * u;
+                const int c = c0 + FD_W * u;
                 v[u] = (ok && c < R) ? db[(long)c * T + t] : 0.0f;
             }
             WN_UNROLL
             for (int u = 0; u < 8; ++u) {
-                const int c = c0 + 4 * u;
+                const int c = c0 + FD_W * u;
                 if (c < R) {
                     WN_UNROLL
                     for (int k = 0; k < 8; ++k)
@@ -543,7 +547,7 @@ __global__ __launch_bounds__(256) void k_front_dw_scatter(const float* __restric
         }
     }
     // bias gradient: row sums of this block's time range (second, cheap pass over the same cache lines)
-    for (int c = wave; c < R; c += 4) {
+    for (int c = wave; c < R; c += FD_W) {
         float rs = 0.0f;
         for (int ts = t0; ts < t1; ts += 256) {
             float v[4];
@@ -559,9 +563,9 @@ __global__ __launch_bounds__(256) void k_front_dw_scatter(const float* __restric
     }
     __syncthreads();
     if ((((long)R * KQ + R) & 3) == 0) {  // per-block slabs stay 16-byte aligned
-        for (int i = tid; i < ntab4; i += 256) reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(acc)[i];
+        for (int i = tid; i < ntab4; i += FD_T) reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(acc)[i];
     } else {
-        for (int i = tid; i < ntab; i += 256) out[i] = acc[i];
+        for (int i = tid; i < ntab; i += FD_T) out[i] = acc[i];
     }
 }
 
@@ -602,7 +606,7 @@ int wn_front_dw(const float* dX0, const int64_t* x, float* partial, float* dW, f
                             (int)lds) != hipSuccess)
         return 2;
 #endif
-    WN_LAUNCH(k_front_dw_scatter, dim3((unsigned)nc, (unsigned)B), dim3(256), lds, st, dX0, x, partial, T, R, K, Q, ch);
+    WN_LAUNCH(k_front_dw_scatter, dim3((unsigned)nc, (unsigned)B), dim3(FD_T), lds, st, dX0, x, partial, T, R, K, Q, ch);
     const long per = (long)R * K * Q + R;
     WN_LAUNCH(k_front_dw_reduce, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, partial, nc * B, dW, db, R, K, Q);
     return 0;
