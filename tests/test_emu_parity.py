@@ -53,6 +53,9 @@ def test_overlap_launch_sequences(name):
     # launch groups of 1 / 2 walked layers inside buckets of 2 / the whole stack
     PC.check_golden_case(GoldenCase(name), emu_library(), "cpu", flags=_lib.FLAG_BWD_OVERLAP | _lib.flag_dw_flush(1), layers_per_bucket=2)
     PC.check_golden_case(GoldenCase(name), emu_library(), "cpu", flags=_lib.flag_dw_flush(2))
+    # only the post-net / skip weight gradients from the second context
+    PC.check_golden_case(GoldenCase(name), emu_library(), "cpu", flags=_lib.FLAG_BWD_OVERLAP | _lib.FLAG_BWD_OVERLAP_HEAD,
+                         layers_per_bucket=1)
 
 
 def test_ragged_T_and_odd_channels():

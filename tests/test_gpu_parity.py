@@ -145,6 +145,10 @@ def test_stream_overlap_modes_midsize():
         assert torch.equal(serial[0], over[0]) and serial[1] == over[1]
         assert torch.equal(serial[2], over[2]), "side-stream weight gradients differ from the serial ones (lpb %d)" % lpb
     base = run(0, 0)  # serial, one launch group per bucket
+    for lpb in (0, 10):  # head-only overlap keeps the bucket-size groups of the serial sequence: bit-identical to it
+        head = run(L.FLAG_BWD_OVERLAP | L.FLAG_BWD_OVERLAP_HEAD, lpb)
+        ref = base if lpb == 0 else run(0, lpb)
+        assert torch.equal(head[0], ref[0]) and torch.equal(head[2], ref[2]), "head-only overlap, lpb %d" % lpb
     for flags in (L.FLAG_BWD_OVERLAP, L.FLAG_BWD_OVERLAP | L.flag_dw_flush(3), L.FLAG_FWD_OVERLAP,
                   L.FLAG_FWD_OVERLAP | L.FLAG_BWD_OVERLAP | L.flag_dw_flush(30)):
         r = run(flags, 0)
