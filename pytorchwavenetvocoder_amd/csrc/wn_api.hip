@@ -349,7 +349,16 @@ static DwPlan dw_plan(int M, int N, int Kdim, int nbatch) {
     const int tm = (M + (M > 64 ? 127 : 63)) / (M > 64 ? 128 : 64);
     const int tn = (N + (N > 64 ? 127 : 63)) / (N > 64 ? 128 : 64);
     const long tiles = (long)tm * tn * nbatch;
-    long ks = (1024 + tiles - 1) / tiles;
+    // 128 x 128 tiles (k_gemm6_dw<2,2>, 3 workgroups per CU): as many k-chunks as fit ONE resident round of 768
+    // workgroups -- measured against "at least 1024" on config 2 (720 instead of 1200 workgroups for the layer-batched
+    // launches, 768 instead of 1024 for the post-net ones): same time for dw_dilated / dw_skip, -15 % for dw_post1/2 and
+    // for the reductions of the fewer partials.  64-wide tiles keep the old rule (dw_res: 0.54 vs 0.59 ms).
+    long ks;
+    if (M > 64 && N > 64) {
+        ks = 768 / tiles;
+    } else {
+        ks = (1024 + tiles - 1) / tiles;
+    }
     const long maxks = (Kdim + 255) / 256;
     if (ks > maxks) ks = maxks;
     if (ks < 1) ks = 1;
