@@ -91,6 +91,10 @@ enum {
 #define WN_FLAG_BWD_OVERLAP 4 /* wn_backward: weight-gradient contractions on the side stream beside the gate'/dX chain;
                                * same kernels, same reduction order: bit-identical to the serial mode for the same
                                * launch-group size */
+#define WN_FLAG_AUX_FUSED 32  /* wn_backward (fused split kernels, upsampling_factor % 16 == 0): the gate kernel also writes the
+                               * partial sums of the aux-path gradients (frame-rate aux gradient, upsampling weight), a
+                               * small kernel finishes them and dP is not re-read by wn_aux_bwd.  Opt-in until measured
+                               * on hardware; sums re-associate (~1e-7 relative) */
 #define WN_FLAG_BWD_OVERLAP_HEAD 16 /* with WN_FLAG_BWD_OVERLAP: only the post-net / skip weight gradients run on the side
                                * stream; the per-layer groups stay on the caller's stream */
 #define WN_FLAG_FWD_OVERLAP 8 /* wn_forward (fused kernels): the skip-sum contraction is issued in three chunks of layers on

@@ -383,6 +383,7 @@ struct Ws {
     long X, G, Sg, Gt, Z, O1, O2;
     // scratch
     long P, dO2, dSk, dZ, dXall, dG, dw_partial, dc, tmpS, partial, rs_partial, red_scratch, loss_partial;
+    long dGp, qp;  // aux-gradient partials of the gate kernel (WN_FLAG_AUX_FUSED); 0 floats when the mode cannot apply
     long red_scratch_floats;
     long apk_floats;
     long front_partial, front_partial_floats;
@@ -429,6 +430,11 @@ static int make_ws(const Dims& d, int B, int T, Ws* w) {
     CARVE(dXall, (long)d.L * BRT);  // dL/dx_l of every layer
     CARVE(dG, (long)d.L * B * 2 * d.R * F);
     CARVE(dw_partial, (long)d.L * B * 2 * d.R * Ue);
+    {
+        const bool auxf = wn_fused_supported(d.R, d.K, d.S) && d.U >= 16 && d.U % 16 == 0;
+        CARVE(dGp, auxf ? (long)d.L * B * 2 * d.R * (T / 16) : 0);
+        CARVE(qp, auxf ? (long)d.L * B * T : 0);
+    }
     CARVE(dc, (long)d.L * 2 * d.R);
     CARVE(tmpS, d.S > d.Qo ? d.S : d.Qo);
     // partial buffers: max over the dW GEMMs issued by wn_backward
@@ -919,6 +925,9 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
     const float* upw = d.U > 0 ? params + y.up_w : ws + w.one;
     const long g_bstride = (long)d.L * 2 * d.R * F;
     const long P_L = 2 * BRT;
+    // WN_FLAG_AUX_FUSED: the gate kernel leaves the partial sums of the aux-path gradients behind, dP is not re-read
+    // for them (split kernels, upsampling layer with U % 16 == 0)
+    const bool aux_fused = (flags & WN_FLAG_AUX_FUSED) && c.fused && c.split_bf16 && d.U >= 16 && d.U % 16 == 0 && w.dGp != w.qp;
     // WN_FLAG_BWD_OVERLAP_HEAD: only the post-net / skip weight gradients (matrix-bound) go to the side stream, the
     // per-layer groups (HBM-bound like the chain itself) follow the chain on the caller's stream
     const Ctx& cl = (flags & WN_FLAG_BWD_OVERLAP_HEAD) ? c : cs;
@@ -975,8 +984,13 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
             g.M = 2 * d.R; g.N = d.A;
             if (d.U > 0) {
                 // through the upsampling layer: dG[f] = sum_j w[j] dP[fU+j]; dW = dG.h^T + b_up*dc (x) 1
-                WN_TRY(wn_aux_bwd(ws + w.P + (long)lo * P_L, P_L, ws + w.G + (long)lo * 2 * d.R * F, g_bstride, upw, ws + w.dG,
-                                  ws + w.dw_partial + (long)lo * B * 2 * d.R * Ue, B, T, 2 * d.R, Ue, F, nl, c.st));
+                if (aux_fused)
+                    WN_TRY(wn_aux_finish(ws + w.dGp + (long)lo * B * 2 * d.R * (T / 16), (long)B * 2 * d.R * (T / 16),
+                                         ws + w.qp + (long)lo * B * T, (long)B * T, ws + w.dG,
+                                         ws + w.dw_partial + (long)lo * B * 2 * d.R * Ue, B, T, 2 * d.R, Ue, F, nl, c.st));
+                else
+                    WN_TRY(wn_aux_bwd(ws + w.P + (long)lo * P_L, P_L, ws + w.G + (long)lo * 2 * d.R * F, g_bstride, upw,
+                                      ws + w.dG, ws + w.dw_partial + (long)lo * B * 2 * d.R * Ue, B, T, 2 * d.R, Ue, F, nl, c.st));
                 g.K = F;
                 g.A = ws + w.dG; g.lda = F; g.a_zstride = (long)2 * d.R * F; g.a_lstride = (long)B * 2 * d.R * F;
                 g.B = h; g.ldb = F; g.b_zstride = (long)d.A * F; g.b_lstride = 0; g.b_clen = F;
@@ -1008,8 +1022,14 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
         float* dXl = ws + w.dXall + (long)l * BRT;
         if (c.fused) {
             // dZ = Wskip^T dSk (+ Wres^T dXn) -> gate' -> dP
-            WN_TRY(wn_fused_bwd_gate(params + y.skip0 + (long)l * y.ls_skip, params + lb + y.o_res_w, ws + w.dSk, dXn, Sl, Gtl,
-                                     dP, B, T, d.S, c.split_bf16 ? 1 : 0, c.st));
+            if (aux_fused)
+                WN_TRY(wn_fused_bwd_gate_aux(params + y.skip0 + (long)l * y.ls_skip, params + lb + y.o_res_w, ws + w.dSk, dXn,
+                                             Sl, Gtl, dP, ws + w.G + (long)l * 2 * d.R * F, g_bstride, upw, Ue, F,
+                                             ws + w.dGp + (long)l * B * 2 * d.R * (T / 16), ws + w.qp + (long)l * B * T, B, T,
+                                             d.S, c.st));
+            else
+                WN_TRY(wn_fused_bwd_gate(params + y.skip0 + (long)l * y.ls_skip, params + lb + y.o_res_w, ws + w.dSk, dXn, Sl,
+                                         Gtl, dP, B, T, d.S, c.split_bf16 ? 1 : 0, c.st));
             WN_TRY(wn_fused_bwd_dx(ws + w.wd_b + (long)l * d.K * 2 * d.R * d.R, dP, dXn, dXl, B, T, d.K, dil, c.split_bf16 ? 1 : 0, c.st));
         } else {
             {   // dZ = Wskip_l^T dSkip

@@ -213,6 +213,25 @@ static __device__ __forceinline__ float wave_reduce_sum(float v) {
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
     return v;
 }
+// Sum over each aligned group of 16 lanes (a DPP "row"); every lane of the group ends with the same bits.
+#ifdef WN_EMU
+static inline float wn_row16_sum(float v) {
+    for (int m = 1; m <= 8; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+#else
+template <int CTRL>
+static __device__ __forceinline__ float wn_dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+static __device__ __forceinline__ float wn_row16_sum(float v) {
+    v += wn_dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += wn_dpp_f32<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += wn_dpp_f32<0x141>(v);  // row_half_mirror: the other quad of the 8
+    v += wn_dpp_f32<0x140>(v);  // row_mirror: the other 8 of the 16
+    return v;
+}
+#endif
 static __device__ __forceinline__ float wave_reduce_max(float v) {
     WN_UNROLL
     for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));

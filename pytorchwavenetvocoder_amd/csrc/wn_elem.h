@@ -78,6 +78,12 @@ int wn_sum_layers(const float* params, long off, long ls, int L, int n, float* o
 // block), dG += l*B*R2*F, dw_partial += l*B*R2*U.
 int wn_aux_bwd(const float* dP, long dp_lstride, const float* G, long g_bstride, const float* upw, float* dG,
                float* dw_partial, int B, int T, int R2, int U, int F, int nl, wn_stream_t st);
+// The same outputs from the partial sums the gate kernel leaves behind (wn_fused_bwd_gate_aux), nl layers per launch:
+//   dG[l][b][o'][f]            = sum_{i < U/16} dGp[l][b][o'][f*(U/16) + i]
+//   dw_partial[l][b][0][j]     = sum_f qp[l][b][fU + j]      (rows o' > 0 of the block are zero: qp is already summed over o')
+// dGp += l*dgp_lstride, qp += l*qp_lstride; dG / dw_partial laid out as wn_aux_bwd writes them.
+int wn_aux_finish(const float* dGp, long dgp_lstride, const float* qp, long qp_lstride, float* dG, float* dw_partial, int B,
+                  int T, int R2, int U, int F, int nl, wn_stream_t st);
 
 // out[map(m,n)] (=|+=) scale * sum_z partial[z][m*N+n] (+ addend_m[m]*addend_scale)
 // map(m,n) = (m/m_seg)*m_seg_stride + (m%m_seg)*m_stride + (n/n_seg)*n_seg_stride + (n%n_seg)*n_stride

@@ -306,6 +306,51 @@ int wn_sum_layers(const float* params, long off, long ls, int L, int n, float* o
 }
 
 // ---------------------------------------------------------------------------------------------
+// grid.x: blocks [0, nbg) sum the 16-sample groups of a frame (one thread per (o', f)), blocks [nbg, nbg + nbw) build
+// the dw_partial block of this (l, b): row 0 = sum over frames of qp, the other rows zero.
+__global__ __launch_bounds__(WN_TPB) void k_aux_finish(const float* __restrict__ dGp, long dgp_lstride,
+                                                       const float* __restrict__ qp, long qp_lstride, float* __restrict__ dG,
+                                                       float* __restrict__ dw_partial, int T, int R2, int U, int F, int nbg) {
+    const int b = blockIdx.y, l = blockIdx.z, nb = gridDim.y;
+    const int H = T >> 4, per = U >> 4;
+    if ((int)blockIdx.x < nbg) {
+        const int idx = blockIdx.x * WN_TPB + threadIdx.x;
+        if (idx >= R2 * F) return;
+        const int o = idx / F, f = idx - o * F;
+        const float* src = dGp + (long)l * dgp_lstride + ((long)b * R2 + o) * H + (long)f * per;
+        float s = 0.0f;
+        for (int i = 0; i < per; ++i) s += src[i];
+        dG[(long)l * nb * R2 * F + ((long)b * R2 + o) * F + f] = s;
+    } else {
+        const int idx = ((int)blockIdx.x - nbg) * WN_TPB + threadIdx.x;
+        if (idx >= R2 * U) return;
+        const int o = idx / U, j = idx - o * U;
+        float s = 0.0f;
+        if (o == 0) {
+            const float* src = qp + (long)l * qp_lstride + (long)b * T + j;
+            for (int f0 = 0; f0 < F; f0 += 8) {  // 8 independent loads in flight, summed in frame order
+                float v[8];
+                WN_UNROLL
+                for (int u = 0; u < 8; ++u) v[u] = (f0 + u < F) ? src[(long)(f0 + u) * U] : 0.0f;
+                WN_UNROLL
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+        }
+        dw_partial[(long)l * nb * R2 * U + ((long)b * R2 + o) * U + j] = s;
+    }
+}
+
+int wn_aux_finish(const float* dGp, long dgp_lstride, const float* qp, long qp_lstride, float* dG, float* dw_partial, int B,
+                  int T, int R2, int U, int F, int nl, wn_stream_t st) {
+    WN_PROF("aux_finish", 0.0, (double)nl * B * ((double)R2 * (T / 16) + T) * 4.0, st);
+    if (U < 16 || (U & 15) || (long)U * F != T) return 1;
+    const int nbg = (R2 * F + WN_TPB - 1) / WN_TPB, nbw = (R2 * U + WN_TPB - 1) / WN_TPB;
+    WN_LAUNCH(k_aux_finish, dim3((unsigned)(nbg + nbw), (unsigned)B, (unsigned)nl), dim3(WN_TPB), 0, st, dGp, dgp_lstride, qp,
+              qp_lstride, dG, dw_partial, T, R2, U, F, nbg);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // NJ = phases per lane (U <= 64*NJ), UNR = frames in flight per wave
 template <int NJ, int UNR>
 __global__ __launch_bounds__(WN_TPB) void k_aux_bwd(const float* __restrict__ dP, long dp_lstride, const float* __restrict__ G,

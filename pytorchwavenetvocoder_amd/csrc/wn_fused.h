@@ -20,6 +20,16 @@ int wn_fused_resblock_fwd(const float* wd_f, const float* wres_f, const float* c
 int wn_fused_bwd_gate(const float* wskip, const float* wres, const float* dSk, const float* dXn, const float* S,
                       const float* Gt, float* dP, int B, int T, int Sch, int split, wn_stream_t st);
 
+// The same plus the partial sums of the aux-path gradients (split kernels only; U % 16 == 0, T == U * F), so that dP
+// is not re-read for them (wn_aux_bwd):
+//   dGp[b][row][h] = sum_{t in [16h, 16h+16)} w[t % U] dP[b][row][t]        (a frame is U/16 consecutive groups)
+//   qp[b][t]       = sum_row dP[b][row][t] * G[b][row][t / U]               (-> d up_w[t % U] after summing over b, frames)
+// A tile's dP sits in the accumulator layout (lane = time): 16-sample groups are DPP rows, and because U % 16 == 0 a
+// frame boundary never cuts one.  wn_aux_finish (wn_elem.h) turns the partials into what wn_aux_bwd produces.
+int wn_fused_bwd_gate_aux(const float* wskip, const float* wres, const float* dSk, const float* dXn, const float* S,
+                          const float* Gt, float* dP, const float* G, long g_bstride, const float* upw, int U, int F, float* dGp,
+                          float* qp, int B, int T, int Sch, wn_stream_t st);
+
 // dX[t] = (dXn[t]) + sum_tap Wd_tap^T dP[t + (K-1-tap) d]
 // wd_b : [(tap*2R + o')*R + i] packed weights ; dXn may be NULL.
 // split != 0: bf16 matrix cores with the 3-way operand split (fp32-equivalent), else the exact f32 MFMA

@@ -794,6 +794,13 @@ struct ConvArgs {
     float* out;          // MODE 0: dP (B,128,T) ; MODE 1: dX (B,64,T)
     int stagger;
     int interleave;      // k_conv64s: chunk q -> segment q % nseg (equal-size segments): the taps of one channel group back to back
+    // MODE 2 (gate' + aux-gradient partials, see wn_fused.h)
+    const float* G;      // (B, g_bstride) frame-rate aux projection of this layer, rows [0,128)
+    long g_bstride;
+    const float* upw;    // [U]
+    int U, F;
+    float* dGp;          // (B, 128, T/16)
+    float* qp;           // (B, T)
 };
 
 template <int MODE>
@@ -1105,7 +1112,7 @@ __global__ __launch_bounds__(WN_FT) void k_conv64s(ConvArgs a) {
 
         // epilogue inputs: issued now, consumed after all MFMAs of the tile
         float e0[2][16], e1[2][16];
-        if (MODE == 0) {
+        if (MODE != 1) {
             const wn_rsrc_t Sr = wn_make_buf(a.S + (long)b * 64 * T, (unsigned)(64 * T4));
             const wn_rsrc_t Gr = wn_make_buf(a.Gt + (long)b * 64 * T, (unsigned)(64 * T4));
             WN_UNROLL
@@ -1140,7 +1147,53 @@ __global__ __launch_bounds__(WN_FT) void k_conv64s(ConvArgs a) {
                 WN_SCHED_BARRIER();
             }
         }
-        if (inb) {
+        if (MODE == 2) {
+            // gate backward + the partial sums of the aux gradient (wn_fused.h): every lane takes part in the
+            // cross-lane sums, lanes past T carry dP = 0 (their operands were zero).
+            const int tc = inb ? t : 0;
+            const int fr = tc / a.U;
+            const float wj = inb ? a.upw[tc - fr * a.U] : 0.0f;
+            const int F4 = a.F * 4;
+            const int H = T >> 4;  // 16-sample groups per channel row
+            const wn_rsrc_t Or = wn_make_buf(a.out + (long)b * 128 * T, (unsigned)(128 * T4));
+            const wn_rsrc_t Gr = wn_make_buf(a.G + (long)b * a.g_bstride, (unsigned)(128 * F4));
+            const wn_rsrc_t Dr = wn_make_buf(a.dGp + (long)b * 128 * H, (unsigned)(128 * H * 4));
+            const int vg = (4 * hi * a.F + fr) * 4;
+            const int l16 = li & 15;
+            const int h16 = (((tile - b * tiles_per_b) * 32) >> 4) + (li >> 4);
+            float qsum = 0.0f;
+            WN_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                float ga[16], gg[16];
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    ga[r] = wn_buf_load(Gr, vg, (32 * q + mfma32_row(r, 0)) * F4);
+                    gg[r] = wn_buf_load(Gr, vg, (64 + 32 * q + mfma32_row(r, 0)) * F4);
+                }
+                float keep_a = 0.0f, keep_g = 0.0f;
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int so = (32 * q + mfma32_row(r, 0)) * T4;
+                    const float s = e0[q][r], g = e1[q][r], dz = inb ? acc[q][r] : 0.0f;
+                    const float dpa = dz * g * (s * (1.0f - s)), dpg = dz * s * (1.0f - g * g);
+                    if (inb) {
+                        wn_buf_store(Or, dpa, vcur, so);
+                        wn_buf_store(Or, dpg, vcur, so + 64 * T4);
+                    }
+                    qsum += dpa * ga[r] + dpg * gg[r];
+                    const float ra = wn_row16_sum(wj * dpa), rg = wn_row16_sum(wj * dpg);
+                    keep_a = (l16 == r) ? ra : keep_a;
+                    keep_g = (l16 == r) ? rg : keep_g;
+                }
+                // lane l16 of each 16-lane group keeps the sums of channel row 32q + mfma32_row(l16, hi)
+                const int row = 32 * q + mfma32_row(l16, hi);
+                const int doff = (h16 < H) ? (row * H + h16) * 4 : 0x7ffffff0;
+                wn_buf_store(Dr, keep_a, doff, 0);
+                wn_buf_store(Dr, keep_g, doff, (h16 < H) ? 64 * H * 4 : 0);
+            }
+            qsum += __shfl_xor(qsum, 32, 64);  // the two lane halves hold complementary channel rows
+            if (hi == 0 && inb) a.qp[(long)b * T + t] = qsum;
+        } else if (inb) {
             if (MODE == 0) {
                 // gate backward: dP = [dZ*g*s*(1-s) ; dZ*s*(1-g^2)]
                 const wn_rsrc_t Or = wn_make_buf(a.out + (long)b * 128 * T, (unsigned)(128 * T4));
@@ -1181,10 +1234,13 @@ static int launch_conv64(const ConvArgs& a, int split, wn_stream_t st) {
         WN_LAUNCH((k_conv64s<MODE>), dim3((unsigned)nblk), dim3(WN_FT), lds, st, a);
         return 0;
     }
-    const size_t lds = (size_t)a.wfloats * sizeof(float);
-    if (set_lds(k_conv64<MODE>, lds)) return 1;
-    WN_LAUNCH((k_conv64<MODE>), dim3((unsigned)nblk), dim3(WN_FT), lds, st, a);
-    return 0;
+    if constexpr (MODE != 2) {  // the aux-partial epilogue exists in the split kernel only
+        const size_t lds = (size_t)a.wfloats * sizeof(float);
+        if (set_lds(k_conv64<MODE>, lds)) return 1;
+        WN_LAUNCH((k_conv64<MODE>), dim3((unsigned)nblk), dim3(WN_FT), lds, st, a);
+        return 0;
+    }
+    return 1;
 }
 
 int wn_fused_bwd_gate(const float* wskip, const float* wres, const float* dSk, const float* dXn, const float* S, const float* Gt,
@@ -1205,7 +1261,32 @@ int wn_fused_bwd_gate(const float* wskip, const float* wres, const float* dSk, c
     a.B = B; a.T = T; a.S = S; a.Gt = Gt; a.resid = nullptr; a.out = dP;
     a.stagger = stagger_setting();
     a.interleave = 0;
+    a.G = nullptr; a.g_bstride = 0; a.upw = nullptr; a.U = 0; a.F = 0; a.dGp = nullptr; a.qp = nullptr;
     return launch_conv64<0>(a, split, st);
+}
+
+int wn_fused_bwd_gate_aux(const float* wskip, const float* wres, const float* dSk, const float* dXn, const float* S,
+                          const float* Gt, float* dP, const float* G, long g_bstride, const float* upw, int U, int F, float* dGp,
+                          float* qp, int B, int T, int Sch, wn_stream_t st) {
+    WN_PROF("fused_bwd_gate", 2.0 * (double)B * T * 64.0 * (Sch + (dXn ? 64.0 : 0.0)),
+            4.0 * (double)B * T * (Sch + (dXn ? 64.0 : 0.0) + 4.0 * 64.0 + 9.0), st);  // + dGp (8/timestep) and qp (1) out
+    if (U < 16 || (U & 15) || (T & 15) || (long)U * F != T) return 1;
+    ConvArgs a;
+    a.nseg = 1;
+    a.seg[0].src = dSk; a.seg[0].w = wskip; a.seg[0].nch = Sch; a.seg[0].shift = 0; a.seg[0].woff = 0;
+    a.wfloats = Sch * 64;
+    a.nchunks = Sch / 32;
+    if (dXn) {
+        a.seg[1].src = dXn; a.seg[1].w = wres; a.seg[1].nch = 64; a.seg[1].shift = 0; a.seg[1].woff = Sch * 64;
+        a.nseg = 2;
+        a.wfloats += 64 * 64;
+        a.nchunks += 2;
+    }
+    a.B = B; a.T = T; a.S = S; a.Gt = Gt; a.resid = nullptr; a.out = dP;
+    a.stagger = stagger_setting();
+    a.interleave = 0;
+    a.G = G; a.g_bstride = g_bstride; a.upw = upw; a.U = U; a.F = F; a.dGp = dGp; a.qp = qp;
+    return launch_conv64<2>(a, 1, st);
 }
 
 int wn_fused_bwd_dx(const float* wd_b, const float* dP, const float* dXn, float* dX, int B, int T, int K, int dilation,
@@ -1236,5 +1317,6 @@ int wn_fused_bwd_dx(const float* wd_b, const float* dP, const float* dXn, float*
         il = e ? atoi(e) : 1;  // measured: 56.3 -> 53.0 us per launch (profiles/r01/tap_probe.txt); WN_DX_INTERLEAVE=0 for A/B
     }
     a.interleave = (K > 1 && il) ? 1 : 0;
+    a.G = nullptr; a.g_bstride = 0; a.upw = nullptr; a.U = 0; a.F = 0; a.dGp = nullptr; a.qp = nullptr;
     return launch_conv64<1>(a, split, st);
 }

@@ -58,6 +58,22 @@ def test_overlap_launch_sequences(name):
                          layers_per_bucket=1)
 
 
+def test_aux_gradient_partials_in_the_gate_kernel():
+    """WN_FLAG_AUX_FUSED: the gate kernel reduces w[j]*dP over 16-sample groups (DPP rows on the GPU) and dP*G over
+    the channel rows, wn_aux_finish sums groups per frame / frames per phase; the gradients of upsampling.conv and
+    aux_1x1_* must meet the same gates as the wn_aux_bwd path.  U = 16, 32, 80 (1, 2, 5 groups per frame), a last tile
+    that is half full (T % 32 == 16), several sequences, one launch group per layer."""
+    from pytorchwavenetvocoder_amd import _lib
+    F = _lib.FLAG_AUX_FUSED
+    PC.check_golden_case(GoldenCase("r64_k2_up"), emu_library(), "cpu", flags=F)
+    PC.check_golden_case(GoldenCase("r64_k2_up"), emu_library(), "cpu", flags=F | _lib.FLAG_BWD_OVERLAP, layers_per_bucket=1)
+    PC.run_oracle_vs_engine((64, 6, 64, 32, 3, 1, 2, 80), 1, 160, 31, emu_library(), "cpu", flags=F, scale=0.2)
+    PC.run_oracle_vs_engine((64, 6, 64, 32, 2, 2, 2, 16), 2, 48, 32, emu_library(), "cpu", flags=F, scale=0.2)
+    PC.run_oracle_vs_engine((64, 6, 64, 32, 2, 1, 2, 32), 2, 128, 33, emu_library(), "cpu", flags=F, scale=0.2)
+    # U % 16 != 0: the flag falls back to wn_aux_bwd
+    PC.check_golden_case(GoldenCase("r64_k3_up"), emu_library(), "cpu", flags=F)
+
+
 def test_ragged_T_and_odd_channels():
     # T not a multiple of any tile, channel counts not multiples of 32, B=3
     PC.run_oracle_vs_engine((37, 7, 12, 20, 2, 2, 2, 0), 3, 77, 5, emu_library(), "cpu")
