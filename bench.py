@@ -151,6 +151,30 @@ def stream_mode(flags):
     return "; ".join(parts) if parts else "serial (one stream)"
 
 
+def check_aux_fused(model, x, h, t, tol=1e-5):
+    """One backward in the default mode and one with WN_FLAG_AUX_FUSED on the benchmark's own batch; the two gradient
+    buffers must agree per parameter tensor to `tol` of the tensor's max (the modes only re-associate sums)."""
+    from pytorchwavenetvocoder_amd import _lib
+    eng = model.engine
+    base = eng.flags
+    model.loss_and_backward(x, h, t)
+    g0 = eng.grads().clone()
+    eng.flags = base | _lib.FLAG_AUX_FUSED
+    model.loss_and_backward(x, h, t)
+    g1 = eng.grads().clone()
+    eng.flags = base
+    worst = 0.0
+    for off, n, shape, dead in model._param_slices:
+        if dead or n == 0:
+            continue
+        a, b = g0[off:off + n], g1[off:off + n]
+        if not bool(torch.isfinite(b).all()):
+            return False, float("inf")
+        m = float(a.abs().max())
+        worst = max(worst, float((a - b).abs().max()) / max(m, 1e-30))
+    return worst <= tol, worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,6 +185,9 @@ def main():
     ap.add_argument("--no-decode", action="store_true", help="skip the configs[4] generation measurement")
     ap.add_argument("--no-fused", action="store_true", help="force the layered (any-size) kernels")
     ap.add_argument("--exact-mfma", action="store_true", help="every contraction on the exact f32-input MFMA")
+    ap.add_argument("--aux-fused", action="store_true",
+                    help="WN_FLAG_AUX_FUSED (opt-in, DESIGN.md 8): aux-gradient partial sums inside the gate kernel; checked "
+                         "against the default path on this batch before the timed steps, falls back if they disagree")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra untimed steps with per-launch HIP events")
     args = ap.parse_args()
 
@@ -211,6 +238,15 @@ def main():
     if world > 1:  # identical initial weights on every rank (no per-step broadcast afterwards)
         dist.broadcast(model.engine.flat_params, src=0)
 
+    aux_mode = "separate wn_aux_bwd launch"
+    if args.aux_fused:
+        ok, err = check_aux_fused(model, x, h, t)
+        if ok:
+            model.engine.flags |= _lib.FLAG_AUX_FUSED
+            aux_mode = "partial sums inside the gate kernel (WN_FLAG_AUX_FUSED); worst per-tensor difference to the default " \
+                       "path on this batch %.2e of the tensor's max" % err
+        else:
+            aux_mode += " (WN_FLAG_AUX_FUSED rejected by the self-check: %.2e)" % err
     opt = FusedAdam(model, lr=1e-4)
     red = GradientReducer(model, layers_per_bucket=10)
 
@@ -283,6 +319,8 @@ def main():
             t_hbm = v["bytes"] / HBM_PEAK
             traffic = None  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/pmc_traffic.json)
             try:
+                if model.engine.flags & _lib.FLAG_AUX_FUSED:
+                    raise ValueError("the PMC passes were taken in the default mode")
                 with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as fh:
                     traffic = json.load(fh).get(dom, {}).get("hbm_bytes_per_launch")
             except (OSError, ValueError):
@@ -318,7 +356,7 @@ def main():
                                        B, T, T - rf),
                        "global_batch": world * B, "parallelism": "dp%d" % world,
                        "kernels": "layered" if args.no_fused else "fused+gemm",
-                       "streams": stream_mode(model.engine.flags),
+                       "streams": stream_mode(model.engine.flags), "aux_gradient": aux_mode,
                        "arithmetic": "fp32 storage and accumulation; contractions on the bf16 matrix cores with a 3-way "
                                      "operand split (6 products, fp32-equivalent to round-off) except K=3 forward blocks "
                                      "(exact f32 MFMA); WN_FLAG_EXACT_MFMA selects the f32 MFMA everywhere"},

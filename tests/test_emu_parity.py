@@ -74,6 +74,23 @@ def test_aux_gradient_partials_in_the_gate_kernel():
     PC.check_golden_case(GoldenCase("r64_k3_up"), emu_library(), "cpu", flags=F)
 
 
+def test_bench_self_check_of_the_aux_fused_mode():
+    """bench.py --aux-fused accepts the mode only after comparing its gradients with the default path on the
+    benchmark's own batch (bench.check_aux_fused); here on a small fused-kernel model under the emulator."""
+    import bench
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd.nets import WaveNet
+    cfg_t = (64, 6, 64, 32, 2, 2, 2, 16)
+    cfg = O.OracleConfig(*cfg_t)
+    model = WaveNet(*cfg_t, _library=emu_library())
+    model.load_state_dict(O.random_params(cfg, 11, scale=0.2))
+    x, h, t = O.synthetic_batch(cfg, 2, 64, 12)
+    flags0 = model.engine.flags
+    ok, worst = bench.check_aux_fused(model, x, h, t)
+    assert ok and 0.0 < worst <= 1e-5, worst   # > 0: the fused mode really ran (its sums re-associate)
+    assert model.engine.flags == flags0
+
+
 def test_ragged_T_and_odd_channels():
     # T not a multiple of any tile, channel counts not multiples of 32, B=3
     PC.run_oracle_vs_engine((37, 7, 12, 20, 2, 2, 2, 0), 3, 77, 5, emu_library(), "cpu")
