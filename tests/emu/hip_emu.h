@@ -194,11 +194,11 @@ inline T shfl_idx(T v, int src_lane) {
     int base = t & ~63;
     uint64_t raw = 0;
     memcpy(&raw, &v, sizeof(T));
-    s.slot_a[t] = raw;
+    s.slot_a[2 * (size_t)t] = raw;  // every thread owns slots [2t, 2t+1] (the bf16 MFMA payload is 16 bytes): no aliasing
     sync_wave();
     int src = base + (src_lane & 63);
     if (src >= s.nthreads) src = t;
-    uint64_t got = s.slot_a[src];
+    uint64_t got = s.slot_a[2 * (size_t)src];
     sync_wave();
     T r;
     memcpy(&r, &got, sizeof(T));
@@ -212,18 +212,18 @@ inline f32x16_t mfma_f32_32x32x2f32(float a, float b, f32x16_t c) {
     State& s = S();
     int t = tid_();
     int base = t & ~63, l = t & 63;
-    memcpy(&s.slot_a[t], &a, 4);
-    memcpy(&s.slot_b[t], &b, 4);
+    memcpy(&s.slot_a[2 * (size_t)t], &a, 4);
+    memcpy(&s.slot_b[2 * (size_t)t], &b, 4);
     sync_wave();
     int col = l & 31, hi = l >> 5;
     f32x16_t d = c;
     for (int r = 0; r < 16; ++r) {
         int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
         float a0, a1, b0, b1;
-        memcpy(&a0, &s.slot_a[base + row], 4);       // A[row][k=0] lives in lane row
-        memcpy(&a1, &s.slot_a[base + 32 + row], 4);  // A[row][k=1] lives in lane 32+row
-        memcpy(&b0, &s.slot_b[base + col], 4);       // B[k=0][col]
-        memcpy(&b1, &s.slot_b[base + 32 + col], 4);  // B[k=1][col]
+        memcpy(&a0, &s.slot_a[2 * (size_t)(base + row)], 4);       // A[row][k=0] lives in lane row
+        memcpy(&a1, &s.slot_a[2 * (size_t)(base + 32 + row)], 4);  // A[row][k=1] lives in lane 32+row
+        memcpy(&b0, &s.slot_b[2 * (size_t)(base + col)], 4);       // B[k=0][col]
+        memcpy(&b1, &s.slot_b[2 * (size_t)(base + 32 + col)], 4);  // B[k=1][col]
         d[r] = fmaf(a1, b1, fmaf(a0, b0, c[r]));
     }
     sync_wave();
@@ -266,8 +266,8 @@ inline f32x4_t mfma_f32_16x16x4f32(float a, float b, f32x4_t c) {
     State& s = S();
     int t = tid_();
     int base = t & ~63, l = t & 63;
-    memcpy(&s.slot_a[t], &a, 4);
-    memcpy(&s.slot_b[t], &b, 4);
+    memcpy(&s.slot_a[2 * (size_t)t], &a, 4);
+    memcpy(&s.slot_b[2 * (size_t)t], &b, 4);
     sync_wave();
     int col = l & 15, q = l >> 4;
     f32x4_t d = c;
@@ -276,8 +276,8 @@ inline f32x4_t mfma_f32_16x16x4f32(float a, float b, f32x4_t c) {
         float acc = c[r];
         for (int k = 0; k < 4; ++k) {
             float av, bv;
-            memcpy(&av, &s.slot_a[base + 16 * k + row], 4);  // A[row][k] in lane 16k+row
-            memcpy(&bv, &s.slot_b[base + 16 * k + col], 4);  // B[k][col] in lane 16k+col
+            memcpy(&av, &s.slot_a[2 * (size_t)(base + 16 * k + row)], 4);  // A[row][k] in lane 16k+row
+            memcpy(&bv, &s.slot_b[2 * (size_t)(base + 16 * k + col)], 4);  // B[k][col] in lane 16k+col
             acc = fmaf(av, bv, acc);
         }
         d[r] = acc;

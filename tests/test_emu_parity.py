@@ -175,3 +175,28 @@ def test_decode_context_lengths_and_ragged_requests():
             for i in range(3):
                 assert float((lc[i] - rl[i]).abs().max()) < 1e-4, (cfg_t, T0, i)
                 assert (c[i].numpy() == ref[i]).all(), (cfg_t, T0, i)
+
+
+def test_persistent_tile_loop_several_tiles_per_wave():
+    """The fused kernels are persistent grids whose waves walk several tiles with cross-tile operand prefetch; on the
+    emulator's small cases every wave gets at most one tile.  WN_CHAIN_BLOCKS (read once per process -> subprocess) caps
+    the grid at 8 workgroups, so the first wave of every workgroup walks 2 of the 72 tiles: default kernels, the tap-interleaved dX order and
+    the aux-fused gate kernel against the oracle.  (This case found an aliasing bug of the emulator itself: the 16-byte
+    bf16-MFMA payload of wave w overlapped the shuffle slots of wave w + 1, visible only when one wave is in its matrix
+    phase while its neighbour shuffles.)"""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from tests import parity_common as PC\n"
+        "from tests.emu_util import emu_library\n"
+        "from pytorchwavenetvocoder_amd import _lib\n"
+        "for fl in (0, _lib.FLAG_AUX_FUSED):\n"
+        "    e, g = PC.run_oracle_vs_engine((32, 4, 64, 32, 2, 1, 2, 16), 1, 2304, 51, emu_library(), 'cpu', flags=fl, scale=0.2)\n"
+        "    print('flags', fl, 'logits', e, 'grads', g)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, WN_CHAIN_BLOCKS="8")
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-2000:]
+    assert out.count("flags") == 2, out[-2000:]
