@@ -10,4 +10,4 @@ g=lambda n: k.get(n,{}).get('ms_per_step',0.0)
 print('flags %2d  ms/step %.3f | gate %.1f us per launch | aux_bwd %.3f aux_finish %.3f dw_dilated %.3f ms' % ($fl, d['ms_per_step'], 1e3*g('fused_bwd_gate')/30, g('aux_bwd'), g('aux_finish'), g('dw_dilated')))
 "
 done | tee gpurun_out/aux_fused_probe.txt
-timeout 100 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "aux_gradient" 2>&1 | tail -3 | tee -a gpurun_out/aux_fused_probe.txt
+timeout 100 python -m pytest tests/test_zz_aux_fused_gpu.py -x -q -m gpu 2>&1 | tail -3 | tee -a gpurun_out/aux_fused_probe.txt
