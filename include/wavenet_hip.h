@@ -31,11 +31,13 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "wavenet_hip_gemm.h" /* struct WnGemmArgs of wn_op_gemm */
+
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define WN_ABI_VERSION 3
+#define WN_ABI_VERSION 4
 
 /* Same fields as the constructor WaveNet(n_quantize, n_aux, n_resch, n_skipch, dilation_depth,
  * dilation_repeat, kernel_size, upsampling_factor)  -- reference wavenet.py:172-173. */
@@ -133,6 +135,18 @@ int wn_dead_param_range(const WnConfig* cfg, int64_t* lo, int64_t* hi);
  * configuration or shape (wn_last_error()). */
 size_t wn_workspace_bytes(const WnConfig* cfg, int B, int T);
 
+/* Introspection for parity tests (since ABI v4; the training path never calls it): offset and length, in floats, of
+ * a tensor that wn_forward / wn_backward leave in the workspace of a (B, T) call.  Layouts (time contiguous):
+ *   X, SIGMOID, TANH, Z  (L, B, R, T)  layer input x_l, sigmoid(.) and tanh(.) of the gate, z_l = their product
+ *                                      (reference wavenet.py:525-536; x_0 = the front conv's output)
+ *   RELU_SKIP, RELU_POST1 (B, S, T)    relu(sum of skips), relu(conv_post_1(.))  (wavenet.py:519-521): their
+ *                                      positivity is the ReLU sub-gradient wn_backward uses
+ *   DSKIP (B, S, T), DP (L, B, 2R, T), DX (L, B, R, T)   after wn_backward: dL/d(skip sum), dL/d(gate pre-activations
+ *                                      [sigmoid rows ; tanh rows]), dL/dx_l */
+enum { WN_WS_X = 0, WN_WS_SIGMOID = 1, WN_WS_TANH = 2, WN_WS_Z = 3, WN_WS_RELU_SKIP = 4, WN_WS_RELU_POST1 = 5,
+       WN_WS_DSKIP = 6, WN_WS_DP = 7, WN_WS_DX = 8 };
+int wn_workspace_region(const WnConfig* cfg, int B, int T, int kind, int64_t* offset_floats, int64_t* n_floats);
+
 /* WaveNet.forward(x, h)  -- reference wavenet.py:212-241 (+ _preprocess :513-516, UpSampling
  * :141-154, _residual_forward :525-536, _postprocess :518-523).
  *   params : flat parameter buffer                         (device, wn_param_count floats)
@@ -176,8 +190,8 @@ int wn_op_front(const float* weight, const float* bias, const int64_t* x, float*
 int wn_op_causal_conv(const float* weight, const float* bias, const float* x /*(B,Cin,T)*/, float* y /*(B,Cout,T)*/,
                       float* scratch, int B, int T, int Cin, int Cout, int K, int dilation, void* stream);
 
-/* Generic C[z] = A.B contraction on the f32 matrix cores; see csrc/wn_gemm.h for the argument block. */
-struct WnGemmArgs;
+/* Generic C[z] = A.B contraction on the f32 matrix cores; argument block: wavenet_hip_gemm.h (struct WnGemmArgs,
+ * wn_gemm_default() fills the neutral values). */
 int wn_op_gemm(const struct WnGemmArgs* args, void* stream);
 
 /* Mixture-of-logistics output head (BASELINE configs[3]).  NOT part of the reference (its WaveNet only has the
@@ -221,7 +235,8 @@ int wn_decode_aux(const WnConfig* cfg, int B, int F, const float* wpack, const f
  * network output computed by step p).  `state` (B, wn_decode_state_floats) must be zero before step 0. */
 int wn_decode_steps(const WnConfig* cfg, int B, const float* params, const float* wpack, const float* G, int F, int n_pad,
                     int64_t* samples, int64_t Ttot, const int32_t* t_forced, const int32_t* t_end, int p0, int p1,
-                    float* state, const float* uniforms, float* logits_out, int mode, float* wave_out, void* stream);
+                    float* state, const float* uniforms, float* logits_out, int mode, float* wave_out, float log_scale_min,
+                    void* stream);
 
 /* Any-size variant of the same decode (layer-wise launches of the contraction kernels on [channels x B]
  * operands: one pass over the weights per step serves the whole batch).  Same positions / teacher forcing
@@ -234,9 +249,11 @@ int wn_decode_layered_prepare(const WnConfig* cfg, int B, int F, const float* pa
 int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* params, const float* G, int F, int n_pad,
                             int64_t* samples, int64_t Ttot, const int32_t* t_forced, const int32_t* t_end, int p0, int p1,
                             float* state, int64_t state_floats, const float* uniforms, float* logits_out, int mode,
-                            float* wave_out, void* stream);
+                            float* wave_out, float log_scale_min, void* stream);
 /* mode 2 (mixture-of-logistics head, out_channels = 3*n_mix): uniforms is (B, Ttot, n_mix+1); the drawn value is
- * written to wave_out (B, Ttot) (nullable) and, mu-law encoded with n_quantize levels, to samples. */
+ * written to wave_out (B, Ttot) (nullable) and, mu-law encoded with n_quantize levels, to samples.  log_scale_min
+ * (since ABI v4; ignored by modes 0/1) is the clamp of the log-scales -- pass the value the model was trained with
+ * (wn_mol_loss's log_scale_min) so that sampling and the likelihood agree. */
 
 /* Parallel context walk.  The reference builds the generation buffers with ONE full forward over the padded
  * context (wavenet.py:338-349, 427-441); stepping the decode kernel through those >= receptive-field positions

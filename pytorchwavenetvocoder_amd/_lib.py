@@ -6,6 +6,7 @@ LOUDLY when it is missing or cannot be built -- there is no CPU or eager-PyTorch
 (``load_library(path, _test_emulator=True)`` exists only so that tests/ can point the same binding
 at the host-compiled kernel emulator; nothing in this package ever passes that flag.)
 """
+import contextlib
 import ctypes
 import os
 import threading
@@ -63,6 +64,9 @@ class WnGemmArgs(ctypes.Structure):
 (P_CAUSAL_W, P_CAUSAL_B, P_UP_W, P_UP_B, P_DSIG_W, P_DSIG_B, P_DTANH_W, P_DTANH_B, P_ASIG_W, P_ASIG_B,
  P_ATANH_W, P_ATANH_B, P_SKIP_W, P_SKIP_B, P_RES_W, P_RES_B, P_POST1_W, P_POST1_B, P_POST2_W, P_POST2_B) = range(20)
 
+# wn_workspace_region kinds (include/wavenet_hip.h WN_WS_*)
+WS_X, WS_SIGMOID, WS_TANH, WS_Z, WS_RELU_SKIP, WS_RELU_POST1, WS_DSKIP, WS_DP, WS_DX = range(9)
+
 FLAG_NO_FUSED = 1
 FLAG_EXACT_MFMA = 2
 FLAG_BWD_OVERLAP = 4  # wn_backward: weight gradients on the library's side stream beside the gate'/dX chain (opt-in)
@@ -76,12 +80,12 @@ def flag_dw_flush(n):
     return (int(n) & 0xff) << 8
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/wavenet_hip.h declares
 EXPORTS = [
     "wn_abi_version", "wn_last_error", "wn_receptive_field", "wn_num_layers", "wn_param_count", "wn_param_offset",
-    "wn_num_buckets", "wn_bucket_range", "wn_dead_param_range", "wn_workspace_bytes", "wn_forward",
+    "wn_num_buckets", "wn_bucket_range", "wn_dead_param_range", "wn_workspace_bytes", "wn_workspace_region", "wn_forward",
     "wn_softmax_ce_loss", "wn_backward", "wn_adam_step", "wn_op_front", "wn_op_causal_conv", "wn_op_gemm", "wn_prof_enable", "wn_prof_report",
     "wn_decode_supported", "wn_decode_pack_floats", "wn_decode_state_floats", "wn_decode_pack", "wn_decode_aux",
     "wn_decode_steps", "wn_decode_stream_bytes",
@@ -119,6 +123,7 @@ class WnLibrary(object):
         L.wn_dead_param_range.argtypes = [cfgp, ctypes.POINTER(i64), ctypes.POINTER(i64)]
         L.wn_workspace_bytes.argtypes = [cfgp, i, i]
         L.wn_workspace_bytes.restype = sz
+        L.wn_workspace_region.argtypes = [cfgp, i, i, i, ctypes.POINTER(i64), ctypes.POINTER(i64)]
         L.wn_forward.argtypes = [cfgp, i, i, vp, vp, vp, vp, vp, sz, i, vp]
         L.wn_softmax_ce_loss.argtypes = [cfgp, i, i, vp, vp, i, f, f, vp, vp, vp, sz, vp]
         L.wn_backward.argtypes = [cfgp, i, i, vp, vp, vp, vp, vp, vp, sz, ctypes.POINTER(vp), i, i, i, vp]
@@ -137,12 +142,12 @@ class WnLibrary(object):
         L.wn_decode_stream_bytes.restype = i64
         L.wn_decode_pack.argtypes = [cfgp, vp, vp, vp]
         L.wn_decode_aux.argtypes = [cfgp, i, i, vp, vp, vp, vp]
-        L.wn_decode_steps.argtypes = [cfgp, i, vp, vp, vp, i, i, vp, i64, vp, vp, i, i, vp, vp, vp, i, vp, vp]
+        L.wn_decode_steps.argtypes = [cfgp, i, vp, vp, vp, i, i, vp, i64, vp, vp, i, i, vp, vp, vp, i, vp, f, vp]
         L.wn_mol_loss.argtypes = [cfgp, i, i, vp, vp, i, f, f, i, f, vp, vp, vp, sz, vp]
         L.wn_decode_layered_state_floats.argtypes = [cfgp, i]
         L.wn_decode_layered_state_floats.restype = i64
         L.wn_decode_layered_prepare.argtypes = [cfgp, i, i, vp, vp, vp, vp, i64, vp]
-        L.wn_decode_layered_steps.argtypes = [cfgp, i, vp, vp, i, i, vp, i64, vp, vp, i, i, vp, i64, vp, vp, i, vp, vp]
+        L.wn_decode_layered_steps.argtypes = [cfgp, i, vp, vp, i, i, vp, i64, vp, vp, i, i, vp, i64, vp, vp, i, vp, f, vp]
         L.wn_decode_ctx_aux.argtypes = [cfgp, i, i, i, i, i, vp, vp, vp, vp]
         L.wn_decode_prefill_workspace_bytes.argtypes = [cfgp, i, i]
         L.wn_decode_prefill_workspace_bytes.restype = ctypes.c_size_t
@@ -163,6 +168,19 @@ _lock = threading.Lock()
 _cached = None
 
 
+@contextlib.contextmanager
+def _build_lock():
+    """Inter-process lock around the in-tree build (flock on csrc/.build.lock)."""
+    import fcntl
+    fh = open(os.path.join(CSRC, ".build.lock"), "w")
+    try:
+        fcntl.flock(fh, fcntl.LOCK_EX)
+        yield
+    finally:
+        fcntl.flock(fh, fcntl.LOCK_UN)
+        fh.close()
+
+
 def load_library(path=None, _test_emulator=False):
     """Load (building if necessary) the gfx950 library.  Raises if that is impossible."""
     global _cached
@@ -172,10 +190,17 @@ def load_library(path=None, _test_emulator=False):
         return WnLibrary(path, is_emulator=_test_emulator)
     with _lock:
         if _cached is None:
-            if not os.path.exists(LIB_PATH):
-                # build in-tree with hipcc (cross-compiles without a GPU); raises when hipcc is absent
-                from .csrc import build as _build
-                _build.build(verbose=False)
+            # Always go through build(): it compares the digest of the sources with the stamp written next to the .so
+            # and returns at once when they match, so a stale library beside edited kernels is never loaded silently.
+            # It cross-compiles with hipcc (no GPU needed) and raises when hipcc is absent.  The file lock serialises
+            # the ranks of a multi-process launch (train.py --n_gpus N) that would otherwise compile into the same paths.
+            from .csrc import build as _build
+            try:
+                with _build_lock():
+                    _build.build(verbose=False)
+            except Exception as e:  # noqa: BLE001 -- reported with the product's own error type
+                raise WnError("libwavenet_hip.so is missing or stale and could not be built (%s): the MI355X HIP "
+                              "extension is required (there is no CPU / eager fallback)" % e)
             if not os.path.exists(LIB_PATH):
                 raise WnError("libwavenet_hip.so is missing and could not be built: the MI355X HIP "
                               "extension is required (there is no CPU / eager fallback)")

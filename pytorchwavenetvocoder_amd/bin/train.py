@@ -91,8 +91,13 @@ def _shard_range(batch_size, shard):
     if shard is None:
         return 0, batch_size
     rank, world = shard
-    per = (batch_size + world - 1) // world
-    return min(rank * per, batch_size), min((rank + 1) * per, batch_size)
+    if batch_size < world:
+        raise ValueError("batch_size (%d) must be >= the number of ranks (%d): every rank needs a window of each "
+                         "minibatch, or it would never reach the gradient all-reduce" % (batch_size, world))
+    # as even as possible, never empty: the first batch_size % world ranks own one window more
+    per, extra = divmod(batch_size, world)
+    lo = rank * per + min(rank, extra)
+    return lo, lo + per + (1 if rank < extra else 0)
 
 
 @background(max_prefetch=16)
@@ -378,9 +383,14 @@ def _worker(rank, world, args, port):
         start = time.time()
         item = generator.next()
         (batch_x, batch_h), batch_t = item[0], item[1]
-        batch_loss = reducer.loss_and_backward(batch_x, batch_h, batch_t, y=item[2] if args.n_mixture > 0 else None)
+        # A rank's loss is the mean over ITS windows: weighting it (and its gradients) by B_local / batch_size makes the
+        # sum over ranks the mean over the whole minibatch -- what the reference's single CrossEntropyLoss over the
+        # gathered logits computes (train.py:534-536) -- also when batch_size is not a multiple of the rank count.
+        share = batch_x.size(0) / float(args.batch_size) if (world > 1 and args.batch_length is not None) else 1.0 / world
+        batch_loss = reducer.loss_and_backward(batch_x, batch_h, batch_t, y=item[2] if args.n_mixture > 0 else None,
+                                               grad_scale=share)
         optimizer.step()
-        loss_acc += batch_loss.detach()
+        loss_acc += batch_loss.detach() * (share * world)
         if args.verbose > 1:
             logging.debug("batch loss = %.3f (%.3f sec / batch)" % (batch_loss.item(), time.time() - start))
         total += time.time() - start

@@ -484,6 +484,34 @@ extern "C" size_t wn_workspace_bytes(const WnConfig* cfg, int B, int T) {
     return (size_t)w.total * sizeof(float);
 }
 
+// Where the tensors a wn_forward / wn_backward pair leaves in the workspace live (parity tests compare them with the
+// oracle's intermediates; the training path itself never calls this).  kind: see WN_WS_* in the header.
+extern "C" int wn_workspace_region(const WnConfig* cfg, int B, int T, int kind, int64_t* offset_floats, int64_t* n_floats) {
+    api_enter();
+    Dims d;
+    WN_TRY(check_cfg(cfg, &d));
+    Ws w;
+    WN_TRY(make_ws(d, B, T, &w));
+    if (!offset_floats || !n_floats) return fail(1, "NULL argument");
+    const long BRT = (long)B * d.R * T, BST = (long)B * d.S * T;
+    long off, n;
+    switch (kind) {
+        case WN_WS_X: off = w.X; n = (long)d.L * BRT; break;
+        case WN_WS_SIGMOID: off = w.Sg; n = (long)d.L * BRT; break;
+        case WN_WS_TANH: off = w.Gt; n = (long)d.L * BRT; break;
+        case WN_WS_Z: off = w.Z; n = (long)d.L * BRT; break;
+        case WN_WS_RELU_SKIP: off = w.O1; n = BST; break;
+        case WN_WS_RELU_POST1: off = w.O2; n = BST; break;
+        case WN_WS_DSKIP: off = w.dSk; n = BST; break;
+        case WN_WS_DP: off = w.P; n = (long)d.L * 2 * BRT; break;
+        case WN_WS_DX: off = w.dXall; n = (long)d.L * BRT; break;
+        default: return fail(1, "unknown workspace region %d", kind);
+    }
+    *offset_floats = off;
+    *n_floats = n;
+    return 0;
+}
+
 struct Ctx {
     const WnConfig* cfg;
     Dims d;
@@ -1271,7 +1299,7 @@ extern "C" int wn_decode_aux(const WnConfig* cfg, int B, int F, const float* wpa
 extern "C" int wn_decode_steps(const WnConfig* cfg, int B, const float* params, const float* wpack, const float* G, int F,
                                int n_pad, int64_t* samples, int64_t Ttot, const int32_t* t_forced, const int32_t* t_end,
                                int p0, int p1, float* state, const float* uniforms, float* logits_out, int mode,
-                               float* wave_out, void* stream) {
+                               float* wave_out, float log_scale_min, void* stream) {
     api_enter();
     Dims d;
     WnDecodePlan pl;
@@ -1302,7 +1330,7 @@ extern "C" int wn_decode_steps(const WnConfig* cfg, int B, const float* params, 
     a.uniforms = uniforms; a.u_bstride = Ttot;   // mode 2: rows of nm+1 draws, indexed (b*Ttot + p+1)*(nm+1)
     a.logits_out = logits_out; a.lo_bstride = Ttot * d.Qo;
     a.mode = mode;
-    a.wave_out = wave_out; a.w_bstride = Ttot;
+    a.wave_out = wave_out; a.w_bstride = Ttot; a.log_scale_min = log_scale_min;
     WN_TRY(wn_decode_launch(&a, B, (wn_stream_t)stream));
     return rt_check("wn_decode_steps");
 }
@@ -1397,7 +1425,7 @@ extern "C" int wn_decode_layered_prepare(const WnConfig* cfg, int B, int F, cons
 extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* params, const float* G, int F, int n_pad,
                                        int64_t* samples, int64_t Ttot, const int32_t* t_forced, const int32_t* t_end, int p0,
                                        int p1, float* state, int64_t state_floats, const float* uniforms, float* logits_out,
-                                       int mode, float* wave_out, void* stream) {
+                                       int mode, float* wave_out, float log_scale_min, void* stream) {
     api_enter();
     Dims d;
     WN_TRY(check_cfg(cfg, &d));
@@ -1495,7 +1523,7 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
         }
         if (mode == 2)
             WN_TRY(wn_dl_select_mol(ws + y.logits, d.Qo / 3, nb, d.Q, samples, wave_out, Ttot, t_forced, t_end, p, uniforms,
-                                    logits_out, -7.0f, c.st));
+                                    logits_out, log_scale_min, c.st));
         else
             WN_TRY(wn_dl_select(ws + y.logits, d.Qo, nb, samples, Ttot, t_forced, t_end, p, uniforms, logits_out, mode, c.st));
         WN_TRY(wn_dl_push(&a, c.st));

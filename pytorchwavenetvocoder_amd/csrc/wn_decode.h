@@ -51,6 +51,7 @@ typedef struct WnDecodeArgs {
     long lo_bstride;
     int mode;             // 0 argmax, 1 sampling, 2 mixture of logistics (Qo = 3*nm, nm <= 64)
     float* wave_out;      // mode 2, nullable (B, Ttot): the drawn waveform value of position p+1
+    float log_scale_min;  // mode 2: clamp of the mixture log-scales (the value wn_mol_loss was trained with)
     long w_bstride;
 #ifdef WN_TIMING
     long long* dbg;

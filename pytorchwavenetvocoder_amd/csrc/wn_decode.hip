@@ -509,7 +509,7 @@ __global__ __launch_bounds__(WN_DT) void k_decode(WnDecodeArgs a) {
                         next = (int)(v < 0 ? v + Q : v);
                     } else {
                         const float mean = lgt[nm + bi];
-                        const float ls = fmaxf(lgt[2 * nm + bi], -7.0f);
+                        const float ls = fmaxf(lgt[2 * nm + bi], a.log_scale_min);
                         const float uu = un[nm];
                         float xv = mean + expf(ls) * (logf(uu) - logf(1.0f - uu));
                         xv = fminf(fmaxf(xv, -1.0f), 1.0f);

@@ -52,19 +52,22 @@ class GradientReducer(object):
             return self.model.mol_loss_and_backward(x, h, y, **kw)
         return self.model.loss_and_backward(x, h, t, **kw)
 
-    def loss_and_backward(self, x, h, t, t_start=None, y=None):
+    def loss_and_backward(self, x, h, t, t_start=None, y=None, grad_scale=None):
         """forward + loss + backward with the bucketed all-reduce overlapped; returns the local
-        mean loss (device tensor).  ``y`` (B, T) float selects the mixture-of-logistics loss."""
+        mean loss (device tensor).  ``y`` (B, T) float selects the mixture-of-logistics loss.
+        ``grad_scale``: this rank's share of the global minibatch (default 1/world = equal shards; pass
+        B_local / B_global when the shards are uneven, so that the summed gradient is the global-batch mean)."""
         if self.world == 1:
             return self._step(x, h, t, y, t_start=t_start)
+        gscale = self.grad_scale if grad_scale is None else float(grad_scale)
         if not self.cuda:
-            loss = self._step(x, h, t, y, t_start=t_start, grad_scale=self.grad_scale)
+            loss = self._step(x, h, t, y, t_start=t_start, grad_scale=gscale)
             flat = self.eng.grads()
             for lo, hi in self.ranges:
                 dist.all_reduce(flat[lo:hi], group=self.group)
             return loss
         handles = [e.cuda_event for e in self.events]
-        loss = self._step(x, h, t, y, t_start=t_start, grad_scale=self.grad_scale, events=handles,
+        loss = self._step(x, h, t, y, t_start=t_start, grad_scale=gscale, events=handles,
                           layers_per_bucket=self.lpb)
         flat = self.eng.grads()
         with torch.cuda.stream(self.side):

@@ -111,6 +111,19 @@ class WaveNetEngine(object):
             self._ws_key = key
         return self._ws
 
+    def saved(self, kind):
+        """View of a tensor the last forward / backward left in the workspace (``_lib.WS_*``; parity tests only)."""
+        if self._last_shape is None:
+            raise _lib.WnError("saved() without a preceding forward()")
+        B, T = self._last_shape
+        off, n = ctypes.c_int64(), ctypes.c_int64()
+        self.lib.check(self.lib.wn_workspace_region(ctypes.byref(self.cfg), B, T, int(kind), ctypes.byref(off),
+                                                    ctypes.byref(n)), "wn_workspace_region")
+        R, S, L = self.cfg.n_resch, self.cfg.n_skipch, self.n_layers
+        shape = {_lib.WS_RELU_SKIP: (B, S, T), _lib.WS_RELU_POST1: (B, S, T), _lib.WS_DSKIP: (B, S, T),
+                 _lib.WS_DP: (L, B, 2 * R, T)}.get(int(kind), (L, B, R, T))
+        return self.workspace(B, T)[off.value:off.value + n.value].view(shape)
+
     def grads(self):
         if self.flat_grads is None:
             self.flat_grads = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
@@ -211,7 +224,7 @@ class WaveNetEngine(object):
         return bool(self.lib.wn_decode_supported(ctypes.byref(self.cfg)))
 
     def decode(self, x, h, n_samples_list, mode="argmax", chunk=4096, return_logits=False, progress=None, layered=None,
-               prefill="parallel", prefill_batch=32):
+               prefill="parallel", prefill_batch=32, log_scale_min=-7.0):
         """Queue-based sample-by-sample generation on the HIP decode kernel.
 
         x (B,T0) int64 context, h (B, n_aux, frames | samples) aux features covering T0 + max(n)
@@ -229,6 +242,7 @@ class WaveNetEngine(object):
         (``prefill_batch`` utterances at a time), then decoding starts at the last context position.  "walk"
         steps the decode kernel through the context sample by sample (teacher forced; receptive-field steps
         before the first new sample) -- kept as the independent check of the former.
+        ``log_scale_min`` (mode "mol"): clamp of the mixture log-scales, the value the model was trained with.
         """
         self._check_device(x, h)
         if x.dtype != torch.int64 or x.dim() != 2 or h.dim() != 3:
@@ -258,22 +272,40 @@ class WaveNetEngine(object):
         st = _stream_handle(self.device)
         dev = self.device
         h = h.contiguous().float()
-        G = torch.empty((B, F, self.n_layers * 2 * self.cfg.n_resch), dtype=torch.float32, device=dev)
+        nG = self.n_layers * 2 * self.cfg.n_resch
+        # Aux projections G (B, columns, L*2R).  With the upsampling layer the columns are frames (small): all of them
+        # up front.  Without it (U = 0, decode.py's extend_time path) a column is a SAMPLE -- 5 s at 16 kHz with the
+        # recipe-size model would be 9.8 GB per utterance -- so G only ever holds the columns of the chunk of steps
+        # being decoded (at most ~1 GiB), recomputed per chunk from the matching slice of h.
+        windowed = (U == 0)
+        if windowed:
+            chunk = max(1, min(int(chunk), (1 << 30) // (4 * nG * B)))
+        wpack = None
         if layered:
             nst = self.lib.wn_decode_layered_state_floats(cfg, B)
             if nst <= 0:
                 raise _lib.WnError("wn_decode_layered_state_floats: %s" % self.lib.wn_last_error().decode())
             state = torch.zeros(nst, dtype=torch.float32, device=dev)
-            self.lib.check(self.lib.wn_decode_layered_prepare(cfg, B, F, _ptr(self.flat_params), _ptr(h), _ptr(G), _ptr(state),
-                                                              nst, st), "wn_decode_layered_prepare")
         else:
             npk = self.lib.wn_decode_pack_floats(cfg)
             if npk <= 0:
                 raise _lib.WnError("wn_decode_pack_floats: %s" % self.lib.wn_last_error().decode())
             wpack = torch.empty(npk, dtype=torch.float32, device=dev)
             self.lib.check(self.lib.wn_decode_pack(cfg, _ptr(self.flat_params), _ptr(wpack), st), "wn_decode_pack")
-            self.lib.check(self.lib.wn_decode_aux(cfg, B, F, _ptr(wpack), _ptr(h), _ptr(G), st), "wn_decode_aux")
             state = torch.zeros((B, self.lib.wn_decode_state_floats(cfg)), dtype=torch.float32, device=dev)
+
+        def aux_columns(c0, c1):
+            """G of aux columns [c0, c1) (the layered variant also (re)packs the weights into its state)."""
+            hw = h if (c0 == 0 and c1 == F) else h[:, :, c0:c1].contiguous()
+            Gw = torch.empty((B, c1 - c0, nG), dtype=torch.float32, device=dev)
+            if layered:
+                self.lib.check(self.lib.wn_decode_layered_prepare(cfg, B, c1 - c0, _ptr(self.flat_params), _ptr(hw), _ptr(Gw),
+                                                                  _ptr(state), nst, st), "wn_decode_layered_prepare")
+            else:
+                self.lib.check(self.lib.wn_decode_aux(cfg, B, c1 - c0, _ptr(wpack), _ptr(hw), _ptr(Gw), st), "wn_decode_aux")
+            return Gw
+
+        G = None if windowed else aux_columns(0, F)
         samples = torch.full((B, Ttot), self.cfg.n_quantize // 2, dtype=torch.int64, device=dev)
         samples[:, n_pad:Tctx] = x
         t_forced = torch.full((B,), Tctx, dtype=torch.int32, device=dev)
@@ -291,16 +323,28 @@ class WaveNetEngine(object):
             p = Tctx - 1
         while p < Ttot - 1:
             p1 = min(p + chunk, Ttot - 1)
+            if windowed:
+                # steps [p, p1) read the aux columns max(q - n_pad, 0) for q in [p, p1): compute that window and shift
+                # the kernel's padding origin by its first column (a position left of it can only be inside the left
+                # padding, which replicates column 0 = the window's first column then)
+                c0 = min(max(p - n_pad, 0), F - 1)
+                c1 = min(max(p1 - 1 - n_pad, 0), F - 1) + 1
+                G = None  # release the previous window first
+                G = aux_columns(c0, c1)
+                Fw, pad_w = c1 - c0, n_pad + c0
+            else:
+                Fw, pad_w = F, n_pad
             if layered:
-                rc = self.lib.wn_decode_layered_steps(cfg, B, _ptr(self.flat_params), _ptr(G), F, n_pad, _ptr(samples), Ttot,
+                rc = self.lib.wn_decode_layered_steps(cfg, B, _ptr(self.flat_params), _ptr(G), Fw, pad_w, _ptr(samples), Ttot,
                                                       _ptr(t_forced), _ptr(t_end), p, p1, _ptr(state), state.numel(),
                                                       _ptr(uniforms), _ptr(logits), {"argmax": 0, "sampling": 1, "mol": 2}[mode],
-                                                      _ptr(wave), st)
+                                                      _ptr(wave), float(log_scale_min), st)
                 self.lib.check(rc, "wn_decode_layered_steps")
             else:
-                rc = self.lib.wn_decode_steps(cfg, B, _ptr(self.flat_params), _ptr(wpack), _ptr(G), F, n_pad, _ptr(samples),
+                rc = self.lib.wn_decode_steps(cfg, B, _ptr(self.flat_params), _ptr(wpack), _ptr(G), Fw, pad_w, _ptr(samples),
                                               Ttot, _ptr(t_forced), _ptr(t_end), p, p1, _ptr(state), _ptr(uniforms),
-                                              _ptr(logits), {"argmax": 0, "sampling": 1, "mol": 2}[mode], _ptr(wave), st)
+                                              _ptr(logits), {"argmax": 0, "sampling": 1, "mol": 2}[mode], _ptr(wave),
+                                              float(log_scale_min), st)
                 self.lib.check(rc, "wn_decode_steps")
             p = p1
             if progress is not None:

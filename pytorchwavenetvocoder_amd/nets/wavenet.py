@@ -184,6 +184,9 @@ class WaveNet(nn.Module):
                  dilation_depth=10, dilation_repeat=3, kernel_size=2, upsampling_factor=0, n_mixture=0, _library=None):
         super(WaveNet, self).__init__()
         self.n_mixture = n_mixture
+        # mixture head: clamp of the predicted log-scales, ONE value for the likelihood (mol_loss_and_backward) and for
+        # sampling (the decode kernels), so that training and generation cannot disagree
+        self.log_scale_min = -7.0
         self.out_channels = 3 * n_mixture if n_mixture > 0 else n_quantize
         self.n_aux = n_aux
         self.n_quantize = n_quantize
@@ -298,7 +301,7 @@ class WaveNet(nn.Module):
             p.grad = None if dead else flat[off:off + n].view(shape)
         return loss
 
-    def mol_loss_and_backward(self, x, h, y, t_start=None, grad_scale=1.0, num_classes=65536, log_scale_min=-7.0,
+    def mol_loss_and_backward(self, x, h, y, t_start=None, grad_scale=1.0, num_classes=65536, log_scale_min=None,
                               events=None, layers_per_bucket=0):
         """Training half-step of the mixture-of-logistics head (``n_mixture > 0``): forward -> mean negative
         log-likelihood of the waveform ``y`` (B, T) in [-1, 1] (the value of the NEXT sample at every position,
@@ -306,6 +309,10 @@ class WaveNet(nn.Module):
         ``loss_and_backward``."""
         if self.n_mixture <= 0:
             raise ValueError("this model has the softmax head (n_mixture = 0)")
+        if log_scale_min is None:
+            log_scale_min = self.log_scale_min
+        else:   # remembered: generation clamps the log-scales at the value the model was trained with
+            self.log_scale_min = float(log_scale_min)
         eng = self._engine
         out = eng.forward(x, h)
         self._fwd_serial += 1
@@ -358,6 +365,11 @@ class WaveNet(nn.Module):
         if mode not in ("sampling", "argmax"):
             logging.error("mode should be sampling or argmax")
             sys.exit(1)
+        if self.n_mixture > 0:
+            # the 3 * n_mixture outputs are mixture parameters, not class logits: a softmax / argmax over them would
+            # return meaningless tokens.  The queue-based generators draw from the mixture on the device.
+            raise ValueError("generate() is the reference's softmax-head generator; a model with the mixture-of-logistics "
+                             "head (n_mixture = %d) generates with fast_generate / batch_fast_generate" % self.n_mixture)
         rf = self.receptive_field
         with torch.no_grad():
             if self.upsampling_factor > 0:
@@ -401,7 +413,8 @@ class WaveNet(nn.Module):
 
         with torch.no_grad():
             return self.engine.decode(x, h, list(n_samples_list), mode=mode,
-                                      chunk=intervals if intervals else 4096, progress=progress)
+                                      chunk=intervals if intervals else 4096, progress=progress,
+                                      log_scale_min=self.log_scale_min)
 
     def fast_generate(self, x, h, n_samples, intervals=None, mode="sampling"):
         """Generate a waveform with the queue algorithm (reference wavenet.py:309-395) on the HIP

@@ -48,16 +48,23 @@ class FusedAdam(torch.optim.Optimizer):
         # gradients produced by the autograd path live in separate tensors: gather them
         lo = flat_g.data_ptr()
         hi = lo + flat_g.numel() * 4
+        skipped = []   # live parameters without a gradient: torch.optim.Adam leaves them (and their moments) untouched
         for p, (off, n, shape, dead) in zip(self.model.parameters(), self.model._param_slices):
             if p.grad is None:
                 if not dead:
                     flat_g[off:off + n].zero_()
+                    sl = slice(off, off + n)
+                    skipped.append((sl, eng.flat_params[sl].clone(), m[sl].clone(), v[sl].clone()))
                 continue
             if not (lo <= p.grad.data_ptr() < hi):
                 flat_g[off:off + n].copy_(p.grad.reshape(-1))
         group = self.param_groups[0]
         self._step += 1
         eng.adam_step(m, v, self._step, group["lr"], group["betas"], group["eps"], group["weight_decay"])
+        for sl, p0, m0, v0 in skipped:   # the one launch covers the whole flat buffer: put the skipped slices back
+            eng.flat_params[sl].copy_(p0)
+            m[sl].copy_(m0)
+            v[sl].copy_(v0)
         return loss
 
     # ---- torch.optim.Adam compatible (de)serialisation --------------------------------------

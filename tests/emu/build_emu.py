@@ -21,7 +21,8 @@ FLAGS = ["-O2", "-std=c++17", "-fPIC", "-DWN_EMU", "-Wno-psabi", "-mfma", "-ffp-
 def _digest():
     h = hashlib.sha256()
     files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
-    files += [os.path.join(HERE, "hip_emu.h"), os.path.join(ROOT, "include", "wavenet_hip.h"), __file__]
+    files += [os.path.join(HERE, "hip_emu.h"), os.path.join(ROOT, "include", "wavenet_hip.h"),
+              os.path.join(ROOT, "include", "wavenet_hip_gemm.h"), __file__]
     for f in files:
         with open(f, "rb") as fh:
             h.update(fh.read())

@@ -25,7 +25,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, btot):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -36,9 +36,10 @@ def _worker(rank, world, port, out_path):
         from tests.emu_util import emu_library
         cfg = O.OracleConfig(*CFG)
         params = O.random_params(cfg, SEED)
-        x, h, t = O.synthetic_batch(cfg, B, T, SEED + 1)
-        per = B // world
-        sl = slice(rank * per, (rank + 1) * per)
+        from pytorchwavenetvocoder_amd.bin.train import _shard_range
+        x, h, t = O.synthetic_batch(cfg, btot, T, SEED + 1)
+        lo, hi = _shard_range(btot, (rank, world))   # uneven when btot % world != 0 (train.py weights by B_local / B)
+        sl = slice(lo, hi)
         model = WaveNet(*CFG, _library=emu_library())
         model.load_state_dict(params)
         opt = FusedAdam(model, lr=1e-3)
@@ -46,7 +47,8 @@ def _worker(rank, world, port, out_path):
         assert red.world == world and len(red.ranges) == 1 + 3 + 1
         losses = []
         for _ in range(2):
-            loss = red.loss_and_backward(x[sl].contiguous(), h[sl].contiguous(), t[sl].contiguous())
+            loss = red.loss_and_backward(x[sl].contiguous(), h[sl].contiguous(), t[sl].contiguous(),
+                                         grad_scale=(hi - lo) / float(btot))
             opt.step()
             losses.append(float(loss))
         if rank == 0:
@@ -55,18 +57,19 @@ def _worker(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-def test_two_rank_data_parallel_equals_single_process(tmp_path):
+@pytest.mark.parametrize("btot", [B, 3])
+def test_two_rank_data_parallel_equals_single_process(tmp_path, btot):
     from pytorchwavenetvocoder_amd.nets import WaveNet
     from pytorchwavenetvocoder_amd.optim import FusedAdam
     from tests.emu_util import emu_library
     emu_library()  # build once in the parent
     out_path = str(tmp_path / "rank0.pt")
-    mp.spawn(_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out_path, btot), nprocs=2, join=True)
     got = torch.load(out_path)
 
     cfg = O.OracleConfig(*CFG)
     params = O.random_params(cfg, SEED)
-    x, h, t = O.synthetic_batch(cfg, B, T, SEED + 1)
+    x, h, t = O.synthetic_batch(cfg, btot, T, SEED + 1)
     model = WaveNet(*CFG, _library=emu_library())
     model.load_state_dict(params)
     opt = FusedAdam(model, lr=1e-3)

@@ -200,3 +200,33 @@ def test_persistent_tile_loop_several_tiles_per_wave():
     out = r.stdout.decode()
     assert r.returncode == 0, out[-2000:]
     assert out.count("flags") == 2, out[-2000:]
+
+
+def test_fused_adam_skips_live_parameters_without_a_gradient_like_torch_adam():
+    """torch.optim.Adam leaves a parameter whose .grad is None untouched (value AND moments); FusedAdam's one launch
+    covers the whole flat buffer, so it has to put such slices back.  Two steps, the second with two live tensors'
+    gradients removed, against torch.optim.Adam on a plain copy of the tensors."""
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd.nets import WaveNet
+    from pytorchwavenetvocoder_amd.optim import FusedAdam
+    cfg_t = (32, 6, 8, 12, 3, 2, 2, 4)
+    cfg = O.OracleConfig(*cfg_t)
+    params = O.random_params(cfg, 3)
+    x, h, t = O.synthetic_batch(cfg, 2, 48, 4)
+    model = WaveNet(*cfg_t, _library=emu_library())
+    model.load_state_dict(params)
+    opt = FusedAdam(model, lr=1e-2, weight_decay=1e-3)
+    ref = {k: v.clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    ropt = torch.optim.Adam(list(ref.values()), lr=1e-2, weight_decay=1e-3)
+    drop = {"conv_post_1.weight", "dil_tanh.1.conv.bias"}
+    for step in range(2):
+        model.loss_and_backward(x, h, t)
+        for k, p in model.named_parameters():
+            ref[k].grad = None if p.grad is None else p.grad.clone()
+            if step == 1 and k in drop:
+                p.grad = None
+                ref[k].grad = None
+        opt.step()
+        ropt.step()
+    for k, v in model.state_dict().items():
+        assert float((v - ref[k].detach()).abs().max()) <= 1e-6, k

@@ -104,6 +104,21 @@ def test_sharded_generator_is_a_partition_of_the_unsharded_one(tmp_path):
             p.close()
 
 
+def test_shard_ranges_are_never_empty_and_partition_the_minibatch():
+    """batch_size not a multiple of the rank count (12 windows on 8 GPUs): every rank owns at least one window (an empty
+    rank would never reach the gradient all-reduce and the step would deadlock), sizes differ by at most one, and the
+    ranges tile [0, batch_size) in rank order.  Fewer windows than ranks is an error, not a hang."""
+    for bs, world in [(12, 8), (5, 2), (8, 8), (64, 8), (9, 4)]:
+        rs = [T._shard_range(bs, (r, world)) for r in range(world)]
+        assert rs[0][0] == 0 and rs[-1][1] == bs
+        assert all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+        sizes = [hi - lo for lo, hi in rs]
+        assert min(sizes) >= 1 and max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        T._shard_range(3, (0, 4))
+    assert T._shard_range(7, None) == (0, 7)
+
+
 def test_generator_yields_the_waveform_targets_of_the_mixture_head(tmp_path):
     wavs, feats, _ = make_corpus(str(tmp_path), n=2)
     gen = T.train_generator(wavs, feats, receptive_field=15, batch_length=400, batch_size=2, feature_type="melspc",
