@@ -12,12 +12,19 @@ BASELINE.json configs[1]: 30-layer WaveNet, 64 residual / 256 skip channels, 80-
 mu-law softmax, batch 8 x batch_len 20000 per GPU (-> T = 23040 model inputs, 19970 loss
 positions per sequence).  Weak scaling: the per-GPU batch is fixed.
 
+The K timed steps are measured `--repeats` times (default 5; each region bracketed by barrier + synchronize, MAX over
+ranks); `ms_per_step` / `value` are the MEDIAN region, min / max are reported beside it.
+
 Prints ONE JSON line (rank 0).  Extra blocks:
-  roofline      dominant kernel: algorithmic FLOPs per launch / HIP-event duration vs the f32
-                matrix-core peak (the path is fp32 compute-bound), plus the
-                step-level HBM-roof and fp32-FLOP-roof fractions north_star asks for.
-  cpu_baseline  the CPU oracle (oracle/wavenet_oracle.py = the reference's torch CPU ops) timed on
-                this host's cores on a bounded sample (B=1 window of the same model).
+  roofline      bound = hbm (north_star's denominator).  `achieved` / `frac` are the WHOLE STEP against SURVEY.md 8(d):
+                timesteps/s x 78 356 algorithmic bytes per timestep vs 8 TB/s.  `traffic` = HBM bytes the step really
+                moved (rocprofv3 PMC passes of this launch mode, profiles/), `traffic_ratio` = traffic / algorithmic.
+                `dominant_kernel`: the kernel with the largest share of HIP-event time -- average launch duration,
+                its 8(d) algorithmic bytes per launch and the fraction of the HBM roof they amount to (`frac_alg`),
+                its compulsory bytes (every operand of the launch once) as bandwidth utilisation (`bw_util`), PMC
+                bytes per launch, and the matrix-core fraction of its FLOPs.
+  cpu_baseline  the CPU oracle (oracle/wavenet_oracle.py = the reference's torch CPU ops) timed on this host's cores
+                on a bounded sample: B=1 and B=8 windows of the same model (thread count calibrated, core count stated).
 """
 import argparse
 import ctypes
@@ -42,6 +49,14 @@ HBM_PEAK = 8.0e12          # B/s  (MI355X_MICROARCH.md)
 F32_MFMA_PEAK = 157.3e12   # FLOP/s dense f32 matrix = f32 vector peak
 BF16_MFMA_PEAK = 2.5e15     # FLOP/s dense bf16 matrix (MI355X_MICROARCH.md); the 3-way split spends 6 bf16
 SPLIT_PRODUCTS = 6.0        # MFMAs per fp32-equivalent product -> 417 TFLOP/s of fp32-equivalent work
+LAYERS_PER_BUCKET = 10      # gradient buckets of the N > 1 exchange; N = 1 runs the SAME launch structure
+# SURVEY.md 8(d) algorithmic bytes per timestep of ONE launch of the per-layer chain kernels (R = 64 words of 4 B):
+#   forward block  read x_l, write x_{l+1}, save s, g                   4R
+#   gate'          read s, g and dx_{l+1}                                3R   (dSkip is on chip in 8(d)'s accounting)
+#   dX             write dx_l (its inputs dP never leave the chip)       1R
+ALG_BYTES_PER_TIMESTEP_OF = {"fused_resblock_fwd": 4 * 64 * 4, "fused_bwd_gate": 3 * 64 * 4, "fused_bwd_dx": 64 * 4,
+                             "fused_bwd_chain": 4 * 64 * 4}
+PMC_FILES = ["profiles/r02/pmc_traffic.json"]
 
 
 def geometry(rf, batch_length, U):
@@ -51,11 +66,12 @@ def geometry(rf, batch_length, U):
     return bl, frames, frames * U
 
 
-def cpu_baseline(seconds_budget=25.0):
+def cpu_baseline(seconds_budget=30.0):
     """The oracle (a restatement of the reference's own torch CPU path) on this host's cores.
 
-    Bounded sample: B=1 window of the same model.  The thread count is calibrated (oneDNN convs of
-    this size get SLOWER with hundreds of threads), every step is checked against the time budget."""
+    Bounded sample (~30 s): the thread count is calibrated on B=1 windows of the same model (oneDNN convs of this size
+    get SLOWER with hundreds of threads), then B=1 and the benchmark's own B=8 minibatch are timed at that count
+    (SURVEY.md 8d asks for both).  `value` is the better of the two rates."""
     from oracle import wavenet_oracle as O
     try:
         navail = len(os.sched_getaffinity(0))
@@ -69,34 +85,49 @@ def cpu_baseline(seconds_budget=25.0):
     x, h, t = O.synthetic_batch(cfg, 1, T, 1)
     opt = O.OracleAdam(lr=1e-4)
     t_begin = time.time()
+
+    def timed(xb, hb, tb):
+        t0 = time.time()
+        O.train_step(cfg, params, opt, xb, hb, tb)
+        return time.time() - t0
+
     results = {}
     cands = sorted(set(min(navail, c) for c in (8, 16, 32, 64)))
     for nthr in cands:
         torch.set_num_threads(nthr)
-        t0 = time.time()
-        O.train_step(cfg, params, opt, x, h, t)      # warm-up at this thread count
-        warm = time.time() - t0
-        if time.time() - t_begin > seconds_budget:
+        warm = timed(x, h, t)                        # warm-up at this thread count
+        if time.time() - t_begin > 0.3 * seconds_budget:
             results.setdefault(nthr, []).append(warm)
             break
-        t0 = time.time()
-        O.train_step(cfg, params, opt, x, h, t)
-        results.setdefault(nthr, []).append(time.time() - t0)
-        if time.time() - t_begin > 0.6 * seconds_budget:
+        results.setdefault(nthr, []).append(timed(x, h, t))
+        if time.time() - t_begin > 0.3 * seconds_budget:
             break
     best_thr = min(results, key=lambda k: min(results[k]))
     torch.set_num_threads(best_thr)
-    times = list(results[best_thr])
-    while time.time() - t_begin < seconds_budget and len(times) < 8:
-        t0 = time.time()
-        O.train_step(cfg, params, opt, x, h, t)
-        times.append(time.time() - t0)
-    best = min(times)
-    return {"value": (T - cfg.receptive_field) / best, "unit": "audio-samples/sec", "cores": best_thr,
-            "kind": "port", "host_logical_cpus": navail,
-            "sample": "CPU oracle (reference torch-CPU ops), same 30-layer model, B=1 x T=%d window, threads "
-                      "calibrated over %s -> %d, %d timed steps, best step %.3f s, median %.3f s" % (
-                          T, cands, best_thr, len(times), best, sorted(times)[len(times) // 2])}
+    t1 = list(results[best_thr])
+    while time.time() - t_begin < 0.4 * seconds_budget and len(t1) < 4:
+        t1.append(timed(x, h, t))
+    b1 = {"B": 1, "steps": len(t1), "best_s": min(t1), "median_s": sorted(t1)[len(t1) // 2],
+          "value": (T - cfg.receptive_field) / min(t1)}
+    b8 = None
+    est8 = 8.0 * min(t1)
+    if time.time() - t_begin + 2.2 * est8 < 1.5 * seconds_budget:   # one warm-up + at least one timed step must fit
+        x8, h8, t8 = O.synthetic_batch(cfg, BATCH_PER_GPU, T, 2)
+        timed(x8, h8, t8)
+        t8s = [timed(x8, h8, t8)]
+        while time.time() - t_begin + t8s[-1] < seconds_budget and len(t8s) < 3:
+            t8s.append(timed(x8, h8, t8))
+        b8 = {"B": BATCH_PER_GPU, "steps": len(t8s), "best_s": min(t8s), "median_s": sorted(t8s)[len(t8s) // 2],
+              "value": BATCH_PER_GPU * (T - cfg.receptive_field) / min(t8s)}
+    best = max([b for b in (b1, b8) if b], key=lambda b: b["value"])
+    return {"value": best["value"], "unit": "audio-samples/sec", "cores": best_thr, "kind": "port",
+            "host_logical_cpus": navail, "b1": b1, "b8": b8,
+            "sample": "CPU oracle (reference torch-CPU ops: train.py:527-540 on wavenet.py:212-241), same 30-layer model, "
+                      "windows of T=%d; threads calibrated over %s -> %d; B=1: %d steps, best %.3f s; B=8: %s; value = the "
+                      "better rate (B=%d); %.0f s of CPU work" % (
+                          T, cands, best_thr, b1["steps"], b1["best_s"],
+                          ("%d steps, best %.3f s" % (b8["steps"], b8["best_s"])) if b8 else "skipped (time budget)",
+                          best["B"], time.time() - t_begin)}
 
 
 def decode_report(model, device, with_cpu):
@@ -152,11 +183,13 @@ def stream_mode(flags):
 
 
 def check_aux_fused(model, x, h, t, tol=1e-5):
-    """One backward in the default mode and one with WN_FLAG_AUX_FUSED on the benchmark's own batch; the two gradient
-    buffers must agree per parameter tensor to `tol` of the tensor's max (the modes only re-associate sums)."""
+    """One backward with the separate wn_aux_bwd launch and one with WN_FLAG_AUX_FUSED (the engine's default) on the
+    benchmark's own batch; the two gradient buffers must agree per parameter tensor to `tol` of the tensor's max (the
+    modes only re-associate sums)."""
     from pytorchwavenetvocoder_amd import _lib
     eng = model.engine
     base = eng.flags
+    eng.flags = base & ~_lib.FLAG_AUX_FUSED
     model.loss_and_backward(x, h, t)
     g0 = eng.grads().clone()
     eng.flags = base | _lib.FLAG_AUX_FUSED
@@ -175,19 +208,38 @@ def check_aux_fused(model, x, h, t, tol=1e-5):
     return worst <= tol, worst
 
 
+def load_pmc_traffic(flags):
+    """HBM traffic of a step / per kernel launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh), used only
+    when they were taken in the launch mode of this run (`_engine_flags`)."""
+    for rel in PMC_FILES:
+        try:
+            with open(os.path.join(ROOT, rel)) as fh:
+                d = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if int(d.get("_engine_flags", -1)) == int(flags):
+            d["_file"] = rel
+            return d
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=5, help="how many times the K timed steps are measured (median reported)")
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="sequences per GPU")
+    ap.add_argument("--layers-per-bucket", type=int, default=LAYERS_PER_BUCKET,
+                    help="gradient buckets = weight-gradient launch groups of this many layers (same for N = 1 and N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the configs[4] generation measurement")
     ap.add_argument("--no-fused", action="store_true", help="force the layered (any-size) kernels")
     ap.add_argument("--exact-mfma", action="store_true", help="every contraction on the exact f32-input MFMA")
-    ap.add_argument("--aux-fused", action="store_true",
-                    help="WN_FLAG_AUX_FUSED (opt-in, DESIGN.md 8): aux-gradient partial sums inside the gate kernel; checked "
-                         "against the default path on this batch before the timed steps, falls back if they disagree")
+    ap.add_argument("--no-aux-fused", action="store_true",
+                    help="aux-path gradients by the separate wn_aux_bwd launch instead of the partial sums inside the gate "
+                         "kernel (WN_FLAG_AUX_FUSED, the engine's default)")
+    ap.add_argument("--aux-fused", action="store_true", help=argparse.SUPPRESS)   # round-1 spelling: now the default
     ap.add_argument("--profile-steps", type=int, default=2, help="extra untimed steps with per-launch HIP events")
     args = ap.parse_args()
 
@@ -227,6 +279,8 @@ def main():
         model.engine.flags |= _lib.FLAG_NO_FUSED
     if args.exact_mfma:
         model.engine.flags |= _lib.FLAG_EXACT_MFMA
+    if args.no_aux_fused:
+        model.engine.flags &= ~_lib.FLAG_AUX_FUSED
     rf = model.receptive_field
     bl, frames, T = geometry(rf, BATCH_LENGTH, CFG2["upsampling_factor"])
     B = args.batch
@@ -238,17 +292,10 @@ def main():
     if world > 1:  # identical initial weights on every rank (no per-step broadcast afterwards)
         dist.broadcast(model.engine.flat_params, src=0)
 
-    aux_mode = "separate wn_aux_bwd launch"
-    if args.aux_fused:
-        ok, err = check_aux_fused(model, x, h, t)
-        if ok:
-            model.engine.flags |= _lib.FLAG_AUX_FUSED
-            aux_mode = "partial sums inside the gate kernel (WN_FLAG_AUX_FUSED); worst per-tensor difference to the default " \
-                       "path on this batch %.2e of the tensor's max" % err
-        else:
-            aux_mode += " (WN_FLAG_AUX_FUSED rejected by the self-check: %.2e)" % err
+    aux_on = bool(model.engine.flags & _lib.FLAG_AUX_FUSED) and not (args.no_fused or args.exact_mfma)
+    aux_mode = "partial sums inside the gate kernel (WN_FLAG_AUX_FUSED)" if aux_on else "separate wn_aux_bwd launch"
     opt = FusedAdam(model, lr=1e-4)
-    red = GradientReducer(model, layers_per_bucket=10)
+    red = GradientReducer(model, layers_per_bucket=args.layers_per_bucket)
 
     def step():
         loss = red.loss_and_backward(x, h, t)
@@ -262,17 +309,21 @@ def main():
 
     for _ in range(args.warmup):
         loss = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        el = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        elapsed = float(el.item())
+    regions = []
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            elapsed = float(el.item())
+        regions.append(elapsed)
     final_loss = float(loss.item())
+    elapsed = sorted(regions)[len(regions) // 2]      # median region of K steps
 
     ms_per_step = elapsed / args.steps * 1e3
     samples_per_s = world * B * (T - rf) * args.steps / elapsed
@@ -292,6 +343,23 @@ def main():
         torch.cuda.synchronize(device)
         if rank == 0:
             lib.wn_prof_enable(0)
+    if rank == 0:
+        pmc = load_pmc_traffic(model.engine.flags)
+        alg_step = B * T * ALG_BYTES_PER_TIMESTEP
+        step_traffic = pmc.get("_step_total_bytes") if pmc else None
+        roofline = {
+            "bound": "hbm", "achieved": timesteps_per_s_gpu * ALG_BYTES_PER_TIMESTEP / 1e9, "peak": HBM_PEAK / 1e9,
+            "unit": "GB/s", "frac": timesteps_per_s_gpu * ALG_BYTES_PER_TIMESTEP / HBM_PEAK,
+            "scope": "whole training step per GPU: SURVEY.md 8(d) algorithmic bytes (78 356 B per timestep x %d timesteps "
+                     "= %.2f GB per step) / median step time, vs the 8 TB/s HBM3E peak" % (B * T, alg_step / 1e9),
+            "algorithmic_bytes_per_step": alg_step,
+            "traffic": step_traffic,
+            "traffic_ratio": (step_traffic / alg_step) if step_traffic else None,
+            "traffic_note": ("HBM bytes of one step, (2*FETCH_SIZE + WRITE_SIZE)*1024 summed over all launches, separate "
+                             "rocprofv3 --pmc passes of this launch mode: %s" % pmc["_file"]) if pmc else
+                            "no PMC passes committed for this launch mode",
+            "step_f32_flop_frac": timesteps_per_s_gpu * ALG_FLOP_PER_TIMESTEP / F32_MFMA_PEAK,
+        }
     if rank == 0 and args.profile_steps > 0:
         need = lib.wn_prof_report(None, 0)
         buf = ctypes.create_string_buffer(max(need, 16))
@@ -305,44 +373,29 @@ def main():
                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
         for k, v in prof.items():
             kernels[k]["GBps_compulsory"] = (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["bytes"] > 0 and v["ms"] > 0 else None
-        # Dominant kernel = largest share of the step.  Its roofline is whichever bound is the
-        # binding one for that launch: t_mfma = flop / f32-MFMA peak vs t_hbm = compulsory bytes /
-        # HBM peak (compulsory = every input/output tensor of the launch once).
+        # Dominant kernel = largest share of the step's HIP-event time.
         dom = next((k for k, v in kernels.items() if v["tflops"] is not None), None)
         if dom is not None:
             v = prof[dom]
-            sec = v["ms"] * 1e-3
-            ach_f = v["flops"] / sec / 1e12
-            ach_b = v["bytes"] / sec / 1e9
+            sec_launch = v["ms"] * 1e-3 / v["count"]
             mfma_peak = F32_MFMA_PEAK if args.exact_mfma else BF16_MFMA_PEAK / SPLIT_PRODUCTS
-            t_mfma = v["flops"] / mfma_peak
-            t_hbm = v["bytes"] / HBM_PEAK
-            traffic = None  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/pmc_traffic.json)
-            try:
-                if model.engine.flags & _lib.FLAG_AUX_FUSED:
-                    raise ValueError("the PMC passes were taken in the default mode")
-                with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as fh:
-                    traffic = json.load(fh).get(dom, {}).get("hbm_bytes_per_launch")
-            except (OSError, ValueError):
-                pass
-            if t_hbm >= t_mfma:
-                roofline = {"kernel": dom, "bound": "hbm", "achieved": ach_b, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                            "frac": ach_b / (HBM_PEAK / 1e9)}
-            else:
-                roofline = {"kernel": dom, "bound": "mfma", "achieved": ach_f, "peak": mfma_peak / 1e12,
-                            "unit": "TFLOP/s", "frac": ach_f / (mfma_peak / 1e12)}
-            roofline.update({
-                "traffic": traffic,
-                "traffic_note": "bytes/launch, (2*FETCH_SIZE+WRITE_SIZE)*1024 from separate --pmc passes",
-                "avg_launch_ms": v["ms"] / v["count"], "flop_per_launch": v["flops"] / v["count"],
+            alg_launch = ALG_BYTES_PER_TIMESTEP_OF.get(dom)
+            alg_launch = alg_launch * B * T if alg_launch else None
+            roofline["dominant_kernel"] = {
+                "kernel": dom, "launches_per_step": v["count"] / args.profile_steps, "avg_launch_ms": sec_launch * 1e3,
+                "share_of_step": v["ms"] / tot_ms,
+                "algorithmic_bytes_per_launch": alg_launch,
+                "achieved_alg_GBps": (alg_launch / sec_launch / 1e9) if alg_launch else None,
+                "frac_alg": (alg_launch / sec_launch / HBM_PEAK) if alg_launch else None,
                 "compulsory_bytes_per_launch": v["bytes"] / v["count"],
-                "mfma_frac": ach_f / (mfma_peak / 1e12), "hbm_frac": ach_b / (HBM_PEAK / 1e9),
-                "dtype_peak": ("f32-input MFMA (v_mfma_f32_32x32x2_f32), dense 157.3 TFLOP/s" if args.exact_mfma else
-                               "fp32-equivalent work on v_mfma_f32_32x32x16_bf16: 2.5 PFLOP/s dense bf16 / 6 products "
-                               "= 417 TFLOP/s") + "; HBM3E 8 TB/s",
-                "step_hbm_frac": timesteps_per_s_gpu * ALG_BYTES_PER_TIMESTEP / HBM_PEAK,
-                "step_hbm_achieved_GBps": timesteps_per_s_gpu * ALG_BYTES_PER_TIMESTEP / 1e9,
-                "step_f32_flop_frac": timesteps_per_s_gpu * ALG_FLOP_PER_TIMESTEP / F32_MFMA_PEAK})
+                "bw_util": v["bytes"] / v["count"] / sec_launch / HBM_PEAK,
+                "traffic": (pmc.get(dom) or {}).get("hbm_bytes_per_launch") if pmc else None,
+                "flop_per_launch": v["flops"] / v["count"],
+                "mfma_frac": v["flops"] / v["count"] / sec_launch / mfma_peak,
+                "notes": "algorithmic = SURVEY 8(d) bytes of this launch (skip-sum gradient and weight-gradient operands "
+                         "on chip); compulsory = every operand tensor of the launch as built, once; traffic = PMC; "
+                         "matrix peak = " + ("f32-input MFMA 157.3 TFLOP/s" if args.exact_mfma else
+                                             "2.5 PFLOP/s dense bf16 / 6 products of the 3-way split = 417 TFLOP/s fp32-equivalent")}
 
     if rank == 0:
         out = {
@@ -350,6 +403,8 @@ def main():
             "value": samples_per_s, "unit": "audio-samples/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "repeats": len(regions), "ms_per_step_min": min(regions) / args.steps * 1e3,
+            "ms_per_step_max": max(regions) / args.steps * 1e3,
             "config": {"workload": "BASELINE configs[1]: 30-layer WaveNet, 64 residual / 256 skip ch, 80-dim mel aux, "
                                    "mu-law softmax, K=2, U=80; batch %d x batch_len 20000 per GPU (T=%d inputs, %d loss "
                                    "positions per sequence), random-init weights, fwd+CE+bwd+allreduce+Adam" % (
@@ -357,6 +412,10 @@ def main():
                        "global_batch": world * B, "parallelism": "dp%d" % world,
                        "kernels": "layered" if args.no_fused else "fused+gemm",
                        "streams": stream_mode(model.engine.flags), "aux_gradient": aux_mode,
+                       "engine_flags": int(model.engine.flags),
+                       "gradient_buckets": "post-net+skip | groups of %d layers | front+upsampling (weight gradients are "
+                                           "launched per bucket; identical structure for N = 1 and N > 1)" % args.layers_per_bucket,
+                       "timing": "median of %d regions of %d steps" % (len(regions), args.steps),
                        "arithmetic": "fp32 storage and accumulation; contractions on the bf16 matrix cores with a 3-way "
                                      "operand split (6 products, fp32-equivalent to round-off) except K=3 forward blocks "
                                      "(exact f32 MFMA); WN_FLAG_EXACT_MFMA selects the f32 MFMA everywhere"},

@@ -97,6 +97,10 @@ enum {
                                * partial sums of the aux-path gradients (frame-rate aux gradient, upsampling weight), a
                                * small kernel finishes them and dP is not re-read by wn_aux_bwd.  Opt-in until measured
                                * on hardware; sums re-associate (~1e-7 relative) */
+#define WN_FLAG_NO_CHAIN 64   /* wn_backward (fused split kernels, kernel_size <= 2): since ABI v4 the data chain runs as ONE launch
+                               * per layer (dX_l and gate'_{l-1} fused, the skip part of dZ pre-contracted for all layers by
+                               * one matrix-bound launch; csrc/wn_fused.hip k_chain64s).  This flag restores the former
+                               * gate' + dX launch pair per layer (kept for A/B measurements and as an independent check) */
 #define WN_FLAG_BWD_OVERLAP_HEAD 16 /* with WN_FLAG_BWD_OVERLAP: only the post-net / skip weight gradients run on the side
                                * stream; the per-layer groups stay on the caller's stream */
 #define WN_FLAG_FWD_OVERLAP 8 /* wn_forward (fused kernels): the skip-sum contraction is issued in three chunks of layers on
@@ -191,7 +195,7 @@ int wn_op_causal_conv(const float* weight, const float* bias, const float* x /*(
                       float* scratch, int B, int T, int Cin, int Cout, int K, int dilation, void* stream);
 
 /* Generic C[z] = A.B contraction on the f32 matrix cores; argument block: wavenet_hip_gemm.h (struct WnGemmArgs,
- * wn_gemm_default() fills the neutral values). */
+ * the inline helper wn_gemm_default fills the neutral values). */
 int wn_op_gemm(const struct WnGemmArgs* args, void* stream);
 
 /* Mixture-of-logistics output head (BASELINE configs[3]).  NOT part of the reference (its WaveNet only has the

@@ -384,6 +384,8 @@ struct Ws {
     // scratch
     long P, dO2, dSk, dZ, dXall, dG, dw_partial, dc, tmpS, partial, rs_partial, red_scratch, loss_partial;
     long dGp, qp;  // aux-gradient partials of the gate kernel (WN_FLAG_AUX_FUSED); 0 floats when the mode cannot apply
+    long wskipT_f, dZs;  // chain mode (wn_fused_chain_supported): skip weights as [s][l*R + i], dZs = Wskip^T dSkip (B, L*R, T)
+    long dZs_floats;
     long red_scratch_floats;
     long apk_floats;
     long front_partial, front_partial_floats;
@@ -435,6 +437,12 @@ static int make_ws(const Dims& d, int B, int T, Ws* w) {
         CARVE(dGp, auxf ? (long)d.L * B * 2 * d.R * (T / 16) : 0);
         CARVE(qp, auxf ? (long)d.L * B * T : 0);
     }
+    {
+        const bool chain = wn_fused_chain_supported(d.R, d.K, d.S) && d.L > 1;
+        w->dZs_floats = chain ? (long)B * d.L * d.R * T : 0;
+        CARVE(wskipT_f, chain ? (long)d.S * d.L * d.R : 0);
+        CARVE(dZs, w->dZs_floats);
+    }
     CARVE(dc, (long)d.L * 2 * d.R);
     CARVE(tmpS, d.S > d.Qo ? d.S : d.Qo);
     // partial buffers: max over the dW GEMMs issued by wn_backward
@@ -462,7 +470,7 @@ static int make_ws(const Dims& d, int B, int T, Ws* w) {
     CARVE(front_partial, w->front_partial_floats);
     {   // split-bf16 weights of the forward-type contractions (wn_gemm6): one buffer, re-packed before each use
         const int mk[][2] = {{d.S, d.L * d.R}, {d.S, d.S}, {d.Qo, d.S}, {d.S, d.Qo}, {2 * d.R, d.K * d.R},
-                             {d.R, d.R}, {d.R, d.S}, {d.R, d.K * 2 * d.R}};
+                             {d.R, d.R}, {d.R, d.S}, {d.R, d.K * 2 * d.R}, {d.L * d.R, d.S}};
         long e = 0;
         for (unsigned i = 0; i < sizeof(mk) / sizeof(mk[0]); ++i) {
             const long ei = wn_gemm6_apk_elems(mk[i][0], mk[i][1]);
@@ -607,6 +615,12 @@ static int pack_weights(const Ctx& c, const float* params) {
     cp.s0 = 0; cp.s1 = 1; cp.s2 = d.R; cp.sl = y.ls_skip;
     cp.d0 = 0; cp.d1 = d.S; cp.d2 = 1; cp.dl = (long)d.R * d.S;
     WN_TRY(wn_copy4_batch_add(&jobs, ws + w.wskip_f, params + y.skip0, &cp));
+    if (w.dZs_floats > 0) {  // wskipT_f[s*(L*R) + l*R + i] = Wskip_l[s][i]: the A operand of dZs = Wskip^T dSkip (all layers)
+        cp.n0 = 1; cp.n1 = d.S; cp.n2 = d.R; cp.nl = d.L;
+        cp.s0 = 0; cp.s1 = d.R; cp.s2 = 1; cp.sl = y.ls_skip;
+        cp.d0 = 0; cp.d1 = (long)d.L * d.R; cp.d2 = 1; cp.dl = d.R;
+        WN_TRY(wn_copy4_batch_add(&jobs, ws + w.wskipT_f, params + y.skip0, &cp));
+    }
     // w1_f[i*S + o] = W1[o][i] ; w2_f[i*Q + q] = W2[q][i]
     cp.n0 = 1; cp.n1 = d.S; cp.n2 = d.S; cp.nl = 1;
     cp.s0 = 0; cp.s1 = 1; cp.s2 = d.S; cp.sl = 0;
@@ -956,6 +970,21 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
     // WN_FLAG_AUX_FUSED: the gate kernel leaves the partial sums of the aux-path gradients behind, dP is not re-read
     // for them (split kernels, upsampling layer with U % 16 == 0)
     const bool aux_fused = (flags & WN_FLAG_AUX_FUSED) && c.fused && c.split_bf16 && d.U >= 16 && d.U % 16 == 0 && w.dGp != w.qp;
+    // Chain mode (default for the fused split kernels, kernel_size <= 2): one launch per layer computes dX_l AND, from it,
+    // dP_{l-1}; the skip part of every layer's dZ is contracted up front, dZs[b][l*R + i][t] = sum_s Wskip_l[s][i] dSkip[b][s][t]
+    // (layers 0 .. L-2; the last layer's gate' takes dSkip itself, it has no dX input).  WN_FLAG_NO_CHAIN: the former pair.
+    const bool chain = c.fused && c.split_bf16 && !(flags & WN_FLAG_NO_CHAIN) && w.dZs_floats > 0 &&
+                       wn_fused_chain_supported(d.R, d.K, d.S);
+    const long zs_bstride = (long)d.L * d.R * T;
+    if (chain) {
+        WnGemmArgs g = wn_gemm_default();
+        g.M = (d.L - 1) * d.R; g.N = T; g.K = d.S;
+        g.A = ws + w.wskipT_f; g.lda = (long)d.L * d.R;
+        g.B = ws + w.dSk; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = T;
+        g.C = ws + w.dZs; g.ldc = T; g.c_zstride = zs_bstride;
+        g.nbatch = B; g.tag = "bwd_dz_skip_all";
+        WN_TRY(fw_gemm(c, g));
+    }
     // WN_FLAG_BWD_OVERLAP_HEAD: only the post-net / skip weight gradients (matrix-bound) go to the side stream, the
     // per-layer groups (HBM-bound like the chain itself) follow the chain on the caller's stream
     const Ctx& cl = (flags & WN_FLAG_BWD_OVERLAP_HEAD) ? c : cs;
@@ -1048,7 +1077,29 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
         float* dP = ws + w.P + (long)l * P_L;
         const float* dXn = (l + 1 < d.L) ? ws + w.dXall + (long)(l + 1) * BRT : nullptr;  // null: dead (last layer)
         float* dXl = ws + w.dXall + (long)l * BRT;
-        if (c.fused) {
+        if (chain) {
+            if (l == d.L - 1) {  // head of the chain: gate' of the last layer straight from dSkip (no dX input)
+                if (aux_fused)
+                    WN_TRY(wn_fused_bwd_gate_aux(params + y.skip0 + (long)l * y.ls_skip, params + lb + y.o_res_w, ws + w.dSk, nullptr,
+                                                 Sl, Gtl, dP, ws + w.G + (long)l * 2 * d.R * F, g_bstride, upw, Ue, F,
+                                                 ws + w.dGp + (long)l * B * 2 * d.R * (T / 16), ws + w.qp + (long)l * B * T, B, T,
+                                                 d.S, c.st));
+                else
+                    WN_TRY(wn_fused_bwd_gate(params + y.skip0 + (long)l * y.ls_skip, params + lb + y.o_res_w, ws + w.dSk, nullptr,
+                                             Sl, Gtl, dP, B, T, d.S, 1, c.st));
+            }
+            if (l > 0) {  // dX_l from dP_l, and gate' of layer l-1 from it
+                const long lbp = layer_base(y, d, l - 1);
+                WN_TRY(wn_fused_bwd_chain(ws + w.wd_b + (long)l * d.K * 2 * d.R * d.R, dP, dXn, dXl, params + lbp + y.o_res_w,
+                                          ws + w.dZs + (long)(l - 1) * d.R * T, zs_bstride, ws + w.Sg + (long)(l - 1) * BRT,
+                                          ws + w.Gt + (long)(l - 1) * BRT, ws + w.P + (long)(l - 1) * P_L,
+                                          ws + w.G + (long)(l - 1) * 2 * d.R * F, g_bstride, upw, Ue, F,
+                                          aux_fused ? ws + w.dGp + (long)(l - 1) * B * 2 * d.R * (T / 16) : nullptr,
+                                          aux_fused ? ws + w.qp + (long)(l - 1) * B * T : nullptr, B, T, d.K, dil, c.st));
+            } else {      // tail: dX_0
+                WN_TRY(wn_fused_bwd_dx(ws + w.wd_b, dP, dXn, dXl, B, T, d.K, dil, 1, c.st));
+            }
+        } else if (c.fused) {
             // dZ = Wskip^T dSk (+ Wres^T dXn) -> gate' -> dP
             if (aux_fused)
                 WN_TRY(wn_fused_bwd_gate_aux(params + y.skip0 + (long)l * y.ls_skip, params + lb + y.o_res_w, ws + w.dSk, dXn,

@@ -35,3 +35,14 @@ int wn_fused_bwd_gate_aux(const float* wskip, const float* wres, const float* dS
 // split != 0: bf16 matrix cores with the 3-way operand split (fp32-equivalent), else the exact f32 MFMA
 int wn_fused_bwd_dx(const float* wd_b, const float* dP, const float* dXn, float* dX, int B, int T, int K, int dilation,
                     int split, wn_stream_t st);
+
+// One launch per layer of the backward data chain (split arithmetic, K <= 2; wn_fused_chain_supported):
+//   dX_l = (dXn) + sum_tap Wd_tap^T dP_l[t + (K-1-tap) d]           -> dX
+//   dZ_{l-1} = dZs_{l-1} + Wres_{l-1}^T dX_l ; dP_{l-1} = gate'(dZ_{l-1}; S, Gt of layer l-1)   -> dP_prev
+// dZs (row stride T, batch stride zs_bstride) is the pre-contracted skip part Wskip_{l-1}^T dSkip.  dX_l goes from the
+// accumulators of the first half straight into the MFMAs of the second.  dGp != NULL adds the aux-gradient partial sums
+// of wn_fused_bwd_gate_aux for layer l-1 (G = that layer's rows of the frame-rate projection).
+int wn_fused_chain_supported(int R, int K, int S);
+int wn_fused_bwd_chain(const float* wd_b, const float* dP, const float* dXn, float* dX, const float* wres_prev, const float* dZs,
+                       long zs_bstride, const float* S, const float* Gt, float* dP_prev, const float* G, long g_bstride,
+                       const float* upw, int U, int F, float* dGp, float* qp, int B, int T, int K, int dilation, wn_stream_t st);

@@ -1320,3 +1320,325 @@ int wn_fused_bwd_dx(const float* wd_b, const float* dP, const float* dXn, float*
     a.G = nullptr; a.g_bstride = 0; a.upw = nullptr; a.U = 0; a.F = 0; a.dGp = nullptr; a.qp = nullptr;
     return launch_conv64<1>(a, split, st);
 }
+
+// ---------------------------------------------------------------------------------------------
+// k_chain64s -- one launch per layer of the backward data chain (split arithmetic, K <= 2):
+//     dX_l[t]     = dX_{l+1}[t] + sum_tap Wd_tap^T dP_l[t + (K-1-tap) d]                    (wavenet.py:527-528 reversed)
+//     dZ_{l-1}[t] = dZs_{l-1}[t] + Wres_{l-1}^T dX_l[t]                                      (wavenet.py:533-535 reversed)
+//     dP_{l-1}[t] = [dZ g s (1-s) ; dZ s (1-g^2)]                                            (wavenet.py:529-532 reversed)
+// dX_l and gate'_{l-1} meet at the SAME time index, so the tile of dX_l a wave has just accumulated goes from its
+// accumulator registers straight into the MFMAs of the res-1x1 transpose -- the chaining the forward kernel uses for
+// z -> res 1x1 (k-step order = accumulator register order) -- and never comes back from HBM: one launch and 64 words
+// per timestep less than the k_conv64s<0/2> + k_conv64s<1> pair.  What makes the weights of both halves fit the LDS in
+// split form is that the skip part of dZ arrives pre-contracted: dZs = Wskip_l^T dSkip for ALL layers is one matrix-bound
+// contraction per step (wn_api.hip), so this kernel reads 64 channels of it instead of the 256 of dSkip and needs no
+// Wskip: taps K x 128 x 64 + Wres^T 64 x 64 = 120 KB of bf16 fragments for K = 2.
+// AUX = 1 adds the aux-gradient partial sums of wn_fused_bwd_gate_aux to the gate epilogue (same arithmetic, same order).
+// ---------------------------------------------------------------------------------------------
+struct ChainArgs {
+    const float* wd_b;   // [tap][128][64]: W_tap^T, row = dP channel, col = dX channel   (layer l)
+    const float* dP;     // (B, 128, T) of layer l
+    const float* dXn;    // (B, 64, T) dX_{l+1}; NULL for the last layer (its residual output is dead)
+    float* dX;           // (B, 64, T) out
+    const float* wres;   // natural res_1x1 weight of layer l-1: [o][i] = [k][row]
+    const float* dZs;    // skip part of dZ_{l-1}: rows [0, 64) at dZs + b * zs_bstride, row stride T
+    long zs_bstride;
+    const float* S;      // (B, 64, T) sigmoid / tanh halves of layer l-1 (saved by the forward)
+    const float* Gt;
+    float* dPm;          // (B, 128, T) out: dP_{l-1}
+    int B, T, K, dil;
+    int stagger;
+    // AUX
+    const float* G;      // (B, g_bstride) frame-rate aux projection of layer l-1, rows [0,128)
+    long g_bstride;
+    const float* upw;    // [U]
+    int U, F;
+    float* dGp;          // (B, 128, T/16)
+    float* qp;           // (B, T)
+};
+
+// 8 fp32 values -> the three bf16 pieces of the lane's share of a 16-k block
+static __device__ __forceinline__ void split8v(const float (&x)[8], bool ok, wn_f4 (&bf)[3]) {
+    float y[8];
+    WN_UNROLL
+    for (int e = 0; e < 8; ++e) y[e] = ok ? x[e] : 0.0f;
+    split8(y, bf);
+}
+
+template <int AUX, int K>
+__global__ __launch_bounds__(WN_FT) void k_chain64s(ChainArgs a) {
+    WN_DYN_SMEM(smem_raw);
+    char* W = smem_raw;                      // tap blocks: chunk q (32 channels) = tap q % K, channel group q / K; 2 blocks of 6 KB each
+    constexpr int NCH = K * 4;               // chunks of the dX part
+    char* Wr = W + NCH * 2 * 6144;           // Wres^T: 4 blocks [piece][64 rows][16 k], k order = accumulator register order
+    for (int idx = threadIdx.x; idx < NCH * 2 * 128; idx += WN_FT) {
+        const int o = idx & 63, h = (idx >> 6) & 1, kbg = idx >> 7;
+        const int q = kbg >> 1;
+        const int tap = q % K;
+        const int c = (q / K) * 32 + (kbg & 1) * 16 + 8 * h;
+        const float* src = a.wd_b + ((long)tap * 128 + c) * 64 + o;
+        float x[8];
+        WN_UNROLL
+        for (int e = 0; e < 8; ++e) x[e] = src[e * 64];
+        wn_f4 bf[3];
+        split8(x, bf);
+        WN_UNROLL
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<wn_f4*>(W + kbg * 6144 + p * 2048 + o * 32 + h * 16) = bf[p];
+    }
+    for (int idx = threadIdx.x; idx < 4 * 2 * 64; idx += WN_FT) {
+        const int o = idx & 63, h = (idx >> 6) & 1, kb = idx >> 7;
+        split_to_lds(a.wres + (long)(16 * kb + 4 * h) * 64 + o, 64, Wr + kb * 6144 + o * 32 + h * 16, 2048);
+    }
+    __syncthreads();
+    if (WN_UNIFORM((int)(threadIdx.x / (WN_FT / 2))) != 0)
+        for (int i = 0; i < a.stagger; ++i) WN_SLEEP(127);
+
+    const int lane = threadIdx.x & 63;
+    const int li = lane & 31, hi = lane >> 5;
+    const int T = a.T;
+    const int T4 = T * 4;
+    const int tiles_per_b = (T + 31) >> 5;
+    const int ntiles = a.B * tiles_per_b;
+    const TileWalk walk = tile_walk(ntiles, threadIdx.x >> 6);
+    const int step = walk.step, tile_end = walk.end;
+
+    float xa[16], xb[16];
+    bool oka = false, okb = false;
+    auto issue = [&](int tl_v, int q, float (&xr)[16], bool& okr) {
+        const int tl = WN_UNIFORM(tl_v);
+        const int b = tl / tiles_per_b;
+        const int t = (tl - b * tiles_per_b) * 32 + li;
+        const int tap = q % K, c0 = (q / K) * 32;
+        const int ts = t + (K - 1 - tap) * a.dil;
+        const bool ok = (t < T) && ts < T;
+        okr = ok;
+        const wn_rsrc_t Sr = wn_make_buf(a.dP + (long)b * 128 * T, (unsigned)(128 * T4));
+        const int vt = ok ? (8 * hi * T + ts) * 4 : 0;
+        WN_UNROLL
+        for (int s = 0; s < 16; ++s) xr[s] = wn_buf_load(Sr, vt, (c0 + 16 * (s >> 3) + (s & 7)) * T4);
+    };
+    f32x16 acc[2];
+    auto consume = [&](int q, const float (&xr)[16], bool okr) {
+        WN_UNROLL
+        for (int blk = 0; blk < 2; ++blk) {
+            float x8[8];
+            WN_UNROLL
+            for (int e = 0; e < 8; ++e) x8[e] = xr[8 * blk + e];
+            wn_f4 bf[3];
+            split8v(x8, okr, bf);
+            const char* Wl = W + (2 * q + blk) * 6144 + li * 32 + hi * 16;
+            wn_f4 af[2][3];
+            WN_UNROLL
+            for (int rt = 0; rt < 2; ++rt) {
+                WN_UNROLL
+                for (int p = 0; p < 3; ++p) af[rt][p] = *reinterpret_cast<const wn_f4*>(Wl + p * 2048 + rt * 1024);
+            }
+            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};  // small terms first
+            WN_UNROLL
+            for (int t6 = 0; t6 < 6; ++t6) {
+                acc[0] = mfma_bf16(af[0][PA[t6]], bf[PB[t6]], acc[0]);
+                acc[1] = mfma_bf16(af[1][PA[t6]], bf[PB[t6]], acc[1]);
+            }
+        }
+    };
+
+    int tile_v = walk.first;
+    if (tile_v < tile_end) {
+        issue(tile_v, 0, xa, oka);
+        issue(tile_v, 1, xb, okb);
+    }
+    while (tile_v < tile_end) {
+        const int tile = WN_UNIFORM(tile_v);
+        const int b = tile / tiles_per_b;
+        const int t = (tile - b * tiles_per_b) * 32 + li;
+        const bool inb = t < T;
+        const int vcur = inb ? (4 * hi * T + t) * 4 : 0;
+        const int next_v = tile_v + step;
+
+        // The residual input dX_{l+1} is the INITIAL VALUE of the tap accumulators (loaded straight into them), and the
+        // pre-contracted skip part of dZ that of the second accumulator pair (requested in the middle of the taps).
+        // Lanes past T read a valid dummy address; their columns never leave the wave.
+        f32x16 dz[2];
+        acc[0] = f32x16_zero();
+        acc[1] = f32x16_zero();
+        if (a.dXn != nullptr) {
+            const wn_rsrc_t Rr = wn_make_buf(a.dXn + (long)b * 64 * T, (unsigned)(64 * T4));
+            WN_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) acc[q][r] = wn_buf_load(Rr, vcur, (32 * q + mfma32_row(r, 0)) * T4);
+            }
+        }
+        WN_SCHED_BARRIER();
+        // saved gate halves of layer l-1: the first 32 channels are requested half way through the taps, the second 32
+        // at their end (their registers are the operand buffers the taps no longer need)
+        const wn_rsrc_t Ssr = wn_make_buf(a.S + (long)b * 64 * T, (unsigned)(64 * T4));
+        const wn_rsrc_t Gsr = wn_make_buf(a.Gt + (long)b * 64 * T, (unsigned)(64 * T4));
+        float e0[2][16], e1[2][16];
+        WN_UNROLL
+        for (int q = 0; q < NCH; q += 2) {
+            consume(q, xa, oka);
+            if (q + 2 < NCH) issue(tile_v, q + 2, xa, oka);
+            WN_SCHED_BARRIER();
+            consume(q + 1, xb, okb);
+            if (q + 3 < NCH) issue(tile_v, q + 3, xb, okb);
+            if (q == (NCH >> 1) - 2) {  // once, in the middle of the tap loop
+                const wn_rsrc_t Zr = wn_make_buf(a.dZs + (long)b * a.zs_bstride, (unsigned)(64 * T4));
+                WN_UNROLL
+                for (int qq = 0; qq < 2; ++qq) {
+                    WN_UNROLL
+                    for (int r = 0; r < 16; ++r) dz[qq][r] = wn_buf_load(Zr, vcur, (32 * qq + mfma32_row(r, 0)) * T4);
+                }
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int so = mfma32_row(r, 0) * T4;
+                    e0[0][r] = wn_buf_load(Ssr, vcur, so);
+                    e1[0][r] = wn_buf_load(Gsr, vcur, so);
+                }
+            }
+            WN_SCHED_BARRIER();
+        }
+        WN_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int so = (32 + mfma32_row(r, 0)) * T4;
+            e0[1][r] = wn_buf_load(Ssr, vcur, so);
+            e1[1][r] = wn_buf_load(Gsr, vcur, so);
+        }
+        // dX_l of this tile is finished in the accumulator layout: register r of lane (li, hi) = channel 32q + row(r, hi)
+        WN_SCHED_BARRIER();
+        // dZ += Wres^T dX: k-step e of block kb takes accumulator register 8 (kb & 1) + e of row tile kb >> 1
+        WN_UNROLL
+        for (int kb = 0; kb < 4; ++kb) {
+            float x8[8];
+            WN_UNROLL
+            for (int e = 0; e < 8; ++e) x8[e] = acc[kb >> 1][8 * (kb & 1) + e];
+            wn_f4 bf[3];
+            split8(x8, bf);
+            const char* Wl = Wr + kb * 6144 + li * 32 + hi * 16;
+            wn_f4 af[2][3];
+            WN_UNROLL
+            for (int rt = 0; rt < 2; ++rt) {
+                WN_UNROLL
+                for (int p = 0; p < 3; ++p) af[rt][p] = *reinterpret_cast<const wn_f4*>(Wl + p * 2048 + rt * 1024);
+            }
+            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+            WN_UNROLL
+            for (int t6 = 0; t6 < 6; ++t6) {
+                dz[0] = mfma_bf16(af[0][PA[t6]], bf[PB[t6]], dz[0]);
+                dz[1] = mfma_bf16(af[1][PA[t6]], bf[PB[t6]], dz[1]);
+            }
+        }
+        WN_SCHED_BARRIER();
+        // the next tile's first operand chunks go out before this tile's stores (vmcnt counts loads and stores in order)
+        if (next_v < tile_end) {
+            issue(next_v, 0, xa, oka);
+            issue(next_v, 1, xb, okb);
+        }
+        if (inb) {
+            const wn_rsrc_t Xr = wn_make_buf(a.dX + (long)b * 64 * T, (unsigned)(64 * T4));
+            WN_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) wn_buf_store(Xr, acc[q][r], vcur, (32 * q + mfma32_row(r, 0)) * T4);
+            }
+        }
+        WN_SCHED_BARRIER();  // the dX registers are free from here on
+        const wn_rsrc_t Or = wn_make_buf(a.dPm + (long)b * 128 * T, (unsigned)(128 * T4));
+        if (AUX) {
+            // gate backward + the partial sums of the aux gradient (as k_conv64s<2>): every lane takes part in the
+            // cross-lane sums, lanes past T carry dP = 0
+            const int tc = inb ? t : 0;
+            const int fr = tc / a.U;
+            const float wj = inb ? a.upw[tc - fr * a.U] : 0.0f;
+            const int F4 = a.F * 4;
+            const int H = T >> 4;  // 16-sample groups per channel row
+            const wn_rsrc_t Gr = wn_make_buf(a.G + (long)b * a.g_bstride, (unsigned)(128 * F4));
+            const wn_rsrc_t Dr = wn_make_buf(a.dGp + (long)b * 128 * H, (unsigned)(128 * H * 4));
+            const int vg = (4 * hi * a.F + fr) * 4;
+            const int l16 = li & 15;
+            const int h16 = (((tile - b * tiles_per_b) * 32) >> 4) + (li >> 4);
+            float qsum = 0.0f;
+            WN_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                float ga[16], gg[16];
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    ga[r] = wn_buf_load(Gr, vg, (32 * q + mfma32_row(r, 0)) * F4);
+                    gg[r] = wn_buf_load(Gr, vg, (64 + 32 * q + mfma32_row(r, 0)) * F4);
+                }
+                float keep_a = 0.0f, keep_g = 0.0f;
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int so = (32 * q + mfma32_row(r, 0)) * T4;
+                    const float s = e0[q][r], g = e1[q][r], dzv = inb ? dz[q][r] : 0.0f;
+                    const float dpa = dzv * g * (s * (1.0f - s)), dpg = dzv * s * (1.0f - g * g);
+                    if (inb) {
+                        wn_buf_store(Or, dpa, vcur, so);
+                        wn_buf_store(Or, dpg, vcur, so + 64 * T4);
+                    }
+                    qsum += dpa * ga[r] + dpg * gg[r];
+                    const float ra = wn_row16_sum(wj * dpa), rg = wn_row16_sum(wj * dpg);
+                    keep_a = (l16 == r) ? ra : keep_a;
+                    keep_g = (l16 == r) ? rg : keep_g;
+                }
+                const int row = 32 * q + mfma32_row(l16, hi);
+                const int doff = (h16 < H) ? (row * H + h16) * 4 : 0x7ffffff0;
+                wn_buf_store(Dr, keep_a, doff, 0);
+                wn_buf_store(Dr, keep_g, doff, (h16 < H) ? 64 * H * 4 : 0);
+                WN_SCHED_BARRIER();  // one 32-row half at a time (register budget)
+            }
+            qsum += __shfl_xor(qsum, 32, 64);
+            if (hi == 0 && inb) a.qp[(long)b * T + t] = qsum;
+        } else if (inb) {
+            WN_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int so = (32 * q + mfma32_row(r, 0)) * T4;
+                    const float s = e0[q][r], g = e1[q][r], dzv = dz[q][r];
+                    wn_buf_store(Or, dzv * g * (s * (1.0f - s)), vcur, so);
+                    wn_buf_store(Or, dzv * s * (1.0f - g * g), vcur, so + 64 * T4);
+                }
+            }
+        }
+        tile_v = next_v;
+    }
+}
+
+int wn_fused_chain_supported(int R, int K, int S) {
+    return wn_fused_supported(R, K, S) && K >= 1 && K <= 2 && (size_t)(K * 8 + 4) * 6144 <= 160 * 1024;
+}
+
+int wn_fused_bwd_chain(const float* wd_b, const float* dP, const float* dXn, float* dX, const float* wres_prev, const float* dZs,
+                       long zs_bstride, const float* S, const float* Gt, float* dP_prev, const float* G, long g_bstride,
+                       const float* upw, int U, int F, float* dGp, float* qp, int B, int T, int K, int dilation, wn_stream_t st) {
+    // dP (, dXn), dZs, S, Gt in; dX, dP_prev out (+ dGp 8 / qp 1 words per timestep with the aux partials)
+    const bool aux = dGp != nullptr;
+    WN_PROF("fused_bwd_chain", 2.0 * (double)B * T * 64.0 * (K * 128.0 + 64.0),
+            4.0 * (double)B * T * (128.0 + (dXn ? 64.0 : 0.0) + 64.0 + 128.0 + 64.0 + 128.0 + (aux ? 9.0 : 0.0)), st);
+    if (K < 1 || K > 2) return 1;
+    if (aux && (U < 16 || (U & 15) || (T & 15) || (long)U * F != T)) return 1;
+    ChainArgs a;
+    a.wd_b = wd_b; a.dP = dP; a.dXn = dXn; a.dX = dX;
+    a.wres = wres_prev; a.dZs = dZs; a.zs_bstride = zs_bstride; a.S = S; a.Gt = Gt; a.dPm = dP_prev;
+    a.B = B; a.T = T; a.K = K; a.dil = dilation;
+    a.stagger = stagger_setting();
+    a.G = G; a.g_bstride = g_bstride; a.upw = upw; a.U = U; a.F = F; a.dGp = dGp; a.qp = qp;
+    const long ntiles = (long)B * ((T + 31) / 32);
+    const long nblk = balanced_blocks(ntiles);
+    const size_t lds = (size_t)(K * 8 + 4) * 6144;
+#define WN_CHAIN_LAUNCH(AUXV, KV)                                                                       \
+    do {                                                                                                \
+        if (set_lds(k_chain64s<AUXV, KV>, lds)) return 1;                                               \
+        WN_LAUNCH((k_chain64s<AUXV, KV>), dim3((unsigned)nblk), dim3(WN_FT), lds, st, a);               \
+    } while (0)
+    if (aux) {
+        if (K == 1) WN_CHAIN_LAUNCH(1, 1);
+        else WN_CHAIN_LAUNCH(1, 2);
+    } else {
+        if (K == 1) WN_CHAIN_LAUNCH(0, 1);
+        else WN_CHAIN_LAUNCH(0, 2);
+    }
+#undef WN_CHAIN_LAUNCH
+    return 0;
+}

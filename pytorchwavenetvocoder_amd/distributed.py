@@ -57,8 +57,8 @@ class GradientReducer(object):
         mean loss (device tensor).  ``y`` (B, T) float selects the mixture-of-logistics loss.
         ``grad_scale``: this rank's share of the global minibatch (default 1/world = equal shards; pass
         B_local / B_global when the shards are uneven, so that the summed gradient is the global-batch mean)."""
-        if self.world == 1:
-            return self._step(x, h, t, y, t_start=t_start)
+        if self.world == 1:   # same launch structure as N > 1 (weight gradients flushed per bucket), no exchange
+            return self._step(x, h, t, y, t_start=t_start, layers_per_bucket=self.lpb)
         gscale = self.grad_scale if grad_scale is None else float(grad_scale)
         if not self.cuda:
             loss = self._step(x, h, t, y, t_start=t_start, grad_scale=gscale)

@@ -12,9 +12,11 @@ import torch
 
 from . import _lib
 
-# Launch modes every engine starts with: 0 = everything on the caller's stream.  The opt-in overlap modes
-# (_lib.FLAG_BWD_OVERLAP / FLAG_FWD_OVERLAP) measured no faster on MI355X (profiles/r01/overlap_probe.txt).
-DEFAULT_FLAGS = 0
+# Launch modes every engine starts with: everything on the caller's stream, and the aux-path gradients as partial sums
+# inside the gate kernel (WN_FLAG_AUX_FUSED: -3.4 % step time, profiles/r01/aux_fused_probe.txt; it applies to the fused
+# split kernels with U % 16 == 0 and is ignored elsewhere).  The opt-in overlap modes (_lib.FLAG_BWD_OVERLAP /
+# FLAG_FWD_OVERLAP) measured no faster on MI355X (profiles/r01/overlap_probe.txt).
+DEFAULT_FLAGS = _lib.FLAG_AUX_FUSED
 
 
 def _ptr(t):

@@ -23,10 +23,11 @@ TOL_GRAD = 1e-4
 TOL_ADAM_REL_LR = 1e-2  # |w - w_ref| <= 1e-2 * lr  (= SURVEY's 1e-6 at the reference's lr=1e-4)
 
 
-def check_golden_case(g, lib, device, flags=0, layers_per_bucket=0):
+def check_golden_case(g, lib, device, flags=None, layers_per_bucket=0):
     """Engine-level (C-ABI) forward / loss / backward against a golden case."""
     eng = WaveNetEngine(*g.cfg.as_tuple(), device=device, library=lib)
-    eng.flags = flags
+    if flags is not None:   # None: the engine's default launch mode (engine.DEFAULT_FLAGS)
+        eng.flags = flags
     assert eng.receptive_field == g.rf
     load_state_into_flat(eng, g.params)
     x, h, t = g.x.to(device), g.h.to(device), g.t.to(device)
@@ -116,13 +117,14 @@ def pick_instance(cfg, B, T, seed, scale, tries=40):
     raise RuntimeError("no instance with ReLU margin >= %g in %d tries" % (KINK_MARGIN, tries))
 
 
-def run_oracle_vs_engine(cfg_tuple, B, T, seed, lib, device, flags=0, scale=0.1, check_grads=True):
+def run_oracle_vs_engine(cfg_tuple, B, T, seed, lib, device, flags=None, scale=0.1, check_grads=True):
     """Live oracle vs HIP path on seeded synthetic inputs (sizes the oracle finishes in seconds)."""
     cfg = O.OracleConfig(*cfg_tuple)
     params, x, h, t, margin, sd = pick_instance(cfg, B, T, seed, scale)
     loss_ref, logits_ref, grads_ref = O.train_step(cfg, params, None, x, h, t)
     eng = WaveNetEngine(*cfg_tuple, device=device, library=lib)
-    eng.flags = flags
+    if flags is not None:
+        eng.flags = flags
     load_state_into_flat(eng, params)
     logits = eng.forward(x.to(device), h.to(device))
     err = float((logits.transpose(1, 2).cpu() - logits_ref).abs().max())
@@ -144,3 +146,77 @@ def run_oracle_vs_engine(cfg_tuple, B, T, seed, lib, device, flags=0, scale=0.1,
 
 def gemm_reference(M, N, K, A, B):
     return A @ B
+
+
+def run_fullsize_vs_oracle(cfg_tuple, B, T, seed, lib, device, flag_sets, scale=0.05, threads=32):
+    """Live oracle vs HIP path at sizes where ReLU kinks are CERTAIN to occur (BASELINE config 2: 8 x 19970 x 512 ReLU
+    inputs -- hundreds within 1e-5 of zero): forward / loss parity on random trained-scale weights as everywhere else,
+    every layer's saved input x_l against the oracle's, and gradient parity of EVERY tensor for the same sub-gradient
+    choice at the kinks -- the oracle back-propagates through its two ReLUs with the HIP path's own (output > 0) masks
+    (``oracle.forward(relu_masks=...)``), and every element where that choice differs from the oracle's own sign must be
+    within 1e-5 of the kink in the oracle.  ``flag_sets``: wn_backward modes to check against the one oracle run (they
+    must not change the forward).  Returns a dict of the observed errors."""
+    import os
+    cfg = O.OracleConfig(*cfg_tuple)
+    params = O.random_params(cfg, seed, scale=scale)
+    x, h, t = O.synthetic_batch(cfg, B, T, seed + 1)
+    eng = WaveNetEngine(*cfg_tuple, device=device, library=lib)
+    load_state_into_flat(eng, params)
+    eng.flags = flag_sets[0]
+    xd, hd, td = x.to(device), h.to(device), t.to(device)
+    logits = eng.forward(xd, hd)
+    loss, dl = eng.loss(logits, td)
+    m_skip = (eng.saved(_lib.WS_RELU_SKIP) > 0).float().cpu()
+    m_post = (eng.saved(_lib.WS_RELU_POST1) > 0).float().cpu()
+    try:
+        navail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        navail = os.cpu_count() or 1
+    old_threads = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(threads, navail)))   # oneDNN convolutions of this size slow down beyond ~32 threads
+    try:
+        loss_ref, logits_ref, grads_ref, inter = O.train_step(cfg, params, None, x, h, t, relu_masks=(m_skip, m_post),
+                                                             return_intermediates=True)
+    finally:
+        torch.set_num_threads(old_threads)
+    out = {}
+    out["logits"] = float((logits.transpose(1, 2).cpu() - logits_ref).abs().max())
+    assert out["logits"] <= TOL_LOGITS, "logits max-abs err %g" % out["logits"]
+    out["loss"] = abs(float(loss.cpu()) - float(loss_ref))
+    assert out["loss"] <= TOL_LOSS, "loss err %g" % out["loss"]
+    # sub-gradient choices that differ from the oracle's own sign: only ever at the kink
+    rf = cfg.receptive_field
+    out["kink_flips"] = 0
+    for pre, m in ((inter["skip_sum"], m_skip), (inter["post1_pre"], m_post)):
+        differ = ((pre > 0).float() != m)
+        n = int(differ.sum())
+        out["kink_flips"] += n
+        if n:
+            worst = float(pre[differ].abs().max())
+            assert worst <= 1e-5, "ReLU mask differs from the oracle's at an element %g away from the kink" % worst
+    out["near_kink_1e-5"] = int(((inter["skip_sum"][:, :, rf:].abs() < 1e-5).sum() + (inter["post1_pre"][:, :, rf:].abs() < 1e-5).sum()))
+    # every layer's input x_l (x_0 = front conv output, x_l = residual output of layer l-1; wavenet.py:534-536)
+    X = eng.saved(_lib.WS_X)
+    worst_x = 0.0
+    for l in range(len(cfg.dilations)):
+        ref = inter["x0"] if l == 0 else inter["layer_out"][l - 1]
+        e = float((X[l].cpu() - ref).abs().max())
+        worst_x = max(worst_x, e)
+        assert e <= TOL_LOGITS, "layer %d input max-abs err %g" % (l, e)
+    out["layer_inputs"] = worst_x
+    del inter
+    out["grads"] = {}
+    for flags in flag_sets:
+        eng.flags = flags
+        grads = flat_to_state(eng, eng.backward(dl).cpu(), O.param_shapes(cfg))
+        worst, worst_k = 0.0, None
+        for k, ref in grads_ref.items():
+            if ref is None:
+                assert float(grads[k].abs().max()) == 0.0, k
+            else:
+                e = rel_to_max(grads[k], ref)
+                if e > worst:
+                    worst, worst_k = e, k
+                assert e <= TOL_GRAD, "%s: grad rel err %g (flags %d)" % (k, e, flags)
+        out["grads"][flags] = (worst, worst_k)
+    return out

@@ -75,8 +75,8 @@ def test_aux_gradient_partials_in_the_gate_kernel():
 
 
 def test_bench_self_check_of_the_aux_fused_mode():
-    """bench.py --aux-fused accepts the mode only after comparing its gradients with the default path on the
-    benchmark's own batch (bench.check_aux_fused); here on a small fused-kernel model under the emulator."""
+    """bench.check_aux_fused compares the gradients of the two aux-gradient modes (separate wn_aux_bwd launch vs the
+    partial sums inside the gate kernel, the default) on a batch; here on a small fused-kernel model under the emulator."""
     import bench
     from oracle import wavenet_oracle as O
     from pytorchwavenetvocoder_amd.nets import WaveNet
@@ -230,3 +230,86 @@ def test_fused_adam_skips_live_parameters_without_a_gradient_like_torch_adam():
         ropt.step()
     for k, v in model.state_dict().items():
         assert float((v - ref[k].detach()).abs().max()) <= 1e-6, k
+
+
+def test_op_level_entry_points():
+    """wn_op_front / wn_op_causal_conv (a subset of the GPU cases of tests/test_gpu_ops.py) on the host-compiled kernels."""
+    from tests import ops_common as OC
+    for case in OC.FRONT_CASES[1:3]:
+        OC.check_op_front(emu_library(), "cpu", *case)
+    for case in (OC.CONV_CASES[2], OC.CONV_CASES[3], (64, 64, 2, 512, 1, 150)):
+        OC.check_op_causal_conv(emu_library(), "cpu", *case)
+
+
+def test_saved_workspace_regions_and_given_relu_subgradient():
+    """wn_workspace_region (the views the full-size GPU parity test reads) on a small fused-kernel model: layer inputs,
+    gate halves and their product against the oracle's intermediates; and the oracle's gradients under the HIP path's
+    own ReLU masks equal its ordinary gradients when no element sits on a kink (the masks then ARE the signs)."""
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd import _lib
+    from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat
+    cfg_t = (64, 8, 64, 64, 3, 2, 2, 16)
+    cfg = O.OracleConfig(*cfg_t)
+    params, x, h, t, margin, sd = PC.pick_instance(cfg, 2, 96, 13, 0.1)
+    eng = WaveNetEngine(*cfg_t, device="cpu", library=emu_library())
+    load_state_into_flat(eng, params)
+    logits = eng.forward(x, h)
+    loss, dl = eng.loss(logits, t)
+    m1 = (eng.saved(_lib.WS_RELU_SKIP) > 0).float()
+    m2 = (eng.saved(_lib.WS_RELU_POST1) > 0).float()
+    l0, lg0, g0 = O.train_step(cfg, params, None, x, h, t)
+    l1, lg1, g1, inter = O.train_step(cfg, params, None, x, h, t, relu_masks=(m1, m2), return_intermediates=True)
+    assert torch.equal((inter["skip_sum"] > 0).float(), m1) and torch.equal((inter["post1_pre"] > 0).float(), m2)
+    assert torch.equal(lg0, lg1) and torch.equal(l0, l1)
+    for k in g0:
+        assert (g0[k] is None and g1[k] is None) or torch.equal(g0[k], g1[k]), k
+    X, S, G, Z = (eng.saved(k) for k in (_lib.WS_X, _lib.WS_SIGMOID, _lib.WS_TANH, _lib.WS_Z))
+    L = len(cfg.dilations)
+    assert tuple(X.shape) == (L, 2, 64, 96)
+    for l in range(L):
+        ref = inter["x0"] if l == 0 else inter["layer_out"][l - 1]
+        assert float((X[l] - ref).abs().max()) <= 1e-5, l
+    assert float((S * G - Z).abs().max()) <= 1e-6 and float(S.min()) >= 0.0 and float(G.abs().max()) <= 1.0
+    eng.backward(dl)
+    dP, dX, dSk = eng.saved(_lib.WS_DP), eng.saved(_lib.WS_DX), eng.saved(_lib.WS_DSKIP)
+    assert tuple(dP.shape) == (L, 2, 128, 96) and tuple(dX.shape) == (L, 2, 64, 96) and tuple(dSk.shape) == (2, 64, 96)
+    assert float(dSk[:, :, :cfg.receptive_field].abs().max()) == 0.0   # no loss before the receptive field
+    # and a flipped mask element changes the oracle's gradients (the override is live)
+    m1b = m1.clone()
+    m1b[0, 0, cfg.receptive_field] = 1.0 - m1b[0, 0, cfg.receptive_field]
+    _, _, g2 = O.train_step(cfg, params, None, x, h, t, relu_masks=(m1b, m2))
+    assert any(g2[k] is not None and not torch.equal(g2[k], g0[k]) for k in g0)
+
+
+def test_backward_chain_kernel_modes():
+    """The one-launch-per-layer backward chain (k_chain64s: dX_l and gate'_{l-1} fused, skip part of dZ pre-contracted;
+    the default) against the golden case and the oracle with and without the aux partial sums, kernel_size 1 and 2, a
+    half-full last tile and several sequences; the former gate' + dX launch pair (WN_FLAG_NO_CHAIN) stays covered, and
+    the two structures agree to round-off."""
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd import _lib
+    from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS, WaveNetEngine, load_state_into_flat
+    A, NC = _lib.FLAG_AUX_FUSED, _lib.FLAG_NO_CHAIN
+    assert DEFAULT_FLAGS == A      # chain + aux partials is what every default-flag test runs
+    for flags in (0, A, NC, A | NC):
+        PC.check_golden_case(GoldenCase("r64_k2_up"), emu_library(), "cpu", flags=flags)
+    PC.check_golden_case(GoldenCase("r64_k2_up"), emu_library(), "cpu", flags=A, layers_per_bucket=1)
+    PC.check_golden_case(GoldenCase("r64_k3_up"), emu_library(), "cpu", flags=A)          # K = 3: falls back to the pair
+    PC.run_oracle_vs_engine((64, 6, 64, 32, 3, 1, 1, 16), 2, 48, 41, emu_library(), "cpu", flags=A, scale=0.2)   # K = 1
+    PC.run_oracle_vs_engine((64, 6, 64, 32, 3, 1, 1, 16), 2, 48, 41, emu_library(), "cpu", flags=0, scale=0.2)
+    PC.run_oracle_vs_engine((64, 6, 64, 32, 2, 2, 2, 16), 3, 80, 42, emu_library(), "cpu", flags=A, scale=0.2)   # T % 32 == 16
+    PC.run_oracle_vs_engine((64, 6, 64, 64, 3, 2, 2, 0), 1, 70, 43, emu_library(), "cpu", flags=A, scale=0.2)    # no upsampling, ragged T
+    PC.run_oracle_vs_engine((64, 6, 64, 32, 1, 1, 2, 16), 1, 32, 44, emu_library(), "cpu", flags=A, scale=0.2)   # a single layer
+    cfg_t = (64, 6, 64, 32, 3, 2, 2, 16)
+    cfg = O.OracleConfig(*cfg_t)
+    params, x, h, t, margin, sd = PC.pick_instance(cfg, 2, 96, 45, 0.2)
+    res = []
+    for flags in (A, A | NC, A):
+        eng = WaveNetEngine(*cfg_t, device="cpu", library=emu_library())
+        eng.flags = flags
+        load_state_into_flat(eng, params)
+        logits = eng.forward(x, h)
+        loss, dl = eng.loss(logits, t)
+        res.append(eng.backward(dl, layers_per_bucket=2).clone())
+    assert torch.equal(res[0], res[2])
+    assert float((res[0] - res[1]).abs().max()) <= 1e-5 * float(res[1].abs().max())

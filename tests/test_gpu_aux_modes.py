@@ -1,0 +1,50 @@
+# -*- coding: utf-8 -*-
+"""GPU parity of the two aux-gradient modes of wn_backward: WN_FLAG_AUX_FUSED (partial sums inside the gate kernel; the
+engine's default since round 2, so every default-mode test exercises it) and the separate wn_aux_bwd launch (flags
+without it) -- each against the oracle and the golden case, and against each other at round-off."""
+import pytest
+import torch
+
+from tests import parity_common as PC
+from tests.golden_util import GoldenCase
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _lib():
+    from pytorchwavenetvocoder_amd import _lib as L
+    lib = L.load_library()
+    assert not lib.is_emulator
+    return lib
+
+
+def test_aux_gradient_modes_agree_and_match_the_oracle():
+    """WN_FLAG_AUX_FUSED (the gate kernel leaves the partial sums of the aux-path gradients, dP is not re-read) and the
+    separate-launch mode: config-2 model on an oracle-sized window against the oracle, against each other at round-off;
+    run to run bitwise."""
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd import _lib as L
+    from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat
+    cfg_t = (256, 80, 64, 256, 10, 3, 2, 80)
+    from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS
+    assert DEFAULT_FLAGS & L.FLAG_AUX_FUSED
+    # ... each with the one-launch-per-layer backward chain (default) and with the former gate' + dX launch pair
+    for flags in (L.FLAG_AUX_FUSED, 0, L.FLAG_AUX_FUSED | L.FLAG_NO_CHAIN, L.FLAG_NO_CHAIN):
+        e, gerr = PC.run_oracle_vs_engine(cfg_t, 1, 3120, 21, _lib(), DEV, scale=0.05, flags=flags)
+        print("aux mode %d: logits err %.3g, worst grad rel err %.3g" % (flags, e, gerr))
+        PC.check_golden_case(GoldenCase("r64_k2_up"), _lib(), DEV, flags=flags)
+    cfg = O.OracleConfig(*cfg_t)
+    params, x, h, t, margin, sd = PC.pick_instance(cfg, 2, 3120 + 80, 41, 0.05)
+    x, h, t = x.to(DEV), h.to(DEV), t.to(DEV)
+    res = []
+    for flags in (L.FLAG_NO_CHAIN, L.FLAG_AUX_FUSED, L.FLAG_AUX_FUSED):
+        eng = WaveNetEngine(*cfg_t, device=DEV, library=_lib())
+        eng.flags = flags
+        load_state_into_flat(eng, params)
+        logits = eng.forward(x, h)
+        loss, dl = eng.loss(logits, t)
+        res.append(eng.backward(dl, layers_per_bucket=10).clone())
+    assert torch.equal(res[1], res[2])
+    assert float((res[1] - res[0]).abs().max()) <= 1e-5 * float(res[0].abs().max())

@@ -1,0 +1,77 @@
+# -*- coding: utf-8 -*-
+"""Oracle parity at the sizes the benchmark and the recipes actually run (GPU, through the C ABI):
+
+  * BASELINE configs[1] at FULL size -- the 30-layer 64/256 model, B = 8, T = 23040 (reference loop train.py:527-540 on
+    wavenet.py:212-241): logits, loss, every layer's input and EVERY gradient tensor against the live oracle on the same
+    tensors, in the default launch mode (one-launch-per-layer backward chain + aux partial sums), with the aux-gradient
+    mode toggled, and with the former gate' + dX launch pair.  5 760 tiles on 1 920 waves: every
+    persistent wave walks three tiles (cross-tile prefetch, XCD tile split, balanced grid).
+  * the recipe-size model (n_resch = 512, egs/arctic/sd/run.sh:46-52) and the configs[3] geometry (kernel_size 3,
+    upsampling_factor 256), formerly uncollected probes.
+"""
+import pytest
+import torch
+
+from tests import parity_common as PC
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _lib():
+    from pytorchwavenetvocoder_amd import _lib as L
+    lib = L.load_library()
+    assert not lib.is_emulator
+    return lib
+
+
+def test_cfg2_full_size_vs_oracle():
+    from pytorchwavenetvocoder_amd import _lib as L
+    from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS
+    cfg_t = (256, 80, 64, 256, 10, 3, 2, 80)
+    res = PC.run_fullsize_vs_oracle(cfg_t, 8, 23040, 101, _lib(), DEV,
+                                    flag_sets=[DEFAULT_FLAGS, DEFAULT_FLAGS ^ L.FLAG_AUX_FUSED, DEFAULT_FLAGS | L.FLAG_NO_CHAIN],
+                                    scale=0.05)
+    print("cfg2 FULL SIZE (B=8, T=23040) vs oracle: logits %.3g, loss %.3g, layer inputs %.3g, grads %s; "
+          "%d ReLU inputs within 1e-5 of the kink, %d sub-gradient choices differing from the oracle's sign"
+          % (res["logits"], res["loss"], res["layer_inputs"], res["grads"], res["near_kink_1e-5"], res["kink_flips"]))
+
+
+def test_cfg2_full_size_bucketed_backward_matches_single_group():
+    """The N > 1 launch structure (weight gradients flushed per bucket of 10 layers, distributed.py) against the
+    single-group structure on the full-size batch: same gradients to round-off (the split-K plans differ)."""
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat
+    cfg_t = (256, 80, 64, 256, 10, 3, 2, 80)
+    cfg = O.OracleConfig(*cfg_t)
+    params = O.random_params(cfg, 102, scale=0.05)
+    x, h, t = O.synthetic_batch(cfg, 8, 23040, 103)
+    eng = WaveNetEngine(*cfg_t, device=DEV, library=_lib())
+    load_state_into_flat(eng, params)
+    logits = eng.forward(x.to(DEV), h.to(DEV))
+    loss, dl = eng.loss(logits, t.to(DEV))
+    g0 = eng.backward(dl).clone()
+    g10 = eng.backward(dl, layers_per_bucket=10).clone()
+    for (lo, hi) in eng.bucket_ranges(10):
+        a, b = g0[lo:hi], g10[lo:hi]
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
+
+
+def test_recipe_size_model_vs_oracle():
+    """n_resch = 512 / n_skipch = 256 (the recipes' default size): forward, loss and all gradients on a window just past
+    the receptive field (the oracle needs ~10 s at this width)."""
+    cfg_t = (256, 80, 512, 256, 10, 3, 2, 80)
+    e, g = PC.run_oracle_vs_engine(cfg_t, 1, 3200, 5, _lib(), DEV, scale=0.02)
+    print("recipe-size model (512/256), T=3200: logits err %.3g, worst grad rel err %.3g" % (e, g))
+
+
+def test_config4_geometry_vs_oracle():
+    """BASELINE configs[3] geometry with the softmax head the reference has: kernel_size 3, upsampling_factor 256,
+    receptive field 6139."""
+    from oracle import wavenet_oracle as O
+    cfg_t = (256, 80, 64, 256, 10, 3, 3, 256)
+    assert O.OracleConfig(*cfg_t).receptive_field == 6139
+    e, g = PC.run_oracle_vs_engine(cfg_t, 1, 6400, 5, _lib(), DEV, scale=0.05)
+    print("configs[3] geometry (K=3, U=256), T=6400: logits err %.3g, worst grad rel err %.3g" % (e, g))
+    e, g = PC.run_oracle_vs_engine(cfg_t, 2, 6400 + 256, 6, _lib(), DEV, scale=0.05)

@@ -1,0 +1,64 @@
+# -*- coding: utf-8 -*-
+"""Op-level entry points of the C ABI and the stand-alone layer modules on the GPU against the oracle's restatement of
+the reference layers: wn_op_front (OneHot + front CausalConv1d as a gather, wavenet.py:78-92,513-516), wn_op_causal_conv
+/ ``CausalConv1d.forward`` (wavenet.py:95-121) and ``UpSampling.forward`` (wavenet.py:124-154, golden vector)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import ops_common as OC
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _lib():
+    from pytorchwavenetvocoder_amd import _lib as L
+    lib = L.load_library()
+    assert not lib.is_emulator
+    return lib
+
+
+@pytest.mark.parametrize("Q,R,K,B,T", OC.FRONT_CASES)
+def test_op_front_is_onehot_plus_causal_conv(Q, R, K, B, T):
+    OC.check_op_front(_lib(), DEV, Q, R, K, B, T)
+
+
+@pytest.mark.parametrize("Cin,Cout,K,d,B,T", OC.CONV_CASES)
+def test_causal_conv_op_and_module(Cin, Cout, K, d, B, T):
+    """y[t] = b + sum_k W[:,:,k] x[t - (K-1-k) d], zero history -- also with a dilation larger than the sequence."""
+    from pytorchwavenetvocoder_amd.nets import CausalConv1d
+    w, b, x, ref = OC.check_op_causal_conv(_lib(), DEV, Cin, Cout, K, d, B, T)
+    m = CausalConv1d(Cin, Cout, K, d)
+    with torch.no_grad():
+        m.conv.weight.copy_(w)
+        m.conv.bias.copy_(b)
+    m.to(DEV)
+    ym = m(x.to(DEV))
+    assert tuple(ym.shape) == (B, Cout, T) and float((ym.cpu() - ref).abs().max()) <= 1e-5
+    with pytest.raises(Exception):
+        m(x)        # CPU tensor: no fallback
+
+
+def test_upsampling_module_on_the_gpu_vs_reference_vector():
+    from pytorchwavenetvocoder_amd.nets import UpSampling, initialize
+    z = np.load(os.path.join(GOLDEN, "upsampling.npz"))
+    up = UpSampling(z["w"].shape[-1])
+    with torch.no_grad():
+        up.conv.weight.copy_(torch.from_numpy(z["w"]))
+        up.conv.bias.copy_(torch.from_numpy(z["b"]))
+    up.to(DEV)
+    y = up(torch.from_numpy(z["h"]).to(DEV))
+    assert float((y.cpu() - torch.from_numpy(z["y"])).abs().max()) <= 1e-6
+    # reference test/test_upsampling.py:13-20
+    aux = torch.randn(1, 28, 1000)
+    conv = UpSampling(10)
+    conv.apply(initialize)
+    conv.to(DEV)
+    out = conv(aux.to(DEV)).cpu()
+    assert out.shape[-1] == aux.shape[-1] * 10
+    assert torch.equal(out, aux.repeat_interleave(10, dim=2))

@@ -1,0 +1,131 @@
+# -*- coding: utf-8 -*-
+"""The reference's own unit tests (test/test_wavenet.py:31-253, test/test_upsampling.py:13-20), restated against this
+package through the reference's import path (``wavenet_vocoder.nets``, the alias package at the repository root) with the
+tensors on the GPU -- the module has no CPU path.  Same models, same call sequences, same assertions: output shapes of
+the four forward variants, every generator runs in sampling mode, and argmax generation agrees between ``generate``
+(window forwards), ``fast_generate`` (queues) and ``batch_fast_generate`` (batched queues, also with different lengths).
+
+Argmax equality across three different kernels is only meaningful where the two best logits are not tied to fp32
+round-off (the reference compares one implementation with itself on one device): positions are compared up to the first
+step whose top-2 margin is below 1e-4, and that prefix must cover most of the utterance."""
+import numpy as np
+import pytest
+import torch
+
+from wavenet_vocoder.nets import WaveNet, encode_mu_law, initialize  # the reference's import line (test_wavenet.py:11-13)
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _sine_batch(seq_size=100, mu=256):
+    """test_wavenet.py:22-29: two close sine tones, mu-law encoded."""
+    t = np.linspace(0, 1, 16000)
+    data = (np.sin(2 * np.pi * 220 * t) + np.sin(2 * np.pi * 224 * t)) / 2
+    return torch.from_numpy(encode_mu_law(data, mu)[:seq_size])
+
+
+def _net(*args):
+    net = WaveNet(*args)
+    net.apply(initialize)
+    net.eval()
+    return net.to(DEV)
+
+
+def test_forward():
+    """test_wavenet.py:31-71 (its "kernel size = 3" no-upsampling block constructs K = 2 again; K = 3 is run here too)."""
+    x = _sine_batch(100).view(1, -1).to(DEV)
+    for args, hlen in [((256, 28, 32, 128, 10, 1, 2), 100), ((256, 28, 32, 128, 10, 1, 3), 100),
+                       ((256, 28, 32, 128, 10, 1, 2, 10), 10), ((256, 28, 32, 128, 10, 1, 3, 10), 10)]:
+        h = torch.rand(1, 28, hlen).float().to(DEV)
+        y = _net(*args)(x, h)[0]
+        assert y.size(0) == x.size(1)
+        assert y.size(1) == 256
+        assert bool(torch.isfinite(y).all())
+
+
+def test_generate():
+    """test_wavenet.py:74-90: all three generators run in sampling mode and return n_samples tokens."""
+    rs = np.random.RandomState(0)
+    batch = 2
+    x = rs.randint(0, 256, size=(batch, 1))
+    h = rs.randn(batch, 28, 10)
+    length = h.shape[-1] - 1
+    with torch.no_grad():
+        net = _net(256, 28, 4, 4, 10, 3, 2)
+        for x_, h_ in zip(x, h):
+            bx = torch.from_numpy(np.expand_dims(x_, 0)).long().to(DEV)
+            bh = torch.from_numpy(np.expand_dims(h_, 0)).float().to(DEV)
+            a = net.generate(bx, bh, length, 1, "sampling")
+            b = net.fast_generate(bx, bh, length, 1, "sampling")
+            assert a.shape == (length,) and b.shape == (length,)
+            assert a.min() >= 0 and a.max() < 256 and b.min() >= 0 and b.max() < 256
+        outs = net.batch_fast_generate(torch.from_numpy(x).long().to(DEV), torch.from_numpy(h).float().to(DEV),
+                                       [length] * batch, 1, "sampling")
+        assert [o.shape for o in outs] == [(length,)] * batch
+
+
+def _safe_prefix(net, bx, bh, length):
+    """Number of leading generated samples whose argmax is not a near-tie (top-2 margin >= 1e-4)."""
+    _, lg = net.engine.decode(bx, bh, [length], mode="argmax", return_logits=True)
+    top2 = lg[0].topk(2, dim=1).values
+    tied = ((top2[:, 0] - top2[:, 1]) < 1e-4).nonzero()
+    return length if tied.numel() == 0 else int(tied[0])
+
+
+def _assert_three_generators_agree(net, x, h, length):
+    bx_all = torch.from_numpy(x).long().to(DEV)
+    bh_all = torch.from_numpy(h).float().to(DEV)
+    fast = []
+    for i in range(x.shape[0]):
+        bx, bh = bx_all[i:i + 1], bh_all[i:i + 1]
+        n_ok = _safe_prefix(net, bx, bh, length)
+        assert n_ok >= (3 * length) // 4, "argmax near-tie after %d of %d samples: pick another seed" % (n_ok, length)
+        gen1 = net.generate(bx, bh, length, 1, "argmax")
+        gen2 = net.fast_generate(bx, bh, length, 1, "argmax")
+        np.testing.assert_array_equal(gen1[:n_ok], gen2[:n_ok])
+        fast.append((gen2, n_ok))
+    gen3 = net.batch_fast_generate(bx_all, bh_all, [length] * x.shape[0], 1, "argmax")
+    for (g2, n_ok), g3 in zip(fast, gen3):
+        np.testing.assert_array_equal(g3[:n_ok], g2[:n_ok])
+
+
+def test_assert_fast_generation():
+    """test_wavenet.py:93-221: generate == fast_generate == batch_fast_generate in argmax mode, without and with the
+    upsampling layer, kernel sizes 2 and 3."""
+    rs = np.random.RandomState(1)
+    batch = 2
+    with torch.no_grad():
+        x = rs.randint(0, 256, size=(batch, 1))
+        h = rs.randn(batch, 28, 32)
+        length = h.shape[-1] - 1
+        _assert_three_generators_agree(_net(256, 28, 4, 4, 10, 3, 2), x, h, length)
+        _assert_three_generators_agree(_net(256, 28, 4, 4, 10, 3, 3), x, h, length)
+        U = 10
+        x = rs.randint(0, 256, size=(batch, 1))
+        h = rs.randn(batch, 28, 3)
+        length = h.shape[-1] * U - 1
+        _assert_three_generators_agree(_net(256, 28, 4, 4, 10, 3, 2, U), x, h, length)
+        _assert_three_generators_agree(_net(256, 28, 4, 4, 10, 3, 3, U), x, h, length)
+
+
+def test_assert_different_length_batch_generation():
+    """test_wavenet.py:224-253: a batch with different lengths returns, shortest first, what the single-utterance calls do."""
+    rs = np.random.RandomState(2)
+    batch, length = 4, 32
+    x = rs.randint(0, 256, size=(batch, 1))
+    h = rs.randn(batch, 28, length)
+    length_list = sorted(list(rs.randint(length // 2, length - 1, batch)))
+    with torch.no_grad():
+        net = _net(256, 28, 4, 4, 10, 3, 2)
+        singles = []
+        for x_, h_, n in zip(x, h, length_list):
+            bx = torch.from_numpy(np.expand_dims(x_, 0)).long().to(DEV)
+            bh = torch.from_numpy(np.expand_dims(h_, 0)).float().to(DEV)
+            singles.append((net.fast_generate(bx, bh, int(n), 1, "argmax"), _safe_prefix(net, bx, bh, int(n))))
+        outs = net.batch_fast_generate(torch.from_numpy(x).long().to(DEV), torch.from_numpy(h).float().to(DEV),
+                                       [int(n) for n in length_list], 1, "argmax")
+        for (g1, n_ok), g2 in zip(singles, outs):
+            assert g1.shape == g2.shape
+            np.testing.assert_array_equal(g1[:n_ok], g2[:n_ok])

@@ -1,0 +1,48 @@
+#!/bin/bash
+# One GPU visit: parity tests, smoke, bench (A/B of the bucket structure), rocprofv3 kernel stats of the same command, PMC
+# passes, the recipe's stage 4/5, the 2-rank control flow on one GPU.  Each part has its own timeout and log under gpurun_out/.
+#   gpurun --timeout 1500 -- 'bash tools/gpu_visit.sh [parts...]'      parts: tests smoke bench lpb rocprof pmc recipe tworank
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+cd "$ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
+OUT="$ROOT/gpurun_out"
+PARTS="${*:-tests smoke bench lpb rocprof pmc recipe tworank}"
+date +%s > $OUT/t0
+has() { echo " $PARTS " | grep -q " $1 "; }
+if has tests; then
+  timeout 900 python -m pytest tests -x -q -m gpu -s > $OUT/pytest_gpu_full.txt 2>&1; echo "pytest(full) rc=$?"; tail -4 $OUT/pytest_gpu_full.txt
+  grep -h "vs oracle\|err \|FULL SIZE" $OUT/pytest_gpu_full.txt | head -20
+fi
+if has smoke; then
+  timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1; echo "smoke rc=$?"
+fi
+if has bench; then
+  timeout 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cut -c1-400 $OUT/bench.json
+fi
+if has lpb; then
+  for lpb in 30 10 30 10; do
+    timeout 200 python bench.py --layers-per-bucket $lpb --no-cpu-baseline --no-decode --profile-steps 0 > $OUT/bench_lpb$lpb.json 2>> $OUT/bench.err
+    python - <<P
+import json
+d = json.load(open("$OUT/bench_lpb$lpb.json"))
+print("lpb $lpb: ms/step median %.3f min %.3f max %.3f" % (d["ms_per_step"], d["ms_per_step_min"], d["ms_per_step_max"]))
+P
+  done | tee $OUT/lpb_ab.txt
+fi
+if has rocprof; then
+  rm -rf $OUT/prof_stats
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python $ROOT/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-decode > $OUT/bench_rocprof.json 2> $OUT/rocprof.err); echo "rocprof rc=$?"
+  find $OUT/prof_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/rocprofv3_kernel_stats.csv
+  find $OUT/prof_stats -name "*kernel_trace.csv" -delete
+  head -12 $OUT/rocprofv3_kernel_stats.csv
+fi
+if has pmc; then
+  bash tools/pmc_traffic.sh
+fi
+if has recipe; then
+  timeout 300 bash tools/recipe_stage45.sh run > $OUT/recipe_stage45.txt 2>&1; echo "recipe rc=$?"; tail -3 $OUT/recipe_stage45.txt
+fi
+if has tworank; then
+  WN_BENCH_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 2 --repeats 2 --no-cpu-baseline --no-decode > $OUT/bench_2rank_gloo.json 2> $OUT/bench_2rank_gloo.err; echo "2-rank gloo rc=$?"; cut -c1-300 $OUT/bench_2rank_gloo.json
+fi
+lscpu | grep -E "Model name|^CPU\(s\)|Socket" > $OUT/host.txt
+echo "elapsed $(( $(date +%s) - $(cat $OUT/t0) )) s"

@@ -2,7 +2,7 @@
 # -*- coding: utf-8 -*-
 """HBM traffic per kernel launch from two rocprofv3 counter passes (tools/pmc_traffic.sh):
 
-    python tools/pmc_traffic.py <dir of the --pmc FETCH_SIZE pass> <dir of the --pmc WRITE_SIZE pass> <steps> > pmc_traffic.json
+    python tools/pmc_traffic.py <dir of the --pmc FETCH_SIZE pass> <dir of the --pmc WRITE_SIZE pass> <steps> [bench log] > pmc_traffic.json
 
 bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KB; on gfx950 FETCH_SIZE tallies the 128-byte fabric
 requests at 64 bytes (MI355X_MICROARCH.md, section HBM) -- calibrated on this code's own dword buffer accesses: the
@@ -16,8 +16,23 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pmc_summary import summarize  # noqa: E402
 
-TAGS = {"fused_bwd_gate": "void k_conv64s<0>(ConvArgs)", "fused_resblock_fwd": "void k_resblock_fwd_s<2>(FwdArgs)",
-        "fused_bwd_dx": "void k_conv64s<1>(ConvArgs)"}
+# bench.py tag -> kernel symbol(s) that implement it (the first one present in the trace is reported)
+TAGS = {"fused_bwd_gate": ["void k_conv64s<2>(ConvArgs)", "void k_conv64s<0>(ConvArgs)"],
+        "fused_resblock_fwd": ["void k_resblock_fwd_s<2>(FwdArgs)"],
+        "fused_bwd_dx": ["void k_conv64s<1>(ConvArgs)"],
+        "fused_bwd_chain": ["void k_chain64s<0>(ChainArgs)", "void k_chain64s<1>(ChainArgs)"]}
+
+
+def engine_flags_of(log_path):
+    """The launch mode of the profiled run: bench.py prints its JSON line into the log; `config.engine_flags`."""
+    try:
+        for line in open(log_path):
+            line = line.strip()
+            if line.startswith("{") and '"metric"' in line:
+                return int(json.loads(line)["config"]["engine_flags"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def main():
@@ -31,12 +46,14 @@ def main():
         per[k[:80]] = b
         total += b * n
     out = {}
-    for tag, name in TAGS.items():
-        if name in fetch or name in write:
+    for tag, names in TAGS.items():
+        name = next((n for n in names if n in fetch or n in write), None)
+        if name is not None:
             out[tag] = {"kernel": name, "fetch_size_kb": fetch.get(name, {}).get("FETCH_SIZE"),
                         "write_size_kb": write.get(name, {}).get("WRITE_SIZE"),
                         "hbm_bytes_per_launch": (2.0 * fetch.get(name, {}).get("FETCH_SIZE", 0.0) +
                                                  write.get(name, {}).get("WRITE_SIZE", 0.0)) * 1024.0}
+    out["_engine_flags"] = engine_flags_of(sys.argv[4]) if len(sys.argv) > 4 else None
     out["_step_total_bytes"] = total / steps
     out["_per_kernel_bytes_per_launch"] = per
     out["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/pmc_traffic.sh); bytes = "
