@@ -373,7 +373,7 @@ def _worker(rank, world, args, port):
     else:
         iterations = 0
     model.to(device)
-    reducer = GradientReducer(model, layers_per_bucket=10)
+    reducer = GradientReducer(model)
     if world > 1:
         dist.broadcast(model.engine.flat_params, src=0)
 

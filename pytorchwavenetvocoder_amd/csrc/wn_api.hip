@@ -384,6 +384,7 @@ struct Ws {
     // scratch
     long P, dO2, dSk, dZ, dXall, dG, dw_partial, dc, tmpS, partial, rs_partial, red_scratch, loss_partial;
     long dGp, qp;  // aux-gradient partials of the gate kernel (WN_FLAG_AUX_FUSED); 0 floats when the mode cannot apply
+    long img_fwd, img_taps, img_res, img_floats;  // pre-split LDS weight images of the fused split kernels (0 floats: not applicable)
     long wskipT_f, dZs;  // chain mode (wn_fused_chain_supported): skip weights as [s][l*R + i], dZs = Wskip^T dSkip (B, L*R, T)
     long dZs_floats;
     long red_scratch_floats;
@@ -436,6 +437,13 @@ static int make_ws(const Dims& d, int B, int T, Ws* w) {
         const bool auxf = wn_fused_supported(d.R, d.K, d.S) && d.U >= 16 && d.U % 16 == 0;
         CARVE(dGp, auxf ? (long)d.L * B * 2 * d.R * (T / 16) : 0);
         CARVE(qp, auxf ? (long)d.L * B * T : 0);
+    }
+    {
+        const bool img = wn_fused_supported(d.R, d.K, d.S) && wn_fused_image_floats(d.K, d.L, 0) > 0;
+        w->img_floats = img ? wn_fused_image_floats(d.K, d.L, 0) : 0;
+        CARVE(img_fwd, w->img_floats);
+        CARVE(img_taps, img ? wn_fused_image_floats(d.K, d.L, 1) : 0);
+        CARVE(img_res, img ? wn_fused_image_floats(d.K, d.L, 2) : 0);
     }
     {
         const bool chain = wn_fused_chain_supported(d.R, d.K, d.S) && d.L > 1;
@@ -549,6 +557,17 @@ static int make_ctx(Ctx* c, const WnConfig* cfg, int B, int T, void* ws, size_t 
     return 0;
 }
 
+// tuning knob (A/B on hardware): WN_WEIGHT_IMAGES=0 -> every workgroup of a fused split kernel builds its LDS weight image
+// itself again instead of copying the image packed once per step
+static bool use_images() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("WN_WEIGHT_IMAGES");
+        v = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return v != 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // weight packing (once per forward; weights change every optimizer step)
 // ------------------------------------------------------------------------------------------
@@ -629,6 +648,9 @@ static int pack_weights(const Ctx& c, const float* params) {
     cp.n1 = d.S; cp.n2 = d.Qo; cp.s1 = 1; cp.s2 = d.S; cp.d1 = d.Qo; cp.d2 = 1;
     WN_TRY(wn_copy4_batch_add(&jobs, ws + w.w2_f, params + y.post2_w, &cp));
     WN_TRY(wn_copy4_batch(&jobs, c.st));
+    if (c.fused && c.split_bf16 && w.img_floats > 0 && use_images())   // LDS images of the split kernels: one launch for all layers
+        WN_TRY(wn_fused_pack_images(ws + w.wd_f, ws + w.wres_f, ws + w.wd_b, params, lb0 + y.o_res_w, lstep, ws + w.img_fwd,
+                                    ws + w.img_taps, ws + w.img_res, d.K, d.L, c.st));
     // cvec / rowsum_aux / bskip / one
     WnCvecArgs ca;
     ca.params = params;
@@ -708,7 +730,8 @@ static int forward_stack(const Ctx& c, const float* params, const int64_t* x, co
         if (c.fused) {
             WN_TRY(wn_fused_resblock_fwd(ws + w.wd_f + (long)l * d.K * d.R * 2 * d.R, ws + w.wres_f + (long)l * d.R * d.R,
                                          ws + w.cvec + (long)l * 2 * d.R, params + lb + y.o_res_b, Xl, Gl, g_bstride, upw, Xn,
-                                         Sl, Gtl, Zl, B, T, d.K, dil, Ue, F, c.split_bf16 ? 1 : 0, c.st));
+                                         Sl, Gtl, Zl, B, T, d.K, dil, Ue, F, c.split_bf16 ? 1 : 0,
+                                         (w.img_floats > 0 && use_images()) ? ws + w.img_fwd + (long)l * (w.img_floats / d.L) : nullptr, c.st));
             if (side && (l + 1) % chunk == 0 && l + 1 < d.L) {
                 WN_TRY(side_link(side, c.st, cs->st));  // z of layers [*skip_done, l] is enqueued
                 WN_TRY(skip_sum(*cs, *skip_done, l + 1, false));
@@ -1095,7 +1118,10 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
                                           ws + w.Gt + (long)(l - 1) * BRT, ws + w.P + (long)(l - 1) * P_L,
                                           ws + w.G + (long)(l - 1) * 2 * d.R * F, g_bstride, upw, Ue, F,
                                           aux_fused ? ws + w.dGp + (long)(l - 1) * B * 2 * d.R * (T / 16) : nullptr,
-                                          aux_fused ? ws + w.qp + (long)(l - 1) * B * T : nullptr, B, T, d.K, dil, c.st));
+                                          aux_fused ? ws + w.qp + (long)(l - 1) * B * T : nullptr, B, T, d.K, dil,
+                                          (w.img_floats > 0 && use_images()) ? ws + w.img_taps + (long)l * (wn_fused_image_floats(d.K, d.L, 1) / d.L) : nullptr,
+                                          (w.img_floats > 0 && use_images()) ? ws + w.img_res + (long)(l - 1) * (wn_fused_image_floats(d.K, d.L, 2) / d.L) : nullptr,
+                                          c.st));
             } else {      // tail: dX_0
                 WN_TRY(wn_fused_bwd_dx(ws + w.wd_b, dP, dXn, dXl, B, T, d.K, dil, 1, c.st));
             }

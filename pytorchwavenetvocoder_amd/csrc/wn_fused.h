@@ -13,7 +13,9 @@ int wn_fused_supported(int R, int K, int S);
 // wres_f: [i*R + o]               packed (transposed) res_1x1 weight
 int wn_fused_resblock_fwd(const float* wd_f, const float* wres_f, const float* cvec, const float* res_bias,
                           const float* X, const float* G, long g_bstride, const float* upw, float* Xnext, float* S,
-                          float* Gt, float* Z, int B, int T, int K, int dilation, int U, int F, int split, wn_stream_t st);
+                          float* Gt, float* Z, int B, int T, int K, int dilation, int U, int F, int split, const float* wimg,
+                          wn_stream_t st);
+// wimg (split kernels, K <= 2; nullable): this layer's pre-built LDS weight image, see wn_fused_pack_images
 
 // dZ = Wskip^T dSkip (+ Wres^T dXn) ; dP = [dZ*g*s*(1-s) ; dZ*s*(1-g^2)]
 // wskip : natural skip_1x1 weight [S][R] ; wres : natural res_1x1 weight [R][R] ; dXn may be NULL.
@@ -45,4 +47,15 @@ int wn_fused_bwd_dx(const float* wd_b, const float* dP, const float* dXn, float*
 int wn_fused_chain_supported(int R, int K, int S);
 int wn_fused_bwd_chain(const float* wd_b, const float* dP, const float* dXn, float* dX, const float* wres_prev, const float* dZs,
                        long zs_bstride, const float* S, const float* Gt, float* dP_prev, const float* G, long g_bstride,
-                       const float* upw, int U, int F, float* dGp, float* qp, int B, int T, int K, int dilation, wn_stream_t st);
+                       const float* upw, int U, int F, float* dGp, float* qp, int B, int T, int K, int dilation,
+                       const float* img_taps, const float* img_res, wn_stream_t st);
+
+// LDS weight images of the split kernels, built ONCE per step for all L layers instead of once per workgroup per launch:
+//   which = 0  forward block of layer l (taps + res 1x1)      from wd_f, wres_f
+//           1  tap weights of the chain kernel's dX half       from wd_b
+//           2  Wres_l^T of the chain kernel's gate half        from the natural res_1x1 weight in the flat parameter buffer
+// wn_fused_image_floats: floats of region `which` for L layers (0 when K is outside the split kernels' range).
+// (img_taps of layer l and img_res of layer l-1 belong to the chain launch of layer l.)
+long wn_fused_image_floats(int K, int L, int which);
+int wn_fused_pack_images(const float* wd_f, const float* wres_f, const float* wd_b, const float* params, long res_off,
+                         long res_lstride, float* img_fwd, float* img_taps, float* img_res, int K, int L, wn_stream_t st);

@@ -143,6 +143,7 @@ static __device__ __forceinline__ void stage_copy(float* dst, const float* __res
 
 // ---------------------------------------------------------------------------------------------
 struct FwdArgs {
+    const float* wimg;   // split kernels: pre-built LDS weight image of this layer (wn_fused_pack_images) or NULL
     const float* wd_f;
     const float* wres_f;
     const float* cvec;
@@ -291,11 +292,13 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
         const float upw_j = a.upw[tc - fr * a.U];
         const wn_rsrc_t Gr = wn_make_buf(a.G + (long)b * a.g_bstride, (unsigned)(128 * F4));
         const int vg = (4 * hi * a.F + fr) * 4;
-        float ga[2][16], gg[2][16];
+        // one register set for both 32-channel halves: an element of the second half is requested right after the
+        // element of the first half in the same register has been consumed (64 registers less across the gate phase)
+        float ga[16], gg[16];
         WN_UNROLL
         for (int r = 0; r < 16; ++r) {
-            ga[0][r] = wn_buf_load(Gr, vg, mfma32_row(r, 0) * F4);
-            gg[0][r] = wn_buf_load(Gr, vg, (mfma32_row(r, 0) + 64) * F4);
+            ga[r] = wn_buf_load(Gr, vg, mfma32_row(r, 0) * F4);
+            gg[r] = wn_buf_load(Gr, vg, (mfma32_row(r, 0) + 64) * F4);
         }
         WN_SCHED_BARRIER();
         // current tap; xc is also the residual input, already in D layout
@@ -337,11 +340,6 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
         // 96 S/Gt/Z stores could only be waited for together with those stores' acknowledgements.
         const int next_v = tile_v + step;
         if (K > 1 && next_v < tile_end) issue_hist(next_v);
-        WN_UNROLL
-        for (int r = 0; r < 16; ++r) {
-            ga[1][r] = wn_buf_load(Gr, vg, (32 + mfma32_row(r, 0)) * F4);
-            gg[1][r] = wn_buf_load(Gr, vg, (96 + mfma32_row(r, 0)) * F4);
-        }
         // gate (reference wavenet.py:529-532): P = conv + w[j]*G[row][f] + c[row]; saved for backward
         const wn_rsrc_t Sr = wn_make_buf(a.S + (long)b * 64 * T, slab);
         const wn_rsrc_t Gtr = wn_make_buf(a.Gt + (long)b * 64 * T, slab);
@@ -353,8 +351,12 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
             WN_UNROLL
             for (int r = 0; r < 16; ++r) {
                 const int row0 = 32 * q + mfma32_row(r, 0);  // + 4*hi is in the per-lane offsets
-                const float pa = acc[q][r] + (upw_j * ga[q][r] + cvl[row0]);
-                const float pg = acc[q + 2][r] + (upw_j * gg[q][r] + cvl[row0 + 64]);
+                const float pa = acc[q][r] + (upw_j * ga[r] + cvl[row0]);
+                const float pg = acc[q + 2][r] + (upw_j * gg[r] + cvl[row0 + 64]);
+                if (q == 0) {
+                    ga[r] = wn_buf_load(Gr, vg, (32 + mfma32_row(r, 0)) * F4);
+                    gg[r] = wn_buf_load(Gr, vg, (96 + mfma32_row(r, 0)) * F4);
+                }
                 const float s = wn_sigmoid(pa);
                 const float g = wn_tanh(pg);
                 const float zz = s * g;
@@ -466,6 +468,106 @@ static __device__ __forceinline__ void split_to_lds(const float* src, int st, ch
     for (int p = 0; p < 3; ++p) *reinterpret_cast<wn_f4*>(dst + p * piece_bytes) = bf[p];
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// LDS weight images of the split kernels.  A kernel either builds its image itself (every workgroup splits the whole
+// weight set again: ~5 us of latency-bound prologue per launch) or copies an image that wn_fused_pack_images built ONCE
+// per step with the SAME functions: the copy is 16 bytes per lane global -> LDS without registers.
+// ---------------------------------------------------------------------------------------------
+static __host__ __device__ constexpr int fwd_image_bytes(int K) { return K * 4 * (3 * 128 * 32) + 4 * (3 * 64 * 32); }
+static __host__ __device__ constexpr int chain_taps_bytes(int K) { return K * 8 * 6144; }
+#define WN_RES_T_BYTES (4 * 6144)
+
+// wd_f[(tap*64 + i)*128 + o'] , wres_f[i*64 + o]: channel i of (block kb, half h, e) = 16 kb + 4 h + (e&3) + 8 (e>>2)
+template <int K>
+static __device__ __forceinline__ void fill_fwd_image(char* Wd, char* Wr, const float* wd_f, const float* wres_f, int tid, int nthr) {
+    constexpr int WD_BLK = 3 * 128 * 32, WR_BLK = 3 * 64 * 32;
+    for (int idx = tid; idx < K * 4 * 2 * 128; idx += nthr) {
+        const int o = idx & 127, h = (idx >> 7) & 1, blk = idx >> 8;  // blk = tap*4 + kb
+        const int tap = blk >> 2, kb = blk & 3;
+        split_to_lds(wd_f + (long)(tap * 64 + 16 * kb + 4 * h) * 128 + o, 128, Wd + blk * WD_BLK + o * 32 + h * 16, 128 * 32);
+    }
+    for (int idx = tid; idx < 4 * 2 * 64; idx += nthr) {
+        const int o = idx & 63, h = (idx >> 6) & 1, kb = idx >> 7;
+        split_to_lds(wres_f + (long)(16 * kb + 4 * h) * 64 + o, 64, Wr + kb * WR_BLK + o * 32 + h * 16, 64 * 32);
+    }
+}
+// tap blocks of the chain kernel: chunk q (32 channels) = tap q % K, channel group q / K; two 6 KB blocks per chunk
+static __device__ __forceinline__ void fill_chain_taps(char* W, const float* wd_b, int K, int tid, int nthr) {
+    for (int idx = tid; idx < K * 4 * 2 * 128; idx += nthr) {
+        const int o = idx & 63, h = (idx >> 6) & 1, kbg = idx >> 7;
+        const int q = kbg >> 1;
+        const int tap = q % K;
+        const int c = (q / K) * 32 + (kbg & 1) * 16 + 8 * h;
+        const float* src = wd_b + ((long)tap * 128 + c) * 64 + o;
+        float x[8];
+        WN_UNROLL
+        for (int e = 0; e < 8; ++e) x[e] = src[e * 64];
+        wn_f4 bf[3];
+        split8(x, bf);
+        WN_UNROLL
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<wn_f4*>(W + kbg * 6144 + p * 2048 + o * 32 + h * 16) = bf[p];
+    }
+}
+// Wres^T of the gate half: natural res_1x1 weight [k = o][row = i], k order = accumulator register order
+static __device__ __forceinline__ void fill_res_t(char* Wr, const float* wres, int tid, int nthr) {
+    for (int idx = tid; idx < 4 * 2 * 64; idx += nthr) {
+        const int o = idx & 63, h = (idx >> 6) & 1, kb = idx >> 7;
+        split_to_lds(wres + (long)(16 * kb + 4 * h) * 64 + o, 64, Wr + kb * 6144 + o * 32 + h * 16, 2048);
+    }
+}
+// `bytes` (a multiple of 1024) from a 16-byte aligned global image to the start of the dynamic LDS, 16 bytes per lane
+static __device__ __forceinline__ void copy_image_to_lds(char* lds, const float* img, int bytes) {
+    const wn_rsrc_t Ir = wn_make_buf(img, (unsigned)bytes);
+    const int lane = threadIdx.x & 63, wave_u = WN_UNIFORM((int)(threadIdx.x >> 6));
+    for (int off = wave_u * 1024; off < bytes; off += WN_FW * 1024) wn_buf_load_lds16(Ir, lds + off, lane * 16, (unsigned)off);
+}
+
+struct PackImgArgs {
+    const float* wd_f;    // [L][K*64][128]
+    const float* wres_f;  // [L][64][64]
+    const float* wd_b;    // [L][K][128][64]
+    const float* params;  // flat parameter buffer; natural res_1x1 weight of layer l at params + res_off + l * res_lstride
+    long res_off, res_lstride;
+    float* img_fwd;       // [L][fwd_image_bytes / 4]
+    float* img_taps;      // [L][chain_taps_bytes / 4]
+    float* img_res;       // [L][WN_RES_T_BYTES / 4]
+    int K;
+};
+template <int K>
+__global__ __launch_bounds__(WN_FT) void k_fused_pack_images(PackImgArgs a) {
+    const int l = blockIdx.x, kind = blockIdx.y;
+    if (kind == 0) {
+        char* img = reinterpret_cast<char*>(a.img_fwd) + (long)l * fwd_image_bytes(K);
+        fill_fwd_image<K>(img, img + K * 4 * (3 * 128 * 32), a.wd_f + (long)l * K * 64 * 128, a.wres_f + (long)l * 64 * 64,
+                          threadIdx.x, WN_FT);
+    } else if (kind == 1) {
+        fill_chain_taps(reinterpret_cast<char*>(a.img_taps) + (long)l * chain_taps_bytes(K), a.wd_b + (long)l * K * 128 * 64, K,
+                        threadIdx.x, WN_FT);
+    } else {
+        fill_res_t(reinterpret_cast<char*>(a.img_res) + (long)l * WN_RES_T_BYTES, a.params + a.res_off + (long)l * a.res_lstride,
+                   threadIdx.x, WN_FT);
+    }
+}
+
+long wn_fused_image_floats(int K, int L, int which) {
+    if (K < 1 || K > 2) return 0;
+    const long per = which == 0 ? fwd_image_bytes(K) : which == 1 ? chain_taps_bytes(K) : WN_RES_T_BYTES;
+    return (long)L * per / 4;
+}
+
+int wn_fused_pack_images(const float* wd_f, const float* wres_f, const float* wd_b, const float* params, long res_off,
+                         long res_lstride, float* img_fwd, float* img_taps, float* img_res, int K, int L, wn_stream_t st) {
+    WN_PROF("fused_pack_images", 0.0, 0.0, st);
+    if (K < 1 || K > 2) return 1;
+    PackImgArgs a;
+    a.wd_f = wd_f; a.wres_f = wres_f; a.wd_b = wd_b; a.params = params; a.res_off = res_off; a.res_lstride = res_lstride;
+    a.img_fwd = img_fwd; a.img_taps = img_taps; a.img_res = img_res; a.K = K;
+    if (K == 1) WN_LAUNCH((k_fused_pack_images<1>), dim3((unsigned)L, 3), dim3(WN_FT), 0, st, a);
+    else WN_LAUNCH((k_fused_pack_images<2>), dim3((unsigned)L, 3), dim3(WN_FT), 0, st, a);
+    return 0;
+}
+
 template <int K>
 __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
     WN_DYN_SMEM(smem_raw);
@@ -481,15 +583,11 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
     }
     if (a.dbg && threadIdx.x == 0) a.dbg[512 + blockIdx.x * 4 + 0] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
-    // wd_f[(tap*64 + i)*128 + o'] , wres_f[i*64 + o]: channel i of (block kb, half h, e) = 16 kb + 4 h + (e&3) + 8 (e>>2)
-    for (int idx = threadIdx.x; idx < K * 4 * 2 * 128; idx += WN_FT) {
-        const int o = idx & 127, h = (idx >> 7) & 1, blk = idx >> 8;  // blk = tap*4 + kb
-        const int tap = blk >> 2, kb = blk & 3;
-        split_to_lds(a.wd_f + (long)(tap * 64 + 16 * kb + 4 * h) * 128 + o, 128, Wd + blk * WD_BLK + o * 32 + h * 16, 128 * 32);
-    }
-    for (int idx = threadIdx.x; idx < 4 * 2 * 64; idx += WN_FT) {
-        const int o = idx & 63, h = (idx >> 6) & 1, kb = idx >> 7;
-        split_to_lds(a.wres_f + (long)(16 * kb + 4 * h) * 64 + o, 64, Wr + kb * WR_BLK + o * 32 + h * 16, 64 * 32);
+    if (a.wimg != nullptr) {
+        copy_image_to_lds(smem_raw, a.wimg, fwd_image_bytes(K));   // pre-split once per step (wn_fused_pack_images)
+        WN_WAIT_VMCNT(0);
+    } else {
+        fill_fwd_image<K>(Wd, Wr, a.wd_f, a.wres_f, threadIdx.x, WN_FT);
     }
     if (threadIdx.x < 128) cv[threadIdx.x] = a.cvec[threadIdx.x];
     if (threadIdx.x < 64) rb[threadIdx.x] = a.res_bias[threadIdx.x];
@@ -600,11 +698,13 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
         const float upw_j = a.upw[tc - fr * a.U];
         const wn_rsrc_t Gr = wn_make_buf(a.G + (long)b * a.g_bstride, (unsigned)(128 * F4));
         const int vg = (4 * hi * a.F + fr) * 4;
-        float ga[2][16], gg[2][16];
+        // one register set for both 32-channel halves: an element of the second half is requested right after the
+        // element of the first half in the same register has been consumed (64 registers less across the gate phase)
+        float ga[16], gg[16];
         WN_UNROLL
         for (int r = 0; r < 16; ++r) {
-            ga[0][r] = wn_buf_load(Gr, vg, mfma32_row(r, 0) * F4);
-            gg[0][r] = wn_buf_load(Gr, vg, (mfma32_row(r, 0) + 64) * F4);
+            ga[r] = wn_buf_load(Gr, vg, mfma32_row(r, 0) * F4);
+            gg[r] = wn_buf_load(Gr, vg, (mfma32_row(r, 0) + 64) * F4);
         }
         WN_SCHED_BARRIER();
         // current tap; xc is also the residual input, already in D layout
@@ -642,11 +742,6 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
         // 96 S/Gt/Z stores could only be waited for together with those stores' acknowledgements.
         const int next_v = tile_v + step;
         if (K > 1 && next_v < tile_end) issue_hist(next_v);
-        WN_UNROLL
-        for (int r = 0; r < 16; ++r) {
-            ga[1][r] = wn_buf_load(Gr, vg, (32 + mfma32_row(r, 0)) * F4);
-            gg[1][r] = wn_buf_load(Gr, vg, (96 + mfma32_row(r, 0)) * F4);
-        }
         // gate (reference wavenet.py:529-532): P = conv + w[j]*G[row][f] + c[row]; saved for backward
         const wn_rsrc_t Sr = wn_make_buf(a.S + (long)b * 64 * T, slab);
         const wn_rsrc_t Gtr = wn_make_buf(a.Gt + (long)b * 64 * T, slab);
@@ -658,8 +753,12 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
             WN_UNROLL
             for (int r = 0; r < 16; ++r) {
                 const int row0 = 32 * q + mfma32_row(r, 0);  // + 4*hi is in the per-lane offsets
-                const float pa = acc[q][r] + (upw_j * ga[q][r] + cvl[row0]);
-                const float pg = acc[q + 2][r] + (upw_j * gg[q][r] + cvl[row0 + 64]);
+                const float pa = acc[q][r] + (upw_j * ga[r] + cvl[row0]);
+                const float pg = acc[q + 2][r] + (upw_j * gg[r] + cvl[row0 + 64]);
+                if (q == 0) {
+                    ga[r] = wn_buf_load(Gr, vg, (32 + mfma32_row(r, 0)) * F4);
+                    gg[r] = wn_buf_load(Gr, vg, (96 + mfma32_row(r, 0)) * F4);
+                }
                 const float s = wn_sigmoid(pa);
                 const float g = wn_tanh(pg);
                 const float zz = s * g;
@@ -752,10 +851,11 @@ static int launch_fwd(const FwdArgs& a, int split, wn_stream_t st) {
 
 int wn_fused_resblock_fwd(const float* wd_f, const float* wres_f, const float* cvec, const float* res_bias, const float* X,
                           const float* G, long g_bstride, const float* upw, float* Xnext, float* S, float* Gt, float* Z, int B,
-                          int T, int K, int dilation, int U, int F, int split, wn_stream_t st) {
+                          int T, int K, int dilation, int U, int F, int split, const float* wimg, wn_stream_t st) {
     WN_PROF("fused_resblock_fwd", 2.0 * (double)B * T * (K * 64.0 * 128.0 + (Xnext ? 64.0 * 64.0 : 0.0)),
             4.0 * (double)B * T * 64.0 * (Xnext ? 5.0 : 4.0), st);  // X in; S, Gt, Z (, Xnext) out
     FwdArgs a;
+    a.wimg = (split && K <= 2) ? wimg : nullptr;
     a.wd_f = wd_f; a.wres_f = wres_f; a.cvec = cvec; a.res_bias = res_bias;
     a.X = X; a.G = G; a.g_bstride = g_bstride; a.upw = upw;
     a.Xnext = Xnext; a.S = S; a.Gt = Gt; a.Z = Z;
@@ -1336,6 +1436,8 @@ int wn_fused_bwd_dx(const float* wd_b, const float* dP, const float* dXn, float*
 // AUX = 1 adds the aux-gradient partial sums of wn_fused_bwd_gate_aux to the gate epilogue (same arithmetic, same order).
 // ---------------------------------------------------------------------------------------------
 struct ChainArgs {
+    const float* img_taps;  // pre-built LDS images of the tap weights (layer l) and of Wres^T (layer l-1), or NULL
+    const float* img_res;
     const float* wd_b;   // [tap][128][64]: W_tap^T, row = dP channel, col = dX channel   (layer l)
     const float* dP;     // (B, 128, T) of layer l
     const float* dXn;    // (B, 64, T) dX_{l+1}; NULL for the last layer (its residual output is dead)
@@ -1371,23 +1473,13 @@ __global__ __launch_bounds__(WN_FT) void k_chain64s(ChainArgs a) {
     char* W = smem_raw;                      // tap blocks: chunk q (32 channels) = tap q % K, channel group q / K; 2 blocks of 6 KB each
     constexpr int NCH = K * 4;               // chunks of the dX part
     char* Wr = W + NCH * 2 * 6144;           // Wres^T: 4 blocks [piece][64 rows][16 k], k order = accumulator register order
-    for (int idx = threadIdx.x; idx < NCH * 2 * 128; idx += WN_FT) {
-        const int o = idx & 63, h = (idx >> 6) & 1, kbg = idx >> 7;
-        const int q = kbg >> 1;
-        const int tap = q % K;
-        const int c = (q / K) * 32 + (kbg & 1) * 16 + 8 * h;
-        const float* src = a.wd_b + ((long)tap * 128 + c) * 64 + o;
-        float x[8];
-        WN_UNROLL
-        for (int e = 0; e < 8; ++e) x[e] = src[e * 64];
-        wn_f4 bf[3];
-        split8(x, bf);
-        WN_UNROLL
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<wn_f4*>(W + kbg * 6144 + p * 2048 + o * 32 + h * 16) = bf[p];
-    }
-    for (int idx = threadIdx.x; idx < 4 * 2 * 64; idx += WN_FT) {
-        const int o = idx & 63, h = (idx >> 6) & 1, kb = idx >> 7;
-        split_to_lds(a.wres + (long)(16 * kb + 4 * h) * 64 + o, 64, Wr + kb * 6144 + o * 32 + h * 16, 2048);
+    if (a.img_taps != nullptr) {   // pre-split once per step (wn_fused_pack_images): two straight global -> LDS copies
+        copy_image_to_lds(W, a.img_taps, chain_taps_bytes(K));
+        copy_image_to_lds(Wr, a.img_res, WN_RES_T_BYTES);
+        WN_WAIT_VMCNT(0);
+    } else {
+        fill_chain_taps(W, a.wd_b, K, threadIdx.x, WN_FT);
+        fill_res_t(Wr, a.wres, threadIdx.x, WN_FT);
     }
     __syncthreads();
     if (WN_UNIFORM((int)(threadIdx.x / (WN_FT / 2))) != 0)
@@ -1611,7 +1703,8 @@ int wn_fused_chain_supported(int R, int K, int S) {
 
 int wn_fused_bwd_chain(const float* wd_b, const float* dP, const float* dXn, float* dX, const float* wres_prev, const float* dZs,
                        long zs_bstride, const float* S, const float* Gt, float* dP_prev, const float* G, long g_bstride,
-                       const float* upw, int U, int F, float* dGp, float* qp, int B, int T, int K, int dilation, wn_stream_t st) {
+                       const float* upw, int U, int F, float* dGp, float* qp, int B, int T, int K, int dilation,
+                       const float* img_taps, const float* img_res, wn_stream_t st) {
     // dP (, dXn), dZs, S, Gt in; dX, dP_prev out (+ dGp 8 / qp 1 words per timestep with the aux partials)
     const bool aux = dGp != nullptr;
     WN_PROF("fused_bwd_chain", 2.0 * (double)B * T * 64.0 * (K * 128.0 + 64.0),
@@ -1619,6 +1712,7 @@ int wn_fused_bwd_chain(const float* wd_b, const float* dP, const float* dXn, flo
     if (K < 1 || K > 2) return 1;
     if (aux && (U < 16 || (U & 15) || (T & 15) || (long)U * F != T)) return 1;
     ChainArgs a;
+    a.img_taps = (img_taps && img_res) ? img_taps : nullptr; a.img_res = img_res;
     a.wd_b = wd_b; a.dP = dP; a.dXn = dXn; a.dX = dX;
     a.wres = wres_prev; a.dZs = dZs; a.zs_bstride = zs_bstride; a.S = S; a.Gt = Gt; a.dPm = dP_prev;
     a.B = B; a.T = T; a.K = K; a.dil = dilation;

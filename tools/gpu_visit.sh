@@ -1,15 +1,15 @@
 #!/bin/bash
 # One GPU visit: parity tests, smoke, bench (A/B of the bucket structure), rocprofv3 kernel stats of the same command, PMC
 # passes, the recipe's stage 4/5, the 2-rank control flow on one GPU.  Each part has its own timeout and log under gpurun_out/.
-#   gpurun --timeout 1500 -- 'bash tools/gpu_visit.sh [parts...]'      parts: tests smoke bench lpb rocprof pmc recipe tworank
+#   gpurun --timeout 1500 -- 'bash tools/gpu_visit.sh [parts...]'      parts: tests smoke bench lpb rocprof pmc recipe tworank recipesize
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 cd "$ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
 OUT="$ROOT/gpurun_out"
-PARTS="${*:-tests smoke bench lpb rocprof pmc recipe tworank}"
+PARTS="${*:-tests smoke bench lpb rocprof pmc recipe tworank recipesize}"
 date +%s > $OUT/t0
 has() { echo " $PARTS " | grep -q " $1 "; }
 if has tests; then
-  timeout 900 python -m pytest tests -x -q -m gpu -s > $OUT/pytest_gpu_full.txt 2>&1; echo "pytest(full) rc=$?"; tail -4 $OUT/pytest_gpu_full.txt
+  timeout 1200 python -m pytest tests -q -m gpu -s > $OUT/pytest_gpu_full.txt 2>&1; echo "pytest(full) rc=$?"; tail -4 $OUT/pytest_gpu_full.txt
   grep -h "vs oracle\|err \|FULL SIZE" $OUT/pytest_gpu_full.txt | head -20
 fi
 if has smoke; then
@@ -19,14 +19,20 @@ if has bench; then
   timeout 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cut -c1-400 $OUT/bench.json
 fi
 if has lpb; then
-  for lpb in 30 10 30 10; do
-    timeout 200 python bench.py --layers-per-bucket $lpb --no-cpu-baseline --no-decode --profile-steps 0 > $OUT/bench_lpb$lpb.json 2>> $OUT/bench.err
-    python - <<P
+  # same-box A/B, interleaved.  Variant = "<WN_ENGINE_FLAGS> <WN_WEIGHT_IMAGES> <layers per bucket>":
+  #   flags 32 = aux partials + one-launch-per-layer chain (default), 96 = aux partials + the former launch pair;
+  #   images 1 = LDS weight images packed once per step (default), 0 = built by every workgroup of every launch
+  for rep in 1 2; do
+    for cfg in ${WN_AB_VARIANTS:-"32_1_30 32_0_30 96_1_30"}; do
+      IFS=_ read fl im lpb <<< "$cfg"
+      WN_ENGINE_FLAGS=$fl WN_WEIGHT_IMAGES=$im timeout 200 python bench.py --layers-per-bucket $lpb --repeats 3 --no-cpu-baseline --no-decode --profile-steps 0 > $OUT/bench_ab.json 2>> $OUT/bench.err
+      python - <<P
 import json
-d = json.load(open("$OUT/bench_lpb$lpb.json"))
-print("lpb $lpb: ms/step median %.3f min %.3f max %.3f" % (d["ms_per_step"], d["ms_per_step_min"], d["ms_per_step_max"]))
+d = json.load(open("$OUT/bench_ab.json"))
+print("flags $fl images $im lpb $lpb: ms/step median %.3f min %.3f max %.3f" % (d["ms_per_step"], d["ms_per_step_min"], d["ms_per_step_max"]))
 P
-  done | tee $OUT/lpb_ab.txt
+    done
+  done | tee $OUT/ab_probe.txt
 fi
 if has rocprof; then
   rm -rf $OUT/prof_stats
@@ -37,6 +43,16 @@ if has rocprof; then
 fi
 if has pmc; then
   bash tools/pmc_traffic.sh
+fi
+if has recipesize; then
+  timeout 300 python tools/recipe_bench.py > $OUT/recipe_size_bench.json 2> $OUT/recipe_size_bench.err; echo "recipe-size bench rc=$?"
+  python - <<P
+import json
+d = json.load(open("$OUT/recipe_size_bench.json"))
+print({k: v for k, v in d.items() if k != "kernels"})
+for k, v in list(d["kernels"].items())[:14]:
+    print("%-24s %3d launches %8.3f ms  tflops %s  GB/s %s" % (k, v["launches"], v["ms"], v["tflops"] and round(v["tflops"], 1), v["GBps"] and round(v["GBps"])))
+P
 fi
 if has recipe; then
   timeout 300 bash tools/recipe_stage45.sh run > $OUT/recipe_stage45.txt 2>&1; echo "recipe rc=$?"; tail -3 $OUT/recipe_stage45.txt

@@ -20,7 +20,8 @@ from pmc_summary import summarize  # noqa: E402
 TAGS = {"fused_bwd_gate": ["void k_conv64s<2>(ConvArgs)", "void k_conv64s<0>(ConvArgs)"],
         "fused_resblock_fwd": ["void k_resblock_fwd_s<2>(FwdArgs)"],
         "fused_bwd_dx": ["void k_conv64s<1>(ConvArgs)"],
-        "fused_bwd_chain": ["void k_chain64s<0>(ChainArgs)", "void k_chain64s<1>(ChainArgs)"]}
+        "fused_bwd_chain": ["void k_chain64s<1, 2>(ChainArgs)", "void k_chain64s<0, 2>(ChainArgs)", "void k_chain64s<1, 1>(ChainArgs)",
+                            "void k_chain64s<0, 1>(ChainArgs)"]}
 
 
 def engine_flags_of(log_path):

@@ -1,0 +1,76 @@
+#!/usr/bin/env python
+# -*- coding: utf-8 -*-
+"""training step of the recipe-size model (n_resch = 512, n_skipch = 256: egs/*/run.sh defaults) at the
+benchmark's window (batch_length 20000 -> T = 23040), per-kernel HIP-event table included.
+
+    python tools/recipe_bench.py [--batch 4] [--steps 5] [--aux 80]
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pytorchwavenetvocoder_amd.nets import WaveNet, initialize  # noqa: E402
+from pytorchwavenetvocoder_amd.optim import FusedAdam  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--aux", type=int, default=80)
+    ap.add_argument("--resch", type=int, default=512)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    R, S, A, U, L = args.resch, 256, args.aux, 80, 30
+    model = WaveNet(256, A, R, S, 10, 3, 2, U)
+    model.apply(initialize)
+    model.to(dev)
+    B, T = args.batch, 23040
+    g = torch.Generator().manual_seed(7)
+    xx = torch.randint(0, 256, (B, T + 1), generator=g)
+    x, t = xx[:, :-1].contiguous().to(dev), xx[:, 1:].contiguous().to(dev)
+    h = torch.randn(B, A, T // U, generator=g).to(dev)
+    opt = FusedAdam(model, lr=1e-4)
+
+    def step():
+        loss = model.loss_and_backward(x, h, t)
+        opt.step()
+        return loss
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    lib = model.engine.lib
+    lib.wn_prof_enable(1)
+    step()
+    torch.cuda.synchronize()
+    lib.wn_prof_enable(0)
+    need = lib.wn_prof_report(None, 0)
+    buf = ctypes.create_string_buffer(max(need, 16))
+    lib.wn_prof_report(buf, len(buf))
+    prof = json.loads(buf.value.decode() or "{}")
+    flop_fwd = 2.0 * B * T * (L * (2 * R * R * 2 + 2 * A * R / U + R * S + R * R) + S * S + S * 256)
+    out = {"model": "%d/%d recipe size, A=%d, K=2, U=%d, 30 layers" % (R, S, A, U), "B": B, "T": T,
+           "ms_per_step": dt * 1e3, "samples_per_sec": B * (T - model.receptive_field) / dt,
+           "approx_train_tflops": 3 * flop_fwd / dt / 1e12, "loss": float(loss),
+           "kernels": {k: {"launches": v["count"], "ms": v["ms"], "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] > 0 and v["ms"] > 0 else None,
+                           "GBps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["bytes"] > 0 and v["ms"] > 0 else None}
+                       for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
