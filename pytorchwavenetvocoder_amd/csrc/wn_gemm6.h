@@ -32,6 +32,7 @@ typedef struct WnGemm6Args {
     int accumulate;             // C += result
     int nbatch;
     const char* tag;
+    int no_interior;            // set by wn_gemm6_launch (tuning knob WN_G6_INTERIOR=0)
 } WnGemm6Args;
 
 static inline long wn_gemm6_apk_elems(int M, int K) {

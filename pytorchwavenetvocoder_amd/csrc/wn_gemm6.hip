@@ -21,6 +21,8 @@
 // loads of step s+1 are in flight during the 48 MFMAs of step s.
 #include "wn_gemm6.h"
 
+#include <stdlib.h>
+
 #include "wn_gemm.h"
 #include "wn_prof.h"
 
@@ -196,6 +198,50 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g) {
     const wn_rsrc_t Er = wn_make_buf(g.E ? g.E + (long)b * g.e_zstride : g.C, g.E ? (unsigned)((long)g.M * g.lde * 4) : 0u);
     const wn_rsrc_t Dr = wn_make_buf(g.D ? g.D + (long)b * g.d_zstride : g.C, g.D ? (unsigned)((long)g.M * g.ldd * 4) : 0u);
     const wn_rsrc_t Biasr = wn_make_buf(g.bias ? g.bias : g.C, g.bias ? (unsigned)(g.M * 4) : 0u);
+    // Interior blocks (the whole 256 x 128 tile inside C; every block of the benchmark's launches): the row part of an
+    // address is a wave-uniform scalar offset, the lane keeps ONE byte offset per tensor -- no per-element range selects.
+    const bool interior = (m0 + WN_G6_BM <= g.M) && (n0 + WN_G6_BN <= g.N) && !g.accumulate && !g.no_interior &&
+                          (long)g.M * g.ldc * 4 < 0x7fffffffL;
+    if (interior) {
+        const int rl = m0 + 128 * wm + 4 * hi, cl = n0 + 64 * wn + li;
+        const int vC = (rl * (int)g.ldc + cl) * 4, vE = (rl * (int)g.lde + cl) * 4, vD = (rl * (int)g.ldd + cl) * 4;
+        WN_UNROLL
+        for (int i = 0; i < 4; ++i) {
+            float bv[16];
+            WN_UNROLL
+            for (int r = 0; r < 16; ++r) bv[r] = 0.f;
+            if (g.bias) {
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) bv[r] = wn_buf_load(Biasr, (rl + 32 * i) * 4, mfma32_row(r, 0) * 4);
+            }
+            WN_UNROLL
+            for (int j = 0; j < 2; ++j) {
+                float ev[16], dv[16];
+                if (g.E) {
+                    WN_UNROLL
+                    for (int r = 0; r < 16; ++r)
+                        ev[r] = wn_buf_load(Er, vE + (32 * i * (int)g.lde + 32 * j) * 4, mfma32_row(r, 0) * (int)g.lde * 4);
+                }
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) dv[r] = 0.f;
+                if (g.D) {
+                    WN_UNROLL
+                    for (int r = 0; r < 16; ++r)
+                        dv[r] = wn_buf_load(Dr, vD + (32 * i * (int)g.ldd + 32 * j) * 4, mfma32_row(r, 0) * (int)g.ldd * 4);
+                }
+                WN_SCHED_BARRIER();
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r];
+                    v += bv[r] + dv[r];
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    if (g.E) v = (ev[r] > 0.f) ? v : 0.f;
+                    wn_buf_store(Cr, v, vC + (32 * i * (int)g.ldc + 32 * j) * 4, mfma32_row(r, 0) * (int)g.ldc * 4);
+                }
+            }
+        }
+        return;
+    }
     WN_UNROLL
     for (int i = 0; i < 4; ++i) {
         float bv[16];  // bias of this lane's 16 rows (0 when absent: out-of-range reads)
@@ -238,7 +284,15 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g) {
 }
 
 int wn_gemm6_launch(const WnGemm6Args* gp, wn_stream_t st) {
-    const WnGemm6Args& g = *gp;
+    WnGemm6Args g = *gp;
+    {   // tuning knob (A/B on hardware): WN_G6_INTERIOR=0 -> every block takes the general (range-checked) epilogue
+        static int v = -1;
+        if (v < 0) {
+            const char* e = getenv("WN_G6_INTERIOR");
+            v = (e && atoi(e) == 0) ? 0 : 1;
+        }
+        g.no_interior = v ? 0 : 1;
+    }
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.nbatch <= 0) return 1;
     if (g.b_seg_len < g.K && (g.b_seg_len % 16) != 0) return 2;
     constexpr int lds = 2 * (3 * WN_G6_BM * 32 + 3 * WN_G6_BN * 32);
