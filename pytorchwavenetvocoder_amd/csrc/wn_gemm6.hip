@@ -510,6 +510,17 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6_dw(WnGemmArgs g) {
     }
 }
 
+// 256-row tiles for weight gradients with >= 256 output rows (skip / post-net / wide-model gradients): tuning knob
+// WN_DW_TALL=0 restores 128 x 128 tiles everywhere.  The split-K plan of the caller must use the same rule.
+int wn_gemm6_dw_tall(int M, int N) {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("WN_DW_TALL");
+        v = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return v && M >= 256 && (M % 256 == 0) && N > 64;
+}
+
 int wn_gemm6_dw_eligible(const WnGemmArgs* g) {
     return g->a_kmajor && g->b_kmajor && !g->b_index && !g->bias && !g->D && !g->E && !g->relu && !g->accumulate &&
            (long)g->M * g->ldc * 4 < 0x7ffffff0L && g->M > 0 && g->N > 0;
@@ -531,6 +542,7 @@ int wn_gemm6_dw_launch(const WnGemmArgs* gp, wn_stream_t st) {
     WN_PROF(g.tag ? g.tag : "gemm6_dw", 2.0 * g.M * g.N * (double)g.K * g.nbatch * g.nlayer,
             ((double)g.M * g.K * 4.0 + (double)g.K * 4.0 * g.N + (double)g.M * g.N * 4.0) * g.nbatch * g.nlayer, st);
     const int tm = g.M > 64 ? 2 : 1, tn = g.N > 64 ? 2 : 1;
+    if (wn_gemm6_dw_tall(g.M, g.N)) return launch_dw<4, 2>(g, st);   // 256 x 128 tiles: every B row is read once per 256 A rows
     if (tm == 2 && tn == 2) return launch_dw<2, 2>(g, st);
     if (tm == 2) return launch_dw<2, 1>(g, st);
     if (tn == 2) return launch_dw<1, 2>(g, st);

@@ -19,17 +19,15 @@ if has bench; then
   timeout 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cut -c1-400 $OUT/bench.json
 fi
 if has lpb; then
-  # same-box A/B, interleaved.  Variant = "<WN_ENGINE_FLAGS>_<WN_WEIGHT_IMAGES>_<layers per bucket>[_<WN_G6_INTERIOR>]":
-  #   flags 32 = aux partials + one-launch-per-layer chain (default), 96 = aux partials + the former launch pair;
-  #   images 1 = LDS weight images packed once per step (default), 0 = built by every workgroup of every launch
+  # same-box A/B, interleaved, two rounds.  A variant is a comma-separated list of environment settings, e.g.
+  #   WN_AB_VARIANTS="WN_DW_TALL=1 WN_DW_TALL=0 WN_ENGINE_FLAGS=96"   (knobs: DESIGN.md 5.2)
   for rep in 1 2; do
-    for cfg in ${WN_AB_VARIANTS:-32_1_30 32_0_30 32_1_30_0 96_1_30}; do
-      IFS=_ read fl im lpb g6 <<< "$cfg"
-      WN_ENGINE_FLAGS=$fl WN_WEIGHT_IMAGES=$im WN_G6_INTERIOR=${g6:-1} timeout 200 python bench.py --layers-per-bucket $lpb --repeats 3 --no-cpu-baseline --no-decode --profile-steps 0 > $OUT/bench_ab.json 2>> $OUT/bench.err
+    for cfg in ${WN_AB_VARIANTS:-WN_DW_TALL=1 WN_DW_TALL=0 WN_WEIGHT_IMAGES=0 WN_ENGINE_FLAGS=96}; do
+      env $(echo $cfg | tr ',' ' ') timeout 200 python bench.py --repeats 3 --no-cpu-baseline --no-decode --profile-steps 0 > $OUT/bench_ab.json 2>> $OUT/bench.err
       python - <<P
 import json
 d = json.load(open("$OUT/bench_ab.json"))
-print("flags $fl images $im lpb $lpb g6-interior ${g6:-1}: ms/step median %.3f min %.3f max %.3f" % (d["ms_per_step"], d["ms_per_step_min"], d["ms_per_step_max"]))
+print("%-40s ms/step median %.3f min %.3f max %.3f" % ("$cfg", d["ms_per_step"], d["ms_per_step_min"], d["ms_per_step_max"]))
 P
     done
   done | tee $OUT/ab_probe.txt
@@ -45,7 +43,9 @@ if has pmc; then
   bash tools/pmc_traffic.sh
 fi
 if has recipesize; then
-  timeout 300 python tools/recipe_bench.py > $OUT/recipe_size_bench.json 2> $OUT/recipe_size_bench.err; echo "recipe-size bench rc=$?"
+  WN_DW_TALL=0 timeout 300 python tools/recipe_bench.py --steps 3 > $OUT/recipe_size_bench_notall.json 2> $OUT/recipe_size_bench.err
+  python -c "import json; d=json.load(open('$OUT/recipe_size_bench_notall.json')); print('recipe size, 128x128 dW tiles: %.1f ms/step' % d['ms_per_step'])"
+  timeout 300 python tools/recipe_bench.py > $OUT/recipe_size_bench.json 2>> $OUT/recipe_size_bench.err; echo "recipe-size bench rc=$?"
   python - <<P
 import json
 d = json.load(open("$OUT/recipe_size_bench.json"))
