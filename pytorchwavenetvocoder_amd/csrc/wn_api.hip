@@ -560,6 +560,17 @@ static int make_ctx(Ctx* c, const WnConfig* cfg, int B, int T, void* ws, size_t 
     return 0;
 }
 
+// tuning knob (A/B on hardware): WN_GATE_EPILOGUE=0 -> the any-size path runs its gate / gate' as separate elementwise
+// launches again instead of as epilogues of the split contractions (n_resch % 128 == 0)
+static bool gate_epilogues() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("WN_GATE_EPILOGUE");
+        v = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return v != 0;
+}
+
 // tuning knob (A/B on hardware): WN_WEIGHT_IMAGES=0 -> every workgroup of a fused split kernel builds its LDS weight image
 // itself again instead of copying the image packed once per step
 static bool use_images() {
@@ -576,15 +587,38 @@ static bool use_images() {
 // ------------------------------------------------------------------------------------------
 // Weights x activations contraction: split-bf16 matrix-core kernel when the launch has its shape
 // (>= 128 output rows, k-minor operands, no shifts), the exact-f32 MFMA kernel otherwise.
-static int fw_gemm(const Ctx& c, const WnGemmArgs& g) {
+struct GateEpi {   // optional gate epilogue of a split contraction (wn_gemm6.h); all NULL = plain
+    int gate_R = 0;
+    float *S = nullptr, *Gt = nullptr, *Z = nullptr;
+    const float* G = nullptr;
+    long g_bstride = 0;
+    int F = 0, U = 1;
+    const float *upw = nullptr, *cvec = nullptr;
+    const float *bw_S = nullptr, *bw_Gt = nullptr;
+    float* bw_dP = nullptr;
+};
+// can this launch run on the split kernel (the only one with the gate epilogues)?
+static bool fw_gemm_split_ok(const Ctx& c, const WnGemmArgs& g) {
+    return c.split_bf16 && g.M >= 128 && !g.a_kmajor && !g.b_kmajor &&
+           (g.b_seg_len >= g.K || g.b_seg_len % 16 == 0) && g.ksplit == 1 && g.nlayer == 1 && !g.b_relu &&
+           !g.b_index && g.a_zstride == 0 && !g.a_rowsum &&
+           wn_gemm6_apk_elems(g.M, g.K) <= 2 * c.w.apk_floats && (long)g.M * g.ldc * 4 < 0x7ffffff0L;
+}
+static int fw_gemm(const Ctx& c, const WnGemmArgs& g, const GateEpi* ge = nullptr) {
     const bool ok = c.split_bf16 && g.M >= 128 && !g.a_kmajor && !g.b_kmajor &&
                     (g.b_seg_len >= g.K || g.b_seg_len % 16 == 0) && g.ksplit == 1 && g.nlayer == 1 && !g.b_relu &&
                     !g.b_index && g.a_zstride == 0 && !g.a_rowsum &&
                     wn_gemm6_apk_elems(g.M, g.K) <= 2 * c.w.apk_floats && (long)g.M * g.ldc * 4 < 0x7ffffff0L;
-    if (!ok) return wn_gemm_launch(&g, c.st);
+    if (!ok) return ge ? fail(3, "gate epilogue needs the split contraction") : wn_gemm_launch(&g, c.st);
     unsigned short* apk = reinterpret_cast<unsigned short*>(c.ws + c.w.apk);
-    WN_TRY(wn_gemm6_pack(g.A, g.lda, g.M, g.K, apk, c.st));
+    WN_TRY(wn_gemm6_pack(g.A, g.lda, g.M, g.K, apk, ge ? ge->gate_R : 0, c.st));
     WnGemm6Args a;
+    wn_gemm6_no_gate(&a);
+    if (ge) {
+        a.gate_R = ge->gate_R; a.gate_S = ge->S; a.gate_Gt = ge->Gt; a.gate_Z = ge->Z; a.gate_G = ge->G; a.gate_gb = ge->g_bstride;
+        a.gate_F = ge->F; a.gate_U = ge->U; a.gate_upw = ge->upw; a.gate_cvec = ge->cvec;
+        a.gbw_S = ge->bw_S; a.gbw_Gt = ge->bw_Gt; a.gbw_dP = ge->bw_dP;
+    }
     a.M = g.M; a.N = g.N; a.K = g.K;
     a.Apk = apk; a.Mpad = (g.M + WN_G6_BM - 1) / WN_G6_BM * WN_G6_BM;
     a.B = g.B; a.ldb = g.ldb; a.b_zstride = g.b_zstride; a.b_seg_len = g.b_seg_len; a.b_seg_stride = g.b_seg_stride;
@@ -749,10 +783,20 @@ static int forward_stack(const Ctx& c, const float* params, const int64_t* x, co
             g.b_seg_len = d.R; g.b_seg_stride = 0; g.b_shift0 = (d.K - 1) * dil; g.b_shift_step = -dil;
             g.C = ws + w.P; g.ldc = T; g.c_zstride = (long)2 * d.R * T;
             g.nbatch = B; g.tag = "fwd_dilated_layered";
-            WN_TRY(fw_gemm(c, g));
-            // z = sigmoid(.)*tanh(.)                           (wavenet.py:529-532)
-            WN_TRY(wn_gate_fwd(ws + w.P, Gl, g_bstride, upw, ws + w.cvec + (long)l * 2 * d.R, Sl, Gtl, Zl, B, T, d.R, Ue, F,
-                               c.st));
+            if (d.R % 128 == 0 && fw_gemm_split_ok(c, g) && gate_epilogues()) {
+                // wide models: the gate is the epilogue of the contraction (sigmoid / tanh rows paired by the weight
+                // packing), the 2R pre-activations never go to memory                  (wavenet.py:527-532)
+                GateEpi ge;
+                ge.gate_R = d.R; ge.S = Sl; ge.Gt = Gtl; ge.Z = Zl; ge.G = Gl; ge.g_bstride = g_bstride; ge.F = F; ge.U = Ue;
+                ge.upw = upw; ge.cvec = ws + w.cvec + (long)l * 2 * d.R;
+                g.tag = "fwd_dilated_gate";
+                WN_TRY(fw_gemm(c, g, &ge));
+            } else {
+                WN_TRY(fw_gemm(c, g));
+                // z = sigmoid(.)*tanh(.)                           (wavenet.py:529-532)
+                WN_TRY(wn_gate_fwd(ws + w.P, Gl, g_bstride, upw, ws + w.cvec + (long)l * 2 * d.R, Sl, Gtl, Zl, B, T, d.R, Ue, F,
+                                   c.st));
+            }
             // x_{l+1} = res_1x1(z) + x_l                       (wavenet.py:534-535); dead for the last layer
             if (Xn) {
                 WnGemmArgs r = wn_gemm_default();
@@ -1140,25 +1184,37 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
                                          Gtl, dP, B, T, d.S, c.split_bf16 ? 1 : 0, c.st));
             WN_TRY(wn_fused_bwd_dx(ws + w.wd_b + (long)l * d.K * 2 * d.R * d.R, dP, dXn, dXl, B, T, d.K, dil, c.split_bf16 ? 1 : 0, c.st));
         } else {
-            {   // dZ = Wskip_l^T dSkip
-                WnGemmArgs g = wn_gemm_default();
-                g.M = d.R; g.N = T; g.K = d.S;
-                g.A = params + y.skip0 + (long)l * y.ls_skip; g.lda = d.R;
-                g.B = ws + w.dSk; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = T;
-                g.C = ws + w.dZ; g.ldc = T; g.c_zstride = (long)d.R * T;
-                g.nbatch = B; g.tag = "bwd_dz_skip_layered";
-                WN_TRY(fw_gemm(c, g));
+            // dZ = Wskip_l^T dSkip (+ Wres_l^T dX_{l+1}) -> gate' -> dP.  Wide models on the split kernels: gate' is the
+            // epilogue of the LAST of the two contractions (dZ never leaves the chip for it).
+            WnGemmArgs gs = wn_gemm_default();
+            gs.M = d.R; gs.N = T; gs.K = d.S;
+            gs.A = params + y.skip0 + (long)l * y.ls_skip; gs.lda = d.R;
+            gs.B = ws + w.dSk; gs.ldb = T; gs.b_zstride = (long)d.S * T; gs.b_clen = T;
+            gs.C = ws + w.dZ; gs.ldc = T; gs.c_zstride = (long)d.R * T;
+            gs.nbatch = B; gs.tag = "bwd_dz_skip_layered";
+            WnGemmArgs gr = wn_gemm_default();
+            gr.M = d.R; gr.N = T; gr.K = d.R;
+            gr.A = params + lb + y.o_res_w; gr.lda = d.R;
+            gr.B = dXn; gr.ldb = T; gr.b_zstride = (long)d.R * T; gr.b_clen = T;
+            gr.C = ws + w.dZ; gr.ldc = T; gr.c_zstride = (long)d.R * T;
+            gr.accumulate = 1; gr.nbatch = B; gr.tag = "bwd_dz_res_layered";
+            const bool epi = d.R % 128 == 0 && gate_epilogues() && fw_gemm_split_ok(c, gs) && (!dXn || fw_gemm_split_ok(c, gr));
+            GateEpi ge;
+            ge.bw_S = Sl; ge.bw_Gt = Gtl; ge.bw_dP = dP;
+            if (epi) {
+                if (dXn) {
+                    WN_TRY(fw_gemm(c, gs));
+                    gr.tag = "bwd_dz_res_gate";
+                    WN_TRY(fw_gemm(c, gr, &ge));
+                } else {
+                    gs.tag = "bwd_dz_skip_gate";
+                    WN_TRY(fw_gemm(c, gs, &ge));
+                }
+            } else {
+                WN_TRY(fw_gemm(c, gs));
+                if (dXn) WN_TRY(fw_gemm(c, gr));
+                WN_TRY(wn_gate_bwd(ws + w.dZ, Sl, Gtl, dP, B, T, d.R, c.st));
             }
-            if (dXn) {  // dZ += Wres_l^T dX_{l+1}
-                WnGemmArgs g = wn_gemm_default();
-                g.M = d.R; g.N = T; g.K = d.R;
-                g.A = params + lb + y.o_res_w; g.lda = d.R;
-                g.B = dXn; g.ldb = T; g.b_zstride = (long)d.R * T; g.b_clen = T;
-                g.C = ws + w.dZ; g.ldc = T; g.c_zstride = (long)d.R * T;
-                g.accumulate = 1; g.nbatch = B; g.tag = "bwd_dz_res_layered";
-                WN_TRY(fw_gemm(c, g));
-            }
-            WN_TRY(wn_gate_bwd(ws + w.dZ, Sl, Gtl, dP, B, T, d.R, c.st));
             {   // dX_l = dX_{l+1} + sum_tap W_tap^T dP[t + (K-1-tap) d]
                 WnGemmArgs g = wn_gemm_default();
                 g.M = d.R; g.N = T; g.K = d.K * 2 * d.R;

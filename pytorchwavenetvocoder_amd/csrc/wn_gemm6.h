@@ -33,14 +33,44 @@ typedef struct WnGemm6Args {
     int nbatch;
     const char* tag;
     int no_interior;            // set by wn_gemm6_launch (tuning knob WN_G6_INTERIOR=0)
+    // Gate epilogues of the any-size residual block (R % 128 == 0): the contraction's result never goes to memory.
+    // gate_S != NULL (forward, reference wavenet.py:529-532): M = 2R rows packed with wn_gemm6_pack(..., gate_R = R), so that
+    //   a lane holds the sigmoid and the tanh pre-activation of the same channel; P = acc + w[t%U] G[:, t/U] + cvec;
+    //   S = sigmoid(P[:R]), Gt = tanh(P[R:]), Z = S * Gt are written as (B, R, T); C is not touched.
+    // gbw_dP != NULL (backward): M = R rows of dZ (+ the previous C when `accumulate`); dP = [dZ g s (1-s) ; dZ s (1-g^2)]
+    //   is written as (B, 2R, T) from the saved halves gbw_S, gbw_Gt (B, R, T); C is read (accumulate) but not written.
+    int gate_R;
+    float* gate_S;
+    float* gate_Gt;
+    float* gate_Z;
+    const float* gate_G;        // frame-rate aux projection of this layer: rows [0, 2R), row stride gate_F, batch stride gate_gb
+    long gate_gb;
+    int gate_F, gate_U;
+    const float* gate_upw;      // [U]
+    const float* gate_cvec;     // [2R]
+    const float* gbw_S;
+    const float* gbw_Gt;
+    float* gbw_dP;
 } WnGemm6Args;
+
+static inline void wn_gemm6_no_gate(WnGemm6Args* a) {
+    a->gate_R = 0; a->gate_S = 0; a->gate_Gt = 0; a->gate_Z = 0; a->gate_G = 0; a->gate_gb = 0; a->gate_F = 0; a->gate_U = 1;
+    a->gate_upw = 0; a->gate_cvec = 0; a->gbw_S = 0; a->gbw_Gt = 0; a->gbw_dP = 0; a->no_interior = 0;
+}
 
 static inline long wn_gemm6_apk_elems(int M, int K) {
     const long Mpad = ((long)M + WN_G6_BM - 1) / WN_G6_BM * WN_G6_BM;
     return ((long)K + 15) / 16 * 3 * Mpad * 16;
 }
-// src holds A(m,k) = src[k*lda + m] (fp32) -> Apk
-int wn_gemm6_pack(const float* src, long lda, int M, int K, unsigned short* Apk, wn_stream_t st);
+// src holds A(m,k) = src[k*lda + m] (fp32) -> Apk.  gate_R > 0 (M = 2 gate_R, gate_R % 128 == 0): packed row p takes
+// source row wn_gemm6_gate_row(p, gate_R) -- every 256-row block holds 128 channels, each wave's 128 rows = 64 sigmoid
+// rows followed by the 64 tanh rows of the same channels (the pairing of the forward gate epilogue).
+int wn_gemm6_pack(const float* src, long lda, int M, int K, unsigned short* Apk, int gate_R, wn_stream_t st);
+static __host__ __device__ inline int wn_gemm6_gate_row(int p, int R) {
+    const int mb = p >> 8, wmi = (p >> 7) & 1, i = (p >> 5) & 3, rr = p & 31;
+    const int c = mb * 128 + wmi * 64 + (i & 1) * 32 + rr;
+    return (i < 2) ? c : R + c;
+}
 int wn_gemm6_launch(const WnGemm6Args* g, wn_stream_t st);
 
 // Weight-gradient type contraction (both operands k-major, k = time; csrc/wn_gemm.h semantics of the

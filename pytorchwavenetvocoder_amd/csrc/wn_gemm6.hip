@@ -28,17 +28,18 @@
 
 #define G6_T 256
 
-__global__ void k_gemm6_pack(const float* src, long lda, int M, int K, int Mpad, unsigned short* Apk) {
+__global__ void k_gemm6_pack(const float* src, long lda, int M, int K, int Mpad, unsigned short* Apk, int gate_R) {
     // one thread per (kb, m): 16 k values -> 3 x 16 bf16
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const int nkb = (K + 15) / 16;
     if (idx >= (long)nkb * Mpad) return;
     const int kb = (int)(idx / Mpad), m = (int)(idx % Mpad);
+    const int ms = (gate_R > 0 && m < M) ? wn_gemm6_gate_row(m, gate_R) : m;   // source row of packed row m
     for (int e = 0; e < 16; e += 2) {
         float x[2];
         for (int u = 0; u < 2; ++u) {
             const int k = kb * 16 + e + u;
-            x[u] = (m < M && k < K) ? src[(long)k * lda + m] : 0.f;
+            x[u] = (m < M && k < K) ? src[(long)k * lda + ms] : 0.f;
         }
         const unsigned h = wn_pk_bf16(x[0], x[1]);
         const float r0 = x[0] - wn_bits_f32(h << 16), r1 = x[1] - wn_bits_f32(h & 0xffff0000u);
@@ -51,11 +52,12 @@ __global__ void k_gemm6_pack(const float* src, long lda, int M, int K, int Mpad,
     }
 }
 
-int wn_gemm6_pack(const float* src, long lda, int M, int K, unsigned short* Apk, wn_stream_t st) {
+int wn_gemm6_pack(const float* src, long lda, int M, int K, unsigned short* Apk, int gate_R, wn_stream_t st) {
     WN_PROF("gemm6_pack", 0.0, 0.0, st);
+    if (gate_R > 0 && (M != 2 * gate_R || gate_R % 128 != 0)) return 1;
     const int Mpad = (M + WN_G6_BM - 1) / WN_G6_BM * WN_G6_BM;
     const long n = (long)((K + 15) / 16) * Mpad;
-    WN_LAUNCH(k_gemm6_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, lda, M, K, Mpad, Apk);
+    WN_LAUNCH(k_gemm6_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, lda, M, K, Mpad, Apk, gate_R);
     return 0;
 }
 
@@ -198,9 +200,83 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g) {
     const wn_rsrc_t Er = wn_make_buf(g.E ? g.E + (long)b * g.e_zstride : g.C, g.E ? (unsigned)((long)g.M * g.lde * 4) : 0u);
     const wn_rsrc_t Dr = wn_make_buf(g.D ? g.D + (long)b * g.d_zstride : g.C, g.D ? (unsigned)((long)g.M * g.ldd * 4) : 0u);
     const wn_rsrc_t Biasr = wn_make_buf(g.bias ? g.bias : g.C, g.bias ? (unsigned)(g.M * 4) : 0u);
+    if (g.gate_S != nullptr) {
+        // Forward gate (wavenet.py:529-532) on the accumulators: row tiles i = 0, 1 of this wave are the sigmoid rows of
+        // channels ch0 + 32 i + row, tiles 2, 3 the tanh rows of the same channels (wn_gemm6_gate_row).
+        const int R = g.gate_R;
+        const int ch0 = (m0 >> 1) + 64 * wm;
+        const int F4 = g.gate_F * 4, T4 = (int)g.ldc * 4;
+        const wn_rsrc_t Gr = wn_make_buf(g.gate_G + (long)b * g.gate_gb, (unsigned)(2 * R * F4));
+        const wn_rsrc_t Sr = wn_make_buf(g.gate_S + (long)b * R * g.ldc, (unsigned)(R * T4));
+        const wn_rsrc_t Tr = wn_make_buf(g.gate_Gt + (long)b * R * g.ldc, (unsigned)(R * T4));
+        const wn_rsrc_t Zr = wn_make_buf(g.gate_Z + (long)b * R * g.ldc, (unsigned)(R * T4));
+        WN_UNROLL
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + 64 * wn + 32 * j + li;
+            const bool ok = col < g.N;
+            const int tc = ok ? col : g.N - 1;
+            const int fr = tc / g.gate_U;
+            const float wj = g.gate_upw[tc - fr * g.gate_U];
+            WN_UNROLL
+            for (int i = 0; i < 2; ++i) {
+                const int cb = ch0 + 32 * i + 4 * hi;   // + mfma32_row(r, 0)
+                float ga[16], gg[16];
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    ga[r] = wn_buf_load(Gr, (cb * g.gate_F + fr) * 4, mfma32_row(r, 0) * F4);
+                    gg[r] = wn_buf_load(Gr, ((R + cb) * g.gate_F + fr) * 4, mfma32_row(r, 0) * F4);
+                }
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int c = cb + mfma32_row(r, 0);
+                    const float pa = acc[i][j][r] + (wj * ga[r] + g.gate_cvec[c]);
+                    const float pg = acc[i + 2][j][r] + (wj * gg[r] + g.gate_cvec[R + c]);
+                    const float sv = wn_sigmoid(pa), gv = wn_tanh(pg);
+                    const int off = ok ? (cb * (int)g.ldc + col) * 4 : 0x7ffffff0;
+                    wn_buf_store(Sr, sv, off, mfma32_row(r, 0) * T4);
+                    wn_buf_store(Tr, gv, off, mfma32_row(r, 0) * T4);
+                    wn_buf_store(Zr, sv * gv, off, mfma32_row(r, 0) * T4);
+                }
+            }
+        }
+        return;
+    }
+    if (g.gbw_dP != nullptr) {
+        // Backward gate (wavenet.py:529-532 reversed): dZ = acc (+ the partial sum already in C) never leaves the chip
+        const int R = g.M, T4 = (int)g.ldc * 4;
+        const wn_rsrc_t Sr = wn_make_buf(g.gbw_S + (long)b * R * g.ldc, (unsigned)(R * T4));
+        const wn_rsrc_t Tr = wn_make_buf(g.gbw_Gt + (long)b * R * g.ldc, (unsigned)(R * T4));
+        const wn_rsrc_t Pr = wn_make_buf(g.gbw_dP + (long)b * 2 * R * g.ldc, (unsigned)(2 * R * T4));
+        WN_UNROLL
+        for (int i = 0; i < 4; ++i) {
+            WN_UNROLL
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + 64 * wn + 32 * j + li;
+                const int rb = m0 + 128 * wm + 32 * i + 4 * hi;
+                float sv[16], gv[16], cv[16];
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rb + mfma32_row(r, 0);
+                    const int off = (row < R && col < g.N) ? (row * (int)g.ldc + col) * 4 : 0x7ffffff0;
+                    sv[r] = wn_buf_load(Sr, off, 0);
+                    gv[r] = wn_buf_load(Tr, off, 0);
+                    cv[r] = g.accumulate ? wn_buf_load(Cr, off, 0) : 0.f;
+                }
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rb + mfma32_row(r, 0);
+                    const int off = (row < R && col < g.N) ? (row * (int)g.ldc + col) * 4 : 0x7ffffff0;
+                    const float dz = acc[i][j][r] + cv[r];
+                    wn_buf_store(Pr, dz * gv[r] * (sv[r] * (1.0f - sv[r])), off, 0);
+                    wn_buf_store(Pr, dz * sv[r] * (1.0f - gv[r] * gv[r]), off, R * T4);
+                }
+            }
+        }
+        return;
+    }
     // Interior blocks (the whole 256 x 128 tile inside C; every block of the benchmark's launches): the row part of an
     // address is a wave-uniform scalar offset, the lane keeps ONE byte offset per tensor -- no per-element range selects.
-    const bool interior = (m0 + WN_G6_BM <= g.M) && (n0 + WN_G6_BN <= g.N) && !g.accumulate && !g.no_interior &&
+    const bool interior = (m0 + WN_G6_BM <= g.M) && (n0 + WN_G6_BN <= g.N) && !g.no_interior &&
                           (long)g.M * g.ldc * 4 < 0x7fffffffL;
     if (interior) {
         const int rl = m0 + 128 * wm + 4 * hi, cl = n0 + 64 * wn + li;
@@ -229,6 +305,14 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g) {
                     for (int r = 0; r < 16; ++r)
                         dv[r] = wn_buf_load(Dr, vD + (32 * i * (int)g.ldd + 32 * j) * 4, mfma32_row(r, 0) * (int)g.ldd * 4);
                 }
+                float cv[16];   // C += result: the previous value of this lane's 16 elements (0 otherwise)
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) cv[r] = 0.f;
+                if (g.accumulate) {
+                    WN_UNROLL
+                    for (int r = 0; r < 16; ++r)
+                        cv[r] = wn_buf_load(Cr, vC + (32 * i * (int)g.ldc + 32 * j) * 4, mfma32_row(r, 0) * (int)g.ldc * 4);
+                }
                 WN_SCHED_BARRIER();
                 WN_UNROLL
                 for (int r = 0; r < 16; ++r) {
@@ -236,6 +320,7 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g) {
                     v += bv[r] + dv[r];
                     if (g.relu) v = fmaxf(v, 0.f);
                     if (g.E) v = (ev[r] > 0.f) ? v : 0.f;
+                    v += cv[r];
                     wn_buf_store(Cr, v, vC + (32 * i * (int)g.ldc + 32 * j) * 4, mfma32_row(r, 0) * (int)g.ldc * 4);
                 }
             }
@@ -510,15 +595,17 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6_dw(WnGemmArgs g) {
     }
 }
 
-// 256-row tiles for weight gradients with >= 256 output rows (skip / post-net / wide-model gradients): tuning knob
-// WN_DW_TALL=0 restores 128 x 128 tiles everywhere.  The split-K plan of the caller must use the same rule.
+// 256-row tiles for the weight gradients of wide models (>= 512 x 512 outputs: n_resch = 512 gives -2 % per step,
+// profiles/r02/ab_probe_dw_tall.txt); at 256 output rows (skip / post-net gradients of the 64/256 model) they measured
+// 0.06 - 0.1 ms SLOWER than 128 x 128 tiles at 3 workgroups per CU, so those keep the square tile.  Tuning knob
+// WN_DW_TALL=0: square tiles everywhere.  The split-K plan of the caller must use the same rule.
 int wn_gemm6_dw_tall(int M, int N) {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("WN_DW_TALL");
         v = (e && atoi(e) == 0) ? 0 : 1;
     }
-    return v && M >= 256 && (M % 256 == 0) && N > 64;
+    return v && M >= 512 && (M % 256 == 0) && N >= 512;
 }
 
 int wn_gemm6_dw_eligible(const WnGemmArgs* g) {

@@ -11,12 +11,44 @@
 #include "../../include/wavenet_hip.h"
 
 #ifdef WN_EMU
-void wn_prof_scope_begin(const char*, double, double, wn_stream_t) {}
+// Host build of the kernels (tests/emu): no events, but the launch LOG is kept -- tests assert which launches a mode
+// issues (count / flops / bytes per tag; "ms" is 0).  wn_prof_is_on() stays false: the emulator has one in-order stream.
+namespace {
+struct EmuAgg {
+    long count = 0;
+    double flops = 0, bytes = 0;
+};
+bool g_emu_on = false;
+std::map<std::string, EmuAgg> g_emu;
+}  // namespace
+void wn_prof_scope_begin(const char* name, double flops, double bytes, wn_stream_t) {
+    if (!g_emu_on) return;
+    EmuAgg& a = g_emu[name];
+    a.count++;
+    a.flops += flops;
+    a.bytes += bytes;
+}
 void wn_prof_scope_end(wn_stream_t) {}
 bool wn_prof_is_on() { return false; }
-extern "C" int wn_prof_enable(int) { return 0; }
+extern "C" int wn_prof_enable(int on) {
+    g_emu_on = on != 0;
+    if (g_emu_on) g_emu.clear();
+    return 0;
+}
 extern "C" int wn_prof_report(char* buf, size_t n) {
-    if (buf && n) buf[0] = 0;
+    std::string s = "{";
+    bool first = true;
+    for (auto& kv : g_emu) {
+        char tmp[512];
+        snprintf(tmp, sizeof(tmp), "%s\"%s\": {\"count\": %ld, \"ms\": 0.0, \"flops\": %.6e, \"bytes\": %.6e}", first ? "" : ", ",
+                 kv.first.c_str(), kv.second.count, kv.second.flops, kv.second.bytes);
+        s += tmp;
+        first = false;
+    }
+    s += "}";
+    if (!buf || n == 0) return (int)s.size() + 1;
+    if (s.size() + 1 > n) return -1;
+    memcpy(buf, s.c_str(), s.size() + 1);
     return 0;
 }
 #else

@@ -220,3 +220,18 @@ def run_fullsize_vs_oracle(cfg_tuple, B, T, seed, lib, device, flag_sets, scale=
                 assert e <= TOL_GRAD, "%s: grad rel err %g (flags %d)" % (k, e, flags)
         out["grads"][flags] = (worst, worst_k)
     return out
+
+
+def launch_log(lib, fn):
+    """Run ``fn()`` with the library's per-launch log on; returns {tag: launches}.  (On the GPU the log carries HIP-event
+    times as well -- bench.py's kernel table; the host emulator keeps the counts.)"""
+    import json
+    lib.wn_prof_enable(1)
+    try:
+        fn()
+    finally:
+        lib.wn_prof_enable(0)
+    need = lib.wn_prof_report(None, 0)
+    buf = ctypes.create_string_buffer(max(need, 16))
+    lib.wn_prof_report(buf, len(buf))
+    return {k: v["count"] for k, v in json.loads(buf.value.decode() or "{}").items()}

@@ -322,3 +322,56 @@ def test_split_contraction_interior_and_edge_blocks():
     block each along both axes at T = 160."""
     from pytorchwavenetvocoder_amd import _lib
     PC.run_oracle_vs_engine((64, 6, 64, 256, 3, 2, 2, 16), 1, 160, 46, emu_library(), "cpu", flags=_lib.FLAG_AUX_FUSED, scale=0.1)
+
+
+def test_gate_epilogues_of_the_wide_model_path():
+    """n_resch % 128 == 0 (the recipes' 512): the any-size path runs the gate as the epilogue of the dilated contraction
+    (sigmoid / tanh rows paired by the weight packing) and gate' as the epilogue of the dZ contraction.  R = 128 and 256
+    (one and two 256-row blocks of the forward contraction), ragged T (edge blocks), last layer without a residual input,
+    against the oracle; and against the separate elementwise launches (WN_GATE_EPILOGUE=0, subprocess) at round-off."""
+    PC.run_oracle_vs_engine((64, 6, 128, 128, 2, 2, 2, 16), 2, 160, 51, emu_library(), "cpu", scale=0.1)
+    PC.run_oracle_vs_engine((32, 4, 256, 128, 2, 1, 2, 8), 1, 136, 52, emu_library(), "cpu", scale=0.1)
+    PC.run_oracle_vs_engine((32, 4, 128, 64, 1, 1, 3, 0), 1, 70, 53, emu_library(), "cpu", scale=0.1)   # one layer, K = 3, no upsampling
+    # the launches of a step really are the epilogue variants: no separate gate kernels, no plain dilated contraction
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat
+    cfg_t = (64, 6, 128, 128, 2, 2, 2, 16)
+    cfg = O.OracleConfig(*cfg_t)
+    eng = WaveNetEngine(*cfg_t, device="cpu", library=emu_library())
+    load_state_into_flat(eng, O.random_params(cfg, 1, scale=0.1))
+    x, h, t = O.synthetic_batch(cfg, 1, 160, 2)
+
+    def step():
+        logits = eng.forward(x, h)
+        loss, dl = eng.loss(logits, t)
+        eng.backward(dl)
+    log = PC.launch_log(emu_library(), step)
+    assert log.get("fwd_dilated_gate") == 4 and log.get("bwd_dz_res_gate") == 3 and log.get("bwd_dz_skip_gate") == 1, log
+    assert "gate_fwd" not in log and "gate_bwd" not in log and "fwd_dilated_layered" not in log, log
+
+
+def test_launch_sequence_of_the_default_training_step():
+    """What a default-mode step of a fused-kernel model launches (the host build's launch log): one forward block per
+    layer, ONE all-layer skip-gradient contraction, the gate' head, L - 1 chain launches, the dX tail, the weight-image
+    pack; and the former structure under WN_FLAG_NO_CHAIN."""
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd import _lib
+    from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat
+    cfg_t = (64, 6, 64, 32, 3, 2, 2, 16)
+    cfg = O.OracleConfig(*cfg_t)
+    x, h, t = O.synthetic_batch(cfg, 1, 64, 2)
+    logs = {}
+    for flags in (_lib.FLAG_AUX_FUSED, _lib.FLAG_AUX_FUSED | _lib.FLAG_NO_CHAIN):
+        eng = WaveNetEngine(*cfg_t, device="cpu", library=emu_library())
+        eng.flags = flags
+        load_state_into_flat(eng, O.random_params(cfg, 1, scale=0.1))
+
+        def step():
+            logits = eng.forward(x, h)
+            loss, dl = eng.loss(logits, t)
+            eng.backward(dl)
+        logs[flags] = PC.launch_log(emu_library(), step)
+    a, b = logs[_lib.FLAG_AUX_FUSED], logs[_lib.FLAG_AUX_FUSED | _lib.FLAG_NO_CHAIN]
+    assert a["fused_resblock_fwd"] == 6 and a["fused_bwd_chain"] == 5 and a["fused_bwd_gate"] == 1 and a["fused_bwd_dx"] == 1, a
+    assert a["bwd_dz_skip_all"] == 1 and a["fused_pack_images"] == 1 and "aux_bwd" not in a and a["aux_finish"] >= 1, a
+    assert b["fused_bwd_gate"] == 6 and b["fused_bwd_dx"] == 6 and "fused_bwd_chain" not in b and "bwd_dz_skip_all" not in b, b

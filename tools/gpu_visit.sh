@@ -43,8 +43,10 @@ if has pmc; then
   bash tools/pmc_traffic.sh
 fi
 if has recipesize; then
-  WN_DW_TALL=0 timeout 300 python tools/recipe_bench.py --steps 3 > $OUT/recipe_size_bench_notall.json 2> $OUT/recipe_size_bench.err
-  python -c "import json; d=json.load(open('$OUT/recipe_size_bench_notall.json')); print('recipe size, 128x128 dW tiles: %.1f ms/step' % d['ms_per_step'])"
+  for v in ${WN_RECIPE_VARIANTS:-WN_GATE_EPILOGUE=0 WN_DW_TALL=0}; do
+    env $v timeout 300 python tools/recipe_bench.py --steps 3 > $OUT/recipe_size_bench_$v.json 2> $OUT/recipe_size_bench.err
+    python -c "import json; d=json.load(open('$OUT/recipe_size_bench_$v.json')); print('recipe size, $v: %.1f ms/step' % d['ms_per_step'])"
+  done
   timeout 300 python tools/recipe_bench.py > $OUT/recipe_size_bench.json 2>> $OUT/recipe_size_bench.err; echo "recipe-size bench rc=$?"
   python - <<P
 import json
