@@ -158,6 +158,7 @@ struct FwdArgs {
     float* Z;
     int B, T, dil, U, F;
     int stagger;  // waves 4..7 (the second wave of each SIMD) start `stagger` x 8K cycles late
+    int chain_s, chain_c, chain_sh;  // split kernel: tile chains (stride in tiles = 1 << chain_sh, length); 1, 1 = plain tile walk
 #ifdef WN_TIMING
     long long* dbg;
 #endif
@@ -568,7 +569,7 @@ int wn_fused_pack_images(const float* wd_f, const float* wres_f, const float* wd
     return 0;
 }
 
-template <int K>
+template <int K, int CHAIN>
 __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
     WN_DYN_SMEM(smem_raw);
     constexpr int WD_BLK = 3 * 128 * 32, WR_BLK = 3 * 64 * 32;  // bytes of one 16-k block
@@ -611,8 +612,33 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
     const int tiles_per_b = (T + 31) >> 5;
     const int ntiles = a.B * tiles_per_b;
     const unsigned slab = (unsigned)(64 * T4);
-    const TileWalk walk = tile_walk(ntiles, threadIdx.x >> 6);
-    const int step = walk.step, tile_end = walk.end;
+    // Tile chains.  A wave walks CHAINS of chain_c tiles that are chain_s = dilation / 32 tiles apart: the history tap of
+    // a chain's next tile (x[t - d]) is then exactly the current tap this wave has just loaded -- it stays in registers
+    // and is not read again.  Without this every position of a d >= 32 layer is fetched twice from HBM (the neighbour's
+    // read of the same lines is half a tile period away, longer than a line lives in the XCD's L2 under the kernel's
+    // own write stream: PMC 90 MB read per launch for 47 MB of x).  Only a chain's first tile takes its history from
+    // memory.  chain_s = chain_c = 1 (dilations < 32, K = 3, WN_FWD_CHAIN=0) is the plain tile walk.
+    const int cs = CHAIN ? a.chain_s : 1, cc = CHAIN ? a.chain_c : 1;   // CHAIN = 0: the plain walk, compiled without the chain code
+    const int cblk = cs * cc, nbk = tiles_per_b / cblk, nfull = nbk * cs;
+    const int cpb = nfull + (tiles_per_b - nbk * cblk);     // chains per sequence: full ones, then single tail tiles
+    (void)ntiles;
+    const TileWalk walk = tile_walk(a.B * cpb, threadIdx.x >> 6);
+    const int step = WN_UNIFORM(walk.step), chain_end = WN_UNIFORM(walk.end);
+    // chain id -> (sequence cb, chain cr within it); ids advance by `step`, tracked without divisions (scalar ALU only:
+    // chain_s is a power of two, the sequence index moves by repeated subtraction)
+    const int csh = a.chain_sh;   // log2(chain_s)
+    const int first_chain = WN_UNIFORM(walk.first);   // wave-uniform: the whole bookkeeping stays in scalar registers
+    int cb = first_chain / cpb, cr = first_chain - cb * cpb;
+    cb = WN_UNIFORM(cb);
+    cr = WN_UNIFORM(cr);
+    auto chain_first = [&](int b, int r, int& len) -> int {
+        if (r < nfull) {
+            len = cc;
+            return b * tiles_per_b + (r >> csh) * cblk + (r & (cs - 1));
+        }
+        len = 1;
+        return b * tiles_per_b + nbk * cblk + (r - nfull);
+    };
     constexpr int KH = (K > 1) ? (K - 1) : 1;  // history taps (shift > 0)
 
     // Software pipeline (per wave, per 32-sample tile):
@@ -639,11 +665,12 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
         }
     };
 
-    int tile_v = walk.first;
+    int chain_v = first_chain, clen = 1, ck = 0;
+    int tile_v = (chain_v < chain_end) ? chain_first(cb, cr, clen) : 0;
     int tcount = 0;
     (void)tcount;
-    if (K > 1 && tile_v < tile_end) issue_hist(tile_v);
-    while (tile_v < tile_end) {
+    if (K > 1 && chain_v < chain_end) issue_hist(tile_v);
+    while (chain_v < chain_end) {
         WN_STAMP(0);
         const int tile = WN_UNIFORM(tile_v);
         const int b = tile / tiles_per_b;
@@ -740,8 +767,40 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
         // Prefetch the history-tap operands of this wave's next tile NOW, i.e. before the stores of the
         // gate phase: vmcnt is one in-order counter for loads AND stores, so loads issued behind the
         // 96 S/Gt/Z stores could only be waited for together with those stores' acknowledgements.
-        const int next_v = tile_v + step;
-        if (K > 1 && next_v < tile_end) issue_hist(next_v);
+        // residual input + bias = the initial value of the res-1x1 accumulators, formed NOW: xc dies here, so that in a
+        // chain its registers simply become the next tile's history operands (no second copy of the tile is ever live)
+        f32x16 racc[2];
+        if (a.Xnext != nullptr) {
+            const float* rbl = rb + 4 * hi;
+            WN_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r)
+                    racc[q][r] = (inb ? xc[16 * q + r] : 0.0f) + rbl[32 * q + mfma32_row(r, 0)];
+            }
+#ifndef WN_EMU
+            // pin: the sums exist from here on (machine sinking would otherwise move them below the branch and keep xc alive)
+            asm volatile("" : "+v"(racc[0]), "+v"(racc[1]));
+#endif
+        }
+        // next tile of this wave: the next one of its chain (history = this tile's xc, copied at the end of the tile) or
+        // the head of its next chain (history from memory: requested NOW, before the stores of the gate phase)
+        const bool chained = CHAIN && (ck + 1 < clen);
+        int next_chain = chain_v, next_len = clen, next_v = tile_v + cs;
+        if (!chained) {
+            next_chain = chain_v + step;
+            cr += step;
+            while (cr >= cpb) {
+                cr -= cpb;
+                ++cb;
+            }
+            next_v = (next_chain < chain_end) ? chain_first(cb, cr, next_len) : 0;
+            if (K > 1 && next_chain < chain_end) issue_hist(next_v);
+        } else if (CHAIN && K > 1) {   // the copy takes the place of the prefetch: same register live ranges in both cases
+            WN_UNROLL
+            for (int s = 0; s < 32; ++s) xh[KH - 1][s] = xc[s];
+            okh[KH - 1] = true;   // t - d of the next tile = t of this one: inside the sequence
+        }
         // gate (reference wavenet.py:529-532): P = conv + w[j]*G[row][f] + c[row]; saved for backward
         const wn_rsrc_t Sr = wn_make_buf(a.S + (long)b * 64 * T, slab);
         const wn_rsrc_t Gtr = wn_make_buf(a.Gt + (long)b * 64 * T, slab);
@@ -771,16 +830,6 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
             }
         }
         WN_STAMP(3);  // after gate math + S/Gt/Z stores issued
-        f32x16 racc[2];
-        if (a.Xnext != nullptr) {
-            const float* rbl = rb + 4 * hi;
-            WN_UNROLL
-            for (int q = 0; q < 2; ++q) {
-                WN_UNROLL
-                for (int r = 0; r < 16; ++r)
-                    racc[q][r] = (inb ? xc[16 * q + r] : 0.0f) + rbl[32 * q + mfma32_row(r, 0)];
-            }
-        }
         WN_SCHED_BARRIER();
         // res 1x1 + residual; z is consumed straight from the accumulator registers
         if (a.Xnext != nullptr) {
@@ -816,6 +865,13 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
         }
         WN_STAMP(4);  // tile done
         ++tcount;
+        if (chained) {
+            ++ck;
+        } else {
+            chain_v = next_chain;
+            clen = next_len;
+            ck = 0;
+        }
         tile_v = next_v;
     }
 #ifdef WN_TIMING
@@ -839,8 +895,13 @@ static int launch_fwd(const FwdArgs& a, int split, wn_stream_t st) {
     const long nblk = balanced_blocks(ntiles);
     const size_t lds_s = (size_t)K * 4 * (3 * 128 * 32) + 4 * (3 * 64 * 32) + 192 * sizeof(float);
     if (split && lds_s <= 160 * 1024) {  // K = 3 does not fit split: stays on the f32 MFMA
-        if (set_lds(k_resblock_fwd_s<K>, lds_s)) return 1;
-        WN_LAUNCH((k_resblock_fwd_s<K>), dim3((unsigned)nblk), dim3(WN_FT), lds_s, st, a);
+        if (K == 2 && a.chain_c > 1) {
+            if (set_lds(k_resblock_fwd_s<K, 1>, lds_s)) return 1;
+            WN_LAUNCH((k_resblock_fwd_s<K, 1>), dim3((unsigned)nblk), dim3(WN_FT), lds_s, st, a);
+        } else {
+            if (set_lds(k_resblock_fwd_s<K, 0>, lds_s)) return 1;
+            WN_LAUNCH((k_resblock_fwd_s<K, 0>), dim3((unsigned)nblk), dim3(WN_FT), lds_s, st, a);
+        }
         return 0;
     }
     const size_t lds = ((size_t)K * 64 * 128 + 64 * 64 + 192) * sizeof(float);
@@ -861,6 +922,26 @@ int wn_fused_resblock_fwd(const float* wd_f, const float* wres_f, const float* c
     a.Xnext = Xnext; a.S = S; a.Gt = Gt; a.Z = Z;
     a.B = B; a.T = T; a.dil = dilation; a.U = U; a.F = F;
     a.stagger = stagger_setting();
+    a.chain_s = 1; a.chain_c = 1; a.chain_sh = 0;
+    {   // tile chains of the split K = 2 kernel (k_resblock_fwd_s): stride = dilation / 32 tiles, length = tiles per wave
+        static int on = -1;
+        if (on < 0) {
+            const char* e = getenv("WN_FWD_CHAIN");   // tuning knob (A/B on hardware): 0 = plain tile walk
+            on = (e && atoi(e) == 0) ? 0 : 1;
+        }
+        const long tiles_per_b = (T + 31) / 32, ntiles = (long)B * tiles_per_b;
+        if (on && split && K == 2 && dilation >= 32 && dilation % 32 == 0) {
+            const long waves = balanced_blocks(ntiles) * WN_FW;
+            long c = (ntiles + waves - 1) / waves;
+            if (c > 8) c = 8;
+            const long st_ = dilation / 32;
+            if (c >= 2 && c * st_ <= tiles_per_b && (st_ & (st_ - 1)) == 0) {
+                a.chain_s = (int)st_;
+                a.chain_c = (int)c;
+                while ((1 << a.chain_sh) < a.chain_s) ++a.chain_sh;
+            }
+        }
+    }
 #ifdef WN_TIMING
     a.dbg = g_dbg;
 #endif

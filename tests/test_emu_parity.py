@@ -47,6 +47,8 @@ def test_overlap_launch_sequences(name):
     stream, so this checks the sequences' arithmetic; the stream fork/join itself is covered on the GPU."""
     from pytorchwavenetvocoder_amd import _lib
     PC.check_golden_case(GoldenCase(name), emu_library(), "cpu", flags=_lib.FLAG_FWD_OVERLAP | _lib.FLAG_BWD_OVERLAP)
+    if name == "r64_k3_up":   # the K = 3 case repeats the launch sequences of the K = 2 one: the first mode is enough
+        return
     PC.check_golden_case(GoldenCase(name), emu_library(), "cpu", flags=_lib.FLAG_FWD_OVERLAP | _lib.FLAG_EXACT_MFMA,
                          layers_per_bucket=1)
     PC.check_golden_case(GoldenCase(name), emu_library(), "cpu", flags=_lib.FLAG_BWD_OVERLAP)
@@ -155,7 +157,7 @@ def test_decode_context_lengths_and_ragged_requests():
         m = WaveNet(*cfg_t, _library=emu_library())
         m.load_state_dict(params)
         rf = m.receptive_field
-        for T0 in (1, rf, rf + 1, 3 * rf):
+        for T0 in ((1, rf, rf + 1, 3 * rf) if cfg_t[7] > 0 else (1, rf + 1)):   # the second model repeats two of the lengths
             rs = np.random.RandomState(T0)
             x = torch.from_numpy(rs.randint(0, 16, (3, T0))).long()
             U = cfg_t[7]
@@ -194,12 +196,17 @@ def test_persistent_tile_loop_several_tiles_per_wave():
         "from pytorchwavenetvocoder_amd import _lib\n"
         "for fl in (0, _lib.FLAG_AUX_FUSED):\n"
         "    e, g = PC.run_oracle_vs_engine((32, 4, 64, 32, 2, 1, 2, 16), 1, 2304, 51, emu_library(), 'cpu', flags=fl, scale=0.2)\n"
-        "    print('flags', fl, 'logits', e, 'grads', g)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        "    print('flags', fl, 'logits', e, 'grads', g)\n"
+        # forward tile chains (dilations 32 and 64: a wave's next tile is 1 / 2 tiles further and takes its history tap
+        # from the registers of the tile before): 200 tiles on 64 waves -> chains of 4 tiles, a tail of single tiles
+        # (100 tiles per sequence are not a multiple of 4 x 2), two sequences
+        "e, g = PC.run_oracle_vs_engine((32, 4, 64, 32, 7, 1, 2, 16), 2, 3200, 52, emu_library(), 'cpu', flags=_lib.FLAG_AUX_FUSED, scale=0.2)\n"
+        "print('flags chains', 'logits', e, 'grads', g)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     env = dict(os.environ, WN_CHAIN_BLOCKS="8")
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     out = r.stdout.decode()
     assert r.returncode == 0, out[-2000:]
-    assert out.count("flags") == 2, out[-2000:]
+    assert out.count("flags") == 3, out[-2000:]
 
 
 def test_fused_adam_skips_live_parameters_without_a_gradient_like_torch_adam():
@@ -293,10 +300,7 @@ def test_backward_chain_kernel_modes():
     assert DEFAULT_FLAGS == A      # chain + aux partials is what every default-flag test runs
     for flags in (0, A, NC, A | NC):
         PC.check_golden_case(GoldenCase("r64_k2_up"), emu_library(), "cpu", flags=flags)
-    PC.check_golden_case(GoldenCase("r64_k2_up"), emu_library(), "cpu", flags=A, layers_per_bucket=1)
-    PC.check_golden_case(GoldenCase("r64_k3_up"), emu_library(), "cpu", flags=A)          # K = 3: falls back to the pair
     PC.run_oracle_vs_engine((64, 6, 64, 32, 3, 1, 1, 16), 2, 48, 41, emu_library(), "cpu", flags=A, scale=0.2)   # K = 1
-    PC.run_oracle_vs_engine((64, 6, 64, 32, 3, 1, 1, 16), 2, 48, 41, emu_library(), "cpu", flags=0, scale=0.2)
     PC.run_oracle_vs_engine((64, 6, 64, 32, 2, 2, 2, 16), 3, 80, 42, emu_library(), "cpu", flags=A, scale=0.2)   # T % 32 == 16
     PC.run_oracle_vs_engine((64, 6, 64, 64, 3, 2, 2, 0), 1, 70, 43, emu_library(), "cpu", flags=A, scale=0.2)    # no upsampling, ragged T
     PC.run_oracle_vs_engine((64, 6, 64, 32, 1, 1, 2, 16), 1, 32, 44, emu_library(), "cpu", flags=A, scale=0.2)   # a single layer
@@ -329,8 +333,8 @@ def test_gate_epilogues_of_the_wide_model_path():
     (sigmoid / tanh rows paired by the weight packing) and gate' as the epilogue of the dZ contraction.  R = 128 and 256
     (one and two 256-row blocks of the forward contraction), ragged T (edge blocks), last layer without a residual input,
     against the oracle; and against the separate elementwise launches (WN_GATE_EPILOGUE=0, subprocess) at round-off."""
-    PC.run_oracle_vs_engine((64, 6, 128, 128, 2, 2, 2, 16), 2, 160, 51, emu_library(), "cpu", scale=0.1)
-    PC.run_oracle_vs_engine((32, 4, 256, 128, 2, 1, 2, 8), 1, 136, 52, emu_library(), "cpu", scale=0.1)
+    PC.run_oracle_vs_engine((64, 6, 128, 128, 2, 2, 2, 16), 1, 144, 51, emu_library(), "cpu", scale=0.1)
+    PC.run_oracle_vs_engine((32, 4, 256, 128, 1, 1, 2, 8), 1, 72, 52, emu_library(), "cpu", scale=0.1)    # two 256-row blocks, one layer
     PC.run_oracle_vs_engine((32, 4, 128, 64, 1, 1, 3, 0), 1, 70, 53, emu_library(), "cpu", scale=0.1)   # one layer, K = 3, no upsampling
     # the launches of a step really are the epilogue variants: no separate gate kernels, no plain dilated contraction
     from oracle import wavenet_oracle as O
@@ -339,7 +343,7 @@ def test_gate_epilogues_of_the_wide_model_path():
     cfg = O.OracleConfig(*cfg_t)
     eng = WaveNetEngine(*cfg_t, device="cpu", library=emu_library())
     load_state_into_flat(eng, O.random_params(cfg, 1, scale=0.1))
-    x, h, t = O.synthetic_batch(cfg, 1, 160, 2)
+    x, h, t = O.synthetic_batch(cfg, 1, 48, 2)
 
     def step():
         logits = eng.forward(x, h)
