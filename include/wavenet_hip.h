@@ -142,7 +142,9 @@ size_t wn_workspace_bytes(const WnConfig* cfg, int B, int T);
 /* Introspection for parity tests (since ABI v4; the training path never calls it): offset and length, in floats, of
  * a tensor that wn_forward / wn_backward leave in the workspace of a (B, T) call.  Layouts (time contiguous):
  *   X, SIGMOID, TANH, Z  (L, B, R, T)  layer input x_l, sigmoid(.) and tanh(.) of the gate, z_l = their product
- *                                      (reference wavenet.py:525-536; x_0 = the front conv's output)
+ *                                      (reference wavenet.py:525-536; x_0 = the front conv's output).  TANH is only
+ *                                      written by the any-size kernels: the fused n_resch = 64 kernels save the sigmoid
+ *                                      half and z, and rebuild tanh = z / sigmoid in the backward pass
  *   RELU_SKIP, RELU_POST1 (B, S, T)    relu(sum of skips), relu(conv_post_1(.))  (wavenet.py:519-521): their
  *                                      positivity is the ReLU sub-gradient wn_backward uses
  *   DSKIP (B, S, T), DP (L, B, 2R, T), DX (L, B, R, T)   after wn_backward: dL/d(skip sum), dL/d(gate pre-activations
@@ -171,7 +173,8 @@ int wn_softmax_ce_loss(const WnConfig* cfg, int B, int T, const float* logits, c
 
 /* Backward of wn_forward (what autograd does for train.py:538): writes EVERY element of the flat
  * gradient buffer `grads` (the dead range gets zeros).  `ws` must still hold the matching
- * wn_forward call.  If events != NULL, hipEvent_t events[i] is recorded on `stream` as soon as
+ * wn_forward call, made with the same WN_FLAG_NO_FUSED / WN_FLAG_EXACT_MFMA choice (the two kernel
+ * families save different activations).  If events != NULL, hipEvent_t events[i] is recorded on `stream` as soon as
  * bucket i (wn_bucket_range) is final, so the caller can all-reduce it on another stream. */
 int wn_backward(const WnConfig* cfg, int B, int T, const float* params, const int64_t* x, const float* h,
                 const float* dlogits, float* grads, void* ws, size_t ws_bytes, void* const* events, int n_events,

@@ -560,6 +560,17 @@ static int make_ctx(Ctx* c, const WnConfig* cfg, int B, int T, void* ws, size_t 
     return 0;
 }
 
+// tuning knob (A/B on hardware): WN_SAVE_TANH=1 -> the fused forward also stores the tanh half of the gate (64 words per
+// timestep and layer more) and the fused backward reads it instead of rebuilding it as z / sigmoid
+static bool save_tanh() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("WN_SAVE_TANH");
+        v = (e && atoi(e) != 0) ? 1 : 0;
+    }
+    return v != 0;
+}
+
 // tuning knob (A/B on hardware): WN_GATE_EPILOGUE=0 -> the any-size path runs its gate / gate' as separate elementwise
 // launches again instead of as epilogues of the split contractions (n_resch % 128 == 0)
 static bool gate_epilogues() {
@@ -767,7 +778,9 @@ static int forward_stack(const Ctx& c, const float* params, const int64_t* x, co
         if (c.fused) {
             WN_TRY(wn_fused_resblock_fwd(ws + w.wd_f + (long)l * d.K * d.R * 2 * d.R, ws + w.wres_f + (long)l * d.R * d.R,
                                          ws + w.cvec + (long)l * 2 * d.R, params + lb + y.o_res_b, Xl, Gl, g_bstride, upw, Xn,
-                                         Sl, Gtl, Zl, B, T, d.K, dil, Ue, F, c.split_bf16 ? 1 : 0,
+                                         Sl, /*tanh half: not saved, backward rebuilds it as z / s*/ save_tanh() ? Gtl : nullptr, Zl, B, T,
+                                         d.K, dil, Ue, F,
+                                         c.split_bf16 ? 1 : 0,
                                          (w.img_floats > 0 && use_images()) ? ws + w.img_fwd + (long)l * (w.img_floats / d.L) : nullptr, c.st));
             if (side && (l + 1) % chunk == 0 && l + 1 < d.L) {
                 WN_TRY(side_link(side, c.st, cs->st));  // z of layers [*skip_done, l] is enqueued
@@ -1143,7 +1156,9 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
         const int dil = dilation_of(cfg, l);
         const long lb = layer_base(y, d, l);
         const float* Sl = ws + w.Sg + (long)l * BRT;
-        const float* Gtl = ws + w.Gt + (long)l * BRT;
+        const float* Gtl = ws + w.Gt + (long)l * BRT;   // any-size path only: the fused forward saves s and z = s * tanh
+        const float* Zl = save_tanh() ? Gtl : ws + w.Z + (long)l * BRT;   // second gate operand of the fused kernels
+        const int gz = save_tanh() ? 0 : 1;
         float* dP = ws + w.P + (long)l * P_L;
         const float* dXn = (l + 1 < d.L) ? ws + w.dXall + (long)(l + 1) * BRT : nullptr;  // null: dead (last layer)
         float* dXl = ws + w.dXall + (long)l * BRT;
@@ -1151,18 +1166,18 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
             if (l == d.L - 1) {  // head of the chain: gate' of the last layer straight from dSkip (no dX input)
                 if (aux_fused)
                     WN_TRY(wn_fused_bwd_gate_aux(params + y.skip0 + (long)l * y.ls_skip, params + lb + y.o_res_w, ws + w.dSk, nullptr,
-                                                 Sl, Gtl, dP, ws + w.G + (long)l * 2 * d.R * F, g_bstride, upw, Ue, F,
+                                                 Sl, Zl, gz, dP, ws + w.G + (long)l * 2 * d.R * F, g_bstride, upw, Ue, F,
                                                  ws + w.dGp + (long)l * B * 2 * d.R * (T / 16), ws + w.qp + (long)l * B * T, B, T,
                                                  d.S, c.st));
                 else
                     WN_TRY(wn_fused_bwd_gate(params + y.skip0 + (long)l * y.ls_skip, params + lb + y.o_res_w, ws + w.dSk, nullptr,
-                                             Sl, Gtl, dP, B, T, d.S, 1, c.st));
+                                             Sl, Zl, gz, dP, B, T, d.S, 1, c.st));
             }
             if (l > 0) {  // dX_l from dP_l, and gate' of layer l-1 from it
                 const long lbp = layer_base(y, d, l - 1);
                 WN_TRY(wn_fused_bwd_chain(ws + w.wd_b + (long)l * d.K * 2 * d.R * d.R, dP, dXn, dXl, params + lbp + y.o_res_w,
                                           ws + w.dZs + (long)(l - 1) * d.R * T, zs_bstride, ws + w.Sg + (long)(l - 1) * BRT,
-                                          ws + w.Gt + (long)(l - 1) * BRT, ws + w.P + (long)(l - 1) * P_L,
+                                          (save_tanh() ? ws + w.Gt : ws + w.Z) + (long)(l - 1) * BRT, gz, ws + w.P + (long)(l - 1) * P_L,
                                           ws + w.G + (long)(l - 1) * 2 * d.R * F, g_bstride, upw, Ue, F,
                                           aux_fused ? ws + w.dGp + (long)(l - 1) * B * 2 * d.R * (T / 16) : nullptr,
                                           aux_fused ? ws + w.qp + (long)(l - 1) * B * T : nullptr, B, T, d.K, dil,
@@ -1176,12 +1191,12 @@ extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* param
             // dZ = Wskip^T dSk (+ Wres^T dXn) -> gate' -> dP
             if (aux_fused)
                 WN_TRY(wn_fused_bwd_gate_aux(params + y.skip0 + (long)l * y.ls_skip, params + lb + y.o_res_w, ws + w.dSk, dXn,
-                                             Sl, Gtl, dP, ws + w.G + (long)l * 2 * d.R * F, g_bstride, upw, Ue, F,
+                                             Sl, Zl, gz, dP, ws + w.G + (long)l * 2 * d.R * F, g_bstride, upw, Ue, F,
                                              ws + w.dGp + (long)l * B * 2 * d.R * (T / 16), ws + w.qp + (long)l * B * T, B, T,
                                              d.S, c.st));
             else
                 WN_TRY(wn_fused_bwd_gate(params + y.skip0 + (long)l * y.ls_skip, params + lb + y.o_res_w, ws + w.dSk, dXn, Sl,
-                                         Gtl, dP, B, T, d.S, c.split_bf16 ? 1 : 0, c.st));
+                                         Zl, gz, dP, B, T, d.S, c.split_bf16 ? 1 : 0, c.st));
             WN_TRY(wn_fused_bwd_dx(ws + w.wd_b + (long)l * d.K * 2 * d.R * d.R, dP, dXn, dXl, B, T, d.K, dil, c.split_bf16 ? 1 : 0, c.st));
         } else {
             // dZ = Wskip_l^T dSkip (+ Wres_l^T dX_{l+1}) -> gate' -> dP.  Wide models on the split kernels: gate' is the

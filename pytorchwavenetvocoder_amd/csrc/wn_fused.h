@@ -19,8 +19,10 @@ int wn_fused_resblock_fwd(const float* wd_f, const float* wres_f, const float* c
 
 // dZ = Wskip^T dSkip (+ Wres^T dXn) ; dP = [dZ*g*s*(1-s) ; dZ*s*(1-g^2)]
 // wskip : natural skip_1x1 weight [S][R] ; wres : natural res_1x1 weight [R][R] ; dXn may be NULL.
+// gt_is_z != 0 (all three gate' launchers): `Gt` holds the saved product z = s * tanh instead of the tanh half, which the
+// fused forward then does not store at all (Gt == NULL there); the kernels rebuild g = z / s (s = sigmoid > 0).
 int wn_fused_bwd_gate(const float* wskip, const float* wres, const float* dSk, const float* dXn, const float* S,
-                      const float* Gt, float* dP, int B, int T, int Sch, int split, wn_stream_t st);
+                      const float* Gt, int gt_is_z, float* dP, int B, int T, int Sch, int split, wn_stream_t st);
 
 // The same plus the partial sums of the aux-path gradients (split kernels only; U % 16 == 0, T == U * F), so that dP
 // is not re-read for them (wn_aux_bwd):
@@ -29,8 +31,8 @@ int wn_fused_bwd_gate(const float* wskip, const float* wres, const float* dSk, c
 // A tile's dP sits in the accumulator layout (lane = time): 16-sample groups are DPP rows, and because U % 16 == 0 a
 // frame boundary never cuts one.  wn_aux_finish (wn_elem.h) turns the partials into what wn_aux_bwd produces.
 int wn_fused_bwd_gate_aux(const float* wskip, const float* wres, const float* dSk, const float* dXn, const float* S,
-                          const float* Gt, float* dP, const float* G, long g_bstride, const float* upw, int U, int F, float* dGp,
-                          float* qp, int B, int T, int Sch, wn_stream_t st);
+                          const float* Gt, int gt_is_z, float* dP, const float* G, long g_bstride, const float* upw, int U, int F,
+                          float* dGp, float* qp, int B, int T, int Sch, wn_stream_t st);
 
 // dX[t] = (dXn[t]) + sum_tap Wd_tap^T dP[t + (K-1-tap) d]
 // wd_b : [(tap*2R + o')*R + i] packed weights ; dXn may be NULL.
@@ -46,7 +48,7 @@ int wn_fused_bwd_dx(const float* wd_b, const float* dP, const float* dXn, float*
 // of wn_fused_bwd_gate_aux for layer l-1 (G = that layer's rows of the frame-rate projection).
 int wn_fused_chain_supported(int R, int K, int S);
 int wn_fused_bwd_chain(const float* wd_b, const float* dP, const float* dXn, float* dX, const float* wres_prev, const float* dZs,
-                       long zs_bstride, const float* S, const float* Gt, float* dP_prev, const float* G, long g_bstride,
+                       long zs_bstride, const float* S, const float* Gt, int gt_is_z, float* dP_prev, const float* G, long g_bstride,
                        const float* upw, int U, int F, float* dGp, float* qp, int B, int T, int K, int dilation,
                        const float* img_taps, const float* img_res, wn_stream_t st);
 

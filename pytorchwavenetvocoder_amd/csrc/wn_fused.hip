@@ -343,7 +343,8 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
         if (K > 1 && next_v < tile_end) issue_hist(next_v);
         // gate (reference wavenet.py:529-532): P = conv + w[j]*G[row][f] + c[row]; saved for backward
         const wn_rsrc_t Sr = wn_make_buf(a.S + (long)b * 64 * T, slab);
-        const wn_rsrc_t Gtr = wn_make_buf(a.Gt + (long)b * 64 * T, slab);
+        const bool keep_g = a.Gt != nullptr;   // NULL: the tanh half is not saved (backward rebuilds it as z / s)
+        const wn_rsrc_t Gtr = wn_make_buf((keep_g ? a.Gt : a.S) + (long)b * 64 * T, slab);
         const wn_rsrc_t Zr = wn_make_buf(a.Z + (long)b * 64 * T, slab);
         const float* cvl = cv + 4 * hi;
         f32x16 z[2];
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
                 z[q][r] = zz;
                 if (inb) {
                     wn_buf_store(Sr, s, vcur, row0 * T4);
-                    wn_buf_store(Gtr, g, vcur, row0 * T4);
+                    if (keep_g) wn_buf_store(Gtr, g, vcur, row0 * T4);
                     wn_buf_store(Zr, zz, vcur, row0 * T4);
                 }
             }
@@ -803,7 +804,8 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
         }
         // gate (reference wavenet.py:529-532): P = conv + w[j]*G[row][f] + c[row]; saved for backward
         const wn_rsrc_t Sr = wn_make_buf(a.S + (long)b * 64 * T, slab);
-        const wn_rsrc_t Gtr = wn_make_buf(a.Gt + (long)b * 64 * T, slab);
+        const bool keep_g = a.Gt != nullptr;   // NULL: the tanh half is not saved (backward rebuilds it as z / s)
+        const wn_rsrc_t Gtr = wn_make_buf((keep_g ? a.Gt : a.S) + (long)b * 64 * T, slab);
         const wn_rsrc_t Zr = wn_make_buf(a.Z + (long)b * 64 * T, slab);
         const float* cvl = cv + 4 * hi;
         f32x16 z[2];
@@ -824,7 +826,7 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
                 z[q][r] = zz;
                 if (inb) {
                     wn_buf_store(Sr, s, vcur, row0 * T4);
-                    wn_buf_store(Gtr, g, vcur, row0 * T4);
+                    if (keep_g) wn_buf_store(Gtr, g, vcur, row0 * T4);
                     wn_buf_store(Zr, zz, vcur, row0 * T4);
                 }
             }
@@ -914,7 +916,7 @@ int wn_fused_resblock_fwd(const float* wd_f, const float* wres_f, const float* c
                           const float* G, long g_bstride, const float* upw, float* Xnext, float* S, float* Gt, float* Z, int B,
                           int T, int K, int dilation, int U, int F, int split, const float* wimg, wn_stream_t st) {
     WN_PROF("fused_resblock_fwd", 2.0 * (double)B * T * (K * 64.0 * 128.0 + (Xnext ? 64.0 * 64.0 : 0.0)),
-            4.0 * (double)B * T * 64.0 * (Xnext ? 5.0 : 4.0), st);  // X in; S, Gt, Z (, Xnext) out
+            4.0 * (double)B * T * 64.0 * ((Xnext ? 4.0 : 3.0) + (Gt ? 1.0 : 0.0)), st);  // X in; S, (Gt,) Z (, Xnext) out
     FwdArgs a;
     a.wimg = (split && K <= 2) ? wimg : nullptr;
     a.wd_f = wd_f; a.wres_f = wres_f; a.cvec = cvec; a.res_bias = res_bias;
@@ -926,8 +928,12 @@ int wn_fused_resblock_fwd(const float* wd_f, const float* wres_f, const float* c
     {   // tile chains of the split K = 2 kernel (k_resblock_fwd_s): stride = dilation / 32 tiles, length = tiles per wave
         static int on = -1;
         if (on < 0) {
-            const char* e = getenv("WN_FWD_CHAIN");   // tuning knob (A/B on hardware): 0 = plain tile walk
-            on = (e && atoi(e) == 0) ? 0 : 1;
+            // Opt-in (WN_FWD_CHAIN=1).  Measured on MI355X, same box: 11.71 - 11.77 ms/step with the chains, 11.59 without
+            // (profiles/r02/ab_probe_fwd_chain.txt): the chained instance needs 256 VGPRs + 60 B/lane of scratch (the
+            // plain one 241 / 0) and its waves touch 16-tile runs 48 tiles apart instead of one contiguous span, which
+            // costs more than the ~40 MB of history-tap re-reads per launch it removes.
+            const char* e = getenv("WN_FWD_CHAIN");
+            on = (e && atoi(e) != 0) ? 1 : 0;
         }
         const long tiles_per_b = (T + 31) / 32, ntiles = (long)B * tiles_per_b;
         if (on && split && K == 2 && dilation >= 32 && dilation % 32 == 0) {
@@ -970,7 +976,8 @@ struct ConvArgs {
     int wfloats;  // total LDS floats
     int B, T;
     const float* S;      // MODE 0
-    const float* Gt;     // MODE 0
+    const float* Gt;     // MODE 0: the saved tanh half -- or, with gz != 0, the saved product z = s * tanh (g = z / s)
+    int gz;
     const float* resid;  // MODE 1 (nullable)
     float* out;          // MODE 0: dP (B,128,T) ; MODE 1: dX (B,64,T)
     int stagger;
@@ -1133,7 +1140,7 @@ __global__ __launch_bounds__(WN_FT) void k_conv64(ConvArgs a) {
                     WN_UNROLL
                     for (int r = 0; r < 16; ++r) {
                         const int so = (32 * q + mfma32_row(r, 0)) * T4;
-                        const float s = e0[q][r], g = e1[q][r], dz = acc[q][r];
+                        const float s = e0[q][r], g = a.gz ? e1[q][r] * wn_rcp(e0[q][r]) : e1[q][r], dz = acc[q][r];
                         wn_buf_store(Or, dz * g * (s * (1.0f - s)), vcur, so);
                         wn_buf_store(Or, dz * s * (1.0f - g * g), vcur, so + 64 * T4);
                     }
@@ -1355,7 +1362,7 @@ __global__ __launch_bounds__(WN_FT) void k_conv64s(ConvArgs a) {
                 WN_UNROLL
                 for (int r = 0; r < 16; ++r) {
                     const int so = (32 * q + mfma32_row(r, 0)) * T4;
-                    const float s = e0[q][r], g = e1[q][r], dz = inb ? acc[q][r] : 0.0f;
+                    const float s = e0[q][r], g = a.gz ? e1[q][r] * wn_rcp(e0[q][r]) : e1[q][r], dz = inb ? acc[q][r] : 0.0f;
                     const float dpa = dz * g * (s * (1.0f - s)), dpg = dz * s * (1.0f - g * g);
                     if (inb) {
                         wn_buf_store(Or, dpa, vcur, so);
@@ -1383,7 +1390,7 @@ __global__ __launch_bounds__(WN_FT) void k_conv64s(ConvArgs a) {
                     WN_UNROLL
                     for (int r = 0; r < 16; ++r) {
                         const int so = (32 * q + mfma32_row(r, 0)) * T4;
-                        const float s = e0[q][r], g = e1[q][r], dz = acc[q][r];
+                        const float s = e0[q][r], g = a.gz ? e1[q][r] * wn_rcp(e0[q][r]) : e1[q][r], dz = acc[q][r];
                         wn_buf_store(Or, dz * g * (s * (1.0f - s)), vcur, so);
                         wn_buf_store(Or, dz * s * (1.0f - g * g), vcur, so + 64 * T4);
                     }
@@ -1425,7 +1432,7 @@ static int launch_conv64(const ConvArgs& a, int split, wn_stream_t st) {
 }
 
 int wn_fused_bwd_gate(const float* wskip, const float* wres, const float* dSk, const float* dXn, const float* S, const float* Gt,
-                      float* dP, int B, int T, int Sch, int split, wn_stream_t st) {
+                      int gt_is_z, float* dP, int B, int T, int Sch, int split, wn_stream_t st) {
     WN_PROF("fused_bwd_gate", 2.0 * (double)B * T * 64.0 * (Sch + (dXn ? 64.0 : 0.0)),
             4.0 * (double)B * T * (Sch + (dXn ? 64.0 : 0.0) + 4.0 * 64.0), st);  // dSk (, dXn), S, Gt in; dP out
     ConvArgs a;
@@ -1439,7 +1446,7 @@ int wn_fused_bwd_gate(const float* wskip, const float* wres, const float* dSk, c
         a.wfloats += 64 * 64;
         a.nchunks += 2;
     }
-    a.B = B; a.T = T; a.S = S; a.Gt = Gt; a.resid = nullptr; a.out = dP;
+    a.B = B; a.T = T; a.S = S; a.Gt = Gt; a.gz = gt_is_z; a.resid = nullptr; a.out = dP;
     a.stagger = stagger_setting();
     a.interleave = 0;
     a.G = nullptr; a.g_bstride = 0; a.upw = nullptr; a.U = 0; a.F = 0; a.dGp = nullptr; a.qp = nullptr;
@@ -1447,8 +1454,8 @@ int wn_fused_bwd_gate(const float* wskip, const float* wres, const float* dSk, c
 }
 
 int wn_fused_bwd_gate_aux(const float* wskip, const float* wres, const float* dSk, const float* dXn, const float* S,
-                          const float* Gt, float* dP, const float* G, long g_bstride, const float* upw, int U, int F, float* dGp,
-                          float* qp, int B, int T, int Sch, wn_stream_t st) {
+                          const float* Gt, int gt_is_z, float* dP, const float* G, long g_bstride, const float* upw, int U, int F,
+                          float* dGp, float* qp, int B, int T, int Sch, wn_stream_t st) {
     WN_PROF("fused_bwd_gate", 2.0 * (double)B * T * 64.0 * (Sch + (dXn ? 64.0 : 0.0)),
             4.0 * (double)B * T * (Sch + (dXn ? 64.0 : 0.0) + 4.0 * 64.0 + 9.0), st);  // + dGp (8/timestep) and qp (1) out
     if (U < 16 || (U & 15) || (T & 15) || (long)U * F != T) return 1;
@@ -1463,7 +1470,7 @@ int wn_fused_bwd_gate_aux(const float* wskip, const float* wres, const float* dS
         a.wfloats += 64 * 64;
         a.nchunks += 2;
     }
-    a.B = B; a.T = T; a.S = S; a.Gt = Gt; a.resid = nullptr; a.out = dP;
+    a.B = B; a.T = T; a.S = S; a.Gt = Gt; a.gz = gt_is_z; a.resid = nullptr; a.out = dP;
     a.stagger = stagger_setting();
     a.interleave = 0;
     a.G = G; a.g_bstride = g_bstride; a.upw = upw; a.U = U; a.F = F; a.dGp = dGp; a.qp = qp;
@@ -1486,7 +1493,7 @@ int wn_fused_bwd_dx(const float* wd_b, const float* dP, const float* dXn, float*
     }
     a.wfloats = K * 128 * 64;
     a.nchunks = K * 4;
-    a.B = B; a.T = T; a.S = nullptr; a.Gt = nullptr; a.resid = dXn; a.out = dX;
+    a.B = B; a.T = T; a.S = nullptr; a.Gt = nullptr; a.gz = 0; a.resid = dXn; a.out = dX;
     a.stagger = stagger_setting();
     // The taps of one 32-channel group are consumed back to back: position p is read as tap K-1 by the wave of its
     // own tile and as an earlier tap by the wave d samples away, and with [tap][channel] order those two reads of the
@@ -1527,7 +1534,8 @@ struct ChainArgs {
     const float* dZs;    // skip part of dZ_{l-1}: rows [0, 64) at dZs + b * zs_bstride, row stride T
     long zs_bstride;
     const float* S;      // (B, 64, T) sigmoid / tanh halves of layer l-1 (saved by the forward)
-    const float* Gt;
+    const float* Gt;     // with gz != 0: the saved product z = s * tanh instead of the tanh half (g = z / s)
+    int gz;
     float* dPm;          // (B, 128, T) out: dP_{l-1}
     int B, T, K, dil;
     int stagger;
@@ -1743,7 +1751,7 @@ __global__ __launch_bounds__(WN_FT) void k_chain64s(ChainArgs a) {
                 WN_UNROLL
                 for (int r = 0; r < 16; ++r) {
                     const int so = (32 * q + mfma32_row(r, 0)) * T4;
-                    const float s = e0[q][r], g = e1[q][r], dzv = inb ? dz[q][r] : 0.0f;
+                    const float s = e0[q][r], g = a.gz ? e1[q][r] * wn_rcp(e0[q][r]) : e1[q][r], dzv = inb ? dz[q][r] : 0.0f;
                     const float dpa = dzv * g * (s * (1.0f - s)), dpg = dzv * s * (1.0f - g * g);
                     if (inb) {
                         wn_buf_store(Or, dpa, vcur, so);
@@ -1768,7 +1776,7 @@ __global__ __launch_bounds__(WN_FT) void k_chain64s(ChainArgs a) {
                 WN_UNROLL
                 for (int r = 0; r < 16; ++r) {
                     const int so = (32 * q + mfma32_row(r, 0)) * T4;
-                    const float s = e0[q][r], g = e1[q][r], dzv = dz[q][r];
+                    const float s = e0[q][r], g = a.gz ? e1[q][r] * wn_rcp(e0[q][r]) : e1[q][r], dzv = dz[q][r];
                     wn_buf_store(Or, dzv * g * (s * (1.0f - s)), vcur, so);
                     wn_buf_store(Or, dzv * s * (1.0f - g * g), vcur, so + 64 * T4);
                 }
@@ -1783,7 +1791,7 @@ int wn_fused_chain_supported(int R, int K, int S) {
 }
 
 int wn_fused_bwd_chain(const float* wd_b, const float* dP, const float* dXn, float* dX, const float* wres_prev, const float* dZs,
-                       long zs_bstride, const float* S, const float* Gt, float* dP_prev, const float* G, long g_bstride,
+                       long zs_bstride, const float* S, const float* Gt, int gt_is_z, float* dP_prev, const float* G, long g_bstride,
                        const float* upw, int U, int F, float* dGp, float* qp, int B, int T, int K, int dilation,
                        const float* img_taps, const float* img_res, wn_stream_t st) {
     // dP (, dXn), dZs, S, Gt in; dX, dP_prev out (+ dGp 8 / qp 1 words per timestep with the aux partials)
@@ -1795,7 +1803,7 @@ int wn_fused_bwd_chain(const float* wd_b, const float* dP, const float* dXn, flo
     ChainArgs a;
     a.img_taps = (img_taps && img_res) ? img_taps : nullptr; a.img_res = img_res;
     a.wd_b = wd_b; a.dP = dP; a.dXn = dXn; a.dX = dX;
-    a.wres = wres_prev; a.dZs = dZs; a.zs_bstride = zs_bstride; a.S = S; a.Gt = Gt; a.dPm = dP_prev;
+    a.wres = wres_prev; a.dZs = dZs; a.zs_bstride = zs_bstride; a.S = S; a.Gt = Gt; a.gz = gt_is_z; a.dPm = dP_prev;
     a.B = B; a.T = T; a.K = K; a.dil = dilation;
     a.stagger = stagger_setting();
     a.G = G; a.g_bstride = g_bstride; a.upw = upw; a.U = U; a.F = F; a.dGp = dGp; a.qp = qp;

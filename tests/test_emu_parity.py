@@ -197,12 +197,12 @@ def test_persistent_tile_loop_several_tiles_per_wave():
         "for fl in (0, _lib.FLAG_AUX_FUSED):\n"
         "    e, g = PC.run_oracle_vs_engine((32, 4, 64, 32, 2, 1, 2, 16), 1, 2304, 51, emu_library(), 'cpu', flags=fl, scale=0.2)\n"
         "    print('flags', fl, 'logits', e, 'grads', g)\n"
-        # forward tile chains (dilations 32 and 64: a wave's next tile is 1 / 2 tiles further and takes its history tap
+        # forward tile chains (opt-in WN_FWD_CHAIN=1; dilations 32 and 64: a wave's next tile is 1 / 2 tiles further and takes its history tap
         # from the registers of the tile before): 200 tiles on 64 waves -> chains of 4 tiles, a tail of single tiles
         # (100 tiles per sequence are not a multiple of 4 x 2), two sequences
         "e, g = PC.run_oracle_vs_engine((32, 4, 64, 32, 7, 1, 2, 16), 2, 3200, 52, emu_library(), 'cpu', flags=_lib.FLAG_AUX_FUSED, scale=0.2)\n"
         "print('flags chains', 'logits', e, 'grads', g)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    env = dict(os.environ, WN_CHAIN_BLOCKS="8")
+    env = dict(os.environ, WN_CHAIN_BLOCKS="8", WN_FWD_CHAIN="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     out = r.stdout.decode()
     assert r.returncode == 0, out[-2000:]
@@ -270,13 +270,22 @@ def test_saved_workspace_regions_and_given_relu_subgradient():
     assert torch.equal(lg0, lg1) and torch.equal(l0, l1)
     for k in g0:
         assert (g0[k] is None and g1[k] is None) or torch.equal(g0[k], g1[k]), k
-    X, S, G, Z = (eng.saved(k) for k in (_lib.WS_X, _lib.WS_SIGMOID, _lib.WS_TANH, _lib.WS_Z))
+    X, S, Z = (eng.saved(k) for k in (_lib.WS_X, _lib.WS_SIGMOID, _lib.WS_Z))
     L = len(cfg.dilations)
     assert tuple(X.shape) == (L, 2, 64, 96)
     for l in range(L):
         ref = inter["x0"] if l == 0 else inter["layer_out"][l - 1]
         assert float((X[l] - ref).abs().max()) <= 1e-5, l
-    assert float((S * G - Z).abs().max()) <= 1e-6 and float(S.min()) >= 0.0 and float(G.abs().max()) <= 1.0
+    # the fused kernels save the sigmoid half and z = sigmoid * tanh (the tanh half is rebuilt as z / s in backward) ...
+    assert float(S.min()) > 0.0 and float(S.max()) <= 1.0 and float((Z / S).abs().max()) <= 1.0 + 1e-6
+    # ... the any-size kernels save all three
+    eng2 = WaveNetEngine(*cfg_t, device="cpu", library=emu_library())
+    eng2.flags = _lib.FLAG_NO_FUSED
+    load_state_into_flat(eng2, params)
+    eng2.forward(x, h)
+    S2, G2, Z2 = (eng2.saved(k) for k in (_lib.WS_SIGMOID, _lib.WS_TANH, _lib.WS_Z))
+    assert float((S2 * G2 - Z2).abs().max()) <= 1e-6 and float(G2.abs().max()) <= 1.0
+    assert float((S2 - S).abs().max()) <= 1e-5 and float((Z2 - Z).abs().max()) <= 1e-5
     eng.backward(dl)
     dP, dX, dSk = eng.saved(_lib.WS_DP), eng.saved(_lib.WS_DX), eng.saved(_lib.WS_DSKIP)
     assert tuple(dP.shape) == (L, 2, 128, 96) and tuple(dX.shape) == (L, 2, 64, 96) and tuple(dSk.shape) == (2, 64, 96)
