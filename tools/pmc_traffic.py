@@ -2,7 +2,12 @@
 # -*- coding: utf-8 -*-
 """HBM traffic per kernel launch from two rocprofv3 counter passes (tools/pmc_traffic.sh):
 
-    python tools/pmc_traffic.py <dir of the --pmc FETCH_SIZE pass> <dir of the --pmc WRITE_SIZE pass> <steps> [bench log] > pmc_traffic.json
+    python tools/pmc_traffic.py <dir of the --pmc FETCH_SIZE pass> <dir of the --pmc WRITE_SIZE pass> <steps> [bench log] [dir of
+        the --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE pass] > pmc_traffic.json
+
+MFMA utilisation of a kernel = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024): the busy counter is in cycles summed
+over the chip's 1024 SIMDs (32 per v_mfma_f32_32x32x16_bf16: the chain kernel's 5 760 tiles x 240 MFMAs x 32 = 44 236 800 is
+reproduced exactly), GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md, counter notes).
 
 bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KB; on gfx950 FETCH_SIZE tallies the 128-byte fabric
 requests at 64 bytes (MI355X_MICROARCH.md, section HBM) -- calibrated on this code's own dword buffer accesses: the
@@ -18,7 +23,7 @@ from pmc_summary import summarize  # noqa: E402
 
 # bench.py tag -> kernel symbol(s) that implement it (the first one present in the trace is reported)
 TAGS = {"fused_bwd_gate": ["void k_conv64s<2>(ConvArgs)", "void k_conv64s<0>(ConvArgs)"],
-        "fused_resblock_fwd": ["void k_resblock_fwd_s<2>(FwdArgs)"],
+        "fused_resblock_fwd": ["void k_resblock_fwd_s<2, 0>(FwdArgs)", "void k_resblock_fwd_s<2, 1>(FwdArgs)", "void k_resblock_fwd_s<2>(FwdArgs)"],
         "fused_bwd_dx": ["void k_conv64s<1>(ConvArgs)"],
         "fused_bwd_chain": ["void k_chain64s<1, 2>(ChainArgs)", "void k_chain64s<0, 2>(ChainArgs)", "void k_chain64s<1, 1>(ChainArgs)",
                             "void k_chain64s<0, 1>(ChainArgs)"]}
@@ -54,6 +59,19 @@ def main():
                         "write_size_kb": write.get(name, {}).get("WRITE_SIZE"),
                         "hbm_bytes_per_launch": (2.0 * fetch.get(name, {}).get("FETCH_SIZE", 0.0) +
                                                  write.get(name, {}).get("WRITE_SIZE", 0.0)) * 1024.0}
+    if len(sys.argv) > 5:
+        mf = summarize([sys.argv[5]])
+        util = {}
+        for k, v in mf.items():
+            act = v.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+            if act > 0:
+                util[k[:80]] = {"mfma_util": v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (act * 1024.0), "active_cycles": act,
+                                "mfma_busy_cycles": v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), "launches": v.get("launches", 0)}
+        out["_mfma_util_per_kernel"] = util
+        for tag, names in TAGS.items():
+            name = next((n for n in names if n[:80] in util), None)
+            if name is not None and tag in out:
+                out[tag]["mfma_util"] = util[name[:80]]["mfma_util"]
     out["_engine_flags"] = engine_flags_of(sys.argv[4]) if len(sys.argv) > 4 else None
     out["_step_total_bytes"] = total / steps
     out["_per_kernel_bytes_per_launch"] = per

@@ -12,7 +12,7 @@ timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc/fetch -- 
 timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc/write -- $CMD > $OUT/pmc/write.log 2>&1; echo "write rc=$?"
 timeout 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc/mfma -- $CMD > $OUT/pmc/mfma.log 2>&1; echo "mfma rc=$?"
 cd $ROOT
-python tools/pmc_traffic.py $OUT/pmc/fetch $OUT/pmc/write 3 $OUT/pmc/fetch.log > $OUT/pmc_traffic.json; echo "summary rc=$?"
+python tools/pmc_traffic.py $OUT/pmc/fetch $OUT/pmc/write 3 $OUT/pmc/fetch.log $OUT/pmc/mfma > $OUT/pmc_traffic.json; echo "summary rc=$?"
 python tools/pmc_summary.py $OUT/pmc/mfma > $OUT/pmc_mfma.json; echo "mfma summary rc=$?"
 python - <<'P'
 import json
