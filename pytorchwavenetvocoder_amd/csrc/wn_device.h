@@ -175,6 +175,20 @@ static __device__ __forceinline__ f32x2 wn_pk_fma(f32x2 a, f32x2 b, f32x2 c) { r
 #define WN_UNROLL_N(n) WN_PRAGMA(unroll n)
 #endif
 
+// bf16 fragment rows in LDS are 32 bytes = [16 k], read with ds_read_b128 by lane (li, hi) at row li, k half hi.  With the
+// plain placement `row * 32 + half * 16` the 16 lanes the hardware services together ({0-3, 12-15, 20-27}, ... of one
+// lane half: MI355X_MICROARCH.md, LDS) land on only 8 of the 16 16-byte slots of a bank row -- every fragment read is a
+// 2-way bank conflict.  Swapping the two halves of the rows whose index has bit 3 set makes the 16 slots distinct:
+// byte offset of (row, half) inside a [rows][16 k] piece.  Writers and readers use the same function.
+// -DWN_NO_FRAG_SWIZZLE restores the plain placement (A/B builds).
+static __host__ __device__ __forceinline__ int wn_frag_off(int row, int half) {
+#ifdef WN_NO_FRAG_SWIZZLE
+    return row * 32 + half * 16;
+#else
+    return row * 32 + ((half ^ ((row >> 3) & 1)) << 4);
+#endif
+}
+
 // Row (M index) of accumulator register r for a lane whose upper-half flag is hi (= lane>>5).
 static __device__ __forceinline__ int mfma32_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 

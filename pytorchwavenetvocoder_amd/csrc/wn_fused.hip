@@ -487,11 +487,11 @@ static __device__ __forceinline__ void fill_fwd_image(char* Wd, char* Wr, const 
     for (int idx = tid; idx < K * 4 * 2 * 128; idx += nthr) {
         const int o = idx & 127, h = (idx >> 7) & 1, blk = idx >> 8;  // blk = tap*4 + kb
         const int tap = blk >> 2, kb = blk & 3;
-        split_to_lds(wd_f + (long)(tap * 64 + 16 * kb + 4 * h) * 128 + o, 128, Wd + blk * WD_BLK + o * 32 + h * 16, 128 * 32);
+        split_to_lds(wd_f + (long)(tap * 64 + 16 * kb + 4 * h) * 128 + o, 128, Wd + blk * WD_BLK + wn_frag_off(o, h), 128 * 32);
     }
     for (int idx = tid; idx < 4 * 2 * 64; idx += nthr) {
         const int o = idx & 63, h = (idx >> 6) & 1, kb = idx >> 7;
-        split_to_lds(wres_f + (long)(16 * kb + 4 * h) * 64 + o, 64, Wr + kb * WR_BLK + o * 32 + h * 16, 64 * 32);
+        split_to_lds(wres_f + (long)(16 * kb + 4 * h) * 64 + o, 64, Wr + kb * WR_BLK + wn_frag_off(o, h), 64 * 32);
     }
 }
 // tap blocks of the chain kernel: chunk q (32 channels) = tap q % K, channel group q / K; two 6 KB blocks per chunk
@@ -508,14 +508,14 @@ static __device__ __forceinline__ void fill_chain_taps(char* W, const float* wd_
         wn_f4 bf[3];
         split8(x, bf);
         WN_UNROLL
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<wn_f4*>(W + kbg * 6144 + p * 2048 + o * 32 + h * 16) = bf[p];
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<wn_f4*>(W + kbg * 6144 + p * 2048 + wn_frag_off(o, h)) = bf[p];
     }
 }
 // Wres^T of the gate half: natural res_1x1 weight [k = o][row = i], k order = accumulator register order
 static __device__ __forceinline__ void fill_res_t(char* Wr, const float* wres, int tid, int nthr) {
     for (int idx = tid; idx < 4 * 2 * 64; idx += nthr) {
         const int o = idx & 63, h = (idx >> 6) & 1, kb = idx >> 7;
-        split_to_lds(wres + (long)(16 * kb + 4 * h) * 64 + o, 64, Wr + kb * 6144 + o * 32 + h * 16, 2048);
+        split_to_lds(wres + (long)(16 * kb + 4 * h) * 64 + o, 64, Wr + kb * 6144 + wn_frag_off(o, h), 2048);
     }
 }
 // `bytes` (a multiple of 1024) from a 16-byte aligned global image to the start of the dynamic LDS, 16 bytes per lane
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
                 for (int e = 0; e < 8; ++e) x8[e] = okh[tap] ? xh[tap][8 * kb + e] : 0.0f;
                 wn_f4 bf[3];
                 split8(x8, bf);
-                const char* Wl = Wd + (tap * 4 + kb) * WD_BLK + li * 32 + hi * 16;
+                const char* Wl = Wd + (tap * 4 + kb) * WD_BLK + wn_frag_off(li, hi);
                 constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};  // small terms first
                 WN_UNROLL
                 for (int qh = 0; qh < 4; qh += 2) {  // two row tiles at a time (register budget)
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
                 for (int e = 0; e < 8; ++e) x8[e] = inb ? xc[8 * kb + e] : 0.0f;
                 wn_f4 bf[3];
                 split8(x8, bf);
-                const char* Wl = Wd + ((K - 1) * 4 + kb) * WD_BLK + li * 32 + hi * 16;
+                const char* Wl = Wd + ((K - 1) * 4 + kb) * WD_BLK + wn_frag_off(li, hi);
                 constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
                 WN_UNROLL
                 for (int qh = 0; qh < 4; qh += 2) {  // two row tiles at a time (register budget)
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
                 for (int e = 0; e < 8; ++e) x8[e] = z[(8 * kb + e) >> 4][(8 * kb + e) & 15];
                 wn_f4 bf[3];
                 split8(x8, bf);
-                const char* Wl = Wr + kb * WR_BLK + li * 32 + hi * 16;
+                const char* Wl = Wr + kb * WR_BLK + wn_frag_off(li, hi);
                 wn_f4 af[2][3];
                 WN_UNROLL
                 for (int q = 0; q < 2; ++q) {
@@ -1194,7 +1194,7 @@ __global__ __launch_bounds__(WN_FT) void k_conv64s(ConvArgs a) {
             mq[q] = wn_pk_bf16(r0, r1);
             lq[q] = wn_pk_bf16(r0 - wn_bits_f32(mq[q] << 16), r1 - wn_bits_f32(mq[q] & 0xffff0000u));
         }
-        unsigned* d = reinterpret_cast<unsigned*>(W + kbg * 6144 + o * 32 + h * 16);
+        unsigned* d = reinterpret_cast<unsigned*>(W + kbg * 6144 + wn_frag_off(o, h));
         WN_UNROLL
         for (int q = 0; q < 4; ++q) {
             d[q] = hq[q];
@@ -1269,7 +1269,7 @@ __global__ __launch_bounds__(WN_FT) void k_conv64s(ConvArgs a) {
             bf[0].x = wn_bits_f32(hq[0]); bf[0].y = wn_bits_f32(hq[1]); bf[0].z = wn_bits_f32(hq[2]); bf[0].w = wn_bits_f32(hq[3]);
             bf[1].x = wn_bits_f32(mq[0]); bf[1].y = wn_bits_f32(mq[1]); bf[1].z = wn_bits_f32(mq[2]); bf[1].w = wn_bits_f32(mq[3]);
             bf[2].x = wn_bits_f32(lq[0]); bf[2].y = wn_bits_f32(lq[1]); bf[2].z = wn_bits_f32(lq[2]); bf[2].w = wn_bits_f32(lq[3]);
-            const char* Wl = W + (2 * q + blk) * 6144 + li * 32 + hi * 16;
+            const char* Wl = W + (2 * q + blk) * 6144 + wn_frag_off(li, hi);
             wn_f4 af[2][3];
             WN_UNROLL
             for (int rt = 0; rt < 2; ++rt) {
@@ -1607,7 +1607,7 @@ __global__ __launch_bounds__(WN_FT) void k_chain64s(ChainArgs a) {
             for (int e = 0; e < 8; ++e) x8[e] = xr[8 * blk + e];
             wn_f4 bf[3];
             split8v(x8, okr, bf);
-            const char* Wl = W + (2 * q + blk) * 6144 + li * 32 + hi * 16;
+            const char* Wl = W + (2 * q + blk) * 6144 + wn_frag_off(li, hi);
             wn_f4 af[2][3];
             WN_UNROLL
             for (int rt = 0; rt < 2; ++rt) {
@@ -1695,7 +1695,7 @@ __global__ __launch_bounds__(WN_FT) void k_chain64s(ChainArgs a) {
             for (int e = 0; e < 8; ++e) x8[e] = acc[kb >> 1][8 * (kb & 1) + e];
             wn_f4 bf[3];
             split8(x8, bf);
-            const char* Wl = Wr + kb * 6144 + li * 32 + hi * 16;
+            const char* Wl = Wr + kb * 6144 + wn_frag_off(li, hi);
             wn_f4 af[2][3];
             WN_UNROLL
             for (int rt = 0; rt < 2; ++rt) {

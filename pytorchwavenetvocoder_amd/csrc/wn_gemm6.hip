@@ -81,13 +81,15 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g) {
     float rb0[8], rb1[8];  // activations are fetched two steps ahead (HBM latency), weights one (L2)
     const int bn = tid & 127, bkh = tid >> 7;  // this thread's B column and k half (8 k values)
     const bool n_ok = (n0 + bn) < g.N;
+    const int a_voff = (tid >> 1) * 32 + (wn_frag_off(tid >> 1, tid & 1) & 16);   // global byte offset of that k half
     auto fetch_a = [&](int kb, int st) {
         char* sa = smem_raw + st * ST_BYTES + wave_u * 1024;
         WN_UNROLL
         for (int p = 0; p < 3; ++p) {
             const unsigned src = kb < nk ? (unsigned)((kb * 3 + p) * g.Mpad + m0) * 32u : 0xfffff000u;  // past the end: zeros
-            wn_buf_load_lds16(Ar, sa + p * (WN_G6_BM * 32), tid * 16, src);
-            wn_buf_load_lds16(Ar, sa + p * (WN_G6_BM * 32) + 4096, tid * 16, src + 4096u);
+            // slot tid of the piece = row tid >> 1, stored half tid & 1, which holds the k half wn_frag_off says
+            wn_buf_load_lds16(Ar, sa + p * (WN_G6_BM * 32), a_voff, src);
+            wn_buf_load_lds16(Ar, sa + p * (WN_G6_BM * 32) + 4096, a_voff, src + 4096u);
         }
     };
     auto fetch_b = [&](int kb, float (&rb)[8]) {
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g) {
             md[q] = wn_pk_bf16(r0, r1);
             lo[q] = wn_pk_bf16(r0 - wn_bits_f32(md[q] << 16), r1 - wn_bits_f32(md[q] & 0xffff0000u));
         }
-        char* sb = sa + A_BYTES + bn * 32 + bkh * 16;
+        char* sb = sa + A_BYTES + wn_frag_off(bn, bkh);
         wn_f4 v;
         v.x = wn_bits_f32(h[0]); v.y = wn_bits_f32(h[1]); v.z = wn_bits_f32(h[2]); v.w = wn_bits_f32(h[3]);
         *reinterpret_cast<wn_f4*>(sb) = v;
@@ -143,14 +145,14 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g) {
         for (int p = 0; p < 3; ++p) {
             WN_UNROLL
             for (int j = 0; j < 2; ++j)
-                bf[p][j] = *reinterpret_cast<const wn_f4*>(sb + p * (WN_G6_BN * 32) + (64 * wn + 32 * j + li) * 32 + hi * 16);
+                bf[p][j] = *reinterpret_cast<const wn_f4*>(sb + p * (WN_G6_BN * 32) + wn_frag_off(64 * wn + 32 * j + li, hi));
         }
         WN_UNROLL
         for (int i = 0; i < 4; ++i) {
             wn_f4 af[3];
             WN_UNROLL
             for (int p = 0; p < 3; ++p)
-                af[p] = *reinterpret_cast<const wn_f4*>(sa + p * (WN_G6_BM * 32) + (128 * wm + 32 * i + li) * 32 + hi * 16);
+                af[p] = *reinterpret_cast<const wn_f4*>(sa + p * (WN_G6_BM * 32) + wn_frag_off(128 * wm + 32 * i + li, hi));
             // small terms first; the two column tiles alternate so that back-to-back MFMAs never
             // depend on each other (a dependent 32x32x16 issues ~25% slower)
             constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
@@ -503,11 +505,13 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6_dw(WnGemmArgs g) {
             md[q] = wn_pk_bf16(r0, r1);
             lo[q] = wn_pk_bf16(r0 - wn_bits_f32(md[q] << 16), r1 - wn_bits_f32(md[q] & 0xffff0000u));
         }
-        char* d = base + row * 32 + kofs * 2;
         const unsigned* src[3] = {h, md, lo};
         for (int p = 0; p < 3; ++p) {
-            unsigned* o = reinterpret_cast<unsigned*>(d + p * rows * 32);
-            for (int q = 0; q < E / 2; ++q) o[q] = src[p][q];
+            char* d = base + p * rows * 32;
+            for (int q = 0; q < E / 2; ++q) {   // dword kq of the row: k half kq >> 2 (placement: wn_frag_off), dword kq & 3 of it
+                const int kq = (kofs >> 1) + q;
+                *reinterpret_cast<unsigned*>(d + wn_frag_off(row, kq >> 2) + (kq & 3) * 4) = src[p][q];
+            }
         }
     };
     auto stage = [&](int st, const float (&ra)[AE], const float (&rb)[BE]) {
@@ -534,14 +538,14 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6_dw(WnGemmArgs g) {
         for (int p = 0; p < 3; ++p) {
             WN_UNROLL
             for (int j = 0; j < TN; ++j)
-                bf[p][j] = *reinterpret_cast<const wn_f4*>(sb + p * (BN * 32) + ((wn * TN + j) * 32 + li) * 32 + hi * 16);
+                bf[p][j] = *reinterpret_cast<const wn_f4*>(sb + p * (BN * 32) + wn_frag_off((wn * TN + j) * 32 + li, hi));
         }
         WN_UNROLL
         for (int i = 0; i < TM; ++i) {
             wn_f4 af[3];
             WN_UNROLL
             for (int p = 0; p < 3; ++p)
-                af[p] = *reinterpret_cast<const wn_f4*>(sa + p * (BM * 32) + ((wm * TM + i) * 32 + li) * 32 + hi * 16);
+                af[p] = *reinterpret_cast<const wn_f4*>(sa + p * (BM * 32) + wn_frag_off((wm * TM + i) * 32 + li, hi));
             constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
             WN_UNROLL
             for (int t = 0; t < 6; ++t) {

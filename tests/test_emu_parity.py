@@ -198,9 +198,9 @@ def test_persistent_tile_loop_several_tiles_per_wave():
         "    e, g = PC.run_oracle_vs_engine((32, 4, 64, 32, 2, 1, 2, 16), 1, 2304, 51, emu_library(), 'cpu', flags=fl, scale=0.2)\n"
         "    print('flags', fl, 'logits', e, 'grads', g)\n"
         # forward tile chains (opt-in WN_FWD_CHAIN=1; dilations 32 and 64: a wave's next tile is 1 / 2 tiles further and takes its history tap
-        # from the registers of the tile before): 200 tiles on 64 waves -> chains of 4 tiles, a tail of single tiles
-        # (100 tiles per sequence are not a multiple of 4 x 2), two sequences
-        "e, g = PC.run_oracle_vs_engine((32, 4, 64, 32, 7, 1, 2, 16), 2, 3200, 52, emu_library(), 'cpu', flags=_lib.FLAG_AUX_FUSED, scale=0.2)\n"
+        # from the registers of the tile before): 100 tiles on 64 waves -> chains of 2 tiles, a tail of single tiles
+        # (100 tiles per sequence are not a multiple of 4 x 2)
+        "e, g = PC.run_oracle_vs_engine((32, 4, 64, 32, 7, 1, 2, 16), 1, 3200, 52, emu_library(), 'cpu', flags=_lib.FLAG_AUX_FUSED, scale=0.2)\n"
         "print('flags chains', 'logits', e, 'grads', g)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     env = dict(os.environ, WN_CHAIN_BLOCKS="8", WN_FWD_CHAIN="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
