@@ -48,3 +48,15 @@ def test_aux_gradient_modes_agree_and_match_the_oracle():
         res.append(eng.backward(dl, layers_per_bucket=10).clone())
     assert torch.equal(res[1], res[2])
     assert float((res[1] - res[0]).abs().max()) <= 1e-5 * float(res[0].abs().max())
+
+
+def test_chain_kernel_ragged_shapes():
+    """The one-launch-per-layer backward chain on shapes the big cases do not have: a half-full last tile (T % 32 == 16),
+    three sequences, kernel_size 1, a single layer (head + tail only), no upsampling layer (aux partials fall back)."""
+    from pytorchwavenetvocoder_amd import _lib as L
+    A = L.FLAG_AUX_FUSED
+    for cfg_t, B, T, seed, flags in [((64, 6, 64, 32, 2, 2, 2, 16), 3, 80, 42, A), ((64, 6, 64, 32, 3, 1, 1, 16), 2, 48, 41, A),
+                                     ((64, 6, 64, 32, 1, 1, 2, 16), 1, 32, 44, A), ((64, 6, 64, 64, 3, 2, 2, 0), 1, 70, 43, A),
+                                     ((64, 6, 64, 32, 2, 2, 2, 16), 3, 80, 42, 0), ((256, 8, 64, 128, 5, 2, 2, 32), 2, 2080, 45, A)]:
+        e, g = PC.run_oracle_vs_engine(cfg_t, B, T, seed, _lib(), DEV, flags=flags, scale=0.2 if cfg_t[3] < 128 else 0.1)
+        print("chain ragged", cfg_t, B, T, "logits %.3g grads %.3g" % (e, g))
