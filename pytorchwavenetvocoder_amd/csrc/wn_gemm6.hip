@@ -461,6 +461,7 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6_dw(WnGemmArgs g) {
     const int b_sh = b_rowshift[b_row];
     const bool a_tile_ok = (m0 + BM) <= g.M, b_tile_ok = (n0 + BN) <= g.N;
     float rowsum = 0.f;
+    const float b_floor = g.b_relu ? 0.f : -__builtin_inff();
 
     auto fetch = [&](int k0, float (&ra)[AE], float (&rb)[BE]) {
         const bool full = (k0 + 16) <= kend;
@@ -490,10 +491,6 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6_dw(WnGemmArgs g) {
                 rb[e] = (b_off >= 0 && k < kend && cc >= 0 && cc < g.b_clen) ? Bz[b_off + cc] : 0.f;
             }
         }
-        if (g.b_relu) {
-            WN_UNROLL
-            for (int e = 0; e < BE; ++e) rb[e] = fmaxf(rb[e], 0.f);
-        }
     };
     // split E consecutive-k values and write the three pieces of row `row` at k offset `kofs`
     auto split_store = [&](char* base, int rows, int row, int kofs, const float* v, int E) {
@@ -514,14 +511,21 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6_dw(WnGemmArgs g) {
             }
         }
     };
-    auto stage = [&](int st, const float (&ra)[AE], const float (&rb)[BE]) {
+    auto stage = [&](int st, const float (&ra)[AE], const float (&rb)[BE], bool counted = true) {
         char* sa = smem_raw + st * ST_BYTES;
         if (g.a_rowsum != nullptr) {
+            float rs = 0.f;
             WN_UNROLL
-            for (int e = 0; e < AE; ++e) rowsum += ra[e];
+            for (int e = 0; e < AE; ++e) rs += ra[e];
+            rowsum += counted ? rs : 0.f;
         }
         split_store(sa, BM, a_row, a_k, ra, AE);
-        split_store(sa + A_BYTES, BN, b_row, b_k, rb, BE);
+        // the optional ReLU on B is a floor applied HERE, not at the load: anything that touches the loaded registers
+        // right after the load makes the wait for them land before the MFMAs they were supposed to hide under
+        float rbf[BE];
+        WN_UNROLL
+        for (int e = 0; e < BE; ++e) rbf[e] = fmaxf(rb[e], b_floor);
+        split_store(sa + A_BYTES, BN, b_row, b_k, rbf, BE);
     };
 
     f32x16 acc[TM][TN];
@@ -555,28 +559,94 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6_dw(WnGemmArgs g) {
         }
     };
 
+    // Branch-free loads of an INTERIOR step (whole tile inside M x N, 16 k inside this k-chunk, every shifted tap inside its
+    // sequence): two or four 16-byte loads per thread, nothing conditional -- so the interior pass below has no control
+    // flow between a load and its use and the compiler keeps counted vmcnt waits.  (With the conditional fetch of the
+    // general pass inside the pipelined loop it merged the two register sets through copies at the loop header and put
+    // an `s_waitcnt vmcnt(0)` in front of every iteration: the loads were never in flight under the MFMAs.)
+    auto fetch_fast = [&](int k0, float (&ra)[AE], float (&rb)[BE]) {
+        WN_UNROLL
+        for (int q = 0; q < AE / 4; ++q) {
+            const wn_f4 v = wn_ld4_unaligned(Az + a_off + k0 + a_k + 4 * q);
+            ra[4 * q] = v.x; ra[4 * q + 1] = v.y; ra[4 * q + 2] = v.z; ra[4 * q + 3] = v.w;
+        }
+        WN_UNROLL
+        for (int q = 0; q < BE / 4; ++q) {
+            const wn_f4 v = wn_ld4_unaligned(Bz + b_off + (k0 + b_k + 4 * q - b_sh));
+            rb[4 * q] = v.x; rb[4 * q + 1] = v.y; rb[4 * q + 2] = v.z; rb[4 * q + 3] = v.w;
+        }
+    };
+    // One pipelined pass over the steps [k_lo, k_lo + 16 n): loads two steps ahead of the MFMAs in two register sets, LDS
+    // double buffered; the accumulators carry over between passes.  FAST: n is even and every step is interior; the
+    // loads past the last step re-read the last step (harmless, never staged) so that nothing in the loop is conditional.
+    auto pass_general = [&](int k_lo, int n) {
+        float ra0[AE], rb0[BE], ra1[AE], rb1[BE];
+        if (n > 0) fetch(k_lo, ra0, rb0);
+        if (n > 1) fetch(k_lo + 16, ra1, rb1);
+        if (n > 0) stage(0, ra0, rb0);
+        __syncthreads();
+        for (int kb = 0; kb < n; kb += 2) {
+            // even step: registers set 0 is free, set 1 holds step kb+1
+            if (kb + 2 < n) fetch(k_lo + (kb + 2) * 16, ra0, rb0);
+            WN_SCHED_BARRIER();
+            compute(0);
+            WN_SCHED_BARRIER();
+            if (kb + 1 < n) stage(1, ra1, rb1);
+            __syncthreads();
+            if (kb + 1 >= n) break;
+            // odd step
+            if (kb + 3 < n) fetch(k_lo + (kb + 3) * 16, ra1, rb1);
+            WN_SCHED_BARRIER();
+            compute(1);
+            WN_SCHED_BARRIER();
+            if (kb + 2 < n) stage(0, ra0, rb0);
+            __syncthreads();
+        }
+    };
+    auto pass_fast = [&](int k_lo, int n) {   // n even, >= 2
+        float ra0[AE], rb0[BE], ra1[AE], rb1[BE];
+        const int k_last = k_lo + (n - 1) * 16;
+        fetch_fast(k_lo, ra0, rb0);
+        fetch_fast(k_lo + 16, ra1, rb1);
+        stage(0, ra0, rb0);
+        __syncthreads();
+        for (int kb = 0; kb < n; kb += 2) {
+            const int ka = k_lo + (kb + 2) * 16, kc = k_lo + (kb + 3) * 16;
+            fetch_fast(ka < k_last ? ka : k_last, ra0, rb0);
+            WN_SCHED_BARRIER();
+            compute(0);
+            WN_SCHED_BARRIER();
+            stage(1, ra1, rb1);
+            __syncthreads();
+            fetch_fast(kc < k_last ? kc : k_last, ra1, rb1);
+            WN_SCHED_BARRIER();
+            compute(1);
+            WN_SCHED_BARRIER();
+            stage(0, ra0, rb0, kb + 2 < n);   // past the end: a copy of the last step that nobody reads (nor counts)
+            __syncthreads();
+        }
+    };
+    // interior steps of this block's k-chunk: [k_a, k_b) in units of 16 from kbeg
     const int nk = (kend > kbeg) ? (kend - kbeg + 15) / 16 : 0;
-    float ra0[AE], rb0[BE], ra1[AE], rb1[BE];
-    if (nk > 0) fetch(kbeg, ra0, rb0);
-    if (nk > 1) fetch(kbeg + 16, ra1, rb1);
-    if (nk > 0) stage(0, ra0, rb0);
-    __syncthreads();
-    for (int kb = 0; kb < nk; kb += 2) {
-        // even step: registers set 0 is free, set 1 holds step kb+1
-        if (kb + 2 < nk) fetch(kbeg + (kb + 2) * 16, ra0, rb0);
-        WN_SCHED_BARRIER();
-        compute(0);
-        WN_SCHED_BARRIER();
-        if (kb + 1 < nk) stage(1, ra1, rb1);
-        __syncthreads();
-        if (kb + 1 >= nk) break;
-        // odd step
-        if (kb + 3 < nk) fetch(kbeg + (kb + 3) * 16, ra1, rb1);
-        WN_SCHED_BARRIER();
-        compute(1);
-        WN_SCHED_BARRIER();
-        if (kb + 2 < nk) stage(0, ra0, rb0);
-        __syncthreads();
+    int s_a = 0, s_b = 0;
+    if (a_tile_ok && b_tile_ok && nk > 0) {
+        // step s (k0 = kbeg + 16 s) is interior iff k0 + 16 <= kend, k0 - b_shmax >= 0 and k0 + 16 - b_shmin <= b_clen
+        int lo = b_shmax - kbeg;                 // k0 >= b_shmax
+        lo = lo > 0 ? (lo + 15) / 16 : 0;
+        int hi_k = kend < g.b_clen + b_shmin ? kend : g.b_clen + b_shmin;   // k0 + 16 <= hi_k
+        int hi_s = (hi_k - kbeg) / 16;           // steps [0, hi_s) satisfy k0 + 16 <= hi_k
+        if (hi_s > nk) hi_s = nk;
+        if (hi_s - lo >= 4) {
+            s_a = lo;
+            s_b = lo + ((hi_s - lo) & ~1);
+        }
+    }
+    if (s_b > s_a) {
+        pass_general(kbeg, s_a);
+        pass_fast(kbeg + 16 * s_a, s_b - s_a);
+        pass_general(kbeg + 16 * s_b, nk - s_b);
+    } else {
+        pass_general(kbeg, nk);
     }
 
     if (g.a_rowsum != nullptr) {
