@@ -52,6 +52,10 @@ static inline void wn_buf_load_lds16(wn_rsrc_t r, char* lds_wave_base, int voff,
 #define WN_SLEEP(n)
 #define WN_SGB_DS(n)
 #define WN_SGB_MFMA(n)
+#define WN_SGB_VALU(n)
+#define WN_SCHED_FENCE_ALU()
+#define WN_SGB_DSW(n)
+#define WN_SGB_VMEM(n)
 // workgroup barrier that orders LDS traffic only (outstanding global loads stay in flight)
 #define WN_LDS_BARRIER() __syncthreads()
 // load that must observe earlier stores of other waves of the same workgroup (bypasses the L1)
@@ -124,9 +128,14 @@ static __device__ __forceinline__ float4 wn_buf_load4(wn_rsrc_t r, int voff, uns
 // scheduling fence: hipcc may not move instructions across it (pins software-pipeline issue order)
 #define WN_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #define WN_SLEEP(n) __builtin_amdgcn_s_sleep(n)
+// fence for VALU, MFMA and global-memory instructions: only LDS and scalar instructions may still be moved across it
+#define WN_SCHED_FENCE_ALU() __builtin_amdgcn_sched_barrier(0x384)
 // scheduling groups: "the next n DS reads" / "the next n MFMAs" are emitted as a block in this order
 #define WN_SGB_DS(n) __builtin_amdgcn_sched_group_barrier(0x100, (n), 0)
 #define WN_SGB_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, (n), 0)
+#define WN_SGB_VALU(n) __builtin_amdgcn_sched_group_barrier(0x002, (n), 0)
+#define WN_SGB_DSW(n) __builtin_amdgcn_sched_group_barrier(0x200, (n), 0)
+#define WN_SGB_VMEM(n) __builtin_amdgcn_sched_group_barrier(0x020, (n), 0)
 // s_barrier preceded by lgkmcnt(0) only: LDS writes are visible afterwards, while prefetched
 // global loads stay outstanding (a __syncthreads() would also wait for vmcnt(0)).
 #define WN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")

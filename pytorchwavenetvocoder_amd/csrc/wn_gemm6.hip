@@ -61,7 +61,68 @@ int wn_gemm6_pack(const float* src, long lda, int M, int K, unsigned short* Apk,
     return 0;
 }
 
-__global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g) {
+// ---------------------------------------------------------------------------------------------
+// block order.  Workgroups are dealt to the 8 XCDs round-robin by their linear id (x fastest), and every XCD has its own
+// L2.  The blocks that read the SAME operand tile (the M-tiles of one time tile in k_gemm6, the N- and M-tiles of one
+// k-chunk in k_gemm6_dw) differ in ONE grid coordinate, so with the plain order they land on different XCDs -- or on the
+// same one a whole grid row later -- and each fetches the shared tile from HBM again (bwd_dz_skip_all: dSkip 8 times).
+// `wn_block_order` renumbers: XCD j gets the contiguous range [j * per, (j + 1) * per) of a logical order in which the
+// sharing coordinate runs fastest, so the sharers are neighbours in time on one XCD and the tile comes out of its L2.
+//   order 0: plain blockIdx; 1: logical order x, y, z (x fastest); 2: logical order y, x, z (y fastest).
+// ---------------------------------------------------------------------------------------------
+struct WnBlock { int x, y, z; };
+__device__ inline WnBlock wn_block_order(int order) {
+    WnBlock r;
+    r.x = (int)blockIdx.x; r.y = (int)blockIdx.y; r.z = (int)blockIdx.z;
+    if (order == 0) return r;
+    const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+    const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned per = total >> 3;
+    unsigned p = lin;
+    if (lin < (per << 3)) p = (lin & 7u) * per + (lin >> 3);   // the last total % 8 blocks keep their id
+    if (order == 1) {
+        r.x = (int)(p % gx); p /= gx;
+        r.y = (int)(p % gy); r.z = (int)(p / gy);
+    } else {
+        r.y = (int)(p % gy); p /= gy;
+        r.x = (int)(p % gx); r.z = (int)(p / gx);
+    }
+    return r;
+}
+static int xcd_block_order() {   // WN_XCD_ORDER=0: plain blockIdx in both kernels (A/B)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("WN_XCD_ORDER");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v;
+}
+
+// Timing builds only (tools/gemm_timing.py, -DWN_TIMING): cycle stamps of the k-loop phases, waves of the block that
+// gets logical tile (0, 0, 0), first 24 steps, for the launches whose tag was selected with wn_debug_gemm6().
+#ifdef WN_TIMING
+#include <string.h>
+static long long* g6_dbg_buf = nullptr;
+static char g6_dbg_tag[64] = "";
+extern "C" void wn_debug_gemm6(void* buf, const char* tag) {
+    g6_dbg_buf = (long long*)buf;
+    strncpy(g6_dbg_tag, tag ? tag : "", sizeof(g6_dbg_tag) - 1);
+}
+static long long* g6_dbg_for(const char* tag) { return (g6_dbg_buf && tag && strcmp(tag, g6_dbg_tag) == 0) ? g6_dbg_buf : nullptr; }
+#define G6_DBG_PARAM , long long* dbg
+#define G6_DBG_ARG(tag) , g6_dbg_for(tag)
+#define G6_STAMP(step, slot)                                                                                          \
+    do {                                                                                                              \
+        if (dbg && dbg_blk && (threadIdx.x & 63) == 0 && (step) < 24)                                                  \
+            dbg[(threadIdx.x >> 6) * 256 + (step) * 8 + (slot)] = (long long)__builtin_readcyclecounter();            \
+    } while (0)
+#else
+#define G6_DBG_PARAM
+#define G6_DBG_ARG(tag)
+#define G6_STAMP(step, slot)
+#endif
+
+__global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_DBG_PARAM) {
     WN_DYN_SMEM(smem_raw);
     // stage s: A pieces [3][256][16] bf16 (24 KB) then B pieces [3][128][16] bf16 (12 KB)
     constexpr int A_BYTES = 3 * WN_G6_BM * 32, B_BYTES = 3 * WN_G6_BN * 32, ST_BYTES = A_BYTES + B_BYTES;
@@ -69,8 +130,12 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g) {
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const int b = blockIdx.z;
-    const int m0 = blockIdx.y * WN_G6_BM, n0 = blockIdx.x * WN_G6_BN;
+    const WnBlock blk = wn_block_order(order);
+    const int b = WN_UNIFORM(blk.z);
+    const int m0 = WN_UNIFORM(blk.y) * WN_G6_BM, n0 = WN_UNIFORM(blk.x) * WN_G6_BN;
+#ifdef WN_TIMING
+    const bool dbg_blk = (blk.x | blk.y | blk.z) == 0;
+#endif
     const float* __restrict__ Bz = g.B + (long)b * g.b_zstride;
     const int nk = (g.K + 15) / 16;
     const bool one_seg = g.b_seg_len >= g.K;
@@ -82,46 +147,54 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g) {
     const int bn = tid & 127, bkh = tid >> 7;  // this thread's B column and k half (8 k values)
     const bool n_ok = (n0 + bn) < g.N;
     const int a_voff = (tid >> 1) * 32 + (wn_frag_off(tid >> 1, tid & 1) & 16);   // global byte offset of that k half
+    // Loads never leave the operands: a step index past the end is clamped to the last step (its data is then simply not
+    // used), a row past K to row K - 1 (the packed weights are zero there, k_gemm6_pack), so nothing in the loop depends on
+    // how the hardware range-checks the scalar offset.  Only the per-lane COLUMN offset carries an out-of-range marker
+    // (zero history / columns past N read as 0).
     auto fetch_a = [&](int kb, int st) {
         char* sa = smem_raw + st * ST_BYTES + wave_u * 1024;
+        const int kc = kb < nk ? kb : nk - 1;
         WN_UNROLL
         for (int p = 0; p < 3; ++p) {
-            const unsigned src = kb < nk ? (unsigned)((kb * 3 + p) * g.Mpad + m0) * 32u : 0xfffff000u;  // past the end: zeros
+            const unsigned src = (unsigned)((kc * 3 + p) * g.Mpad + m0) * 32u;
             // slot tid of the piece = row tid >> 1, stored half tid & 1, which holds the k half wn_frag_off says
             wn_buf_load_lds16(Ar, sa + p * (WN_G6_BM * 32), a_voff, src);
             wn_buf_load_lds16(Ar, sa + p * (WN_G6_BM * 32) + 4096, a_voff, src + 4096u);
         }
     };
-    auto fetch_b = [&](int kb, float (&rb)[8]) {
-        const int k0 = kb * 16;
-        int seg = 0, rr0 = k0;
-        if (!one_seg) {
-            seg = k0 / g.b_seg_len;
-            rr0 = k0 - seg * g.b_seg_len;
-        }
-        // buffer loads: rows past K / columns past N get an out-of-range offset and read as 0 without
-        // a branch (a predicated load becomes a branch with its own vmcnt(0) and serialises the loads)
-        const int rows = one_seg ? g.K : g.b_seg_len;
-        const wn_rsrc_t Br = wn_make_buf(Bz + (long)seg * g.b_seg_stride, (unsigned)((long)rows * g.ldb * 4));
-        const int krem = g.K - (k0 + 8 * bkh);  // valid rows of this thread's 8
-        const int cc = n0 + bn - (g.b_shift0 + seg * g.b_shift_step);  // shifted column: zero history outside [0, clen)
-        const bool c_ok = n_ok && cc >= 0 && cc < g.b_clen;
-        const int base = ((rr0 + 8 * bkh) * (int)g.ldb + cc) * 4;
+    const int bkh_u = WN_UNIFORM(bkh);
+    // fetch_b is called for the steps 0, 1, 2, ... in order: the segment and the row inside it advance with the calls
+    // (no division, no branch: the step function must stay ONE basic block for its scheduling fences to mean anything)
+    const int seg_rows = one_seg ? nk * 16 : g.b_seg_len;
+    int fb_k0 = 0, fb_seg = 0, fb_rr = 0;
+    auto fetch_b = [&](float (&rb)[8]) {
+        const wn_rsrc_t Br = wn_make_buf(Bz + (long)fb_seg * g.b_seg_stride, (unsigned)((long)(one_seg ? g.K : g.b_seg_len) * g.ldb * 4));
+        const int cc = n0 + bn - (g.b_shift0 + fb_seg * g.b_shift_step);  // shifted column: zero history outside [0, clen)
+        const int voff = (n_ok && cc >= 0 && cc < g.b_clen) ? cc * 4 : 0x7ffffff0;
+        const int rlast = g.K - 1 - (fb_k0 - fb_rr);   // last valid row of this segment (>= 0: the step starts inside K)
         WN_UNROLL
-        for (int e = 0; e < 8; ++e) rb[e] = wn_buf_load(Br, (c_ok && e < krem) ? base + e * (int)g.ldb * 4 : 0x7ffffff0, 0);
+        for (int e = 0; e < 8; ++e) {   // the row offsets are wave-uniform: scalar registers, no vector arithmetic per load
+            int r = fb_rr + 8 * bkh_u + e;
+            r = r < rlast ? r : rlast;
+            rb[e] = wn_buf_load(Br, voff, r * (int)g.ldb * 4);
+        }
+        // next step; a step past the end stays on the last one (its data is not used)
+        const bool more = fb_k0 + 16 < nk * 16;
+        const bool wrap = fb_rr + 16 >= seg_rows;
+        fb_k0 = more ? fb_k0 + 16 : fb_k0;
+        fb_seg = (more && wrap) ? fb_seg + 1 : fb_seg;
+        fb_rr = more ? (wrap ? 0 : fb_rr + 16) : fb_rr;
     };
-    auto stage = [&](int st, const float (&rb)[8]) {
-        char* sa = smem_raw + st * ST_BYTES;
-        unsigned h[4], md[4], lo[4];
-        WN_UNROLL
-        for (int q = 0; q < 4; ++q) {
-            const float x0 = rb[2 * q], x1 = rb[2 * q + 1];
-            h[q] = wn_pk_bf16(x0, x1);
-            const float r0 = x0 - wn_bits_f32(h[q] << 16), r1 = x1 - wn_bits_f32(h[q] & 0xffff0000u);
-            md[q] = wn_pk_bf16(r0, r1);
-            lo[q] = wn_pk_bf16(r0 - wn_bits_f32(md[q] << 16), r1 - wn_bits_f32(md[q] & 0xffff0000u));
-        }
-        char* sb = sa + A_BYTES + wn_frag_off(bn, bkh);
+    // split of one pair of this thread's 8 activations into its three bf16 pieces (9 VALU instructions)
+    auto split_pair = [&](int q, const float (&rb)[8], unsigned (&h)[4], unsigned (&md)[4], unsigned (&lo)[4]) {
+        const float x0 = rb[2 * q], x1 = rb[2 * q + 1];
+        h[q] = wn_pk_bf16(x0, x1);
+        const float r0 = x0 - wn_bits_f32(h[q] << 16), r1 = x1 - wn_bits_f32(h[q] & 0xffff0000u);
+        md[q] = wn_pk_bf16(r0, r1);
+        lo[q] = wn_pk_bf16(r0 - wn_bits_f32(md[q] << 16), r1 - wn_bits_f32(md[q] & 0xffff0000u));
+    };
+    auto write_pieces = [&](int st, const unsigned (&h)[4], const unsigned (&md)[4], const unsigned (&lo)[4]) {
+        char* sb = smem_raw + st * ST_BYTES + A_BYTES + wn_frag_off(bn, bkh);
         wn_f4 v;
         v.x = wn_bits_f32(h[0]); v.y = wn_bits_f32(h[1]); v.z = wn_bits_f32(h[2]); v.w = wn_bits_f32(h[3]);
         *reinterpret_cast<wn_f4*>(sb) = v;
@@ -130,6 +203,12 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g) {
         v.x = wn_bits_f32(lo[0]); v.y = wn_bits_f32(lo[1]); v.z = wn_bits_f32(lo[2]); v.w = wn_bits_f32(lo[3]);
         *reinterpret_cast<wn_f4*>(sb + 2 * WN_G6_BN * 32) = v;
     };
+    auto stage = [&](int st, const float (&rb)[8]) {
+        unsigned h[4], md[4], lo[4];
+        WN_UNROLL
+        for (int q = 0; q < 4; ++q) split_pair(q, rb, h, md, lo);
+        write_pieces(st, h, md, lo);
+    };
 
     f32x16 acc[4][2];
     WN_UNROLL
@@ -137,9 +216,20 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g) {
         acc[i][0] = f32x16_zero();
         acc[i][1] = f32x16_zero();
     }
-    auto compute = [&](int st) {
+    // One k-step.  The 48 MFMAs on LDS stage `st` carry everything else of the step in their shadow: a wave's own
+    // independent VALU / memory instructions issue between its MFMAs for free (measured, tools/microbench/mfma_valu.hip: up
+    // to 6 VALU per 32x32x16 MFMA at no cost), whereas as separate phases before / after the MFMAs the same instructions
+    // cost the wave ~1000 (loads) + ~1500 (split) cycles per step in which it issued no MFMA (tools/gemm_timing.py).
+    //   after row tile 0: the weight slab of step `ka` -> LDS stage stn (6 LDS-DMA instructions), split of pair 0
+    //   after row tile 1: the activations of the step after next -> registers rbn (8 loads),     split of pair 1
+    //   after row tiles 2, 3: split of pairs 2, 3;   then the three LDS writes of the split pieces (stage stn)
+    // The fences pin this order for VALU, MFMA and memory instructions; LDS reads (the next row tile's fragments) and scalar
+    // instructions may cross them.  The slab is issued BEFORE the activation loads, so "at most 8 loads outstanding" at the
+    // end of the step == "the weight slab has landed in LDS" (vmcnt retires in order).
+    auto step = [&](int st, int stn, const float (&rb)[8], float (&rbn)[8], int ka, bool last) {
         const char* sa = smem_raw + st * ST_BYTES;
         const char* sb = sa + A_BYTES;
+        unsigned h[4], md[4], lo[4];
         wn_f4 bf[3][2];
         WN_UNROLL
         for (int p = 0; p < 3; ++p) {
@@ -161,39 +251,41 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g) {
                 WN_UNROLL
                 for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(af[PA[t]], bf[PB[t]][j], acc[i][j]);
             }
+            if (last) continue;   // the final step has nothing to prepare
+            WN_SCHED_FENCE_ALU();
+            if (i == 0) fetch_a(ka, stn);
+            if (i == 1) fetch_b(rbn);
+            split_pair(i, rb, h, md, lo);
+            WN_SCHED_FENCE_ALU();
         }
+        if (!last) write_pieces(stn, h, md, lo);
     };
-    // The weight slab of step s+1 is issued FIRST in step s, the activation loads of step s+2 after it,
-    // so "at most 8 loads outstanding" == "the weight slab has landed in LDS" (vmcnt retires in order).
-    // Steps are processed in pairs with the two register sets swapping roles; steps past the end read
-    // out-of-range offsets (zeros) and add nothing, which keeps the loop body branch-free.
-    const int nk2 = (nk + 1) & ~1;
+    // Steps are processed in pairs with the two register sets swapping roles.  Entering a pair (kb, kb + 1): LDS stage 0
+    // holds step kb (weights and split activations), rb1 the activations of step kb + 1, rb0 is free.
     fetch_a(0, 0);
-    fetch_b(0, rb0);
-    fetch_b(1, rb1);
+    fetch_b(rb0);
+    fetch_b(rb1);
     stage(0, rb0);
     WN_WAIT_VMCNT(8);
     __syncthreads();
-    for (int kb = 0; kb < nk2; kb += 2) {
-        // even step: LDS stage 0 holds step kb, rb1 holds step kb+1, rb0 is free
-        fetch_a(kb + 1, 1);
-        fetch_b(kb + 2, rb0);
-        WN_SCHED_BARRIER();  // the loads stay in flight during the MFMAs
-        compute(0);
-        WN_SCHED_BARRIER();
-        stage(1, rb1);
+    const int npair = nk >> 1;
+    for (int kp = 0; kp < npair; ++kp) {
+        const int kb = 2 * kp;
+        G6_STAMP(kb, 0);
+        step(0, 1, rb1, rb0, kb + 1, false);
+        G6_STAMP(kb, 3);
         WN_WAIT_VMCNT(8);
+        G6_STAMP(kb, 4);
         __syncthreads();
-        // odd step
-        fetch_a(kb + 2, 0);
-        fetch_b(kb + 3, rb1);
-        WN_SCHED_BARRIER();
-        compute(1);
-        WN_SCHED_BARRIER();
-        stage(0, rb0);
+        G6_STAMP(kb, 5);
+        step(1, 0, rb0, rb1, kb + 2, false);
+        G6_STAMP(kb + 1, 3);
         WN_WAIT_VMCNT(8);
+        G6_STAMP(kb + 1, 4);
         __syncthreads();
+        G6_STAMP(kb + 1, 5);
     }
+    if (nk & 1) step(0, 1, rb1, rb0, 0, true);   // odd number of steps: the last one is staged in LDS stage 0
     WN_WAIT_VMCNT(0);
 
     // epilogue: bias, mask, relu; rows of a lane are (r&3) + 8*(r>>2) + 4*hi, its column is li.
@@ -382,7 +474,11 @@ int wn_gemm6_launch(const WnGemm6Args* gp, wn_stream_t st) {
     }
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.nbatch <= 0) return 1;
     if (g.b_seg_len < g.K && (g.b_seg_len % 16) != 0) return 2;
+#ifdef WN_TIMING
+    const int lds = getenv("WN_G6_ONE_PER_CU") ? 120 * 1024 : 2 * (3 * WN_G6_BM * 32 + 3 * WN_G6_BN * 32);   // experiment: no second block on the CU
+#else
     constexpr int lds = 2 * (3 * WN_G6_BM * 32 + 3 * WN_G6_BN * 32);
+#endif
 #ifndef WN_EMU
     static bool attr_set = false;
     if (!attr_set) {
@@ -395,7 +491,7 @@ int wn_gemm6_launch(const WnGemm6Args* gp, wn_stream_t st) {
     WN_PROF(g.tag ? g.tag : "gemm6", 2.0 * g.M * g.N * (double)g.K * g.nbatch,
             ((double)g.M * g.K * 6.0 + (double)g.K * g.N * 4.0 + (double)g.M * g.N * (g.E ? 8.0 : 4.0)) * g.nbatch, st);
     dim3 grid((unsigned)((g.N + WN_G6_BN - 1) / WN_G6_BN), (unsigned)(g.Mpad / WN_G6_BM), (unsigned)g.nbatch);
-    WN_LAUNCH(k_gemm6, grid, dim3(G6_T), lds, st, g);
+    WN_LAUNCH(k_gemm6, grid, dim3(G6_T), lds, st, g, xcd_block_order() ? 2 : 0 G6_DBG_ARG(g.tag));
     return 0;
 }
 
@@ -408,7 +504,7 @@ int wn_gemm6_launch(const WnGemm6Args* gp, wn_stream_t st) {
 // into the fragment layout [piece][row][16 k].  The loads run two steps ahead of the MFMAs (two
 // register sets), LDS is double buffered.
 template <int TM, int TN>
-__global__ __launch_bounds__(G6_T, 2) void k_gemm6_dw(WnGemmArgs g) {
+__global__ __launch_bounds__(G6_T, (TM * TN > 4 ? 2 : 3)) void k_gemm6_dw(WnGemmArgs g, int order G6_DBG_PARAM) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int AE = BM / 16, BE = BN / 16;            // fp32 elements per thread and step
     constexpr int A_BYTES = 3 * BM * 32, B_BYTES = 3 * BN * 32, ST_BYTES = A_BYTES + B_BYTES;
@@ -420,7 +516,11 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6_dw(WnGemmArgs g) {
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const int z = blockIdx.z;
+    const WnBlock blk = wn_block_order(order);
+    const int z = WN_UNIFORM(blk.z);
+#ifdef WN_TIMING
+    const bool dbg_blk = (blk.x | blk.y | blk.z) == 0;
+#endif
     const int zl = z / (g.nbatch * g.ksplit);
     const int zr = z - zl * (g.nbatch * g.ksplit);
     const int b = zr / g.ksplit;
@@ -429,7 +529,8 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6_dw(WnGemmArgs g) {
     const int sh0 = g.b_shift0 * dmul, shstep = g.b_shift_step * dmul;
     const int kbeg = ks * g.kchunk;
     const int kend = (g.K - kbeg > g.kchunk) ? (kbeg + g.kchunk) : g.K;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int bx = WN_UNIFORM(blk.x);
+    const int m0 = WN_UNIFORM(blk.y) * BM, n0 = bx * BN;
     const float* __restrict__ Az = g.A + (long)zl * g.a_lstride + (long)b * g.a_zstride;
     const float* __restrict__ Bz = g.B + (long)zl * g.b_lstride + (long)b * g.b_zstride;
     const bool one_seg = g.b_seg_len >= g.N;
@@ -603,6 +704,79 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6_dw(WnGemmArgs g) {
             __syncthreads();
         }
     };
+    // One interior k-step: the TM x TN x 6 MFMAs on LDS stage `st` with everything else of the step in their shadow (see
+    // k_gemm6: a wave's own independent VALU / memory instructions issue between its MFMAs for free, as separate phases they
+    // cost the wave more cycles than the MFMAs themselves).  After every group of TN MFMAs comes one slice of the rest:
+    // first the loads of the step after next, then the split of the next step's operands pair by pair (A, then B), each
+    // operand's three LDS writes right after its last pair.  The fences pin this order for VALU, MFMA and memory
+    // instructions; LDS reads (the next row tile's fragments) and scalar instructions may cross them.
+    auto step_fast = [&](int st, int stn, const float (&ra)[AE], const float (&rb)[BE], float (&ran)[AE], float (&rbn)[BE],
+                         int k_next, bool counted) {
+        const char* sa = smem_raw + st * ST_BYTES;
+        const char* sb = sa + A_BYTES;
+        char* da = smem_raw + stn * ST_BYTES;
+        constexpr int NPA = AE / 2, NPB = BE / 2, NSL = TM * 6;             // pairs of A, of B; slices
+        constexpr int PPS = (NPA + NPB + NSL - 2) / (NSL - 1);              // pairs per slice (slice 0 is the loads)
+        unsigned ha[NPA], ma[NPA], la[NPA], hb[NPB], mb[NPB], lb[NPB];
+        auto pair = [&](float x0, float x1, unsigned& h, unsigned& md, unsigned& lo) {
+            h = wn_pk_bf16(x0, x1);
+            const float r0 = x0 - wn_bits_f32(h << 16), r1 = x1 - wn_bits_f32(h & 0xffff0000u);
+            md = wn_pk_bf16(r0, r1);
+            lo = wn_pk_bf16(r0 - wn_bits_f32(md << 16), r1 - wn_bits_f32(md & 0xffff0000u));
+        };
+        auto put = [&](char* base, int rows, int row, int kofs, const unsigned* h, const unsigned* md, const unsigned* lo, int np) {
+            const unsigned* src[3] = {h, md, lo};
+            for (int p = 0; p < 3; ++p) {
+                char* d = base + p * rows * 32;
+                for (int q = 0; q < np; ++q) {
+                    const int kq = (kofs >> 1) + q;
+                    *reinterpret_cast<unsigned*>(d + wn_frag_off(row, kq >> 2) + (kq & 3) * 4) = src[p][q];
+                }
+            }
+        };
+        auto slice = [&](int sl) {
+            if (sl == 0) {
+                fetch_fast(k_next, ran, rbn);
+                return;
+            }
+            WN_UNROLL
+            for (int u = 0; u < PPS; ++u) {
+                const int q = (sl - 1) * PPS + u;
+                if (q < NPA) {
+                    pair(ra[2 * q], ra[2 * q + 1], ha[q], ma[q], la[q]);
+                    if (g.a_rowsum != nullptr) rowsum += counted ? ra[2 * q] + ra[2 * q + 1] : 0.f;
+                    if (q == NPA - 1) put(da, BM, a_row, a_k, ha, ma, la, NPA);
+                } else if (q < NPA + NPB) {
+                    const int qb = q - NPA;
+                    pair(fmaxf(rb[2 * qb], b_floor), fmaxf(rb[2 * qb + 1], b_floor), hb[qb], mb[qb], lb[qb]);
+                    if (qb == NPB - 1) put(da + A_BYTES, BN, b_row, b_k, hb, mb, lb, NPB);
+                }
+            }
+        };
+        wn_f4 bf[3][TN];
+        WN_UNROLL
+        for (int p = 0; p < 3; ++p) {
+            WN_UNROLL
+            for (int j = 0; j < TN; ++j)
+                bf[p][j] = *reinterpret_cast<const wn_f4*>(sb + p * (BN * 32) + wn_frag_off((wn * TN + j) * 32 + li, hi));
+        }
+        WN_UNROLL
+        for (int i = 0; i < TM; ++i) {
+            wn_f4 af[3];
+            WN_UNROLL
+            for (int p = 0; p < 3; ++p)
+                af[p] = *reinterpret_cast<const wn_f4*>(sa + p * (BM * 32) + wn_frag_off((wm * TM + i) * 32 + li, hi));
+            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+            WN_UNROLL
+            for (int t = 0; t < 6; ++t) {
+                WN_UNROLL
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(af[PA[t]], bf[PB[t]][j], acc[i][j]);
+                WN_SCHED_FENCE_ALU();
+                slice(i * 6 + t);
+                WN_SCHED_FENCE_ALU();
+            }
+        }
+    };
     auto pass_fast = [&](int k_lo, int n) {   // n even, >= 2
         float ra0[AE], rb0[BE], ra1[AE], rb1[BE];
         const int k_last = k_lo + (n - 1) * 16;
@@ -612,18 +786,16 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6_dw(WnGemmArgs g) {
         __syncthreads();
         for (int kb = 0; kb < n; kb += 2) {
             const int ka = k_lo + (kb + 2) * 16, kc = k_lo + (kb + 3) * 16;
-            fetch_fast(ka < k_last ? ka : k_last, ra0, rb0);
-            WN_SCHED_BARRIER();
-            compute(0);
-            WN_SCHED_BARRIER();
-            stage(1, ra1, rb1);
+            G6_STAMP(kb, 0);
+            step_fast(0, 1, ra1, rb1, ra0, rb0, ka < k_last ? ka : k_last, true);
+            G6_STAMP(kb, 3);
             __syncthreads();
-            fetch_fast(kc < k_last ? kc : k_last, ra1, rb1);
-            WN_SCHED_BARRIER();
-            compute(1);
-            WN_SCHED_BARRIER();
-            stage(0, ra0, rb0, kb + 2 < n);   // past the end: a copy of the last step that nobody reads (nor counts)
+            G6_STAMP(kb, 5);
+            // past the end the staged step is a copy of the last one that nobody reads (nor counts)
+            step_fast(1, 0, ra0, rb0, ra1, rb1, kc < k_last ? kc : k_last, kb + 2 < n);
+            G6_STAMP(kb + 1, 3);
             __syncthreads();
+            G6_STAMP(kb + 1, 5);
         }
     };
     // interior steps of this block's k-chunk: [k_a, k_b) in units of 16 from kbeg
@@ -652,7 +824,7 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6_dw(WnGemmArgs g) {
     if (g.a_rowsum != nullptr) {
         // the 16/AE threads of a row are adjacent lanes
         for (int m = 1; m < 16 / AE; m <<= 1) rowsum += __shfl_xor(rowsum, m, 64);
-        if (blockIdx.x == 0 && a_k == 0 && a_row_ok) g.a_rowsum[(long)z * g.M + m0 + a_row] = rowsum;
+        if (bx == 0 && a_k == 0 && a_row_ok) g.a_rowsum[(long)z * g.M + m0 + a_row] = rowsum;
     }
     const wn_rsrc_t Cr = wn_make_buf(g.C + (long)z * g.c_zstride, (unsigned)((long)g.M * g.ldc * 4));
     WN_UNROLL
@@ -692,7 +864,7 @@ static int launch_dw(const WnGemmArgs& g, wn_stream_t st) {
     constexpr int lds = 2 * (3 * 64 * TM * 32 + 3 * 64 * TN * 32);
     dim3 grid((unsigned)((g.N + 64 * TN - 1) / (64 * TN)), (unsigned)((g.M + 64 * TM - 1) / (64 * TM)),
               (unsigned)(g.nlayer * g.nbatch * g.ksplit));
-    WN_LAUNCH((k_gemm6_dw<TM, TN>), grid, dim3(G6_T), lds, st, g);
+    WN_LAUNCH((k_gemm6_dw<TM, TN>), grid, dim3(G6_T), lds, st, g, xcd_block_order() G6_DBG_ARG(g.tag));
     return 0;
 }
 

@@ -36,6 +36,7 @@ if has rocprof; then
   rm -rf $OUT/prof_stats
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python $ROOT/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-decode > $OUT/bench_rocprof.json 2> $OUT/rocprof.err); echo "rocprof rc=$?"
   find $OUT/prof_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/rocprofv3_kernel_stats.csv
+  python tools/kernel_gaps.py $OUT/prof_stats > $OUT/kernel_gaps.txt 2>&1; cat $OUT/kernel_gaps.txt
   find $OUT/prof_stats -name "*kernel_trace.csv" -delete
   head -12 $OUT/rocprofv3_kernel_stats.csv
 fi
