@@ -12,6 +12,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#define WN_VOFF_DEAD 0x7ffffff0   // per-lane byte offset of a lane whose buffer store must not land
 #ifdef WN_EMU
 #include "hip_emu.h"
 typedef emu::f32x16_t f32x16;
@@ -100,7 +101,9 @@ static __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // Buffer access (CDNA "MUBUF"): the 128-bit resource descriptor and the scalar offset live in SGPRs,
 // only the per-lane byte offset needs a VGPR -> a tile's 32 channel rows cost ONE address VGPR
 // (voff = time) plus an SGPR per row (soff = channel * T * 4) instead of 32 64-bit address pairs.
-// Correctness never relies on the hardware range check: callers clamp voff to 0 for dead lanes.
+// Loads of dead lanes clamp voff to 0 (a valid dummy address).  STORES of dead lanes carry WN_VOFF_DEAD instead of sitting
+// under a lane-conditional branch: an offset past num_records is dropped by the hardware range check (and by the host
+// emulation), and the store stays in the straight-line instruction stream.
 typedef __amdgpu_buffer_rsrc_t wn_rsrc_t;
 static __device__ __forceinline__ wn_rsrc_t wn_make_buf(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);

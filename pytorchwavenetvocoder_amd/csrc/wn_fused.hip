@@ -23,6 +23,7 @@
 //     waits vmcnt(0) on each, and both waves of a SIMD stall in lock step).
 // The f32-input MFMA is an exact fp32 fma chain, so parity with the fp32 reference is kept.
 #include "wn_fused.h"
+#include <type_traits>
 
 
 #include "wn_prof.h"
@@ -348,6 +349,9 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
         const wn_rsrc_t Zr = wn_make_buf(a.Z + (long)b * 64 * T, slab);
         const float* cvl = cv + 4 * hi;
         f32x16 z[2];
+        const int vst = inb ? vcur : WN_VOFF_DEAD;
+        auto gate_phase = [&](auto keep_tag) {
+        constexpr bool KEEP_G = decltype(keep_tag)::value;
         WN_UNROLL
         for (int q = 0; q < 2; ++q) {
             WN_UNROLL
@@ -363,13 +367,18 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
                 const float g = wn_tanh(pg);
                 const float zz = s * g;
                 z[q][r] = zz;
-                if (inb) {
-                    wn_buf_store(Sr, s, vcur, row0 * T4);
-                    if (keep_g) wn_buf_store(Gtr, g, vcur, row0 * T4);
-                    wn_buf_store(Zr, zz, vcur, row0 * T4);
-                }
+                // unconditional stores: lanes past T carry an out-of-range offset (dropped by the buffer range check), and
+                // the tanh half goes through the same instruction stream only when it is kept -- a lane- or kernel-
+                // conditional store here would cut the gate phase into one basic block per element (no overlap of the
+                // exp / rcp chains of different elements: measured 11000 cycles for ~4500 cycles of arithmetic)
+                wn_buf_store(Sr, s, vst, row0 * T4);
+                if (KEEP_G) wn_buf_store(Gtr, g, vst, row0 * T4);
+                wn_buf_store(Zr, zz, vst, row0 * T4);
             }
         }
+        };
+        if (keep_g) gate_phase(std::true_type{});
+        else gate_phase(std::false_type{});
         WN_STAMP(3);  // after gate math + S/Gt/Z stores issued
         f32x16 racc[2];
         if (a.Xnext != nullptr) {
@@ -411,12 +420,12 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
                 WN_SGB_DS(2);
                 WN_SGB_MFMA(4);
             }
-            if (inb) {
+            {
                 const wn_rsrc_t Xn = wn_make_buf(a.Xnext + (long)b * 64 * T, slab);
                 WN_UNROLL
                 for (int q = 0; q < 2; ++q) {
                     WN_UNROLL
-                    for (int r = 0; r < 16; ++r) wn_buf_store(Xn, racc[q][r], vcur, (32 * q + mfma32_row(r, 0)) * T4);
+                    for (int r = 0; r < 16; ++r) wn_buf_store(Xn, racc[q][r], vst, (32 * q + mfma32_row(r, 0)) * T4);
                 }
             }
         }
@@ -809,6 +818,9 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
         const wn_rsrc_t Zr = wn_make_buf(a.Z + (long)b * 64 * T, slab);
         const float* cvl = cv + 4 * hi;
         f32x16 z[2];
+        const int vst = inb ? vcur : WN_VOFF_DEAD;
+        auto gate_phase = [&](auto keep_tag) {
+        constexpr bool KEEP_G = decltype(keep_tag)::value;
         WN_UNROLL
         for (int q = 0; q < 2; ++q) {
             WN_UNROLL
@@ -824,13 +836,18 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
                 const float g = wn_tanh(pg);
                 const float zz = s * g;
                 z[q][r] = zz;
-                if (inb) {
-                    wn_buf_store(Sr, s, vcur, row0 * T4);
-                    if (keep_g) wn_buf_store(Gtr, g, vcur, row0 * T4);
-                    wn_buf_store(Zr, zz, vcur, row0 * T4);
-                }
+                // unconditional stores: lanes past T carry an out-of-range offset (dropped by the buffer range check), and
+                // the tanh half goes through the same instruction stream only when it is kept -- a lane- or kernel-
+                // conditional store here would cut the gate phase into one basic block per element (no overlap of the
+                // exp / rcp chains of different elements: measured 11000 cycles for ~4500 cycles of arithmetic)
+                wn_buf_store(Sr, s, vst, row0 * T4);
+                if (KEEP_G) wn_buf_store(Gtr, g, vst, row0 * T4);
+                wn_buf_store(Zr, zz, vst, row0 * T4);
             }
         }
+        };
+        if (keep_g) gate_phase(std::true_type{});
+        else gate_phase(std::false_type{});
         WN_STAMP(3);  // after gate math + S/Gt/Z stores issued
         WN_SCHED_BARRIER();
         // res 1x1 + residual; z is consumed straight from the accumulator registers
@@ -856,12 +873,12 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
                     racc[1] = mfma_bf16(af[1][PA[t6]], bf[PB[t6]], racc[1]);
                 }
             }
-            if (inb) {
+            {
                 const wn_rsrc_t Xn = wn_make_buf(a.Xnext + (long)b * 64 * T, slab);
                 WN_UNROLL
                 for (int q = 0; q < 2; ++q) {
                     WN_UNROLL
-                    for (int r = 0; r < 16; ++r) wn_buf_store(Xn, racc[q][r], vcur, (32 * q + mfma32_row(r, 0)) * T4);
+                    for (int r = 0; r < 16; ++r) wn_buf_store(Xn, racc[q][r], vst, (32 * q + mfma32_row(r, 0)) * T4);
                 }
             }
         }
@@ -1092,6 +1109,7 @@ __global__ __launch_bounds__(WN_FT) void k_conv64(ConvArgs a) {
         const int t = (tile - b * tiles_per_b) * 32 + li;
         const bool inb = t < T;
         const int vcur = inb ? (4 * hi * T + t) * 4 : 0;
+        const int vst = inb ? vcur : WN_VOFF_DEAD;   // stores of lanes past T are dropped by the range check
         const int next_v = tile_v + step;
 
         // epilogue inputs: issued now, consumed after all MFMAs of the tile
@@ -1131,7 +1149,7 @@ __global__ __launch_bounds__(WN_FT) void k_conv64(ConvArgs a) {
                 WN_SCHED_BARRIER();
             }
         }
-        if (inb) {
+        {
             if (MODE == 0) {
                 // gate backward: dP = [dZ*g*s*(1-s) ; dZ*s*(1-g^2)]
                 const wn_rsrc_t Or = wn_make_buf(a.out + (long)b * 128 * T, (unsigned)(128 * T4));
@@ -1141,8 +1159,8 @@ __global__ __launch_bounds__(WN_FT) void k_conv64(ConvArgs a) {
                     for (int r = 0; r < 16; ++r) {
                         const int so = (32 * q + mfma32_row(r, 0)) * T4;
                         const float s = e0[q][r], g = a.gz ? e1[q][r] * wn_rcp(e0[q][r]) : e1[q][r], dz = acc[q][r];
-                        wn_buf_store(Or, dz * g * (s * (1.0f - s)), vcur, so);
-                        wn_buf_store(Or, dz * s * (1.0f - g * g), vcur, so + 64 * T4);
+                        wn_buf_store(Or, dz * g * (s * (1.0f - s)), vst, so);
+                        wn_buf_store(Or, dz * s * (1.0f - g * g), vst, so + 64 * T4);
                     }
                 }
             } else {
@@ -1153,7 +1171,7 @@ __global__ __launch_bounds__(WN_FT) void k_conv64(ConvArgs a) {
                     for (int r = 0; r < 16; ++r) {
                         float v = acc[q][r];
                         if (a.resid != nullptr) v += e0[q][r];
-                        wn_buf_store(Or, v, vcur, (32 * q + mfma32_row(r, 0)) * T4);
+                        wn_buf_store(Or, v, vst, (32 * q + mfma32_row(r, 0)) * T4);
                     }
                 }
             }
@@ -1296,6 +1314,7 @@ __global__ __launch_bounds__(WN_FT) void k_conv64s(ConvArgs a) {
         const int t = (tile - b * tiles_per_b) * 32 + li;
         const bool inb = t < T;
         const int vcur = inb ? (4 * hi * T + t) * 4 : 0;
+        const int vst = inb ? vcur : WN_VOFF_DEAD;   // stores of lanes past T are dropped by the range check
         const int next_v = tile_v + step;
 
         // epilogue inputs: issued now, consumed after all MFMAs of the tile
@@ -1364,10 +1383,8 @@ __global__ __launch_bounds__(WN_FT) void k_conv64s(ConvArgs a) {
                     const int so = (32 * q + mfma32_row(r, 0)) * T4;
                     const float s = e0[q][r], g = a.gz ? e1[q][r] * wn_rcp(e0[q][r]) : e1[q][r], dz = inb ? acc[q][r] : 0.0f;
                     const float dpa = dz * g * (s * (1.0f - s)), dpg = dz * s * (1.0f - g * g);
-                    if (inb) {
-                        wn_buf_store(Or, dpa, vcur, so);
-                        wn_buf_store(Or, dpg, vcur, so + 64 * T4);
-                    }
+                    wn_buf_store(Or, dpa, vst, so);   // lanes past T: out-of-range offset, dropped (no branch per element)
+                    wn_buf_store(Or, dpg, vst, so + 64 * T4);
                     qsum += dpa * ga[r] + dpg * gg[r];
                     const float ra = wn_row16_sum(wj * dpa), rg = wn_row16_sum(wj * dpg);
                     keep_a = (l16 == r) ? ra : keep_a;
@@ -1381,7 +1398,7 @@ __global__ __launch_bounds__(WN_FT) void k_conv64s(ConvArgs a) {
             }
             qsum += __shfl_xor(qsum, 32, 64);  // the two lane halves hold complementary channel rows
             if (hi == 0 && inb) a.qp[(long)b * T + t] = qsum;
-        } else if (inb) {
+        } else {
             if (MODE == 0) {
                 // gate backward: dP = [dZ*g*s*(1-s) ; dZ*s*(1-g^2)]
                 const wn_rsrc_t Or = wn_make_buf(a.out + (long)b * 128 * T, (unsigned)(128 * T4));
@@ -1391,8 +1408,8 @@ __global__ __launch_bounds__(WN_FT) void k_conv64s(ConvArgs a) {
                     for (int r = 0; r < 16; ++r) {
                         const int so = (32 * q + mfma32_row(r, 0)) * T4;
                         const float s = e0[q][r], g = a.gz ? e1[q][r] * wn_rcp(e0[q][r]) : e1[q][r], dz = acc[q][r];
-                        wn_buf_store(Or, dz * g * (s * (1.0f - s)), vcur, so);
-                        wn_buf_store(Or, dz * s * (1.0f - g * g), vcur, so + 64 * T4);
+                        wn_buf_store(Or, dz * g * (s * (1.0f - s)), vst, so);
+                        wn_buf_store(Or, dz * s * (1.0f - g * g), vst, so + 64 * T4);
                     }
                 }
             } else {
@@ -1403,7 +1420,7 @@ __global__ __launch_bounds__(WN_FT) void k_conv64s(ConvArgs a) {
                     for (int r = 0; r < 16; ++r) {
                         float v = acc[q][r];
                         if (a.resid != nullptr) v += e0[q][r];
-                        wn_buf_store(Or, v, vcur, (32 * q + mfma32_row(r, 0)) * T4);
+                        wn_buf_store(Or, v, vst, (32 * q + mfma32_row(r, 0)) * T4);
                     }
                 }
             }
@@ -1634,6 +1651,7 @@ __global__ __launch_bounds__(WN_FT) void k_chain64s(ChainArgs a) {
         const int t = (tile - b * tiles_per_b) * 32 + li;
         const bool inb = t < T;
         const int vcur = inb ? (4 * hi * T + t) * 4 : 0;
+        const int vst = inb ? vcur : WN_VOFF_DEAD;   // stores of lanes past T are dropped by the range check
         const int next_v = tile_v + step;
 
         // The residual input dX_{l+1} is the INITIAL VALUE of the tap accumulators (loaded straight into them), and the
@@ -1715,12 +1733,12 @@ __global__ __launch_bounds__(WN_FT) void k_chain64s(ChainArgs a) {
             issue(next_v, 0, xa, oka);
             issue(next_v, 1, xb, okb);
         }
-        if (inb) {
+        {
             const wn_rsrc_t Xr = wn_make_buf(a.dX + (long)b * 64 * T, (unsigned)(64 * T4));
             WN_UNROLL
             for (int q = 0; q < 2; ++q) {
                 WN_UNROLL
-                for (int r = 0; r < 16; ++r) wn_buf_store(Xr, acc[q][r], vcur, (32 * q + mfma32_row(r, 0)) * T4);
+                for (int r = 0; r < 16; ++r) wn_buf_store(Xr, acc[q][r], vst, (32 * q + mfma32_row(r, 0)) * T4);
             }
         }
         WN_SCHED_BARRIER();  // the dX registers are free from here on
@@ -1753,10 +1771,8 @@ __global__ __launch_bounds__(WN_FT) void k_chain64s(ChainArgs a) {
                     const int so = (32 * q + mfma32_row(r, 0)) * T4;
                     const float s = e0[q][r], g = a.gz ? e1[q][r] * wn_rcp(e0[q][r]) : e1[q][r], dzv = inb ? dz[q][r] : 0.0f;
                     const float dpa = dzv * g * (s * (1.0f - s)), dpg = dzv * s * (1.0f - g * g);
-                    if (inb) {
-                        wn_buf_store(Or, dpa, vcur, so);
-                        wn_buf_store(Or, dpg, vcur, so + 64 * T4);
-                    }
+                    wn_buf_store(Or, dpa, vst, so);   // lanes past T: out-of-range offset, dropped (no branch per element)
+                    wn_buf_store(Or, dpg, vst, so + 64 * T4);
                     qsum += dpa * ga[r] + dpg * gg[r];
                     const float ra = wn_row16_sum(wj * dpa), rg = wn_row16_sum(wj * dpg);
                     keep_a = (l16 == r) ? ra : keep_a;
@@ -1770,15 +1786,15 @@ __global__ __launch_bounds__(WN_FT) void k_chain64s(ChainArgs a) {
             }
             qsum += __shfl_xor(qsum, 32, 64);
             if (hi == 0 && inb) a.qp[(long)b * T + t] = qsum;
-        } else if (inb) {
+        } else {
             WN_UNROLL
             for (int q = 0; q < 2; ++q) {
                 WN_UNROLL
                 for (int r = 0; r < 16; ++r) {
                     const int so = (32 * q + mfma32_row(r, 0)) * T4;
                     const float s = e0[q][r], g = a.gz ? e1[q][r] * wn_rcp(e0[q][r]) : e1[q][r], dzv = dz[q][r];
-                    wn_buf_store(Or, dzv * g * (s * (1.0f - s)), vcur, so);
-                    wn_buf_store(Or, dzv * s * (1.0f - g * g), vcur, so + 64 * T4);
+                    wn_buf_store(Or, dzv * g * (s * (1.0f - s)), vst, so);
+                    wn_buf_store(Or, dzv * s * (1.0f - g * g), vst, so + 64 * T4);
                 }
             }
         }
