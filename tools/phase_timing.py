@@ -52,6 +52,7 @@ for it in range(3):
     m.engine.forward(x, h)
     torch.cuda.synchronize()
 blk = dbg.cpu()[512:].view(256, 4)
+blk = blk[blk[:, 0] != 0]   # only the blocks that ran (the persistent grid is smaller than 256)
 d = dbg.cpu()[:512].view(8, 4, 16)   # stamps of the LAST layer launch (each launch overwrites)
 t0 = int(d[:, 0, 0].min())
 names = ["start", "hist", "cur", "gate", "done"]
