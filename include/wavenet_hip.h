@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define WN_ABI_VERSION 4
+#define WN_ABI_VERSION 5
 
 /* Same fields as the constructor WaveNet(n_quantize, n_aux, n_resch, n_skipch, dilation_depth,
  * dilation_repeat, kernel_size, upsampling_factor)  -- reference wavenet.py:172-173. */
@@ -179,6 +179,18 @@ int wn_softmax_ce_loss(const WnConfig* cfg, int B, int T, const float* logits, c
 int wn_backward(const WnConfig* cfg, int B, int T, const float* params, const int64_t* x, const float* h,
                 const float* dlogits, float* grads, void* ws, size_t ws_bytes, void* const* events, int n_events,
                 int layers_per_bucket, int flags, void* stream);
+
+/* wn_backward for a loss that covers positions [t_first, T) only (since ABI v5) -- the reference's training loss,
+ * train.py:534-536: CrossEntropyLoss on batch_output[:, receptive_field:].  The caller guarantees
+ * dlogits[:, :, :t_first] == 0 (wn_softmax_ce_loss / wn_mol_loss with t_start = t_first write exactly that).  Between the
+ * logits and the residual stack everything is pointwise in time (wavenet.py:518-523,533), so dO2, dSkip and the skip part
+ * of every layer's dZ are zero in front of t_first as well: their contractions and the post-net / skip weight gradients
+ * run over the window only (from t_first rounded down to a multiple of 128; the skipped columns of dSkip are zero-filled
+ * for the residual chain, which needs every position).  Same gradients as wn_backward up to the rounding of a different
+ * split-K plan; t_first = 0 IS wn_backward.  WN_LOSS_WINDOW=0 in the environment ignores t_first (A/B measurements). */
+int wn_backward_window(const WnConfig* cfg, int B, int T, const float* params, const int64_t* x, const float* h,
+                       const float* dlogits, int t_first, float* grads, void* ws, size_t ws_bytes, void* const* events,
+                       int n_events, int layers_per_bucket, int flags, void* stream);
 
 /* torch.optim.Adam step over the flat buffers (reference train.py:457-460,539): L2-in-gradient
  * weight decay, bias correction with `step` (1-based); [skip_lo, skip_hi) is left untouched. */

@@ -51,6 +51,7 @@ static inline void wn_buf_load_lds16(wn_rsrc_t r, char* lds_wave_base, int voff,
 #define WN_UNIFORM(x) (x)
 #define WN_SCHED_BARRIER()
 #define WN_SLEEP(n)
+#define WN_HW_WAVE_SLOT() 0
 #define WN_SGB_DS(n)
 #define WN_SGB_MFMA(n)
 #define WN_SGB_VALU(n)
@@ -131,6 +132,8 @@ static __device__ __forceinline__ float4 wn_buf_load4(wn_rsrc_t r, int voff, uns
 // scheduling fence: hipcc may not move instructions across it (pins software-pipeline issue order)
 #define WN_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #define WN_SLEEP(n) __builtin_amdgcn_s_sleep(n)
+// wave slot of this wave on its SIMD: HW_REG_HW_ID (4), bits [3:0]
+#define WN_HW_WAVE_SLOT() (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 15)
 // fence for VALU, MFMA and global-memory instructions: only LDS and scalar instructions may still be moved across it
 #define WN_SCHED_FENCE_ALU() __builtin_amdgcn_sched_barrier(0x384)
 // scheduling groups: "the next n DS reads" / "the next n MFMAs" are emitted as a block in this order

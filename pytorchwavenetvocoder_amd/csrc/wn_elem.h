@@ -108,6 +108,8 @@ int wn_reduce(const WnReduceArgs* a, wn_stream_t st);
 // out[0] (=|+=) sum_i a[i]*b[i]
 int wn_dot(const float* a, const float* b, long n, float* out, int accumulate, wn_stream_t st);
 int wn_fill(float* p, float v, long n, wn_stream_t st);
+// p[r * stride + c] = 0 for r < rows, c < ncols (ncols % 4 == 0, rows 16-byte aligned)
+int wn_fill_cols(float* p, long rows, long stride, int ncols, wn_stream_t st);
 
 // Front-conv weight / bias gradient as a scatter (reference: autograd of OneHot + CausalConv1d,
 // wavenet.py:78-92,513-516): dW[c][q][k] = sum_{b,t} dX0[b][c][t] * [x[b][t-(K-1-k)] mod Q == q]  (zero history),

@@ -516,6 +516,25 @@ int wn_fill(float* p, float v, long n, wn_stream_t st) {
     return 0;
 }
 
+// zero the first `ncols` (a multiple of 4) columns of `rows` rows that are `stride` floats apart: 16 bytes per lane
+__global__ __launch_bounds__(WN_TPB) void k_fill_cols(float* __restrict__ p, long rows, long stride, int ncols4) {
+    const long i = (long)blockIdx.x * WN_TPB + threadIdx.x;
+    if (i >= rows * ncols4) return;
+    const long r = i / ncols4;
+    const int c = (int)(i - r * ncols4);
+    float* q = p + r * stride + 4 * c;
+    q[0] = 0.0f; q[1] = 0.0f; q[2] = 0.0f; q[3] = 0.0f;
+}
+
+int wn_fill_cols(float* p, long rows, long stride, int ncols, wn_stream_t st) {
+    WN_PROF("fill_cols", 0.0, (double)rows * ncols * 4, st);
+    if (rows <= 0 || ncols <= 0) return 0;
+    if (ncols % 4 != 0) return 1;
+    const long n = rows * (ncols / 4);
+    WN_LAUNCH(k_fill_cols, dim3((unsigned)((n + WN_TPB - 1) / WN_TPB)), dim3(WN_TPB), 0, st, p, rows, stride, ncols / 4);
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // front-conv weight gradient as a scatter (see wn_elem.h)
 // ---------------------------------------------------------------------------------------------

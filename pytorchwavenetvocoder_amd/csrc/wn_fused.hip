@@ -1550,6 +1550,7 @@ struct ChainArgs {
     const float* wres;   // natural res_1x1 weight of layer l-1: [o][i] = [k][row]
     const float* dZs;    // skip part of dZ_{l-1}: rows [0, 64) at dZs + b * zs_bstride, row stride T
     long zs_bstride;
+    int zs_t0;           // dZs is zero (and was never written) in front of this position: the loss window of wn_backward_window
     const float* S;      // (B, 64, T) sigmoid / tanh halves of layer l-1 (saved by the forward)
     const float* Gt;     // with gz != 0: the saved product z = s * tanh instead of the tanh half (g = z / s)
     int gz;
@@ -1652,6 +1653,9 @@ __global__ __launch_bounds__(WN_FT) void k_chain64s(ChainArgs a) {
         const bool inb = t < T;
         const int vcur = inb ? (4 * hi * T + t) * 4 : 0;
         const int vst = inb ? vcur : WN_VOFF_DEAD;   // stores of lanes past T are dropped by the range check
+        // positions in front of the loss window have no skip gradient: their dZs loads carry an out-of-range offset, which the
+        // range check answers with 0 without touching memory (no branch, and the region needs no zero-fill)
+        const int vzs = (t >= a.zs_t0) ? vst : WN_VOFF_DEAD;
         const int next_v = tile_v + step;
 
         // The residual input dX_{l+1} is the INITIAL VALUE of the tap accumulators (loaded straight into them), and the
@@ -1686,7 +1690,7 @@ __global__ __launch_bounds__(WN_FT) void k_chain64s(ChainArgs a) {
                 WN_UNROLL
                 for (int qq = 0; qq < 2; ++qq) {
                     WN_UNROLL
-                    for (int r = 0; r < 16; ++r) dz[qq][r] = wn_buf_load(Zr, vcur, (32 * qq + mfma32_row(r, 0)) * T4);
+                    for (int r = 0; r < 16; ++r) dz[qq][r] = wn_buf_load(Zr, vzs, (32 * qq + mfma32_row(r, 0)) * T4);
                 }
                 WN_UNROLL
                 for (int r = 0; r < 16; ++r) {
@@ -1809,7 +1813,7 @@ int wn_fused_chain_supported(int R, int K, int S) {
 int wn_fused_bwd_chain(const float* wd_b, const float* dP, const float* dXn, float* dX, const float* wres_prev, const float* dZs,
                        long zs_bstride, const float* S, const float* Gt, int gt_is_z, float* dP_prev, const float* G, long g_bstride,
                        const float* upw, int U, int F, float* dGp, float* qp, int B, int T, int K, int dilation,
-                       const float* img_taps, const float* img_res, wn_stream_t st) {
+                       const float* img_taps, const float* img_res, int zs_t0, wn_stream_t st) {
     // dP (, dXn), dZs, S, Gt in; dX, dP_prev out (+ dGp 8 / qp 1 words per timestep with the aux partials)
     const bool aux = dGp != nullptr;
     WN_PROF("fused_bwd_chain", 2.0 * (double)B * T * 64.0 * (K * 128.0 + 64.0),
@@ -1819,7 +1823,7 @@ int wn_fused_bwd_chain(const float* wd_b, const float* dP, const float* dXn, flo
     ChainArgs a;
     a.img_taps = (img_taps && img_res) ? img_taps : nullptr; a.img_res = img_res;
     a.wd_b = wd_b; a.dP = dP; a.dXn = dXn; a.dX = dX;
-    a.wres = wres_prev; a.dZs = dZs; a.zs_bstride = zs_bstride; a.S = S; a.Gt = Gt; a.gz = gt_is_z; a.dPm = dP_prev;
+    a.wres = wres_prev; a.dZs = dZs; a.zs_bstride = zs_bstride; a.zs_t0 = zs_t0; a.S = S; a.Gt = Gt; a.gz = gt_is_z; a.dPm = dP_prev;
     a.B = B; a.T = T; a.K = K; a.dil = dilation;
     a.stagger = stagger_setting();
     a.G = G; a.g_bstride = g_bstride; a.upw = upw; a.U = U; a.F = F; a.dGp = dGp; a.qp = qp;

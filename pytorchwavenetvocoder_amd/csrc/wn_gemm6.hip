@@ -139,6 +139,12 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
     const float* __restrict__ Bz = g.B + (long)b * g.b_zstride;
     const int nk = (g.K + 15) / 16;
     const bool one_seg = g.b_seg_len >= g.K;
+    // De-phase the two blocks that share a CU (WN_G6_STAGGER, A/B knob).  They start together, do the same work and so
+    // stay in lock step: both in their prologue (HBM latency) and both in their epilogue (stores) at the same time, with the
+    // matrix pipe idle.  The second resident of the first round -- its waves sit in wave slot 1 of their SIMDs -- starts
+    // late by a fraction of a block; every later block inherits the offset of the slot it takes over.
+    if (g.stagger > 0 && blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z) < 512u && (WN_HW_WAVE_SLOT() & 1))
+        for (int i = 0; i < g.stagger; ++i) WN_SLEEP(127);
 
     // the split weights go global -> LDS directly (their packed layout IS the LDS layout)
     const wn_rsrc_t Ar = wn_make_buf(g.Apk, (unsigned)((long)nk * 3 * g.Mpad * 32));
@@ -471,6 +477,19 @@ int wn_gemm6_launch(const WnGemm6Args* gp, wn_stream_t st) {
             v = (e && atoi(e) == 0) ? 0 : 1;
         }
         g.no_interior = v ? 0 : 1;
+    }
+    {   // WN_G6_STAGGER=<percent of a block's k-loop> (default 50; 0 = off), see k_gemm6.  Only for short contractions
+        // (K <= 512: the post-net and the all-layer skip gradient, 16 steps per block), where a block's prologue and epilogue
+        // are a third of its life; measured on MI355X (profiles/r02/ab_probe_loss_window_stagger.txt): bwd_post{1,2}_dx
+        // 0.172 -> 0.147 ms each, while the long skip-sum (120 steps per block) only pays for the late start (+0.04 ms).
+        static int pct = -1;
+        if (pct < 0) {
+            const char* e = getenv("WN_G6_STAGGER");
+            pct = e ? atoi(e) : 50;
+            if (pct < 0) pct = 0;
+        }
+        // ~4000 cycles per 16-k step with two blocks per CU; one s_sleep(127) = 8128 cycles
+        g.stagger = g.K <= 512 ? (int)(((long)pct * ((g.K + 15) / 16) * 4000L) / (100L * 8128L)) : 0;
     }
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.nbatch <= 0) return 1;
     if (g.b_seg_len < g.K && (g.b_seg_len % 16) != 0) return 2;

@@ -191,8 +191,10 @@ class WaveNetEngine(object):
         self.lib.check(rc, "wn_mol_loss")
         return loss, dout
 
-    def backward(self, dlogits, events=None, layers_per_bucket=0):
-        """Backward of the last ``forward`` call; fills ``self.grads()`` completely."""
+    def backward(self, dlogits, events=None, layers_per_bucket=0, t_first=0):
+        """Backward of the last ``forward`` call; fills ``self.grads()`` completely.  ``t_first``: the caller guarantees
+        ``dlogits[:, :, :t_first] == 0`` (the training loss covers ``[:, receptive_field:]``, train.py:534-536): the
+        post-net / skip part of the backward pass then runs over the loss window only (``wn_backward_window``)."""
         if self._last_shape is None:
             raise _lib.WnError("backward() without a preceding forward()")
         B, T = self._last_shape
@@ -207,10 +209,10 @@ class WaveNetEngine(object):
             n_ev = len(events)
         else:
             arr, n_ev = None, 0
-        rc = self.lib.wn_backward(ctypes.byref(self.cfg), B, T, _ptr(self.flat_params), _ptr(x), _ptr(h), _ptr(dlogits),
-                                  _ptr(g), _ptr(ws), ws.numel() * 4, arr, n_ev, int(layers_per_bucket), self.flags,
-                                  _stream_handle(self.device))
-        self.lib.check(rc, "wn_backward")
+        rc = self.lib.wn_backward_window(ctypes.byref(self.cfg), B, T, _ptr(self.flat_params), _ptr(x), _ptr(h),
+                                         _ptr(dlogits), int(t_first), _ptr(g), _ptr(ws), ws.numel() * 4, arr, n_ev,
+                                         int(layers_per_bucket), self.flags, _stream_handle(self.device))
+        self.lib.check(rc, "wn_backward_window")
         return g
 
     def adam_step(self, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):

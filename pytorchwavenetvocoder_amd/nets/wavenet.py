@@ -295,8 +295,10 @@ class WaveNet(nn.Module):
         eng = self._engine
         logits = eng.forward(x, h)
         self._fwd_serial += 1
+        if t_start is None:
+            t_start = eng.receptive_field
         loss, dlogits = eng.loss(logits, t, t_start=t_start, grad_scale=grad_scale)
-        flat = eng.backward(dlogits, events=events, layers_per_bucket=layers_per_bucket)
+        flat = eng.backward(dlogits, events=events, layers_per_bucket=layers_per_bucket, t_first=t_start)
         for p, (off, n, shape, dead) in zip(self.parameters(), self._param_slices):
             p.grad = None if dead else flat[off:off + n].view(shape)
         return loss
@@ -316,9 +318,11 @@ class WaveNet(nn.Module):
         eng = self._engine
         out = eng.forward(x, h)
         self._fwd_serial += 1
+        if t_start is None:
+            t_start = eng.receptive_field
         loss, dout = eng.mol_loss(out, y, t_start=t_start, grad_scale=grad_scale, num_classes=num_classes,
                                   log_scale_min=log_scale_min)
-        flat = eng.backward(dout, events=events, layers_per_bucket=layers_per_bucket)
+        flat = eng.backward(dout, events=events, layers_per_bucket=layers_per_bucket, t_first=t_start)
         for p, (off, n, shape, dead) in zip(self.parameters(), self._param_slices):
             p.grad = None if dead else flat[off:off + n].view(shape)
         return loss

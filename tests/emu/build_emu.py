@@ -5,6 +5,7 @@
 Gives tests/ a way to execute the very same kernel source (index arithmetic, LDS layouts, MFMA
 lane maps) without a GPU.  Never used by the product package.
 """
+import fcntl
 import hashlib
 import os
 import subprocess
@@ -32,6 +33,12 @@ def _digest():
 
 def build(force=False):
     os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "lock"), "w") as lk:   # pytest-xdist workers would otherwise build into the same objects
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        return _build_locked(force)
+
+
+def _build_locked(force):
     stamp = os.path.join(OUT, "stamp")
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:

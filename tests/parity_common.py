@@ -37,7 +37,7 @@ def check_golden_case(g, lib, device, flags=None, layers_per_bucket=0):
     assert err <= TOL_LOGITS, "logits max-abs err %g" % err
     loss, dl = eng.loss(logits, t)
     assert abs(float(loss.cpu()) - g.loss) <= TOL_LOSS
-    grads = flat_to_state(eng, eng.backward(dl, layers_per_bucket=layers_per_bucket).cpu(), O.param_shapes(g.cfg))
+    grads = flat_to_state(eng, eng.backward(dl, layers_per_bucket=layers_per_bucket, t_first=eng.receptive_field).cpu(), O.param_shapes(g.cfg))
     for k, ref in g.grads.items():
         if ref is None:
             assert float(grads[k].abs().max()) == 0.0, k
@@ -133,7 +133,7 @@ def run_oracle_vs_engine(cfg_tuple, B, T, seed, lib, device, flags=None, scale=0
     assert abs(float(loss.cpu()) - float(loss_ref)) <= TOL_LOSS
     worst = 0.0
     if check_grads:
-        grads = flat_to_state(eng, eng.backward(dl).cpu(), O.param_shapes(cfg))
+        grads = flat_to_state(eng, eng.backward(dl, t_first=eng.receptive_field).cpu(), O.param_shapes(cfg))   # the training step's call (loss window)
         for k, ref in grads_ref.items():
             if ref is None:
                 assert float(grads[k].abs().max()) == 0.0, k
@@ -208,7 +208,7 @@ def run_fullsize_vs_oracle(cfg_tuple, B, T, seed, lib, device, flag_sets, scale=
     out["grads"] = {}
     for flags in flag_sets:
         eng.flags = flags
-        grads = flat_to_state(eng, eng.backward(dl).cpu(), O.param_shapes(cfg))
+        grads = flat_to_state(eng, eng.backward(dl, t_first=eng.receptive_field).cpu(), O.param_shapes(cfg))   # the training step's call (loss window)
         worst, worst_k = 0.0, None
         for k, ref in grads_ref.items():
             if ref is None:

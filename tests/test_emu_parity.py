@@ -388,3 +388,43 @@ def test_launch_sequence_of_the_default_training_step():
     assert a["fused_resblock_fwd"] == 6 and a["fused_bwd_chain"] == 5 and a["fused_bwd_gate"] == 1 and a["fused_bwd_dx"] == 1, a
     assert a["bwd_dz_skip_all"] == 1 and a["fused_pack_images"] == 1 and "aux_bwd" not in a and a["aux_finish"] >= 1, a
     assert b["fused_bwd_gate"] == 6 and b["fused_bwd_dx"] == 6 and "fused_bwd_chain" not in b and "bwd_dz_skip_all" not in b, b
+
+
+def test_loss_window_backward_equals_the_full_backward():
+    """wn_backward_window (ABI v5): with the loss on [:, rf:] (train.py:534-536) the post-net / skip part of the backward pass
+    runs over [t0, T) only, t0 = rf rounded down to a 128-column tile.  rf = 128 here, so t0 = 128 > 0: same gradients as
+    the full-range backward at round-off (a different split-K plan), against the oracle, dSkip exactly zero in front of
+    the window, and the launch log shows its zero-fill -- for the chain mode, the launch pair and the any-size path."""
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd import _lib
+    from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat
+    cfg_t = (32, 4, 64, 32, 7, 1, 2, 16)
+    cfg = O.OracleConfig(*cfg_t)
+    assert cfg.receptive_field == 128
+    B, T = 2, 304
+    params, x, h, t, margin, sd = PC.pick_instance(cfg, B, T, 61, 0.1)
+    _, _, grads_ref = O.train_step(cfg, params, None, x, h, t)
+    for flags in (_lib.FLAG_AUX_FUSED, _lib.FLAG_AUX_FUSED | _lib.FLAG_NO_CHAIN, _lib.FLAG_NO_FUSED):
+        eng = WaveNetEngine(*cfg_t, device="cpu", library=emu_library())
+        eng.flags = flags
+        load_state_into_flat(eng, params)
+        logits = eng.forward(x, h)
+        loss, dl = eng.loss(logits, t)
+        assert float(dl[:, :, :128].abs().max()) == 0.0
+        full = eng.backward(dl).clone()
+        log = PC.launch_log(emu_library(), lambda: eng.backward(dl, t_first=cfg.receptive_field))
+        win = eng.grads().clone()
+        assert log.get("fill_cols") == 1, log   # dSkip; the chain kernel takes dZs as zero in front of the window without a fill
+        dSk = eng.saved(_lib.WS_DSKIP)
+        assert float(dSk[:, :, :128].abs().max()) == 0.0 and float(dSk[:, :, 128:].abs().max()) > 0.0
+        scale = float(full.abs().max())
+        assert float((win - full).abs().max()) <= 2e-6 * scale, (flags, float((win - full).abs().max()), scale)
+        grads = PC.flat_to_state(eng, win, O.param_shapes(cfg))
+        for k, ref in grads_ref.items():
+            if ref is not None:
+                assert PC.rel_to_max(grads[k], ref) <= PC.TOL_GRAD, (flags, k)
+    # t_first below one tile, or WN_LOSS_WINDOW=0 semantics (t_first = 0): the plain backward, bit for bit
+    eng.flags = _lib.FLAG_AUX_FUSED
+    a = eng.backward(dl).clone()
+    b = eng.backward(dl, t_first=127).clone()
+    assert torch.equal(a, b)

@@ -60,3 +60,42 @@ def test_chain_kernel_ragged_shapes():
                                      ((64, 6, 64, 32, 2, 2, 2, 16), 3, 80, 42, 0), ((256, 8, 64, 128, 5, 2, 2, 16), 2, 304, 45, A)]:
         e, g = PC.run_oracle_vs_engine(cfg_t, B, T, seed, _lib(), DEV, flags=flags, scale=0.2 if cfg_t[3] < 128 else 0.1)
         print("chain ragged", cfg_t, B, T, "logits %.3g grads %.3g" % (e, g))
+
+
+def test_loss_window_backward_vs_full_backward():
+    """wn_backward_window (what loss_and_backward calls: post-net / skip part over [rf rounded down to 128, T) only)
+    against the full-range wn_backward on the same dlogits: config-2 model (rf = 3070 -> t0 = 2944), three sequences of 6400
+    (ragged last 128-column tile of the window), every launch mode; dSkip exactly zero in front of the window; T barely past
+    the receptive field (a window of one tile); and the module-level training half-step uses it."""
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd import _lib as L
+    from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat
+    from pytorchwavenetvocoder_amd.nets import WaveNet
+    cfg_t = (256, 80, 64, 256, 10, 3, 2, 80)
+    cfg = O.OracleConfig(*cfg_t)
+    rf = cfg.receptive_field
+    for B, T in ((3, 6400), (2, 3120)):
+        # both calls take the same ReLU sub-gradients (the saved activations), so no kink-free instance is needed
+        params = O.random_params(cfg, 43, scale=0.05)
+        x, h, t = (v.to(DEV) for v in O.synthetic_batch(cfg, B, T, 44))
+        for flags in (L.FLAG_AUX_FUSED, L.FLAG_AUX_FUSED | L.FLAG_NO_CHAIN, L.FLAG_NO_FUSED):
+            eng = WaveNetEngine(*cfg_t, device=DEV, library=_lib())
+            eng.flags = flags
+            load_state_into_flat(eng, params)
+            logits = eng.forward(x, h)
+            loss, dl = eng.loss(logits, t)
+            full = eng.backward(dl).clone()
+            win = eng.backward(dl, t_first=rf).clone()
+            dSk = eng.saved(L.WS_DSKIP)
+            assert float(dSk[:, :, :rf].abs().max()) == 0.0 and float(dSk[:, :, rf:].abs().max()) > 0.0
+            err = float((win - full).abs().max()) / float(full.abs().max())
+            print("loss window B=%d T=%d flags=%d: |window - full| / max = %.3g" % (B, T, flags, err))
+            assert err <= 2e-6
+            assert torch.equal(win, eng.backward(dl, t_first=rf))   # run to run bitwise
+    m = WaveNet(*cfg_t).to(DEV)
+    load_state_into_flat(m.engine, params)
+    m.loss_and_backward(x, h, t)
+    g_mod = m.engine.grads().clone()
+    logits = m.engine.forward(x, h)
+    loss, dl = m.engine.loss(logits, t)
+    assert torch.equal(g_mod, m.engine.backward(dl, t_first=rf))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU visit: parity tests, smoke, bench (A/B of the bucket structure), rocprofv3 kernel stats of the same command, PMC
 # passes, the recipe's stage 4/5, the 2-rank control flow on one GPU.  Each part has its own timeout and log under gpurun_out/.
-#   gpurun --timeout 1500 -- 'bash tools/gpu_visit.sh [parts...]'      parts: tests smoke bench lpb rocprof pmc recipe tworank recipesize
+#   gpurun --timeout 1500 -- 'bash tools/gpu_visit.sh [parts...]'      parts: tests smoke bench lpb abk rocprof pmc recipe tworank recipesize
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 cd "$ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
 OUT="$ROOT/gpurun_out"
@@ -31,6 +31,22 @@ print("%-40s ms/step median %.3f min %.3f max %.3f" % ("$cfg", d["ms_per_step"],
 P
     done
   done | tee $OUT/ab_probe.txt
+fi
+if has abk; then
+  # like lpb, with the per-kernel HIP-event table of each variant (WN_AB_VARIANTS; WN_ABK_KERNELS = tags to print)
+  for rep in 1 2; do
+    for cfg in ${WN_AB_VARIANTS:-WN_X=1}; do
+      env $(echo $cfg | tr ',' ' ') timeout 200 python bench.py --repeats 3 --no-cpu-baseline --no-decode > $OUT/bench_abk.json 2>> $OUT/bench.err
+      python - <<P
+import json
+d = json.load(open("$OUT/bench_abk.json"))
+ks = d.get("kernels", {})
+sel = "${WN_ABK_KERNELS:-bwd_dz_skip_all fwd_skip_sum dw_skip bwd_post2_dx bwd_post1_dx fwd_post1 fwd_post2 dw_post1 dw_post2 fill_cols softmax_ce fused_bwd_chain fused_resblock_fwd}".split()
+print("%-32s ms/step median %.3f min %.3f max %.3f | " % ("$cfg", d["ms_per_step"], d["ms_per_step_min"], d["ms_per_step_max"]) +
+      " ".join("%s %.3f" % (k, ks[k]["ms_per_step"]) for k in sel if k in ks))
+P
+    done
+  done | tee $OUT/abk_probe.txt
 fi
 if has rocprof; then
   rm -rf $OUT/prof_stats
