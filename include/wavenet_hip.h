@@ -171,6 +171,18 @@ int wn_softmax_ce_loss(const WnConfig* cfg, int B, int T, const float* logits, c
                        float grad_scale, float loss_scale, float* loss, float* dlogits, void* ws, size_t ws_bytes,
                        void* stream);
 
+/* wn_forward + wn_softmax_ce_loss in one call, for the training step (since ABI v5; reference train.py:533-536:
+ * batch_output = model(x, h); loss = CrossEntropyLoss()(batch_output[:, rf:], batch_t[:, rf:])).  When
+ * wn_forward_loss_fused(cfg, B, T, flags) == 1 the loss is the EPILOGUE of the conv_post_2 contraction: a workgroup holds all
+ * n_quantize <= 256 classes of its 128 positions on chip, so the (B, Q, T) logits are never written to or read back from
+ * memory -- `loss` and `dlogits` (nullable) come out exactly as wn_softmax_ce_loss defines them, logits_scratch is not
+ * touched (may be NULL).  Otherwise (exact-MFMA mode, more than 256 classes, mixture head) the call runs the two entry
+ * points back to back and needs logits_scratch (B, Q, T).  The workspace is left as wn_forward leaves it. */
+int wn_forward_loss_fused(const WnConfig* cfg, int B, int T, int flags);
+int wn_forward_loss(const WnConfig* cfg, int B, int T, const float* params, const int64_t* x, const float* h,
+                    const int64_t* target, int t_start, float grad_scale, float loss_scale, float* loss, float* dlogits,
+                    float* logits_scratch, void* ws, size_t ws_bytes, int flags, void* stream);
+
 /* Backward of wn_forward (what autograd does for train.py:538): writes EVERY element of the flat
  * gradient buffer `grads` (the dead range gets zeros).  `ws` must still hold the matching
  * wn_forward call, made with the same WN_FLAG_NO_FUSED / WN_FLAG_EXACT_MFMA choice (the two kernel

@@ -87,7 +87,7 @@ ABI_VERSION = 5
 EXPORTS = [
     "wn_abi_version", "wn_last_error", "wn_receptive_field", "wn_num_layers", "wn_param_count", "wn_param_offset",
     "wn_num_buckets", "wn_bucket_range", "wn_dead_param_range", "wn_workspace_bytes", "wn_workspace_region", "wn_forward",
-    "wn_softmax_ce_loss", "wn_backward", "wn_backward_window", "wn_adam_step", "wn_op_front", "wn_op_causal_conv", "wn_op_gemm", "wn_prof_enable", "wn_prof_report",
+    "wn_softmax_ce_loss", "wn_forward_loss_fused", "wn_forward_loss", "wn_backward", "wn_backward_window", "wn_adam_step", "wn_op_front", "wn_op_causal_conv", "wn_op_gemm", "wn_prof_enable", "wn_prof_report",
     "wn_decode_supported", "wn_decode_pack_floats", "wn_decode_state_floats", "wn_decode_pack", "wn_decode_aux",
     "wn_decode_steps", "wn_decode_stream_bytes",
     "wn_decode_layered_state_floats", "wn_decode_layered_prepare", "wn_decode_layered_steps", "wn_mol_loss",
@@ -127,6 +127,8 @@ class WnLibrary(object):
         L.wn_workspace_region.argtypes = [cfgp, i, i, i, ctypes.POINTER(i64), ctypes.POINTER(i64)]
         L.wn_forward.argtypes = [cfgp, i, i, vp, vp, vp, vp, vp, sz, i, vp]
         L.wn_softmax_ce_loss.argtypes = [cfgp, i, i, vp, vp, i, f, f, vp, vp, vp, sz, vp]
+        L.wn_forward_loss_fused.argtypes = [cfgp, i, i, i]
+        L.wn_forward_loss.argtypes = [cfgp, i, i, vp, vp, vp, vp, i, f, f, vp, vp, vp, vp, sz, i, vp]
         L.wn_backward.argtypes = [cfgp, i, i, vp, vp, vp, vp, vp, vp, sz, ctypes.POINTER(vp), i, i, i, vp]
         L.wn_backward_window.argtypes = [cfgp, i, i, vp, vp, vp, vp, i, vp, vp, sz, ctypes.POINTER(vp), i, i, i, vp]
         L.wn_adam_step.argtypes = [vp, vp, vp, vp, i64, i64, f, f, f, f, f, i64, i64, vp]

@@ -476,7 +476,7 @@ static int make_ws(const Dims& d, int B, int T, Ws* w) {
     CARVE(rs_partial, rmax);
     w->red_scratch_floats = 1 << 20;
     CARVE(red_scratch, w->red_scratch_floats);
-    CARVE(loss_partial, wn_softmax_ce_nblocks(B, T) + 64);
+    CARVE(loss_partial, 2 * wn_softmax_ce_nblocks(B, T) + 64);   // CE epilogue: one partial per 128-column block
     w->front_partial_floats = wn_front_dw_supported(d.R, d.K, d.Q) ? wn_front_dw_partial_floats(B, T, d.R, d.K, d.Q) : 0;
     CARVE(front_partial, w->front_partial_floats);
     {   // split-bf16 weights of the forward-type contractions (wn_gemm6): one buffer, re-packed before each use
@@ -615,12 +615,18 @@ static bool fw_gemm_split_ok(const Ctx& c, const WnGemmArgs& g) {
            !g.b_index && g.a_zstride == 0 && !g.a_rowsum &&
            wn_gemm6_apk_elems(g.M, g.K) <= 2 * c.w.apk_floats && (long)g.M * g.ldc * 4 < 0x7ffffff0L;
 }
-static int fw_gemm(const Ctx& c, const WnGemmArgs& g, const GateEpi* ge = nullptr) {
+struct CeEpi {   // softmax cross-entropy as the epilogue of the contraction that produces the logits (wn_gemm6.h)
+    const int64_t* target;
+    int t_start;
+    float gs;
+    float* partial;
+};
+static int fw_gemm(const Ctx& c, const WnGemmArgs& g, const GateEpi* ge = nullptr, const CeEpi* ce = nullptr) {
     const bool ok = c.split_bf16 && g.M >= 128 && !g.a_kmajor && !g.b_kmajor &&
                     (g.b_seg_len >= g.K || g.b_seg_len % 16 == 0) && g.ksplit == 1 && g.nlayer == 1 && !g.b_relu &&
                     !g.b_index && g.a_zstride == 0 && !g.a_rowsum &&
                     wn_gemm6_apk_elems(g.M, g.K) <= 2 * c.w.apk_floats && (long)g.M * g.ldc * 4 < 0x7ffffff0L;
-    if (!ok) return ge ? fail(3, "gate epilogue needs the split contraction") : wn_gemm_launch(&g, c.st);
+    if (!ok) return (ge || ce) ? fail(3, "gate / loss epilogue needs the split contraction") : wn_gemm_launch(&g, c.st);
     unsigned short* apk = reinterpret_cast<unsigned short*>(c.ws + c.w.apk);
     WN_TRY(wn_gemm6_pack(g.A, g.lda, g.M, g.K, apk, ge ? ge->gate_R : 0, c.st));
     WnGemm6Args a;
@@ -638,6 +644,10 @@ static int fw_gemm(const Ctx& c, const WnGemmArgs& g, const GateEpi* ge = nullpt
     a.C = g.C; a.ldc = g.ldc; a.c_zstride = g.c_zstride;
     a.bias = g.bias; a.E = g.E; a.lde = g.lde; a.e_zstride = g.e_zstride; a.relu = g.relu;
     a.nbatch = g.nbatch; a.tag = g.tag;
+    if (ce) {
+        a.ce_target = reinterpret_cast<const long long*>(ce->target); a.ce_tstride = g.N; a.ce_t_start = ce->t_start;
+        a.ce_gs = ce->gs; a.ce_partial = ce->partial;
+    }
     return wn_gemm6_launch(&a, c.st);
 }
 
@@ -827,12 +837,12 @@ static int forward_stack(const Ctx& c, const float* params, const int64_t* x, co
     return 0;
 }
 
-extern "C" int wn_forward(const WnConfig* cfg, int B, int T, const float* params, const int64_t* x, const float* h,
-                          float* logits, void* wsp, size_t ws_bytes, int flags, void* stream) {
-    api_enter();
+// wn_forward, optionally with the softmax cross-entropy as the epilogue of conv_post_2 (`ce`: the logits are not written)
+static int forward_impl(const WnConfig* cfg, int B, int T, const float* params, const int64_t* x, const float* h,
+                        float* logits, const CeEpi* ce_in, void* wsp, size_t ws_bytes, int flags, void* stream, const char* who) {
     Ctx c;
     WN_TRY(make_ctx(&c, cfg, B, T, wsp, ws_bytes, flags, stream));
-    if (!params || !x || !h || !logits) return fail(1, "NULL argument");
+    if (!params || !x || !h || (!logits && !ce_in)) return fail(1, "NULL argument");
     // overlap mode (opt-in, fused kernels): partial skip-sums run on the internal side stream beside the stack
     SideLock side((flags & WN_FLAG_FWD_OVERLAP) && c.fused && !wn_prof_is_on(), c.st);
     Ctx cs = c;
@@ -864,9 +874,66 @@ extern "C" int wn_forward(const WnConfig* cfg, int B, int T, const float* params
         g.B = ws + w.O2; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = T;
         g.C = logits; g.ldc = T; g.c_zstride = (long)d.Qo * T;
         g.bias = params + y.post2_b; g.nbatch = B; g.tag = "fwd_post2";
-        WN_TRY(fw_gemm(c, g));
+        if (ce_in) {
+            CeEpi ce = *ce_in;
+            ce.partial = ws + w.loss_partial;
+            g.tag = "fwd_post2_ce";
+            WN_TRY(fw_gemm(c, g, nullptr, &ce));   // g.C = the caller's dlogits (or NULL)
+        } else {
+            WN_TRY(fw_gemm(c, g));
+        }
     }
-    return rt_check("wn_forward");
+    return rt_check(who);
+}
+
+extern "C" int wn_forward(const WnConfig* cfg, int B, int T, const float* params, const int64_t* x, const float* h,
+                          float* logits, void* wsp, size_t ws_bytes, int flags, void* stream) {
+    api_enter();
+    return forward_impl(cfg, B, T, params, x, h, logits, nullptr, wsp, ws_bytes, flags, stream, "wn_forward");
+}
+
+// 1: wn_forward_loss runs the loss as the epilogue of conv_post_2 for this model / flags (softmax head with at most 256
+// classes on the split contractions); 0: it needs the logits scratch buffer and runs wn_forward + wn_softmax_ce_loss.
+// WN_CE_EPILOGUE=0 in the environment forces 0 (A/B measurements).
+static bool ce_epilogue_on() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("WN_CE_EPILOGUE");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v != 0;
+}
+extern "C" int wn_forward_loss_fused(const WnConfig* cfg, int B, int T, int flags) {
+    api_enter();
+    Dims d;
+    Ws w;
+    if (check_cfg(cfg, &d) || B < 1 || T < 1 || make_ws(d, B, T, &w)) return 0;
+    const bool split = !(flags & WN_FLAG_EXACT_MFMA);
+    // the conditions under which fw_gemm takes the split contraction for conv_post_2, plus: every class in one 256-row block
+    return (ce_epilogue_on() && split && d.Qo == d.Q && d.Qo >= 128 && d.Qo <= WN_G6_BM &&
+            wn_gemm6_apk_elems(d.Qo, d.S) <= 2 * w.apk_floats && (long)d.Qo * T * 4 < 0x7ffffff0L) ? 1 : 0;
+}
+
+extern "C" int wn_forward_loss(const WnConfig* cfg, int B, int T, const float* params, const int64_t* x, const float* h,
+                               const int64_t* target, int t_start, float grad_scale, float loss_scale, float* loss,
+                               float* dlogits, float* logits_scratch, void* wsp, size_t ws_bytes, int flags, void* stream) {
+    api_enter();
+    if (!target || !loss) return fail(1, "NULL argument");
+    if (t_start < 0 || t_start >= T) return fail(1, "t_start=%d outside [0,%d)", t_start, T);
+    if (!wn_forward_loss_fused(cfg, B, T, flags)) {
+        if (!logits_scratch) return fail(1, "this model / flag set needs the logits scratch buffer (wn_forward_loss_fused() == 0)");
+        WN_TRY(forward_impl(cfg, B, T, params, x, h, logits_scratch, nullptr, wsp, ws_bytes, flags, stream, "wn_forward_loss"));
+        return wn_softmax_ce_loss(cfg, B, T, logits_scratch, target, t_start, grad_scale, loss_scale, loss, dlogits, wsp, ws_bytes,
+                                  stream);
+    }
+    CeEpi ce;
+    ce.target = target; ce.t_start = t_start; ce.gs = grad_scale / ((float)B * (float)(T - t_start)); ce.partial = nullptr;
+    WN_TRY(forward_impl(cfg, B, T, params, x, h, dlogits, &ce, wsp, ws_bytes, flags, stream, "wn_forward_loss"));
+    Ctx c;
+    WN_TRY(make_ctx(&c, cfg, B, T, wsp, ws_bytes, flags, stream));
+    const int np = ((T + WN_G6_BN - 1) / WN_G6_BN) * B;
+    WN_TRY(wn_sum_partials(c.ws + c.w.loss_partial, np, loss_scale / ((float)B * (float)(T - t_start)), loss, c.st));
+    return rt_check("wn_forward_loss");
 }
 
 // ------------------------------------------------------------------------------------------

@@ -222,9 +222,11 @@ static __device__ __forceinline__ f32x16 f32x16_zero() {
 #ifdef WN_EMU
 static inline float wn_exp2(float x) { return exp2f(x); }
 static inline float wn_rcp(float x) { return 1.0f / x; }
+static inline float wn_log2(float x) { return log2f(x); }
 #else
 static __device__ __forceinline__ float wn_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 static __device__ __forceinline__ float wn_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+static __device__ __forceinline__ float wn_log2(float x) { return __builtin_amdgcn_logf(x); }
 #endif
 static __device__ __forceinline__ float wn_sigmoid(float x) {
     const float xc = fminf(fmaxf(x, -80.0f), 80.0f);  // keeps 2^(...) finite; sigmoid(+-80) is 1/0 in fp32

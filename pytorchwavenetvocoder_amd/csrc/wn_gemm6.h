@@ -52,11 +52,22 @@ typedef struct WnGemm6Args {
     const float* gbw_S;
     const float* gbw_Gt;
     float* gbw_dP;
+    // Softmax cross-entropy epilogue (ce_target != NULL; the post-net's last contraction, reference wavenet.py:522 +
+    // train.py:461,534-536): the block holds ALL M <= 256 rows (classes) of its 128 columns (positions), so
+    //   logit = acc + bias never goes to memory; C (nullable) receives d(mean loss)/d(logit) * ce_gs = (softmax - onehot) * ce_gs
+    //   for columns >= ce_t_start and 0 in front of them; ce_partial[z * gridDim.x + x] = sum over the block's columns
+    //   >= ce_t_start of (logsumexp - logit[target]).  target[z * ce_tstride + column] is taken modulo M.
+    const long long* ce_target;
+    long ce_tstride;
+    int ce_t_start;
+    float ce_gs;
+    float* ce_partial;
 } WnGemm6Args;
 
 static inline void wn_gemm6_no_gate(WnGemm6Args* a) {
     a->gate_R = 0; a->gate_S = 0; a->gate_Gt = 0; a->gate_Z = 0; a->gate_G = 0; a->gate_gb = 0; a->gate_F = 0; a->gate_U = 1;
     a->gate_upw = 0; a->gate_cvec = 0; a->gbw_S = 0; a->gbw_Gt = 0; a->gbw_dP = 0; a->no_interior = 0; a->stagger = 0;
+    a->ce_target = 0; a->ce_tstride = 0; a->ce_t_start = 0; a->ce_gs = 0.f; a->ce_partial = 0;
 }
 
 static inline long wn_gemm6_apk_elems(int M, int K) {

@@ -122,6 +122,9 @@ static long long* g6_dbg_for(const char* tag) { return (g6_dbg_buf && tag && str
 #define G6_STAMP(step, slot)
 #endif
 
+// CE = true: the instantiation with the softmax cross-entropy epilogue (its own kernel, so that the register allocation of
+// the plain one does not depend on it)
+template <bool CE>
 __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_DBG_PARAM) {
     WN_DYN_SMEM(smem_raw);
     // stage s: A pieces [3][256][16] bf16 (24 KB) then B pieces [3][128][16] bf16 (12 KB)
@@ -374,6 +377,107 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
         }
         return;
     }
+    if (CE) {
+        // Softmax cross-entropy on the accumulators (see WnGemm6Args).  A column's M classes are spread over the two lane
+        // halves (rows 4 hi + ...) of the two waves wm = 0, 1 with the same wn: per-lane reduction over its 64 values, one
+        // lane-half exchange, one exchange through LDS -- for the maximum, then for the sum of exponentials.  The logits stay
+        // in the accumulator registers (overwritten by exp(logit - max)).
+        float* red = reinterpret_cast<float*>(smem_raw);   // [max | sum][wave][64 columns], then [4] loss
+        __syncthreads();                                   // every wave is done with the operand stages
+        const float NEG = -3.0e38f;
+        float mx[2], sm[2], vt[2];
+        int tq[2];
+        bool okc[2], live[2];
+        WN_UNROLL
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + 64 * wn + 32 * j + li;
+            okc[j] = col < g.N;
+            live[j] = okc[j] && col >= g.ce_t_start;
+            // class index modulo M like k_softmax_ce; the 64-bit division only runs for a target outside [0, M)
+            long long tg = okc[j] ? g.ce_target[(long)b * g.ce_tstride + col] : 0;
+            if ((unsigned long long)tg >= (unsigned long long)g.M) {
+                tg %= g.M;
+                if (tg < 0) tg += g.M;
+            }
+            tq[j] = (int)tg;
+            mx[j] = NEG;
+        }
+        WN_UNROLL
+        for (int i = 0; i < 4; ++i) {
+            float bv[16];
+            WN_UNROLL
+            for (int r = 0; r < 16; ++r)
+                bv[r] = wn_buf_load(Biasr, (128 * wm + 32 * i + 4 * hi) * 4, mfma32_row(r, 0) * 4);   // no bias: empty descriptor, reads 0
+            WN_UNROLL
+            for (int j = 0; j < 2; ++j) {
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 128 * wm + 32 * i + mfma32_row(r, hi);
+                    float v = acc[i][j][r] + bv[r];
+                    v = row < g.M ? v : NEG;
+                    acc[i][j][r] = v;
+                    mx[j] = fmaxf(mx[j], v);
+                }
+            }
+        }
+        WN_UNROLL
+        for (int j = 0; j < 2; ++j) {
+            mx[j] = fmaxf(mx[j], __shfl_xor(mx[j], 32, 64));
+            red[wave * 64 + 32 * j + li] = mx[j];   // both lane halves write the same value
+        }
+        __syncthreads();
+        WN_UNROLL
+        for (int j = 0; j < 2; ++j) {
+            const float m = fmaxf(mx[j], red[(wave ^ 2) * 64 + 32 * j + li]);
+            mx[j] = m;
+            float s = 0.f, t = 0.f;
+            WN_UNROLL
+            for (int i = 0; i < 4; ++i) {
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 128 * wm + 32 * i + mfma32_row(r, hi);
+                    const float v = acc[i][j][r];
+                    t = (row == tq[j]) ? v : t;   // the target's logit, in the one lane that holds its row
+                    const float e = wn_exp2((v - m) * 1.4426950408889634f);
+                    acc[i][j][r] = e;
+                    s += e;
+                }
+            }
+            vt[j] = t;
+            s += __shfl_xor(s, 32, 64);
+            sm[j] = s;
+            red[256 + wave * 64 + 32 * j + li] = s;
+        }
+        __syncthreads();
+        const wn_rsrc_t Dl = wn_make_buf(g.C ? g.C + (long)b * g.c_zstride : g.B, g.C ? (unsigned)((long)g.M * g.ldc * 4) : 0u);
+        float my_loss = 0.f;
+        WN_UNROLL
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + 64 * wn + 32 * j + li;
+            const float s = sm[j] + red[256 + (wave ^ 2) * 64 + 32 * j + li];
+            const float lse = wn_log2(s) * 0.6931471805599453f + mx[j];
+            const float scale = live[j] ? wn_rcp(s) * g.ce_gs : 0.f;
+            const float hot = live[j] ? g.ce_gs : 0.f;
+            const int tl = tq[j] - 128 * wm - 4 * hi;   // row == tq  <=>  32 i + mfma32_row(r, 0) == tl
+            my_loss += (live[j] && tl >= 0 && tl < 128 && ((tl >> 2) & 1) == 0) ? (lse - vt[j]) : 0.f;
+            const int vC = okc[j] ? ((128 * wm + 4 * hi) * (int)g.ldc + col) * 4 : 0x7ffffff0;
+            WN_UNROLL
+            for (int i = 0; i < 4; ++i) {
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = 32 * i + mfma32_row(r, 0);
+                    const float d = acc[i][j][r] * scale - (rl == tl ? hot : 0.f);
+                    wn_buf_store(Dl, d, vC, rl * (int)g.ldc * 4);   // rows >= M fall outside the descriptor: dropped
+                }
+            }
+        }
+        my_loss = wave_reduce_sum(my_loss);
+        __syncthreads();
+        if (lane == 0) red[wave] = my_loss;
+        __syncthreads();
+        if (tid == 0) g.ce_partial[(long)blk.z * gridDim.x + blk.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        return;
+    }
     // Interior blocks (the whole 256 x 128 tile inside C; every block of the benchmark's launches): the row part of an
     // address is a wave-uniform scalar offset, the lane keeps ONE byte offset per tensor -- no per-element range selects.
     const bool interior = (m0 + WN_G6_BM <= g.M) && (n0 + WN_G6_BN <= g.N) && !g.no_interior &&
@@ -493,6 +597,7 @@ int wn_gemm6_launch(const WnGemm6Args* gp, wn_stream_t st) {
     }
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.nbatch <= 0) return 1;
     if (g.b_seg_len < g.K && (g.b_seg_len % 16) != 0) return 2;
+    if (g.ce_target && (g.Mpad != WN_G6_BM || !g.ce_partial || g.gate_S || g.gbw_dP || g.E || g.D || g.accumulate || g.relu)) return 4;
 #ifdef WN_TIMING
     const int lds = getenv("WN_G6_ONE_PER_CU") ? 120 * 1024 : 2 * (3 * WN_G6_BM * 32 + 3 * WN_G6_BN * 32);   // experiment: no second block on the CU
 #else
@@ -501,8 +606,10 @@ int wn_gemm6_launch(const WnGemm6Args* gp, wn_stream_t st) {
 #ifndef WN_EMU
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm6), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-            hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm6<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+                hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm6<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+                hipSuccess)
             return 3;
         attr_set = true;
     }
@@ -510,7 +617,10 @@ int wn_gemm6_launch(const WnGemm6Args* gp, wn_stream_t st) {
     WN_PROF(g.tag ? g.tag : "gemm6", 2.0 * g.M * g.N * (double)g.K * g.nbatch,
             ((double)g.M * g.K * 6.0 + (double)g.K * g.N * 4.0 + (double)g.M * g.N * (g.E ? 8.0 : 4.0)) * g.nbatch, st);
     dim3 grid((unsigned)((g.N + WN_G6_BN - 1) / WN_G6_BN), (unsigned)(g.Mpad / WN_G6_BM), (unsigned)g.nbatch);
-    WN_LAUNCH(k_gemm6, grid, dim3(G6_T), lds, st, g, xcd_block_order() ? 2 : 0 G6_DBG_ARG(g.tag));
+    if (g.ce_target)
+        WN_LAUNCH(k_gemm6<true>, grid, dim3(G6_T), lds, st, g, xcd_block_order() ? 2 : 0 G6_DBG_ARG(g.tag));
+    else
+        WN_LAUNCH(k_gemm6<false>, grid, dim3(G6_T), lds, st, g, xcd_block_order() ? 2 : 0 G6_DBG_ARG(g.tag));
     return 0;
 }
 

@@ -155,6 +155,37 @@ class WaveNetEngine(object):
         self._last_inputs = (x, h)
         return logits
 
+    def forward_loss(self, x, h, target, t_start=None, grad_scale=1.0, loss_scale=1.0, want_grad=True):
+        """``forward`` + ``loss`` of a training step in one call (reference train.py:533-536).  Softmax head with at most
+        256 classes on the split contractions: the cross-entropy is the EPILOGUE of the conv_post_2 contraction, the
+        (B, Q, T) logits never reach memory (``wn_forward_loss``); otherwise the two calls back to back.
+        Returns (loss, dlogits) exactly as ``loss`` does."""
+        self._check_device(x, h, target)
+        if x.dtype != torch.int64 or x.dim() != 2:
+            raise ValueError("x must be a LongTensor (B, T)")
+        B, T = x.shape
+        if t_start is None:
+            t_start = self.receptive_field
+        flen = T // self.cfg.upsampling_factor if self.cfg.upsampling_factor > 0 else T
+        if h.dim() != 3 or h.size(0) != B or h.size(1) != self.cfg.n_aux or h.size(2) != flen:
+            raise ValueError("h must be (B, n_aux, %d)" % flen)
+        if self.cfg.upsampling_factor > 0 and T % self.cfg.upsampling_factor != 0:
+            raise ValueError("T must be a multiple of the upsampling factor")
+        x, h, target = x.contiguous(), h.contiguous().float(), target.contiguous()
+        cfg = ctypes.byref(self.cfg)
+        fused = bool(self.lib.wn_forward_loss_fused(cfg, B, T, self.flags))
+        ws = self.workspace(B, T)
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        dlogits = torch.empty((B, self.out_channels, T), dtype=torch.float32, device=self.device) if want_grad else None
+        scratch = None if fused else torch.empty((B, self.out_channels, T), dtype=torch.float32, device=self.device)
+        rc = self.lib.wn_forward_loss(cfg, B, T, _ptr(self.flat_params), _ptr(x), _ptr(h), _ptr(target), int(t_start),
+                                      float(grad_scale), float(loss_scale), _ptr(loss), _ptr(dlogits), _ptr(scratch),
+                                      _ptr(ws), ws.numel() * 4, self.flags, _stream_handle(self.device))
+        self.lib.check(rc, "wn_forward_loss")
+        self._last_shape = (B, T)
+        self._last_inputs = (x, h)
+        return loss, dlogits
+
     def loss(self, logits, target, t_start=None, grad_scale=1.0, loss_scale=1.0, want_grad=True):
         """Softmax-CE over positions >= t_start (default: receptive field).  Returns (loss, dlogits)."""
         self._check_device(logits, target)

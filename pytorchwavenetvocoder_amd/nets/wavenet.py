@@ -293,11 +293,12 @@ class WaveNet(nn.Module):
         ``None`` for the dead last ``res_1x1``) and returns the mean loss as a 1-element device
         tensor (no host sync).  ``grad_scale`` multiplies the gradients (1/world_size for DP)."""
         eng = self._engine
-        logits = eng.forward(x, h)
-        self._fwd_serial += 1
         if t_start is None:
             t_start = eng.receptive_field
-        loss, dlogits = eng.loss(logits, t, t_start=t_start, grad_scale=grad_scale)
+        # forward + loss in one call: the cross-entropy is the epilogue of conv_post_2 where the model allows it (the logits
+        # never reach memory), and the backward pass runs its post-net part over the loss window only
+        loss, dlogits = eng.forward_loss(x, h, t, t_start=t_start, grad_scale=grad_scale)
+        self._fwd_serial += 1
         flat = eng.backward(dlogits, events=events, layers_per_bucket=layers_per_bucket, t_first=t_start)
         for p, (off, n, shape, dead) in zip(self.parameters(), self._param_slices):
             p.grad = None if dead else flat[off:off + n].view(shape)

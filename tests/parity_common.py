@@ -165,7 +165,13 @@ def run_fullsize_vs_oracle(cfg_tuple, B, T, seed, lib, device, flag_sets, scale=
     eng.flags = flag_sets[0]
     xd, hd, td = x.to(device), h.to(device), t.to(device)
     logits = eng.forward(xd, hd)
-    loss, dl = eng.loss(logits, td)
+    loss_sep, dl_sep = eng.loss(logits, td)
+    # the training step's own call: forward + loss in one, the cross-entropy as the epilogue of conv_post_2 (wn_forward_loss);
+    # its loss and dlogits are what is compared with the oracle below, and against the separate entry points here
+    loss, dl = eng.forward_loss(xd, hd, td)
+    assert abs(float(loss.cpu()) - float(loss_sep.cpu())) <= 2e-6 * max(1.0, abs(float(loss_sep.cpu())))
+    assert float((dl - dl_sep).abs().max()) <= 1e-5 * float(dl_sep.abs().max())
+    del dl_sep
     m_skip = (eng.saved(_lib.WS_RELU_SKIP) > 0).float().cpu()
     m_post = (eng.saved(_lib.WS_RELU_POST1) > 0).float().cpu()
     try:

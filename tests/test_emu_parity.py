@@ -401,7 +401,7 @@ def test_loss_window_backward_equals_the_full_backward():
     cfg_t = (32, 4, 64, 32, 7, 1, 2, 16)
     cfg = O.OracleConfig(*cfg_t)
     assert cfg.receptive_field == 128
-    B, T = 2, 304
+    B, T = 1, 272
     params, x, h, t, margin, sd = PC.pick_instance(cfg, B, T, 61, 0.1)
     _, _, grads_ref = O.train_step(cfg, params, None, x, h, t)
     for flags in (_lib.FLAG_AUX_FUSED, _lib.FLAG_AUX_FUSED | _lib.FLAG_NO_CHAIN, _lib.FLAG_NO_FUSED):
@@ -428,3 +428,43 @@ def test_loss_window_backward_equals_the_full_backward():
     a = eng.backward(dl).clone()
     b = eng.backward(dl, t_first=127).clone()
     assert torch.equal(a, b)
+
+
+def test_cross_entropy_as_the_epilogue_of_conv_post_2():
+    """wn_forward_loss (ABI v5): with a softmax head of 128..256 classes the loss is the epilogue of the conv_post_2
+    contraction (k_gemm6: max / sum of exponentials across lane halves and the two wave rows of a block, logits never
+    written).  Same loss and dlogits as wn_forward + wn_softmax_ce_loss and as the oracle; ragged last 128-column tile;
+    targets of every class range; 128 classes (the second wave row holds no class), 200 (part of it), 256; fallback
+    (64 classes: wn_forward_loss_fused == 0) through the logits scratch; the launch log shows no softmax_ce launch."""
+    import ctypes
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat
+    for cfg_t, B, T, fused in (((256, 6, 64, 128, 2, 2, 2, 16), 2, 176, 1), ((200, 4, 64, 128, 2, 1, 2, 0), 1, 150, 1),
+                                ((128, 4, 64, 128, 2, 1, 2, 8), 1, 136, 1), ((64, 4, 64, 128, 2, 1, 2, 8), 1, 72, 0)):
+        cfg = O.OracleConfig(*cfg_t)
+        params = O.random_params(cfg, 71, scale=0.3)
+        x, h, t = O.synthetic_batch(cfg, B, T, 72)
+        eng = WaveNetEngine(*cfg_t, device="cpu", library=emu_library())
+        load_state_into_flat(eng, params)
+        assert eng.lib.wn_forward_loss_fused(ctypes.byref(eng.cfg), B, T, eng.flags) == fused
+        logits = eng.forward(x, h)
+        loss0, dl0 = eng.loss(logits, t, grad_scale=0.5)
+        log = PC.launch_log(emu_library(), lambda: eng.forward_loss(x, h, t, grad_scale=0.5))
+        loss1, dl1 = eng.forward_loss(x, h, t, grad_scale=0.5)
+        assert ("fwd_post2_ce" in log) == bool(fused) and ("softmax_ce" in log) == (not fused), log
+        rf = cfg.receptive_field
+        assert float(dl1[:, :, :rf].abs().max()) == 0.0
+        assert abs(float(loss1) - float(loss0)) <= 2e-6 * max(1.0, abs(float(loss0)))
+        # p = e / sum vs exp(v - lse): a few ulp of a probability near 1, seen through p - 1
+        assert float((dl1 - dl0).abs().max()) <= 1e-5 * float(dl0.abs().max()), float((dl1 - dl0).abs().max())
+        loss_ref, logits_ref, _ = O.train_step(cfg, params, None, x, h, t)
+        assert abs(float(loss1) - float(loss_ref)) <= PC.TOL_LOSS
+        # another loss window and no gradient buffer
+        loss2, none = eng.forward_loss(x, h, t, t_start=rf + 5, want_grad=False)
+        loss3, _ = eng.loss(logits, t, t_start=rf + 5, want_grad=False)
+        assert none is None and abs(float(loss2) - float(loss3)) <= 2e-6 * max(1.0, abs(float(loss3)))
+        # the backward pass after forward_loss sees the same saved activations as after forward
+        g1 = eng.backward(dl1, t_first=rf).clone()
+        eng.forward(x, h)
+        g0 = eng.backward(dl0, t_first=rf).clone()
+        assert float((g1 - g0).abs().max()) <= 5e-6 * float(g0.abs().max())

@@ -98,4 +98,49 @@ def test_loss_window_backward_vs_full_backward():
     g_mod = m.engine.grads().clone()
     logits = m.engine.forward(x, h)
     loss, dl = m.engine.loss(logits, t)
-    assert torch.equal(g_mod, m.engine.backward(dl, t_first=rf))
+    g_sep = m.engine.backward(dl, t_first=rf)   # (the module takes its dlogits from the loss epilogue of conv_post_2: round-off apart)
+    assert float((g_mod - g_sep).abs().max()) <= 5e-6 * float(g_sep.abs().max())
+
+
+def test_cross_entropy_epilogue_vs_separate_loss_kernel():
+    """wn_forward_loss on the GPU: the cross-entropy as the epilogue of the conv_post_2 contraction (logits never written)
+    against wn_forward + wn_softmax_ce_loss -- config-2 model on three ragged sequences (last 128-column block partly
+    outside T), several loss windows and gradient scales, no gradient buffer; then one full training half-step through
+    the module against the same step assembled from the separate entry points; bitwise run to run."""
+    import ctypes
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat
+    from pytorchwavenetvocoder_amd.nets import WaveNet
+    cfg_t = (256, 80, 64, 256, 10, 3, 2, 80)
+    cfg = O.OracleConfig(*cfg_t)
+    rf = cfg.receptive_field
+    B, T = 3, 3120 + 80 * 13       # 4160 = 32.5 blocks of 128 columns
+    params = O.random_params(cfg, 47, scale=0.05)
+    x, h, t = (v.to(DEV) for v in O.synthetic_batch(cfg, B, T, 48))
+    eng = WaveNetEngine(*cfg_t, device=DEV, library=_lib())
+    load_state_into_flat(eng, params)
+    assert eng.lib.wn_forward_loss_fused(ctypes.byref(eng.cfg), B, T, eng.flags) == 1
+    logits = eng.forward(x, h)
+    for t_start, gs in ((None, 1.0), (rf + 77, 0.125), (0, 1.0)):
+        l0, d0 = eng.loss(logits, t, t_start=t_start, grad_scale=gs)
+        l1, d1 = eng.forward_loss(x, h, t, t_start=t_start, grad_scale=gs)
+        l2, d2 = eng.forward_loss(x, h, t, t_start=t_start, grad_scale=gs)
+        e_l = abs(float(l1) - float(l0)) / max(1.0, abs(float(l0)))
+        e_d = float((d1 - d0).abs().max()) / float(d0.abs().max())
+        print("CE epilogue t_start=%s: loss rel err %.3g, dlogits err / max %.3g" % (t_start, e_l, e_d))
+        assert e_l <= 2e-6 and e_d <= 1e-5
+        assert torch.equal(l1, l2) and torch.equal(d1, d2)
+        ts = rf if t_start is None else t_start
+        assert ts == 0 or float(d1[:, :, :ts].abs().max()) == 0.0
+    l3, none = eng.forward_loss(x, h, t, want_grad=False)
+    assert none is None and abs(float(l3) - float(eng.loss(logits, t)[0])) <= 2e-6 * abs(float(l3))
+    # the module's training half-step = forward_loss + windowed backward
+    m = WaveNet(*cfg_t).to(DEV)
+    load_state_into_flat(m.engine, params)
+    lm = m.loss_and_backward(x, h, t)
+    g_mod = m.engine.grads().clone()
+    logits = m.engine.forward(x, h)
+    ls, dl = m.engine.loss(logits, t)
+    g_sep = m.engine.backward(dl, t_first=rf)
+    assert abs(float(lm) - float(ls)) <= 2e-6 * abs(float(ls))
+    assert float((g_mod - g_sep).abs().max()) <= 5e-6 * float(g_sep.abs().max())
