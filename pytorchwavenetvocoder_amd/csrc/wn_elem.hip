@@ -31,8 +31,11 @@ __global__ __launch_bounds__(WN_TPB) void k_front_gather(const int64_t* __restri
         const int idx = t - (K - 1 - tap);
         int v = -1;
         if (idx >= 0) {
-            long long xv = x[(long)b * T + idx] % Q;
-            if (xv < 0) xv += Q;
+            long long xv = x[(long)b * T + idx];
+            if ((unsigned long long)xv >= (unsigned long long)Q) {   // OneHot's modulo (wavenet.py:88): 64-bit division, rare
+                xv %= Q;
+                if (xv < 0) xv += Q;
+            }
             v = (int)xv;
         }
         q[tap] = v;
@@ -45,10 +48,93 @@ __global__ __launch_bounds__(WN_TPB) void k_front_gather(const int64_t* __restri
     }
 }
 
+// The same gather with the weight table in LDS.  k_front_gather reads wc_f[(tap Q + q) R + r] with a different q in every
+// lane: 64 cache lines per load instruction, K R of them per thread -- bound by the texture addresser (63 us for the
+// benchmark's 47 MB of output).  Here one 1024-thread workgroup per CU copies the table (K Q R floats: 128 KB for the
+// benchmark's model) into LDS once, rows padded to R + 1 words so that the lanes' rows fall into different banks, and walks
+// a chunk of one sequence.  Same additions in the same order: bit-identical output.
+#define FG_T 1024
+__global__ __launch_bounds__(FG_T) void k_front_gather_lds(const int64_t* __restrict__ x, const float* __restrict__ wc_f,
+                                                           const float* __restrict__ bias, float* __restrict__ x0, int T,
+                                                           int Q, int R, int K, int chunk) {
+    WN_DYN_SMEM(smem_raw);
+    float* tab = reinterpret_cast<float*>(smem_raw);   // [K * Q][R + 1]
+    const int RP = R + 1;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, t0 = blockIdx.x * chunk;
+    const int t1 = (t0 + chunk < T) ? t0 + chunk : T;
+    {   // table copy: 8 independent 16-byte loads in flight per thread (a dependent load per iteration made it latency bound)
+        const int n4 = (K * Q * R) >> 2;   // R % 4 == 0 (launcher): the 4 elements of a load share a table row
+        for (int base = 0; base < n4; base += 8 * FG_T) {
+            float4 v[8];
+            WN_UNROLL
+            for (int u = 0; u < 8; ++u) {
+                const int i4 = base + u * FG_T + tid;
+                v[u] = i4 < n4 ? reinterpret_cast<const float4*>(wc_f)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            WN_UNROLL
+            for (int u = 0; u < 8; ++u) {
+                const int i4 = base + u * FG_T + tid;
+                if (i4 < n4) {
+                    const int e = i4 << 2, row = e / R, r = e - row * R;
+                    float* d = tab + row * RP + r;
+                    d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = t0 + tid; t < t1; t += FG_T) {
+        int q[8];
+        for (int tap = 0; tap < K; ++tap) {
+            const int idx = t - (K - 1 - tap);
+            int v = -1;
+            if (idx >= 0) {
+                long long xv = x[(long)b * T + idx];
+                if ((unsigned long long)xv >= (unsigned long long)Q) {
+                    xv %= Q;
+                    if (xv < 0) xv += Q;
+                }
+                v = (tap * Q + (int)xv) * RP;
+            }
+            q[tap] = v;
+        }
+        for (int r0 = 0; r0 < R; r0 += 4) {   // R % 4 == 0; 4 K LDS reads in flight
+            float v[4];
+            WN_UNROLL
+            for (int u = 0; u < 4; ++u) v[u] = bias[r0 + u];
+            for (int tap = 0; tap < K; ++tap) {
+                if (q[tap] >= 0) {
+                    WN_UNROLL
+                    for (int u = 0; u < 4; ++u) v[u] += tab[q[tap] + r0 + u];
+                }
+            }
+            WN_UNROLL
+            for (int u = 0; u < 4; ++u) x0[((long)b * R + r0 + u) * T + t] = v[u];
+        }
+    }
+}
+
 int wn_front_gather(const int64_t* x, const float* wc_f, const float* bias, float* x0, int B, int T, int Q, int R, int K,
                     wn_stream_t st) {
     WN_PROF("front_gather", 0.0, 0.0, st);
     if (K > 8 || K < 1) return 1;
+    const size_t lds = (size_t)K * Q * (R + 1) * 4;
+    if (lds <= 150 * 1024 && R % 4 == 0 && (long)B * T >= 16384) {   // (small calls: the table copy would dominate)
+        int nc = 256 / B;
+        if (nc < 1) nc = 1;
+        int ch = (T + nc - 1) / nc;
+        ch = (ch + 63) / 64 * 64;
+        nc = (T + ch - 1) / ch;
+#ifndef WN_EMU
+        if (lds > 64 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_gather_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return 2;
+#endif
+        WN_LAUNCH(k_front_gather_lds, dim3((unsigned)nc, (unsigned)B), dim3(FG_T), lds, st, x, wc_f, bias, x0, T, Q, R, K, ch);
+        return 0;
+    }
     dim3 grid((T + WN_TPB - 1) / WN_TPB, B);
     WN_LAUNCH(k_front_gather, grid, dim3(WN_TPB), 0, st, x, wc_f, bias, x0, T, Q, R, K);
     return 0;
@@ -306,7 +392,7 @@ int wn_sum_layers(const float* params, long off, long ls, int L, int n, float* o
 }
 
 // ---------------------------------------------------------------------------------------------
-// grid.x: blocks [0, nbg) sum the 16-sample groups of a frame (one thread per (o', f)), blocks [nbg, nbg + nbw) build
+// grid.x: blocks [0, nbg) sum the 16-sample groups of a frame (one thread per (o', f)), block nbg builds
 // the dw_partial block of this (l, b): row 0 = sum over frames of qp, the other rows zero.
 __global__ __launch_bounds__(WN_TPB) void k_aux_finish(const float* __restrict__ dGp, long dgp_lstride,
                                                        const float* __restrict__ qp, long qp_lstride, float* __restrict__ dG,
@@ -322,21 +408,51 @@ __global__ __launch_bounds__(WN_TPB) void k_aux_finish(const float* __restrict__
         for (int i = 0; i < per; ++i) s += src[i];
         dG[(long)l * nb * R2 * F + ((long)b * R2 + o) * F + f] = s;
     } else {
-        const int idx = ((int)blockIdx.x - nbg) * WN_TPB + threadIdx.x;
-        if (idx >= R2 * U) return;
-        const int o = idx / U, j = idx - o * U;
-        float s = 0.0f;
-        if (o == 0) {
-            const float* src = qp + (long)l * qp_lstride + (long)b * T + j;
-            for (int f0 = 0; f0 < F; f0 += 8) {  // 8 independent loads in flight, summed in frame order
-                float v[8];
-                WN_UNROLL
-                for (int u = 0; u < 8; ++u) v[u] = (f0 + u < F) ? src[(long)(f0 + u) * U] : 0.0f;
-                WN_UNROLL
-                for (int u = 0; u < 8; ++u) s += v[u];
+        // ONE workgroup per (l, b): row 0 of its dw_partial block = sum over the frames of qp (per phase j), the other rows
+        // zero.  The frames are dealt to WN_TPB / U thread groups in contiguous ranges (8 loads in flight each) and the range
+        // sums added in group order: one thread per phase walking all F frames was 36 dependent rounds of loads on 80
+        // threads -- the critical path of this launch.
+        __shared__ float part[WN_TPB];
+        const int tid = threadIdx.x;
+        float* dst = dw_partial + (long)l * nb * R2 * U + (long)b * R2 * U;
+        const float* src0 = qp + (long)l * qp_lstride + (long)b * T;
+        if (U <= WN_TPB) {
+            const int np = WN_TPB / U, p = tid / U, j = tid - p * U;
+            const int Fp = (F + np - 1) / np;
+            const int f_lo = p * Fp, f_hi = (f_lo + Fp < F) ? f_lo + Fp : F;
+            float s = 0.0f;
+            if (p < np) {
+                const float* src = src0 + j;
+                for (int f0 = f_lo; f0 < f_hi; f0 += 8) {  // summed in frame order
+                    float v[8];
+                    WN_UNROLL
+                    for (int u = 0; u < 8; ++u) v[u] = (f0 + u < f_hi) ? src[(long)(f0 + u) * U] : 0.0f;
+                    WN_UNROLL
+                    for (int u = 0; u < 8; ++u) s += v[u];
+                }
+            }
+            part[tid] = s;
+            __syncthreads();
+            if (p == 0) {
+                float t = part[j];
+                for (int q = 1; q < np; ++q) t += part[q * U + j];
+                dst[j] = t;
+            }
+        } else {
+            for (int j = tid; j < U; j += WN_TPB) {
+                const float* src = src0 + j;
+                float s = 0.0f;
+                for (int f0 = 0; f0 < F; f0 += 8) {
+                    float v[8];
+                    WN_UNROLL
+                    for (int u = 0; u < 8; ++u) v[u] = (f0 + u < F) ? src[(long)(f0 + u) * U] : 0.0f;
+                    WN_UNROLL
+                    for (int u = 0; u < 8; ++u) s += v[u];
+                }
+                dst[j] = s;
             }
         }
-        dw_partial[(long)l * nb * R2 * U + ((long)b * R2 + o) * U + j] = s;
+        for (int idx = U + tid; idx < R2 * U; idx += WN_TPB) dst[idx] = 0.0f;
     }
 }
 
@@ -344,7 +460,7 @@ int wn_aux_finish(const float* dGp, long dgp_lstride, const float* qp, long qp_l
                   int T, int R2, int U, int F, int nl, wn_stream_t st) {
     WN_PROF("aux_finish", 0.0, (double)nl * B * ((double)R2 * (T / 16) + T) * 4.0, st);
     if (U < 16 || (U & 15) || (long)U * F != T) return 1;
-    const int nbg = (R2 * F + WN_TPB - 1) / WN_TPB, nbw = (R2 * U + WN_TPB - 1) / WN_TPB;
+    const int nbg = (R2 * F + WN_TPB - 1) / WN_TPB, nbw = 1;
     WN_LAUNCH(k_aux_finish, dim3((unsigned)(nbg + nbw), (unsigned)B, (unsigned)nl), dim3(WN_TPB), 0, st, dGp, dgp_lstride, qp,
               qp_lstride, dG, dw_partial, T, R2, U, F, nbg);
     return 0;
@@ -578,52 +694,85 @@ __global__ __launch_bounds__(FD_T) void k_front_dw_scatter(const float* __restri
     // number of waves).  16 waves per CU instead of 4 hide the LDS-atomic latency.  The token
     // columns of a 64-step strip are looked up once and reused for all channels of the wave.
     float* rsum = acc + R * KQ;  // [R] row sums (bias gradient)
-    for (int ts = t0; ts < t1; ts += 64) {
-        const int t = ts + lane;
-        const bool ok = t < t1;
-        int col[8];
+    // FD_S strips of 64 time steps are in flight together: their token columns and their (up to 8) channel rows are all
+    // requested before the first LDS atomic -- one memory latency per FD_S strips instead of two per strip (the atomics
+    // order the loop, so the compiler cannot overlap strips on its own).  The bias gradient (row sums of dX0) is
+    // accumulated from the same registers: per lane and channel slot, reduced across the wave at the end.
+    constexpr int FD_S = 4;
+    float rs[8];
+    WN_UNROLL
+    for (int u = 0; u < 8; ++u) rs[u] = 0.0f;
+    for (int ts = t0; ts < t1; ts += 64 * FD_S) {
+        int col[FD_S][8];
+        bool okS[FD_S];
         WN_UNROLL
-        for (int k = 0; k < 8; ++k) {
-            col[k] = -1;
-            const int tq = t - (K - 1 - k);
-            if (k < K && ok && tq >= 0) {
-                long long q = xb[tq] % Q;
-                if (q < 0) q += Q;
-                col[k] = k * Q + (int)q;
+        for (int sidx = 0; sidx < FD_S; ++sidx) {
+            const int t = ts + 64 * sidx + lane;
+            const bool ok = t < t1;
+            okS[sidx] = ok;
+            WN_UNROLL
+            for (int k = 0; k < 8; ++k) {
+                col[sidx][k] = -1;
+                const int tq = t - (K - 1 - k);
+                if (k < K && ok && tq >= 0) {
+                    long long q = xb[tq];
+                    if ((unsigned long long)q >= (unsigned long long)Q) {   // OneHot takes indices modulo Q (wavenet.py:88); rare
+                        q %= Q;
+                        if (q < 0) q += Q;
+                    }
+                    col[sidx][k] = k * Q + (int)q;
+                }
             }
         }
-        for (int c0 = wave; c0 < R; c0 += 8 * FD_W) {  // up to 8 channels of this wave per step: 8 loads in flight
-            float v[8];
+        for (int c0 = wave; c0 < R; c0 += 8 * FD_W) {  // up to 8 channels of this wave per step
+            float v[FD_S][8];
             WN_UNROLL
-            for (int u = 0; u < 8; ++u) {
-                const int c = c0 + FD_W * u;
-                v[u] = (ok && c < R) ? db[(long)c * T + t] : 0.0f;
+            for (int sidx = 0; sidx < FD_S; ++sidx) {
+                const int t = ts + 64 * sidx + lane;
+                WN_UNROLL
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + FD_W * u;
+                    v[sidx][u] = (okS[sidx] && c < R) ? db[(long)c * T + t] : 0.0f;
+                }
             }
             WN_UNROLL
-            for (int u = 0; u < 8; ++u) {
-                const int c = c0 + FD_W * u;
-                if (c < R) {
-                    WN_UNROLL
-                    for (int k = 0; k < 8; ++k)
-                        if (col[k] >= 0) atomicAdd(&acc[c * KQ + col[k]], v[u]);
+            for (int sidx = 0; sidx < FD_S; ++sidx) {
+                WN_UNROLL
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + FD_W * u;
+                    if (c < R) {
+                        if (c0 == wave) rs[u] += v[sidx][u];   // R <= 8 FD_W: one slot per channel (else the second pass below)
+                        WN_UNROLL
+                        for (int k = 0; k < 8; ++k)
+                            if (col[sidx][k] >= 0) atomicAdd(&acc[c * KQ + col[sidx][k]], v[sidx][u]);
+                    }
                 }
             }
         }
     }
-    // bias gradient: row sums of this block's time range (second, cheap pass over the same cache lines)
-    for (int c = wave; c < R; c += FD_W) {
-        float rs = 0.0f;
-        for (int ts = t0; ts < t1; ts += 256) {
-            float v[4];
-            WN_UNROLL
-            for (int u = 0; u < 4; ++u) {
-                const int t = ts + 64 * u + lane;
-                v[u] = t < t1 ? db[(long)c * T + t] : 0.0f;
-            }
-            rs += (v[0] + v[1]) + (v[2] + v[3]);
+    if (R <= 8 * FD_W) {
+        WN_UNROLL
+        for (int u = 0; u < 8; ++u) {
+            const int c = wave + FD_W * u;
+            const float tot = wave_reduce_sum(rs[u]);
+            if (lane == 0 && c < R) rsum[c] = tot;
         }
-        rs = wave_reduce_sum(rs);
-        if (lane == 0) rsum[c] = rs;
+    } else {
+        // bias gradient: row sums of this block's time range (second pass over the same cache lines)
+        for (int c = wave; c < R; c += FD_W) {
+            float r1 = 0.0f;
+            for (int ts = t0; ts < t1; ts += 256) {
+                float v[4];
+                WN_UNROLL
+                for (int u = 0; u < 4; ++u) {
+                    const int t = ts + 64 * u + lane;
+                    v[u] = t < t1 ? db[(long)c * T + t] : 0.0f;
+                }
+                r1 += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+            r1 = wave_reduce_sum(r1);
+            if (lane == 0) rsum[c] = r1;
+        }
     }
     __syncthreads();
     if ((((long)R * KQ + R) & 3) == 0) {  // per-block slabs stay 16-byte aligned
@@ -633,21 +782,157 @@ __global__ __launch_bounds__(FD_T) void k_front_dw_scatter(const float* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same partial tables on the matrix cores, without atomics (R <= 64, K Q <= 512: the benchmark's front conv).
+// LDS float atomics retire about one lane per 3 cycles on gfx950: the 1 536 wave-atomics of a k_front_dw_scatter workgroup
+// cost 125 us, two thirds of that launch (profiles/r02/front_dw_probe.txt).  Here the table of a workgroup's time chunk is
+//      acc[c][(k, q)] = sum_t dX0[c][t] * onehot(x[t - (K-1-k)])[q]
+// as a contraction over t: A = dX0 (R x 32 time steps per iteration) in the 3-way bf16 split -- every thread splits ONE pair
+// of values and leaves the pieces in LDS in the A-fragment layout -- and B = the one-hot columns, which a lane builds in
+// registers from the chunk's token indices (kept in LDS as ints): 1.0 is exact in bf16, so three MFMAs per fragment
+// (h, m, l pieces of A) give the fp32 result; wave w owns the 32 columns [32 w, 32 w + 32) of the table (all of one tap) in
+// 2 accumulator tiles.  Deterministic (no atomics), same partial layout as the scatter kernel.
+#define FM_T 1024
+__global__ __launch_bounds__(FM_T) void k_front_dw_mfma(const float* __restrict__ dX0, const int64_t* __restrict__ x,
+                                                       float* __restrict__ partial, int T, int R, int K, int Q, int chunk) {
+    WN_DYN_SMEM(smem_raw);
+    // stage[buf][kblock][piece][64 rows][32 B]  (2 x 2 x 3 x 2 KB = 24 KB), then the chunk's tokens as ints
+    char* stage = smem_raw;
+    int* tok = reinterpret_cast<int*>(smem_raw + 2 * 2 * 3 * 2048);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.y, t0 = blockIdx.x * chunk;
+    const int t1 = (t0 + chunk < T) ? t0 + chunk : T;
+    const int KQ = K * Q;
+    const int64_t* xb = x + (long)b * T;
+    const float* db = dX0 + (long)b * R * T;
+    float* out = partial + ((long)b * gridDim.x + blockIdx.x) * ((long)R * KQ + R);
+    // tokens of positions [t0 - (K-1), t1): index i <-> position t0 - (K-1) + i; -1 in front of the sequence
+    for (int i = tid; i < (t1 - t0) + K - 1; i += FM_T) {
+        const int tq = t0 - (K - 1) + i;
+        int v = -1;
+        if (tq >= 0) {
+            long long q = xb[tq];
+            if ((unsigned long long)q >= (unsigned long long)Q) {   // OneHot takes indices modulo Q (wavenet.py:88); rare
+                q %= Q;
+                if (q < 0) q += Q;
+            }
+            v = (int)q;
+        }
+        tok[i] = v;
+    }
+    // phase-1 role of this thread: one pair of time steps of one row per iteration
+    const int prow = tid >> 4, pkq = tid & 15;
+    const int pkb = pkq >> 3, phi = (pkq & 7) >> 2, pdw = pkq & 3;
+    const int pofs = pkb * (3 * 2048) + (prow * 2 + phi) * 16 + pdw * 4;   // + piece * 2048 + buf * 2 * 3 * 2048
+    const float* prowp = db + (long)prow * T;
+    float rsum = 0.0f;
+    // phase-2 role of this wave: column tile `wave` (32 columns of one tap), if the table has that many
+    const bool active = wave * 32 < KQ;
+    const int col = wave * 32 + li;
+    const int tap = col / Q, q = col - tap * Q;
+    const int tshift = tap;   // token index of position t with this tap: (t - t0) + (K-1) - (K-1-tap) = (t - t0) + tap
+    f32x16 acc[2];
+    acc[0] = f32x16_zero();
+    acc[1] = f32x16_zero();
+    const int nrt = R >> 5;
+    auto stage_pair = [&](int ts, int buf) {
+        const int t = ts + 2 * pkq;
+        const float x0 = (prow < R && t < t1) ? prowp[t] : 0.0f;
+        const float x1 = (prow < R && t + 1 < t1) ? prowp[t + 1] : 0.0f;
+        rsum += x0 + x1;
+        const unsigned h = wn_pk_bf16(x0, x1);
+        const float r0 = x0 - wn_bits_f32(h << 16), r1 = x1 - wn_bits_f32(h & 0xffff0000u);
+        const unsigned m = wn_pk_bf16(r0, r1);
+        const unsigned l = wn_pk_bf16(r0 - wn_bits_f32(m << 16), r1 - wn_bits_f32(m & 0xffff0000u));
+        char* d = stage + buf * (2 * 3 * 2048) + pofs;
+        *reinterpret_cast<unsigned*>(d) = h;
+        *reinterpret_cast<unsigned*>(d + 2048) = m;
+        *reinterpret_cast<unsigned*>(d + 4096) = l;
+    };
+    stage_pair(t0, 0);
+    __syncthreads();   // tokens and the first stage
+    int buf = 0;
+    for (int ts = t0; ts < t1; ts += 32, buf ^= 1) {
+        if (ts + 32 < t1) stage_pair(ts + 32, buf ^ 1);
+        if (active) {
+            WN_UNROLL
+            for (int kb = 0; kb < 2; ++kb) {
+                // one-hot B fragment: this lane's column q against the tokens of its 8 time steps
+                const int* tk = tok + (ts - t0) + 16 * kb + 8 * hi + tshift;
+                unsigned bq[4];
+                WN_UNROLL
+                for (int e = 0; e < 4; ++e)
+                    bq[e] = (tk[2 * e] == q ? 0x3F80u : 0u) | (tk[2 * e + 1] == q ? 0x3F800000u : 0u);
+                wn_f4 bf;
+                bf.x = wn_bits_f32(bq[0]); bf.y = wn_bits_f32(bq[1]); bf.z = wn_bits_f32(bq[2]); bf.w = wn_bits_f32(bq[3]);
+                const char* sa = stage + buf * (2 * 3 * 2048) + kb * (3 * 2048) + (li * 2 + hi) * 16;
+                WN_UNROLL
+                for (int rt = 0; rt < 2; ++rt) {
+                    if (rt < nrt) {
+                        const wn_f4 al = *reinterpret_cast<const wn_f4*>(sa + 4096 + rt * 1024);
+                        const wn_f4 am = *reinterpret_cast<const wn_f4*>(sa + 2048 + rt * 1024);
+                        const wn_f4 ah = *reinterpret_cast<const wn_f4*>(sa + rt * 1024);
+                        acc[rt] = mfma_bf16(al, bf, acc[rt]);   // small pieces first
+                        acc[rt] = mfma_bf16(am, bf, acc[rt]);
+                        acc[rt] = mfma_bf16(ah, bf, acc[rt]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (active) {
+        WN_UNROLL
+        for (int rt = 0; rt < 2; ++rt) {
+            if (rt < nrt) {
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) out[(long)(32 * rt + mfma32_row(r, hi)) * KQ + col] = acc[rt][r];
+            }
+        }
+    }
+    // bias gradient: the 16 threads of a row are adjacent lanes
+    for (int m = 1; m < 16; m <<= 1) rsum += __shfl_xor(rsum, m, 64);
+    if (pkq == 0 && prow < R) out[(long)R * KQ + prow] = rsum;
+}
+
+static bool front_dw_mfma_ok(int R, int K, int Q) {
+    static int on = -1;   // WN_FRONT_DW_MFMA=0: the LDS-atomic scatter kernel (A/B)
+    if (on < 0) {
+        const char* e = getenv("WN_FRONT_DW_MFMA");
+        on = (e && e[0] == '0') ? 0 : 1;
+    }
+    return on && (R == 32 || R == 64) && Q % 32 == 0 && K * Q <= 512 && K <= 8;
+}
+
 // dW[c][q][k] = sum_blk partial[blk][c][k*Q+q] ; db[c] = sum_blk partial[blk][R*KQ + c]
+// 64 outputs per workgroup (one per lane: coalesced rows of the partial slabs), the partial slabs dealt to the 4 waves in
+// contiguous ranges, 8 loads in flight per thread; the 4 range sums are added in wave order -- a fixed order, whatever the
+// grid.  (One thread per output walking all 256 slabs was latency bound on half the CUs: 129 workgroups x 32 dependent
+// rounds of loads, most of the 0.18 ms of the front-conv weight gradient.)
 __global__ __launch_bounds__(256) void k_front_dw_reduce(const float* __restrict__ partial, int nblk, float* __restrict__ dW,
                                                          float* __restrict__ db, int R, int K, int Q) {
+    __shared__ float part[4][64];
     const int KQ = K * Q;
     const long per = (long)R * KQ + R;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= per) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + lane;
+    const int per_w = (nblk + 3) / 4;
+    const int b_lo = wave * per_w, b_hi = (b_lo + per_w < nblk) ? b_lo + per_w : nblk;
     float s = 0.0f;
-    for (int b0 = 0; b0 < nblk; b0 += 8) {  // 8 independent loads in flight, summed in block order
-        float v[8];
-        WN_UNROLL
-        for (int u = 0; u < 8; ++u) v[u] = (b0 + u < nblk) ? partial[(long)(b0 + u) * per + i] : 0.0f;
-        WN_UNROLL
-        for (int u = 0; u < 8; ++u) s += v[u];
+    if (i < per) {
+        for (int b0 = b_lo; b0 < b_hi; b0 += 8) {  // 8 independent loads in flight, summed in slab order
+            float v[8];
+            WN_UNROLL
+            for (int u = 0; u < 8; ++u) v[u] = (b0 + u < b_hi) ? partial[(long)(b0 + u) * per + i] : 0.0f;
+            WN_UNROLL
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
     }
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave != 0 || i >= per) return;
+    s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
     if (i < (long)R * KQ) {
         const int c = (int)(i / KQ), r = (int)(i % KQ);
         const int k = r / Q, q = r % Q;
@@ -670,9 +955,13 @@ int wn_front_dw(const float* dX0, const int64_t* x, float* partial, float* dW, f
                             (int)lds) != hipSuccess)
         return 2;
 #endif
+    if (front_dw_mfma_ok(R, K, Q)) {
+        const size_t lds_m = 2 * 2 * 3 * 2048 + (size_t)(ch + K) * 4;
+        WN_LAUNCH(k_front_dw_mfma, dim3((unsigned)nc, (unsigned)B), dim3(FM_T), lds_m, st, dX0, x, partial, T, R, K, Q, ch);
+    } else
     WN_LAUNCH(k_front_dw_scatter, dim3((unsigned)nc, (unsigned)B), dim3(FD_T), lds, st, dX0, x, partial, T, R, K, Q, ch);
     const long per = (long)R * K * Q + R;
-    WN_LAUNCH(k_front_dw_reduce, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, partial, nc * B, dW, db, R, K, Q);
+    WN_LAUNCH(k_front_dw_reduce, dim3((unsigned)((per + 63) / 64)), dim3(256), 0, st, partial, nc * B, dW, db, R, K, Q);
     return 0;
 }
 

@@ -8,7 +8,10 @@ import torch
 
 from oracle import wavenet_oracle as O
 
-FRONT_CASES = [(256, 64, 2, 2, 1000), (256, 64, 3, 1, 333), (37, 12, 2, 3, 77), (256, 512, 2, 1, 257)]
+# the last three have B * T >= 16384: the LDS-table variant of the gather (k_front_gather_lds), incl. a ragged last chunk,
+# a table that does not fit the LDS (Q = 256, R = 64, K = 3 -> the plain gather) and negative / out-of-range indices
+FRONT_CASES = [(256, 64, 2, 2, 1000), (256, 64, 3, 1, 333), (37, 12, 2, 3, 77), (256, 512, 2, 1, 257),
+               (256, 64, 2, 3, 5501), (64, 32, 3, 2, 8200), (256, 64, 3, 2, 8200)]
 CONV_CASES = [(64, 64, 2, 1, 2, 500), (64, 128, 2, 16, 1, 300), (64, 64, 3, 4, 2, 257), (12, 20, 3, 7, 3, 91),
               (64, 64, 2, 512, 1, 300), (256, 64, 2, 1, 1, 200)]
 
@@ -22,7 +25,7 @@ def check_op_front(lib, device, Q, R, K, B, T):
     rs = np.random.RandomState(Q + R + K)
     w = torch.from_numpy(rs.standard_normal((R, Q, K)).astype(np.float32))
     b = torch.from_numpy(rs.standard_normal(R).astype(np.float32))
-    x = torch.from_numpy(rs.randint(0, 3 * Q, (B, T)))        # values beyond Q: taken modulo Q (wavenet.py:88)
+    x = torch.from_numpy(rs.randint(-Q, 3 * Q, (B, T)))       # values outside [0, Q): taken modulo Q (wavenet.py:88)
     ref = O.causal_conv1d(O.onehot(x, Q, torch.float32).transpose(1, 2), w, b, 1)
     out = torch.empty((B, R, T), dtype=torch.float32, device=device)
     scratch = torch.empty(K * Q * R, dtype=torch.float32, device=device)

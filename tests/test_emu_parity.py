@@ -242,7 +242,7 @@ def test_fused_adam_skips_live_parameters_without_a_gradient_like_torch_adam():
 def test_op_level_entry_points():
     """wn_op_front / wn_op_causal_conv (a subset of the GPU cases of tests/test_gpu_ops.py) on the host-compiled kernels."""
     from tests import ops_common as OC
-    for case in OC.FRONT_CASES[1:3]:
+    for case in OC.FRONT_CASES[1:3] + [OC.FRONT_CASES[5]]:   # the last one: the LDS-table gather (B * T >= 16384)
         OC.check_op_front(emu_library(), "cpu", *case)
     for case in (OC.CONV_CASES[2], OC.CONV_CASES[3], (64, 64, 2, 512, 1, 150)):
         OC.check_op_causal_conv(emu_library(), "cpu", *case)
@@ -468,3 +468,19 @@ def test_cross_entropy_as_the_epilogue_of_conv_post_2():
         eng.forward(x, h)
         g0 = eng.backward(dl0, t_first=rf).clone()
         assert float((g1 - g0).abs().max()) <= 5e-6 * float(g0.abs().max())
+
+
+def test_front_conv_weight_gradient_on_the_matrix_cores():
+    """k_front_dw_mfma (R in {32, 64}, K * Q <= 512): the front conv's weight gradient as a contraction over time with a
+    one-hot B operand built from the token indices, instead of LDS float atomics.  256 classes x 2 taps (all 16 column
+    tiles), a chunk that ends inside a 32-step iteration (T % 32 != 0), two sequences, R = 32 (one row tile) and
+    kernel_size 1 / 3 tables -- every gradient against the oracle (the front conv's is causal.weight / causal.bias)."""
+    for cfg_t, B, T, seed in (((256, 4, 64, 32, 2, 1, 2, 8), 2, 72, 81), ((128, 4, 32, 32, 2, 1, 3, 0), 1, 45, 82),
+                              ((256, 4, 64, 32, 2, 1, 1, 8), 1, 40, 83)):
+        log = {}
+
+        def run():
+            e, g = PC.run_oracle_vs_engine(cfg_t, B, T, seed, emu_library(), "cpu", scale=0.2)
+            log["err"] = (e, g)
+        counts = PC.launch_log(emu_library(), run)
+        assert counts.get("dw_front_scatter") == 1 and "dw_front_onehot" not in counts, counts
