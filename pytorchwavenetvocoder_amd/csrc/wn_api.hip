@@ -392,6 +392,7 @@ struct Ws {
     long dZs_floats;
     long red_scratch_floats;
     long apk_floats;
+    long apk_pre[6];   // the six weight sets of a training step, split ONCE per step (pack_weights): offsets, -1 = none
     long front_partial, front_partial_floats;
     long total;
     int F;  // frames (T/U, or T without upsampling)
@@ -489,6 +490,14 @@ static int make_ws(const Dims& d, int B, int T, Ws* w) {
         }
         w->apk_floats = (e + 1) / 2;
         CARVE(apk, w->apk_floats);
+        // ... and one buffer each for the weight sets every step uses (same order as pre_jobs())
+        const int pre[6][2] = {{d.S, d.L * d.R}, {d.S, d.S}, {d.Qo, d.S}, {d.S, d.Qo}, {d.S, d.S}, {(d.L - 1) * d.R, d.S}};
+        for (int i = 0; i < 6; ++i) {
+            w->apk_pre[i] = -1;
+            if (pre[i][0] < 128 || (i == 5 && w->dZs_floats <= 0)) continue;   // (the split contraction wants M >= 128)
+            w->apk_pre[i] = o;
+            o += al64((wn_gemm6_apk_elems(pre[i][0], pre[i][1]) + 1) / 2);
+        }
     }
 #undef CARVE
     w->total = o;
@@ -541,6 +550,8 @@ struct Ctx {
     wn_stream_t st;
     bool fused;
     bool split_bf16;  // forward-type contractions on the bf16 matrix cores (3-way split, fp32-equivalent)
+    const float* params;   // set by the training entry points: lets fw_gemm recognise the pre-split weight sets
+    bool have_pre;         // apk_pre[] of this workspace is valid (regular layout, not the decode state)
 };
 
 static int make_ctx(Ctx* c, const WnConfig* cfg, int B, int T, void* ws, size_t ws_bytes, int flags, void* stream) {
@@ -557,6 +568,8 @@ static int make_ctx(Ctx* c, const WnConfig* cfg, int B, int T, void* ws, size_t 
     c->st = (wn_stream_t)stream;
     c->fused = wn_fused_supported(c->d.R, c->d.K, c->d.S) && !(flags & WN_FLAG_NO_FUSED);
     c->split_bf16 = !(flags & WN_FLAG_EXACT_MFMA);
+    c->params = nullptr;
+    c->have_pre = true;
     return 0;
 }
 
@@ -609,6 +622,43 @@ struct GateEpi {   // optional gate epilogue of a split contraction (wn_gemm6.h)
     float* bw_dP = nullptr;
 };
 // can this launch run on the split kernel (the only one with the gate epilogues)?
+// The weight sets of the split contractions every training step launches: (A, lda, M, K) and where their split form lives.
+// They are split ONCE per step by one launch at the end of pack_weights (six dependent little launches in front of the
+// contractions otherwise); wn_backward finds them in the workspace wn_forward left.  WN_PREPACK=0: split before each use.
+struct PreJob { const float* A; long lda; int M, K; long off; };
+static bool prepack_on() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("WN_PREPACK");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v != 0;
+}
+static int pre_jobs(const Ctx& c, const float* params, PreJob (&j)[6]) {
+    const Dims& d = c.d;
+    const Lay& y = c.y;
+    const Ws& w = c.w;
+    float* ws = c.ws;
+    const PreJob all[6] = {{ws + w.wskip_f, d.S, d.S, d.L * d.R, w.apk_pre[0]},
+                           {ws + w.w1_f, d.S, d.S, d.S, w.apk_pre[1]},
+                           {ws + w.w2_f, d.Qo, d.Qo, d.S, w.apk_pre[2]},
+                           {params ? params + y.post2_w : nullptr, d.S, d.S, d.Qo, w.apk_pre[3]},
+                           {params ? params + y.post1_w : nullptr, d.S, d.S, d.S, w.apk_pre[4]},
+                           {ws + w.wskipT_f, (long)d.L * d.R, (d.L - 1) * d.R, d.S, w.apk_pre[5]}};
+    int n = 0;
+    if (!c.have_pre || !c.split_bf16 || !prepack_on()) return 0;
+    for (int i = 0; i < 6; ++i)
+        if (all[i].A && all[i].off >= 0) j[n++] = all[i];
+    return n;
+}
+static long prepacked_offset(const Ctx& c, const WnGemmArgs& g) {
+    PreJob j[6];
+    const int n = pre_jobs(c, c.params, j);
+    for (int i = 0; i < n; ++i)
+        if (j[i].A == g.A && j[i].lda == g.lda && j[i].M == g.M && j[i].K == g.K) return j[i].off;
+    return -1;
+}
+
 static bool fw_gemm_split_ok(const Ctx& c, const WnGemmArgs& g) {
     return c.split_bf16 && g.M >= 128 && !g.a_kmajor && !g.b_kmajor &&
            (g.b_seg_len >= g.K || g.b_seg_len % 16 == 0) && g.ksplit == 1 && g.nlayer == 1 && !g.b_relu &&
@@ -628,7 +678,11 @@ static int fw_gemm(const Ctx& c, const WnGemmArgs& g, const GateEpi* ge = nullpt
                     wn_gemm6_apk_elems(g.M, g.K) <= 2 * c.w.apk_floats && (long)g.M * g.ldc * 4 < 0x7ffffff0L;
     if (!ok) return (ge || ce) ? fail(3, "gate / loss epilogue needs the split contraction") : wn_gemm_launch(&g, c.st);
     unsigned short* apk = reinterpret_cast<unsigned short*>(c.ws + c.w.apk);
-    WN_TRY(wn_gemm6_pack(g.A, g.lda, g.M, g.K, apk, ge ? ge->gate_R : 0, c.st));
+    const long pre = ge ? -1 : prepacked_offset(c, g);
+    if (pre >= 0)
+        apk = reinterpret_cast<unsigned short*>(c.ws + pre);   // split once per step by pack_weights
+    else
+        WN_TRY(wn_gemm6_pack(g.A, g.lda, g.M, g.K, apk, ge ? ge->gate_R : 0, c.st));
     WnGemm6Args a;
     wn_gemm6_no_gate(&a);
     if (ge) {
@@ -722,6 +776,19 @@ static int pack_weights(const Ctx& c, const float* params) {
     WN_TRY(wn_cvec(&ca, c.st));
     WN_TRY(wn_sum_layers(params, y.skip0 + (long)d.S * d.R, y.ls_skip, d.L, d.S, ws + w.bskip, c.st));
     WN_TRY(wn_fill(ws + w.one, 1.0f, 64, c.st));
+    {   // the split form of the weight sets every step contracts with: one launch (after the re-layouts above)
+        PreJob pj[6];
+        const int n = pre_jobs(c, params, pj);
+        if (n > 0) {
+            WnGemm6PackJobs jobs;
+            jobs.njobs = n;
+            for (int i = 0; i < n; ++i) {
+                jobs.src[i] = pj[i].A; jobs.lda[i] = pj[i].lda; jobs.M[i] = pj[i].M; jobs.K[i] = pj[i].K;
+                jobs.dst[i] = reinterpret_cast<unsigned short*>(ws + pj[i].off);
+            }
+            WN_TRY(wn_gemm6_pack_batch(&jobs, c.st));
+        }
+    }
     return rt_check("pack_weights");
 }
 
@@ -843,6 +910,7 @@ static int forward_impl(const WnConfig* cfg, int B, int T, const float* params, 
     Ctx c;
     WN_TRY(make_ctx(&c, cfg, B, T, wsp, ws_bytes, flags, stream));
     if (!params || !x || !h || (!logits && !ce_in)) return fail(1, "NULL argument");
+    c.params = params;
     // overlap mode (opt-in, fused kernels): partial skip-sums run on the internal side stream beside the stack
     SideLock side((flags & WN_FLAG_FWD_OVERLAP) && c.fused && !wn_prof_is_on(), c.st);
     Ctx cs = c;
@@ -1052,6 +1120,7 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
     Ctx c;
     WN_TRY(make_ctx(&c, cfg, B, T, wsp, ws_bytes, flags, stream));
     if (!params || !x || !h || !dlogits || !grads) return fail(1, "NULL argument");
+    c.params = params;
     if (t_first < 0 || t_first >= T) return fail(1, "t_first=%d outside [0,%d)", t_first, T);
     // Loss window.  The loss of train.py:534-536 covers [:, receptive_field:], so dlogits is exactly zero in front of it, and
     // everything between the logits and the residual stack is pointwise in time: dO2, dSkip and the skip part of every
@@ -1632,6 +1701,8 @@ static void dl_ctx(Ctx* c, const WnConfig* cfg, const Dims& d, const DlLay& y, i
     // exact f32 MFMA here: with a handful of utterance columns the contractions are weight-streaming bound and
     // the split path would re-split (or stream 1.5x the bytes of) the weights on every step
     c->split_bf16 = false;
+    c->params = nullptr;
+    c->have_pre = false;
 }
 
 extern "C" int64_t wn_decode_layered_state_floats(const WnConfig* cfg, int B) {

@@ -78,6 +78,17 @@ static inline long wn_gemm6_apk_elems(int M, int K) {
 // source row wn_gemm6_gate_row(p, gate_R) -- every 256-row block holds 128 channels, each wave's 128 rows = 64 sigmoid
 // rows followed by the 64 tanh rows of the same channels (the pairing of the forward gate epilogue).
 int wn_gemm6_pack(const float* src, long lda, int M, int K, unsigned short* Apk, int gate_R, wn_stream_t st);
+// several weight sets in ONE launch (the six of a training step are split once per step: wn_api.hip pack_weights)
+#define WN_G6_PACK_MAXJOBS 8
+typedef struct WnGemm6PackJobs {
+    int njobs;
+    int blk0[WN_G6_PACK_MAXJOBS + 1];   // first block of job j (filled by wn_gemm6_pack_batch)
+    const float* src[WN_G6_PACK_MAXJOBS];
+    long lda[WN_G6_PACK_MAXJOBS];
+    int M[WN_G6_PACK_MAXJOBS], K[WN_G6_PACK_MAXJOBS];
+    unsigned short* dst[WN_G6_PACK_MAXJOBS];
+} WnGemm6PackJobs;
+int wn_gemm6_pack_batch(WnGemm6PackJobs* jobs, wn_stream_t st);
 static __host__ __device__ inline int wn_gemm6_gate_row(int p, int R) {
     const int mb = p >> 8, wmi = (p >> 7) & 1, i = (p >> 5) & 3, rr = p & 31;
     const int c = mb * 128 + wmi * 64 + (i & 1) * 32 + rr;

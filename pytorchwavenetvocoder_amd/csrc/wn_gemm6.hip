@@ -28,9 +28,20 @@
 
 #define G6_T 256
 
+static __device__ __forceinline__ void gemm6_pack_elem(const float* src, long lda, int M, int K, int Mpad, unsigned short* Apk,
+                                                       int gate_R, long idx);
 __global__ void k_gemm6_pack(const float* src, long lda, int M, int K, int Mpad, unsigned short* Apk, int gate_R) {
+    gemm6_pack_elem(src, lda, M, K, Mpad, Apk, gate_R, (long)blockIdx.x * 256 + threadIdx.x);
+}
+__global__ void k_gemm6_pack_batch(WnGemm6PackJobs a) {
+    int j = 0;
+    while (j + 1 < a.njobs && (int)blockIdx.x >= a.blk0[j + 1]) ++j;   // block-uniform
+    const int Mpad = (a.M[j] + WN_G6_BM - 1) / WN_G6_BM * WN_G6_BM;
+    gemm6_pack_elem(a.src[j], a.lda[j], a.M[j], a.K[j], Mpad, a.dst[j], 0, (long)((int)blockIdx.x - a.blk0[j]) * 256 + threadIdx.x);
+}
+static __device__ __forceinline__ void gemm6_pack_elem(const float* src, long lda, int M, int K, int Mpad, unsigned short* Apk,
+                                                       int gate_R, long idx) {
     // one thread per (kb, m): 16 k values -> 3 x 16 bf16
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const int nkb = (K + 15) / 16;
     if (idx >= (long)nkb * Mpad) return;
     const int kb = (int)(idx / Mpad), m = (int)(idx % Mpad);
@@ -50,6 +61,20 @@ __global__ void k_gemm6_pack(const float* src, long lda, int M, int K, int Mpad,
         d[(((long)kb * 3 + 1) * Mpad + m) * 8 + e / 2] = md;
         d[(((long)kb * 3 + 2) * Mpad + m) * 8 + e / 2] = lo;
     }
+}
+
+int wn_gemm6_pack_batch(WnGemm6PackJobs* jobs, wn_stream_t st) {
+    WN_PROF("gemm6_pack", 0.0, 0.0, st);
+    int nblk = 0;
+    for (int j = 0; j < jobs->njobs; ++j) {
+        const int Mpad = (jobs->M[j] + WN_G6_BM - 1) / WN_G6_BM * WN_G6_BM;
+        jobs->blk0[j] = nblk;
+        nblk += (int)(((long)((jobs->K[j] + 15) / 16) * Mpad + 255) / 256);
+    }
+    jobs->blk0[jobs->njobs] = nblk;
+    if (nblk <= 0) return 0;
+    WN_LAUNCH(k_gemm6_pack_batch, dim3((unsigned)nblk), dim3(256), 0, st, *jobs);
+    return 0;
 }
 
 int wn_gemm6_pack(const float* src, long lda, int M, int K, unsigned short* Apk, int gate_R, wn_stream_t st) {
