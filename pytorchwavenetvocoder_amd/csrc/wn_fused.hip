@@ -908,15 +908,285 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_resblock_fwd_v2 -- the split K = 2 forward block with everything but the MFMAs in the MFMAs' shadow (opt-in: WN_FWD_V2=1).
+//
+// What tools/microbench/mfma_valu.hip measured: a wave's OWN independent VALU / memory instructions issue between its MFMAs
+// for free (up to ~6 per 32x32x16 MFMA), whereas VALU work of the OTHER wave of the SIMD slows a wave's MFMAs down 3x.  In
+// k_resblock_fwd_s the gate phase (4 transcendentals per element) is a phase of its own, so the two waves of a SIMD add their
+// MFMA and gate phases up instead of overlapping them (0.31 matrix utilisation).  Here the row tiles are contracted in two
+// passes -- first {0, 2} (sigmoid / tanh rows of channels 0..31), then {1, 3} -- so that the gate of the first 32 channels
+// runs between the MFMAs of the second pass, the gate of the other 32 between the res-1x1 MFMAs of the first 32 (whose
+// k-blocks need exactly the first half's z), and every operand split sits in the shadow of the previous group of MFMAs.  The
+// price is splitting the tile's operands twice.  Every accumulator sees the same MFMAs in the same order and the gate math
+// is the same code: the output is bit-identical to k_resblock_fwd_s<2, 0>.
+// ---------------------------------------------------------------------------------------------
+template <bool KEEP_G>
+__global__ __launch_bounds__(WN_FT) void k_resblock_fwd_v2(FwdArgs a) {
+    WN_DYN_SMEM(smem_raw);
+    constexpr int K = 2;
+    constexpr int WD_BLK = 3 * 128 * 32, WR_BLK = 3 * 64 * 32;  // bytes of one 16-k block
+    char* Wd = smem_raw;
+    char* Wr = Wd + K * 4 * WD_BLK;
+    float* cv = reinterpret_cast<float*>(Wr + 4 * WR_BLK);       // [128]
+    float* rb = cv + 128;                                        // [64]
+    if (a.wimg != nullptr) {
+        copy_image_to_lds(smem_raw, a.wimg, fwd_image_bytes(K));
+        WN_WAIT_VMCNT(0);
+    } else {
+        fill_fwd_image<K>(Wd, Wr, a.wd_f, a.wres_f, threadIdx.x, WN_FT);
+    }
+    if (threadIdx.x < 128) cv[threadIdx.x] = a.cvec[threadIdx.x];
+    if (threadIdx.x < 64) rb[threadIdx.x] = a.res_bias[threadIdx.x];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int li = lane & 31, hi = lane >> 5;
+    const int T = a.T;
+    const int T4 = T * 4;
+    const int F4 = a.F * 4;
+    const int tiles_per_b = (T + 31) >> 5;
+    const unsigned slab = (unsigned)(64 * T4);
+    const TileWalk walk = tile_walk(a.B * tiles_per_b, threadIdx.x >> 6);
+    const int step = WN_UNIFORM(walk.step), tile_end = WN_UNIFORM(walk.end);
+    const int fo = wn_frag_off(li, hi);
+    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};  // small terms first
+
+    float xh[32], xc[32];
+    // operand loads: lanes outside the sequence carry an out-of-range offset and read 0 (no select at use)
+    auto issue_hist = [&](int tl_v) {
+        const int tl = WN_UNIFORM(tl_v);
+        const int b = tl / tiles_per_b;
+        const int t = (tl - b * tiles_per_b) * 32 + li;
+        const wn_rsrc_t Xr = wn_make_buf(a.X + (long)b * 64 * T, slab);
+        const int ts = t - a.dil;
+        const int vt = (t < T && ts >= 0) ? (4 * hi * T + ts) * 4 : WN_VOFF_DEAD;
+        WN_UNROLL
+        for (int s = 0; s < 32; ++s) xh[s] = wn_buf_load(Xr, vt, kappa64(s, 0) * T4);
+    };
+    // product t6 of one 16-k block for a pair of row tiles: the unit between two slices of shadow work
+    auto mfma_pair = [&](f32x16& A0, f32x16& A1, const wn_f4 (&af)[2][3], const wn_f4 (&bf)[3], int t6) {
+        A0 = mfma_bf16(af[0][PA[t6]], bf[PB[t6]], A0);
+        A1 = mfma_bf16(af[1][PA[t6]], bf[PB[t6]], A1);
+    };
+
+    int tile_v = walk.first;
+    if (tile_v < tile_end) issue_hist(tile_v);
+    while (tile_v < tile_end) {
+        const int tile = WN_UNIFORM(tile_v);
+        const int b = tile / tiles_per_b;
+        const int t = (tile - b * tiles_per_b) * 32 + li;
+        const bool inb = t < T;
+        const int tc = inb ? t : T - 1;
+        const int vcur = inb ? (4 * hi * T + t) * 4 : WN_VOFF_DEAD;
+        {
+            const wn_rsrc_t Xr = wn_make_buf(a.X + (long)b * 64 * T, slab);
+            WN_UNROLL
+            for (int s = 0; s < 32; ++s) xc[s] = wn_buf_load(Xr, vcur, kappa64(s, 0) * T4);
+        }
+        // aux / gate inputs of the first 32 channels (frame rate, L2 resident)
+        const int fr = tc / a.U;
+        const float upw_j = a.upw[tc - fr * a.U];
+        const wn_rsrc_t Gr = wn_make_buf(a.G + (long)b * a.g_bstride, (unsigned)(128 * F4));
+        const int vg = (4 * hi * a.F + fr) * 4;
+        float ga[16], gg[16];
+        WN_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            ga[r] = wn_buf_load(Gr, vg, mfma32_row(r, 0) * F4);
+            gg[r] = wn_buf_load(Gr, vg, (mfma32_row(r, 0) + 64) * F4);
+        }
+        WN_SCHED_BARRIER();
+        f32x16 acc[4];
+        WN_UNROLL
+        for (int q = 0; q < 4; ++q) acc[q] = f32x16_zero();
+        const wn_rsrc_t Sr = wn_make_buf(a.S + (long)b * 64 * T, slab);
+        const wn_rsrc_t Gtr = wn_make_buf((KEEP_G ? a.Gt : a.S) + (long)b * 64 * T, slab);
+        const wn_rsrc_t Zr = wn_make_buf(a.Z + (long)b * 64 * T, slab);
+        const float* cvl = cv + 4 * hi;
+        f32x16 z[2];
+        // gate of element (q, r) (reference wavenet.py:529-532): P = conv + w[j]*G[row][f] + c[row]; saved for backward
+        auto gate_elem = [&](int q, int r) {
+            const int row0 = 32 * q + mfma32_row(r, 0);  // + 4*hi is in the per-lane offsets
+            const float pa = acc[q][r] + (upw_j * ga[r] + cvl[row0]);
+            const float pg = acc[q + 2][r] + (upw_j * gg[r] + cvl[row0 + 64]);
+            if (q == 0) {   // the register pair now takes the aux projection of channel 32 + row (second half)
+                ga[r] = wn_buf_load(Gr, vg, (32 + mfma32_row(r, 0)) * F4);
+                gg[r] = wn_buf_load(Gr, vg, (96 + mfma32_row(r, 0)) * F4);
+            }
+            const float sv = wn_sigmoid(pa);
+            const float gv = wn_tanh(pg);
+            const float zz = sv * gv;
+            z[q][r] = zz;
+            wn_buf_store(Sr, sv, vcur, row0 * T4);
+            if (KEEP_G) wn_buf_store(Gtr, gv, vcur, row0 * T4);
+            wn_buf_store(Zr, zz, vcur, row0 * T4);
+        };
+        // operand block g of the dilated contraction: g = 0..3 history tap (xh), 4..7 current tap (xc)
+        auto split_pair = [&](int g, int e, unsigned (&hq)[4], unsigned (&mq)[4], unsigned (&lq)[4]) {
+            const int i0 = 8 * (g & 3) + 2 * e;
+            const float x0 = (g < 4) ? xh[i0] : xc[i0], x1 = (g < 4) ? xh[i0 + 1] : xc[i0 + 1];
+            hq[e] = wn_pk_bf16(x0, x1);
+            const float r0 = x0 - wn_bits_f32(hq[e] << 16), r1 = x1 - wn_bits_f32(hq[e] & 0xffff0000u);
+            mq[e] = wn_pk_bf16(r0, r1);
+            lq[e] = wn_pk_bf16(r0 - wn_bits_f32(mq[e] << 16), r1 - wn_bits_f32(mq[e] & 0xffff0000u));
+        };
+        auto pack_bf = [&](const unsigned (&hq)[4], const unsigned (&mq)[4], const unsigned (&lq)[4], wn_f4 (&bf)[3]) {
+            bf[0].x = wn_bits_f32(hq[0]); bf[0].y = wn_bits_f32(hq[1]); bf[0].z = wn_bits_f32(hq[2]); bf[0].w = wn_bits_f32(hq[3]);
+            bf[1].x = wn_bits_f32(mq[0]); bf[1].y = wn_bits_f32(mq[1]); bf[1].z = wn_bits_f32(mq[2]); bf[1].w = wn_bits_f32(mq[3]);
+            bf[2].x = wn_bits_f32(lq[0]); bf[2].y = wn_bits_f32(lq[1]); bf[2].z = wn_bits_f32(lq[2]); bf[2].w = wn_bits_f32(lq[3]);
+        };
+        // ---- dilated taps.  Per tap: pass A (row tiles 0, 2) then pass B (row tiles 1, 3), so that the history operands die
+        // after the first tap (their registers take the NEXT tile's history tap) and the accumulators of the first 32 channels
+        // are complete before the last pass, which carries their gate in its shadow.  Block index g = 4 tap + kb. ----
+        wn_f4 bf[3];
+        {
+            unsigned hq[4], mq[4], lq[4];
+            WN_UNROLL
+            for (int e = 0; e < 4; ++e) split_pair(0, e, hq, mq, lq);
+            pack_bf(hq, mq, lq, bf);
+        }
+        const int next_v = tile_v + step;
+        WN_UNROLL
+        for (int tp = 0; tp < 4; ++tp) {   // (tap, pass) = (tp >> 1, tp & 1)
+            const int tap = tp >> 1, pass = tp & 1;
+            WN_UNROLL
+            for (int kb = 0; kb < 4; ++kb) {
+                const int g = 4 * tap + kb;
+                const char* Wl = Wd + g * WD_BLK + fo;
+                wn_f4 af[2][3];
+                WN_UNROLL
+                for (int p = 0; p < 3; ++p) {
+                    af[0][p] = *reinterpret_cast<const wn_f4*>(Wl + p * (128 * 32) + (pass + 0) * 1024);
+                    af[1][p] = *reinterpret_cast<const wn_f4*>(Wl + p * (128 * 32) + (pass + 2) * 1024);
+                }
+                // the block split in this group's shadow: the next one of this (tap, pass), else the first of the next
+                const int tpn = (kb == 3) ? tp + 1 : tp;
+                const int gn = 4 * ((tpn >> 1) & 1) + ((kb + 1) & 3);
+                const bool more = !(tp == 3 && kb == 3);
+                unsigned hq[4], mq[4], lq[4];
+                // six slots of two MFMAs; between them one slice each: the split of one operand pair of the next block
+                // (slots 0..3) and, in the last pass, one gate element of the first 32 channels (slots 2..5)
+                WN_UNROLL
+                for (int t6 = 0; t6 < 6; ++t6) {
+                    mfma_pair(acc[pass], acc[pass + 2], af, bf, t6);
+                    WN_SCHED_FENCE_ALU();
+                    if (more && t6 < 4) split_pair(gn, t6, hq, mq, lq);
+                    if (tp == 3 && t6 >= 2) gate_elem(0, 4 * kb + (t6 - 2));
+                    WN_SCHED_FENCE_ALU();
+                }
+                if (more) pack_bf(hq, mq, lq, bf);
+                WN_SCHED_FENCE_ALU();
+            }
+            if (tp == 1) {   // history operands consumed: their registers take the next tile's history tap
+                WN_SCHED_BARRIER();
+                if (next_v < tile_end) issue_hist(next_v);
+                WN_SCHED_BARRIER();
+            }
+        }
+        WN_SCHED_BARRIER();
+        // residual input + bias = the initial value of the res-1x1 accumulators (xc dies here)
+        f32x16 racc[2];
+        const bool has_res = a.Xnext != nullptr;
+        if (has_res) {
+            const float* rbl = rb + 4 * hi;
+            WN_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) racc[q][r] = xc[16 * q + r] + rbl[32 * q + mfma32_row(r, 0)];
+            }
+#ifndef WN_EMU
+            asm volatile("" : "+v"(racc[0]), "+v"(racc[1]));
+#endif
+        }
+        // ---- res 1x1: k-blocks 0, 1 contract the first half's z (gate of the second half in their shadow), 2, 3 the second's ----
+        auto split_zpair = [&](int kb, int e, unsigned (&hq)[4], unsigned (&mq)[4], unsigned (&lq)[4]) {
+            const int i0 = 8 * kb + 2 * e;
+            const float x0 = z[i0 >> 4][i0 & 15], x1 = z[(i0 + 1) >> 4][(i0 + 1) & 15];
+            hq[e] = wn_pk_bf16(x0, x1);
+            const float r0 = x0 - wn_bits_f32(hq[e] << 16), r1 = x1 - wn_bits_f32(hq[e] & 0xffff0000u);
+            mq[e] = wn_pk_bf16(r0, r1);
+            lq[e] = wn_pk_bf16(r0 - wn_bits_f32(mq[e] << 16), r1 - wn_bits_f32(mq[e] & 0xffff0000u));
+        };
+        if (has_res) {
+            wn_f4 zb[3];
+            {
+                unsigned hq[4], mq[4], lq[4];
+                WN_UNROLL
+                for (int e = 0; e < 4; ++e) split_zpair(0, e, hq, mq, lq);
+                pack_bf(hq, mq, lq, zb);
+            }
+            WN_UNROLL
+            for (int kb = 0; kb < 4; ++kb) {
+                const char* Wl = Wr + kb * WR_BLK + fo;
+                wn_f4 af[2][3];
+                WN_UNROLL
+                for (int q = 0; q < 2; ++q) {
+                    WN_UNROLL
+                    for (int p = 0; p < 3; ++p) af[q][p] = *reinterpret_cast<const wn_f4*>(Wl + p * (64 * 32) + q * 1024);
+                }
+                unsigned hq[4], mq[4], lq[4];
+                WN_UNROLL
+                for (int t6 = 0; t6 < 6; ++t6) {
+                    mfma_pair(racc[0], racc[1], af, zb, t6);
+                    WN_SCHED_FENCE_ALU();
+                    if (kb < 2) {   // the 16 gate elements of the second half over the 12 slots of k-blocks 0, 1
+                        const int s12 = 6 * kb + t6;
+                        WN_UNROLL
+                        for (int r = (16 * s12) / 12; r < (16 * (s12 + 1)) / 12; ++r) gate_elem(1, r);
+                    }
+                    // the next k-block's operand pairs: block 1 is first-half z (slots 0..3); block 2 needs the second half
+                    // complete, i.e. the last slots of block 1 come too early: it is split in the first slots of ... itself is
+                    // too late, so blocks 2 and 3 are split in slots 2..5 of the block before (z[1][0..15] is complete after
+                    // slot 11 = block 1's slot 5: block 2's pairs wait for it below)
+                    if (kb != 1 && kb < 3 && t6 < 4) split_zpair(kb + 1, t6, hq, mq, lq);
+#ifndef WN_EMU
+                    // pin: the next MFMA pair takes its accumulators from here, i.e. after this slot's stores.  (The fences
+                    // bound the machine scheduler's regions, but instruction selection had already hoisted all 12 MFMAs of the
+                    // block -- their operands are ready at its start -- above the slices.)
+                    if (kb < 2) asm volatile("" : "+v"(racc[0]), "+v"(racc[1]));
+#endif
+                    WN_SCHED_FENCE_ALU();
+                }
+                if (kb == 1) {   // second-half z complete: block 2's operands (exposed: 44 VALU once per tile)
+                    WN_UNROLL
+                    for (int e = 0; e < 4; ++e) split_zpair(2, e, hq, mq, lq);
+                }
+                if (kb < 3) pack_bf(hq, mq, lq, zb);
+            }
+            const wn_rsrc_t Xn = wn_make_buf(a.Xnext + (long)b * 64 * T, slab);
+            WN_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) wn_buf_store(Xn, racc[q][r], vcur, (32 * q + mfma32_row(r, 0)) * T4);
+            }
+        } else {
+            WN_UNROLL
+            for (int r = 0; r < 16; ++r) gate_elem(1, r);
+        }
+        tile_v = next_v;
+    }
+}
+
 template <int K>
 static int launch_fwd(const FwdArgs& a, int split, wn_stream_t st) {
     const long ntiles = (long)a.B * ((a.T + 31) / 32);
     const long nblk = balanced_blocks(ntiles);
     const size_t lds_s = (size_t)K * 4 * (3 * 128 * 32) + 4 * (3 * 64 * 32) + 192 * sizeof(float);
     if (split && lds_s <= 160 * 1024) {  // K = 3 does not fit split: stays on the f32 MFMA
+        static int v2 = -1;   // WN_FWD_V2=1: k_resblock_fwd_v2 (K = 2, plain tile walk)
+        if (v2 < 0) {
+            const char* e = getenv("WN_FWD_V2");
+            v2 = (e && atoi(e) != 0) ? 1 : 0;
+        }
         if (K == 2 && a.chain_c > 1) {
             if (set_lds(k_resblock_fwd_s<K, 1>, lds_s)) return 1;
             WN_LAUNCH((k_resblock_fwd_s<K, 1>), dim3((unsigned)nblk), dim3(WN_FT), lds_s, st, a);
+        } else if (K == 2 && v2 && a.Gt != nullptr) {
+            if (set_lds(k_resblock_fwd_v2<true>, lds_s)) return 1;
+            WN_LAUNCH((k_resblock_fwd_v2<true>), dim3((unsigned)nblk), dim3(WN_FT), lds_s, st, a);
+        } else if (K == 2 && v2) {
+            if (set_lds(k_resblock_fwd_v2<false>, lds_s)) return 1;
+            WN_LAUNCH((k_resblock_fwd_v2<false>), dim3((unsigned)nblk), dim3(WN_FT), lds_s, st, a);
         } else {
             if (set_lds(k_resblock_fwd_s<K, 0>, lds_s)) return 1;
             WN_LAUNCH((k_resblock_fwd_s<K, 0>), dim3((unsigned)nblk), dim3(WN_FT), lds_s, st, a);

@@ -484,3 +484,48 @@ def test_front_conv_weight_gradient_on_the_matrix_cores():
             log["err"] = (e, g)
         counts = PC.launch_log(emu_library(), run)
         assert counts.get("dw_front_scatter") == 1 and "dw_front_onehot" not in counts, counts
+
+
+def test_forward_block_v2_is_bit_identical_to_the_default_kernel():
+    """k_resblock_fwd_v2 (opt-in WN_FWD_V2=1: row-tile passes per tap with the gate math and the operand splits in the
+    shadow of the MFMAs) sees, per accumulator, the same MFMAs in the same order as k_resblock_fwd_s<2, 0> and runs the same
+    gate code: logits, every saved x_l, sigmoid half and z must be BIT-identical.  Several tiles per wave
+    (WN_CHAIN_BLOCKS=8), dilations up to 64, a ragged last tile (T % 32 = 16), two sequences, the last layer (no residual
+    output); the env knob is read once per process, so the v2 run is a subprocess."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd import _lib
+    from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    body = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "from oracle import wavenet_oracle as O\n"
+        "from tests.emu_util import emu_library\n"
+        "from pytorchwavenetvocoder_amd import _lib\n"
+        "from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat\n"
+        "cfg_t = (32, 4, 64, 32, 7, 1, 2, 16)\n"
+        "cfg = O.OracleConfig(*cfg_t)\n"
+        "params = O.random_params(cfg, 91, scale=0.2)\n"
+        "x, h, t = O.synthetic_batch(cfg, 2, 1360, 92)\n"
+        "eng = WaveNetEngine(*cfg_t, device='cpu', library=emu_library())\n"
+        "load_state_into_flat(eng, params)\n"
+        "logits = eng.forward(x, h)\n"
+        "out = {'logits': logits.clone(), 'X': eng.saved(_lib.WS_X).clone(), 'S': eng.saved(_lib.WS_SIGMOID).clone(),\n"
+        "       'Z': eng.saved(_lib.WS_Z).clone()}\n"
+        "torch.save(out, sys.argv[1])\n" % root)
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name, v2 in (("v1", "0"), ("v2", "1")):
+            path = os.path.join(td, name + ".pt")
+            env = dict(os.environ, WN_CHAIN_BLOCKS="8", WN_FWD_V2=v2)
+            r = subprocess.run([sys.executable, "-c", body, path], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                               timeout=900)
+            assert r.returncode == 0, r.stdout.decode()[-2000:]
+            res[name] = torch.load(path)
+    for k in ("logits", "X", "S", "Z"):
+        assert torch.equal(res["v1"][k], res["v2"][k]), k
+    assert float(res["v1"]["Z"].abs().max()) > 0.0
