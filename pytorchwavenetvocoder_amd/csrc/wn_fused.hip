@@ -34,7 +34,7 @@
 // Experimental build only (tools/exp): per-phase cycle stamps of block 0, lane 0 of every wave.
 static long long* g_dbg = nullptr;
 extern "C" void wn_debug_set_buffer(void* p) { g_dbg = (long long*)p; }
-#define WN_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && lane == 0 && tcount < 4) a.dbg[(wave * 4 + tcount) * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define WN_STAMP(i) do { if (a.dbg && a.Xnext != nullptr && blockIdx.x == 0 && lane == 0 && tcount < 4) a.dbg[(wave * 4 + tcount) * 16 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define WN_STAMP(i)
 #endif
@@ -938,9 +938,16 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_v2(FwdArgs a) {
     }
     if (threadIdx.x < 128) cv[threadIdx.x] = a.cvec[threadIdx.x];
     if (threadIdx.x < 64) rb[threadIdx.x] = a.res_bias[threadIdx.x];
+#ifdef WN_TIMING
+    if (a.dbg && threadIdx.x == 0) a.dbg[512 + blockIdx.x * 4 + 0] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    (void)wave;
+    int tcount = 0;
+    (void)tcount;
     const int li = lane & 31, hi = lane >> 5;
     const int T = a.T;
     const int T4 = T * 4;
@@ -973,6 +980,7 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_v2(FwdArgs a) {
     int tile_v = walk.first;
     if (tile_v < tile_end) issue_hist(tile_v);
     while (tile_v < tile_end) {
+        WN_STAMP(0);
         const int tile = WN_UNIFORM(tile_v);
         const int b = tile / tiles_per_b;
         const int t = (tile - b * tiles_per_b) * 32 + li;
@@ -1079,11 +1087,13 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_v2(FwdArgs a) {
             }
             if (tp == 1) {   // history operands consumed: their registers take the next tile's history tap
                 WN_SCHED_BARRIER();
+                WN_STAMP(1);
                 if (next_v < tile_end) issue_hist(next_v);
                 WN_SCHED_BARRIER();
             }
         }
         WN_SCHED_BARRIER();
+        WN_STAMP(2);
         // residual input + bias = the initial value of the res-1x1 accumulators (xc dies here)
         f32x16 racc[2];
         const bool has_res = a.Xnext != nullptr;
@@ -1153,6 +1163,7 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_v2(FwdArgs a) {
                 }
                 if (kb < 3) pack_bf(hq, mq, lq, zb);
             }
+            WN_STAMP(3);
             const wn_rsrc_t Xn = wn_make_buf(a.Xnext + (long)b * 64 * T, slab);
             WN_UNROLL
             for (int q = 0; q < 2; ++q) {
@@ -1163,8 +1174,18 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_v2(FwdArgs a) {
             WN_UNROLL
             for (int r = 0; r < 16; ++r) gate_elem(1, r);
         }
+        WN_STAMP(4);
+        ++tcount;
         tile_v = next_v;
     }
+#ifdef WN_TIMING
+    if (a.dbg && lane == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        if (wave == 0) a.dbg[512 + blockIdx.x * 4 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+        if (wave == 7) a.dbg[512 + blockIdx.x * 4 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
+        if (wave == 0) a.dbg[512 + blockIdx.x * 4 + 3] = tcount;
+    }
+#endif
 }
 
 template <int K>

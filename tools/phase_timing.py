@@ -55,7 +55,7 @@ blk = dbg.cpu()[512:].view(256, 4)
 blk = blk[blk[:, 0] != 0]   # only the blocks that ran (the persistent grid is smaller than 256)
 d = dbg.cpu()[:512].view(8, 4, 16)   # stamps of the LAST layer launch (each launch overwrites)
 t0 = int(d[:, 0, 0].min())
-names = ["start", "hist", "cur", "gate", "done"]
+names = ["start", "hist", "cur", "gate", "done"]   # WN_FWD_V2=1: tap 0 (both passes) | tap 1 (+ gate of channels 0..31) | res 1x1 (+ gate of 32..63) | stores
 for w in range(8):
     for t in range(3):
         st = [int(d[w, t, i]) - t0 for i in range(5)]
@@ -66,6 +66,8 @@ for w in range(8):
 for w in range(8):
     e = d[w, 0]
     cyc = int(e[9] - e[5]); rt = int(e[8] - e[7])
+    if rt <= 0:   # (k_resblock_fwd_v2 keeps the per-tile stamps only)
+        continue
     print("wave %d: prologue %6d cyc | entry->exit %7d cyc, %6d realtime ticks (100 MHz => %.1f us, clock %.2f GHz) | entry@%d" % (
         w, int(e[6] - e[5]), cyc, rt, rt / 100.0, cyc / (rt / 100.0) / 1e3, int(e[5]) - t0))
 
