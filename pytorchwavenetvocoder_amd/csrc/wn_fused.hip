@@ -57,6 +57,29 @@ static long chain_blocks() {
     return v;
 }
 
+// -DWN_PRIO_PHASES (A/B builds): a wave raises its issue priority for its MFMA phases and drops it for its gate phase
+#ifndef WN_PRIO_MFMA
+#define WN_PRIO_MFMA 3
+#endif
+#ifndef WN_PRIO_GATE
+#define WN_PRIO_GATE 0
+#endif
+// Issue priority by phase (default; -DWN_NO_PRIO_PHASES builds without it).  The two waves of a SIMD compete for one issue
+// port; a wave in its MFMA phase issues one instruction every ~32 cycles and is otherwise idle, a wave in its gate phase issues
+// VALU work back to back -- and tools/microbench/mfma_valu.hip shows that VALU work of the neighbour slows a wave's MFMAs
+// down 3x when both have the same priority.  A wave therefore raises its priority (s_setprio) for its MFMA phases and drops it
+// for its gate phase: the MFMAs go out when their operands are ready, the neighbour's gate math fills the gaps.  Same box:
+// forward blocks 1.89 -> 1.82 ms per step, backward chain 2.94 -> 2.91 (profiles/r02/ab_probe_prio_phases.txt); the opposite
+// assignment is slower than none (1.94).
+#if !defined(WN_NO_PRIO_PHASES) && !defined(WN_EMU)
+#ifdef WN_PRIO_GATE_BY_WAVE   // experiment: the second wave of a SIMD keeps priority 1 in its gate phase
+#define WN_PRIO(n) do { if ((n) == WN_PRIO_GATE && (threadIdx.x >> 8)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(n); } while (0)
+#else
+#define WN_PRIO(n) __builtin_amdgcn_s_setprio(n)
+#endif
+#else
+#define WN_PRIO(n)
+#endif
 #ifndef WN_FT
 #define WN_FT 512  // threads per workgroup (8 waves = 2 per SIMD)
 #endif
@@ -697,6 +720,7 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
             for (int s = 0; s < 32; ++s) xc[s] = wn_buf_load(Xr, vcur, kappa64(s, 0) * T4);
         }
         WN_SCHED_BARRIER();
+        WN_PRIO(WN_PRIO_MFMA);
         f32x16 acc[4];
         WN_UNROLL
         for (int q = 0; q < 4; ++q) acc[q] = f32x16_zero();
@@ -773,6 +797,7 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
             }
         }
         WN_SCHED_BARRIER();
+        WN_PRIO(WN_PRIO_GATE);
         WN_STAMP(2);  // after current-tap MFMAs
         // Prefetch the history-tap operands of this wave's next tile NOW, i.e. before the stores of the
         // gate phase: vmcnt is one in-order counter for loads AND stores, so loads issued behind the
@@ -850,6 +875,7 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
         else gate_phase(std::false_type{});
         WN_STAMP(3);  // after gate math + S/Gt/Z stores issued
         WN_SCHED_BARRIER();
+        WN_PRIO(WN_PRIO_MFMA);
         // res 1x1 + residual; z is consumed straight from the accumulator registers
         if (a.Xnext != nullptr) {
             WN_UNROLL
@@ -882,6 +908,7 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
                 }
             }
         }
+        WN_PRIO(WN_PRIO_GATE);
         WN_STAMP(4);  // tile done
         ++tcount;
         if (chained) {
@@ -1952,6 +1979,7 @@ __global__ __launch_bounds__(WN_FT) void k_chain64s(ChainArgs a) {
         // The residual input dX_{l+1} is the INITIAL VALUE of the tap accumulators (loaded straight into them), and the
         // pre-contracted skip part of dZ that of the second accumulator pair (requested in the middle of the taps).
         // Lanes past T read a valid dummy address; their columns never leave the wave.
+        WN_PRIO(WN_PRIO_MFMA);
         f32x16 dz[2];
         acc[0] = f32x16_zero();
         acc[1] = f32x16_zero();
@@ -2037,6 +2065,7 @@ __global__ __launch_bounds__(WN_FT) void k_chain64s(ChainArgs a) {
             }
         }
         WN_SCHED_BARRIER();  // the dX registers are free from here on
+        WN_PRIO(WN_PRIO_GATE);
         const wn_rsrc_t Or = wn_make_buf(a.dPm + (long)b * 128 * T, (unsigned)(128 * T4));
         if (AUX) {
             // gate backward + the partial sums of the aux gradient (as k_conv64s<2>): every lane takes part in the
