@@ -78,7 +78,7 @@ def test_loss_window_backward_vs_full_backward():
         # both calls take the same ReLU sub-gradients (the saved activations), so no kink-free instance is needed
         params = O.random_params(cfg, 43, scale=0.05)
         x, h, t = (v.to(DEV) for v in O.synthetic_batch(cfg, B, T, 44))
-        for flags in (L.FLAG_AUX_FUSED, L.FLAG_AUX_FUSED | L.FLAG_NO_CHAIN, L.FLAG_NO_FUSED):
+        for flags in (L.FLAG_AUX_FUSED, L.FLAG_AUX_FUSED | L.FLAG_NO_CHAIN, L.FLAG_NO_FUSED, L.FLAG_EXACT_MFMA):
             eng = WaveNetEngine(*cfg_t, device=DEV, library=_lib())
             eng.flags = flags
             load_state_into_flat(eng, params)
