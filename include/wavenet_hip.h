@@ -95,8 +95,9 @@ enum {
                                * launch-group size */
 #define WN_FLAG_AUX_FUSED 32  /* wn_backward (fused split kernels, upsampling_factor % 16 == 0): the gate kernel also writes the
                                * partial sums of the aux-path gradients (frame-rate aux gradient, upsampling weight), a
-                               * small kernel finishes them and dP is not re-read by wn_aux_bwd.  Opt-in until measured
-                               * on hardware; sums re-associate (~1e-7 relative) */
+                               * small kernel finishes them and dP is not re-read by wn_aux_bwd.  What WaveNetEngine passes by
+                               * default since round 2 (measured -3 %); a flag of the C ABI because the sums re-associate
+                               * (~1e-7 relative) */
 #define WN_FLAG_NO_CHAIN 64   /* wn_backward (fused split kernels, kernel_size <= 2): since ABI v4 the data chain runs as ONE launch
                                * per layer (dX_l and gate'_{l-1} fused, the skip part of dZ pre-contracted for all layers by
                                * one matrix-bound launch; csrc/wn_fused.hip k_chain64s).  This flag restores the former
