@@ -491,7 +491,7 @@ static int make_ws(const Dims& d, int B, int T, Ws* w) {
         w->apk_floats = (e + 1) / 2;
         CARVE(apk, w->apk_floats);
         // ... and one buffer each for the weight sets every step uses (same order as pre_jobs())
-        const int pre[6][2] = {{d.S, d.L * d.R}, {d.S, d.S}, {d.Qo, d.S}, {d.S, d.Qo}, {d.S, d.S}, {(d.L - 1) * d.R, d.S}};
+        const int pre[6][2] = {{d.S, d.L * d.R}, {d.S, d.S}, {d.Qo, d.S}, {d.S, d.Qo}, {d.S, d.S}, {d.L * d.R, d.S}};
         for (int i = 0; i < 6; ++i) {
             w->apk_pre[i] = -1;
             if (pre[i][0] < 128 || (i == 5 && w->dZs_floats <= 0)) continue;   // (the split contraction wants M >= 128)
@@ -622,6 +622,18 @@ struct GateEpi {   // optional gate epilogue of a split contraction (wn_gemm6.h)
     float* bw_dP = nullptr;
 };
 // can this launch run on the split kernel (the only one with the gate epilogues)?
+// WN_CHAIN_HEAD=0: the top of the chain takes dSkip itself (k_conv64s, a K = n_skipch contraction) instead of its row block of
+// the all-layer pre-contraction (A/B)
+static bool chain_head_on() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("WN_CHAIN_HEAD");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v != 0;
+}
+static int dzs_layers(const Dims& d) { return chain_head_on() ? d.L : d.L - 1; }   // layers bwd_dz_skip_all contracts
+
 // The weight sets of the split contractions every training step launches: (A, lda, M, K) and where their split form lives.
 // They are split ONCE per step by one launch at the end of pack_weights (six dependent little launches in front of the
 // contractions otherwise); wn_backward finds them in the workspace wn_forward left.  WN_PREPACK=0: split before each use.
@@ -644,7 +656,7 @@ static int pre_jobs(const Ctx& c, const float* params, PreJob (&j)[6]) {
                            {ws + w.w2_f, d.Qo, d.Qo, d.S, w.apk_pre[2]},
                            {params ? params + y.post2_w : nullptr, d.S, d.S, d.Qo, w.apk_pre[3]},
                            {params ? params + y.post1_w : nullptr, d.S, d.S, d.S, w.apk_pre[4]},
-                           {ws + w.wskipT_f, (long)d.L * d.R, (d.L - 1) * d.R, d.S, w.apk_pre[5]}};
+                           {ws + w.wskipT_f, (long)d.L * d.R, dzs_layers(d) * d.R, d.S, w.apk_pre[5]}};
     int n = 0;
     if (!c.have_pre || !c.split_bf16 || !prepack_on()) return 0;
     for (int i = 0; i < 6; ++i)
@@ -1223,7 +1235,7 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
     const long zs_bstride = (long)d.L * d.R * T;
     if (chain) {
         WnGemmArgs g = wn_gemm_default();
-        g.M = (d.L - 1) * d.R; g.N = Tw; g.K = d.S;
+        g.M = dzs_layers(d) * d.R; g.N = Tw; g.K = d.S;
         g.A = ws + w.wskipT_f; g.lda = (long)d.L * d.R;
         g.B = ws + w.dSk + t0; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = Tw;
         g.C = ws + w.dZs + t0; g.ldc = T; g.c_zstride = zs_bstride;
@@ -1326,7 +1338,12 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
         const float* dXn = (l + 1 < d.L) ? ws + w.dXall + (long)(l + 1) * BRT : nullptr;  // null: dead (last layer)
         float* dXl = ws + w.dXall + (long)l * BRT;
         if (chain) {
-            if (l == d.L - 1) {  // head of the chain: gate' of the last layer straight from dSkip (no dX input)
+            if (l == d.L - 1 && chain_head_on()) {   // head of the chain: gate' of the last layer on its rows of dZs (no dX input)
+                WN_TRY(wn_fused_bwd_chain_head(ws + w.dZs + (long)l * d.R * T, zs_bstride, Sl, Zl, gz, dP,
+                                               ws + w.G + (long)l * 2 * d.R * F, g_bstride, upw, Ue, F,
+                                               aux_fused ? ws + w.dGp + (long)l * B * 2 * d.R * (T / 16) : nullptr,
+                                               aux_fused ? ws + w.qp + (long)l * B * T : nullptr, B, T, t0, c.st));
+            } else if (l == d.L - 1) {  // (WN_CHAIN_HEAD=0) straight from dSkip: a K = n_skipch contraction in k_conv64s
                 if (aux_fused)
                     WN_TRY(wn_fused_bwd_gate_aux(params + y.skip0 + (long)l * y.ls_skip, params + lb + y.o_res_w, ws + w.dSk, nullptr,
                                                  Sl, Zl, gz, dP, ws + w.G + (long)l * 2 * d.R * F, g_bstride, upw, Ue, F,

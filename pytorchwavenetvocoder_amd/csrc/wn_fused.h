@@ -52,6 +52,10 @@ int wn_fused_bwd_chain(const float* wd_b, const float* dP, const float* dXn, flo
                        const float* upw, int U, int F, float* dGp, float* qp, int B, int T, int K, int dilation,
                        const float* img_taps, const float* img_res, int zs_t0, wn_stream_t st);
 // zs_t0: dZs[.., t < zs_t0] is taken as zero and never read (loss window, wn_backward_window)
+// top of the chain: dP_{L-1} = gate'(dZs_{L-1}) alone (the last layer has no residual gradient); same aux outputs
+int wn_fused_bwd_chain_head(const float* dZs, long zs_bstride, const float* S, const float* Gt, int gt_is_z, float* dP_prev,
+                            const float* G, long g_bstride, const float* upw, int U, int F, float* dGp, float* qp, int B, int T,
+                            int zs_t0, wn_stream_t st);
 
 // LDS weight images of the split kernels, built ONCE per step for all L layers instead of once per workgroup per launch:
 //   which = 0  forward block of layer l (taps + res 1x1)      from wd_f, wres_f

@@ -1892,13 +1892,18 @@ static __device__ __forceinline__ void split8v(const float (&x)[8], bool ok, wn_
     split8(y, bf);
 }
 
-template <int AUX, int K>
+// HEAD = true: the top of the chain.  The last layer's residual output is dead (wavenet.py:231-238), so dP_{L-1} is the gate'
+// epilogue alone on dZs_{L-1} (which bwd_dz_skip_all now produces for ALL layers): no taps, no Wres^T, no dX -- its own
+// instantiation, so that the main one compiles exactly as before.
+template <int AUX, int K, bool HEAD = false>
 __global__ __launch_bounds__(WN_FT) void k_chain64s(ChainArgs a) {
     WN_DYN_SMEM(smem_raw);
     char* W = smem_raw;                      // tap blocks: chunk q (32 channels) = tap q % K, channel group q / K; 2 blocks of 6 KB each
     constexpr int NCH = K * 4;               // chunks of the dX part
     char* Wr = W + NCH * 2 * 6144;           // Wres^T: 4 blocks [piece][64 rows][16 k], k order = accumulator register order
-    if (a.img_taps != nullptr) {   // pre-split once per step (wn_fused_pack_images): two straight global -> LDS copies
+    if (HEAD) {
+        // no weights
+    } else if (a.img_taps != nullptr) {   // pre-split once per step (wn_fused_pack_images): two straight global -> LDS copies
         copy_image_to_lds(W, a.img_taps, chain_taps_bytes(K));
         copy_image_to_lds(Wr, a.img_res, WN_RES_T_BYTES);
         WN_WAIT_VMCNT(0);
@@ -1960,7 +1965,7 @@ __global__ __launch_bounds__(WN_FT) void k_chain64s(ChainArgs a) {
     };
 
     int tile_v = walk.first;
-    if (tile_v < tile_end) {
+    if (!HEAD && tile_v < tile_end) {
         issue(tile_v, 0, xa, oka);
         issue(tile_v, 1, xb, okb);
     }
@@ -1979,89 +1984,103 @@ __global__ __launch_bounds__(WN_FT) void k_chain64s(ChainArgs a) {
         // The residual input dX_{l+1} is the INITIAL VALUE of the tap accumulators (loaded straight into them), and the
         // pre-contracted skip part of dZ that of the second accumulator pair (requested in the middle of the taps).
         // Lanes past T read a valid dummy address; their columns never leave the wave.
-        WN_PRIO(WN_PRIO_MFMA);
         f32x16 dz[2];
-        acc[0] = f32x16_zero();
-        acc[1] = f32x16_zero();
-        if (a.dXn != nullptr) {
-            const wn_rsrc_t Rr = wn_make_buf(a.dXn + (long)b * 64 * T, (unsigned)(64 * T4));
-            WN_UNROLL
-            for (int q = 0; q < 2; ++q) {
-                WN_UNROLL
-                for (int r = 0; r < 16; ++r) acc[q][r] = wn_buf_load(Rr, vcur, (32 * q + mfma32_row(r, 0)) * T4);
-            }
-        }
-        WN_SCHED_BARRIER();
-        // saved gate halves of layer l-1: the first 32 channels are requested half way through the taps, the second 32
-        // at their end (their registers are the operand buffers the taps no longer need)
         const wn_rsrc_t Ssr = wn_make_buf(a.S + (long)b * 64 * T, (unsigned)(64 * T4));
         const wn_rsrc_t Gsr = wn_make_buf(a.Gt + (long)b * 64 * T, (unsigned)(64 * T4));
         float e0[2][16], e1[2][16];
-        WN_UNROLL
-        for (int q = 0; q < NCH; q += 2) {
-            consume(q, xa, oka);
-            if (q + 2 < NCH) issue(tile_v, q + 2, xa, oka);
-            WN_SCHED_BARRIER();
-            consume(q + 1, xb, okb);
-            if (q + 3 < NCH) issue(tile_v, q + 3, xb, okb);
-            if (q == (NCH >> 1) - 2) {  // once, in the middle of the tap loop
-                const wn_rsrc_t Zr = wn_make_buf(a.dZs + (long)b * a.zs_bstride, (unsigned)(64 * T4));
-                WN_UNROLL
-                for (int qq = 0; qq < 2; ++qq) {
-                    WN_UNROLL
-                    for (int r = 0; r < 16; ++r) dz[qq][r] = wn_buf_load(Zr, vzs, (32 * qq + mfma32_row(r, 0)) * T4);
-                }
+        if (HEAD) {
+            const wn_rsrc_t Zr = wn_make_buf(a.dZs + (long)b * a.zs_bstride, (unsigned)(64 * T4));
+            WN_UNROLL
+            for (int qq = 0; qq < 2; ++qq) {
                 WN_UNROLL
                 for (int r = 0; r < 16; ++r) {
-                    const int so = mfma32_row(r, 0) * T4;
-                    e0[0][r] = wn_buf_load(Ssr, vcur, so);
-                    e1[0][r] = wn_buf_load(Gsr, vcur, so);
+                    const int so = (32 * qq + mfma32_row(r, 0)) * T4;
+                    dz[qq][r] = wn_buf_load(Zr, vzs, so);
+                    e0[qq][r] = wn_buf_load(Ssr, vcur, so);
+                    e1[qq][r] = wn_buf_load(Gsr, vcur, so);
+                }
+            }
+        } else {
+            WN_PRIO(WN_PRIO_MFMA);
+            acc[0] = f32x16_zero();
+            acc[1] = f32x16_zero();
+            if (a.dXn != nullptr) {
+                const wn_rsrc_t Rr = wn_make_buf(a.dXn + (long)b * 64 * T, (unsigned)(64 * T4));
+                WN_UNROLL
+                for (int q = 0; q < 2; ++q) {
+                    WN_UNROLL
+                    for (int r = 0; r < 16; ++r) acc[q][r] = wn_buf_load(Rr, vcur, (32 * q + mfma32_row(r, 0)) * T4);
                 }
             }
             WN_SCHED_BARRIER();
-        }
-        WN_UNROLL
-        for (int r = 0; r < 16; ++r) {
-            const int so = (32 + mfma32_row(r, 0)) * T4;
-            e0[1][r] = wn_buf_load(Ssr, vcur, so);
-            e1[1][r] = wn_buf_load(Gsr, vcur, so);
-        }
-        // dX_l of this tile is finished in the accumulator layout: register r of lane (li, hi) = channel 32q + row(r, hi)
-        WN_SCHED_BARRIER();
-        // dZ += Wres^T dX: k-step e of block kb takes accumulator register 8 (kb & 1) + e of row tile kb >> 1
-        WN_UNROLL
-        for (int kb = 0; kb < 4; ++kb) {
-            float x8[8];
+            // saved gate halves of layer l-1: the first 32 channels are requested half way through the taps, the second 32
+            // at their end (their registers are the operand buffers the taps no longer need)
             WN_UNROLL
-            for (int e = 0; e < 8; ++e) x8[e] = acc[kb >> 1][8 * (kb & 1) + e];
-            wn_f4 bf[3];
-            split8(x8, bf);
-            const char* Wl = Wr + kb * 6144 + wn_frag_off(li, hi);
-            wn_f4 af[2][3];
-            WN_UNROLL
-            for (int rt = 0; rt < 2; ++rt) {
-                WN_UNROLL
-                for (int p = 0; p < 3; ++p) af[rt][p] = *reinterpret_cast<const wn_f4*>(Wl + p * 2048 + rt * 1024);
+            for (int q = 0; q < NCH; q += 2) {
+                consume(q, xa, oka);
+                if (q + 2 < NCH) issue(tile_v, q + 2, xa, oka);
+                WN_SCHED_BARRIER();
+                consume(q + 1, xb, okb);
+                if (q + 3 < NCH) issue(tile_v, q + 3, xb, okb);
+                if (q == (NCH >> 1) - 2) {  // once, in the middle of the tap loop
+                    const wn_rsrc_t Zr = wn_make_buf(a.dZs + (long)b * a.zs_bstride, (unsigned)(64 * T4));
+                    WN_UNROLL
+                    for (int qq = 0; qq < 2; ++qq) {
+                        WN_UNROLL
+                        for (int r = 0; r < 16; ++r) dz[qq][r] = wn_buf_load(Zr, vzs, (32 * qq + mfma32_row(r, 0)) * T4);
+                    }
+                    WN_UNROLL
+                    for (int r = 0; r < 16; ++r) {
+                        const int so = mfma32_row(r, 0) * T4;
+                        e0[0][r] = wn_buf_load(Ssr, vcur, so);
+                        e1[0][r] = wn_buf_load(Gsr, vcur, so);
+                    }
+                }
+                WN_SCHED_BARRIER();
             }
-            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
             WN_UNROLL
-            for (int t6 = 0; t6 < 6; ++t6) {
-                dz[0] = mfma_bf16(af[0][PA[t6]], bf[PB[t6]], dz[0]);
-                dz[1] = mfma_bf16(af[1][PA[t6]], bf[PB[t6]], dz[1]);
+            for (int r = 0; r < 16; ++r) {
+                const int so = (32 + mfma32_row(r, 0)) * T4;
+                e0[1][r] = wn_buf_load(Ssr, vcur, so);
+                e1[1][r] = wn_buf_load(Gsr, vcur, so);
             }
-        }
-        WN_SCHED_BARRIER();
-        // the next tile's first operand chunks go out before this tile's stores (vmcnt counts loads and stores in order)
-        if (next_v < tile_end) {
-            issue(next_v, 0, xa, oka);
-            issue(next_v, 1, xb, okb);
-        }
-        {
-            const wn_rsrc_t Xr = wn_make_buf(a.dX + (long)b * 64 * T, (unsigned)(64 * T4));
+            // dX_l of this tile is finished in the accumulator layout: register r of lane (li, hi) = channel 32q + row(r, hi)
+            WN_SCHED_BARRIER();
+            // dZ += Wres^T dX: k-step e of block kb takes accumulator register 8 (kb & 1) + e of row tile kb >> 1
             WN_UNROLL
-            for (int q = 0; q < 2; ++q) {
+            for (int kb = 0; kb < 4; ++kb) {
+                float x8[8];
                 WN_UNROLL
-                for (int r = 0; r < 16; ++r) wn_buf_store(Xr, acc[q][r], vst, (32 * q + mfma32_row(r, 0)) * T4);
+                for (int e = 0; e < 8; ++e) x8[e] = acc[kb >> 1][8 * (kb & 1) + e];
+                wn_f4 bf[3];
+                split8(x8, bf);
+                const char* Wl = Wr + kb * 6144 + wn_frag_off(li, hi);
+                wn_f4 af[2][3];
+                WN_UNROLL
+                for (int rt = 0; rt < 2; ++rt) {
+                    WN_UNROLL
+                    for (int p = 0; p < 3; ++p) af[rt][p] = *reinterpret_cast<const wn_f4*>(Wl + p * 2048 + rt * 1024);
+                }
+                constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+                WN_UNROLL
+                for (int t6 = 0; t6 < 6; ++t6) {
+                    dz[0] = mfma_bf16(af[0][PA[t6]], bf[PB[t6]], dz[0]);
+                    dz[1] = mfma_bf16(af[1][PA[t6]], bf[PB[t6]], dz[1]);
+                }
+            }
+            WN_SCHED_BARRIER();
+            // the next tile's first operand chunks go out before this tile's stores (vmcnt counts loads and stores in order)
+            if (next_v < tile_end) {
+                issue(next_v, 0, xa, oka);
+                issue(next_v, 1, xb, okb);
+            }
+            {
+                const wn_rsrc_t Xr = wn_make_buf(a.dX + (long)b * 64 * T, (unsigned)(64 * T4));
+                WN_UNROLL
+                for (int q = 0; q < 2; ++q) {
+                    WN_UNROLL
+                    for (int r = 0; r < 16; ++r) wn_buf_store(Xr, acc[q][r], vst, (32 * q + mfma32_row(r, 0)) * T4);
+                }
             }
         }
         WN_SCHED_BARRIER();  // the dX registers are free from here on
@@ -2163,5 +2182,29 @@ int wn_fused_bwd_chain(const float* wd_b, const float* dP, const float* dXn, flo
         else WN_CHAIN_LAUNCH(0, 2);
     }
 #undef WN_CHAIN_LAUNCH
+    return 0;
+}
+
+// Top of the chain: dP_{L-1} = gate'(dZs_{L-1}) (k_chain64s<AUX, K, true>: no weights, no LDS, the epilogue only)
+int wn_fused_bwd_chain_head(const float* dZs, long zs_bstride, const float* S, const float* Gt, int gt_is_z, float* dP_prev,
+                            const float* G, long g_bstride, const float* upw, int U, int F, float* dGp, float* qp, int B, int T,
+                            int zs_t0, wn_stream_t st) {
+    const bool aux = dGp != nullptr;
+    WN_PROF("fused_bwd_gate", 0.0, 4.0 * (double)B * T * (64.0 + 128.0 + 128.0 + (aux ? 9.0 : 0.0)), st);
+    if (aux && (U < 16 || (U & 15) || (T & 15) || (long)U * F != T)) return 1;
+    ChainArgs a;
+    a.img_taps = nullptr; a.img_res = nullptr; a.wd_b = nullptr; a.dP = nullptr; a.dXn = nullptr; a.dX = nullptr; a.wres = nullptr;
+    a.dZs = dZs; a.zs_bstride = zs_bstride; a.zs_t0 = zs_t0; a.S = S; a.Gt = Gt; a.gz = gt_is_z; a.dPm = dP_prev;
+    a.B = B; a.T = T; a.K = 1; a.dil = 1;
+    a.stagger = 0;
+    a.G = G; a.g_bstride = g_bstride; a.upw = upw; a.U = U; a.F = F; a.dGp = dGp; a.qp = qp;
+    const long ntiles = (long)B * ((T + 31) / 32);
+    long nblk = (ntiles + WN_FW - 1) / WN_FW;   // one tile per wave up to 1024 workgroups (HBM-bound, nothing to amortise)
+    if (nblk > 1024) nblk = 1024;
+    if (nblk >= 8) nblk &= ~7L;                 // whole XCD rounds for the tile walk
+    if (aux)
+        WN_LAUNCH((k_chain64s<1, 1, true>), dim3((unsigned)nblk), dim3(WN_FT), 0, st, a);
+    else
+        WN_LAUNCH((k_chain64s<0, 1, true>), dim3((unsigned)nblk), dim3(WN_FT), 0, st, a);
     return 0;
 }
