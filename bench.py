@@ -7,7 +7,9 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = forward + softmax-CE on [:, rf:] + backward + gradient all-reduce (N>1) + Adam, on
-one synthetic minibatch already resident in HBM (reference train.py:527-540).  Workload =
+one synthetic minibatch already resident in HBM (reference train.py:527-540), through the module's training half-step
+(`WaveNet.loss_and_backward` = wn_forward_loss + wn_backward_window: loss as the epilogue of conv_post_2, post-net / skip
+backward over the loss window; DESIGN.md 3.3c -- same loss and gradients as the separate entry points).  Workload =
 BASELINE.json configs[1]: 30-layer WaveNet, 64 residual / 256 skip channels, 80-dim mel aux,
 mu-law softmax, batch 8 x batch_len 20000 per GPU (-> T = 23040 model inputs, 19970 loss
 positions per sequence).  Weak scaling: the per-GPU batch is fixed.
@@ -413,6 +415,11 @@ def main():
                        "engine_flags": int(model.engine.flags),
                        "gradient_buckets": "post-net+skip | groups of %d layers | front+upsampling (weight gradients are "
                                            "launched per bucket; identical structure for N = 1 and N > 1)" % args.layers_per_bucket,
+                       "loss_path": "wn_forward_loss + wn_backward_window: the forward pass computes every position; the "
+                                    "cross-entropy on [:, rf:] is the epilogue of the conv_post_2 contraction (logits not "
+                                    "materialised: same loss / dlogits as the separate kernel to 1e-7) and the post-net / skip "
+                                    "part of the backward pass runs over the loss window only (dlogits is exactly zero in "
+                                    "front of it: same gradients)",
                        "timing": "median of %d regions of %d steps" % (len(regions), args.steps),
                        "arithmetic": "fp32 storage and accumulation; contractions on the bf16 matrix cores with a 3-way "
                                      "operand split (6 products, fp32-equivalent to round-off) except K=3 forward blocks "

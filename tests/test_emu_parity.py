@@ -531,3 +531,44 @@ def test_forward_block_v2_is_bit_identical_to_the_default_kernel():
     for k in ("logits", "X", "S", "Z"):
         assert torch.equal(res["v1"][k], res["v2"][k]), k
     assert float(res["v1"]["Z"].abs().max()) > 0.0
+
+
+def test_chain_head_variants_agree():
+    """Top of the backward chain: the default takes dP_{L-1} from its rows of the all-layer skip pre-contraction
+    (k_chain64s<.., HEAD>), WN_CHAIN_HEAD=0 (read once per process -> subprocess) contracts dSkip in k_conv64s as before.
+    Same gradients at round-off, with and without the aux partial sums, single-layer model included."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    body = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "from oracle import wavenet_oracle as O\n"
+        "from tests.emu_util import emu_library\n"
+        "from pytorchwavenetvocoder_amd import _lib\n"
+        "from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat\n"
+        "out = {}\n"
+        "for name, cfg_t, T, flags in (('a', (32, 4, 64, 32, 3, 1, 2, 16), 96, _lib.FLAG_AUX_FUSED), ('b', (32, 4, 64, 32, 3, 1, 2, 16), 96, 0),\n"
+        "                              ('c', (32, 4, 64, 32, 1, 1, 2, 16), 48, _lib.FLAG_AUX_FUSED)):\n"
+        "    cfg = O.OracleConfig(*cfg_t)\n"
+        "    x, h, t = O.synthetic_batch(cfg, 2, T, 95)\n"
+        "    eng = WaveNetEngine(*cfg_t, device='cpu', library=emu_library())\n"
+        "    eng.flags = flags\n"
+        "    load_state_into_flat(eng, O.random_params(cfg, 94, scale=0.2))\n"
+        "    loss, dl = eng.forward_loss(x, h, t)\n"
+        "    out[name] = eng.backward(dl, t_first=cfg.receptive_field).clone()\n"
+        "torch.save(out, sys.argv[1])\n" % root)
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name, head in (("head", "1"), ("conv", "0")):
+            path = os.path.join(td, name + ".pt")
+            r = subprocess.run([sys.executable, "-c", body, path], env=dict(os.environ, WN_CHAIN_HEAD=head),
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+            assert r.returncode == 0, r.stdout.decode()[-2000:]
+            res[name] = torch.load(path)
+    for k in ("a", "b", "c"):
+        g0, g1 = res["head"][k], res["conv"][k]
+        assert float(g0.abs().max()) > 0.0
+        assert float((g0 - g1).abs().max()) <= 5e-6 * float(g1.abs().max()), k
