@@ -57,7 +57,8 @@ def read_wav(path):
 
 
 def validate_length(x, y, upsampling_factor=None):
-    """Trim waveform ``x`` and features ``y`` to consistent lengths (reference train.py:35-64)."""
+    """Trim waveform ``x`` and features ``y`` to consistent lengths.  A deliberate RESTATEMENT of reference train.py:35-64
+    (13 lines of required index behaviour; pinned against the reference by tests/golden/slicer.npz)."""
     if upsampling_factor is None:
         n = min(x.shape[0], y.shape[0])
         x, y = x[:n], y[:n]
@@ -72,6 +73,20 @@ def validate_length(x, y, upsampling_factor=None):
             x = x[:y.shape[0] * upsampling_factor]
         assert len(x) == len(y) * upsampling_factor
     return x, y
+
+
+def make_feat_transform(mean, scale):
+    """``StandardScaler.transform`` with given statistics (reference train.py:463-465,468-469): a float copy of the
+    features, ``-= mean`` and ``/= scale`` IN PLACE -- i.e. in the features' own dtype, each step rounded to it, which is
+    what the reference's float32 features get from float64 statistics (bit-equal: tests/test_train_cli.py slicer golden)."""
+    mean, scale = np.asarray(mean), np.asarray(scale)
+
+    def transform(x):
+        x = np.array(x, dtype=x.dtype if np.issubdtype(np.asarray(x).dtype, np.floating) else np.float64, copy=True)
+        x -= mean
+        x /= scale
+        return x
+    return transform
 
 
 def _to_batch(xs, hs, ts, device, ys=None):
@@ -150,7 +165,9 @@ def train_generator(wav_list, feat_list, receptive_field,
             h_ = feat_transform(h_)
         return torch.from_numpy(np.asarray(x_)).long(), torch.from_numpy(np.asarray(h_)).float()
 
-    my_lo, my_hi = _shard_range(batch_size, shard)
+    # window sharding only exists in the windowed modes; utterance batches (batch_length None, effective batch size 1)
+    # are dealt round-robin by utterance below, so a batch_size below the world size is fine there
+    my_lo, my_hi = _shard_range(batch_size, shard) if batch_length is not None else (0, batch_size)
     raw = []  # un-quantised windows in the order of prep() calls
     x_buffer = h_buffer = None
     while True:
@@ -333,7 +350,7 @@ def _worker(rank, world, args, port):
     mean = read_hdf5(args.stats, "/" + args.feature_type + "/mean")
     scale = read_hdf5(args.stats, "/" + args.feature_type + "/scale")
     wav_transform = lambda x: encode_mu_law(x, args.n_quantize)   # noqa: E731
-    feat_transform = lambda x: (x - mean) / scale                  # noqa: E731
+    feat_transform = make_feat_transform(mean, scale)
 
     if os.path.isdir(args.waveforms):
         filenames = sorted(find_files(args.waveforms, "*.wav", use_dir_name=False))

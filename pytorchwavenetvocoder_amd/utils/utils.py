@@ -127,6 +127,13 @@ def read_txt(file_list):
         return [line.rstrip("\n") for line in f.readlines()]
 
 
+class _ProducerError(object):
+    """Wrapper that carries an exception of the producer thread to the consumer."""
+
+    def __init__(self, error):
+        self.error = error
+
+
 class BackgroundGenerator(threading.Thread):
     """Runs ``generator`` in a daemon thread and hands items over through a bounded queue."""
 
@@ -139,9 +146,15 @@ class BackgroundGenerator(threading.Thread):
         self.start()
 
     def run(self):
-        for item in self.generator:
-            if not self._put(item):
-                return
+        # a producer that dies must not leave the consumer blocked in queue.get(): its exception travels through the
+        # queue and is re-raised by next(); a normal end hands over the None sentinel
+        try:
+            for item in self.generator:
+                if not self._put(item):
+                    return
+        except BaseException as e:  # noqa: B902  (re-raised in the consumer thread)
+            self._put(_ProducerError(e))
+            return
         self._put(None)
 
     def _put(self, item):
@@ -161,6 +174,9 @@ class BackgroundGenerator(threading.Thread):
         item = self.queue.get()
         if item is None:
             raise StopIteration
+        if isinstance(item, _ProducerError):
+            self._closed = True
+            raise item.error
         return item
 
     __next__ = next

@@ -51,3 +51,33 @@ def rel_to_max(a, b):
     if denom == 0.0:
         return float((a - b).abs().max())
     return float((a - b).abs().max()) / denom
+
+
+# ---- window-slicer fixtures (tests/golden/slicer.npz, written by tests/golden/make_slicer_golden.py) ----
+SLICER_U, SLICER_DIM, SLICER_RF, SLICER_Q = 10, 5, 61, 256
+# name: (batch_length, batch_size, use_upsampling_layer, use_speaker_code, stats dtype, batches recorded)
+SLICER_CASES = {
+    "utt_up": (None, 1, True, False, "float32", 5),
+    "utt_noup": (None, 1, False, False, "float32", 5),
+    "win_up": (200, 2, True, False, "float32", 6),
+    "win_noup": (200, 2, False, False, "float32", 6),
+    "win_up_spk": (170, 3, True, True, "float32", 4),
+    "win_up_f64stats": (200, 2, True, False, "float64", 3),
+}
+
+
+def slicer_corpus():
+    """Synthetic 3-utterance corpus of the window-slicer fixtures: int16 waveforms (so that a wav file
+    and an in-memory float32 copy are bit-equal after /32768), float32 features, a speaker code per
+    utterance and non-trivial statistics.  Utterance 0 has more samples than frames * U, utterance 1
+    fewer (both branches of validate_length, reference train.py:35-64), utterance 2 matches."""
+    rs = np.random.RandomState(77)
+    utts = []
+    for i, (frames, extra) in enumerate([(64, 13), (71, -27), (58, 0)]):
+        wav = (rs.uniform(-0.9, 0.9, size=frames * SLICER_U + extra) * 32767).astype(np.int16)
+        feat = rs.standard_normal((frames, SLICER_DIM)).astype(np.float32)
+        code = rs.standard_normal((2,)).astype(np.float32)
+        utts.append((wav, feat, code))
+    mean = rs.standard_normal(SLICER_DIM) * 0.3
+    scale = rs.uniform(0.5, 2.0, SLICER_DIM)
+    return utts, mean, scale
