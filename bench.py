@@ -72,28 +72,40 @@ def geometry(rf, batch_length, U):
 
 
 def cpu_baseline(seconds_budget=30.0):
-    """The oracle (a restatement of the reference's own torch CPU path) on this host's cores.
+    """The reference's own CPU path on this host's cores.
+
+    ``kind: "reference"``: the reference's WaveNet module itself (oracle/_ref/wavenet.py, a build-time copy made by
+    oracle/build_ref.py; git-ignored, travels to the GPU box) under the reference's training loop (train.py:527-540 restated in
+    oracle/ref_step.py: nn.CrossEntropyLoss + torch.optim.Adam).  Without the copy: the restatement (oracle/wavenet_oracle.py),
+    ``kind: "port"`` -- bit-identical results, same torch ops.
 
     Bounded sample (~30 s): the thread count is calibrated on B=1 windows of the same model (oneDNN convs of this size
     get SLOWER with hundreds of threads), then B=1 and the benchmark's own B=8 minibatch are timed at that count
     (SURVEY.md 8d asks for both).  `value` is the better of the two rates."""
+    from oracle import ref_step as RS
     from oracle import wavenet_oracle as O
     try:
         navail = len(os.sched_getaffinity(0))
     except AttributeError:
         navail = os.cpu_count() or 1
-    cfg = O.OracleConfig(*[CFG2[k] for k in ("n_quantize", "n_aux", "n_resch", "n_skipch", "dilation_depth",
-                                              "dilation_repeat", "kernel_size", "upsampling_factor")])
+    cfg_t = tuple(CFG2[k] for k in ("n_quantize", "n_aux", "n_resch", "n_skipch", "dilation_depth",
+                                     "dilation_repeat", "kernel_size", "upsampling_factor"))
+    cfg = O.OracleConfig(*cfg_t)
     bl, frames, T = geometry(cfg.receptive_field, BATCH_LENGTH, cfg.upsampling_factor)
-    g = torch.Generator().manual_seed(1)
-    params = O.init_params(cfg, generator=g)
     x, h, t = O.synthetic_batch(cfg, 1, T, 1)
-    opt = O.OracleAdam(lr=1e-4)
+    kind = "reference" if RS.available() else "port"
+    if kind == "reference":
+        trainer = RS.ReferenceTrainer(cfg_t, lr=1e-4, seed=1)     # the reference's module, initialised as train.py does
+        step = trainer.step
+    else:
+        params = O.init_params(cfg, generator=torch.Generator().manual_seed(1))
+        opt = O.OracleAdam(lr=1e-4)
+        step = lambda xb, hb, tb: O.train_step(cfg, params, opt, xb, hb, tb)   # noqa: E731
     t_begin = time.time()
 
     def timed(xb, hb, tb):
         t0 = time.time()
-        O.train_step(cfg, params, opt, xb, hb, tb)
+        step(xb, hb, tb)
         return time.time() - t0
 
     results = {}
@@ -121,12 +133,15 @@ def cpu_baseline(seconds_budget=30.0):
     b8 = {"B": BATCH_PER_GPU, "steps": len(t8s), "best_s": min(t8s), "median_s": sorted(t8s)[len(t8s) // 2],
           "value": BATCH_PER_GPU * (T - cfg.receptive_field) / min(t8s)}
     best = max((b1, b8), key=lambda b: b["value"])
-    return {"value": best["value"], "unit": "audio-samples/sec", "cores": best_thr, "kind": "port",
+    what = ("the reference's own WaveNet module (wavenet_vocoder/nets/wavenet.py, build-time copy in oracle/_ref) under its "
+            "training loop train.py:527-540" if kind == "reference" else
+            "CPU oracle (restatement of the reference's torch-CPU ops: train.py:527-540 on wavenet.py:212-241)")
+    return {"value": best["value"], "unit": "audio-samples/sec", "cores": best_thr, "kind": kind,
             "host_logical_cpus": navail, "b1": b1, "b8": b8,
-            "sample": "CPU oracle (reference torch-CPU ops: train.py:527-540 on wavenet.py:212-241), same 30-layer model, "
+            "sample": "%s, same 30-layer model, "
                       "windows of T=%d; threads calibrated over %s -> %d; B=1: %d steps, best %.3f s; B=8 (one step, no warm-up): %s; "
                       "value = the better rate (B=%d); %.0f s of CPU work" % (
-                          T, cands, best_thr, b1["steps"], b1["best_s"], "%.3f s" % b8["best_s"], best["B"],
+                          what, T, cands, best_thr, b1["steps"], b1["best_s"], "%.3f s" % b8["best_s"], best["B"],
                           time.time() - t_begin)}
 
 

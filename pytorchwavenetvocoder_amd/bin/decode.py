@@ -123,7 +123,8 @@ def build_model(config):
     return WaveNet(n_quantize=config.n_quantize, n_aux=config.n_aux, n_resch=config.n_resch,
                    n_skipch=config.n_skipch, dilation_depth=config.dilation_depth,
                    dilation_repeat=config.dilation_repeat, kernel_size=config.kernel_size,
-                   upsampling_factor=upsampling_factor, n_mixture=getattr(config, "n_mixture", 0))
+                   upsampling_factor=upsampling_factor, n_mixture=getattr(config, "n_mixture", 0),
+                   log_scale_min=getattr(config, "log_scale_min", -7.0))
 
 
 def _worker(gpu, feat_list, args, config, mean, scale):

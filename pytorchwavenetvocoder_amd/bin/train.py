@@ -287,6 +287,8 @@ def get_parser():
     parser.add_argument("--feature_type", default="world", choices=["world", "melspc"], type=str)
     # extension (not a reference flag): mixture-of-logistics output head with N components, 0 = softmax head
     parser.add_argument("--n_mixture", default=0, type=int, help="mixture-of-logistics components (0: softmax head)")
+    parser.add_argument("--log_scale_min", default=-7.0, type=float,
+                        help="mixture head: clamp of the log-scales (saved in model.conf, so decode.py samples with it)")
     parser.add_argument("--resume", default=None, nargs="?", type=str, help="checkpoint to continue from")
     return parser
 
@@ -338,7 +340,8 @@ def _worker(rank, world, args, port):
     upsampling_factor = args.upsampling_factor if args.use_upsampling_layer else 0
     model = WaveNet(n_quantize=args.n_quantize, n_aux=args.n_aux, n_resch=args.n_resch, n_skipch=args.n_skipch,
                     dilation_depth=args.dilation_depth, dilation_repeat=args.dilation_repeat,
-                    kernel_size=args.kernel_size, upsampling_factor=upsampling_factor, n_mixture=args.n_mixture)
+                    kernel_size=args.kernel_size, upsampling_factor=upsampling_factor, n_mixture=args.n_mixture,
+                    log_scale_min=args.log_scale_min)
     if is_main:
         logging.info(model)
     model.apply(initialize)

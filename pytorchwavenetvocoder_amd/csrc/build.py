@@ -29,9 +29,17 @@ def _digest():
     return h.hexdigest()
 
 
+def up_to_date():
+    """True when the .so next to the sources was built from exactly these sources and flags."""
+    try:
+        return os.path.exists(LIB) and open(STAMP).read().strip() == _digest()
+    except OSError:
+        return False
+
+
 def build(force=False, verbose=True):
     dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read().strip() == dig:
+    if not force and up_to_date():
         return LIB
     if not os.path.exists(HIPCC):
         raise RuntimeError("hipcc not found at %s; cannot build the gfx950 library" % HIPCC)

@@ -40,7 +40,9 @@ static inline void wn_buf_store(wn_rsrc_t r, float v, int voff, int soff) {
 }
 static inline float4 wn_buf_load4(wn_rsrc_t r, int voff, unsigned soff) {
     const unsigned long off = (unsigned long)(unsigned)voff + (unsigned long)soff;
-    return off + 16 <= r.bytes ? *(const float4*)(r.base + off) : float4{0.f, 0.f, 0.f, 0.f};
+    float4 v{0.f, 0.f, 0.f, 0.f};
+    if (off + 16 <= r.bytes) memcpy(&v, r.base + off, 16);   // 4-byte aligned sources (shifted taps)
+    return v;
 }
 // global -> LDS without registers: lane l of the wave writes 16 bytes at lds_wave_base + 16*l
 static inline void wn_buf_load_lds16(wn_rsrc_t r, char* lds_wave_base, int voff, unsigned soff) {
@@ -50,7 +52,7 @@ static inline void wn_buf_load_lds16(wn_rsrc_t r, char* lds_wave_base, int voff,
 #define WN_WAIT_VMCNT(n)
 #define WN_UNIFORM(x) (x)
 #define WN_SCHED_BARRIER()
-#define WN_SLEEP(n)
+#define WN_SLEEP(n) emu::yield_()   // a polling wave lets the other fibers run
 #define WN_HW_WAVE_SLOT() 0
 #define WN_SGB_DS(n)
 #define WN_SGB_MFMA(n)

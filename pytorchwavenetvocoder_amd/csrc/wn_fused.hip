@@ -84,15 +84,18 @@ static long chain_blocks() {
 #define WN_FT 512  // threads per workgroup (8 waves = 2 per SIMD)
 #endif
 #define WN_FW (WN_FT / 64)  // waves per workgroup
+#ifndef WN_LB
+#define WN_LB WN_FT   // launch bound of the fused kernels (experiments: fewer threads under the same register cap)
+#endif
 
 // Persistent grid of the fused kernels: the smallest multiple of 8 workgroups (XCD-aware walk) that needs no more
 // rounds of tiles than one workgroup per CU would.  Config 2 has 5 760 tiles: 256 x 8 waves walk them in 2.81 -> 3
 // rounds, 240 x 8 in exactly 3 -- same time (12.95 vs 13.05 ms/step measured, profiles/r01/cosched_probe.txt), and 16
 // CUs stay free for whatever runs beside the chain (the RCCL kernels of the gradient all-reduce).  WN_CHAIN_BALANCE=0
 // restores one workgroup per CU.
-static long balanced_blocks(long ntiles) {
+static long balanced_blocks(long ntiles, long fw = WN_FW) {
     const long cap = chain_blocks();
-    long nblk = (ntiles + WN_FW - 1) / WN_FW;
+    long nblk = (ntiles + fw - 1) / fw;
     if (nblk <= cap) return nblk;
     static int balance = -1;
     if (balance < 0) {
@@ -100,8 +103,8 @@ static long balanced_blocks(long ntiles) {
         balance = (e && atoi(e) == 0) ? 0 : 1;
     }
     if (!balance) return cap;
-    const long rounds = (ntiles + cap * WN_FW - 1) / (cap * WN_FW);
-    long nb = (ntiles + rounds * WN_FW - 1) / (rounds * WN_FW);
+    const long rounds = (ntiles + cap * fw - 1) / (cap * fw);
+    long nb = (ntiles + rounds * fw - 1) / (rounds * fw);
     nb = (nb + 7) / 8 * 8;
     return nb < cap ? nb : cap;
 }
@@ -138,18 +141,18 @@ static int set_lds(Kern, size_t) { return 0; }
 struct TileWalk {
     int first, end, step;
 };
-static __device__ __forceinline__ TileWalk tile_walk(int ntiles, int wave) {
+static __device__ __forceinline__ TileWalk tile_walk(int ntiles, int wave, int fw = WN_FW) {   // fw: tile-walking waves per workgroup
     TileWalk w;
     if ((gridDim.x & 7) == 0) {
         const int per = (ntiles + 7) >> 3, x = blockIdx.x & 7;
         const int lo = x * per;
         w.end = lo + per < ntiles ? lo + per : ntiles;
-        w.first = lo + (blockIdx.x >> 3) * WN_FW + wave;
-        w.step = (gridDim.x >> 3) * WN_FW;
+        w.first = lo + (blockIdx.x >> 3) * fw + wave;
+        w.step = (gridDim.x >> 3) * fw;
     } else {
         w.end = ntiles;
-        w.first = blockIdx.x * WN_FW + wave;
-        w.step = gridDim.x * WN_FW;
+        w.first = blockIdx.x * fw + wave;
+        w.step = gridDim.x * fw;
     }
     return w;
 }
@@ -189,7 +192,7 @@ struct FwdArgs {
 };
 
 template <int K>
-__global__ __launch_bounds__(WN_FT) void k_resblock_fwd(FwdArgs a) {
+__global__ __launch_bounds__(WN_LB) void k_resblock_fwd(FwdArgs a) {
     WN_DYN_SMEM(smem_raw);
     float* Wd = reinterpret_cast<float*>(smem_raw);  // [K*64][128]
     float* Wr = Wd + K * 64 * 128;                   // [64][64]
@@ -569,7 +572,7 @@ struct PackImgArgs {
     int K;
 };
 template <int K>
-__global__ __launch_bounds__(WN_FT) void k_fused_pack_images(PackImgArgs a) {
+__global__ __launch_bounds__(WN_LB) void k_fused_pack_images(PackImgArgs a) {
     const int l = blockIdx.x, kind = blockIdx.y;
     if (kind == 0) {
         char* img = reinterpret_cast<char*>(a.img_fwd) + (long)l * fwd_image_bytes(K);
@@ -603,7 +606,7 @@ int wn_fused_pack_images(const float* wd_f, const float* wres_f, const float* wd
 }
 
 template <int K, int CHAIN>
-__global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
+__global__ __launch_bounds__(WN_LB) void k_resblock_fwd_s(FwdArgs a) {
     WN_DYN_SMEM(smem_raw);
     constexpr int WD_BLK = 3 * 128 * 32, WR_BLK = 3 * 64 * 32;  // bytes of one 16-k block
     char* Wd = smem_raw;                                         // [K*4 blocks][piece][128 rows][16 k] bf16
@@ -949,7 +952,7 @@ __global__ __launch_bounds__(WN_FT) void k_resblock_fwd_s(FwdArgs a) {
 // is the same code: the output is bit-identical to k_resblock_fwd_s<2, 0>.
 // ---------------------------------------------------------------------------------------------
 template <bool KEEP_G>
-__global__ __launch_bounds__(WN_FT) void k_resblock_fwd_v2(FwdArgs a) {
+__global__ __launch_bounds__(WN_LB) void k_resblock_fwd_v2(FwdArgs a) {
     WN_DYN_SMEM(smem_raw);
     constexpr int K = 2;
     constexpr int WD_BLK = 3 * 128 * 32, WR_BLK = 3 * 64 * 32;  // bytes of one 16-k block
@@ -1327,7 +1330,7 @@ struct ConvArgs {
 };
 
 template <int MODE>
-__global__ __launch_bounds__(WN_FT) void k_conv64(ConvArgs a) {
+__global__ __launch_bounds__(WN_LB) void k_conv64(ConvArgs a) {
     WN_DYN_SMEM(smem_raw);
     float* W = reinterpret_cast<float*>(smem_raw);
     for (int sg = 0; sg < a.nseg; ++sg) stage_copy(W + a.seg[sg].woff, a.seg[sg].w, a.seg[sg].nch * 64);
@@ -1504,7 +1507,7 @@ __global__ __launch_bounds__(WN_FT) void k_conv64(ConvArgs a) {
 // the activation chunk of a lane (2 x 8 consecutive channels of its time step) is split in registers.
 // 24 bf16 MFMAs (768 cycles) replace the 32 f32 MFMAs (2048 cycles) of a 32-channel chunk.
 template <int MODE>
-__global__ __launch_bounds__(WN_FT) void k_conv64s(ConvArgs a) {
+__global__ __launch_bounds__(WN_LB) void k_conv64s(ConvArgs a) {
     WN_DYN_SMEM(smem_raw);
     char* W = smem_raw;  // 6 KB per 16-k block: [piece][row][16 k] bf16
     for (int idx = threadIdx.x; idx < a.nchunks * 2 * 128; idx += WN_FT) {
@@ -1882,6 +1885,13 @@ struct ChainArgs {
     int U, F;
     float* dGp;          // (B, 128, T/16)
     float* qp;           // (B, T)
+    // DW (weight-gradient waves, below)
+    const float* Xl;     // (B, 64, T) input of layer l
+    const float* Zl;     // (B, 64, T) gate output z of layer l
+    float* dwp;          // [workgroup][128][K*64]  partial dW_dil of layer l
+    float* dwrp;         // [workgroup][64][64]     partial dW_res of layer l (unused when dXn == NULL)
+    float* rsp;          // [workgroup][128]        partial row sums of dP_l
+    float* rsrp;         // [workgroup][64]         partial row sums of dX_{l+1}
 };
 
 // 8 fp32 values -> the three bf16 pieces of the lane's share of a 16-k block
@@ -1892,15 +1902,165 @@ static __device__ __forceinline__ void split8v(const float (&x)[8], bool ok, wn_
     split8(y, bf);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight-gradient waves of the chain kernel (k_chain64s<..., DW = true>; round 3).
+//
+// The weight gradients of layer l contract over TIME the very tensors the chain launch of layer l streams anyway:
+//   dW_dil,l[tap][o][i] = sum_t dP_l[o][t] x_l[i][t - (K-1-tap) d]      (wavenet.py:201-202 backward)
+//   dW_res,l[c][i]      = sum_t dX_{l+1}[c][t] z_l[i][t]                (wavenet.py:206 backward)
+// As separate contractions (dw_dilated, dw_res) they re-read dP, x, dX, z of all layers from HBM at the end of the
+// backward pass: 320 words per timestep and layer.  Here the workgroup is 4 chain waves + 4 weight-gradient waves (one
+// of each per SIMD): the chain waves walk tiles exactly as before, the other four contract the SAME four tiles of the round
+// while their lines are in the XCD's L2 / the memory-side cache, so only x_l and z_l are new HBM traffic.
+//
+// A tile's contribution is a rank-32 update of a 128 x (K 64) + 64 x 64 matrix: 320 accumulator registers per wave if every
+// wave kept all of it -- so the four waves SHARE the accumulators of the workgroup, wave (oh, ch) owns output rows
+// [64 oh, 64 oh + 64) x column half ch (K = 2: tap ch; K = 1: input channels [32 ch, 32 ch + 32)) of dW_dil and the
+// (32 oh, 32 ch) quadrant of dW_res: 64 + 16 registers, kept across the whole persistent walk and written ONCE per launch as
+// a per-workgroup partial (240 x 80 KB per layer; reduced in a fixed order by wn_reduce -> deterministic).  Time has to be
+// the contraction index, i.e. operands are needed as [lane = channel][8 consecutive samples]: that is a plain 2 x 16-byte
+// load per lane from the (B, C, T) tensors -- no transposition, no LDS -- split into the three bf16 pieces in registers.
+// Every operand exists before the launch starts (dP_l was written by the previous launch), so the two kinds of waves never
+// synchronise on data; an LDS round counter only keeps the weight-gradient waves from running ahead of their chain waves.
+// ---------------------------------------------------------------------------------------------
+#ifndef WN_DW_PRIO
+#define WN_DW_PRIO 1
+#endif
+// 8 consecutive samples of this lane's row (voff = its row / k-half offset inside a 32-row block, soff_row = the block's byte
+// offset, both >= 0), starting `lead` samples into the sequence for the wave's first lane half.  lead >= 0 (wave-uniform) is
+// the fast path: two 16-byte loads.  lead < 0: the tile overlaps the zero history in front of the sequence -- per-sample
+// validity, an invalid sample carries an out-of-range offset (reads 0 without touching memory; offsets never go negative).
+static __device__ __forceinline__ void dw_load8(const wn_rsrc_t& R, int voff, int soff_row, int lead, int hi, float (&x)[8]) {
+    if (lead >= 0) {
+        const unsigned so = (unsigned)(soff_row + lead * 4);
+        const float4 a = wn_buf_load4(R, voff, so), b = wn_buf_load4(R, voff + 16, so);
+        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    } else {
+        WN_UNROLL
+        for (int e = 0; e < 8; ++e)
+            x[e] = wn_buf_load(R, (lead + 8 * hi + e >= 0) ? voff + (lead + e) * 4 : WN_VOFF_DEAD, soff_row);
+    }
+}
+static __device__ __forceinline__ f32x16 dw_mfma6(const wn_f4 (&af)[3], const wn_f4 (&bf)[3], f32x16 acc) {
+    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};  // small terms first
+    WN_UNROLL
+    for (int t6 = 0; t6 < 6; ++t6) acc = mfma_bf16(af[PA[t6]], bf[PB[t6]], acc);
+    return acc;
+}
+
+template <int K>
+static __device__ __forceinline__ void chain_dw_role(const ChainArgs& a, int w4, volatile int* round_flag) {
+    const int lane = threadIdx.x & 63;
+    const int li = lane & 31, hi = lane >> 5;
+    const int T = a.T, T4 = T * 4;
+    const int tiles_per_b = (T + 31) >> 5;
+    const int ntiles = a.B * tiles_per_b;
+    const TileWalk walk = tile_walk(ntiles, 0, 4);   // the tiles of chain wave 0; chain wave j takes the j-th next one
+    const int oh = w4 >> 1, ch = w4 & 1;
+    const bool has_res = a.dXn != nullptr;
+    f32x16 acc[2][K], accr = f32x16_zero();
+    WN_UNROLL
+    for (int rb = 0; rb < 2; ++rb) {
+        WN_UNROLL
+        for (int j = 0; j < K; ++j) acc[rb][j] = f32x16_zero();
+    }
+    float rs[2] = {0.0f, 0.0f}, rsr = 0.0f;
+    const int vrow = (li * T + 8 * hi) * 4;   // this lane's row and k half inside a 32-row block
+    WN_PRIO(WN_DW_PRIO);
+    int round = 0;
+    for (int base_v = walk.first; base_v < walk.end; base_v += walk.step, ++round) {
+        const int base = WN_UNIFORM(base_v);
+        while (*round_flag < round) WN_SLEEP(4);   // not ahead of the chain waves: their loads and ours share cache lines
+        for (int j4 = 0; j4 < 4; ++j4) {
+            const int tile = base + j4;
+            if (tile >= walk.end) break;
+            const int b = tile / tiles_per_b;
+            const int t0 = (tile - b * tiles_per_b) * 32;
+            const wn_rsrc_t Pr = wn_make_buf(a.dP + (long)b * 128 * T, (unsigned)(128 * T4));
+            const wn_rsrc_t Xr = wn_make_buf(a.Xl + (long)b * 64 * T, (unsigned)(64 * T4));
+            const wn_rsrc_t Dr = wn_make_buf(has_res ? a.dXn + (long)b * 64 * T : a.Xl, (unsigned)(64 * T4));
+            const wn_rsrc_t Zr = wn_make_buf(a.Zl + (long)b * 64 * T, (unsigned)(64 * T4));
+            WN_UNROLL
+            for (int kb = 0; kb < 2; ++kb) {
+                const int tk = t0 + 16 * kb;
+                if (tk >= T) break;   // T % 16 == 0 (launcher): a k-block is inside the sequence or outside it
+                float xa[2][8], xb[K][8], xr[2][8];
+                WN_UNROLL
+                for (int rb = 0; rb < 2; ++rb) dw_load8(Pr, vrow, (64 * oh + 32 * rb) * T4, tk, hi, xa[rb]);
+                WN_UNROLL
+                for (int j = 0; j < K; ++j) {
+                    const int cbg = ch * K + j, tap = cbg >> 1, ih = cbg & 1;
+                    const int lead = tk - (K - 1 - tap) * a.dil;
+                    dw_load8(Xr, vrow, 32 * ih * T4, lead, hi, xb[j]);
+                }
+                if (has_res) {
+                    dw_load8(Dr, vrow, 32 * oh * T4, tk, hi, xr[0]);
+                    dw_load8(Zr, vrow, 32 * ch * T4, tk, hi, xr[1]);
+                }
+                wn_f4 bfb[K][3];
+                WN_UNROLL
+                for (int j = 0; j < K; ++j) split8(xb[j], bfb[j]);
+                WN_UNROLL
+                for (int rb = 0; rb < 2; ++rb) {
+                    wn_f4 bfa[3];
+                    split8(xa[rb], bfa);
+                    WN_UNROLL
+                    for (int e = 0; e < 8; ++e) rs[rb] += xa[rb][e];
+                    WN_UNROLL
+                    for (int j = 0; j < K; ++j) acc[rb][j] = dw_mfma6(bfa, bfb[j], acc[rb][j]);
+                }
+                if (has_res) {
+                    wn_f4 bfa[3], bfz[3];
+                    split8(xr[0], bfa);
+                    split8(xr[1], bfz);
+                    WN_UNROLL
+                    for (int e = 0; e < 8; ++e) rsr += xr[0][e];
+                    accr = dw_mfma6(bfa, bfz, accr);
+                }
+            }
+        }
+    }
+    // the workgroup's partial sums: [128][K*64], [64][64], row sums [128], [64]
+    const int NC = K * 64;
+    float* dw = a.dwp + (long)blockIdx.x * 128 * NC;
+    WN_UNROLL
+    for (int rb = 0; rb < 2; ++rb) {
+        WN_UNROLL
+        for (int j = 0; j < K; ++j) {
+            WN_UNROLL
+            for (int r = 0; r < 16; ++r)
+                dw[(long)(64 * oh + 32 * rb + mfma32_row(r, hi)) * NC + 32 * (ch * K + j) + li] = acc[rb][j][r];
+        }
+    }
+    if (ch == 0) {
+        WN_UNROLL
+        for (int rb = 0; rb < 2; ++rb) {
+            const float v = rs[rb] + __shfl_xor(rs[rb], 32, 64);
+            if (hi == 0) a.rsp[(long)blockIdx.x * 128 + 64 * oh + 32 * rb + li] = v;
+        }
+    }
+    if (has_res) {
+        float* dr = a.dwrp + (long)blockIdx.x * 64 * 64;
+        WN_UNROLL
+        for (int r = 0; r < 16; ++r) dr[(32 * oh + mfma32_row(r, hi)) * 64 + 32 * ch + li] = accr[r];
+        if (ch == 0) {
+            const float v = rsr + __shfl_xor(rsr, 32, 64);
+            if (hi == 0) a.rsrp[(long)blockIdx.x * 64 + 32 * oh + li] = v;
+        }
+    }
+}
+
 // HEAD = true: the top of the chain.  The last layer's residual output is dead (wavenet.py:231-238), so dP_{L-1} is the gate'
 // epilogue alone on dZs_{L-1} (which bwd_dz_skip_all now produces for ALL layers): no taps, no Wres^T, no dX -- its own
 // instantiation, so that the main one compiles exactly as before.
-template <int AUX, int K, bool HEAD = false>
-__global__ __launch_bounds__(WN_FT) void k_chain64s(ChainArgs a) {
+template <int AUX, int K, bool HEAD = false, bool DW = false>
+__global__ __launch_bounds__(WN_LB) void k_chain64s(ChainArgs a) {
     WN_DYN_SMEM(smem_raw);
     char* W = smem_raw;                      // tap blocks: chunk q (32 channels) = tap q % K, channel group q / K; 2 blocks of 6 KB each
     constexpr int NCH = K * 4;               // chunks of the dX part
     char* Wr = W + NCH * 2 * 6144;           // Wres^T: 4 blocks [piece][64 rows][16 k], k order = accumulator register order
+    volatile int* round_flag = reinterpret_cast<volatile int*>(Wr + WN_RES_T_BYTES);   // DW: round the chain waves are in
+    if (DW && threadIdx.x == 0) *round_flag = -1;
     if (HEAD) {
         // no weights
     } else if (a.img_taps != nullptr) {   // pre-split once per step (wn_fused_pack_images): two straight global -> LDS copies
@@ -1912,8 +2072,15 @@ __global__ __launch_bounds__(WN_FT) void k_chain64s(ChainArgs a) {
         fill_res_t(Wr, a.wres, threadIdx.x, WN_FT);
     }
     __syncthreads();
-    if (WN_UNIFORM((int)(threadIdx.x / (WN_FT / 2))) != 0)
+    if (DW) {   // waves 4..7: the weight gradients of this layer (chain_dw_role); waves 0..3 walk the tiles
+        const int wv = WN_UNIFORM((int)(threadIdx.x >> 6));
+        if (wv >= 4) {
+            chain_dw_role<K>(a, wv - 4, round_flag);
+            return;
+        }
+    } else if (WN_UNIFORM((int)(threadIdx.x / (WN_FT / 2))) != 0) {
         for (int i = 0; i < a.stagger; ++i) WN_SLEEP(127);
+    }
 
     const int lane = threadIdx.x & 63;
     const int li = lane & 31, hi = lane >> 5;
@@ -1921,8 +2088,9 @@ __global__ __launch_bounds__(WN_FT) void k_chain64s(ChainArgs a) {
     const int T4 = T * 4;
     const int tiles_per_b = (T + 31) >> 5;
     const int ntiles = a.B * tiles_per_b;
-    const TileWalk walk = tile_walk(ntiles, threadIdx.x >> 6);
+    const TileWalk walk = tile_walk(ntiles, threadIdx.x >> 6, DW ? 4 : WN_FW);
     const int step = walk.step, tile_end = walk.end;
+    int dw_round = 0;
 
     float xa[16], xb[16];
     bool oka = false, okb = false;
@@ -1971,6 +2139,7 @@ __global__ __launch_bounds__(WN_FT) void k_chain64s(ChainArgs a) {
     }
     while (tile_v < tile_end) {
         const int tile = WN_UNIFORM(tile_v);
+        if (DW && threadIdx.x == 0) *round_flag = dw_round++;   // chain wave 0 owns the first tile of every round
         const int b = tile / tiles_per_b;
         const int t = (tile - b * tiles_per_b) * 32 + li;
         const bool inb = t < T;
@@ -2146,19 +2315,29 @@ __global__ __launch_bounds__(WN_FT) void k_chain64s(ChainArgs a) {
 }
 
 int wn_fused_chain_supported(int R, int K, int S) {
-    return wn_fused_supported(R, K, S) && K >= 1 && K <= 2 && (size_t)(K * 8 + 4) * 6144 <= 160 * 1024;
+    return wn_fused_supported(R, K, S) && K >= 1 && K <= 2 && (size_t)(K * 8 + 4) * 6144 + 16 <= 160 * 1024;
+}
+
+// workgroups of a DW launch (4 tile-walking waves each): what the workspace / the reduction of the partials is sized by
+int wn_fused_chain_dw_blocks(int B, int T) {
+    const long ntiles = (long)B * ((T + 31) / 32);
+    return (int)balanced_blocks(ntiles, 4);
 }
 
 int wn_fused_bwd_chain(const float* wd_b, const float* dP, const float* dXn, float* dX, const float* wres_prev, const float* dZs,
                        long zs_bstride, const float* S, const float* Gt, int gt_is_z, float* dP_prev, const float* G, long g_bstride,
                        const float* upw, int U, int F, float* dGp, float* qp, int B, int T, int K, int dilation,
-                       const float* img_taps, const float* img_res, int zs_t0, wn_stream_t st) {
+                       const float* img_taps, const float* img_res, int zs_t0, const float* Xl, const float* Zl, float* dwp,
+                       float* dwrp, float* rsp, float* rsrp, wn_stream_t st) {
     // dP (, dXn), dZs, S, Gt in; dX, dP_prev out (+ dGp 8 / qp 1 words per timestep with the aux partials)
     const bool aux = dGp != nullptr;
-    WN_PROF("fused_bwd_chain", 2.0 * (double)B * T * 64.0 * (K * 128.0 + 64.0),
-            4.0 * (double)B * T * (128.0 + (dXn ? 64.0 : 0.0) + 64.0 + 128.0 + 64.0 + 128.0 + (aux ? 9.0 : 0.0)), st);
+    const bool dw = dwp != nullptr;
+    WN_PROF(dw ? "fused_bwd_chain_dw" : "fused_bwd_chain",
+            2.0 * (double)B * T * 64.0 * (K * 128.0 + 64.0) + (dw ? 2.0 * (double)B * T * (128.0 * K * 64.0 + (dXn ? 4096.0 : 0.0)) : 0.0),
+            4.0 * (double)B * T * (128.0 + (dXn ? 64.0 : 0.0) + 64.0 + 128.0 + 64.0 + 128.0 + (aux ? 9.0 : 0.0) + (dw ? 128.0 : 0.0)), st);
     if (K < 1 || K > 2) return 1;
     if (aux && (U < 16 || (U & 15) || (T & 15) || (long)U * F != T)) return 1;
+    if (dw && ((T & 15) || !Xl || !Zl || !dwrp || !rsp || !rsrp || WN_FT != 512)) return 1;
     ChainArgs a;
     a.img_taps = (img_taps && img_res) ? img_taps : nullptr; a.img_res = img_res;
     a.wd_b = wd_b; a.dP = dP; a.dXn = dXn; a.dX = dX;
@@ -2166,20 +2345,29 @@ int wn_fused_bwd_chain(const float* wd_b, const float* dP, const float* dXn, flo
     a.B = B; a.T = T; a.K = K; a.dil = dilation;
     a.stagger = stagger_setting();
     a.G = G; a.g_bstride = g_bstride; a.upw = upw; a.U = U; a.F = F; a.dGp = dGp; a.qp = qp;
+    a.Xl = Xl; a.Zl = Zl; a.dwp = dwp; a.dwrp = dwrp; a.rsp = rsp; a.rsrp = rsrp;
     const long ntiles = (long)B * ((T + 31) / 32);
-    const long nblk = balanced_blocks(ntiles);
-    const size_t lds = (size_t)(K * 8 + 4) * 6144;
-#define WN_CHAIN_LAUNCH(AUXV, KV)                                                                       \
-    do {                                                                                                \
-        if (set_lds(k_chain64s<AUXV, KV>, lds)) return 1;                                               \
-        WN_LAUNCH((k_chain64s<AUXV, KV>), dim3((unsigned)nblk), dim3(WN_FT), lds, st, a);               \
+    const long nblk = dw ? balanced_blocks(ntiles, 4) : balanced_blocks(ntiles);
+    const size_t lds = (size_t)(K * 8 + 4) * 6144 + 16;   // + the round counter of the DW waves
+#define WN_CHAIN_LAUNCH(AUXV, KV, DWV)                                                                    \
+    do {                                                                                                  \
+        if (set_lds(k_chain64s<AUXV, KV, false, DWV>, lds)) return 1;                                     \
+        WN_LAUNCH((k_chain64s<AUXV, KV, false, DWV>), dim3((unsigned)nblk), dim3(WN_FT), lds, st, a);     \
     } while (0)
-    if (aux) {
-        if (K == 1) WN_CHAIN_LAUNCH(1, 1);
-        else WN_CHAIN_LAUNCH(1, 2);
+    if (dw) {
+        if (aux) {
+            if (K == 1) WN_CHAIN_LAUNCH(1, 1, true);
+            else WN_CHAIN_LAUNCH(1, 2, true);
+        } else {
+            if (K == 1) WN_CHAIN_LAUNCH(0, 1, true);
+            else WN_CHAIN_LAUNCH(0, 2, true);
+        }
+    } else if (aux) {
+        if (K == 1) WN_CHAIN_LAUNCH(1, 1, false);
+        else WN_CHAIN_LAUNCH(1, 2, false);
     } else {
-        if (K == 1) WN_CHAIN_LAUNCH(0, 1);
-        else WN_CHAIN_LAUNCH(0, 2);
+        if (K == 1) WN_CHAIN_LAUNCH(0, 1, false);
+        else WN_CHAIN_LAUNCH(0, 2, false);
     }
 #undef WN_CHAIN_LAUNCH
     return 0;

@@ -178,15 +178,19 @@ class WaveNet(nn.Module):
             > 0 = mixture-of-logistics head with that many components (BASELINE configs[3]): ``conv_post_2`` then
             has 3 * n_mixture channels (mixture logits, means, log-scales), the input stays the mu-law one-hot
             front end, the loss is ``mol_loss_and_backward`` and generation draws from the mixture.
+        log_scale_min (float): mixture head only -- clamp of the predicted log-scales, used by the loss AND by sampling.
     """
 
     def __init__(self, n_quantize=256, n_aux=28, n_resch=512, n_skipch=256,
-                 dilation_depth=10, dilation_repeat=3, kernel_size=2, upsampling_factor=0, n_mixture=0, _library=None):
+                 dilation_depth=10, dilation_repeat=3, kernel_size=2, upsampling_factor=0, n_mixture=0, _library=None,
+                 log_scale_min=-7.0):
         super(WaveNet, self).__init__()
         self.n_mixture = n_mixture
         # mixture head: clamp of the predicted log-scales, ONE value for the likelihood (mol_loss_and_backward) and for
-        # sampling (the decode kernels), so that training and generation cannot disagree
-        self.log_scale_min = -7.0
+        # sampling (the decode kernels), so that training and generation cannot disagree.  A constructor argument, so it
+        # lives in the model configuration (train.py writes it into model.conf, decode.py rebuilds the model from it) and
+        # state_dict keeps exactly the reference's parameter keys.
+        self.log_scale_min = float(log_scale_min)
         self.out_channels = 3 * n_mixture if n_mixture > 0 else n_quantize
         self.n_aux = n_aux
         self.n_quantize = n_quantize

@@ -374,7 +374,8 @@ def test_launch_sequence_of_the_default_training_step():
     cfg = O.OracleConfig(*cfg_t)
     x, h, t = O.synthetic_batch(cfg, 1, 64, 2)
     logs = {}
-    for flags in (_lib.FLAG_AUX_FUSED, _lib.FLAG_AUX_FUSED | _lib.FLAG_NO_CHAIN):
+    NDW = _lib.FLAG_NO_CHAIN_DW
+    for flags in (_lib.FLAG_AUX_FUSED, _lib.FLAG_AUX_FUSED | NDW, _lib.FLAG_AUX_FUSED | _lib.FLAG_NO_CHAIN):
         eng = WaveNetEngine(*cfg_t, device="cpu", library=emu_library())
         eng.flags = flags
         load_state_into_flat(eng, O.random_params(cfg, 1, scale=0.1))
@@ -384,10 +385,39 @@ def test_launch_sequence_of_the_default_training_step():
             loss, dl = eng.loss(logits, t)
             eng.backward(dl)
         logs[flags] = PC.launch_log(emu_library(), step)
-    a, b = logs[_lib.FLAG_AUX_FUSED], logs[_lib.FLAG_AUX_FUSED | _lib.FLAG_NO_CHAIN]
+    d, a, b = logs[_lib.FLAG_AUX_FUSED], logs[_lib.FLAG_AUX_FUSED | NDW], logs[_lib.FLAG_AUX_FUSED | _lib.FLAG_NO_CHAIN]
+    # default (round 3): the chain launches carry the weight-gradient waves; only layer 0 (no chain launch) still contracts
+    assert d["fused_resblock_fwd"] == 6 and d["fused_bwd_chain_dw"] == 5 and "fused_bwd_chain" not in d, d
+    assert d["fused_bwd_gate"] == 1 and d["fused_bwd_dx"] == 1 and d["dw_dilated"] == 1 and d["dw_res"] == 1, d
     assert a["fused_resblock_fwd"] == 6 and a["fused_bwd_chain"] == 5 and a["fused_bwd_gate"] == 1 and a["fused_bwd_dx"] == 1, a
     assert a["bwd_dz_skip_all"] == 1 and a["fused_pack_images"] == 1 and "aux_bwd" not in a and a["aux_finish"] >= 1, a
     assert b["fused_bwd_gate"] == 6 and b["fused_bwd_dx"] == 6 and "fused_bwd_chain" not in b and "bwd_dz_skip_all" not in b, b
+
+
+def test_weight_gradient_waves_of_the_chain_launch():
+    """Round 3: four of the eight waves of a chain workgroup contract dW_dil / dW_res of the layer over time
+    (csrc/wn_fused.hip chain_dw_role).  Against the layer-batched contractions (WN_FLAG_NO_CHAIN_DW) on the same dP / dX:
+    kernel_size 1 and 2, dilations larger than a tile (zero history inside and across tiles), several sequences, a last
+    tile of 16 samples, gradient buckets; and against the oracle."""
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd import _lib
+    from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat
+    A, NDW = _lib.FLAG_AUX_FUSED, _lib.FLAG_NO_CHAIN_DW
+    for cfg_t, B, T, lpb in [((64, 6, 64, 32, 7, 1, 2, 16), 2, 208, 0), ((64, 6, 64, 32, 4, 2, 1, 16), 3, 80, 3),
+                             ((64, 6, 64, 32, 3, 1, 2, 0), 1, 48, 0)]:
+        cfg = O.OracleConfig(*cfg_t)
+        params = O.random_params(cfg, 51, scale=0.2)
+        x, h, t = O.synthetic_batch(cfg, B, T, 52)
+        res = []
+        for flags in (A, A | NDW):
+            eng = WaveNetEngine(*cfg_t, device="cpu", library=emu_library())
+            eng.flags = flags
+            load_state_into_flat(eng, params)
+            loss, dl = eng.forward_loss(x, h, t)
+            res.append(eng.backward(dl, t_first=eng.receptive_field, layers_per_bucket=lpb).clone())
+        scale = float(res[1].abs().max())
+        assert float((res[0] - res[1]).abs().max()) <= 2e-6 * scale, (cfg_t, float((res[0] - res[1]).abs().max()) / scale)
+    PC.run_oracle_vs_engine((64, 6, 64, 32, 7, 1, 2, 16), 1, 160, 53, emu_library(), "cpu", flags=A, scale=0.2)
 
 
 def test_loss_window_backward_equals_the_full_backward():

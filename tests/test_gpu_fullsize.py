@@ -79,3 +79,27 @@ def test_config4_geometry_vs_oracle():
     from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS
     res = PC.run_fullsize_vs_oracle(cfg_t, 2, 6400 + 256, 6, _lib(), DEV, flag_sets=[DEFAULT_FLAGS], scale=0.05)
     print("configs[3] geometry, B=2, T=6656: logits %.3g, grads %s, %d kink flips" % (res["logits"], res["grads"], res["kink_flips"]))
+
+
+def test_config4_stated_size_vs_oracle():
+    """BASELINE configs[3] at ITS OWN size: kernel_size 3, upsampling_factor 256, B = 8 windows of batch_len 20000 ->
+    T = 26112 (rf 6139, bl 20000 -> 19973, 102 frames): logits, loss, every layer input and every gradient
+    against the oracle, method of the config-2 full-size test (the kernels take other tile walks / split-K plans /
+    loss-window rounding here than at the reduced sizes above)."""
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS
+    cfg_t = (256, 80, 64, 256, 10, 3, 3, 256)
+    assert O.batch_geometry(6139, 20000, 256)["T"] == 26112
+    res = PC.run_fullsize_vs_oracle(cfg_t, 8, 26112, 111, _lib(), DEV, flag_sets=[DEFAULT_FLAGS], scale=0.05)
+    print("configs[3] STATED SIZE (K=3, U=256, B=8, T=26112) vs oracle: logits %.3g, loss %.3g, layer inputs %.3g, grads %s, "
+          "%d kink flips" % (res["logits"], res["loss"], res["layer_inputs"], res["grads"], res["kink_flips"]))
+
+
+def test_recipe_size_model_at_the_timed_length_vs_oracle():
+    """The recipe-size model (n_resch 512) at the window length tools/recipe_bench.py times (T = 23040; B = 2 of its 4 windows:
+    the CPU oracle needs ~1 min and ~30 GB at this width): multi-round tile walks and the split-K plans of the full length."""
+    from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS
+    cfg_t = (256, 80, 512, 256, 10, 3, 2, 80)
+    res = PC.run_fullsize_vs_oracle(cfg_t, 2, 23040, 112, _lib(), DEV, flag_sets=[DEFAULT_FLAGS], scale=0.02)
+    print("recipe-size model at T=23040, B=2 vs oracle: logits %.3g, loss %.3g, layer inputs %.3g, grads %s, %d kink flips"
+          % (res["logits"], res["loss"], res["layer_inputs"], res["grads"], res["kink_flips"]))

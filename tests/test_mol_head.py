@@ -39,3 +39,24 @@ def test_mol_training_step_gpu():
 @pytest.mark.gpu
 def test_mol_generation_gpu():
     MC.check_mol_generation(_gpu_lib(), "cuda:0")
+
+
+@pytest.mark.emu
+def test_log_scale_min_is_part_of_the_model_configuration():
+    """The clamp of the mixture log-scales is a constructor argument: train.py stores it in model.conf, decode.py rebuilds
+    the model with it (round-2 advisor finding: a model trained with a non-default clamp sampled with -7 after a reload);
+    state_dict keeps the reference's parameter keys."""
+    import argparse
+    from pytorchwavenetvocoder_amd.bin import decode as D, train as T
+    from pytorchwavenetvocoder_amd.nets import WaveNet
+    a = T.get_parser().parse_args(["--waveforms", "w", "--feats", "f", "--stats", "s", "--expdir", "e",
+                                   "--n_mixture", "2", "--log_scale_min", "-5.5"])
+    assert a.log_scale_min == -5.5
+    conf = argparse.Namespace(n_quantize=16, n_aux=3, n_resch=8, n_skipch=8, dilation_depth=2, dilation_repeat=1,
+                              kernel_size=2, upsampling_factor=0, use_upsampling_layer=False, n_mixture=2,
+                              log_scale_min=-5.5)
+    import inspect
+    assert "log_scale_min" in inspect.signature(WaveNet.__init__).parameters
+    assert "log_scale_min=getattr(config" in inspect.getsource(D.build_model)
+    m = WaveNet(16, 3, 8, 8, 2, 1, 2, 0, n_mixture=2, _library=emu_library(), log_scale_min=conf.log_scale_min)
+    assert m.log_scale_min == -5.5 and not any("log_scale" in k for k in m.state_dict())

@@ -91,3 +91,27 @@ def test_oracle_generation_vs_reference(name):
     batch = O.batch_fast_generate(g.cfg, g.params, g.x, g.h, g.n_list)
     for a, r in zip(batch, g.batch):
         assert (a == r).all()
+
+
+def test_restatement_equals_the_reference_module_copy():
+    """oracle/_ref/wavenet.py (the reference's own model file, copied at build time by oracle/build_ref.py; absent from the
+    repository's history) under the reference's training loop == the restatement, bit for bit, incl. the Adam step."""
+    import pytest
+    from oracle import ref_step as RS
+    if not RS.available():
+        pytest.skip("oracle/_ref/wavenet.py not built (needs /root/reference at build time)")
+    import torch
+    from oracle import wavenet_oracle as O
+    for cfg_t, B, T in [((256, 5, 4, 4, 3, 2, 2, 10), 2, 60), ((64, 8, 64, 32, 3, 1, 3, 8), 2, 64), ((32, 6, 8, 8, 4, 1, 2, 0), 1, 40)]:
+        cfg = O.OracleConfig(*cfg_t)
+        p = O.random_params(cfg, 5)
+        x, h, t = O.synthetic_batch(cfg, B, T, 6)
+        tr = RS.ReferenceTrainer(cfg_t, state=p, lr=1e-3, weight_decay=0.01)
+        pp = {k: v.clone() for k, v in p.items()}
+        opt = O.OracleAdam(lr=1e-3, weight_decay=0.01)
+        for _ in range(2):
+            l_ref, out_ref = tr.step(x, h, t)
+            l, lg, _g = O.train_step(cfg, pp, opt, x, h, t)
+            assert l_ref == float(l) and torch.equal(out_ref.detach(), lg)
+        for k, v in tr.model.state_dict().items():
+            assert torch.equal(v, pp[k]), k
