@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define WN_ABI_VERSION 5
+#define WN_ABI_VERSION 6
 
 /* Same fields as the constructor WaveNet(n_quantize, n_aux, n_resch, n_skipch, dilation_depth,
  * dilation_repeat, kernel_size, upsampling_factor)  -- reference wavenet.py:172-173. */
@@ -324,6 +324,9 @@ int wn_decode_prefill(const WnConfig* cfg, int B, int Tctx, int pos0, const floa
  * {"tag": {"count", "ms", "flops", "bytes"}} into buf (returns the needed size when buf == NULL). */
 int wn_prof_enable(int on);
 int wn_prof_report(char* buf, size_t n);
+/* the recorded tags in issue order, comma separated; "bucket_event" marks where wn_backward recorded a gradient-bucket
+ * event (tests assert that a bucket's event follows the last launch that writes into the bucket).  Same buffer protocol. */
+int wn_prof_sequence(char* buf, size_t n);
 
 #ifdef __cplusplus
 }

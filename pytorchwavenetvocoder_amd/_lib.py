@@ -82,13 +82,13 @@ def flag_dw_flush(n):
     return (int(n) & 0xff) << 8
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # every symbol include/wavenet_hip.h declares
 EXPORTS = [
     "wn_abi_version", "wn_last_error", "wn_receptive_field", "wn_num_layers", "wn_param_count", "wn_param_offset",
     "wn_num_buckets", "wn_bucket_range", "wn_dead_param_range", "wn_workspace_bytes", "wn_workspace_region", "wn_forward",
-    "wn_softmax_ce_loss", "wn_forward_loss_fused", "wn_forward_loss", "wn_backward", "wn_backward_window", "wn_adam_step", "wn_op_front", "wn_op_causal_conv", "wn_op_gemm", "wn_prof_enable", "wn_prof_report",
+    "wn_softmax_ce_loss", "wn_forward_loss_fused", "wn_forward_loss", "wn_backward", "wn_backward_window", "wn_adam_step", "wn_op_front", "wn_op_causal_conv", "wn_op_gemm", "wn_prof_enable", "wn_prof_report", "wn_prof_sequence",
     "wn_decode_supported", "wn_decode_pack_floats", "wn_decode_state_floats", "wn_decode_pack", "wn_decode_aux",
     "wn_decode_steps", "wn_decode_stream_bytes",
     "wn_decode_layered_state_floats", "wn_decode_layered_prepare", "wn_decode_layered_steps", "wn_mol_loss",
@@ -138,6 +138,7 @@ class WnLibrary(object):
         L.wn_op_gemm.argtypes = [ctypes.POINTER(WnGemmArgs), vp]
         L.wn_prof_enable.argtypes = [i]
         L.wn_prof_report.argtypes = [ctypes.c_char_p, sz]
+        L.wn_prof_sequence.argtypes = [ctypes.c_char_p, sz]
         L.wn_decode_supported.argtypes = [cfgp]
         L.wn_decode_pack_floats.argtypes = [cfgp]
         L.wn_decode_pack_floats.restype = i64

@@ -41,14 +41,17 @@ static void api_enter() {
 
 #ifdef WN_EMU
 static int rt_check(const char*) { return 0; }
-static void rt_event_record(void*, wn_stream_t) {}
+static void rt_event_record(void*, wn_stream_t) { wn_prof_mark("bucket_event"); }
 #else
 static int rt_check(const char* where) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(100, "HIP error after %s: %s", where, hipGetErrorString(e));
     return 0;
 }
-static void rt_event_record(void* ev, wn_stream_t st) { (void)hipEventRecord((hipEvent_t)ev, st); }
+static void rt_event_record(void* ev, wn_stream_t st) {
+    wn_prof_mark("bucket_event");
+    (void)hipEventRecord((hipEvent_t)ev, st);
+}
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -98,23 +101,9 @@ static SideRt* side_get(wn_stream_t caller) {
     if (!g_rt[dev]) {
         SideRt* r = new SideRt();
         // lowest priority: the side stream carries filler work, the caller's stream carries the dependent chain
-        // (WN_SIDE_PRIORITY=normal, read once, for A/B measurements)
         int least = 0, greatest = 0;
-        const char* pr = getenv("WN_SIDE_PRIORITY");
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || (pr && !strcmp(pr, "normal"))) least = 0;
-        // WN_SIDE_CUS=<n> (A/B measurements): the side stream may only use n CUs (CU-mask bits interleave the XCDs, so
-        // the first n bits are n/8 CUs of every XCD).  Such a stream is a BLOCKING stream (hipExtStreamCreateWithCUMask
-        // has no flags): it only overlaps with a caller stream other than the NULL stream.
-        const char* cus = getenv("WN_SIDE_CUS");
-        const int ncu = cus ? atoi(cus) : 0;
-        hipError_t ce;
-        if (ncu > 0 && ncu < 1024) {
-            uint32_t mask[32] = {0};
-            for (int i = 0; i < ncu; ++i) mask[i >> 5] |= 1u << (i & 31);
-            ce = hipExtStreamCreateWithCUMask(&r->st, 32, mask);
-        } else {
-            ce = hipStreamCreateWithPriority(&r->st, hipStreamNonBlocking, least);
-        }
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+        const hipError_t ce = hipStreamCreateWithPriority(&r->st, hipStreamNonBlocking, least);
         if (ce != hipSuccess) {
             (void)hipGetLastError();
             delete r;
@@ -582,39 +571,6 @@ static int make_ctx(Ctx* c, const WnConfig* cfg, int B, int T, void* ws, size_t 
     return 0;
 }
 
-// tuning knob (A/B on hardware): WN_SAVE_TANH=1 -> the fused forward also stores the tanh half of the gate (64 words per
-// timestep and layer more) and the fused backward reads it instead of rebuilding it as z / sigmoid
-static bool save_tanh() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("WN_SAVE_TANH");
-        v = (e && atoi(e) != 0) ? 1 : 0;
-    }
-    return v != 0;
-}
-
-// tuning knob (A/B on hardware): WN_GATE_EPILOGUE=0 -> the any-size path runs its gate / gate' as separate elementwise
-// launches again instead of as epilogues of the split contractions (n_resch % 128 == 0)
-static bool gate_epilogues() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("WN_GATE_EPILOGUE");
-        v = (e && atoi(e) == 0) ? 0 : 1;
-    }
-    return v != 0;
-}
-
-// tuning knob (A/B on hardware): WN_WEIGHT_IMAGES=0 -> every workgroup of a fused split kernel builds its LDS weight image
-// itself again instead of copying the image packed once per step
-static bool use_images() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("WN_WEIGHT_IMAGES");
-        v = (e && atoi(e) == 0) ? 0 : 1;
-    }
-    return v != 0;
-}
-
 // ------------------------------------------------------------------------------------------
 // weight packing (once per forward; weights change every optimizer step)
 // ------------------------------------------------------------------------------------------
@@ -630,31 +586,12 @@ struct GateEpi {   // optional gate epilogue of a split contraction (wn_gemm6.h)
     const float *bw_S = nullptr, *bw_Gt = nullptr;
     float* bw_dP = nullptr;
 };
-// can this launch run on the split kernel (the only one with the gate epilogues)?
-// WN_CHAIN_HEAD=0: the top of the chain takes dSkip itself (k_conv64s, a K = n_skipch contraction) instead of its row block of
-// the all-layer pre-contraction (A/B)
-static bool chain_head_on() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("WN_CHAIN_HEAD");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v != 0;
-}
-static int dzs_layers(const Dims& d) { return chain_head_on() ? d.L : d.L - 1; }   // layers bwd_dz_skip_all contracts
+static int dzs_layers(const Dims& d) { return d.L; }   // layers bwd_dz_skip_all contracts (all: the head of the chain takes its rows)
 
 // The weight sets of the split contractions every training step launches: (A, lda, M, K) and where their split form lives.
 // They are split ONCE per step by one launch at the end of pack_weights (six dependent little launches in front of the
-// contractions otherwise); wn_backward finds them in the workspace wn_forward left.  WN_PREPACK=0: split before each use.
+// contractions otherwise); wn_backward finds them in the workspace wn_forward left.
 struct PreJob { const float* A; long lda; int M, K; long off; };
-static bool prepack_on() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("WN_PREPACK");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v != 0;
-}
 static int pre_jobs(const Ctx& c, const float* params, PreJob (&j)[6]) {
     const Dims& d = c.d;
     const Lay& y = c.y;
@@ -667,7 +604,7 @@ static int pre_jobs(const Ctx& c, const float* params, PreJob (&j)[6]) {
                            {params ? params + y.post1_w : nullptr, d.S, d.S, d.S, w.apk_pre[4]},
                            {ws + w.wskipT_f, (long)d.L * d.R, dzs_layers(d) * d.R, d.S, w.apk_pre[5]}};
     int n = 0;
-    if (!c.have_pre || !c.split_bf16 || !prepack_on()) return 0;
+    if (!c.have_pre || !c.split_bf16) return 0;
     for (int i = 0; i < 6; ++i)
         if (all[i].A && all[i].off >= 0) j[n++] = all[i];
     return n;
@@ -720,7 +657,7 @@ static int fw_gemm(const Ctx& c, const WnGemmArgs& g, const GateEpi* ge = nullpt
     a.bias = g.bias; a.E = g.E; a.lde = g.lde; a.e_zstride = g.e_zstride; a.relu = g.relu;
     a.nbatch = g.nbatch; a.tag = g.tag;
     if (ce) {
-        a.ce_target = reinterpret_cast<const long long*>(ce->target); a.ce_tstride = g.N; a.ce_t_start = ce->t_start;
+        a.ce_target = reinterpret_cast<const long long*>(ce->target); a.ce_tstride = g.ldc; a.ce_t_start = ce->t_start;
         a.ce_gs = ce->gs; a.ce_partial = ce->partial;
     }
     return wn_gemm6_launch(&a, c.st);
@@ -781,7 +718,7 @@ static int pack_weights(const Ctx& c, const float* params) {
     cp.n1 = d.S; cp.n2 = d.Qo; cp.s1 = 1; cp.s2 = d.S; cp.d1 = d.Qo; cp.d2 = 1;
     WN_TRY(wn_copy4_batch_add(&jobs, ws + w.w2_f, params + y.post2_w, &cp));
     WN_TRY(wn_copy4_batch(&jobs, c.st));
-    if (c.fused && c.split_bf16 && w.img_floats > 0 && use_images())   // LDS images of the split kernels: one launch for all layers
+    if (c.fused && c.split_bf16 && w.img_floats > 0)   // LDS images of the split kernels: one launch for all layers
         WN_TRY(wn_fused_pack_images(ws + w.wd_f, ws + w.wres_f, ws + w.wd_b, params, lb0 + y.o_res_w, lstep, ws + w.img_fwd,
                                     ws + w.img_taps, ws + w.img_res, d.K, d.L, c.st));
     // cvec / rowsum_aux / bskip / one
@@ -820,19 +757,19 @@ static int pack_weights(const Ctx& c, const float* params) {
 // skip-sum of layers [lo, hi) into O1: O1 = (lo == 0 ? b_skip : O1) + sum_l Wskip_l z_l, relu when `last`
 // (wavenet.py:533,238,519).  One launch over all layers is the serial form; wn_forward's overlap mode issues it in
 // chunks on the side stream while the residual stack is still running.
-static int skip_sum(const Ctx& c, int lo, int hi, bool last) {
+static int skip_sum(const Ctx& c, int lo, int hi, bool last, int t0 = 0) {   // t0: columns [t0, T) only (loss window)
     const Dims& d = c.d;
     const Ws& w = c.w;
     float* ws = c.ws;
     const long BRT = (long)c.B * d.R * c.T;
     WnGemmArgs g = wn_gemm_default();
-    g.M = d.S; g.N = c.T; g.K = (hi - lo) * d.R;
+    g.M = d.S; g.N = c.T - t0; g.K = (hi - lo) * d.R;
     g.A = ws + w.wskip_f + (long)lo * d.R * d.S; g.lda = d.S;
-    g.B = ws + w.Z + (long)lo * BRT; g.ldb = c.T; g.b_zstride = (long)d.R * c.T; g.b_clen = c.T;
+    g.B = ws + w.Z + (long)lo * BRT + t0; g.ldb = c.T; g.b_zstride = (long)d.R * c.T; g.b_clen = c.T - t0;
     g.b_seg_len = d.R; g.b_seg_stride = BRT;
-    g.C = ws + w.O1; g.ldc = c.T; g.c_zstride = (long)d.S * c.T;
+    g.C = ws + w.O1 + t0; g.ldc = c.T; g.c_zstride = (long)d.S * c.T;
     if (lo == 0) g.bias = ws + w.bskip;
-    else { g.D = ws + w.O1; g.ldd = c.T; g.d_zstride = (long)d.S * c.T; }  // in place: an element is read by the lane that writes it
+    else { g.D = ws + w.O1 + t0; g.ldd = c.T; g.d_zstride = (long)d.S * c.T; }  // in place: an element is read by the lane that writes it
     g.relu = last ? 1 : 0; g.nbatch = c.B; g.tag = "fwd_skip_sum";
     return fw_gemm(c, g);
 }
@@ -876,10 +813,10 @@ static int forward_stack(const Ctx& c, const float* params, const int64_t* x, co
         if (c.fused) {
             WN_TRY(wn_fused_resblock_fwd(ws + w.wd_f + (long)l * d.K * d.R * 2 * d.R, ws + w.wres_f + (long)l * d.R * d.R,
                                          ws + w.cvec + (long)l * 2 * d.R, params + lb + y.o_res_b, Xl, Gl, g_bstride, upw, Xn,
-                                         Sl, /*tanh half: not saved, backward rebuilds it as z / s*/ save_tanh() ? Gtl : nullptr, Zl, B, T,
+                                         Sl, /*tanh half: not saved, backward rebuilds it as z / s*/ nullptr, Zl, B, T,
                                          d.K, dil, Ue, F,
                                          c.split_bf16 ? 1 : 0,
-                                         (w.img_floats > 0 && use_images()) ? ws + w.img_fwd + (long)l * (w.img_floats / d.L) : nullptr, c.st));
+                                         (w.img_floats > 0) ? ws + w.img_fwd + (long)l * (w.img_floats / d.L) : nullptr, c.st));
             if (side && (l + 1) % chunk == 0 && l + 1 < d.L) {
                 WN_TRY(side_link(side, c.st, cs->st));  // z of layers [*skip_done, l] is enqueued
                 WN_TRY(skip_sum(*cs, *skip_done, l + 1, false));
@@ -894,7 +831,7 @@ static int forward_stack(const Ctx& c, const float* params, const int64_t* x, co
             g.b_seg_len = d.R; g.b_seg_stride = 0; g.b_shift0 = (d.K - 1) * dil; g.b_shift_step = -dil;
             g.C = ws + w.P; g.ldc = T; g.c_zstride = (long)2 * d.R * T;
             g.nbatch = B; g.tag = "fwd_dilated_layered";
-            if (d.R % 128 == 0 && fw_gemm_split_ok(c, g) && gate_epilogues()) {
+            if (d.R % 128 == 0 && fw_gemm_split_ok(c, g)) {
                 // wide models: the gate is the epilogue of the contraction (sigmoid / tanh rows paired by the weight
                 // packing), the 2R pre-activations never go to memory                  (wavenet.py:527-532)
                 GateEpi ge;
@@ -943,31 +880,41 @@ static int forward_impl(const WnConfig* cfg, int B, int T, const float* params, 
     const Lay& y = c.y;
     const Ws& w = c.w;
     float* ws = c.ws;
+    // Loss window (training step only: `ce_in` given, the logits themselves are not an output).  The loss of train.py:534-536
+    // covers [:, receptive_field:], and everything between the skip sum and the loss is pointwise in time
+    // (wavenet.py:518-523,533): the skip-sum / post-net contractions of the step run over the columns [t0, T) only, t0 = the
+    // first loss position rounded down to a whole 128-column tile -- the same window wn_backward_window takes, so nothing in
+    // front of it is ever read.  The residual stack itself needs every position.  dlogits[.., t < t0] is zero-filled.
+    const int t0 = ce_in ? (ce_in->t_start / 128) * 128 : 0;
+    const int Tw = T - t0;
     WN_TRY(forward_stack(c, params, x, h, side.rt, &cs, (d.L + 2) / 3, &skip_done));
     WN_TRY(side_link(side.rt, cs.st, c.st));  // join: O1 holds the sum of layers [0, skip_done)
     // skip-sum over (the remaining) layers as ONE contraction with K = L*R (wavenet.py:533,238), relu fused (:519)
-    WN_TRY(skip_sum(c, skip_done, d.L, true));
+    WN_TRY(skip_sum(c, skip_done, d.L, true, t0));
     {   // conv_post_1 + relu  (wavenet.py:520-521)
         WnGemmArgs g = wn_gemm_default();
-        g.M = d.S; g.N = T; g.K = d.S;
+        g.M = d.S; g.N = Tw; g.K = d.S;
         g.A = ws + w.w1_f; g.lda = d.S;
-        g.B = ws + w.O1; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = T;
-        g.C = ws + w.O2; g.ldc = T; g.c_zstride = (long)d.S * T;
+        g.B = ws + w.O1 + t0; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = Tw;
+        g.C = ws + w.O2 + t0; g.ldc = T; g.c_zstride = (long)d.S * T;
         g.bias = params + y.post1_b; g.relu = 1; g.nbatch = B; g.tag = "fwd_post1";
         WN_TRY(fw_gemm(c, g));
     }
     {   // conv_post_2  (wavenet.py:522)
         WnGemmArgs g = wn_gemm_default();
-        g.M = d.Qo; g.N = T; g.K = d.S;
+        g.M = d.Qo; g.N = Tw; g.K = d.S;
         g.A = ws + w.w2_f; g.lda = d.Qo;
-        g.B = ws + w.O2; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = T;
-        g.C = logits; g.ldc = T; g.c_zstride = (long)d.Qo * T;
+        g.B = ws + w.O2 + t0; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = Tw;
+        g.C = logits ? logits + t0 : nullptr; g.ldc = T; g.c_zstride = (long)d.Qo * T;
         g.bias = params + y.post2_b; g.nbatch = B; g.tag = "fwd_post2";
         if (ce_in) {
             CeEpi ce = *ce_in;
+            ce.target = ce_in->target + t0;     // column j of the window is position t0 + j (row stride T)
+            ce.t_start = ce_in->t_start - t0;
             ce.partial = ws + w.loss_partial;
             g.tag = "fwd_post2_ce";
             WN_TRY(fw_gemm(c, g, nullptr, &ce));   // g.C = the caller's dlogits (or NULL)
+            if (logits && t0 > 0) WN_TRY(wn_fill_cols(logits, (long)B * d.Qo, T, t0, c.st));
         } else {
             WN_TRY(fw_gemm(c, g));
         }
@@ -983,15 +930,6 @@ extern "C" int wn_forward(const WnConfig* cfg, int B, int T, const float* params
 
 // 1: wn_forward_loss runs the loss as the epilogue of conv_post_2 for this model / flags (softmax head with at most 256
 // classes on the split contractions); 0: it needs the logits scratch buffer and runs wn_forward + wn_softmax_ce_loss.
-// WN_CE_EPILOGUE=0 in the environment forces 0 (A/B measurements).
-static bool ce_epilogue_on() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("WN_CE_EPILOGUE");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v != 0;
-}
 extern "C" int wn_forward_loss_fused(const WnConfig* cfg, int B, int T, int flags) {
     api_enter();
     Dims d;
@@ -999,7 +937,7 @@ extern "C" int wn_forward_loss_fused(const WnConfig* cfg, int B, int T, int flag
     if (check_cfg(cfg, &d) || B < 1 || T < 1 || make_ws(d, B, T, &w)) return 0;
     const bool split = !(flags & WN_FLAG_EXACT_MFMA);
     // the conditions under which fw_gemm takes the split contraction for conv_post_2, plus: every class in one 256-row block
-    return (ce_epilogue_on() && split && d.Qo == d.Q && d.Qo >= 128 && d.Qo <= WN_G6_BM &&
+    return (split && d.Qo == d.Q && d.Qo >= 128 && d.Qo <= WN_G6_BM &&
             wn_gemm6_apk_elems(d.Qo, d.S) <= 2 * w.apk_floats && (long)d.Qo * T * 4 < 0x7ffffff0L) ? 1 : 0;
 }
 
@@ -1020,7 +958,8 @@ extern "C" int wn_forward_loss(const WnConfig* cfg, int B, int T, const float* p
     WN_TRY(forward_impl(cfg, B, T, params, x, h, dlogits, &ce, wsp, ws_bytes, flags, stream, "wn_forward_loss"));
     Ctx c;
     WN_TRY(make_ctx(&c, cfg, B, T, wsp, ws_bytes, flags, stream));
-    const int np = ((T + WN_G6_BN - 1) / WN_G6_BN) * B;
+    const int t0w = (t_start / 128) * 128;   // the column window forward_impl ran the loss epilogue over
+    const int np = ((T - t0w + WN_G6_BN - 1) / WN_G6_BN) * B;
     WN_TRY(wn_sum_partials(c.ws + c.w.loss_partial, np, loss_scale / ((float)B * (float)(T - t_start)), loss, c.st));
     return rt_check("wn_forward_loss");
 }
@@ -1123,16 +1062,6 @@ static DwOut dw_out_plain(float* out, long ld, float* rowsum_out) {
     return o;
 }
 
-// WN_LOSS_WINDOW=0: wn_backward_window ignores t_first (A/B measurements)
-static bool loss_window_on() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("WN_LOSS_WINDOW");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v != 0;
-}
-
 extern "C" int wn_backward(const WnConfig* cfg, int B, int T, const float* params, const int64_t* x, const float* h,
                            const float* dlogits, float* grads, void* wsp, size_t ws_bytes, void* const* events, int n_events,
                            int lpb, int flags, void* stream) {
@@ -1154,7 +1083,7 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
     // contractions of this part run over [t0, T) only (t0 = t_first rounded down to a whole 128-column tile, so that every
     // row keeps its alignment); dSkip is zero-filled in front of t0 and the chain kernel takes dZs as zero there: the chain
     // itself needs every position (dX_l[t] depends on dP_l[t + dilation]).  13 % less matrix work in these launches at the benchmark's geometry.
-    const int t0 = loss_window_on() ? (t_first / 128) * 128 : 0;
+    const int t0 = (t_first / 128) * 128;
     const int Tw = T - t0;
     // c = the data chain on the caller's stream; cs = the weight gradients, on the side stream unless serial
     SideLock side((flags & WN_FLAG_BWD_OVERLAP) && !wn_prof_is_on(), c.st);
@@ -1369,37 +1298,28 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
         const long lb = layer_base(y, d, l);
         const float* Sl = ws + w.Sg + (long)l * BRT;
         const float* Gtl = ws + w.Gt + (long)l * BRT;   // any-size path only: the fused forward saves s and z = s * tanh
-        const float* Zl = save_tanh() ? Gtl : ws + w.Z + (long)l * BRT;   // second gate operand of the fused kernels
-        const int gz = save_tanh() ? 0 : 1;
+        const float* Zl = ws + w.Z + (long)l * BRT;   // second gate operand of the fused kernels: z = s * tanh (g = z / s)
+        const int gz = 1;
         float* dP = ws + w.P + (long)l * P_L;
         const float* dXn = (l + 1 < d.L) ? ws + w.dXall + (long)(l + 1) * BRT : nullptr;  // null: dead (last layer)
         float* dXl = ws + w.dXall + (long)l * BRT;
         if (chain) {
-            if (l == d.L - 1 && chain_head_on()) {   // head of the chain: gate' of the last layer on its rows of dZs (no dX input)
+            if (l == d.L - 1) {   // head of the chain: gate' of the last layer on its rows of dZs (no dX input)
                 WN_TRY(wn_fused_bwd_chain_head(ws + w.dZs + (long)l * d.R * T, zs_bstride, Sl, Zl, gz, dP,
                                                ws + w.G + (long)l * 2 * d.R * F, g_bstride, upw, Ue, F,
                                                aux_fused ? ws + w.dGp + (long)l * B * 2 * d.R * (T / 16) : nullptr,
                                                aux_fused ? ws + w.qp + (long)l * B * T : nullptr, B, T, t0, c.st));
-            } else if (l == d.L - 1) {  // (WN_CHAIN_HEAD=0) straight from dSkip: a K = n_skipch contraction in k_conv64s
-                if (aux_fused)
-                    WN_TRY(wn_fused_bwd_gate_aux(params + y.skip0 + (long)l * y.ls_skip, params + lb + y.o_res_w, ws + w.dSk, nullptr,
-                                                 Sl, Zl, gz, dP, ws + w.G + (long)l * 2 * d.R * F, g_bstride, upw, Ue, F,
-                                                 ws + w.dGp + (long)l * B * 2 * d.R * (T / 16), ws + w.qp + (long)l * B * T, B, T,
-                                                 d.S, c.st));
-                else
-                    WN_TRY(wn_fused_bwd_gate(params + y.skip0 + (long)l * y.ls_skip, params + lb + y.o_res_w, ws + w.dSk, nullptr,
-                                             Sl, Zl, gz, dP, B, T, d.S, 1, c.st));
             }
             if (l > 0) {  // dX_l from dP_l, and gate' of layer l-1 from it
                 const long lbp = layer_base(y, d, l - 1);
                 WN_TRY(wn_fused_bwd_chain(ws + w.wd_b + (long)l * d.K * 2 * d.R * d.R, dP, dXn, dXl, params + lbp + y.o_res_w,
                                           ws + w.dZs + (long)(l - 1) * d.R * T, zs_bstride, ws + w.Sg + (long)(l - 1) * BRT,
-                                          (save_tanh() ? ws + w.Gt : ws + w.Z) + (long)(l - 1) * BRT, gz, ws + w.P + (long)(l - 1) * P_L,
+                                          ws + w.Z + (long)(l - 1) * BRT, gz, ws + w.P + (long)(l - 1) * P_L,
                                           ws + w.G + (long)(l - 1) * 2 * d.R * F, g_bstride, upw, Ue, F,
                                           aux_fused ? ws + w.dGp + (long)(l - 1) * B * 2 * d.R * (T / 16) : nullptr,
                                           aux_fused ? ws + w.qp + (long)(l - 1) * B * T : nullptr, B, T, d.K, dil,
-                                          (w.img_floats > 0 && use_images()) ? ws + w.img_taps + (long)l * (wn_fused_image_floats(d.K, d.L, 1) / d.L) : nullptr,
-                                          (w.img_floats > 0 && use_images()) ? ws + w.img_res + (long)(l - 1) * (wn_fused_image_floats(d.K, d.L, 2) / d.L) : nullptr,
+                                          (w.img_floats > 0) ? ws + w.img_taps + (long)l * (wn_fused_image_floats(d.K, d.L, 1) / d.L) : nullptr,
+                                          (w.img_floats > 0) ? ws + w.img_res + (long)(l - 1) * (wn_fused_image_floats(d.K, d.L, 2) / d.L) : nullptr,
                                           t0, ws + w.X + (long)l * BRT, ws + w.Z + (long)l * BRT,
                                           chain_dw ? ws + w.cdw_p + l * cdw_pL : nullptr, ws + w.cdw_r + l * cdw_rL,
                                           ws + w.cdw_s + l * cdw_sL, ws + w.cdw_sr + l * cdw_srL, c.st));
@@ -1432,7 +1352,7 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
             gr.B = dXn; gr.ldb = T; gr.b_zstride = (long)d.R * T; gr.b_clen = T;
             gr.C = ws + w.dZ; gr.ldc = T; gr.c_zstride = (long)d.R * T;
             gr.accumulate = 1; gr.nbatch = B; gr.tag = "bwd_dz_res_layered";
-            const bool epi = d.R % 128 == 0 && gate_epilogues() && fw_gemm_split_ok(c, gs) && (!dXn || fw_gemm_split_ok(c, gr));
+            const bool epi = d.R % 128 == 0 && fw_gemm_split_ok(c, gs) && (!dXn || fw_gemm_split_ok(c, gr));
             GateEpi ge;
             ge.bw_S = Sl; ge.bw_Gt = Gtl; ge.bw_dP = dP;
             if (epi) {

@@ -39,12 +39,6 @@ extern "C" void wn_debug_set_buffer(void* p) { g_dbg = (long long*)p; }
 #define WN_STAMP(i)
 #endif
 
-// tuning knob (A/B on hardware): WN_STAGGER=<n> delays the second wave of every SIMD by n x 8128 cycles
-static int stagger_setting() {
-    const char* e = getenv("WN_STAGGER");
-    return e ? atoi(e) : 0;  // measured on MI355X (profiles/r01): 0 -> 19.8 ms, 1 -> 20.0, 3 -> 20.1, 5 -> 20.5 ms per step
-}
-
 // tuning knob (A/B on hardware): WN_CHAIN_BLOCKS=<n> caps the persistent grid of the fused kernels (default 256 = one
 // workgroup per CU); measures how many CUs the HBM-bound chain kernels need to keep their rate
 static long chain_blocks() {
@@ -91,18 +85,11 @@ static long chain_blocks() {
 // Persistent grid of the fused kernels: the smallest multiple of 8 workgroups (XCD-aware walk) that needs no more
 // rounds of tiles than one workgroup per CU would.  Config 2 has 5 760 tiles: 256 x 8 waves walk them in 2.81 -> 3
 // rounds, 240 x 8 in exactly 3 -- same time (12.95 vs 13.05 ms/step measured, profiles/r01/cosched_probe.txt), and 16
-// CUs stay free for whatever runs beside the chain (the RCCL kernels of the gradient all-reduce).  WN_CHAIN_BALANCE=0
-// restores one workgroup per CU.
+// CUs stay free for whatever runs beside the chain (the RCCL kernels of the gradient all-reduce).
 static long balanced_blocks(long ntiles, long fw = WN_FW) {
     const long cap = chain_blocks();
     long nblk = (ntiles + fw - 1) / fw;
     if (nblk <= cap) return nblk;
-    static int balance = -1;
-    if (balance < 0) {
-        const char* e = getenv("WN_CHAIN_BALANCE");
-        balance = (e && atoi(e) == 0) ? 0 : 1;
-    }
-    if (!balance) return cap;
     const long rounds = (ntiles + cap * fw - 1) / (cap * fw);
     long nb = (ntiles + rounds * fw - 1) / (rounds * fw);
     nb = (nb + 7) / 8 * 8;
@@ -184,8 +171,6 @@ struct FwdArgs {
     float* Gt;
     float* Z;
     int B, T, dil, U, F;
-    int stagger;  // waves 4..7 (the second wave of each SIMD) start `stagger` x 8K cycles late
-    int chain_s, chain_c, chain_sh;  // split kernel: tile chains (stride in tiles = 1 << chain_sh, length); 1, 1 = plain tile walk
 #ifdef WN_TIMING
     long long* dbg;
 #endif
@@ -218,8 +203,6 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd(FwdArgs a) {
     // their MFMA phases and their gate/store phases in lock step and leave the matrix pipe idle
     // during the latter; half a tile of head start makes one wave's VALU/VMEM phase coincide with
     // the other's MFMA phase.
-    if (WN_UNIFORM((int)(threadIdx.x / (WN_FT / 2))) != 0)
-        for (int i = 0; i < a.stagger; ++i) WN_SLEEP(127);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, hi = lane >> 5;
@@ -605,7 +588,7 @@ int wn_fused_pack_images(const float* wd_f, const float* wres_f, const float* wd
     return 0;
 }
 
-template <int K, int CHAIN>
+template <int K>
 __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_s(FwdArgs a) {
     WN_DYN_SMEM(smem_raw);
     constexpr int WD_BLK = 3 * 128 * 32, WR_BLK = 3 * 64 * 32;  // bytes of one 16-k block
@@ -637,8 +620,6 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_s(FwdArgs a) {
     // their MFMA phases and their gate/store phases in lock step and leave the matrix pipe idle
     // during the latter; half a tile of head start makes one wave's VALU/VMEM phase coincide with
     // the other's MFMA phase.
-    if (WN_UNIFORM((int)(threadIdx.x / (WN_FT / 2))) != 0)
-        for (int i = 0; i < a.stagger; ++i) WN_SLEEP(127);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, hi = lane >> 5;
@@ -648,33 +629,8 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_s(FwdArgs a) {
     const int tiles_per_b = (T + 31) >> 5;
     const int ntiles = a.B * tiles_per_b;
     const unsigned slab = (unsigned)(64 * T4);
-    // Tile chains.  A wave walks CHAINS of chain_c tiles that are chain_s = dilation / 32 tiles apart: the history tap of
-    // a chain's next tile (x[t - d]) is then exactly the current tap this wave has just loaded -- it stays in registers
-    // and is not read again.  Without this every position of a d >= 32 layer is fetched twice from HBM (the neighbour's
-    // read of the same lines is half a tile period away, longer than a line lives in the XCD's L2 under the kernel's
-    // own write stream: PMC 90 MB read per launch for 47 MB of x).  Only a chain's first tile takes its history from
-    // memory.  chain_s = chain_c = 1 (dilations < 32, K = 3, WN_FWD_CHAIN=0) is the plain tile walk.
-    const int cs = CHAIN ? a.chain_s : 1, cc = CHAIN ? a.chain_c : 1;   // CHAIN = 0: the plain walk, compiled without the chain code
-    const int cblk = cs * cc, nbk = tiles_per_b / cblk, nfull = nbk * cs;
-    const int cpb = nfull + (tiles_per_b - nbk * cblk);     // chains per sequence: full ones, then single tail tiles
-    (void)ntiles;
-    const TileWalk walk = tile_walk(a.B * cpb, threadIdx.x >> 6);
-    const int step = WN_UNIFORM(walk.step), chain_end = WN_UNIFORM(walk.end);
-    // chain id -> (sequence cb, chain cr within it); ids advance by `step`, tracked without divisions (scalar ALU only:
-    // chain_s is a power of two, the sequence index moves by repeated subtraction)
-    const int csh = a.chain_sh;   // log2(chain_s)
-    const int first_chain = WN_UNIFORM(walk.first);   // wave-uniform: the whole bookkeeping stays in scalar registers
-    int cb = first_chain / cpb, cr = first_chain - cb * cpb;
-    cb = WN_UNIFORM(cb);
-    cr = WN_UNIFORM(cr);
-    auto chain_first = [&](int b, int r, int& len) -> int {
-        if (r < nfull) {
-            len = cc;
-            return b * tiles_per_b + (r >> csh) * cblk + (r & (cs - 1));
-        }
-        len = 1;
-        return b * tiles_per_b + nbk * cblk + (r - nfull);
-    };
+    const TileWalk walk = tile_walk(ntiles, threadIdx.x >> 6);
+    const int step = WN_UNIFORM(walk.step), tile_end = WN_UNIFORM(walk.end);
     constexpr int KH = (K > 1) ? (K - 1) : 1;  // history taps (shift > 0)
 
     // Software pipeline (per wave, per 32-sample tile):
@@ -701,12 +657,11 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_s(FwdArgs a) {
         }
     };
 
-    int chain_v = first_chain, clen = 1, ck = 0;
-    int tile_v = (chain_v < chain_end) ? chain_first(cb, cr, clen) : 0;
+    int tile_v = WN_UNIFORM(walk.first);
     int tcount = 0;
     (void)tcount;
-    if (K > 1 && chain_v < chain_end) issue_hist(tile_v);
-    while (chain_v < chain_end) {
+    if (K > 1 && tile_v < tile_end) issue_hist(tile_v);
+    while (tile_v < tile_end) {
         WN_STAMP(0);
         const int tile = WN_UNIFORM(tile_v);
         const int b = tile / tiles_per_b;
@@ -821,24 +776,11 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_s(FwdArgs a) {
             asm volatile("" : "+v"(racc[0]), "+v"(racc[1]));
 #endif
         }
-        // next tile of this wave: the next one of its chain (history = this tile's xc, copied at the end of the tile) or
-        // the head of its next chain (history from memory: requested NOW, before the stores of the gate phase)
-        const bool chained = CHAIN && (ck + 1 < clen);
-        int next_chain = chain_v, next_len = clen, next_v = tile_v + cs;
-        if (!chained) {
-            next_chain = chain_v + step;
-            cr += step;
-            while (cr >= cpb) {
-                cr -= cpb;
-                ++cb;
-            }
-            next_v = (next_chain < chain_end) ? chain_first(cb, cr, next_len) : 0;
-            if (K > 1 && next_chain < chain_end) issue_hist(next_v);
-        } else if (CHAIN && K > 1) {   // the copy takes the place of the prefetch: same register live ranges in both cases
-            WN_UNROLL
-            for (int s = 0; s < 32; ++s) xh[KH - 1][s] = xc[s];
-            okh[KH - 1] = true;   // t - d of the next tile = t of this one: inside the sequence
-        }
+        // next tile of this wave: its history taps are requested NOW, before the stores of the gate phase.  (A variant that
+        // kept the history tap of a d >= 32 layer in registers across "tile chains" measured slower -- 60 B/lane of scratch and
+        // 16-tile runs instead of one contiguous span: profiles/r02/ab_probe_fwd_chain.txt -- and was removed in round 3.)
+        const int next_v = tile_v + step;
+        if (K > 1 && next_v < tile_end) issue_hist(next_v);
         // gate (reference wavenet.py:529-532): P = conv + w[j]*G[row][f] + c[row]; saved for backward
         const wn_rsrc_t Sr = wn_make_buf(a.S + (long)b * 64 * T, slab);
         const bool keep_g = a.Gt != nullptr;   // NULL: the tanh half is not saved (backward rebuilds it as z / s)
@@ -914,13 +856,6 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_s(FwdArgs a) {
         WN_PRIO(WN_PRIO_GATE);
         WN_STAMP(4);  // tile done
         ++tcount;
-        if (chained) {
-            ++ck;
-        } else {
-            chain_v = next_chain;
-            clen = next_len;
-            ck = 0;
-        }
         tile_v = next_v;
     }
 #ifdef WN_TIMING
@@ -938,310 +873,14 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_s(FwdArgs a) {
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------
-// k_resblock_fwd_v2 -- the split K = 2 forward block with everything but the MFMAs in the MFMAs' shadow (opt-in: WN_FWD_V2=1).
-//
-// What tools/microbench/mfma_valu.hip measured: a wave's OWN independent VALU / memory instructions issue between its MFMAs
-// for free (up to ~6 per 32x32x16 MFMA), whereas VALU work of the OTHER wave of the SIMD slows a wave's MFMAs down 3x.  In
-// k_resblock_fwd_s the gate phase (4 transcendentals per element) is a phase of its own, so the two waves of a SIMD add their
-// MFMA and gate phases up instead of overlapping them (0.31 matrix utilisation).  Here the row tiles are contracted in two
-// passes -- first {0, 2} (sigmoid / tanh rows of channels 0..31), then {1, 3} -- so that the gate of the first 32 channels
-// runs between the MFMAs of the second pass, the gate of the other 32 between the res-1x1 MFMAs of the first 32 (whose
-// k-blocks need exactly the first half's z), and every operand split sits in the shadow of the previous group of MFMAs.  The
-// price is splitting the tile's operands twice.  Every accumulator sees the same MFMAs in the same order and the gate math
-// is the same code: the output is bit-identical to k_resblock_fwd_s<2, 0>.
-// ---------------------------------------------------------------------------------------------
-template <bool KEEP_G>
-__global__ __launch_bounds__(WN_LB) void k_resblock_fwd_v2(FwdArgs a) {
-    WN_DYN_SMEM(smem_raw);
-    constexpr int K = 2;
-    constexpr int WD_BLK = 3 * 128 * 32, WR_BLK = 3 * 64 * 32;  // bytes of one 16-k block
-    char* Wd = smem_raw;
-    char* Wr = Wd + K * 4 * WD_BLK;
-    float* cv = reinterpret_cast<float*>(Wr + 4 * WR_BLK);       // [128]
-    float* rb = cv + 128;                                        // [64]
-    if (a.wimg != nullptr) {
-        copy_image_to_lds(smem_raw, a.wimg, fwd_image_bytes(K));
-        WN_WAIT_VMCNT(0);
-    } else {
-        fill_fwd_image<K>(Wd, Wr, a.wd_f, a.wres_f, threadIdx.x, WN_FT);
-    }
-    if (threadIdx.x < 128) cv[threadIdx.x] = a.cvec[threadIdx.x];
-    if (threadIdx.x < 64) rb[threadIdx.x] = a.res_bias[threadIdx.x];
-#ifdef WN_TIMING
-    if (a.dbg && threadIdx.x == 0) a.dbg[512 + blockIdx.x * 4 + 0] = (long long)__builtin_amdgcn_s_memrealtime();
-#endif
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    (void)wave;
-    int tcount = 0;
-    (void)tcount;
-    const int li = lane & 31, hi = lane >> 5;
-    const int T = a.T;
-    const int T4 = T * 4;
-    const int F4 = a.F * 4;
-    const int tiles_per_b = (T + 31) >> 5;
-    const unsigned slab = (unsigned)(64 * T4);
-    const TileWalk walk = tile_walk(a.B * tiles_per_b, threadIdx.x >> 6);
-    const int step = WN_UNIFORM(walk.step), tile_end = WN_UNIFORM(walk.end);
-    const int fo = wn_frag_off(li, hi);
-    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};  // small terms first
-
-    float xh[32], xc[32];
-    // operand loads: lanes outside the sequence carry an out-of-range offset and read 0 (no select at use)
-    auto issue_hist = [&](int tl_v) {
-        const int tl = WN_UNIFORM(tl_v);
-        const int b = tl / tiles_per_b;
-        const int t = (tl - b * tiles_per_b) * 32 + li;
-        const wn_rsrc_t Xr = wn_make_buf(a.X + (long)b * 64 * T, slab);
-        const int ts = t - a.dil;
-        const int vt = (t < T && ts >= 0) ? (4 * hi * T + ts) * 4 : WN_VOFF_DEAD;
-        WN_UNROLL
-        for (int s = 0; s < 32; ++s) xh[s] = wn_buf_load(Xr, vt, kappa64(s, 0) * T4);
-    };
-    // product t6 of one 16-k block for a pair of row tiles: the unit between two slices of shadow work
-    auto mfma_pair = [&](f32x16& A0, f32x16& A1, const wn_f4 (&af)[2][3], const wn_f4 (&bf)[3], int t6) {
-        A0 = mfma_bf16(af[0][PA[t6]], bf[PB[t6]], A0);
-        A1 = mfma_bf16(af[1][PA[t6]], bf[PB[t6]], A1);
-    };
-
-    int tile_v = walk.first;
-    if (tile_v < tile_end) issue_hist(tile_v);
-    while (tile_v < tile_end) {
-        WN_STAMP(0);
-        const int tile = WN_UNIFORM(tile_v);
-        const int b = tile / tiles_per_b;
-        const int t = (tile - b * tiles_per_b) * 32 + li;
-        const bool inb = t < T;
-        const int tc = inb ? t : T - 1;
-        const int vcur = inb ? (4 * hi * T + t) * 4 : WN_VOFF_DEAD;
-        {
-            const wn_rsrc_t Xr = wn_make_buf(a.X + (long)b * 64 * T, slab);
-            WN_UNROLL
-            for (int s = 0; s < 32; ++s) xc[s] = wn_buf_load(Xr, vcur, kappa64(s, 0) * T4);
-        }
-        // aux / gate inputs of the first 32 channels (frame rate, L2 resident)
-        const int fr = tc / a.U;
-        const float upw_j = a.upw[tc - fr * a.U];
-        const wn_rsrc_t Gr = wn_make_buf(a.G + (long)b * a.g_bstride, (unsigned)(128 * F4));
-        const int vg = (4 * hi * a.F + fr) * 4;
-        float ga[16], gg[16];
-        WN_UNROLL
-        for (int r = 0; r < 16; ++r) {
-            ga[r] = wn_buf_load(Gr, vg, mfma32_row(r, 0) * F4);
-            gg[r] = wn_buf_load(Gr, vg, (mfma32_row(r, 0) + 64) * F4);
-        }
-        WN_SCHED_BARRIER();
-        f32x16 acc[4];
-        WN_UNROLL
-        for (int q = 0; q < 4; ++q) acc[q] = f32x16_zero();
-        const wn_rsrc_t Sr = wn_make_buf(a.S + (long)b * 64 * T, slab);
-        const wn_rsrc_t Gtr = wn_make_buf((KEEP_G ? a.Gt : a.S) + (long)b * 64 * T, slab);
-        const wn_rsrc_t Zr = wn_make_buf(a.Z + (long)b * 64 * T, slab);
-        const float* cvl = cv + 4 * hi;
-        f32x16 z[2];
-        // gate of element (q, r) (reference wavenet.py:529-532): P = conv + w[j]*G[row][f] + c[row]; saved for backward
-        auto gate_elem = [&](int q, int r) {
-            const int row0 = 32 * q + mfma32_row(r, 0);  // + 4*hi is in the per-lane offsets
-            const float pa = acc[q][r] + (upw_j * ga[r] + cvl[row0]);
-            const float pg = acc[q + 2][r] + (upw_j * gg[r] + cvl[row0 + 64]);
-            if (q == 0) {   // the register pair now takes the aux projection of channel 32 + row (second half)
-                ga[r] = wn_buf_load(Gr, vg, (32 + mfma32_row(r, 0)) * F4);
-                gg[r] = wn_buf_load(Gr, vg, (96 + mfma32_row(r, 0)) * F4);
-            }
-            const float sv = wn_sigmoid(pa);
-            const float gv = wn_tanh(pg);
-            const float zz = sv * gv;
-            z[q][r] = zz;
-            wn_buf_store(Sr, sv, vcur, row0 * T4);
-            if (KEEP_G) wn_buf_store(Gtr, gv, vcur, row0 * T4);
-            wn_buf_store(Zr, zz, vcur, row0 * T4);
-        };
-        // operand block g of the dilated contraction: g = 0..3 history tap (xh), 4..7 current tap (xc)
-        auto split_pair = [&](int g, int e, unsigned (&hq)[4], unsigned (&mq)[4], unsigned (&lq)[4]) {
-            const int i0 = 8 * (g & 3) + 2 * e;
-            const float x0 = (g < 4) ? xh[i0] : xc[i0], x1 = (g < 4) ? xh[i0 + 1] : xc[i0 + 1];
-            hq[e] = wn_pk_bf16(x0, x1);
-            const float r0 = x0 - wn_bits_f32(hq[e] << 16), r1 = x1 - wn_bits_f32(hq[e] & 0xffff0000u);
-            mq[e] = wn_pk_bf16(r0, r1);
-            lq[e] = wn_pk_bf16(r0 - wn_bits_f32(mq[e] << 16), r1 - wn_bits_f32(mq[e] & 0xffff0000u));
-        };
-        auto pack_bf = [&](const unsigned (&hq)[4], const unsigned (&mq)[4], const unsigned (&lq)[4], wn_f4 (&bf)[3]) {
-            bf[0].x = wn_bits_f32(hq[0]); bf[0].y = wn_bits_f32(hq[1]); bf[0].z = wn_bits_f32(hq[2]); bf[0].w = wn_bits_f32(hq[3]);
-            bf[1].x = wn_bits_f32(mq[0]); bf[1].y = wn_bits_f32(mq[1]); bf[1].z = wn_bits_f32(mq[2]); bf[1].w = wn_bits_f32(mq[3]);
-            bf[2].x = wn_bits_f32(lq[0]); bf[2].y = wn_bits_f32(lq[1]); bf[2].z = wn_bits_f32(lq[2]); bf[2].w = wn_bits_f32(lq[3]);
-        };
-        // ---- dilated taps.  Per tap: pass A (row tiles 0, 2) then pass B (row tiles 1, 3), so that the history operands die
-        // after the first tap (their registers take the NEXT tile's history tap) and the accumulators of the first 32 channels
-        // are complete before the last pass, which carries their gate in its shadow.  Block index g = 4 tap + kb. ----
-        wn_f4 bf[3];
-        {
-            unsigned hq[4], mq[4], lq[4];
-            WN_UNROLL
-            for (int e = 0; e < 4; ++e) split_pair(0, e, hq, mq, lq);
-            pack_bf(hq, mq, lq, bf);
-        }
-        const int next_v = tile_v + step;
-        WN_UNROLL
-        for (int tp = 0; tp < 4; ++tp) {   // (tap, pass) = (tp >> 1, tp & 1)
-            const int tap = tp >> 1, pass = tp & 1;
-            WN_UNROLL
-            for (int kb = 0; kb < 4; ++kb) {
-                const int g = 4 * tap + kb;
-                const char* Wl = Wd + g * WD_BLK + fo;
-                wn_f4 af[2][3];
-                WN_UNROLL
-                for (int p = 0; p < 3; ++p) {
-                    af[0][p] = *reinterpret_cast<const wn_f4*>(Wl + p * (128 * 32) + (pass + 0) * 1024);
-                    af[1][p] = *reinterpret_cast<const wn_f4*>(Wl + p * (128 * 32) + (pass + 2) * 1024);
-                }
-                // the block split in this group's shadow: the next one of this (tap, pass), else the first of the next
-                const int tpn = (kb == 3) ? tp + 1 : tp;
-                const int gn = 4 * ((tpn >> 1) & 1) + ((kb + 1) & 3);
-                const bool more = !(tp == 3 && kb == 3);
-                unsigned hq[4], mq[4], lq[4];
-                // six slots of two MFMAs; between them one slice each: the split of one operand pair of the next block
-                // (slots 0..3) and, in the last pass, one gate element of the first 32 channels (slots 2..5)
-                WN_UNROLL
-                for (int t6 = 0; t6 < 6; ++t6) {
-                    mfma_pair(acc[pass], acc[pass + 2], af, bf, t6);
-                    WN_SCHED_FENCE_ALU();
-                    if (more && t6 < 4) split_pair(gn, t6, hq, mq, lq);
-                    if (tp == 3 && t6 >= 2) gate_elem(0, 4 * kb + (t6 - 2));
-                    WN_SCHED_FENCE_ALU();
-                }
-                if (more) pack_bf(hq, mq, lq, bf);
-                WN_SCHED_FENCE_ALU();
-            }
-            if (tp == 1) {   // history operands consumed: their registers take the next tile's history tap
-                WN_SCHED_BARRIER();
-                WN_STAMP(1);
-                if (next_v < tile_end) issue_hist(next_v);
-                WN_SCHED_BARRIER();
-            }
-        }
-        WN_SCHED_BARRIER();
-        WN_STAMP(2);
-        // residual input + bias = the initial value of the res-1x1 accumulators (xc dies here)
-        f32x16 racc[2];
-        const bool has_res = a.Xnext != nullptr;
-        if (has_res) {
-            const float* rbl = rb + 4 * hi;
-            WN_UNROLL
-            for (int q = 0; q < 2; ++q) {
-                WN_UNROLL
-                for (int r = 0; r < 16; ++r) racc[q][r] = xc[16 * q + r] + rbl[32 * q + mfma32_row(r, 0)];
-            }
-#ifndef WN_EMU
-            asm volatile("" : "+v"(racc[0]), "+v"(racc[1]));
-#endif
-        }
-        // ---- res 1x1: k-blocks 0, 1 contract the first half's z (gate of the second half in their shadow), 2, 3 the second's ----
-        auto split_zpair = [&](int kb, int e, unsigned (&hq)[4], unsigned (&mq)[4], unsigned (&lq)[4]) {
-            const int i0 = 8 * kb + 2 * e;
-            const float x0 = z[i0 >> 4][i0 & 15], x1 = z[(i0 + 1) >> 4][(i0 + 1) & 15];
-            hq[e] = wn_pk_bf16(x0, x1);
-            const float r0 = x0 - wn_bits_f32(hq[e] << 16), r1 = x1 - wn_bits_f32(hq[e] & 0xffff0000u);
-            mq[e] = wn_pk_bf16(r0, r1);
-            lq[e] = wn_pk_bf16(r0 - wn_bits_f32(mq[e] << 16), r1 - wn_bits_f32(mq[e] & 0xffff0000u));
-        };
-        if (has_res) {
-            wn_f4 zb[3];
-            {
-                unsigned hq[4], mq[4], lq[4];
-                WN_UNROLL
-                for (int e = 0; e < 4; ++e) split_zpair(0, e, hq, mq, lq);
-                pack_bf(hq, mq, lq, zb);
-            }
-            WN_UNROLL
-            for (int kb = 0; kb < 4; ++kb) {
-                const char* Wl = Wr + kb * WR_BLK + fo;
-                wn_f4 af[2][3];
-                WN_UNROLL
-                for (int q = 0; q < 2; ++q) {
-                    WN_UNROLL
-                    for (int p = 0; p < 3; ++p) af[q][p] = *reinterpret_cast<const wn_f4*>(Wl + p * (64 * 32) + q * 1024);
-                }
-                unsigned hq[4], mq[4], lq[4];
-                WN_UNROLL
-                for (int t6 = 0; t6 < 6; ++t6) {
-                    mfma_pair(racc[0], racc[1], af, zb, t6);
-                    WN_SCHED_FENCE_ALU();
-                    if (kb < 2) {   // the 16 gate elements of the second half over the 12 slots of k-blocks 0, 1
-                        const int s12 = 6 * kb + t6;
-                        WN_UNROLL
-                        for (int r = (16 * s12) / 12; r < (16 * (s12 + 1)) / 12; ++r) gate_elem(1, r);
-                    }
-                    // the next k-block's operand pairs: block 1 is first-half z (slots 0..3); block 2 needs the second half
-                    // complete, i.e. the last slots of block 1 come too early: it is split in the first slots of ... itself is
-                    // too late, so blocks 2 and 3 are split in slots 2..5 of the block before (z[1][0..15] is complete after
-                    // slot 11 = block 1's slot 5: block 2's pairs wait for it below)
-                    if (kb != 1 && kb < 3 && t6 < 4) split_zpair(kb + 1, t6, hq, mq, lq);
-#ifndef WN_EMU
-                    // pin: the next MFMA pair takes its accumulators from here, i.e. after this slot's stores.  (The fences
-                    // bound the machine scheduler's regions, but instruction selection had already hoisted all 12 MFMAs of the
-                    // block -- their operands are ready at its start -- above the slices.)
-                    if (kb < 2) asm volatile("" : "+v"(racc[0]), "+v"(racc[1]));
-#endif
-                    WN_SCHED_FENCE_ALU();
-                }
-                if (kb == 1) {   // second-half z complete: block 2's operands (exposed: 44 VALU once per tile)
-                    WN_UNROLL
-                    for (int e = 0; e < 4; ++e) split_zpair(2, e, hq, mq, lq);
-                }
-                if (kb < 3) pack_bf(hq, mq, lq, zb);
-            }
-            WN_STAMP(3);
-            const wn_rsrc_t Xn = wn_make_buf(a.Xnext + (long)b * 64 * T, slab);
-            WN_UNROLL
-            for (int q = 0; q < 2; ++q) {
-                WN_UNROLL
-                for (int r = 0; r < 16; ++r) wn_buf_store(Xn, racc[q][r], vcur, (32 * q + mfma32_row(r, 0)) * T4);
-            }
-        } else {
-            WN_UNROLL
-            for (int r = 0; r < 16; ++r) gate_elem(1, r);
-        }
-        WN_STAMP(4);
-        ++tcount;
-        tile_v = next_v;
-    }
-#ifdef WN_TIMING
-    if (a.dbg && lane == 0) {
-        __builtin_amdgcn_s_waitcnt(0);
-        if (wave == 0) a.dbg[512 + blockIdx.x * 4 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
-        if (wave == 7) a.dbg[512 + blockIdx.x * 4 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
-        if (wave == 0) a.dbg[512 + blockIdx.x * 4 + 3] = tcount;
-    }
-#endif
-}
-
 template <int K>
 static int launch_fwd(const FwdArgs& a, int split, wn_stream_t st) {
     const long ntiles = (long)a.B * ((a.T + 31) / 32);
     const long nblk = balanced_blocks(ntiles);
     const size_t lds_s = (size_t)K * 4 * (3 * 128 * 32) + 4 * (3 * 64 * 32) + 192 * sizeof(float);
     if (split && lds_s <= 160 * 1024) {  // K = 3 does not fit split: stays on the f32 MFMA
-        static int v2 = -1;   // WN_FWD_V2=1: k_resblock_fwd_v2 (K = 2, plain tile walk)
-        if (v2 < 0) {
-            const char* e = getenv("WN_FWD_V2");
-            v2 = (e && atoi(e) != 0) ? 1 : 0;
-        }
-        if (K == 2 && a.chain_c > 1) {
-            if (set_lds(k_resblock_fwd_s<K, 1>, lds_s)) return 1;
-            WN_LAUNCH((k_resblock_fwd_s<K, 1>), dim3((unsigned)nblk), dim3(WN_FT), lds_s, st, a);
-        } else if (K == 2 && v2 && a.Gt != nullptr) {
-            if (set_lds(k_resblock_fwd_v2<true>, lds_s)) return 1;
-            WN_LAUNCH((k_resblock_fwd_v2<true>), dim3((unsigned)nblk), dim3(WN_FT), lds_s, st, a);
-        } else if (K == 2 && v2) {
-            if (set_lds(k_resblock_fwd_v2<false>, lds_s)) return 1;
-            WN_LAUNCH((k_resblock_fwd_v2<false>), dim3((unsigned)nblk), dim3(WN_FT), lds_s, st, a);
-        } else {
-            if (set_lds(k_resblock_fwd_s<K, 0>, lds_s)) return 1;
-            WN_LAUNCH((k_resblock_fwd_s<K, 0>), dim3((unsigned)nblk), dim3(WN_FT), lds_s, st, a);
-        }
+        if (set_lds(k_resblock_fwd_s<K>, lds_s)) return 1;
+        WN_LAUNCH((k_resblock_fwd_s<K>), dim3((unsigned)nblk), dim3(WN_FT), lds_s, st, a);
         return 0;
     }
     const size_t lds = ((size_t)K * 64 * 128 + 64 * 64 + 192) * sizeof(float);
@@ -1261,31 +900,6 @@ int wn_fused_resblock_fwd(const float* wd_f, const float* wres_f, const float* c
     a.X = X; a.G = G; a.g_bstride = g_bstride; a.upw = upw;
     a.Xnext = Xnext; a.S = S; a.Gt = Gt; a.Z = Z;
     a.B = B; a.T = T; a.dil = dilation; a.U = U; a.F = F;
-    a.stagger = stagger_setting();
-    a.chain_s = 1; a.chain_c = 1; a.chain_sh = 0;
-    {   // tile chains of the split K = 2 kernel (k_resblock_fwd_s): stride = dilation / 32 tiles, length = tiles per wave
-        static int on = -1;
-        if (on < 0) {
-            // Opt-in (WN_FWD_CHAIN=1).  Measured on MI355X, same box: 11.71 - 11.77 ms/step with the chains, 11.59 without
-            // (profiles/r02/ab_probe_fwd_chain.txt): the chained instance needs 256 VGPRs + 60 B/lane of scratch (the
-            // plain one 241 / 0) and its waves touch 16-tile runs 48 tiles apart instead of one contiguous span, which
-            // costs more than the ~40 MB of history-tap re-reads per launch it removes.
-            const char* e = getenv("WN_FWD_CHAIN");
-            on = (e && atoi(e) != 0) ? 1 : 0;
-        }
-        const long tiles_per_b = (T + 31) / 32, ntiles = (long)B * tiles_per_b;
-        if (on && split && K == 2 && dilation >= 32 && dilation % 32 == 0) {
-            const long waves = balanced_blocks(ntiles) * WN_FW;
-            long c = (ntiles + waves - 1) / waves;
-            if (c > 8) c = 8;
-            const long st_ = dilation / 32;
-            if (c >= 2 && c * st_ <= tiles_per_b && (st_ & (st_ - 1)) == 0) {
-                a.chain_s = (int)st_;
-                a.chain_c = (int)c;
-                while ((1 << a.chain_sh) < a.chain_s) ++a.chain_sh;
-            }
-        }
-    }
 #ifdef WN_TIMING
     a.dbg = g_dbg;
 #endif
@@ -1318,7 +932,6 @@ struct ConvArgs {
     int gz;
     const float* resid;  // MODE 1 (nullable)
     float* out;          // MODE 0: dP (B,128,T) ; MODE 1: dX (B,64,T)
-    int stagger;
     int interleave;      // k_conv64s: chunk q -> segment q % nseg (equal-size segments): the taps of one channel group back to back
     // MODE 2 (gate' + aux-gradient partials, see wn_fused.h)
     const float* G;      // (B, g_bstride) frame-rate aux projection of this layer, rows [0,128)
@@ -1339,8 +952,6 @@ __global__ __launch_bounds__(WN_LB) void k_conv64(ConvArgs a) {
     // their MFMA phases and their gate/store phases in lock step and leave the matrix pipe idle
     // during the latter; half a tile of head start makes one wave's VALU/VMEM phase coincide with
     // the other's MFMA phase.
-    if (WN_UNIFORM((int)(threadIdx.x / (WN_FT / 2))) != 0)
-        for (int i = 0; i < a.stagger; ++i) WN_SLEEP(127);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, hi = lane >> 5;
@@ -1546,8 +1157,6 @@ __global__ __launch_bounds__(WN_LB) void k_conv64s(ConvArgs a) {
     // their MFMA phases and their gate/store phases in lock step and leave the matrix pipe idle
     // during the latter; half a tile of head start makes one wave's VALU/VMEM phase coincide with
     // the other's MFMA phase.
-    if (WN_UNIFORM((int)(threadIdx.x / (WN_FT / 2))) != 0)
-        for (int i = 0; i < a.stagger; ++i) WN_SLEEP(127);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, hi = lane >> 5;
@@ -1785,7 +1394,6 @@ int wn_fused_bwd_gate(const float* wskip, const float* wres, const float* dSk, c
         a.nchunks += 2;
     }
     a.B = B; a.T = T; a.S = S; a.Gt = Gt; a.gz = gt_is_z; a.resid = nullptr; a.out = dP;
-    a.stagger = stagger_setting();
     a.interleave = 0;
     a.G = nullptr; a.g_bstride = 0; a.upw = nullptr; a.U = 0; a.F = 0; a.dGp = nullptr; a.qp = nullptr;
     return launch_conv64<0>(a, split, st);
@@ -1809,7 +1417,6 @@ int wn_fused_bwd_gate_aux(const float* wskip, const float* wres, const float* dS
         a.nchunks += 2;
     }
     a.B = B; a.T = T; a.S = S; a.Gt = Gt; a.gz = gt_is_z; a.resid = nullptr; a.out = dP;
-    a.stagger = stagger_setting();
     a.interleave = 0;
     a.G = G; a.g_bstride = g_bstride; a.upw = upw; a.U = U; a.F = F; a.dGp = dGp; a.qp = qp;
     return launch_conv64<2>(a, 1, st);
@@ -1832,17 +1439,12 @@ int wn_fused_bwd_dx(const float* wd_b, const float* dP, const float* dXn, float*
     a.wfloats = K * 128 * 64;
     a.nchunks = K * 4;
     a.B = B; a.T = T; a.S = nullptr; a.Gt = nullptr; a.gz = 0; a.resid = dXn; a.out = dX;
-    a.stagger = stagger_setting();
     // The taps of one 32-channel group are consumed back to back: position p is read as tap K-1 by the wave of its
     // own tile and as an earlier tap by the wave d samples away, and with [tap][channel] order those two reads of the
     // same lines were half a tile period apart -- longer than a line survives in the XCD's 4 MB L2 under the
     // kernel's write stream, so the second tap came over the fabric again (PMC: 253 MB per launch for 189 compulsory).
-    static int il = -1;
-    if (il < 0) {
-        const char* e = getenv("WN_DX_INTERLEAVE");
-        il = e ? atoi(e) : 1;  // measured: 56.3 -> 53.0 us per launch (profiles/r01/tap_probe.txt); WN_DX_INTERLEAVE=0 for A/B
-    }
-    a.interleave = (K > 1 && il) ? 1 : 0;
+    // measured: 56.3 -> 53.0 us per launch (profiles/r01/tap_probe.txt)
+    a.interleave = (K > 1) ? 1 : 0;
     a.G = nullptr; a.g_bstride = 0; a.upw = nullptr; a.U = 0; a.F = 0; a.dGp = nullptr; a.qp = nullptr;
     return launch_conv64<1>(a, split, st);
 }
@@ -1877,7 +1479,6 @@ struct ChainArgs {
     int gz;
     float* dPm;          // (B, 128, T) out: dP_{l-1}
     int B, T, K, dil;
-    int stagger;
     // AUX
     const float* G;      // (B, g_bstride) frame-rate aux projection of layer l-1, rows [0,128)
     long g_bstride;
@@ -1926,20 +1527,12 @@ static __device__ __forceinline__ void split8v(const float (&x)[8], bool ok, wn_
 #ifndef WN_DW_PRIO
 #define WN_DW_PRIO 1
 #endif
-// 8 consecutive samples of this lane's row (voff = its row / k-half offset inside a 32-row block, soff_row = the block's byte
-// offset, both >= 0), starting `lead` samples into the sequence for the wave's first lane half.  lead >= 0 (wave-uniform) is
-// the fast path: two 16-byte loads.  lead < 0: the tile overlaps the zero history in front of the sequence -- per-sample
-// validity, an invalid sample carries an out-of-range offset (reads 0 without touching memory; offsets never go negative).
-static __device__ __forceinline__ void dw_load8(const wn_rsrc_t& R, int voff, int soff_row, int lead, int hi, float (&x)[8]) {
-    if (lead >= 0) {
-        const unsigned so = (unsigned)(soff_row + lead * 4);
-        const float4 a = wn_buf_load4(R, voff, so), b = wn_buf_load4(R, voff + 16, so);
-        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
-    } else {
-        WN_UNROLL
-        for (int e = 0; e < 8; ++e)
-            x[e] = wn_buf_load(R, (lead + 8 * hi + e >= 0) ? voff + (lead + e) * 4 : WN_VOFF_DEAD, soff_row);
-    }
+// 8 consecutive samples of this lane's row: `v` = the lane's byte offset inside the 32-row block (row * T + first sample) or
+// WN_VOFF_DEAD (the range check then answers 0 without touching memory: no branches around loads), `soff_row` >= 0 the
+// block's wave-uniform byte offset.  Two 16-byte loads; only 4-byte alignment is needed (shifted taps).
+static __device__ __forceinline__ void dw_load8(const wn_rsrc_t& R, int v, int soff_row, float (&x)[8]) {
+    const float4 a = wn_buf_load4(R, v, (unsigned)soff_row), b = wn_buf_load4(R, v == WN_VOFF_DEAD ? v : v + 16, (unsigned)soff_row);
+    x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
 }
 static __device__ __forceinline__ f32x16 dw_mfma6(const wn_f4 (&af)[3], const wn_f4 (&bf)[3], f32x16 acc) {
     constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};  // small terms first
@@ -1948,8 +1541,14 @@ static __device__ __forceinline__ f32x16 dw_mfma6(const wn_f4 (&af)[3], const wn
     return acc;
 }
 
+// operands of one 16-sample k-block of one tile for this wave
 template <int K>
-static __device__ __forceinline__ void chain_dw_role(const ChainArgs& a, int w4, volatile int* round_flag) {
+struct DwOps {
+    float xa[2][8], xb[K][8], xr[2][8];
+};
+
+template <int K>
+static __device__ __forceinline__ void chain_dw_role(const ChainArgs& a, int w4, const char* round_flag) {
     const int lane = threadIdx.x & 63;
     const int li = lane & 31, hi = lane >> 5;
     const int T = a.T, T4 = T * 4;
@@ -1958,6 +1557,7 @@ static __device__ __forceinline__ void chain_dw_role(const ChainArgs& a, int w4,
     const TileWalk walk = tile_walk(ntiles, 0, 4);   // the tiles of chain wave 0; chain wave j takes the j-th next one
     const int oh = w4 >> 1, ch = w4 & 1;
     const bool has_res = a.dXn != nullptr;
+    const float* dXn = has_res ? a.dXn : a.Xl;   // dXn == NULL (top launch): the res part runs on dummy operands, unwritten
     f32x16 acc[2][K], accr = f32x16_zero();
     WN_UNROLL
     for (int rb = 0; rb < 2; ++rb) {
@@ -1967,59 +1567,107 @@ static __device__ __forceinline__ void chain_dw_role(const ChainArgs& a, int w4,
     float rs[2] = {0.0f, 0.0f}, rsr = 0.0f;
     const int vrow = (li * T + 8 * hi) * 4;   // this lane's row and k half inside a 32-row block
     WN_PRIO(WN_DW_PRIO);
+
+    // Requests of k-block `idx` (0..7: tile idx >> 1 of the round that starts at tile `base`, half idx & 1).  No branches: a
+    // k-block outside the walk or the sequence, and a lane whose 8 samples lie in the zero history in front of the sequence,
+    // carry the dead offset (their operands read as 0 and contribute nothing).  A shifted tap with 0 < shift < 8 cuts the 8
+    // samples of the hi = 0 lanes of a sequence's FIRST k-block: those lanes are dead here and added by dw_fixup below.
+    auto issue = [&](int base, int idx, DwOps<K>& o) {
+        const int tile = WN_UNIFORM(base + (idx >> 1));
+        const bool tv = tile < walk.end;
+        const int tl = tv ? tile : 0;
+        const int b = tl / tiles_per_b;
+        const int tk = (tl - b * tiles_per_b) * 32 + 16 * (idx & 1);
+        const bool kv = tv && tk < T;   // T % 16 == 0 (launcher): a k-block is inside the sequence or outside it
+        const wn_rsrc_t Pr = wn_make_buf(a.dP + (long)b * 128 * T, (unsigned)(128 * T4));
+        const wn_rsrc_t Xr = wn_make_buf(a.Xl + (long)b * 64 * T, (unsigned)(64 * T4));
+        const wn_rsrc_t Dr = wn_make_buf(dXn + (long)b * 64 * T, (unsigned)(64 * T4));
+        const wn_rsrc_t Zr = wn_make_buf(a.Zl + (long)b * 64 * T, (unsigned)(64 * T4));
+        const int v0 = kv ? vrow + tk * 4 : WN_VOFF_DEAD;
+        WN_UNROLL
+        for (int rb = 0; rb < 2; ++rb) dw_load8(Pr, v0, (64 * oh + 32 * rb) * T4, o.xa[rb]);
+        WN_UNROLL
+        for (int j = 0; j < K; ++j) {
+            const int cbg = ch * K + j, tap = cbg >> 1, ih = cbg & 1;
+            const int lead = tk - (K - 1 - tap) * a.dil;              // first sample of the hi = 0 lanes
+            const bool ok = kv && (lead + 8 * hi >= 0);   // the lane's 8 samples are inside the sequence (else: zero history / fixup)
+            dw_load8(Xr, ok ? vrow + lead * 4 : WN_VOFF_DEAD, 32 * ih * T4, o.xb[j]);
+        }
+        dw_load8(Dr, v0, 32 * oh * T4, o.xr[0]);
+        dw_load8(Zr, v0, 32 * ch * T4, o.xr[1]);
+    };
+    auto compute = [&](const DwOps<K>& o) {
+        wn_f4 bfb[K][3];
+        WN_UNROLL
+        for (int j = 0; j < K; ++j) split8(o.xb[j], bfb[j]);
+        WN_UNROLL
+        for (int rb = 0; rb < 2; ++rb) {
+            wn_f4 bfa[3];
+            split8(o.xa[rb], bfa);
+            WN_UNROLL
+            for (int e = 0; e < 8; ++e) rs[rb] += o.xa[rb][e];
+            WN_UNROLL
+            for (int j = 0; j < K; ++j) acc[rb][j] = dw_mfma6(bfa, bfb[j], acc[rb][j]);
+        }
+        wn_f4 bfa[3], bfz[3];
+        split8(o.xr[0], bfa);
+        split8(o.xr[1], bfz);
+        WN_UNROLL
+        for (int e = 0; e < 8; ++e) rsr += o.xr[0][e];
+        accr = dw_mfma6(bfa, bfz, accr);
+    };
+
+    // software pipeline, one k-block ahead: the requests of block i + 1 are in flight while block i is split and contracted
+    // (two operand sets with static names: no copies of registers that are still being loaded)
+    DwOps<K> o0, o1;
     int round = 0;
-    for (int base_v = walk.first; base_v < walk.end; base_v += walk.step, ++round) {
+    int base_v = walk.first;
+    if (base_v < walk.end) issue(base_v, 0, o0);
+    for (; base_v < walk.end; base_v += walk.step, ++round) {
         const int base = WN_UNIFORM(base_v);
-        while (*round_flag < round) WN_SLEEP(4);   // not ahead of the chain waves: their loads and ours share cache lines
-        for (int j4 = 0; j4 < 4; ++j4) {
-            const int tile = base + j4;
-            if (tile >= walk.end) break;
-            const int b = tile / tiles_per_b;
-            const int t0 = (tile - b * tiles_per_b) * 32;
+#ifndef WN_DIAG_DW_ONLY
+        while (wn_lds_flag_read(round_flag) < round) WN_SLEEP(4);   // not ahead of the chain waves: their loads and ours share cache lines
+#endif
+        WN_UNROLL
+        for (int idx = 0; idx < 8; idx += 2) {
+            issue(base, idx + 1, o1);
+            compute(o0);
+            if (idx + 2 < 8) issue(base, idx + 2, o0);
+            else issue(base + walk.step, 0, o0);    // first block of the next round (dead past the end of the walk)
+            compute(o1);
+        }
+    }
+
+    // The hi = 0 lanes of a sequence's first k-block under a tap shifted by 0 < shift < 8 samples (K = 2, dilations 1, 2, 4; tap 0):
+    // samples [-shift, 8 - shift) straddle the start of the sequence.  Rare (one k-block per sequence), so outside the loop:
+    // the wave whose walk holds the sequence's first tile adds the valid samples, per-sample validity, hi = 1 lanes zero.
+    const int shift0 = (K - 1) * a.dil;   // shift of tap 0
+    if (K > 1 && ch == 0 && shift0 > 0 && shift0 < 8) {
+        for (int b = 0; b < a.B; ++b) {
+            const int tb = b * tiles_per_b, rel = tb - walk.first;
+            if (tb >= walk.end || rel < 0 || rel % walk.step >= 4) continue;   // (uniform) not a tile of this workgroup's walk
             const wn_rsrc_t Pr = wn_make_buf(a.dP + (long)b * 128 * T, (unsigned)(128 * T4));
             const wn_rsrc_t Xr = wn_make_buf(a.Xl + (long)b * 64 * T, (unsigned)(64 * T4));
-            const wn_rsrc_t Dr = wn_make_buf(has_res ? a.dXn + (long)b * 64 * T : a.Xl, (unsigned)(64 * T4));
-            const wn_rsrc_t Zr = wn_make_buf(a.Zl + (long)b * 64 * T, (unsigned)(64 * T4));
             WN_UNROLL
-            for (int kb = 0; kb < 2; ++kb) {
-                const int tk = t0 + 16 * kb;
-                if (tk >= T) break;   // T % 16 == 0 (launcher): a k-block is inside the sequence or outside it
-                float xa[2][8], xb[K][8], xr[2][8];
+            for (int j = 0; j < K; ++j) {   // this wave's column blocks are tap 0's two input-channel halves
+                float xb[8];
                 WN_UNROLL
-                for (int rb = 0; rb < 2; ++rb) dw_load8(Pr, vrow, (64 * oh + 32 * rb) * T4, tk, hi, xa[rb]);
-                WN_UNROLL
-                for (int j = 0; j < K; ++j) {
-                    const int cbg = ch * K + j, tap = cbg >> 1, ih = cbg & 1;
-                    const int lead = tk - (K - 1 - tap) * a.dil;
-                    dw_load8(Xr, vrow, 32 * ih * T4, lead, hi, xb[j]);
-                }
-                if (has_res) {
-                    dw_load8(Dr, vrow, 32 * oh * T4, tk, hi, xr[0]);
-                    dw_load8(Zr, vrow, 32 * ch * T4, tk, hi, xr[1]);
-                }
-                wn_f4 bfb[K][3];
-                WN_UNROLL
-                for (int j = 0; j < K; ++j) split8(xb[j], bfb[j]);
+                for (int e = 0; e < 8; ++e)
+                    xb[e] = wn_buf_load(Xr, (hi == 0 && e - shift0 >= 0) ? vrow + (e - shift0) * 4 : WN_VOFF_DEAD, 32 * j * T4);
+                wn_f4 bfb[3];
+                split8(xb, bfb);
                 WN_UNROLL
                 for (int rb = 0; rb < 2; ++rb) {
+                    float xa[8];
+                    dw_load8(Pr, vrow, (64 * oh + 32 * rb) * T4, xa);
                     wn_f4 bfa[3];
-                    split8(xa[rb], bfa);
-                    WN_UNROLL
-                    for (int e = 0; e < 8; ++e) rs[rb] += xa[rb][e];
-                    WN_UNROLL
-                    for (int j = 0; j < K; ++j) acc[rb][j] = dw_mfma6(bfa, bfb[j], acc[rb][j]);
-                }
-                if (has_res) {
-                    wn_f4 bfa[3], bfz[3];
-                    split8(xr[0], bfa);
-                    split8(xr[1], bfz);
-                    WN_UNROLL
-                    for (int e = 0; e < 8; ++e) rsr += xr[0][e];
-                    accr = dw_mfma6(bfa, bfz, accr);
+                    split8(xa, bfa);
+                    acc[rb][j] = dw_mfma6(bfa, bfb, acc[rb][j]);
                 }
             }
         }
     }
+
     // the workgroup's partial sums: [128][K*64], [64][64], row sums [128], [64]
     const int NC = K * 64;
     float* dw = a.dwp + (long)blockIdx.x * 128 * NC;
@@ -2059,8 +1707,8 @@ __global__ __launch_bounds__(WN_LB) void k_chain64s(ChainArgs a) {
     char* W = smem_raw;                      // tap blocks: chunk q (32 channels) = tap q % K, channel group q / K; 2 blocks of 6 KB each
     constexpr int NCH = K * 4;               // chunks of the dX part
     char* Wr = W + NCH * 2 * 6144;           // Wres^T: 4 blocks [piece][64 rows][16 k], k order = accumulator register order
-    volatile int* round_flag = reinterpret_cast<volatile int*>(Wr + WN_RES_T_BYTES);   // DW: round the chain waves are in
-    if (DW && threadIdx.x == 0) *round_flag = -1;
+    char* round_flag = Wr + WN_RES_T_BYTES;   // DW: the round the chain waves are in
+    if (DW && threadIdx.x == 0) wn_lds_flag_write(round_flag, -1);
     if (HEAD) {
         // no weights
     } else if (a.img_taps != nullptr) {   // pre-split once per step (wn_fused_pack_images): two straight global -> LDS copies
@@ -2075,11 +1723,14 @@ __global__ __launch_bounds__(WN_LB) void k_chain64s(ChainArgs a) {
     if (DW) {   // waves 4..7: the weight gradients of this layer (chain_dw_role); waves 0..3 walk the tiles
         const int wv = WN_UNIFORM((int)(threadIdx.x >> 6));
         if (wv >= 4) {
+#ifndef WN_DIAG_CHAIN_ONLY   // (timing builds: one of the two roles alone -- results are wrong, the time is the point)
             chain_dw_role<K>(a, wv - 4, round_flag);
+#endif
             return;
         }
-    } else if (WN_UNIFORM((int)(threadIdx.x / (WN_FT / 2))) != 0) {
-        for (int i = 0; i < a.stagger; ++i) WN_SLEEP(127);
+#ifdef WN_DIAG_DW_ONLY
+        return;
+#endif
     }
 
     const int lane = threadIdx.x & 63;
@@ -2139,7 +1790,7 @@ __global__ __launch_bounds__(WN_LB) void k_chain64s(ChainArgs a) {
     }
     while (tile_v < tile_end) {
         const int tile = WN_UNIFORM(tile_v);
-        if (DW && threadIdx.x == 0) *round_flag = dw_round++;   // chain wave 0 owns the first tile of every round
+        if (DW && threadIdx.x == 0) wn_lds_flag_write(round_flag, dw_round++);   // chain wave 0 owns the first tile of every round
         const int b = tile / tiles_per_b;
         const int t = (tile - b * tiles_per_b) * 32 + li;
         const bool inb = t < T;
@@ -2171,16 +1822,16 @@ __global__ __launch_bounds__(WN_LB) void k_chain64s(ChainArgs a) {
             }
         } else {
             WN_PRIO(WN_PRIO_MFMA);
+            // The tap products are accumulated FROM ZERO and the residual input dX_{l+1} is added once, in fp32 VALU
+            // arithmetic, after the last tap.  (Round 2 loaded it straight into the accumulators as their initial value, which
+            // saved its 32 registers -- but every one of the 96 MFMA steps per accumulator then aligned its small products
+            // against the large residual value and lost their low bits with a consistent sign: dX drifted by -1.3e-8 of its
+            // mean magnitude PER LAYER, 6 x the launch pair's drift, and the bias-type gradients (sums over 184 320 positions)
+            // showed it: profiles/r03/chain_pair_diff.txt, grad_gap_probe.txt.)
             acc[0] = f32x16_zero();
             acc[1] = f32x16_zero();
-            if (a.dXn != nullptr) {
-                const wn_rsrc_t Rr = wn_make_buf(a.dXn + (long)b * 64 * T, (unsigned)(64 * T4));
-                WN_UNROLL
-                for (int q = 0; q < 2; ++q) {
-                    WN_UNROLL
-                    for (int r = 0; r < 16; ++r) acc[q][r] = wn_buf_load(Rr, vcur, (32 * q + mfma32_row(r, 0)) * T4);
-                }
-            }
+            float rx[2][16];
+            const bool have_res = a.dXn != nullptr;
             WN_SCHED_BARRIER();
             // saved gate halves of layer l-1: the first 32 channels are requested half way through the taps, the second 32
             // at their end (their registers are the operand buffers the taps no longer need)
@@ -2191,6 +1842,14 @@ __global__ __launch_bounds__(WN_LB) void k_chain64s(ChainArgs a) {
                 WN_SCHED_BARRIER();
                 consume(q + 1, xb, okb);
                 if (q + 3 < NCH) issue(tile_v, q + 3, xb, okb);
+                if (q == 0 && have_res) {   // the residual input: needed after the last tap
+                    const wn_rsrc_t Rr = wn_make_buf(a.dXn + (long)b * 64 * T, (unsigned)(64 * T4));
+                    WN_UNROLL
+                    for (int qq = 0; qq < 2; ++qq) {
+                        WN_UNROLL
+                        for (int r = 0; r < 16; ++r) rx[qq][r] = wn_buf_load(Rr, vcur, (32 * qq + mfma32_row(r, 0)) * T4);
+                    }
+                }
                 if (q == (NCH >> 1) - 2) {  // once, in the middle of the tap loop
                     const wn_rsrc_t Zr = wn_make_buf(a.dZs + (long)b * a.zs_bstride, (unsigned)(64 * T4));
                     WN_UNROLL
@@ -2212,6 +1871,13 @@ __global__ __launch_bounds__(WN_LB) void k_chain64s(ChainArgs a) {
                 const int so = (32 + mfma32_row(r, 0)) * T4;
                 e0[1][r] = wn_buf_load(Ssr, vcur, so);
                 e1[1][r] = wn_buf_load(Gsr, vcur, so);
+            }
+            if (have_res) {
+                WN_UNROLL
+                for (int qq = 0; qq < 2; ++qq) {
+                    WN_UNROLL
+                    for (int r = 0; r < 16; ++r) acc[qq][r] += rx[qq][r];
+                }
             }
             // dX_l of this tile is finished in the accumulator layout: register r of lane (li, hi) = channel 32q + row(r, hi)
             WN_SCHED_BARRIER();
@@ -2343,7 +2009,6 @@ int wn_fused_bwd_chain(const float* wd_b, const float* dP, const float* dXn, flo
     a.wd_b = wd_b; a.dP = dP; a.dXn = dXn; a.dX = dX;
     a.wres = wres_prev; a.dZs = dZs; a.zs_bstride = zs_bstride; a.zs_t0 = zs_t0; a.S = S; a.Gt = Gt; a.gz = gt_is_z; a.dPm = dP_prev;
     a.B = B; a.T = T; a.K = K; a.dil = dilation;
-    a.stagger = stagger_setting();
     a.G = G; a.g_bstride = g_bstride; a.upw = upw; a.U = U; a.F = F; a.dGp = dGp; a.qp = qp;
     a.Xl = Xl; a.Zl = Zl; a.dwp = dwp; a.dwrp = dwrp; a.rsp = rsp; a.rsrp = rsrp;
     const long ntiles = (long)B * ((T + 31) / 32);
@@ -2384,7 +2049,6 @@ int wn_fused_bwd_chain_head(const float* dZs, long zs_bstride, const float* S, c
     a.img_taps = nullptr; a.img_res = nullptr; a.wd_b = nullptr; a.dP = nullptr; a.dXn = nullptr; a.dX = nullptr; a.wres = nullptr;
     a.dZs = dZs; a.zs_bstride = zs_bstride; a.zs_t0 = zs_t0; a.S = S; a.Gt = Gt; a.gz = gt_is_z; a.dPm = dP_prev;
     a.B = B; a.T = T; a.K = 1; a.dil = 1;
-    a.stagger = 0;
     a.G = G; a.g_bstride = g_bstride; a.upw = upw; a.U = U; a.F = F; a.dGp = dGp; a.qp = qp;
     const long ntiles = (long)B * ((T + 31) / 32);
     long nblk = (ntiles + WN_FW - 1) / WN_FW;   // one tile per wave up to 1024 workgroups (HBM-bound, nothing to amortise)

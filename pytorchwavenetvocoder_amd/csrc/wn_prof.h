@@ -6,6 +6,7 @@
 
 void wn_prof_scope_begin(const char* name, double flops, double bytes, wn_stream_t st);
 void wn_prof_scope_end(wn_stream_t st);
+void wn_prof_mark(const char* name);   // an entry of the issue-order log that is not a launch (gradient-bucket events)
 bool wn_prof_is_on();  // per-launch timing active: launchers keep everything on one stream
 
 struct WnProfScope {

@@ -20,9 +20,14 @@ struct EmuAgg {
 };
 bool g_emu_on = false;
 std::map<std::string, EmuAgg> g_emu;
+std::vector<std::string> g_seq;   // tags in issue order, incl. the "bucket_event" marks of wn_backward
 }  // namespace
+void wn_prof_mark(const char* name) {
+    if (g_emu_on) g_seq.push_back(name);
+}
 void wn_prof_scope_begin(const char* name, double flops, double bytes, wn_stream_t) {
     if (!g_emu_on) return;
+    g_seq.push_back(name);
     EmuAgg& a = g_emu[name];
     a.count++;
     a.flops += flops;
@@ -32,7 +37,10 @@ void wn_prof_scope_end(wn_stream_t) {}
 bool wn_prof_is_on() { return false; }
 extern "C" int wn_prof_enable(int on) {
     g_emu_on = on != 0;
-    if (g_emu_on) g_emu.clear();
+    if (g_emu_on) {
+        g_emu.clear();
+        g_seq.clear();
+    }
     return 0;
 }
 extern "C" int wn_prof_report(char* buf, size_t n) {
@@ -60,6 +68,7 @@ struct Rec {
 };
 bool g_on = false;
 std::vector<Rec> g_recs;
+std::vector<std::string> g_seq;   // tags in issue order, incl. the "bucket_event" marks of wn_backward
 std::vector<hipEvent_t> g_pool;
 hipEvent_t get_event() {
     if (!g_pool.empty()) {
@@ -73,8 +82,13 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
+void wn_prof_mark(const char* name) {
+    if (g_on) g_seq.push_back(name);
+}
+
 void wn_prof_scope_begin(const char* name, double flops, double bytes, wn_stream_t st) {
     if (!g_on) return;
+    g_seq.push_back(name);
     Rec r;
     r.name = name;
     r.flops = flops;
@@ -100,6 +114,7 @@ extern "C" int wn_prof_enable(int on) {
             g_pool.push_back(r.e1);
         }
         g_recs.clear();
+        g_seq.clear();
     }
     return 0;
 }
@@ -137,3 +152,16 @@ extern "C" int wn_prof_report(char* buf, size_t n) {
     return 0;
 }
 #endif
+
+// The recorded tags in issue order, comma separated ("bucket_event" = wn_backward recorded a gradient-bucket event there).
+extern "C" int wn_prof_sequence(char* buf, size_t n) {
+    std::string s;
+    for (size_t i = 0; i < g_seq.size(); ++i) {
+        if (i) s += ",";
+        s += g_seq[i];
+    }
+    if (!buf || n == 0) return (int)s.size() + 1;
+    if (s.size() + 1 > n) return -1;
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return 0;
+}

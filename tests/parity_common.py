@@ -241,3 +241,18 @@ def launch_log(lib, fn):
     buf = ctypes.create_string_buffer(max(need, 16))
     lib.wn_prof_report(buf, len(buf))
     return {k: v["count"] for k, v in json.loads(buf.value.decode() or "{}").items()}
+
+
+def launch_sequence(lib, fn):
+    """Run ``fn()`` with the per-launch log on; returns the tags in ISSUE ORDER, including the ``bucket_event`` marks
+    wn_backward leaves where it records a gradient-bucket event (wn_prof_sequence)."""
+    lib.wn_prof_enable(1)
+    try:
+        fn()
+    finally:
+        lib.wn_prof_enable(0)
+    need = lib.wn_prof_sequence(None, 0)
+    buf = ctypes.create_string_buffer(max(need, 16))
+    lib.wn_prof_sequence(buf, len(buf))
+    s = buf.value.decode()
+    return s.split(",") if s else []

@@ -197,12 +197,11 @@ def test_persistent_tile_loop_several_tiles_per_wave():
         "for fl in (0, _lib.FLAG_AUX_FUSED):\n"
         "    e, g = PC.run_oracle_vs_engine((32, 4, 64, 32, 2, 1, 2, 16), 1, 2304, 51, emu_library(), 'cpu', flags=fl, scale=0.2)\n"
         "    print('flags', fl, 'logits', e, 'grads', g)\n"
-        # forward tile chains (opt-in WN_FWD_CHAIN=1; dilations 32 and 64: a wave's next tile is 1 / 2 tiles further and takes its history tap
-        # from the registers of the tile before): 100 tiles on 64 waves -> chains of 2 tiles, a tail of single tiles
-        # (100 tiles per sequence are not a multiple of 4 x 2)
+        # dilations up to 64 (history taps 1 / 2 tiles back), 100 tiles on 64 waves (32 chain waves with the weight-gradient
+        # waves of the chain launches): several rounds per wave, a partial last round
         "e, g = PC.run_oracle_vs_engine((32, 4, 64, 32, 7, 1, 2, 16), 1, 3200, 52, emu_library(), 'cpu', flags=_lib.FLAG_AUX_FUSED, scale=0.2)\n"
         "print('flags chains', 'logits', e, 'grads', g)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    env = dict(os.environ, WN_CHAIN_BLOCKS="8", WN_FWD_CHAIN="1")
+    env = dict(os.environ, WN_CHAIN_BLOCKS="8")
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     out = r.stdout.decode()
     assert r.returncode == 0, out[-2000:]
@@ -341,7 +340,7 @@ def test_gate_epilogues_of_the_wide_model_path():
     """n_resch % 128 == 0 (the recipes' 512): the any-size path runs the gate as the epilogue of the dilated contraction
     (sigmoid / tanh rows paired by the weight packing) and gate' as the epilogue of the dZ contraction.  R = 128 and 256
     (one and two 256-row blocks of the forward contraction), ragged T (edge blocks), last layer without a residual input,
-    against the oracle; and against the separate elementwise launches (WN_GATE_EPILOGUE=0, subprocess) at round-off."""
+    against the oracle."""
     PC.run_oracle_vs_engine((64, 6, 128, 128, 2, 2, 2, 16), 1, 144, 51, emu_library(), "cpu", scale=0.1)
     PC.run_oracle_vs_engine((32, 4, 256, 128, 1, 1, 2, 8), 1, 72, 52, emu_library(), "cpu", scale=0.1)    # two 256-row blocks, one layer
     PC.run_oracle_vs_engine((32, 4, 128, 64, 1, 1, 3, 0), 1, 70, 53, emu_library(), "cpu", scale=0.1)   # one layer, K = 3, no upsampling
@@ -418,6 +417,41 @@ def test_weight_gradient_waves_of_the_chain_launch():
         scale = float(res[1].abs().max())
         assert float((res[0] - res[1]).abs().max()) <= 2e-6 * scale, (cfg_t, float((res[0] - res[1]).abs().max()) / scale)
     PC.run_oracle_vs_engine((64, 6, 64, 32, 7, 1, 2, 16), 1, 160, 53, emu_library(), "cpu", flags=A, scale=0.2)
+
+
+def test_gradient_bucket_events_follow_the_launches_that_fill_the_bucket():
+    """N > 1 readiness (row e): wn_backward records bucket i's event AFTER the last launch that writes into bucket i and BEFORE
+    the chain launches of the layers that follow, so the all-reduce of a finished bucket runs under the rest of the backward
+    pass (distributed.GradientReducer waits on exactly these events).  Checked on the issue-order log for the three-bucket
+    structure and for the mid-chain split (two groups of layers): with the weight gradients inside the chain launches a
+    bucket of layers is final as soon as its last chain launch and the small reductions behind it are issued."""
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd import _lib
+    from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat
+    cfg_t = (64, 6, 64, 32, 3, 2, 2, 16)   # 6 layers
+    cfg = O.OracleConfig(*cfg_t)
+    x, h, t = O.synthetic_batch(cfg, 1, 64, 2)
+    eng = WaveNetEngine(*cfg_t, device="cpu", library=emu_library())
+    load_state_into_flat(eng, O.random_params(cfg, 1, scale=0.1))
+    chain_tags = ("fused_bwd_chain_dw", "fused_bwd_chain", "fused_bwd_gate", "fused_bwd_dx")
+    for lpb, nb in ((0, 3), (3, 4), (2, 5)):
+        loss, dl = eng.forward_loss(x, h, t)
+        seq = PC.launch_sequence(emu_library(), lambda: eng.backward(dl, events=list(range(1, nb + 1)), layers_per_bucket=lpb,
+                                                                      t_first=eng.receptive_field))
+        ev = [i for i, s in enumerate(seq) if s == "bucket_event"]
+        assert len(ev) == nb and ev[-1] == len(seq) - 1, (lpb, seq)
+        chain_pos = [i for i, s in enumerate(seq) if s in chain_tags]
+        # bucket 0 = post-net + skip: final before the residual chain starts, after dw_post2 / dw_post1 / dw_skip
+        assert max(i for i, s in enumerate(seq) if s in ("dw_post2", "dw_post1", "dw_skip")) < ev[0] < chain_pos[0], (lpb, seq)
+        # layer buckets: the k-th one is recorded after k * lpb layers' chain launches (head + chain + tail = L + 1 launches
+        # for L layers: the tail belongs to layer 0) and before the next layer's launch
+        per = lpb if lpb else 6
+        for k in range(1, nb - 1):
+            done = min(k * per, 6)
+            n_launch_before = sum(1 for i in chain_pos if i < ev[k])
+            assert n_launch_before == done + 1, (lpb, k, seq)
+        # the front-conv / upsampling bucket is last
+        assert any(s.startswith("dw_front") or s == "front_dw" for s in seq[ev[-2]:ev[-1]]), (lpb, seq[ev[-2]:])
 
 
 def test_loss_window_backward_equals_the_full_backward():
@@ -516,89 +550,3 @@ def test_front_conv_weight_gradient_on_the_matrix_cores():
             log["err"] = (e, g)
         counts = PC.launch_log(emu_library(), run)
         assert counts.get("dw_front_scatter") == 1 and "dw_front_onehot" not in counts, counts
-
-
-def test_forward_block_v2_is_bit_identical_to_the_default_kernel():
-    """k_resblock_fwd_v2 (opt-in WN_FWD_V2=1: row-tile passes per tap with the gate math and the operand splits in the
-    shadow of the MFMAs) sees, per accumulator, the same MFMAs in the same order as k_resblock_fwd_s<2, 0> and runs the same
-    gate code: logits, every saved x_l, sigmoid half and z must be BIT-identical.  Several tiles per wave
-    (WN_CHAIN_BLOCKS=8), dilations up to 64, a ragged last tile (T % 32 = 16), two sequences, the last layer (no residual
-    output); the env knob is read once per process, so the v2 run is a subprocess."""
-    import os
-    import subprocess
-    import sys
-    import tempfile
-    from oracle import wavenet_oracle as O
-    from pytorchwavenetvocoder_amd import _lib
-    from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    body = (
-        "import sys; sys.path.insert(0, %r)\n"
-        "import torch\n"
-        "from oracle import wavenet_oracle as O\n"
-        "from tests.emu_util import emu_library\n"
-        "from pytorchwavenetvocoder_amd import _lib\n"
-        "from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat\n"
-        "cfg_t = (32, 4, 64, 32, 7, 1, 2, 16)\n"
-        "cfg = O.OracleConfig(*cfg_t)\n"
-        "params = O.random_params(cfg, 91, scale=0.2)\n"
-        "x, h, t = O.synthetic_batch(cfg, 2, 1360, 92)\n"
-        "eng = WaveNetEngine(*cfg_t, device='cpu', library=emu_library())\n"
-        "load_state_into_flat(eng, params)\n"
-        "logits = eng.forward(x, h)\n"
-        "out = {'logits': logits.clone(), 'X': eng.saved(_lib.WS_X).clone(), 'S': eng.saved(_lib.WS_SIGMOID).clone(),\n"
-        "       'Z': eng.saved(_lib.WS_Z).clone()}\n"
-        "torch.save(out, sys.argv[1])\n" % root)
-    res = {}
-    with tempfile.TemporaryDirectory() as td:
-        for name, v2 in (("v1", "0"), ("v2", "1")):
-            path = os.path.join(td, name + ".pt")
-            env = dict(os.environ, WN_CHAIN_BLOCKS="8", WN_FWD_V2=v2)
-            r = subprocess.run([sys.executable, "-c", body, path], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                               timeout=900)
-            assert r.returncode == 0, r.stdout.decode()[-2000:]
-            res[name] = torch.load(path)
-    for k in ("logits", "X", "S", "Z"):
-        assert torch.equal(res["v1"][k], res["v2"][k]), k
-    assert float(res["v1"]["Z"].abs().max()) > 0.0
-
-
-def test_chain_head_variants_agree():
-    """Top of the backward chain: the default takes dP_{L-1} from its rows of the all-layer skip pre-contraction
-    (k_chain64s<.., HEAD>), WN_CHAIN_HEAD=0 (read once per process -> subprocess) contracts dSkip in k_conv64s as before.
-    Same gradients at round-off, with and without the aux partial sums, single-layer model included."""
-    import os
-    import subprocess
-    import sys
-    import tempfile
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    body = (
-        "import sys; sys.path.insert(0, %r)\n"
-        "import torch\n"
-        "from oracle import wavenet_oracle as O\n"
-        "from tests.emu_util import emu_library\n"
-        "from pytorchwavenetvocoder_amd import _lib\n"
-        "from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat\n"
-        "out = {}\n"
-        "for name, cfg_t, T, flags in (('a', (32, 4, 64, 32, 3, 1, 2, 16), 96, _lib.FLAG_AUX_FUSED), ('b', (32, 4, 64, 32, 3, 1, 2, 16), 96, 0),\n"
-        "                              ('c', (32, 4, 64, 32, 1, 1, 2, 16), 48, _lib.FLAG_AUX_FUSED)):\n"
-        "    cfg = O.OracleConfig(*cfg_t)\n"
-        "    x, h, t = O.synthetic_batch(cfg, 2, T, 95)\n"
-        "    eng = WaveNetEngine(*cfg_t, device='cpu', library=emu_library())\n"
-        "    eng.flags = flags\n"
-        "    load_state_into_flat(eng, O.random_params(cfg, 94, scale=0.2))\n"
-        "    loss, dl = eng.forward_loss(x, h, t)\n"
-        "    out[name] = eng.backward(dl, t_first=cfg.receptive_field).clone()\n"
-        "torch.save(out, sys.argv[1])\n" % root)
-    res = {}
-    with tempfile.TemporaryDirectory() as td:
-        for name, head in (("head", "1"), ("conv", "0")):
-            path = os.path.join(td, name + ".pt")
-            r = subprocess.run([sys.executable, "-c", body, path], env=dict(os.environ, WN_CHAIN_HEAD=head),
-                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
-            assert r.returncode == 0, r.stdout.decode()[-2000:]
-            res[name] = torch.load(path)
-    for k in ("a", "b", "c"):
-        g0, g1 = res["head"][k], res["conv"][k]
-        assert float(g0.abs().max()) > 0.0
-        assert float((g0 - g1).abs().max()) <= 5e-6 * float(g1.abs().max()), k
