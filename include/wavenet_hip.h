@@ -102,11 +102,6 @@ enum {
                                * per layer (dX_l and gate'_{l-1} fused, the skip part of dZ pre-contracted for all layers by
                                * one matrix-bound launch; csrc/wn_fused.hip k_chain64s).  This flag restores the former
                                * gate' + dX launch pair per layer (kept for A/B measurements and as an independent check) */
-#define WN_FLAG_NO_CHAIN_DW 128 /* wn_backward (chain mode, T % 16 == 0): since round 3 the chain launch of layer l also contracts that
-                               * layer's dilated-conv and res_1x1 weight gradients -- four of its eight waves per workgroup, from
-                               * the tensors the chain streams anyway (csrc/wn_fused.hip chain_dw_role) -- and the layer-batched
-                               * dw_dilated / dw_res contractions are gone.  This flag restores them (A/B measurements,
-                               * independent check; the sums re-associate: ~1e-7 relative) */
 #define WN_FLAG_BWD_OVERLAP_HEAD 16 /* with WN_FLAG_BWD_OVERLAP: only the post-net / skip weight gradients run on the side
                                * stream; the per-layer groups stay on the caller's stream */
 #define WN_FLAG_FWD_OVERLAP 8 /* wn_forward (fused kernels): the skip-sum contraction is issued in three chunks of layers on

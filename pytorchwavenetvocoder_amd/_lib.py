@@ -71,7 +71,6 @@ FLAG_NO_FUSED = 1
 FLAG_EXACT_MFMA = 2
 FLAG_BWD_OVERLAP = 4  # wn_backward: weight gradients on the library's side stream beside the gate'/dX chain (opt-in)
 FLAG_NO_CHAIN = 64  # wn_backward: the former gate' + dX launch pair per layer instead of the fused chain kernel
-FLAG_NO_CHAIN_DW = 128  # wn_backward: layer-batched dw_dilated / dw_res contractions instead of the chain launches' weight-gradient waves
 FLAG_AUX_FUSED = 32  # wn_backward: aux-gradient partial sums in the gate kernel (dP not re-read by aux_bwd); the engine's default
 FLAG_BWD_OVERLAP_HEAD = 16  # with FLAG_BWD_OVERLAP: only the post-net / skip weight gradients on the side stream
 FLAG_FWD_OVERLAP = 8  # wn_forward: chunked skip-sum on the side stream beside the residual stack (opt-in)

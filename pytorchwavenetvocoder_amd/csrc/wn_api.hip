@@ -377,8 +377,6 @@ struct Ws {
     long P, dO2, dSk, dZ, dXall, dG, dw_partial, dc, tmpS, partial, rs_partial, red_scratch, loss_partial;
     long dGp, qp;  // aux-gradient partials of the gate kernel (WN_FLAG_AUX_FUSED); 0 floats when the mode cannot apply
     long img_fwd, img_taps, img_res, img_floats;  // pre-split LDS weight images of the fused split kernels (0 floats: not applicable)
-    long cdw_p, cdw_r, cdw_s, cdw_sr;  // per-layer, per-workgroup partial weight gradients of the chain launches' DW waves (0 floats: off)
-    int cdw_nwg;
     long wskipT_f, dZs;  // chain mode (wn_fused_chain_supported): skip weights as [s][l*R + i], dZs = Wskip^T dSkip (B, L*R, T)
     long dZs_floats;
     long red_scratch_floats;
@@ -445,13 +443,6 @@ static int make_ws(const Dims& d, int B, int T, Ws* w) {
         w->dZs_floats = chain ? (long)B * d.L * d.R * T : 0;
         CARVE(wskipT_f, chain ? (long)d.S * d.L * d.R : 0);
         CARVE(dZs, w->dZs_floats);
-        // weight gradients inside the chain launches (wn_fused.h): one partial per workgroup and layer
-        const bool cdw = chain && T % 16 == 0;
-        w->cdw_nwg = cdw ? wn_fused_chain_dw_blocks(B, T) : 0;
-        CARVE(cdw_p, (long)d.L * w->cdw_nwg * 2 * d.R * d.K * d.R);
-        CARVE(cdw_r, (long)d.L * w->cdw_nwg * d.R * d.R);
-        CARVE(cdw_s, (long)d.L * w->cdw_nwg * 2 * d.R);
-        CARVE(cdw_sr, (long)d.L * w->cdw_nwg * d.R);
     }
     CARVE(dc, (long)d.L * 2 * d.R);
     CARVE(tmpS, d.S > d.Qo ? d.S : d.Qo);
@@ -1175,10 +1166,6 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
     // (layers 0 .. L-2; the last layer's gate' takes dSkip itself, it has no dX input).  WN_FLAG_NO_CHAIN: the former pair.
     const bool chain = c.fused && c.split_bf16 && !(flags & WN_FLAG_NO_CHAIN) && w.dZs_floats > 0 &&
                        wn_fused_chain_supported(d.R, d.K, d.S);
-    // weight gradients of the dilated convs / res 1x1 inside the chain launches (layers >= 1; layer 0 has no chain launch)
-    const bool chain_dw = chain && w.cdw_nwg > 0 && !(flags & WN_FLAG_NO_CHAIN_DW);
-    const long cdw_pL = (long)w.cdw_nwg * 2 * d.R * d.K * d.R, cdw_rL = (long)w.cdw_nwg * d.R * d.R;
-    const long cdw_sL = (long)w.cdw_nwg * 2 * d.R, cdw_srL = (long)w.cdw_nwg * d.R;
     const long zs_bstride = (long)d.L * d.R * T;
     if (chain) {
         WnGemmArgs g = wn_gemm_default();
@@ -1198,32 +1185,21 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
         const int nl = hi - lo;
         const long lb_lo = layer_base(y, d, lo);
         float* dc = ws + w.dc + (long)lo * 2 * d.R;
-        // With chain_dw the layers >= 1 come as per-workgroup partials of their chain launches (fixed-order sum here); layer 0
-        // -- whose dX comes from the tail launch -- keeps the contraction.
-        const int lo_p = chain_dw ? (lo > 1 ? lo : 1) : hi;   // layers [lo_p, hi): from the chain launches' partials
-        const int hi_g = chain_dw ? (hi < 1 ? hi : 1) : hi;   // layers [lo, hi_g): contracted here
         {   // d dil_{sigmoid,tanh}.l.conv.weight ; dc_l = rowsum(dP_l) -> conv + aux biases
+            WnGemmArgs g = wn_gemm_default();
+            g.M = 2 * d.R; g.N = d.K * d.R; g.K = T;
+            g.A = ws + w.P + (long)lo * P_L; g.lda = T; g.a_zstride = (long)2 * d.R * T; g.a_lstride = P_L;
+            g.B = ws + w.X + (long)lo * BRT; g.ldb = T; g.b_zstride = (long)d.R * T; g.b_lstride = BRT; g.b_clen = T;
+            g.b_seg_len = d.R; g.b_seg_stride = 0; g.b_shift0 = d.K - 1; g.b_shift_step = -1;
+            g.b_dil_depth = cfg->dilation_depth; g.b_layer0 = lo;
+            g.tag = "dw_dilated";
             DwOut o;
+            o.out = grads + lb_lo + y.o_dsig_w;
             o.m_seg = d.R; o.m_seg_stride = y.o_dtanh_w - y.o_dsig_w; o.m_stride = (long)d.R * d.K;
             o.n_seg = d.R; o.n_seg_stride = 1; o.n_stride = d.K;
-            o.addend_m = nullptr; o.addend_scale_ptr = nullptr;
+            o.addend_m = nullptr; o.addend_scale_ptr = nullptr; o.rowsum_out = dc;
             o.out_lstride = -y.LB; o.addend_lstride = 0; o.rowsum_lstride = 2 * d.R;
-            if (lo < hi_g) {
-                WnGemmArgs g = wn_gemm_default();
-                g.M = 2 * d.R; g.N = d.K * d.R; g.K = T;
-                g.A = ws + w.P + (long)lo * P_L; g.lda = T; g.a_zstride = (long)2 * d.R * T; g.a_lstride = P_L;
-                g.B = ws + w.X + (long)lo * BRT; g.ldb = T; g.b_zstride = (long)d.R * T; g.b_lstride = BRT; g.b_clen = T;
-                g.b_seg_len = d.R; g.b_seg_stride = 0; g.b_shift0 = d.K - 1; g.b_shift_step = -1;
-                g.b_dil_depth = cfg->dilation_depth; g.b_layer0 = lo;
-                g.tag = "dw_dilated";
-                o.out = grads + lb_lo + y.o_dsig_w; o.rowsum_out = dc;
-                WN_TRY(dw_gemm(c, g, o, hi_g - lo));
-            }
-            if (lo_p < hi) {
-                o.out = grads + layer_base(y, d, lo_p) + y.o_dsig_w; o.rowsum_out = ws + w.dc + (long)lo_p * 2 * d.R;
-                WN_TRY(dw_reduce(c, ws + w.cdw_p + lo_p * cdw_pL, ws + w.cdw_s + lo_p * cdw_sL, w.cdw_nwg, 2 * d.R, d.K * d.R, o,
-                                 hi - lo_p));
-            }
+            WN_TRY(dw_gemm(c, g, o, nl));
             WnCopy4 cp;  // biases: dil_{sig,tanh}.bias = dc ; aux_{sig,tanh}.bias = dc
             cp.n0 = 1; cp.n1 = 2; cp.n2 = d.R; cp.nl = nl;
             cp.s0 = 0; cp.s1 = d.R; cp.s2 = 1; cp.sl = 2 * d.R;
@@ -1235,8 +1211,7 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
         {   // d res_1x1.l = dX_{l+1} . z_l^T ; the last layer's res_1x1 is dead -> zeros
             const int hi_res = hi < d.L ? hi : d.L - 1;
             if (hi == d.L) WN_TRY(wn_fill(grads + layer_base(y, d, d.L - 1) + y.o_res_w, 0.0f, (long)d.R * d.R + d.R, c.st));
-            const int hi_rg = hi_res < hi_g ? hi_res : hi_g;
-            if (hi_rg > lo) {
+            if (hi_res > lo) {
                 WnGemmArgs g = wn_gemm_default();
                 g.M = d.R; g.N = d.R; g.K = T;
                 g.A = ws + w.dXall + (long)(lo + 1) * BRT; g.lda = T; g.a_zstride = (long)d.R * T; g.a_lstride = BRT;
@@ -1244,14 +1219,7 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
                 g.tag = "dw_res";
                 DwOut o = dw_out_plain(grads + lb_lo + y.o_res_w, d.R, grads + lb_lo + y.o_res_b);
                 o.out_lstride = -y.LB; o.rowsum_lstride = -y.LB;
-                WN_TRY(dw_gemm(c, g, o, hi_rg - lo));
-            }
-            if (lo_p < hi_res) {
-                const long lbp = layer_base(y, d, lo_p);
-                DwOut o = dw_out_plain(grads + lbp + y.o_res_w, d.R, grads + lbp + y.o_res_b);
-                o.out_lstride = -y.LB; o.rowsum_lstride = -y.LB;
-                WN_TRY(dw_reduce(c, ws + w.cdw_r + lo_p * cdw_rL, ws + w.cdw_sr + lo_p * cdw_srL, w.cdw_nwg, d.R, d.R, o,
-                                 hi_res - lo_p));
+                WN_TRY(dw_gemm(c, g, o, hi_res - lo));
             }
         }
         {   // d aux_1x1_{sigmoid,tanh}.l.weight
@@ -1320,9 +1288,7 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
                                           aux_fused ? ws + w.qp + (long)(l - 1) * B * T : nullptr, B, T, d.K, dil,
                                           (w.img_floats > 0) ? ws + w.img_taps + (long)l * (wn_fused_image_floats(d.K, d.L, 1) / d.L) : nullptr,
                                           (w.img_floats > 0) ? ws + w.img_res + (long)(l - 1) * (wn_fused_image_floats(d.K, d.L, 2) / d.L) : nullptr,
-                                          t0, ws + w.X + (long)l * BRT, ws + w.Z + (long)l * BRT,
-                                          chain_dw ? ws + w.cdw_p + l * cdw_pL : nullptr, ws + w.cdw_r + l * cdw_rL,
-                                          ws + w.cdw_s + l * cdw_sL, ws + w.cdw_sr + l * cdw_srL, c.st));
+                                          t0, c.st));
             } else {      // tail: dX_0
                 WN_TRY(wn_fused_bwd_dx(ws + w.wd_b, dP, dXn, dXl, B, T, d.K, dil, 1, c.st));
             }

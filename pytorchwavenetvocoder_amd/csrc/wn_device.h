@@ -64,9 +64,6 @@ static inline void wn_buf_load_lds16(wn_rsrc_t r, char* lds_wave_base, int voff,
 #define WN_LDS_BARRIER() __syncthreads()
 // load that must observe earlier stores of other waves of the same workgroup (bypasses the L1)
 static inline float wn_ld_coherent(const float* p) { return *p; }
-// a flag word in LDS that one wave publishes and others poll, without waiting for anything but that LDS access
-static inline int wn_lds_flag_read(const char* p) { return *reinterpret_cast<const volatile int*>(p); }
-static inline void wn_lds_flag_write(char* p, int v) { *reinterpret_cast<volatile int*>(p) = v; }
 // v + the value of lane (l ^ m); all lanes of an aligned group of 2m hold the same partial sums
 static inline float wn_xor_add(float v, int m) { return v + __shfl_xor(v, m, 64); }
 // bf16 matrix-core step (v_mfma_f32_32x32x16_bf16): a / b = 8 bf16 per lane packed in a float4
@@ -152,17 +149,6 @@ static __device__ __forceinline__ float4 wn_buf_load4(wn_rsrc_t r, int voff, uns
 #define WN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 static __device__ __forceinline__ float wn_ld_coherent(const float* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// A flag word in LDS that one wave publishes and others poll.  Plain ds_read / ds_write with an lgkmcnt wait only: a volatile
-// access through a C++ pointer makes hipcc drain the vector-memory counter as well (vmcnt(0)), i.e. every prefetched global
-// load of the polling / publishing wave.
-static __device__ __forceinline__ int wn_lds_flag_read(const char* p) {
-    int v;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((__attribute__((address_space(3))) const char*)p) : "memory");
-    return v;
-}
-static __device__ __forceinline__ void wn_lds_flag_write(char* p, int v) {
-    asm volatile("ds_write_b32 %0, %1" : : "v"((__attribute__((address_space(3))) char*)p), "v"(v) : "memory");
 }
 // v + partner value, partner in the other half of the aligned 2m-lane group.  m = 1,2,4,8 are DPP
 // moves (quad_perm / row_half_mirror / row_mirror: valid because after the previous steps every

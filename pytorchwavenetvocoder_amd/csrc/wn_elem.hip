@@ -897,12 +897,8 @@ __global__ __launch_bounds__(FM_T) void k_front_dw_mfma(const float* __restrict_
 }
 
 static bool front_dw_mfma_ok(int R, int K, int Q) {
-    static int on = -1;   // WN_FRONT_DW_MFMA=0: the LDS-atomic scatter kernel (A/B)
-    if (on < 0) {
-        const char* e = getenv("WN_FRONT_DW_MFMA");
-        on = (e && e[0] == '0') ? 0 : 1;
-    }
-    return on && (R == 32 || R == 64) && Q % 32 == 0 && K * Q <= 512 && K <= 8;
+    // (other shapes keep the LDS-atomic scatter kernel: 0.18 vs 0.07 ms at the benchmark's size, profiles/r02/front_dw_probe.txt)
+    return (R == 32 || R == 64) && Q % 32 == 0 && K * Q <= 512 && K <= 8;
 }
 
 // dW[c][q][k] = sum_blk partial[blk][c][k*Q+q] ; db[c] = sum_blk partial[blk][R*KQ + c]

@@ -50,16 +50,8 @@ int wn_fused_chain_supported(int R, int K, int S);
 int wn_fused_bwd_chain(const float* wd_b, const float* dP, const float* dXn, float* dX, const float* wres_prev, const float* dZs,
                        long zs_bstride, const float* S, const float* Gt, int gt_is_z, float* dP_prev, const float* G, long g_bstride,
                        const float* upw, int U, int F, float* dGp, float* qp, int B, int T, int K, int dilation,
-                       const float* img_taps, const float* img_res, int zs_t0, const float* Xl, const float* Zl, float* dwp,
-                       float* dwrp, float* rsp, float* rsrp, wn_stream_t st);
+                       const float* img_taps, const float* img_res, int zs_t0, wn_stream_t st);
 // zs_t0: dZs[.., t < zs_t0] is taken as zero and never read (loss window, wn_backward_window)
-// dwp != NULL (T % 16 == 0): the launch also contracts the weight gradients of layer l over time -- four of the eight waves of
-// every workgroup (wn_fused.hip, chain_dw_role) -- from the tensors the chain streams anyway plus Xl = x_l and Zl = z_l:
-//   dwp [nwg][2R][K*R]  partial of dW_dil,l[o][tap*R + i] = sum_t dP_l[o][t] x_l[i][t - (K-1-tap) d]
-//   dwrp[nwg][R][R]     partial of dW_res,l[c][i] = sum_t dXn[c][t] z_l[i][t]      (not written when dXn == NULL)
-//   rsp [nwg][2R], rsrp [nwg][R]   partial row sums of dP_l and of dXn            (-> the bias gradients)
-// nwg = wn_fused_chain_dw_blocks(B, T) partials, to be summed in a fixed order (wn_reduce).
-int wn_fused_chain_dw_blocks(int B, int T);
 // top of the chain: dP_{L-1} = gate'(dZs_{L-1}) alone (the last layer has no residual gradient); same aux outputs
 int wn_fused_bwd_chain_head(const float* dZs, long zs_bstride, const float* S, const float* Gt, int gt_is_z, float* dP_prev,
                             const float* G, long g_bstride, const float* upw, int U, int F, float* dGp, float* qp, int B, int T,

@@ -571,7 +571,7 @@ __global__ __launch_bounds__(WN_LB) void k_fused_pack_images(PackImgArgs a) {
 }
 
 long wn_fused_image_floats(int K, int L, int which) {
-    if (K < 1 || K > 2) return 0;
+    if (K < 1 || K > 3) return 0;
     const long per = which == 0 ? fwd_image_bytes(K) : which == 1 ? chain_taps_bytes(K) : WN_RES_T_BYTES;
     return (long)L * per / 4;
 }
@@ -579,12 +579,13 @@ long wn_fused_image_floats(int K, int L, int which) {
 int wn_fused_pack_images(const float* wd_f, const float* wres_f, const float* wd_b, const float* params, long res_off,
                          long res_lstride, float* img_fwd, float* img_taps, float* img_res, int K, int L, wn_stream_t st) {
     WN_PROF("fused_pack_images", 0.0, 0.0, st);
-    if (K < 1 || K > 2) return 1;
+    if (K < 1 || K > 3) return 1;
     PackImgArgs a;
     a.wd_f = wd_f; a.wres_f = wres_f; a.wd_b = wd_b; a.params = params; a.res_off = res_off; a.res_lstride = res_lstride;
     a.img_fwd = img_fwd; a.img_taps = img_taps; a.img_res = img_res; a.K = K;
     if (K == 1) WN_LAUNCH((k_fused_pack_images<1>), dim3((unsigned)L, 3), dim3(WN_FT), 0, st, a);
-    else WN_LAUNCH((k_fused_pack_images<2>), dim3((unsigned)L, 3), dim3(WN_FT), 0, st, a);
+    else if (K == 2) WN_LAUNCH((k_fused_pack_images<2>), dim3((unsigned)L, 3), dim3(WN_FT), 0, st, a);
+    else WN_LAUNCH((k_fused_pack_images<3>), dim3((unsigned)L, 3), dim3(WN_FT), 0, st, a);
     return 0;
 }
 
@@ -593,8 +594,11 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_s(FwdArgs a) {
     WN_DYN_SMEM(smem_raw);
     constexpr int WD_BLK = 3 * 128 * 32, WR_BLK = 3 * 64 * 32;  // bytes of one 16-k block
     char* Wd = smem_raw;                                         // [K*4 blocks][piece][128 rows][16 k] bf16
-    char* Wr = Wd + K * 4 * WD_BLK;                              // [4 blocks][piece][64 rows][16 k] bf16
-    float* cv = reinterpret_cast<float*>(Wr + 4 * WR_BLK);       // [128]
+    // K = 3: the three taps alone fill the LDS (144 KB), so the res-1x1 fragments (24 KB per layer, L2 resident) are read
+    // from the layer's pre-split image in global memory, one 16-k block ahead of their MFMAs (RG = "res from global")
+    constexpr bool RG = (K >= 3);
+    char* Wr = Wd + K * 4 * WD_BLK;                              // [4 blocks][piece][64 rows][16 k] bf16   (not with RG)
+    float* cv = reinterpret_cast<float*>(Wr + (RG ? 0 : 4 * WR_BLK));   // [128]
     float* rb = cv + 128;                                        // [64]
 #ifdef WN_TIMING
     if (a.dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
@@ -603,7 +607,10 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_s(FwdArgs a) {
     }
     if (a.dbg && threadIdx.x == 0) a.dbg[512 + blockIdx.x * 4 + 0] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
-    if (a.wimg != nullptr) {
+    if (RG) {   // (the launcher only takes this kernel with an image)
+        copy_image_to_lds(smem_raw, a.wimg, K * 4 * WD_BLK);
+        WN_WAIT_VMCNT(0);
+    } else if (a.wimg != nullptr) {
         copy_image_to_lds(smem_raw, a.wimg, fwd_image_bytes(K));   // pre-split once per step (wn_fused_pack_images)
         WN_WAIT_VMCNT(0);
     } else {
@@ -632,6 +639,9 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_s(FwdArgs a) {
     const TileWalk walk = tile_walk(ntiles, threadIdx.x >> 6);
     const int step = WN_UNIFORM(walk.step), tile_end = WN_UNIFORM(walk.end);
     constexpr int KH = (K > 1) ? (K - 1) : 1;  // history taps (shift > 0)
+    // history taps requested one tile ahead (across the gate phase of the previous tile).  K = 3 keeps only the oldest tap
+    // that way and requests the middle one at tile start with the current tap: 32 registers less across the gate phase.
+    constexpr int KP = (K >= 3) ? 1 : K - 1;
 
     // Software pipeline (per wave, per 32-sample tile):
     //   history-tap operands xh : issued before the res MFMAs of the PREVIOUS tile (cross-tile prefetch)
@@ -647,7 +657,7 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_s(FwdArgs a) {
         const int t = (tl - b * tiles_per_b) * 32 + li;
         const wn_rsrc_t Xr = wn_make_buf(a.X + (long)b * 64 * T, slab);
         WN_UNROLL
-        for (int tap = 0; tap + 1 < K; ++tap) {
+        for (int tap = 0; tap < KP; ++tap) {
             const int ts = t - (K - 1 - tap) * a.dil;
             const bool ok = (t < T) && ts >= 0;
             okh[tap] = ok;
@@ -674,6 +684,15 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_s(FwdArgs a) {
         float xc[32];
         {
             const wn_rsrc_t Xr = wn_make_buf(a.X + (long)b * 64 * T, slab);
+            WN_UNROLL
+            for (int tap = KP; tap + 1 < K; ++tap) {   // (K = 3) the history taps that are not requested a tile ahead
+                const int ts = t - (K - 1 - tap) * a.dil;
+                const bool ok = inb && ts >= 0;
+                okh[tap] = ok;
+                const int vt = ok ? (4 * hi * T + ts) * 4 : 0;
+                WN_UNROLL
+                for (int s = 0; s < 32; ++s) xh[tap][s] = wn_buf_load(Xr, vt, kappa64(s, 0) * T4);
+            }
             WN_UNROLL
             for (int s = 0; s < 32; ++s) xc[s] = wn_buf_load(Xr, vcur, kappa64(s, 0) * T4);
         }
@@ -762,18 +781,20 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_s(FwdArgs a) {
         // 96 S/Gt/Z stores could only be waited for together with those stores' acknowledgements.
         // residual input + bias = the initial value of the res-1x1 accumulators, formed NOW: xc dies here, so that in a
         // chain its registers simply become the next tile's history operands (no second copy of the tile is ever live)
-        f32x16 racc[2];
+        // (Round 3: the sums are ADDED to the res products after the last MFMA instead of being the accumulators' initial
+        // value -- products aligned against a large initial value lose their low bits with a consistent sign, see k_chain64s.)
+        f32x16 xb2[2];
         if (a.Xnext != nullptr) {
             const float* rbl = rb + 4 * hi;
             WN_UNROLL
             for (int q = 0; q < 2; ++q) {
                 WN_UNROLL
                 for (int r = 0; r < 16; ++r)
-                    racc[q][r] = (inb ? xc[16 * q + r] : 0.0f) + rbl[32 * q + mfma32_row(r, 0)];
+                    xb2[q][r] = (inb ? xc[16 * q + r] : 0.0f) + rbl[32 * q + mfma32_row(r, 0)];
             }
 #ifndef WN_EMU
             // pin: the sums exist from here on (machine sinking would otherwise move them below the branch and keep xc alive)
-            asm volatile("" : "+v"(racc[0]), "+v"(racc[1]));
+            asm volatile("" : "+v"(xb2[0]), "+v"(xb2[1]));
 #endif
         }
         // next tile of this wave: its history taps are requested NOW, before the stores of the gate phase.  (A variant that
@@ -823,6 +844,27 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_s(FwdArgs a) {
         WN_PRIO(WN_PRIO_MFMA);
         // res 1x1 + residual; z is consumed straight from the accumulator registers
         if (a.Xnext != nullptr) {
+            f32x16 racc[2];
+            racc[0] = f32x16_zero();
+            racc[1] = f32x16_zero();
+            const wn_rsrc_t Ir = wn_make_buf(a.wimg, (unsigned)(RG ? fwd_image_bytes(K) : 16));
+            const int vfrag = wn_frag_off(li, hi);
+            auto res_frags = [&](int kb, wn_f4 (&af)[2][3]) {
+                WN_UNROLL
+                for (int q = 0; q < 2; ++q) {
+                    WN_UNROLL
+                    for (int p = 0; p < 3; ++p) {
+                        if (RG) {
+                            const float4 f = wn_buf_load4(Ir, vfrag, (unsigned)(K * 4 * WD_BLK + kb * WR_BLK + p * (64 * 32) + q * 1024));
+                            af[q][p] = wn_f4{f.x, f.y, f.z, f.w};
+                        } else {
+                            af[q][p] = *reinterpret_cast<const wn_f4*>(Wr + kb * WR_BLK + vfrag + p * (64 * 32) + q * 1024);
+                        }
+                    }
+                }
+            };
+            wn_f4 afr[2][2][3];   // two sets: with RG the fragments of block kb + 1 are in flight under the MFMAs of block kb
+            res_frags(0, afr[0]);
             WN_UNROLL
             for (int kb = 0; kb < 4; ++kb) {
                 float x8[8];
@@ -830,19 +872,18 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_s(FwdArgs a) {
                 for (int e = 0; e < 8; ++e) x8[e] = z[(8 * kb + e) >> 4][(8 * kb + e) & 15];
                 wn_f4 bf[3];
                 split8(x8, bf);
-                const char* Wl = Wr + kb * WR_BLK + wn_frag_off(li, hi);
-                wn_f4 af[2][3];
-                WN_UNROLL
-                for (int q = 0; q < 2; ++q) {
-                    WN_UNROLL
-                    for (int p = 0; p < 3; ++p) af[q][p] = *reinterpret_cast<const wn_f4*>(Wl + p * (64 * 32) + q * 1024);
-                }
+                if (kb + 1 < 4) res_frags(kb + 1, afr[(kb + 1) & 1]);
                 constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
                 WN_UNROLL
                 for (int t6 = 0; t6 < 6; ++t6) {
-                    racc[0] = mfma_bf16(af[0][PA[t6]], bf[PB[t6]], racc[0]);
-                    racc[1] = mfma_bf16(af[1][PA[t6]], bf[PB[t6]], racc[1]);
+                    racc[0] = mfma_bf16(afr[kb & 1][0][PA[t6]], bf[PB[t6]], racc[0]);
+                    racc[1] = mfma_bf16(afr[kb & 1][1][PA[t6]], bf[PB[t6]], racc[1]);
                 }
+            }
+            WN_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) racc[q][r] += xb2[q][r];
             }
             {
                 const wn_rsrc_t Xn = wn_make_buf(a.Xnext + (long)b * 64 * T, slab);
@@ -877,8 +918,9 @@ template <int K>
 static int launch_fwd(const FwdArgs& a, int split, wn_stream_t st) {
     const long ntiles = (long)a.B * ((a.T + 31) / 32);
     const long nblk = balanced_blocks(ntiles);
-    const size_t lds_s = (size_t)K * 4 * (3 * 128 * 32) + 4 * (3 * 64 * 32) + 192 * sizeof(float);
-    if (split && lds_s <= 160 * 1024) {  // K = 3 does not fit split: stays on the f32 MFMA
+    // split arithmetic: taps (+ res 1x1 for K <= 2; K = 3 reads those fragments from the global image) + cvec / bias
+    const size_t lds_s = (size_t)K * 4 * (3 * 128 * 32) + (K >= 3 ? 0 : 4 * (3 * 64 * 32)) + 192 * sizeof(float);
+    if (split && lds_s <= 160 * 1024 && (K < 3 || a.wimg != nullptr)) {  // (K = 3 without a weight image: the f32 MFMA kernel)
         if (set_lds(k_resblock_fwd_s<K>, lds_s)) return 1;
         WN_LAUNCH((k_resblock_fwd_s<K>), dim3((unsigned)nblk), dim3(WN_FT), lds_s, st, a);
         return 0;
@@ -895,7 +937,7 @@ int wn_fused_resblock_fwd(const float* wd_f, const float* wres_f, const float* c
     WN_PROF("fused_resblock_fwd", 2.0 * (double)B * T * (K * 64.0 * 128.0 + (Xnext ? 64.0 * 64.0 : 0.0)),
             4.0 * (double)B * T * 64.0 * ((Xnext ? 4.0 : 3.0) + (Gt ? 1.0 : 0.0)), st);  // X in; S, (Gt,) Z (, Xnext) out
     FwdArgs a;
-    a.wimg = (split && K <= 2) ? wimg : nullptr;
+    a.wimg = split ? wimg : nullptr;
     a.wd_f = wd_f; a.wres_f = wres_f; a.cvec = cvec; a.res_bias = res_bias;
     a.X = X; a.G = G; a.g_bstride = g_bstride; a.upw = upw;
     a.Xnext = Xnext; a.S = S; a.Gt = Gt; a.Z = Z;
@@ -1486,13 +1528,6 @@ struct ChainArgs {
     int U, F;
     float* dGp;          // (B, 128, T/16)
     float* qp;           // (B, T)
-    // DW (weight-gradient waves, below)
-    const float* Xl;     // (B, 64, T) input of layer l
-    const float* Zl;     // (B, 64, T) gate output z of layer l
-    float* dwp;          // [workgroup][128][K*64]  partial dW_dil of layer l
-    float* dwrp;         // [workgroup][64][64]     partial dW_res of layer l (unused when dXn == NULL)
-    float* rsp;          // [workgroup][128]        partial row sums of dP_l
-    float* rsrp;         // [workgroup][64]         partial row sums of dX_{l+1}
 };
 
 // 8 fp32 values -> the three bf16 pieces of the lane's share of a 16-k block
@@ -1503,214 +1538,23 @@ static __device__ __forceinline__ void split8v(const float (&x)[8], bool ok, wn_
     split8(y, bf);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Weight-gradient waves of the chain kernel (k_chain64s<..., DW = true>; round 3).
-//
-// The weight gradients of layer l contract over TIME the very tensors the chain launch of layer l streams anyway:
-//   dW_dil,l[tap][o][i] = sum_t dP_l[o][t] x_l[i][t - (K-1-tap) d]      (wavenet.py:201-202 backward)
-//   dW_res,l[c][i]      = sum_t dX_{l+1}[c][t] z_l[i][t]                (wavenet.py:206 backward)
-// As separate contractions (dw_dilated, dw_res) they re-read dP, x, dX, z of all layers from HBM at the end of the
-// backward pass: 320 words per timestep and layer.  Here the workgroup is 4 chain waves + 4 weight-gradient waves (one
-// of each per SIMD): the chain waves walk tiles exactly as before, the other four contract the SAME four tiles of the round
-// while their lines are in the XCD's L2 / the memory-side cache, so only x_l and z_l are new HBM traffic.
-//
-// A tile's contribution is a rank-32 update of a 128 x (K 64) + 64 x 64 matrix: 320 accumulator registers per wave if every
-// wave kept all of it -- so the four waves SHARE the accumulators of the workgroup, wave (oh, ch) owns output rows
-// [64 oh, 64 oh + 64) x column half ch (K = 2: tap ch; K = 1: input channels [32 ch, 32 ch + 32)) of dW_dil and the
-// (32 oh, 32 ch) quadrant of dW_res: 64 + 16 registers, kept across the whole persistent walk and written ONCE per launch as
-// a per-workgroup partial (240 x 80 KB per layer; reduced in a fixed order by wn_reduce -> deterministic).  Time has to be
-// the contraction index, i.e. operands are needed as [lane = channel][8 consecutive samples]: that is a plain 2 x 16-byte
-// load per lane from the (B, C, T) tensors -- no transposition, no LDS -- split into the three bf16 pieces in registers.
-// Every operand exists before the launch starts (dP_l was written by the previous launch), so the two kinds of waves never
-// synchronise on data; an LDS round counter only keeps the weight-gradient waves from running ahead of their chain waves.
-// ---------------------------------------------------------------------------------------------
-#ifndef WN_DW_PRIO
-#define WN_DW_PRIO 1
-#endif
-// 8 consecutive samples of this lane's row: `v` = the lane's byte offset inside the 32-row block (row * T + first sample) or
-// WN_VOFF_DEAD (the range check then answers 0 without touching memory: no branches around loads), `soff_row` >= 0 the
-// block's wave-uniform byte offset.  Two 16-byte loads; only 4-byte alignment is needed (shifted taps).
-static __device__ __forceinline__ void dw_load8(const wn_rsrc_t& R, int v, int soff_row, float (&x)[8]) {
-    const float4 a = wn_buf_load4(R, v, (unsigned)soff_row), b = wn_buf_load4(R, v == WN_VOFF_DEAD ? v : v + 16, (unsigned)soff_row);
-    x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
-}
-static __device__ __forceinline__ f32x16 dw_mfma6(const wn_f4 (&af)[3], const wn_f4 (&bf)[3], f32x16 acc) {
-    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};  // small terms first
-    WN_UNROLL
-    for (int t6 = 0; t6 < 6; ++t6) acc = mfma_bf16(af[PA[t6]], bf[PB[t6]], acc);
-    return acc;
-}
-
-// operands of one 16-sample k-block of one tile for this wave
-template <int K>
-struct DwOps {
-    float xa[2][8], xb[K][8], xr[2][8];
-};
-
-template <int K>
-static __device__ __forceinline__ void chain_dw_role(const ChainArgs& a, int w4, const char* round_flag) {
-    const int lane = threadIdx.x & 63;
-    const int li = lane & 31, hi = lane >> 5;
-    const int T = a.T, T4 = T * 4;
-    const int tiles_per_b = (T + 31) >> 5;
-    const int ntiles = a.B * tiles_per_b;
-    const TileWalk walk = tile_walk(ntiles, 0, 4);   // the tiles of chain wave 0; chain wave j takes the j-th next one
-    const int oh = w4 >> 1, ch = w4 & 1;
-    const bool has_res = a.dXn != nullptr;
-    const float* dXn = has_res ? a.dXn : a.Xl;   // dXn == NULL (top launch): the res part runs on dummy operands, unwritten
-    f32x16 acc[2][K], accr = f32x16_zero();
-    WN_UNROLL
-    for (int rb = 0; rb < 2; ++rb) {
-        WN_UNROLL
-        for (int j = 0; j < K; ++j) acc[rb][j] = f32x16_zero();
-    }
-    float rs[2] = {0.0f, 0.0f}, rsr = 0.0f;
-    const int vrow = (li * T + 8 * hi) * 4;   // this lane's row and k half inside a 32-row block
-    WN_PRIO(WN_DW_PRIO);
-
-    // Requests of k-block `idx` (0..7: tile idx >> 1 of the round that starts at tile `base`, half idx & 1).  No branches: a
-    // k-block outside the walk or the sequence, and a lane whose 8 samples lie in the zero history in front of the sequence,
-    // carry the dead offset (their operands read as 0 and contribute nothing).  A shifted tap with 0 < shift < 8 cuts the 8
-    // samples of the hi = 0 lanes of a sequence's FIRST k-block: those lanes are dead here and added by dw_fixup below.
-    auto issue = [&](int base, int idx, DwOps<K>& o) {
-        const int tile = WN_UNIFORM(base + (idx >> 1));
-        const bool tv = tile < walk.end;
-        const int tl = tv ? tile : 0;
-        const int b = tl / tiles_per_b;
-        const int tk = (tl - b * tiles_per_b) * 32 + 16 * (idx & 1);
-        const bool kv = tv && tk < T;   // T % 16 == 0 (launcher): a k-block is inside the sequence or outside it
-        const wn_rsrc_t Pr = wn_make_buf(a.dP + (long)b * 128 * T, (unsigned)(128 * T4));
-        const wn_rsrc_t Xr = wn_make_buf(a.Xl + (long)b * 64 * T, (unsigned)(64 * T4));
-        const wn_rsrc_t Dr = wn_make_buf(dXn + (long)b * 64 * T, (unsigned)(64 * T4));
-        const wn_rsrc_t Zr = wn_make_buf(a.Zl + (long)b * 64 * T, (unsigned)(64 * T4));
-        const int v0 = kv ? vrow + tk * 4 : WN_VOFF_DEAD;
-        WN_UNROLL
-        for (int rb = 0; rb < 2; ++rb) dw_load8(Pr, v0, (64 * oh + 32 * rb) * T4, o.xa[rb]);
-        WN_UNROLL
-        for (int j = 0; j < K; ++j) {
-            const int cbg = ch * K + j, tap = cbg >> 1, ih = cbg & 1;
-            const int lead = tk - (K - 1 - tap) * a.dil;              // first sample of the hi = 0 lanes
-            const bool ok = kv && (lead + 8 * hi >= 0);   // the lane's 8 samples are inside the sequence (else: zero history / fixup)
-            dw_load8(Xr, ok ? vrow + lead * 4 : WN_VOFF_DEAD, 32 * ih * T4, o.xb[j]);
-        }
-        dw_load8(Dr, v0, 32 * oh * T4, o.xr[0]);
-        dw_load8(Zr, v0, 32 * ch * T4, o.xr[1]);
-    };
-    auto compute = [&](const DwOps<K>& o) {
-        wn_f4 bfb[K][3];
-        WN_UNROLL
-        for (int j = 0; j < K; ++j) split8(o.xb[j], bfb[j]);
-        WN_UNROLL
-        for (int rb = 0; rb < 2; ++rb) {
-            wn_f4 bfa[3];
-            split8(o.xa[rb], bfa);
-            WN_UNROLL
-            for (int e = 0; e < 8; ++e) rs[rb] += o.xa[rb][e];
-            WN_UNROLL
-            for (int j = 0; j < K; ++j) acc[rb][j] = dw_mfma6(bfa, bfb[j], acc[rb][j]);
-        }
-        wn_f4 bfa[3], bfz[3];
-        split8(o.xr[0], bfa);
-        split8(o.xr[1], bfz);
-        WN_UNROLL
-        for (int e = 0; e < 8; ++e) rsr += o.xr[0][e];
-        accr = dw_mfma6(bfa, bfz, accr);
-    };
-
-    // software pipeline, one k-block ahead: the requests of block i + 1 are in flight while block i is split and contracted
-    // (two operand sets with static names: no copies of registers that are still being loaded)
-    DwOps<K> o0, o1;
-    int round = 0;
-    int base_v = walk.first;
-    if (base_v < walk.end) issue(base_v, 0, o0);
-    for (; base_v < walk.end; base_v += walk.step, ++round) {
-        const int base = WN_UNIFORM(base_v);
-#ifndef WN_DIAG_DW_ONLY
-        while (wn_lds_flag_read(round_flag) < round) WN_SLEEP(4);   // not ahead of the chain waves: their loads and ours share cache lines
-#endif
-        WN_UNROLL
-        for (int idx = 0; idx < 8; idx += 2) {
-            issue(base, idx + 1, o1);
-            compute(o0);
-            if (idx + 2 < 8) issue(base, idx + 2, o0);
-            else issue(base + walk.step, 0, o0);    // first block of the next round (dead past the end of the walk)
-            compute(o1);
-        }
-    }
-
-    // The hi = 0 lanes of a sequence's first k-block under a tap shifted by 0 < shift < 8 samples (K = 2, dilations 1, 2, 4; tap 0):
-    // samples [-shift, 8 - shift) straddle the start of the sequence.  Rare (one k-block per sequence), so outside the loop:
-    // the wave whose walk holds the sequence's first tile adds the valid samples, per-sample validity, hi = 1 lanes zero.
-    const int shift0 = (K - 1) * a.dil;   // shift of tap 0
-    if (K > 1 && ch == 0 && shift0 > 0 && shift0 < 8) {
-        for (int b = 0; b < a.B; ++b) {
-            const int tb = b * tiles_per_b, rel = tb - walk.first;
-            if (tb >= walk.end || rel < 0 || rel % walk.step >= 4) continue;   // (uniform) not a tile of this workgroup's walk
-            const wn_rsrc_t Pr = wn_make_buf(a.dP + (long)b * 128 * T, (unsigned)(128 * T4));
-            const wn_rsrc_t Xr = wn_make_buf(a.Xl + (long)b * 64 * T, (unsigned)(64 * T4));
-            WN_UNROLL
-            for (int j = 0; j < K; ++j) {   // this wave's column blocks are tap 0's two input-channel halves
-                float xb[8];
-                WN_UNROLL
-                for (int e = 0; e < 8; ++e)
-                    xb[e] = wn_buf_load(Xr, (hi == 0 && e - shift0 >= 0) ? vrow + (e - shift0) * 4 : WN_VOFF_DEAD, 32 * j * T4);
-                wn_f4 bfb[3];
-                split8(xb, bfb);
-                WN_UNROLL
-                for (int rb = 0; rb < 2; ++rb) {
-                    float xa[8];
-                    dw_load8(Pr, vrow, (64 * oh + 32 * rb) * T4, xa);
-                    wn_f4 bfa[3];
-                    split8(xa, bfa);
-                    acc[rb][j] = dw_mfma6(bfa, bfb, acc[rb][j]);
-                }
-            }
-        }
-    }
-
-    // the workgroup's partial sums: [128][K*64], [64][64], row sums [128], [64]
-    const int NC = K * 64;
-    float* dw = a.dwp + (long)blockIdx.x * 128 * NC;
-    WN_UNROLL
-    for (int rb = 0; rb < 2; ++rb) {
-        WN_UNROLL
-        for (int j = 0; j < K; ++j) {
-            WN_UNROLL
-            for (int r = 0; r < 16; ++r)
-                dw[(long)(64 * oh + 32 * rb + mfma32_row(r, hi)) * NC + 32 * (ch * K + j) + li] = acc[rb][j][r];
-        }
-    }
-    if (ch == 0) {
-        WN_UNROLL
-        for (int rb = 0; rb < 2; ++rb) {
-            const float v = rs[rb] + __shfl_xor(rs[rb], 32, 64);
-            if (hi == 0) a.rsp[(long)blockIdx.x * 128 + 64 * oh + 32 * rb + li] = v;
-        }
-    }
-    if (has_res) {
-        float* dr = a.dwrp + (long)blockIdx.x * 64 * 64;
-        WN_UNROLL
-        for (int r = 0; r < 16; ++r) dr[(32 * oh + mfma32_row(r, hi)) * 64 + 32 * ch + li] = accr[r];
-        if (ch == 0) {
-            const float v = rsr + __shfl_xor(rsr, 32, 64);
-            if (hi == 0) a.rsrp[(long)blockIdx.x * 64 + 32 * oh + li] = v;
-        }
-    }
-}
-
 // HEAD = true: the top of the chain.  The last layer's residual output is dead (wavenet.py:231-238), so dP_{L-1} is the gate'
 // epilogue alone on dZs_{L-1} (which bwd_dz_skip_all now produces for ALL layers): no taps, no Wres^T, no dX -- its own
 // instantiation, so that the main one compiles exactly as before.
-template <int AUX, int K, bool HEAD = false, bool DW = false>
+template <int AUX, int K, bool HEAD = false>
 __global__ __launch_bounds__(WN_LB) void k_chain64s(ChainArgs a) {
     WN_DYN_SMEM(smem_raw);
     char* W = smem_raw;                      // tap blocks: chunk q (32 channels) = tap q % K, channel group q / K; 2 blocks of 6 KB each
     constexpr int NCH = K * 4;               // chunks of the dX part
     char* Wr = W + NCH * 2 * 6144;           // Wres^T: 4 blocks [piece][64 rows][16 k], k order = accumulator register order
-    char* round_flag = Wr + WN_RES_T_BYTES;   // DW: the round the chain waves are in
-    if (DW && threadIdx.x == 0) wn_lds_flag_write(round_flag, -1);
+    // K = 3: the taps alone fill the LDS (144 KB); the Wres^T fragments (24 KB, L2 resident) are read from the pre-split image
+    // in global memory, one 16-k block ahead of their MFMAs (the launcher only takes K = 3 with images)
+    constexpr bool RG = (K >= 3);
     if (HEAD) {
         // no weights
+    } else if (RG) {
+        copy_image_to_lds(W, a.img_taps, chain_taps_bytes(K));
+        WN_WAIT_VMCNT(0);
     } else if (a.img_taps != nullptr) {   // pre-split once per step (wn_fused_pack_images): two straight global -> LDS copies
         copy_image_to_lds(W, a.img_taps, chain_taps_bytes(K));
         copy_image_to_lds(Wr, a.img_res, WN_RES_T_BYTES);
@@ -1720,28 +1564,14 @@ __global__ __launch_bounds__(WN_LB) void k_chain64s(ChainArgs a) {
         fill_res_t(Wr, a.wres, threadIdx.x, WN_FT);
     }
     __syncthreads();
-    if (DW) {   // waves 4..7: the weight gradients of this layer (chain_dw_role); waves 0..3 walk the tiles
-        const int wv = WN_UNIFORM((int)(threadIdx.x >> 6));
-        if (wv >= 4) {
-#ifndef WN_DIAG_CHAIN_ONLY   // (timing builds: one of the two roles alone -- results are wrong, the time is the point)
-            chain_dw_role<K>(a, wv - 4, round_flag);
-#endif
-            return;
-        }
-#ifdef WN_DIAG_DW_ONLY
-        return;
-#endif
-    }
-
     const int lane = threadIdx.x & 63;
     const int li = lane & 31, hi = lane >> 5;
     const int T = a.T;
     const int T4 = T * 4;
     const int tiles_per_b = (T + 31) >> 5;
     const int ntiles = a.B * tiles_per_b;
-    const TileWalk walk = tile_walk(ntiles, threadIdx.x >> 6, DW ? 4 : WN_FW);
+    const TileWalk walk = tile_walk(ntiles, threadIdx.x >> 6);
     const int step = walk.step, tile_end = walk.end;
-    int dw_round = 0;
 
     float xa[16], xb[16];
     bool oka = false, okb = false;
@@ -1790,7 +1620,6 @@ __global__ __launch_bounds__(WN_LB) void k_chain64s(ChainArgs a) {
     }
     while (tile_v < tile_end) {
         const int tile = WN_UNIFORM(tile_v);
-        if (DW && threadIdx.x == 0) wn_lds_flag_write(round_flag, dw_round++);   // chain wave 0 owns the first tile of every round
         const int b = tile / tiles_per_b;
         const int t = (tile - b * tiles_per_b) * 32 + li;
         const bool inb = t < T;
@@ -1882,6 +1711,24 @@ __global__ __launch_bounds__(WN_LB) void k_chain64s(ChainArgs a) {
             // dX_l of this tile is finished in the accumulator layout: register r of lane (li, hi) = channel 32q + row(r, hi)
             WN_SCHED_BARRIER();
             // dZ += Wres^T dX: k-step e of block kb takes accumulator register 8 (kb & 1) + e of row tile kb >> 1
+            const wn_rsrc_t Ir = wn_make_buf(a.img_res, (unsigned)(RG ? WN_RES_T_BYTES : 16));
+            const int vfrag = wn_frag_off(li, hi);
+            auto res_frags = [&](int kb, wn_f4 (&af)[2][3]) {
+                WN_UNROLL
+                for (int rt = 0; rt < 2; ++rt) {
+                    WN_UNROLL
+                    for (int p = 0; p < 3; ++p) {
+                        if (RG) {
+                            const float4 f = wn_buf_load4(Ir, vfrag, (unsigned)(kb * 6144 + p * 2048 + rt * 1024));
+                            af[rt][p] = wn_f4{f.x, f.y, f.z, f.w};
+                        } else {
+                            af[rt][p] = *reinterpret_cast<const wn_f4*>(Wr + kb * 6144 + vfrag + p * 2048 + rt * 1024);
+                        }
+                    }
+                }
+            };
+            wn_f4 afr[2][2][3];
+            res_frags(0, afr[0]);
             WN_UNROLL
             for (int kb = 0; kb < 4; ++kb) {
                 float x8[8];
@@ -1889,18 +1736,12 @@ __global__ __launch_bounds__(WN_LB) void k_chain64s(ChainArgs a) {
                 for (int e = 0; e < 8; ++e) x8[e] = acc[kb >> 1][8 * (kb & 1) + e];
                 wn_f4 bf[3];
                 split8(x8, bf);
-                const char* Wl = Wr + kb * 6144 + wn_frag_off(li, hi);
-                wn_f4 af[2][3];
-                WN_UNROLL
-                for (int rt = 0; rt < 2; ++rt) {
-                    WN_UNROLL
-                    for (int p = 0; p < 3; ++p) af[rt][p] = *reinterpret_cast<const wn_f4*>(Wl + p * 2048 + rt * 1024);
-                }
+                if (kb + 1 < 4) res_frags(kb + 1, afr[(kb + 1) & 1]);
                 constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
                 WN_UNROLL
                 for (int t6 = 0; t6 < 6; ++t6) {
-                    dz[0] = mfma_bf16(af[0][PA[t6]], bf[PB[t6]], dz[0]);
-                    dz[1] = mfma_bf16(af[1][PA[t6]], bf[PB[t6]], dz[1]);
+                    dz[0] = mfma_bf16(afr[kb & 1][0][PA[t6]], bf[PB[t6]], dz[0]);
+                    dz[1] = mfma_bf16(afr[kb & 1][1][PA[t6]], bf[PB[t6]], dz[1]);
                 }
             }
             WN_SCHED_BARRIER();
@@ -1981,58 +1822,42 @@ __global__ __launch_bounds__(WN_LB) void k_chain64s(ChainArgs a) {
 }
 
 int wn_fused_chain_supported(int R, int K, int S) {
-    return wn_fused_supported(R, K, S) && K >= 1 && K <= 2 && (size_t)(K * 8 + 4) * 6144 + 16 <= 160 * 1024;
-}
-
-// workgroups of a DW launch (4 tile-walking waves each): what the workspace / the reduction of the partials is sized by
-int wn_fused_chain_dw_blocks(int B, int T) {
-    const long ntiles = (long)B * ((T + 31) / 32);
-    return (int)balanced_blocks(ntiles, 4);
+    return wn_fused_supported(R, K, S) && K >= 1 && K <= 3 && (size_t)(K * 8 + (K >= 3 ? 0 : 4)) * 6144 <= 160 * 1024;
 }
 
 int wn_fused_bwd_chain(const float* wd_b, const float* dP, const float* dXn, float* dX, const float* wres_prev, const float* dZs,
                        long zs_bstride, const float* S, const float* Gt, int gt_is_z, float* dP_prev, const float* G, long g_bstride,
                        const float* upw, int U, int F, float* dGp, float* qp, int B, int T, int K, int dilation,
-                       const float* img_taps, const float* img_res, int zs_t0, const float* Xl, const float* Zl, float* dwp,
-                       float* dwrp, float* rsp, float* rsrp, wn_stream_t st) {
+                       const float* img_taps, const float* img_res, int zs_t0, wn_stream_t st) {
     // dP (, dXn), dZs, S, Gt in; dX, dP_prev out (+ dGp 8 / qp 1 words per timestep with the aux partials)
     const bool aux = dGp != nullptr;
-    const bool dw = dwp != nullptr;
-    WN_PROF(dw ? "fused_bwd_chain_dw" : "fused_bwd_chain",
-            2.0 * (double)B * T * 64.0 * (K * 128.0 + 64.0) + (dw ? 2.0 * (double)B * T * (128.0 * K * 64.0 + (dXn ? 4096.0 : 0.0)) : 0.0),
-            4.0 * (double)B * T * (128.0 + (dXn ? 64.0 : 0.0) + 64.0 + 128.0 + 64.0 + 128.0 + (aux ? 9.0 : 0.0) + (dw ? 128.0 : 0.0)), st);
-    if (K < 1 || K > 2) return 1;
+    WN_PROF("fused_bwd_chain", 2.0 * (double)B * T * 64.0 * (K * 128.0 + 64.0),
+            4.0 * (double)B * T * (128.0 + (dXn ? 64.0 : 0.0) + 64.0 + 128.0 + 64.0 + 128.0 + (aux ? 9.0 : 0.0)), st);
+    if (K < 1 || K > 3) return 1;
     if (aux && (U < 16 || (U & 15) || (T & 15) || (long)U * F != T)) return 1;
-    if (dw && ((T & 15) || !Xl || !Zl || !dwrp || !rsp || !rsrp || WN_FT != 512)) return 1;
+    if (K == 3 && !(img_taps && img_res)) return 1;   // K = 3 reads the Wres^T fragments from the image
     ChainArgs a;
     a.img_taps = (img_taps && img_res) ? img_taps : nullptr; a.img_res = img_res;
     a.wd_b = wd_b; a.dP = dP; a.dXn = dXn; a.dX = dX;
     a.wres = wres_prev; a.dZs = dZs; a.zs_bstride = zs_bstride; a.zs_t0 = zs_t0; a.S = S; a.Gt = Gt; a.gz = gt_is_z; a.dPm = dP_prev;
     a.B = B; a.T = T; a.K = K; a.dil = dilation;
     a.G = G; a.g_bstride = g_bstride; a.upw = upw; a.U = U; a.F = F; a.dGp = dGp; a.qp = qp;
-    a.Xl = Xl; a.Zl = Zl; a.dwp = dwp; a.dwrp = dwrp; a.rsp = rsp; a.rsrp = rsrp;
     const long ntiles = (long)B * ((T + 31) / 32);
-    const long nblk = dw ? balanced_blocks(ntiles, 4) : balanced_blocks(ntiles);
-    const size_t lds = (size_t)(K * 8 + 4) * 6144 + 16;   // + the round counter of the DW waves
-#define WN_CHAIN_LAUNCH(AUXV, KV, DWV)                                                                    \
-    do {                                                                                                  \
-        if (set_lds(k_chain64s<AUXV, KV, false, DWV>, lds)) return 1;                                     \
-        WN_LAUNCH((k_chain64s<AUXV, KV, false, DWV>), dim3((unsigned)nblk), dim3(WN_FT), lds, st, a);     \
+    const long nblk = balanced_blocks(ntiles);
+    const size_t lds = (size_t)(K * 8 + (K >= 3 ? 0 : 4)) * 6144;
+#define WN_CHAIN_LAUNCH(AUXV, KV)                                                                       \
+    do {                                                                                                \
+        if (set_lds(k_chain64s<AUXV, KV>, lds)) return 1;                                               \
+        WN_LAUNCH((k_chain64s<AUXV, KV>), dim3((unsigned)nblk), dim3(WN_FT), lds, st, a);               \
     } while (0)
-    if (dw) {
-        if (aux) {
-            if (K == 1) WN_CHAIN_LAUNCH(1, 1, true);
-            else WN_CHAIN_LAUNCH(1, 2, true);
-        } else {
-            if (K == 1) WN_CHAIN_LAUNCH(0, 1, true);
-            else WN_CHAIN_LAUNCH(0, 2, true);
-        }
-    } else if (aux) {
-        if (K == 1) WN_CHAIN_LAUNCH(1, 1, false);
-        else WN_CHAIN_LAUNCH(1, 2, false);
+    if (aux) {
+        if (K == 1) WN_CHAIN_LAUNCH(1, 1);
+        else if (K == 2) WN_CHAIN_LAUNCH(1, 2);
+        else WN_CHAIN_LAUNCH(1, 3);
     } else {
-        if (K == 1) WN_CHAIN_LAUNCH(0, 1, false);
-        else WN_CHAIN_LAUNCH(0, 2, false);
+        if (K == 1) WN_CHAIN_LAUNCH(0, 1);
+        else if (K == 2) WN_CHAIN_LAUNCH(0, 2);
+        else WN_CHAIN_LAUNCH(0, 3);
     }
 #undef WN_CHAIN_LAUNCH
     return 0;

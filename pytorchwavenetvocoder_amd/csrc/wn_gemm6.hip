@@ -114,14 +114,7 @@ __device__ inline WnBlock wn_block_order(int order) {
     }
     return r;
 }
-static int xcd_block_order() {   // WN_XCD_ORDER=0: plain blockIdx in both kernels (A/B)
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("WN_XCD_ORDER");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v;
-}
+static int xcd_block_order() { return 1; }   // (measured against plain blockIdx: PMC 43.3 -> 38.9 GB per step, profiles/r02)
 
 // Timing builds only (tools/gemm_timing.py, -DWN_TIMING): cycle stamps of the k-loop phases, waves of the block that
 // gets logical tile (0, 0, 0), first 24 steps, for the launches whose tag was selected with wn_debug_gemm6().
@@ -599,35 +592,19 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
 
 int wn_gemm6_launch(const WnGemm6Args* gp, wn_stream_t st) {
     WnGemm6Args g = *gp;
-    {   // tuning knob (A/B on hardware): WN_G6_INTERIOR=0 -> every block takes the general (range-checked) epilogue
-        static int v = -1;
-        if (v < 0) {
-            const char* e = getenv("WN_G6_INTERIOR");
-            v = (e && atoi(e) == 0) ? 0 : 1;
-        }
-        g.no_interior = v ? 0 : 1;
-    }
-    {   // WN_G6_STAGGER=<percent of a block's k-loop> (default 50; 0 = off), see k_gemm6.  Only for short contractions
+    g.no_interior = 0;
+    {   // head start of a CU's first block over its co-resident: 50 % of a block's k-loop, see k_gemm6.  Only for short contractions
         // (K <= 512: the post-net and the all-layer skip gradient, 16 steps per block), where a block's prologue and epilogue
         // are a third of its life; measured on MI355X (profiles/r02/ab_probe_loss_window_stagger.txt): bwd_post{1,2}_dx
         // 0.172 -> 0.147 ms each, while the long skip-sum (120 steps per block) only pays for the late start (+0.04 ms).
-        static int pct = -1;
-        if (pct < 0) {
-            const char* e = getenv("WN_G6_STAGGER");
-            pct = e ? atoi(e) : 50;
-            if (pct < 0) pct = 0;
-        }
+        const int pct = 50;
         // ~4000 cycles per 16-k step with two blocks per CU; one s_sleep(127) = 8128 cycles
         g.stagger = g.K <= 512 ? (int)(((long)pct * ((g.K + 15) / 16) * 4000L) / (100L * 8128L)) : 0;
     }
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.nbatch <= 0) return 1;
     if (g.b_seg_len < g.K && (g.b_seg_len % 16) != 0) return 2;
     if (g.ce_target && (g.Mpad != WN_G6_BM || !g.ce_partial || g.gate_S || g.gbw_dP || g.E || g.D || g.accumulate || g.relu)) return 4;
-#ifdef WN_TIMING
-    const int lds = getenv("WN_G6_ONE_PER_CU") ? 120 * 1024 : 2 * (3 * WN_G6_BM * 32 + 3 * WN_G6_BN * 32);   // experiment: no second block on the CU
-#else
     constexpr int lds = 2 * (3 * WN_G6_BM * 32 + 3 * WN_G6_BN * 32);
-#endif
 #ifndef WN_EMU
     static bool attr_set = false;
     if (!attr_set) {
@@ -997,16 +974,9 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 4 ? 2 : 3)) void k_gemm6_dw(WnGemm
 
 // 256-row tiles for the weight gradients of wide models (>= 512 x 512 outputs: n_resch = 512 gives -2 % per step,
 // profiles/r02/ab_probe_dw_tall.txt); at 256 output rows (skip / post-net gradients of the 64/256 model) they measured
-// 0.06 - 0.1 ms SLOWER than 128 x 128 tiles at 3 workgroups per CU, so those keep the square tile.  Tuning knob
-// WN_DW_TALL=0: square tiles everywhere.  The split-K plan of the caller must use the same rule.
-int wn_gemm6_dw_tall(int M, int N) {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("WN_DW_TALL");
-        v = (e && atoi(e) == 0) ? 0 : 1;
-    }
-    return v && M >= 512 && (M % 256 == 0) && N >= 512;
-}
+// 0.06 - 0.1 ms SLOWER than 128 x 128 tiles at 3 workgroups per CU, so those keep the square tile.  The split-K plan of
+// the caller must use the same rule.
+int wn_gemm6_dw_tall(int M, int N) { return M >= 512 && (M % 256 == 0) && N >= 512; }
 
 int wn_gemm6_dw_eligible(const WnGemmArgs* g) {
     return g->a_kmajor && g->b_kmajor && !g->b_index && !g->bias && !g->D && !g->E && !g->relu && !g->accumulate &&

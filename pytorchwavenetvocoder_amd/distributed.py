@@ -29,14 +29,25 @@ def rccl_footprint_defaults():
 class GradientReducer(object):
     def __init__(self, model, process_group=None, layers_per_bucket=None):
         """``layers_per_bucket``: residual layers per gradient bucket = per weight-gradient launch group of wn_backward.
-        Default: all of them, i.e. three buckets [post-net + skip] [residual layers] [front + upsampling] -- the
-        weight-gradient contractions are most efficient as ONE layer-batched launch per tensor kind (groups of 10 layers
-        measured +0.17 ms per step on MI355X, profiles/r02/ab_probe.txt), and the first bucket (40 % of the bytes) still
-        travels under the whole backward chain, the second under the front-conv / upsampling gradients."""
+        Default (None): chosen by the size of the gradient.
+          * small models (the BASELINE 64 / 256 model: 6.4 MB): ALL layers in one bucket, i.e. three buckets
+            [post-net + skip] [residual layers] [front + upsampling].  Measured on MI355X at N = 1
+            (profiles/r03/visit3_chain_dw_pipelined_lpb_chainpairdiff.txt): 10.42 ms per step with one layer bucket, 10.49 with
+            two (15 layers each), 10.64 with three -- the weight-gradient contractions are most efficient as ONE layer-batched
+            launch per tensor kind.  What a split would hide is the all-reduce of the 3.7 MB layer bucket, a latency-bound
+            ring of ~0.1 ms over xGMI: splitting costs as much compute as it could hide, so it is not done; the first bucket
+            (40 % of the bytes) travels under the whole backward chain either way.
+          * large models (gradient above 32 MB; the recipe-size 512 / 256 model: 185 MB, ~2 - 3 ms of ring time against a
+            131 ms step): groups of 10 layers, so that two thirds of the layer gradients travel under the rest of the chain;
+            at that width the launch-group cost is below 0.5 % of the step."""
         self.model = model
         self.group = process_group
         self.eng = model.engine
-        self.lpb = int(layers_per_bucket) if layers_per_bucket else int(self.eng.n_layers)
+        if layers_per_bucket:
+            self.lpb = int(layers_per_bucket)
+        else:
+            big = 4 * int(self.eng.n_params) > 32 * 1024 * 1024
+            self.lpb = min(10, int(self.eng.n_layers)) if big else int(self.eng.n_layers)
         self.ranges = self.eng.bucket_ranges(self.lpb)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.cuda = self.eng.device.type == "cuda"

@@ -197,8 +197,7 @@ def test_persistent_tile_loop_several_tiles_per_wave():
         "for fl in (0, _lib.FLAG_AUX_FUSED):\n"
         "    e, g = PC.run_oracle_vs_engine((32, 4, 64, 32, 2, 1, 2, 16), 1, 2304, 51, emu_library(), 'cpu', flags=fl, scale=0.2)\n"
         "    print('flags', fl, 'logits', e, 'grads', g)\n"
-        # dilations up to 64 (history taps 1 / 2 tiles back), 100 tiles on 64 waves (32 chain waves with the weight-gradient
-        # waves of the chain launches): several rounds per wave, a partial last round
+        # dilations up to 64 (history taps 1 / 2 tiles back), 100 tiles on 64 waves : several rounds per wave, a partial last round
         "e, g = PC.run_oracle_vs_engine((32, 4, 64, 32, 7, 1, 2, 16), 1, 3200, 52, emu_library(), 'cpu', flags=_lib.FLAG_AUX_FUSED, scale=0.2)\n"
         "print('flags chains', 'logits', e, 'grads', g)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     env = dict(os.environ, WN_CHAIN_BLOCKS="8")
@@ -312,6 +311,19 @@ def test_backward_chain_kernel_modes():
     PC.run_oracle_vs_engine((64, 6, 64, 32, 2, 2, 2, 16), 3, 80, 42, emu_library(), "cpu", flags=A, scale=0.2)   # T % 32 == 16
     PC.run_oracle_vs_engine((64, 6, 64, 64, 3, 2, 2, 0), 1, 70, 43, emu_library(), "cpu", flags=A, scale=0.2)    # no upsampling, ragged T
     PC.run_oracle_vs_engine((64, 6, 64, 32, 1, 1, 2, 16), 1, 32, 44, emu_library(), "cpu", flags=A, scale=0.2)   # a single layer
+    # kernel_size 3 (round 3: split forward block and chain kernel with the res-1x1 fragments read from the global weight
+    # image, the three taps filling the LDS): dilations up to 64 = history taps up to 4 tiles back, with and without aux partials
+    PC.run_oracle_vs_engine((64, 6, 64, 32, 7, 1, 3, 16), 1, 288, 46, emu_library(), "cpu", flags=A, scale=0.15)
+    PC.run_oracle_vs_engine((64, 6, 64, 32, 2, 2, 3, 0), 2, 48, 47, emu_library(), "cpu", flags=0, scale=0.2)
+    eng3 = WaveNetEngine(64, 6, 64, 32, 2, 2, 3, 16, device="cpu", library=emu_library())
+    load_state_into_flat(eng3, O.random_params(O.OracleConfig(64, 6, 64, 32, 2, 2, 3, 16), 3, scale=0.1))
+    x3, h3, t3 = O.synthetic_batch(O.OracleConfig(64, 6, 64, 32, 2, 2, 3, 16), 1, 64, 4)
+
+    def step3():
+        loss3, dl3 = eng3.forward_loss(x3, h3, t3)
+        eng3.backward(dl3, t_first=eng3.receptive_field)
+    log3 = PC.launch_log(emu_library(), step3)
+    assert log3.get("fused_bwd_chain") == 3 and log3.get("fused_resblock_fwd") == 4 and log3.get("fused_bwd_dx") == 1, log3
     cfg_t = (64, 6, 64, 32, 3, 2, 2, 16)
     cfg = O.OracleConfig(*cfg_t)
     params, x, h, t, margin, sd = PC.pick_instance(cfg, 2, 96, 45, 0.2)
@@ -373,8 +385,7 @@ def test_launch_sequence_of_the_default_training_step():
     cfg = O.OracleConfig(*cfg_t)
     x, h, t = O.synthetic_batch(cfg, 1, 64, 2)
     logs = {}
-    NDW = _lib.FLAG_NO_CHAIN_DW
-    for flags in (_lib.FLAG_AUX_FUSED, _lib.FLAG_AUX_FUSED | NDW, _lib.FLAG_AUX_FUSED | _lib.FLAG_NO_CHAIN):
+    for flags in (_lib.FLAG_AUX_FUSED, _lib.FLAG_AUX_FUSED | _lib.FLAG_NO_CHAIN):
         eng = WaveNetEngine(*cfg_t, device="cpu", library=emu_library())
         eng.flags = flags
         load_state_into_flat(eng, O.random_params(cfg, 1, scale=0.1))
@@ -384,47 +395,17 @@ def test_launch_sequence_of_the_default_training_step():
             loss, dl = eng.loss(logits, t)
             eng.backward(dl)
         logs[flags] = PC.launch_log(emu_library(), step)
-    d, a, b = logs[_lib.FLAG_AUX_FUSED], logs[_lib.FLAG_AUX_FUSED | NDW], logs[_lib.FLAG_AUX_FUSED | _lib.FLAG_NO_CHAIN]
-    # default (round 3): the chain launches carry the weight-gradient waves; only layer 0 (no chain launch) still contracts
-    assert d["fused_resblock_fwd"] == 6 and d["fused_bwd_chain_dw"] == 5 and "fused_bwd_chain" not in d, d
-    assert d["fused_bwd_gate"] == 1 and d["fused_bwd_dx"] == 1 and d["dw_dilated"] == 1 and d["dw_res"] == 1, d
+    a, b = logs[_lib.FLAG_AUX_FUSED], logs[_lib.FLAG_AUX_FUSED | _lib.FLAG_NO_CHAIN]
     assert a["fused_resblock_fwd"] == 6 and a["fused_bwd_chain"] == 5 and a["fused_bwd_gate"] == 1 and a["fused_bwd_dx"] == 1, a
     assert a["bwd_dz_skip_all"] == 1 and a["fused_pack_images"] == 1 and "aux_bwd" not in a and a["aux_finish"] >= 1, a
     assert b["fused_bwd_gate"] == 6 and b["fused_bwd_dx"] == 6 and "fused_bwd_chain" not in b and "bwd_dz_skip_all" not in b, b
-
-
-def test_weight_gradient_waves_of_the_chain_launch():
-    """Round 3: four of the eight waves of a chain workgroup contract dW_dil / dW_res of the layer over time
-    (csrc/wn_fused.hip chain_dw_role).  Against the layer-batched contractions (WN_FLAG_NO_CHAIN_DW) on the same dP / dX:
-    kernel_size 1 and 2, dilations larger than a tile (zero history inside and across tiles), several sequences, a last
-    tile of 16 samples, gradient buckets; and against the oracle."""
-    from oracle import wavenet_oracle as O
-    from pytorchwavenetvocoder_amd import _lib
-    from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat
-    A, NDW = _lib.FLAG_AUX_FUSED, _lib.FLAG_NO_CHAIN_DW
-    for cfg_t, B, T, lpb in [((64, 6, 64, 32, 7, 1, 2, 16), 2, 208, 0), ((64, 6, 64, 32, 4, 2, 1, 16), 3, 80, 3),
-                             ((64, 6, 64, 32, 3, 1, 2, 0), 1, 48, 0)]:
-        cfg = O.OracleConfig(*cfg_t)
-        params = O.random_params(cfg, 51, scale=0.2)
-        x, h, t = O.synthetic_batch(cfg, B, T, 52)
-        res = []
-        for flags in (A, A | NDW):
-            eng = WaveNetEngine(*cfg_t, device="cpu", library=emu_library())
-            eng.flags = flags
-            load_state_into_flat(eng, params)
-            loss, dl = eng.forward_loss(x, h, t)
-            res.append(eng.backward(dl, t_first=eng.receptive_field, layers_per_bucket=lpb).clone())
-        scale = float(res[1].abs().max())
-        assert float((res[0] - res[1]).abs().max()) <= 2e-6 * scale, (cfg_t, float((res[0] - res[1]).abs().max()) / scale)
-    PC.run_oracle_vs_engine((64, 6, 64, 32, 7, 1, 2, 16), 1, 160, 53, emu_library(), "cpu", flags=A, scale=0.2)
 
 
 def test_gradient_bucket_events_follow_the_launches_that_fill_the_bucket():
     """N > 1 readiness (row e): wn_backward records bucket i's event AFTER the last launch that writes into bucket i and BEFORE
     the chain launches of the layers that follow, so the all-reduce of a finished bucket runs under the rest of the backward
     pass (distributed.GradientReducer waits on exactly these events).  Checked on the issue-order log for the three-bucket
-    structure and for the mid-chain split (two groups of layers): with the weight gradients inside the chain launches a
-    bucket of layers is final as soon as its last chain launch and the small reductions behind it are issued."""
+    structure and for mid-chain splits (groups of layers)."""
     from oracle import wavenet_oracle as O
     from pytorchwavenetvocoder_amd import _lib
     from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat
@@ -433,7 +414,7 @@ def test_gradient_bucket_events_follow_the_launches_that_fill_the_bucket():
     x, h, t = O.synthetic_batch(cfg, 1, 64, 2)
     eng = WaveNetEngine(*cfg_t, device="cpu", library=emu_library())
     load_state_into_flat(eng, O.random_params(cfg, 1, scale=0.1))
-    chain_tags = ("fused_bwd_chain_dw", "fused_bwd_chain", "fused_bwd_gate", "fused_bwd_dx")
+    chain_tags = ("fused_bwd_chain", "fused_bwd_gate", "fused_bwd_dx")
     for lpb, nb in ((0, 3), (3, 4), (2, 5)):
         loss, dl = eng.forward_loss(x, h, t)
         seq = PC.launch_sequence(emu_library(), lambda: eng.backward(dl, events=list(range(1, nb + 1)), layers_per_bucket=lpb,

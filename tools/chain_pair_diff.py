@@ -4,7 +4,7 @@
 biased one?  Runs one backward pass of the config-2 model in three modes on the same batch --
   E: exact f32 MFMA arithmetic (WN_FLAG_EXACT_MFMA: k-ordered fp32 fma chains; launch pair structure) = the reference,
   P: split arithmetic, launch pair (WN_FLAG_NO_CHAIN),
-  C: split arithmetic, chain (default; weight gradients by contraction so that dP / dX are comparable)
+  C: split arithmetic, chain (default)
 and prints per layer, for dP (sigmoid rows / tanh rows) and dX: max |X - E| / max |E| and the MEAN signed difference
 relative to the mean magnitude (a non-zero mean = a systematic bias, which is what a bias gradient -- a sum over 184 320
 positions -- amplifies).      python tools/chain_pair_diff.py [B T]      (GPU)
@@ -29,8 +29,8 @@ def main():
     params = O.random_params(cfg, 101, scale=0.05)
     x, h, t = O.synthetic_batch(cfg, B, T, 102)
     xd, hd, td = x.to(DEV), h.to(DEV), t.to(DEV)
-    A, NDW = L.FLAG_AUX_FUSED, L.FLAG_NO_CHAIN_DW
-    modes = [("E", L.FLAG_EXACT_MFMA), ("P", A | L.FLAG_NO_CHAIN), ("C", A | NDW)]
+    A = L.FLAG_AUX_FUSED
+    modes = [("E", L.FLAG_EXACT_MFMA), ("P", A | L.FLAG_NO_CHAIN), ("C", A)]
     got = {}
     eng = WaveNetEngine(*cfg_t, device=DEV, library=L.load_library())
     load_state_into_flat(eng, params)

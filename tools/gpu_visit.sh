@@ -20,9 +20,9 @@ if has bench; then
 fi
 if has lpb; then
   # same-box A/B, interleaved, two rounds.  A variant is a comma-separated list of environment settings, e.g.
-  #   WN_AB_VARIANTS="WN_DW_TALL=1 WN_DW_TALL=0 WN_ENGINE_FLAGS=96"   (knobs: DESIGN.md 5.2)
+  #   WN_AB_VARIANTS="WN_X=1 WN_ENGINE_FLAGS=96 WN_LIB_PATH=tools/exp/libwn_x.so"   (launch-mode flags / variant builds: DESIGN.md 5.2)
   for rep in 1 2; do
-    for cfg in ${WN_AB_VARIANTS:-WN_DW_TALL=1 WN_DW_TALL=0 WN_WEIGHT_IMAGES=0 WN_ENGINE_FLAGS=96}; do
+    for cfg in ${WN_AB_VARIANTS:-WN_X=1 WN_ENGINE_FLAGS=96}; do
       env $(echo $cfg | tr ',' ' ') timeout 200 python bench.py --repeats 3 --no-cpu-baseline --no-decode --profile-steps 0 > $OUT/bench_ab.json 2>> $OUT/bench.err
       python - <<P
 import json
@@ -60,10 +60,15 @@ if has pmc; then
   bash tools/pmc_traffic.sh
 fi
 if has recipesize; then
-  for v in ${WN_RECIPE_VARIANTS:-WN_GATE_EPILOGUE=0 WN_DW_TALL=0}; do
-    env $v timeout 300 python tools/recipe_bench.py --steps 3 > $OUT/recipe_size_bench_$v.json 2> $OUT/recipe_size_bench.err
-    python -c "import json; d=json.load(open('$OUT/recipe_size_bench_$v.json')); print('recipe size, $v: %.1f ms/step' % d['ms_per_step'])"
-  done
+  # BASELINE configs[3] geometry (kernel_size 3, upsampling 256, T = 26112), softmax head
+  timeout 300 python tools/recipe_bench.py --resch 64 --kernel-size 3 --upsampling 256 --T 26112 --batch 8 --steps 10 > $OUT/config4_bench.json 2> $OUT/config4_bench.err; echo "configs[3] bench rc=$?"
+  python - <<P
+import json
+d = json.load(open("$OUT/config4_bench.json"))
+print({k: v for k, v in d.items() if k != "kernels"})
+for k, v in list(d["kernels"].items())[:12]:
+    print("%-24s %3d launches %8.3f ms  tflops %s  GB/s %s" % (k, v["launches"], v["ms"], v["tflops"] and round(v["tflops"], 1), v["GBps"] and round(v["GBps"])))
+P
   timeout 300 python tools/recipe_bench.py > $OUT/recipe_size_bench.json 2>> $OUT/recipe_size_bench.err; echo "recipe-size bench rc=$?"
   python - <<P
 import json

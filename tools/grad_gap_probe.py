@@ -43,8 +43,7 @@ def main():
         return float((a.double() - b.double()).abs().max()) / max(float(b.abs().max()), 1e-300)
 
     print("fp32 oracle vs fp64 oracle: worst %s" % sorted(((rel(g32[k], g64[k]), k) for k in g64 if g64[k] is not None), reverse=True)[:3])
-    modes = [("chain (default)", DEFAULT_FLAGS), ("launch pair", DEFAULT_FLAGS | L.FLAG_NO_CHAIN),
-             ("chain, dW contracted", DEFAULT_FLAGS | L.FLAG_NO_CHAIN_DW)]
+    modes = [("chain (default)", DEFAULT_FLAGS), ("launch pair", DEFAULT_FLAGS | L.FLAG_NO_CHAIN)]
     for name, fl in modes:
         eng.flags = fl
         g = flat_to_state(eng, eng.backward(dl, t_first=eng.receptive_field).cpu(), O.param_shapes(cfg))

@@ -26,14 +26,17 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--aux", type=int, default=80)
     ap.add_argument("--resch", type=int, default=512)
+    ap.add_argument("--kernel-size", type=int, default=2)
+    ap.add_argument("--upsampling", type=int, default=80)
+    ap.add_argument("--T", type=int, default=23040, help="model inputs per window (BASELINE configs[3]: 26112)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(1)
-    R, S, A, U, L = args.resch, 256, args.aux, 80, 30
-    model = WaveNet(256, A, R, S, 10, 3, 2, U)
+    R, S, A, U, L, K = args.resch, 256, args.aux, args.upsampling, 30, args.kernel_size
+    model = WaveNet(256, A, R, S, 10, 3, K, U)
     model.apply(initialize)
     model.to(dev)
-    B, T = args.batch, 23040
+    B, T = args.batch, args.T
     g = torch.Generator().manual_seed(7)
     xx = torch.randint(0, 256, (B, T + 1), generator=g)
     x, t = xx[:, :-1].contiguous().to(dev), xx[:, 1:].contiguous().to(dev)
@@ -62,8 +65,8 @@ def main():
     buf = ctypes.create_string_buffer(max(need, 16))
     lib.wn_prof_report(buf, len(buf))
     prof = json.loads(buf.value.decode() or "{}")
-    flop_fwd = 2.0 * B * T * (L * (2 * R * R * 2 + 2 * A * R / U + R * S + R * R) + S * S + S * 256)
-    out = {"model": "%d/%d recipe size, A=%d, K=2, U=%d, 30 layers" % (R, S, A, U), "B": B, "T": T,
+    flop_fwd = 2.0 * B * T * (L * (2 * R * R * K + 2 * A * R / U + R * S + R * R) + S * S + S * 256)
+    out = {"model": "%d/%d, A=%d, K=%d, U=%d, 30 layers" % (R, S, A, K, U), "B": B, "T": T, "rf": model.receptive_field,
            "ms_per_step": dt * 1e3, "samples_per_sec": B * (T - model.receptive_field) / dt,
            "approx_train_tflops": 3 * flop_fwd / dt / 1e12, "loss": float(loss),
            "kernels": {k: {"launches": v["count"], "ms": v["ms"], "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] > 0 and v["ms"] > 0 else None,
