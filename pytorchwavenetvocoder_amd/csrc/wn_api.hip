@@ -336,7 +336,8 @@ struct DwPlan {
 };
 static DwPlan dw_plan(int M, int N, int Kdim, int nbatch) {
     const int tm = (M + (M > 64 ? 127 : 63)) / (M > 64 ? 128 : 64);
-    const int tn = (N + (N > 64 ? 127 : 63)) / (N > 64 ? 128 : 64);
+    const int tnw = 64 * wn_gemm6_dw_tn(N);   // column tile width the kernel will use
+    const int tn = (N + tnw - 1) / tnw;
     const long tiles = (long)tm * tn * nbatch;
     // 128 x 128 tiles (k_gemm6_dw<2,2>, 3 workgroups per CU): as many k-chunks as fit ONE resident round of 768
     // workgroups -- measured against "at least 1024" on config 2 (720 instead of 1200 workgroups for the layer-batched
@@ -346,7 +347,7 @@ static DwPlan dw_plan(int M, int N, int Kdim, int nbatch) {
     if (wn_gemm6_dw_tall(M, N)) {   // 256 x 128 tiles (k_gemm6_dw<4,2>, 2 workgroups per CU): one resident round of 512
         const long tall = (long)(M / 256) * tn * nbatch;
         ks = 512 / tall;
-    } else if (M > 64 && N > 64) {
+    } else if (M > 64 && tnw == 128) {
         ks = 768 / tiles;
     } else {
         ks = (1024 + tiles - 1) / tiles;

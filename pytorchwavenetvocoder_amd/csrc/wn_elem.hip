@@ -664,7 +664,11 @@ static void front_dw_grid(int B, int T, int* nchunk, int* chunk) {
     *nchunk = (T + ch - 1) / ch;
 }
 
-int wn_front_dw_supported(int R, int K, int Q) { return ((long)R * K * Q + R) * 4 <= 150 * 1024 && K <= 8; }
+static bool front_dw_mfma_ok(int R, int K, int Q);
+// the matrix-core kernel (small LDS), or the scatter kernel with its [R][K*Q] table in LDS
+int wn_front_dw_supported(int R, int K, int Q) {
+    return (front_dw_mfma_ok(R, K, Q) || ((long)R * K * Q + R) * 4 <= 150 * 1024) && K <= 8;
+}
 
 long wn_front_dw_partial_floats(int B, int T, int R, int K, int Q) {
     int nc, ch;
@@ -827,14 +831,25 @@ __global__ __launch_bounds__(FM_T) void k_front_dw_mfma(const float* __restrict_
     const int pofs = pkb * (3 * 2048) + (prow * 2 + phi) * 16 + pdw * 4;   // + piece * 2048 + buf * 2 * 3 * 2048
     const float* prowp = db + (long)prow * T;
     float rsum = 0.0f;
-    // phase-2 role of this wave: column tile `wave` (32 columns of one tap), if the table has that many
-    const bool active = wave * 32 < KQ;
-    const int col = wave * 32 + li;
-    const int tap = col / Q, q = col - tap * Q;
-    const int tshift = tap;   // token index of position t with this tap: (t - t0) + (K-1) - (K-1-tap) = (t - t0) + tap
-    f32x16 acc[2];
-    acc[0] = f32x16_zero();
-    acc[1] = f32x16_zero();
+    // phase-2 role of this wave: column tiles `wave` and `wave + 16` (32 columns of one tap each), if the table has that many
+    // (K * Q <= 512: one tile per wave; kernel_size 3 with 256 classes: 24 tiles, the first 8 waves take two)
+    constexpr int NW = FM_T / 64;
+    bool active[2];
+    int col[2], q[2], tshift[2];
+    WN_UNROLL
+    for (int ct = 0; ct < 2; ++ct) {
+        active[ct] = (wave + NW * ct) * 32 < KQ;
+        col[ct] = (wave + NW * ct) * 32 + li;
+        const int tap = col[ct] / Q;
+        q[ct] = col[ct] - tap * Q;
+        tshift[ct] = tap;   // token index of position t with this tap: (t - t0) + (K-1) - (K-1-tap) = (t - t0) + tap
+    }
+    f32x16 acc[2][2];
+    WN_UNROLL
+    for (int ct = 0; ct < 2; ++ct) {
+        acc[ct][0] = f32x16_zero();
+        acc[ct][1] = f32x16_zero();
+    }
     const int nrt = R >> 5;
     auto stage_pair = [&](int ts, int buf) {
         const int t = ts + 2 * pkq;
@@ -855,15 +870,17 @@ __global__ __launch_bounds__(FM_T) void k_front_dw_mfma(const float* __restrict_
     int buf = 0;
     for (int ts = t0; ts < t1; ts += 32, buf ^= 1) {
         if (ts + 32 < t1) stage_pair(ts + 32, buf ^ 1);
-        if (active) {
+        WN_UNROLL
+        for (int ct = 0; ct < 2; ++ct) {
+            if (!active[ct]) continue;   // (wave-uniform)
             WN_UNROLL
             for (int kb = 0; kb < 2; ++kb) {
                 // one-hot B fragment: this lane's column q against the tokens of its 8 time steps
-                const int* tk = tok + (ts - t0) + 16 * kb + 8 * hi + tshift;
+                const int* tk = tok + (ts - t0) + 16 * kb + 8 * hi + tshift[ct];
                 unsigned bq[4];
                 WN_UNROLL
                 for (int e = 0; e < 4; ++e)
-                    bq[e] = (tk[2 * e] == q ? 0x3F80u : 0u) | (tk[2 * e + 1] == q ? 0x3F800000u : 0u);
+                    bq[e] = (tk[2 * e] == q[ct] ? 0x3F80u : 0u) | (tk[2 * e + 1] == q[ct] ? 0x3F800000u : 0u);
                 wn_f4 bf;
                 bf.x = wn_bits_f32(bq[0]); bf.y = wn_bits_f32(bq[1]); bf.z = wn_bits_f32(bq[2]); bf.w = wn_bits_f32(bq[3]);
                 const char* sa = stage + buf * (2 * 3 * 2048) + kb * (3 * 2048) + (li * 2 + hi) * 16;
@@ -873,21 +890,23 @@ __global__ __launch_bounds__(FM_T) void k_front_dw_mfma(const float* __restrict_
                         const wn_f4 al = *reinterpret_cast<const wn_f4*>(sa + 4096 + rt * 1024);
                         const wn_f4 am = *reinterpret_cast<const wn_f4*>(sa + 2048 + rt * 1024);
                         const wn_f4 ah = *reinterpret_cast<const wn_f4*>(sa + rt * 1024);
-                        acc[rt] = mfma_bf16(al, bf, acc[rt]);   // small pieces first
-                        acc[rt] = mfma_bf16(am, bf, acc[rt]);
-                        acc[rt] = mfma_bf16(ah, bf, acc[rt]);
+                        acc[ct][rt] = mfma_bf16(al, bf, acc[ct][rt]);   // small pieces first
+                        acc[ct][rt] = mfma_bf16(am, bf, acc[ct][rt]);
+                        acc[ct][rt] = mfma_bf16(ah, bf, acc[ct][rt]);
                     }
                 }
             }
         }
         __syncthreads();
     }
-    if (active) {
+    WN_UNROLL
+    for (int ct = 0; ct < 2; ++ct) {
+        if (!active[ct]) continue;
         WN_UNROLL
         for (int rt = 0; rt < 2; ++rt) {
             if (rt < nrt) {
                 WN_UNROLL
-                for (int r = 0; r < 16; ++r) out[(long)(32 * rt + mfma32_row(r, hi)) * KQ + col] = acc[rt][r];
+                for (int r = 0; r < 16; ++r) out[(long)(32 * rt + mfma32_row(r, hi)) * KQ + col[ct]] = acc[ct][rt][r];
             }
         }
     }
@@ -898,7 +917,7 @@ __global__ __launch_bounds__(FM_T) void k_front_dw_mfma(const float* __restrict_
 
 static bool front_dw_mfma_ok(int R, int K, int Q) {
     // (other shapes keep the LDS-atomic scatter kernel: 0.18 vs 0.07 ms at the benchmark's size, profiles/r02/front_dw_probe.txt)
-    return (R == 32 || R == 64) && Q % 32 == 0 && K * Q <= 512 && K <= 8;
+    return (R == 32 || R == 64) && Q % 32 == 0 && K * Q <= 1024 && K <= 8;
 }
 
 // dW[c][q][k] = sum_blk partial[blk][c][k*Q+q] ; db[c] = sum_blk partial[blk][R*KQ + c]
@@ -946,7 +965,7 @@ int wn_front_dw(const float* dX0, const int64_t* x, float* partial, float* dW, f
     front_dw_grid(B, T, &nc, &ch);
     const size_t lds = ((size_t)R * K * Q + R) * 4;
 #ifndef WN_EMU
-    if (lds > 64 * 1024 &&
+    if (!front_dw_mfma_ok(R, K, Q) && lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_front_dw_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
         return 2;

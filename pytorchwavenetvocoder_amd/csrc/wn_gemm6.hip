@@ -978,6 +978,11 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 4 ? 2 : 3)) void k_gemm6_dw(WnGemm
 // the caller must use the same rule.
 int wn_gemm6_dw_tall(int M, int N) { return M >= 512 && (M % 256 == 0) && N >= 512; }
 
+// Column tiles of the weight-gradient kernel: 128 wide unless the last one would be at most half full -- kernel_size 3 has
+// N = 3 * 64 = 192 columns: with 128-wide tiles the second one is ragged, i.e. never takes the branch-free interior pass
+// (5.05 ms for dw_dilated of the configs[3] geometry against 1.1 ms at kernel_size 2, profiles/r03) -- then 64 wide.
+int wn_gemm6_dw_tn(int N) { return (N > 64 && (N % 128 == 0 || N % 128 > 64)) ? 2 : 1; }
+
 int wn_gemm6_dw_eligible(const WnGemmArgs* g) {
     return g->a_kmajor && g->b_kmajor && !g->b_index && !g->bias && !g->D && !g->E && !g->relu && !g->accumulate &&
            (long)g->M * g->ldc * 4 < 0x7ffffff0L && g->M > 0 && g->N > 0;
@@ -998,7 +1003,7 @@ int wn_gemm6_dw_launch(const WnGemmArgs* gp, wn_stream_t st) {
     if (g.K < 0 || g.nbatch <= 0 || g.ksplit <= 0 || g.nlayer <= 0 || g.b_seg_len <= 0 || g.kchunk <= 0) return 2;
     WN_PROF(g.tag ? g.tag : "gemm6_dw", 2.0 * g.M * g.N * (double)g.K * g.nbatch * g.nlayer,
             ((double)g.M * g.K * 4.0 + (double)g.K * 4.0 * g.N + (double)g.M * g.N * 4.0) * g.nbatch * g.nlayer, st);
-    const int tm = g.M > 64 ? 2 : 1, tn = g.N > 64 ? 2 : 1;
+    const int tm = g.M > 64 ? 2 : 1, tn = wn_gemm6_dw_tn(g.N);
     if (wn_gemm6_dw_tall(g.M, g.N)) return launch_dw<4, 2>(g, st);   // 256 x 128 tiles: every B row is read once per 256 A rows
     if (tm == 2 && tn == 2) return launch_dw<2, 2>(g, st);
     if (tm == 2) return launch_dw<2, 1>(g, st);
