@@ -38,6 +38,7 @@ static inline void wn_buf_store(wn_rsrc_t r, float v, int voff, int soff) {
     const unsigned long off = (unsigned long)(unsigned)voff + (unsigned long)(unsigned)soff;
     if (off + 4 <= r.bytes) *(float*)(r.base + off) = v;
 }
+static inline float wn_buf_load_once(wn_rsrc_t r, int voff, int soff) { return wn_buf_load(r, voff, soff); }
 static inline float4 wn_buf_load4(wn_rsrc_t r, int voff, unsigned soff) {
     const unsigned long off = (unsigned long)(unsigned)voff + (unsigned long)soff;
     float4 v{0.f, 0.f, 0.f, 0.f};
@@ -116,6 +117,14 @@ static __device__ __forceinline__ float wn_buf_load(wn_rsrc_t r, int voff, int s
 }
 static __device__ __forceinline__ void wn_buf_store(wn_rsrc_t r, float v, int voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, voff, soff, 0);
+}
+// load of data that is read exactly once per launch: non-temporal (does not displace the lines a later launch re-reads)
+static __device__ __forceinline__ float wn_buf_load_once(wn_rsrc_t r, int voff, int soff) {
+#ifndef WN_NO_NT_LOADS   // (-DWN_NO_NT_LOADS: A/B builds)
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 2));
+#else
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+#endif
 }
 // global -> LDS without registers (buffer_load_dwordx4 ... lds): lane l of the wave writes 16 bytes at
 // lds_wave_base + 16*l; lds_wave_base must be wave-uniform.  Completion is counted by vmcnt.
