@@ -61,7 +61,7 @@ LAYERS_PER_BUCKET = 30      # gradient buckets = weight-gradient launch groups; 
 #   dX             write dx_l (its inputs dP never leave the chip)       1R
 ALG_BYTES_PER_TIMESTEP_OF = {"fused_resblock_fwd": 4 * 64 * 4, "fused_bwd_gate": 3 * 64 * 4, "fused_bwd_dx": 64 * 4,
                              "fused_bwd_chain": 4 * 64 * 4}
-PMC_FILES = ["profiles/r02/pmc_traffic.json"]
+PMC_FILES = ["profiles/r03/pmc_traffic.json", "profiles/r02/pmc_traffic.json"]
 
 
 def geometry(rf, batch_length, U):
@@ -182,6 +182,26 @@ def decode_report(model, device, with_cpu):
     return out
 
 
+def extra_workloads(*release):
+    """Two further training workloads of the same code, timed after the headline (N = 1 only; NOT the metric):
+      * BASELINE configs[3] geometry -- LJSpeech recipe shape: kernel_size 3, upsampling 256, receptive field 6139, batch 8 x
+        batch_len 20000 (T = 26112) -- with the softmax head the reference has (egs/ljspeech/sd-melspc/run.sh:29);
+      * the recipe-size model (n_resch 512 / n_skipch 256, egs/arctic/sd/run.sh:46-57) on 4 windows of batch_len 20000:
+        matrix-bound, so reported against the split-arithmetic matrix peak (2.5 PFLOP/s bf16 / 6 products = 417 TFLOP/s)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import recipe_bench
+    out = {}
+    try:
+        c3 = recipe_bench.measure(resch=64, kernel_size=3, upsampling=256, T=26112, batch=8, steps=10, with_kernels=False)
+        out["configs3_geometry"] = {k: c3[k] for k in ("model", "B", "T", "rf", "ms_per_step", "samples_per_sec")}
+        rs = recipe_bench.measure(resch=512, kernel_size=2, upsampling=80, T=23040, batch=4, steps=3, with_kernels=False)
+        out["recipe_size"] = {k: rs[k] for k in ("model", "B", "T", "rf", "ms_per_step", "samples_per_sec", "approx_train_tflops")}
+        out["recipe_size"]["frac_of_split_matrix_peak"] = rs["approx_train_tflops"] * 1e12 / (BF16_MFMA_PEAK / SPLIT_PRODUCTS)
+    except Exception as e:  # noqa: BLE001 -- the extras never take the headline line down
+        out["error"] = repr(e)
+    return out
+
+
 def stream_mode(flags):
     """Launch mode of the timed steps (include/wavenet_hip.h WN_FLAG_*).  The per-launch HIP-event table of the
     `kernels` / `roofline` blocks is always taken serially (wn_prof_enable keeps everything on one stream)."""
@@ -256,6 +276,8 @@ def main():
                          "kernel (WN_FLAG_AUX_FUSED, the engine's default)")
     ap.add_argument("--aux-fused", action="store_true", help=argparse.SUPPRESS)   # round-1 spelling: now the default
     ap.add_argument("--profile-steps", type=int, default=2, help="extra untimed steps with per-launch HIP events")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the two extra (non-headline) workloads: BASELINE configs[3] geometry and the recipe-size model")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -430,15 +452,16 @@ def main():
                        "engine_flags": int(model.engine.flags),
                        "gradient_buckets": "post-net+skip | groups of %d layers | front+upsampling (weight gradients are "
                                            "launched per bucket; identical structure for N = 1 and N > 1)" % args.layers_per_bucket,
-                       "loss_path": "wn_forward_loss + wn_backward_window: the forward pass computes every position; the "
-                                    "cross-entropy on [:, rf:] is the epilogue of the conv_post_2 contraction (logits not "
-                                    "materialised: same loss / dlogits as the separate kernel to 1e-7) and the post-net / skip "
-                                    "part of the backward pass runs over the loss window only (dlogits is exactly zero in "
-                                    "front of it: same gradients)",
+                       "loss_path": "wn_forward_loss + wn_backward_window: the residual stack computes every position in both "
+                                    "directions; the loss of train.py:534-536 covers [:, rf:], so the skip-sum / post-net "
+                                    "contractions of the forward pass and the post-net / skip part of the backward pass run over "
+                                    "that window only (everything between skip sum and loss is pointwise in time: same loss, same "
+                                    "gradients), and the cross-entropy is the epilogue of the conv_post_2 contraction (logits not "
+                                    "materialised: same loss / dlogits as the separate kernel to 1e-7)",
                        "timing": "median of %d regions of %d steps" % (len(regions), args.steps),
                        "arithmetic": "fp32 storage and accumulation; contractions on the bf16 matrix cores with a 3-way "
-                                     "operand split (6 products, fp32-equivalent to round-off) except K=3 forward blocks "
-                                     "(exact f32 MFMA); WN_FLAG_EXACT_MFMA selects the f32 MFMA everywhere"},
+                                     "operand split (6 products, fp32-equivalent to round-off); "
+                                     "WN_FLAG_EXACT_MFMA selects the f32 MFMA everywhere"},
             "timesteps_per_sec": world * timesteps_per_s_gpu, "final_loss": final_loss,
             "roofline": roofline, "kernels": kernels,
         }
@@ -448,6 +471,8 @@ def main():
             out["cpu_baseline"] = None
         if not args.no_decode and world == 1:
             out["decode"] = decode_report(model, device, not args.no_cpu_baseline)
+        if not args.no_extras and world == 1:
+            out["extras"] = extra_workloads(model, opt, red)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

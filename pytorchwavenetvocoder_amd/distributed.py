@@ -27,7 +27,7 @@ def rccl_footprint_defaults():
 
 
 class GradientReducer(object):
-    def __init__(self, model, process_group=None, layers_per_bucket=None):
+    def __init__(self, model, process_group=None, layers_per_bucket=None, exchange_when_alone=False):
         """``layers_per_bucket``: residual layers per gradient bucket = per weight-gradient launch group of wn_backward.
         Default (None): chosen by the size of the gradient.
           * small models (the BASELINE 64 / 256 model: 6.4 MB): ALL layers in one bucket, i.e. three buckets
@@ -50,6 +50,8 @@ class GradientReducer(object):
             self.lpb = min(10, int(self.eng.n_layers)) if big else int(self.eng.n_layers)
         self.ranges = self.eng.bucket_ranges(self.lpb)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # tests: run the bucket-event / side-stream / all-reduce branch with a single rank too (RCCL then executes, on this GPU)
+        self.exchange_alone = bool(exchange_when_alone) and dist.is_initialized()
         self.cuda = self.eng.device.type == "cuda"
         if self.cuda:
             self.side = torch.cuda.Stream(device=self.eng.device)
@@ -73,7 +75,7 @@ class GradientReducer(object):
         mean loss (device tensor).  ``y`` (B, T) float selects the mixture-of-logistics loss.
         ``grad_scale``: this rank's share of the global minibatch (default 1/world = equal shards; pass
         B_local / B_global when the shards are uneven, so that the summed gradient is the global-batch mean)."""
-        if self.world == 1:   # same launch structure as N > 1 (weight gradients flushed per bucket), no exchange
+        if self.world == 1 and not self.exchange_alone:   # same launch structure as N > 1 (weight gradients flushed per bucket), no exchange
             return self._step(x, h, t, y, t_start=t_start, layers_per_bucket=self.lpb)
         gscale = self.grad_scale if grad_scale is None else float(grad_scale)
         if not self.cuda:

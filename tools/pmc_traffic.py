@@ -22,11 +22,21 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pmc_summary import summarize  # noqa: E402
 
 # bench.py tag -> kernel symbol(s) that implement it (the first one present in the trace is reported)
-TAGS = {"fused_bwd_gate": ["void k_conv64s<2>(ConvArgs)", "void k_conv64s<0>(ConvArgs)"],
-        "fused_resblock_fwd": ["void k_resblock_fwd_s<2, 0>(FwdArgs)", "void k_resblock_fwd_s<2, 1>(FwdArgs)", "void k_resblock_fwd_s<2>(FwdArgs)"],
-        "fused_bwd_dx": ["void k_conv64s<1>(ConvArgs)"],
-        "fused_bwd_chain": ["void k_chain64s<1, 2>(ChainArgs)", "void k_chain64s<0, 2>(ChainArgs)", "void k_chain64s<1, 1>(ChainArgs)",
-                            "void k_chain64s<0, 1>(ChainArgs)"]}
+# (prefixes: the first kernel of the trace that starts with one of them)
+TAGS = {"fused_bwd_gate": ["void k_conv64s<2>", "void k_conv64s<0>"],
+        "fused_resblock_fwd": ["void k_resblock_fwd_s<2", "void k_resblock_fwd_s<3", "void k_resblock_fwd_s<1"],
+        "fused_bwd_dx": ["void k_conv64s<1>"],
+        "fused_bwd_chain": ["void k_chain64s<1, 2, false", "void k_chain64s<0, 2, false", "void k_chain64s<1, 3, false", "void k_chain64s<1, 1, false",
+                            "void k_chain64s<0, 1, false", "void k_chain64s<1, 2>", "void k_chain64s<0, 2>"]}
+
+
+def find_kernel(prefixes, *tables):
+    for pre in prefixes:
+        for tab in tables:
+            for k in tab:
+                if k.startswith(pre):
+                    return k
+    return None
 
 
 def engine_flags_of(log_path):
@@ -53,7 +63,7 @@ def main():
         total += b * n
     out = {}
     for tag, names in TAGS.items():
-        name = next((n for n in names if n in fetch or n in write), None)
+        name = find_kernel(names, fetch, write)
         if name is not None:
             out[tag] = {"kernel": name, "fetch_size_kb": fetch.get(name, {}).get("FETCH_SIZE"),
                         "write_size_kb": write.get(name, {}).get("WRITE_SIZE"),
@@ -69,9 +79,9 @@ def main():
                                 "mfma_busy_cycles": v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), "launches": v.get("launches", 0)}
         out["_mfma_util_per_kernel"] = util
         for tag, names in TAGS.items():
-            name = next((n for n in names if n[:80] in util), None)
+            name = find_kernel(names, util)
             if name is not None and tag in out:
-                out[tag]["mfma_util"] = util[name[:80]]["mfma_util"]
+                out[tag]["mfma_util"] = util[name]["mfma_util"]
     out["_engine_flags"] = engine_flags_of(sys.argv[4]) if len(sys.argv) > 4 else None
     out["_step_total_bytes"] = total / steps
     out["_per_kernel_bytes_per_launch"] = per
