@@ -23,7 +23,7 @@ if has lpb; then
   #   WN_AB_VARIANTS="WN_X=1 WN_ENGINE_FLAGS=96 WN_LIB_PATH=tools/exp/libwn_x.so"   (launch-mode flags / variant builds: DESIGN.md 5.2)
   for rep in 1 2; do
     for cfg in ${WN_AB_VARIANTS:-WN_X=1 WN_ENGINE_FLAGS=96}; do
-      env $(echo $cfg | tr ',' ' ') timeout 200 python bench.py --repeats 3 --no-cpu-baseline --no-decode --profile-steps 0 > $OUT/bench_ab.json 2>> $OUT/bench.err
+      env $(echo $cfg | tr ',' ' ') timeout 200 python bench.py --repeats 3 --no-cpu-baseline --no-decode --no-extras --profile-steps 0 > $OUT/bench_ab.json 2>> $OUT/bench.err
       python - <<P
 import json
 d = json.load(open("$OUT/bench_ab.json"))
@@ -36,7 +36,7 @@ if has abk; then
   # like lpb, with the per-kernel HIP-event table of each variant (WN_AB_VARIANTS; WN_ABK_KERNELS = tags to print)
   for rep in 1 2; do
     for cfg in ${WN_AB_VARIANTS:-WN_X=1}; do
-      env $(echo $cfg | tr ',' ' ') timeout 200 python bench.py --repeats 3 --no-cpu-baseline --no-decode > $OUT/bench_abk.json 2>> $OUT/bench.err
+      env $(echo $cfg | tr ',' ' ') timeout 200 python bench.py --repeats 3 --no-cpu-baseline --no-decode --no-extras > $OUT/bench_abk.json 2>> $OUT/bench.err
       python - <<P
 import json
 d = json.load(open("$OUT/bench_abk.json"))
@@ -50,7 +50,7 @@ P
 fi
 if has rocprof; then
   rm -rf $OUT/prof_stats
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python $ROOT/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-decode > $OUT/bench_rocprof.json 2> $OUT/rocprof.err); echo "rocprof rc=$?"
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python $ROOT/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-decode --no-extras > $OUT/bench_rocprof.json 2> $OUT/rocprof.err); echo "rocprof rc=$?"
   find $OUT/prof_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/rocprofv3_kernel_stats.csv
   python tools/kernel_gaps.py $OUT/prof_stats > $OUT/kernel_gaps.txt 2>&1; cat $OUT/kernel_gaps.txt
   find $OUT/prof_stats -name "*kernel_trace.csv" -delete
@@ -82,7 +82,7 @@ if has recipe; then
   timeout 300 bash tools/recipe_stage45.sh run > $OUT/recipe_stage45.txt 2>&1; echo "recipe rc=$?"; tail -3 $OUT/recipe_stage45.txt
 fi
 if has tworank; then
-  WN_BENCH_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 2 --repeats 2 --no-cpu-baseline --no-decode > $OUT/bench_2rank_gloo.json 2> $OUT/bench_2rank_gloo.err; echo "2-rank gloo rc=$?"; cut -c1-300 $OUT/bench_2rank_gloo.json
+  WN_BENCH_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 2 --repeats 2 --no-cpu-baseline --no-decode --no-extras > $OUT/bench_2rank_gloo.json 2> $OUT/bench_2rank_gloo.err; echo "2-rank gloo rc=$?"; cut -c1-300 $OUT/bench_2rank_gloo.json
 fi
 lscpu | grep -E "Model name|^CPU\(s\)|Socket" > $OUT/host.txt
 echo "elapsed $(( $(date +%s) - $(cat $OUT/t0) )) s"

@@ -7,7 +7,7 @@
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$ROOT/gpurun_out"; mkdir -p $OUT; rm -rf $OUT/pmc; mkdir -p $OUT/pmc; export TMPDIR=/tmp
 cd /tmp
-CMD="python $ROOT/bench.py --steps 2 --warmup 1 --repeats 1 --profile-steps 0 --no-cpu-baseline --no-decode $WN_PMC_BENCH_ARGS"
+CMD="python $ROOT/bench.py --steps 2 --warmup 1 --repeats 1 --profile-steps 0 --no-cpu-baseline --no-decode --no-extras $WN_PMC_BENCH_ARGS"
 timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc/fetch -- $CMD > $OUT/pmc/fetch.log 2>&1; echo "fetch rc=$?"
 timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc/write -- $CMD > $OUT/pmc/write.log 2>&1; echo "write rc=$?"
 timeout 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc/mfma -- $CMD > $OUT/pmc/mfma.log 2>&1; echo "mfma rc=$?"
