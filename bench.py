@@ -254,6 +254,11 @@ def load_pmc_traffic(flags):
             continue
         if int(d.get("_engine_flags", -1)) == int(flags):
             d["_file"] = rel
+            try:   # was the counter pass taken on exactly the kernel sources this run's library was built from?
+                from pytorchwavenetvocoder_amd.csrc import build as _b
+                d["_same_build"] = d.get("_source_digest") == _b._digest()
+            except Exception:  # noqa: BLE001
+                d["_same_build"] = None
             return d
     return None
 
@@ -393,8 +398,12 @@ def main():
             "traffic": step_traffic,
             "traffic_ratio": (step_traffic / alg_step) if step_traffic else None,
             "traffic_note": ("HBM bytes of one step, (2*FETCH_SIZE + WRITE_SIZE)*1024 summed over all launches, separate "
-                             "rocprofv3 --pmc passes of this launch mode: %s" % pmc["_file"]) if pmc else
+                             "rocprofv3 --pmc passes of this launch mode, NOT taken in this run: %s (commit %s; kernel sources "
+                             "%s those of this run's library)" % (
+                                 pmc["_file"], pmc.get("_commit"),
+                                 "identical to" if pmc.get("_same_build") else "DIFFERENT from (or unknown vs)")) if pmc else
                             "no PMC passes committed for this launch mode",
+            "traffic_same_build": pmc.get("_same_build") if pmc else None,
             "step_f32_flop_frac": timesteps_per_s_gpu * ALG_FLOP_PER_TIMESTEP / F32_MFMA_PEAK,
         }
     if rank == 0 and args.profile_steps > 0:

@@ -187,8 +187,11 @@ int wn_forward_loss(const WnConfig* cfg, int B, int T, const float* params, cons
 /* Backward of wn_forward (what autograd does for train.py:538): writes EVERY element of the flat
  * gradient buffer `grads` (the dead range gets zeros).  `ws` must still hold the matching
  * wn_forward call, made with the same WN_FLAG_NO_FUSED / WN_FLAG_EXACT_MFMA choice (the two kernel
- * families save different activations).  If events != NULL, hipEvent_t events[i] is recorded on `stream` as soon as
- * bucket i (wn_bucket_range) is final, so the caller can all-reduce it on another stream. */
+ * families save different activations), and `params` must be UNCHANGED since that call: the workspace also holds the
+ * re-laid-out / pre-split weight sets wn_forward packed from them (the post-net and skip weights of the backward
+ * contractions among them), and wn_backward does not re-pack.  The training loop satisfies this by construction (the
+ * optimizer step comes after the backward pass, train.py:533-539).  If events != NULL, hipEvent_t events[i] is recorded on
+ * `stream` as soon as bucket i (wn_bucket_range) is final, so the caller can all-reduce it on another stream. */
 int wn_backward(const WnConfig* cfg, int B, int T, const float* params, const int64_t* x, const float* h,
                 const float* dlogits, float* grads, void* ws, size_t ws_bytes, void* const* events, int n_events,
                 int layers_per_bucket, int flags, void* stream);

@@ -83,6 +83,20 @@ def main():
             if name is not None and tag in out:
                 out[tag]["mfma_util"] = util[name]["mfma_util"]
     out["_engine_flags"] = engine_flags_of(sys.argv[4]) if len(sys.argv) > 4 else None
+    # which build this was taken on: the digest of the kernel sources + flags the library was built from (the same one the
+    # loader checks, pytorchwavenetvocoder_amd/csrc/build.py), and the commit the tree was at (tools/BUILD_COMMIT, written
+    # before the snapshot is sent to the GPU box, which has no .git)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        sys.path.insert(0, root)
+        from pytorchwavenetvocoder_amd.csrc import build as _b
+        out["_source_digest"] = _b._digest()
+    except Exception as e:  # noqa: BLE001
+        out["_source_digest"] = "unavailable: %r" % (e,)
+    try:
+        out["_commit"] = open(os.path.join(root, "tools", "BUILD_COMMIT")).read().strip()
+    except OSError:
+        out["_commit"] = None
     out["_step_total_bytes"] = total / steps
     out["_per_kernel_bytes_per_launch"] = per
     out["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/pmc_traffic.sh); bytes = "
