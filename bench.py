@@ -405,6 +405,9 @@ def main():
                             "no PMC passes committed for this launch mode",
             "traffic_same_build": pmc.get("_same_build") if pmc else None,
             "step_f32_flop_frac": timesteps_per_s_gpu * ALG_FLOP_PER_TIMESTEP / F32_MFMA_PEAK,
+            "stream_plateau_note": "a no-arithmetic float4 stream of the fused launches' bytes sustains 4.95 - 5.2 TB/s on an MI355X "
+                                   "of this pool (tools/microbench/stream_mix.hip, profiles/r03/stream_mix.txt), i.e. 0.63 - 0.65 of `peak`; "
+                                   "`frac` stays priced against the 8 TB/s peak",
         }
     if rank == 0 and args.profile_steps > 0:
         need = lib.wn_prof_report(None, 0)
