@@ -277,7 +277,9 @@ int wn_decode_steps(const WnConfig* cfg, int B, const float* params, const float
  * operands: one pass over the weights per step serves the whole batch).  Same positions / teacher forcing
  * / mode / uniforms / logits_out conventions as wn_decode_steps.  `state` is ONE caller-owned buffer of
  * wn_decode_layered_state_floats(cfg, B) floats, zero-filled before wn_decode_layered_prepare, which packs
- * the weights into it and computes G (B, F, L*2R) from h (B, n_aux, F). */
+ * the weights into it and computes G (B, F, L*2R) from h (B, n_aux, F).  A later wn_decode_layered_prepare on the
+ * same state with params == NULL keeps the packed weights and only projects the given window of h (a decode
+ * without an upsampling layer projects one window of aux columns per chunk of steps). */
 int64_t wn_decode_layered_state_floats(const WnConfig* cfg, int B);
 int wn_decode_layered_prepare(const WnConfig* cfg, int B, int F, const float* params, const float* h, float* G, float* state,
                               int64_t state_floats, void* stream);

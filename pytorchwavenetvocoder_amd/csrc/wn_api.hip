@@ -1657,19 +1657,21 @@ extern "C" int64_t wn_decode_layered_state_floats(const WnConfig* cfg, int B) {
 }
 
 // Packs the weights into `state` (which must be zero-filled first: the queues start from zero history) and
-// computes the aux projections G (B, F, L*2R) of all layers at the aux rate.
+// computes the aux projections G (B, F, L*2R) of all layers at the aux rate.  params == NULL: `state` already holds the
+// weights packed by an earlier call (same cfg, B and parameters) -- only the projection of this window of h is computed
+// (windowed decoding without an upsampling layer calls this once per chunk of steps).
 extern "C" int wn_decode_layered_prepare(const WnConfig* cfg, int B, int F, const float* params, const float* h, float* G,
                                          float* state, int64_t state_floats, void* stream) {
     api_enter();
     Dims d;
     WN_TRY(check_cfg(cfg, &d));
-    if (!params || !h || !G || !state || B < 1 || F < 1) return fail(1, "bad argument");
+    if (!h || !G || !state || B < 1 || F < 1) return fail(1, "bad argument");
     DlLay y;
     WN_TRY(dl_layout(cfg, d, B, &y));
     if (state_floats < y.total) return fail(1, "decode state too small: %ld < %ld floats", (long)state_floats, y.total);
     Ctx c;
     dl_ctx(&c, cfg, d, y, B, state, stream);
-    WN_TRY(pack_weights(c, params));
+    if (params) WN_TRY(pack_weights(c, params));
     const int nG = d.L * 2 * d.R;
     WnGemmArgs g = wn_gemm_default();  // G[b] (F x nG) = h[b]^T (F x A) . waux_f (A x nG)
     g.M = F; g.N = nG; g.K = d.A;

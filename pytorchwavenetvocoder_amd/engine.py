@@ -329,13 +329,18 @@ class WaveNetEngine(object):
             self.lib.check(self.lib.wn_decode_pack(cfg, _ptr(self.flat_params), _ptr(wpack), st), "wn_decode_pack")
             state = torch.zeros((B, self.lib.wn_decode_state_floats(cfg)), dtype=torch.float32, device=dev)
 
+        packed = [False]
+
         def aux_columns(c0, c1):
-            """G of aux columns [c0, c1) (the layered variant also (re)packs the weights into its state)."""
+            """G of aux columns [c0, c1).  The layered variant packs the weights into its state on the first call only
+            (params = NULL afterwards: a windowed decode comes here once per chunk of steps)."""
             hw = h if (c0 == 0 and c1 == F) else h[:, :, c0:c1].contiguous()
             Gw = torch.empty((B, c1 - c0, nG), dtype=torch.float32, device=dev)
             if layered:
-                self.lib.check(self.lib.wn_decode_layered_prepare(cfg, B, c1 - c0, _ptr(self.flat_params), _ptr(hw), _ptr(Gw),
-                                                                  _ptr(state), nst, st), "wn_decode_layered_prepare")
+                self.lib.check(self.lib.wn_decode_layered_prepare(cfg, B, c1 - c0, None if packed[0] else _ptr(self.flat_params),
+                                                                  _ptr(hw), _ptr(Gw), _ptr(state), nst, st),
+                               "wn_decode_layered_prepare")
+                packed[0] = True
             else:
                 self.lib.check(self.lib.wn_decode_aux(cfg, B, c1 - c0, _ptr(wpack), _ptr(hw), _ptr(Gw), st), "wn_decode_aux")
             return Gw

@@ -177,6 +177,14 @@ def test_decode_context_lengths_and_ragged_requests():
             for i in range(3):
                 assert float((lc[i] - rl[i]).abs().max()) < 1e-4, (cfg_t, T0, i)
                 assert (c[i].numpy() == ref[i]).all(), (cfg_t, T0, i)
+            if U == 0:
+                # no upsampling layer: the aux columns are projected per chunk of steps; on the any-size path every chunk
+                # after the first passes params = NULL to wn_decode_layered_prepare (weights stay packed in the state)
+                for lay in (False, True):
+                    e, le = m.engine.decode(x, h, [9, 9, 9], return_logits=True, layered=lay, chunk=4)
+                    for i in range(3):
+                        assert float((le[i] - rl[i]).abs().max()) < 1e-4, (cfg_t, T0, lay, i)
+                        assert (e[i].numpy() == ref[i]).all(), (cfg_t, T0, lay, i)
 
 
 def test_persistent_tile_loop_several_tiles_per_wave():
