@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define WN_ABI_VERSION 6
+#define WN_ABI_VERSION 7
 
 /* Same fields as the constructor WaveNet(n_quantize, n_aux, n_resch, n_skipch, dilation_depth,
  * dilation_repeat, kernel_size, upsampling_factor)  -- reference wavenet.py:172-173. */
@@ -107,6 +107,15 @@ enum {
 #define WN_FLAG_FWD_OVERLAP 8 /* wn_forward (fused kernels): the skip-sum contraction is issued in three chunks of layers on
                                * the side stream while the residual stack is still running (the partial sums round
                                * differently from the single contraction: ~1e-7 relative on the logits) */
+#define WN_FLAG_WS_FINITE (1 << 16) /* wn_forward_loss (since ABI v7): the caller vouches that the workspace holds only FINITE
+                               * values (it was allocated zero-filled, or an earlier full wn_forward of the same shape wrote it).
+                               * wn_forward_loss runs the skip-sum / post-net over the loss window only and leaves the columns
+                               * of relu(skip) / relu(post1) in front of it untouched; without this flag it zero-fills them
+                               * (two small fills per call) so that a later wn_backward with an earlier window start cannot
+                               * multiply dlogits == 0 with NaN / Inf bit patterns of uninitialised memory */
+#define WN_FLAG_REPACK (1 << 17)    /* wn_backward / wn_backward_window (since ABI v7): re-build the re-laid-out / pre-split weight
+                               * sets in the workspace from the `params` given to THIS call before using them (for callers that
+                               * modified params after the forward call; costs one pack pass, ~0.05 ms at the BASELINE size) */
 #define WN_FLAG_DW_FLUSH(n) (((n) & 0xff) << 8) /* wn_backward: issue the weight gradients of at most n walked layers per
                                * launch group (0 = default: a whole gradient bucket; 5 layers with WN_FLAG_BWD_OVERLAP).
                                * Groups never straddle a bucket.  The split-K plan of a group depends on its size, so
@@ -178,7 +187,12 @@ int wn_softmax_ce_loss(const WnConfig* cfg, int B, int T, const float* logits, c
  * n_quantize <= 256 classes of its 128 positions on chip, so the (B, Q, T) logits are never written to or read back from
  * memory -- `loss` and `dlogits` (nullable) come out exactly as wn_softmax_ce_loss defines them, logits_scratch is not
  * touched (may be NULL).  Otherwise (exact-MFMA mode, more than 256 classes, mixture head) the call runs the two entry
- * points back to back and needs logits_scratch (B, Q, T).  The workspace is left as wn_forward leaves it. */
+ * points back to back and needs logits_scratch (B, Q, T).
+ * Workspace after the call: as wn_forward leaves it, EXCEPT that the fused form computes the skip sum and the post-net over
+ * the loss window only -- columns [t0, T) with t0 = t_start rounded down to a multiple of 128: relu(skip) and relu(post1)
+ * (WN_WS_RELU_SKIP / WN_WS_RELU_POST1) are valid from t0 on; in front of t0 they hold zeros (or, with WN_FLAG_WS_FINITE,
+ * whatever finite values were there).  dlogits is exactly zero there, so a backward pass over ANY window start t_first <= t_start
+ * (wn_backward included) yields the same gradients; wn_backward_window(t_first = t_start) is the cheapest. */
 int wn_forward_loss_fused(const WnConfig* cfg, int B, int T, int flags);
 int wn_forward_loss(const WnConfig* cfg, int B, int T, const float* params, const int64_t* x, const float* h,
                     const int64_t* target, int t_start, float grad_scale, float loss_scale, float* loss, float* dlogits,
@@ -189,8 +203,9 @@ int wn_forward_loss(const WnConfig* cfg, int B, int T, const float* params, cons
  * wn_forward call, made with the same WN_FLAG_NO_FUSED / WN_FLAG_EXACT_MFMA choice (the two kernel
  * families save different activations), and `params` must be UNCHANGED since that call: the workspace also holds the
  * re-laid-out / pre-split weight sets wn_forward packed from them (the post-net and skip weights of the backward
- * contractions among them), and wn_backward does not re-pack.  The training loop satisfies this by construction (the
- * optimizer step comes after the backward pass, train.py:533-539).  If events != NULL, hipEvent_t events[i] is recorded on
+ * contractions among them), and wn_backward does not re-pack unless WN_FLAG_REPACK is given.  The training loop satisfies
+ * this by construction (the optimizer step comes after the backward pass, train.py:533-539); the Python engine tracks a
+ * parameter version and raises, like torch.autograd does for a tensor modified in place between forward and backward.  If events != NULL, hipEvent_t events[i] is recorded on
  * `stream` as soon as bucket i (wn_bucket_range) is final, so the caller can all-reduce it on another stream. */
 int wn_backward(const WnConfig* cfg, int B, int T, const float* params, const int64_t* x, const float* h,
                 const float* dlogits, float* grads, void* ws, size_t ws_bytes, void* const* events, int n_events,
@@ -203,7 +218,7 @@ int wn_backward(const WnConfig* cfg, int B, int T, const float* params, const in
  * of every layer's dZ are zero in front of t_first as well: their contractions and the post-net / skip weight gradients
  * run over the window only (from t_first rounded down to a multiple of 128; the skipped columns of dSkip are zero-filled
  * for the residual chain, which needs every position).  Same gradients as wn_backward up to the rounding of a different
- * split-K plan; t_first = 0 IS wn_backward.  WN_LOSS_WINDOW=0 in the environment ignores t_first (A/B measurements). */
+ * split-K plan; t_first = 0 IS wn_backward. */
 int wn_backward_window(const WnConfig* cfg, int B, int T, const float* params, const int64_t* x, const float* h,
                        const float* dlogits, int t_first, float* grads, void* ws, size_t ws_bytes, void* const* events,
                        int n_events, int layers_per_bucket, int flags, void* stream);

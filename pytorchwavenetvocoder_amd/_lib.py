@@ -74,6 +74,8 @@ FLAG_NO_CHAIN = 64  # wn_backward: the former gate' + dX launch pair per layer i
 FLAG_AUX_FUSED = 32  # wn_backward: aux-gradient partial sums in the gate kernel (dP not re-read by aux_bwd); the engine's default
 FLAG_BWD_OVERLAP_HEAD = 16  # with FLAG_BWD_OVERLAP: only the post-net / skip weight gradients on the side stream
 FLAG_FWD_OVERLAP = 8  # wn_forward: chunked skip-sum on the side stream beside the residual stack (opt-in)
+FLAG_WS_FINITE = 1 << 16  # wn_forward_loss: the workspace holds only finite values (the engine allocates it zero-filled)
+FLAG_REPACK = 1 << 17  # wn_backward: rebuild the packed / pre-split weight sets from the params given to that call
 
 
 def flag_dw_flush(n):
@@ -81,7 +83,7 @@ def flag_dw_flush(n):
     return (int(n) & 0xff) << 8
 
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # every symbol include/wavenet_hip.h declares
 EXPORTS = [

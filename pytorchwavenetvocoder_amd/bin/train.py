@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from pytorchwavenetvocoder_amd.nets import WaveNet, encode_mu_law, initialize
-from pytorchwavenetvocoder_amd.utils import background, extend_time, find_files, read_hdf5, read_txt
+from pytorchwavenetvocoder_amd.utils import background, extend_time, find_files, make_feat_transform, read_hdf5, read_txt
 
 
 def strtobool(v):
@@ -73,20 +73,6 @@ def validate_length(x, y, upsampling_factor=None):
             x = x[:y.shape[0] * upsampling_factor]
         assert len(x) == len(y) * upsampling_factor
     return x, y
-
-
-def make_feat_transform(mean, scale):
-    """``StandardScaler.transform`` with given statistics (reference train.py:463-465,468-469): a float copy of the
-    features, ``-= mean`` and ``/= scale`` IN PLACE -- i.e. in the features' own dtype, each step rounded to it, which is
-    what the reference's float32 features get from float64 statistics (bit-equal: tests/test_train_cli.py slicer golden)."""
-    mean, scale = np.asarray(mean), np.asarray(scale)
-
-    def transform(x):
-        x = np.array(x, dtype=x.dtype if np.issubdtype(np.asarray(x).dtype, np.floating) else np.float64, copy=True)
-        x -= mean
-        x /= scale
-        return x
-    return transform
 
 
 def _to_batch(xs, hs, ts, device, ys=None):

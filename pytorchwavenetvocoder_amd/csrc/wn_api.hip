@@ -336,7 +336,8 @@ struct DwPlan {
 };
 static DwPlan dw_plan(int M, int N, int Kdim, int nbatch) {
     const int tm = (M + (M > 64 ? 127 : 63)) / (M > 64 ? 128 : 64);
-    const int tnw = 64 * wn_gemm6_dw_tn(N);   // column tile width the kernel will use
+    // column tile width the kernel will use (the 256-row tiles of wn_gemm6_dw_tall always come with 128 columns)
+    const int tnw = wn_gemm6_dw_tall(M, N) ? 128 : 64 * wn_gemm6_dw_tn(N);
     const int tn = (N + tnw - 1) / tnw;
     const long tiles = (long)tm * tn * nbatch;
     // 128 x 128 tiles (k_gemm6_dw<2,2>, 3 workgroups per CU): as many k-chunks as fit ONE resident round of 768
@@ -879,6 +880,14 @@ static int forward_impl(const WnConfig* cfg, int B, int T, const float* params, 
     // front of it is ever read.  The residual stack itself needs every position.  dlogits[.., t < t0] is zero-filled.
     const int t0 = ce_in ? (ce_in->t_start / 128) * 128 : 0;
     const int Tw = T - t0;
+    // The columns in front of the window are not written by this call.  A later backward pass whose window starts further
+    // left (wn_backward = t_first 0) contracts them with dlogits == 0: any FINITE value there contributes exactly nothing,
+    // uninitialised memory (NaN / Inf bit patterns) would not.  So they are zero-filled unless the caller vouches for the
+    // workspace (WN_FLAG_WS_FINITE: allocated zero-filled, or written by an earlier full forward).
+    if (t0 > 0 && !(flags & WN_FLAG_WS_FINITE)) {
+        WN_TRY(wn_fill_cols(c.ws + c.w.O1, (long)B * c.d.S, T, t0, c.st));
+        WN_TRY(wn_fill_cols(c.ws + c.w.O2, (long)B * c.d.S, T, t0, c.st));
+    }
     WN_TRY(forward_stack(c, params, x, h, side.rt, &cs, (d.L + 2) / 3, &skip_done));
     WN_TRY(side_link(side.rt, cs.st, c.st));  // join: O1 holds the sum of layers [0, skip_done)
     // skip-sum over (the remaining) layers as ONE contraction with K = L*R (wavenet.py:533,238), relu fused (:519)
@@ -1069,6 +1078,10 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
     if (!params || !x || !h || !dlogits || !grads) return fail(1, "NULL argument");
     c.params = params;
     if (t_first < 0 || t_first >= T) return fail(1, "t_first=%d outside [0,%d)", t_first, T);
+    // WN_FLAG_REPACK: `params` changed since the forward call (or the caller cannot tell): rebuild every re-laid-out /
+    // pre-split weight set of the workspace from the buffer given HERE, so that the backward contractions use one
+    // consistent set of weights (the saved activations are the forward pass's own either way).
+    if (flags & WN_FLAG_REPACK) WN_TRY(pack_weights(c, params));
     // Loss window.  The loss of train.py:534-536 covers [:, receptive_field:], so dlogits is exactly zero in front of it, and
     // everything between the logits and the residual stack is pointwise in time: dO2, dSkip and the skip part of every
     // layer's dZ are zero there too, and those columns contribute nothing to the post-net / skip weight gradients.  The

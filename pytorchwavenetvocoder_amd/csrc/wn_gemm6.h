@@ -100,6 +100,7 @@ int wn_gemm6_launch(const WnGemm6Args* g, wn_stream_t st);
 // a_kmajor = b_kmajor = 1 mode incl. segments, shifts, split-K, layers, a_rowsum) on the same 3-way split.
 struct WnGemmArgs;
 int wn_gemm6_dw_eligible(const struct WnGemmArgs* g);
-int wn_gemm6_dw_tall(int M, int N);
-int wn_gemm6_dw_tn(int N);   // 2: 128-column tiles, 1: 64-column tiles (the split-K plan of the caller must use the same rule)   // 256 x 128 tiles for this shape (split path)
+// The split-K plan of the caller (wn_api.hip dw_plan) must count tiles with the same two rules the launcher applies:
+int wn_gemm6_dw_tall(int M, int N);   // 1: 256 x 128 tiles (k_gemm6_dw<4,2>) for this output shape
+int wn_gemm6_dw_tn(int N);            // otherwise: 2 = 128-column tiles, 1 = 64-column tiles
 int wn_gemm6_dw_launch(const struct WnGemmArgs* g, wn_stream_t st);

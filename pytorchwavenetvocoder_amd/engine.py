@@ -53,6 +53,12 @@ class WaveNetEngine(object):
         self._ws = None
         self._ws_key = None
         self._last_shape = None
+        self._fwd_window = 0      # first loss position of the last forward_loss (0: a full forward)
+        self._fwd_version = None  # parameter version the last forward packed its weight sets from
+        self._fwd_flags = 0       # launch-mode flags of the last forward
+        self._params_epoch = 0    # bumped by every in-library parameter update (adam_step): torch cannot see those
+        self._version_sources = ()  # tensors aliasing flat_params whose in-place version counters count as well
+        self.ws_finite = True     # workspace() allocates zero-filled memory -> WN_FLAG_WS_FINITE (tests clear it)
         lo, hi = ctypes.c_int64(), ctypes.c_int64()
         self.lib.check(self.lib.wn_dead_param_range(ctypes.byref(self.cfg), ctypes.byref(lo), ctypes.byref(hi)),
                        "wn_dead_param_range")
@@ -109,9 +115,19 @@ class WaveNetEngine(object):
             if nbytes == 0:
                 raise _lib.WnError("wn_workspace_bytes: %s" % self.lib.wn_last_error().decode())
             self._ws = None  # free first
-            self._ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.device)
+            # zero-filled: wn_forward_loss (FLAG_WS_FINITE) leaves the post-net columns in front of the loss window
+            # untouched, and whatever is there must be finite (include/wavenet_hip.h)
+            self._ws = torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=self.device)
             self._ws_key = key
         return self._ws
+
+    def params_version(self):
+        """Changes whenever the flat parameter buffer is written: torch's in-place version counter (optimizers working
+        on the nn.Parameter views, load_state_dict, ...) plus the engine's count of in-library updates."""
+        v = self.flat_params._version
+        for t in self._version_sources:   # nn.Parameter views keep their own counters (nets.WaveNet registers them)
+            v += t._version
+        return (self.flat_params.data_ptr(), v, self._params_epoch)
 
     def saved(self, kind):
         """View of a tensor the last forward / backward left in the workspace (``_lib.WS_*``; parity tests only)."""
@@ -153,6 +169,9 @@ class WaveNetEngine(object):
         self.lib.check(rc, "wn_forward")
         self._last_shape = (B, T)
         self._last_inputs = (x, h)
+        self._fwd_window = 0
+        self._fwd_version = self.params_version()
+        self._fwd_flags = self.flags
         return logits
 
     def forward_loss(self, x, h, target, t_start=None, grad_scale=1.0, loss_scale=1.0, want_grad=True):
@@ -180,10 +199,16 @@ class WaveNetEngine(object):
         scratch = None if fused else torch.empty((B, self.out_channels, T), dtype=torch.float32, device=self.device)
         rc = self.lib.wn_forward_loss(cfg, B, T, _ptr(self.flat_params), _ptr(x), _ptr(h), _ptr(target), int(t_start),
                                       float(grad_scale), float(loss_scale), _ptr(loss), _ptr(dlogits), _ptr(scratch),
-                                      _ptr(ws), ws.numel() * 4, self.flags, _stream_handle(self.device))
+                                      _ptr(ws), ws.numel() * 4, self.flags | (_lib.FLAG_WS_FINITE if self.ws_finite else 0),
+                                      _stream_handle(self.device))
         self.lib.check(rc, "wn_forward_loss")
         self._last_shape = (B, T)
         self._last_inputs = (x, h)
+        # the fused form ran the skip sum / post-net over the loss window only (saved(WS_RELU_*) is valid from
+        # t_start rounded down to a multiple of 128 on); backward() defaults its window to it
+        self._fwd_window = int(t_start) if fused else 0
+        self._fwd_version = self.params_version()
+        self._fwd_flags = self.flags
         return loss, dlogits
 
     def loss(self, logits, target, t_start=None, grad_scale=1.0, loss_scale=1.0, want_grad=True):
@@ -222,12 +247,33 @@ class WaveNetEngine(object):
         self.lib.check(rc, "wn_mol_loss")
         return loss, dout
 
-    def backward(self, dlogits, events=None, layers_per_bucket=0, t_first=0):
-        """Backward of the last ``forward`` call; fills ``self.grads()`` completely.  ``t_first``: the caller guarantees
-        ``dlogits[:, :, :t_first] == 0`` (the training loss covers ``[:, receptive_field:]``, train.py:534-536): the
-        post-net / skip part of the backward pass then runs over the loss window only (``wn_backward_window``)."""
+    def backward(self, dlogits, events=None, layers_per_bucket=0, t_first=None, repack=False):
+        """Backward of the last ``forward`` / ``forward_loss`` call; fills ``self.grads()`` completely.  ``t_first``: the
+        caller guarantees ``dlogits[:, :, :t_first] == 0`` (the training loss covers ``[:, receptive_field:]``,
+        train.py:534-536): the post-net / skip part of the backward pass then runs over the loss window only
+        (``wn_backward_window``).  Default: the window of the forward call (0 after ``forward``, its ``t_start`` after
+        ``forward_loss``, whose ``dlogits`` is zero in front of it by construction).
+
+        The parameters must not have changed since the forward call -- the workspace holds the weight sets that call
+        packed from them next to its activations.  Like torch.autograd for a tensor modified in place between forward
+        and backward this raises; ``repack=True`` instead rebuilds the weight sets from the current parameters
+        (``WN_FLAG_REPACK``) and back-propagates through those."""
         if self._last_shape is None:
             raise _lib.WnError("backward() without a preceding forward()")
+        if t_first is None:
+            t_first = self._fwd_window
+        flags = self.flags
+        family = _lib.FLAG_NO_FUSED | _lib.FLAG_EXACT_MFMA
+        if (flags ^ self._fwd_flags) & family:
+            raise _lib.WnError("engine.flags changed the kernel family (NO_FUSED / EXACT_MFMA) since the forward call: the "
+                               "two families save different activations and weight sets -- run forward again")
+        if repack:
+            flags |= _lib.FLAG_REPACK
+        elif self._fwd_version is not None and self._fwd_version != self.params_version():
+            raise _lib.WnError("the WaveNet parameters were modified between forward and backward (in-place update, "
+                               "optimizer step or load_state_dict): the gradient of the forward pass is no longer "
+                               "defined -- run forward again, or pass repack=True to back-propagate through the "
+                               "current weights")
         B, T = self._last_shape
         x, h = self._last_inputs
         self._check_device(dlogits)
@@ -242,7 +288,7 @@ class WaveNetEngine(object):
             arr, n_ev = None, 0
         rc = self.lib.wn_backward_window(ctypes.byref(self.cfg), B, T, _ptr(self.flat_params), _ptr(x), _ptr(h),
                                          _ptr(dlogits), int(t_first), _ptr(g), _ptr(ws), ws.numel() * 4, arr, n_ev,
-                                         int(layers_per_bucket), self.flags, _stream_handle(self.device))
+                                         int(layers_per_bucket), flags, _stream_handle(self.device))
         self.lib.check(rc, "wn_backward_window")
         return g
 
@@ -253,6 +299,7 @@ class WaveNetEngine(object):
                                    float(weight_decay), self.dead_range[0], self.dead_range[1],
                                    _stream_handle(self.device))
         self.lib.check(rc, "wn_adam_step")
+        self._params_epoch += 1
 
     # ---- autoregressive decode (reference wavenet.py:309-511) ---------------------------------
     def decode_supported(self):

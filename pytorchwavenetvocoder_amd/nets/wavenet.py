@@ -262,6 +262,8 @@ class WaveNet(nn.Module):
         eng.flat_grads = None
         eng._ws = None
         eng._ws_key = None
+        eng._version_sources = tuple(p for _, p in named)
+        eng._fwd_version = None
         self._param_slices = slices
 
     def _apply(self, fn, *args, **kwargs):
@@ -316,10 +318,13 @@ class WaveNet(nn.Module):
         ``loss_and_backward``."""
         if self.n_mixture <= 0:
             raise ValueError("this model has the softmax head (n_mixture = 0)")
-        if log_scale_min is None:
-            log_scale_min = self.log_scale_min
-        else:   # remembered: generation clamps the log-scales at the value the model was trained with
-            self.log_scale_min = float(log_scale_min)
+        # ONE clamp for the likelihood and for sampling: the constructor's value (it travels in model.conf; a per-call
+        # value would be lost with the checkpoint and generation would clamp differently from training)
+        if log_scale_min is not None and float(log_scale_min) != self.log_scale_min:
+            raise ValueError("log_scale_min=%g differs from the model's %g: pass it to the constructor "
+                             "(train.py --log_scale_min), it is part of the model configuration"
+                             % (float(log_scale_min), self.log_scale_min))
+        log_scale_min = self.log_scale_min
         eng = self._engine
         out = eng.forward(x, h)
         self._fwd_serial += 1

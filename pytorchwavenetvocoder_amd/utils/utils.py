@@ -200,3 +200,17 @@ class background(object):
 def extend_time(feats, upsampling_factor):
     """(T, D) -> (upsampling_factor * T, D) by repeating every frame."""
     return np.repeat(np.asarray(feats), upsampling_factor, axis=0).astype(np.float64)
+
+
+def make_feat_transform(mean, scale):
+    """``StandardScaler.transform`` with given statistics (reference train.py:463-465,468-469): a float copy of the
+    features, ``-= mean`` and ``/= scale`` IN PLACE -- i.e. in the features' own dtype, each step rounded to it, which is
+    what the reference's float32 features get from float64 statistics (bit-equal: tests/test_train_cli.py slicer golden)."""
+    mean, scale = np.asarray(mean), np.asarray(scale)
+
+    def transform(x):
+        x = np.array(x, dtype=x.dtype if np.issubdtype(np.asarray(x).dtype, np.floating) else np.float64, copy=True)
+        x -= mean
+        x /= scale
+        return x
+    return transform

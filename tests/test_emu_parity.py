@@ -480,9 +480,12 @@ def test_loss_window_backward_equals_the_full_backward():
                 assert PC.rel_to_max(grads[k], ref) <= PC.TOL_GRAD, (flags, k)
     # t_first below one tile, or WN_LOSS_WINDOW=0 semantics (t_first = 0): the plain backward, bit for bit
     eng.flags = _lib.FLAG_AUX_FUSED
+    with pytest.raises(_lib.WnError):   # the forward in the workspace is the exact-MFMA family's
+        eng.backward(dl)
+    eng.forward(x, h)
     a = eng.backward(dl).clone()
     b = eng.backward(dl, t_first=127).clone()
-    assert torch.equal(a, b)
+    assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
 
 
 def test_cross_entropy_as_the_epilogue_of_conv_post_2():
@@ -523,6 +526,59 @@ def test_cross_entropy_as_the_epilogue_of_conv_post_2():
         eng.forward(x, h)
         g0 = eng.backward(dl0, t_first=rf).clone()
         assert float((g1 - g0).abs().max()) <= 5e-6 * float(g0.abs().max())
+
+
+def test_windowed_forward_loss_workspace_and_the_parameter_guard():
+    """wn_forward_loss runs the skip sum / post-net over the loss window only (ABI v7 contract): without
+    WN_FLAG_WS_FINITE it zero-fills relu(skip) / relu(post1) in front of the window, so a backward pass with an EARLIER
+    window start (wn_backward: t_first = 0) multiplies dlogits == 0 with zeros, not with whatever the workspace held
+    (here: NaN everywhere) -- same gradients as the windowed backward, which is the engine's default after forward_loss.
+    And the guards of the Python engine: parameters modified between forward and backward raise (like torch.autograd),
+    repack=True rebuilds the packed weight sets instead (WN_FLAG_REPACK)."""
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd import _lib
+    from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat
+    cfg_t = (256, 4, 64, 128, 7, 1, 2, 16)
+    cfg = O.OracleConfig(*cfg_t)
+    rf = cfg.receptive_field
+    assert rf == 128
+    B, T = 1, 272
+    params = O.random_params(cfg, 91, scale=0.2)
+    x, h, t = O.synthetic_batch(cfg, B, T, 92)
+    eng = WaveNetEngine(*cfg_t, device="cpu", library=emu_library())
+    load_state_into_flat(eng, params)
+    eng.workspace(B, T).fill_(float("nan"))
+    eng.ws_finite = False
+    out = {}
+    log = PC.launch_log(emu_library(), lambda: out.update(r=eng.forward_loss(x, h, t)))
+    loss, dl = out["r"]
+    assert log.get("fwd_post2_ce") == 1 and log.get("fill_cols") == 3, log   # dlogits, relu(skip), relu(post1)
+    assert float(eng.saved(_lib.WS_RELU_SKIP)[:, :, :rf].abs().max()) == 0.0
+    assert float(eng.saved(_lib.WS_RELU_POST1)[:, :, :rf].abs().max()) == 0.0
+    g_win = eng.backward(dl).clone()               # default window: the forward's
+    g_full = eng.backward(dl, t_first=0).clone()   # what wn_backward does
+    assert bool(torch.isfinite(g_win).all()) and bool(torch.isfinite(g_full).all())
+    assert float((g_win - g_full).abs().max()) <= 2e-6 * float(g_full.abs().max())
+    loss_ref, _, grads_ref = O.train_step(cfg, params, None, x, h, t)
+    assert abs(float(loss) - float(loss_ref)) <= PC.TOL_LOSS
+    grads = PC.flat_to_state(eng, g_win, O.param_shapes(cfg))
+    for k, ref in grads_ref.items():
+        if ref is not None:
+            assert PC.rel_to_max(grads[k], ref) <= PC.TOL_GRAD, k
+    # the caller vouches for a workspace that is NOT finite: documents what the flag means (no fill launches)
+    eng.ws_finite = True
+    log = PC.launch_log(emu_library(), lambda: eng.forward_loss(x, h, t))
+    assert log.get("fill_cols") == 1, log
+    # parameter guard
+    eng.flat_params[:4] += 0.0    # an in-place write, whatever its value
+    with pytest.raises(_lib.WnError):
+        eng.backward(dl)
+    g_re = eng.backward(dl, repack=True).clone()
+    assert torch.equal(g_re, g_win)
+    eng.forward_loss(x, h, t)
+    eng.adam_step(torch.zeros_like(eng.flat_params), torch.zeros_like(eng.flat_params), 1, 0.0)   # in-library update
+    with pytest.raises(_lib.WnError):
+        eng.backward(dl)
 
 
 def test_front_conv_weight_gradient_on_the_matrix_cores():
