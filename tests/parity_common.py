@@ -228,6 +228,57 @@ def run_fullsize_vs_oracle(cfg_tuple, B, T, seed, lib, device, flag_sets, scale=
     return out
 
 
+def run_mol_vs_restatement(cfg_tuple, n_mix, B, T, seed, lib, device, scale=0.05, threads=32, tol_grad=1e-3):
+    """Mixture-of-logistics head (NOT in the reference: parity unpinned by it) against this repo's own restatement of the
+    published formula (oracle.mol_nll) on the oracle's network output, in fp32 like the kernel: network output, loss,
+    d(loss)/d(output) and every parameter gradient, with the HIP path's own ReLU sub-gradient choice
+    (run_fullsize_vs_oracle's method).  Gates: output TOL_LOGITS abs, loss 1e-4 relative, gradients ``tol_grad`` of a tensor's
+    maximum (the formula with 65536 classes is itself ~1e-3 accurate on gradients in fp32, tests/mol_common.py)."""
+    import os
+    import numpy as np
+    cfg = O.OracleConfig(*cfg_tuple, out_channels=3 * n_mix)
+    rf = cfg.receptive_field
+    params = O.random_params(cfg, seed, scale=scale)
+    x, h, _ = O.synthetic_batch(cfg, B, T, seed + 1)
+    y = torch.from_numpy(np.random.RandomState(seed + 2).uniform(-1, 1, (B, T)).astype(np.float32))
+    eng = WaveNetEngine(*cfg_tuple, device=device, library=lib, out_channels=3 * n_mix)
+    load_state_into_flat(eng, params)
+    out = eng.forward(x.to(device), h.to(device))
+    loss, dout = eng.mol_loss(out, y.to(device))
+    grads = flat_to_state(eng, eng.backward(dout, t_first=rf).cpu(), O.param_shapes(cfg))
+    m_skip = (eng.saved(_lib.WS_RELU_SKIP) > 0).float().cpu()
+    m_post = (eng.saved(_lib.WS_RELU_POST1) > 0).float().cpu()
+    try:
+        navail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        navail = os.cpu_count() or 1
+    old_threads = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(threads, navail)))
+    try:
+        leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        out_ref = O.forward(cfg, leaves, x, h, relu_masks=(m_skip, m_post))      # (B, T, 3 n_mix)
+        out_ref.retain_grad()
+        loss_ref = O.mol_nll(out_ref, y, start=rf)
+        loss_ref.backward()
+    finally:
+        torch.set_num_threads(old_threads)
+    r = {}
+    r["out"] = float((out.transpose(1, 2).cpu() - out_ref.detach()).abs().max())
+    r["loss_rel"] = abs(float(loss.cpu()) - float(loss_ref.detach())) / abs(float(loss_ref.detach()))
+    g_out = out_ref.grad
+    r["dout"] = float((dout.transpose(1, 2).cpu() - g_out).abs().max()) / float(g_out.abs().max())
+    r["grad"], r["grad_key"] = 0.0, None
+    for k, v in leaves.items():
+        if v.grad is None or float(v.grad.abs().max()) == 0.0:
+            assert float(grads[k].abs().max()) == 0.0, k
+            continue
+        e = rel_to_max(grads[k], v.grad)
+        if e > r["grad"]:
+            r["grad"], r["grad_key"] = e, k
+    assert r["out"] <= TOL_LOGITS and r["loss_rel"] <= 1e-4 and r["dout"] <= tol_grad and r["grad"] <= tol_grad, r
+    return r
+
+
 def launch_log(lib, fn):
     """Run ``fn()`` with the library's per-launch log on; returns {tag: launches}.  (On the GPU the log carries HIP-event
     times as well -- bench.py's kernel table; the host emulator keeps the counts.)"""

@@ -95,11 +95,28 @@ def test_config4_stated_size_vs_oracle():
           "%d kink flips" % (res["logits"], res["loss"], res["layer_inputs"], res["grads"], res["kink_flips"]))
 
 
-def test_recipe_size_model_at_the_timed_length_vs_oracle():
-    """The recipe-size model (n_resch 512) at the window length tools/recipe_bench.py times (T = 23040; B = 2 of its 4 windows:
-    the CPU oracle needs ~1 min and ~30 GB at this width): multi-round tile walks and the split-K plans of the full length."""
+def test_recipe_size_model_at_the_timed_size_vs_oracle():
+    """The recipe-size model (n_resch 512) at EXACTLY the size tools/recipe_bench.py and bench.py's extras time: B = 4 windows
+    of T = 23040 (the CPU oracle needs ~2 min and ~60 GB at this width): multi-round tile walks and the split-K plans of
+    the full length and batch.  (Round 3 checked B = 2 of the 4 windows.)"""
     from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS
     cfg_t = (256, 80, 512, 256, 10, 3, 2, 80)
-    res = PC.run_fullsize_vs_oracle(cfg_t, 2, 23040, 112, _lib(), DEV, flag_sets=[DEFAULT_FLAGS], scale=0.02)
-    print("recipe-size model at T=23040, B=2 vs oracle: logits %.3g, loss %.3g, layer inputs %.3g, grads %s, %d kink flips"
-          % (res["logits"], res["loss"], res["layer_inputs"], res["grads"], res["kink_flips"]))
+    res = PC.run_fullsize_vs_oracle(cfg_t, 4, 23040, 112, _lib(), DEV, flag_sets=[DEFAULT_FLAGS], scale=0.02)
+    print("recipe-size model at the TIMED SIZE (B=4, T=23040) vs oracle: logits %.3g, loss %.3g, layer inputs %.3g, grads %s, "
+          "%d kink flips" % (res["logits"], res["loss"], res["layer_inputs"], res["grads"], res["kink_flips"]))
+
+
+def test_config4_mol_head_stated_size_vs_own_restatement():
+    """BASELINE configs[3] AS STATED -- kernel_size 3, upsampling_factor 256, B = 8 x batch_len 20000 (T = 26112), 10-component
+    mixture-of-logistics head.  PARITY UNPINNED BY THE REFERENCE: it has no such head (wavenet.py:209-210,518-523 is softmax
+    only), so the checker is this repo's own restatement of the published discretised mixture of logistics
+    (oracle.mol_nll) on the oracle's network output, evaluated in fp32 like the kernel: network output, loss, d(loss)/d(output)
+    and every parameter gradient (same ReLU sub-gradient choice as the HIP path, parity_common.run_fullsize_vs_oracle's method).
+    Gates: output 1e-4 abs; loss 1e-4 relative; gradients 1e-3 of a tensor's maximum -- the published formula with 65536 classes
+    is itself only ~1e-3 accurate on gradients in fp32 (tests/mol_common.py: the fp32 oracle against its fp64 evaluation)."""
+    from oracle import wavenet_oracle as O
+    cfg_t = (256, 80, 64, 256, 10, 3, 3, 256)
+    assert O.OracleConfig(*cfg_t).receptive_field == 6139
+    r = PC.run_mol_vs_restatement(cfg_t, 10, 8, 26112, 121, _lib(), DEV, scale=0.05)
+    print("configs[3] MoL head STATED SIZE (K=3, U=256, B=8, T=26112, 10 mixtures) vs own restatement (unpinned by the reference): "
+          "output %.3g, loss rel %.3g, dout %.3g, worst gradient %.3g (%s)" % (r["out"], r["loss_rel"], r["dout"], r["grad"], r["grad_key"]))

@@ -60,3 +60,11 @@ def test_log_scale_min_is_part_of_the_model_configuration():
     assert "log_scale_min=getattr(config" in inspect.getsource(D.build_model)
     m = WaveNet(16, 3, 8, 8, 2, 1, 2, 0, n_mixture=2, _library=emu_library(), log_scale_min=conf.log_scale_min)
     assert m.log_scale_min == -5.5 and not any("log_scale" in k for k in m.state_dict())
+
+
+def test_mol_vs_restatement_harness_emulator():
+    """The harness of the stated-size GPU test (tests/test_gpu_fullsize.py::test_config4_mol_head_stated_size...) on a toy
+    geometry with kernel_size 3 and an upsampling layer, on the emulator."""
+    from tests import parity_common as PC
+    r = PC.run_mol_vs_restatement((32, 4, 8, 12, 3, 2, 3, 4), 4, 2, 64, 31, emu_library(), "cpu", scale=0.3, threads=4, tol_grad=5e-3)
+    assert r["grad_key"] is not None

@@ -20,13 +20,14 @@ from pytorchwavenetvocoder_amd.nets import WaveNet, initialize  # noqa: E402
 from pytorchwavenetvocoder_amd.optim import FusedAdam  # noqa: E402
 
 
-def measure(resch=512, kernel_size=2, upsampling=80, T=23040, batch=4, steps=5, aux=80, device="cuda:0", with_kernels=True):
+def measure(resch=512, kernel_size=2, upsampling=80, T=23040, batch=4, steps=5, aux=80, device="cuda:0", with_kernels=True,
+            n_mixture=0):
     """Median-free quick timing of one training step (forward + CE + backward + Adam) of a 30-layer model of the given
     geometry on synthetic data; returns a dict (ms_per_step, samples_per_sec, approx_train_tflops, per-kernel table)."""
     dev = torch.device(device)
     torch.manual_seed(1)
     R, S, A, U, L, K = resch, 256, aux, upsampling, 30, kernel_size
-    model = WaveNet(256, A, R, S, 10, 3, K, U)
+    model = WaveNet(256, A, R, S, 10, 3, K, U, n_mixture=n_mixture)
     model.apply(initialize)
     model.to(dev)
     B = batch
@@ -34,10 +35,11 @@ def measure(resch=512, kernel_size=2, upsampling=80, T=23040, batch=4, steps=5, 
     xx = torch.randint(0, 256, (B, T + 1), generator=g)
     x, t = xx[:, :-1].contiguous().to(dev), xx[:, 1:].contiguous().to(dev)
     h = torch.randn(B, A, T // U, generator=g).to(dev)
+    y = (torch.rand(B, T, generator=g) * 2 - 1).to(dev)   # mixture head: the waveform value of the next sample
     opt = FusedAdam(model, lr=1e-4)
 
     def step():
-        loss = model.loss_and_backward(x, h, t)
+        loss = model.mol_loss_and_backward(x, h, y) if n_mixture > 0 else model.loss_and_backward(x, h, t)
         opt.step()
         return loss
 
@@ -50,7 +52,8 @@ def measure(resch=512, kernel_size=2, upsampling=80, T=23040, batch=4, steps=5, 
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     flop_fwd = 2.0 * B * T * (L * (2 * R * R * K + 2 * A * R / U + R * S + R * R) + S * S + S * 256)
-    out = {"model": "%d/%d, A=%d, K=%d, U=%d, 30 layers" % (R, S, A, K, U), "B": B, "T": T, "rf": model.receptive_field,
+    out = {"model": "%d/%d, A=%d, K=%d, U=%d, 30 layers%s" % (R, S, A, K, U, ", %d-component mixture-of-logistics head" % n_mixture if n_mixture else ""),
+           "B": B, "T": T, "rf": model.receptive_field,
            "ms_per_step": dt * 1e3, "samples_per_sec": B * (T - model.receptive_field) / dt,
            "approx_train_tflops": 3 * flop_fwd / dt / 1e12, "loss": float(loss)}
     if with_kernels:
@@ -81,8 +84,10 @@ def main():
     ap.add_argument("--kernel-size", type=int, default=2)
     ap.add_argument("--upsampling", type=int, default=80)
     ap.add_argument("--T", type=int, default=23040, help="model inputs per window (BASELINE configs[3]: 26112)")
+    ap.add_argument("--n-mixture", type=int, default=0, help="mixture-of-logistics head with this many components (0: softmax)")
     args = ap.parse_args()
-    print(json.dumps(measure(args.resch, args.kernel_size, args.upsampling, args.T, args.batch, args.steps, args.aux)))
+    print(json.dumps(measure(args.resch, args.kernel_size, args.upsampling, args.T, args.batch, args.steps, args.aux,
+                             n_mixture=args.n_mixture)))
 
 
 if __name__ == "__main__":
