@@ -258,6 +258,80 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
     // The fences pin this order for VALU, MFMA and memory instructions; LDS reads (the next row tile's fragments) and scalar
     // instructions may cross them.  The slab is issued BEFORE the activation loads, so "at most 8 loads outstanding" at the
     // end of the step == "the weight slab has landed in LDS" (vmcnt retires in order).
+#ifdef WN_G6_FINE
+    // Fine interleave (A/B build): ONE piece of the step's other work after every pair of MFMAs (24 slots per step) instead of
+    // one slice after every 12: the MFMAs of a row tile otherwise issue as a burst, and the wave then issues its 20 - 50
+    // loads / VALU instructions with the matrix pipe draining behind it.  Same MFMAs in the same order: bit-identical.
+    //   slots 0-5: the weight slab (6 LDS-DMA pieces)   6-13: the 8 activation loads   14-21: the operand split, half a pair
+    //   per slot   22: the three LDS writes of the split pieces
+    auto step = [&](int st, int stn, const float (&rb)[8], float (&rbn)[8], int ka, bool last) {
+        const char* sa = smem_raw + st * ST_BYTES;
+        const char* sb = sa + A_BYTES;
+        unsigned h[4], md[4], lo[4];
+        float r0[4], r1[4];
+        wn_f4 bf[3][2];
+        WN_UNROLL
+        for (int p = 0; p < 3; ++p) {
+            WN_UNROLL
+            for (int j = 0; j < 2; ++j)
+                bf[p][j] = *reinterpret_cast<const wn_f4*>(sb + p * (WN_G6_BN * 32) + wn_frag_off(64 * wn + 32 * j + li, hi));
+        }
+        // state of the activation loads of this step (see fetch_b)
+        const wn_rsrc_t Br = wn_make_buf(Bz + (long)fb_seg * g.b_seg_stride, (unsigned)((long)(one_seg ? g.K : g.b_seg_len) * g.ldb * 4));
+        const int cc = n0 + bn - (g.b_shift0 + fb_seg * g.b_shift_step);
+        const int voff = (n_ok && cc >= 0 && cc < g.b_clen) ? cc * 4 : 0x7ffffff0;
+        const int rlast = g.K - 1 - (fb_k0 - fb_rr);
+        char* sda = smem_raw + stn * ST_BYTES + wave_u * 1024;
+        const int kc = ka < nk ? ka : nk - 1;
+        WN_UNROLL
+        for (int i = 0; i < 4; ++i) {
+            wn_f4 af[3];
+            WN_UNROLL
+            for (int p = 0; p < 3; ++p)
+                af[p] = *reinterpret_cast<const wn_f4*>(sa + p * (WN_G6_BM * 32) + wn_frag_off(128 * wm + 32 * i + li, hi));
+            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+            WN_UNROLL
+            for (int t = 0; t < 6; ++t) {
+                WN_UNROLL
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(af[PA[t]], bf[PB[t]][j], acc[i][j]);
+                if (last) continue;   // the final step has nothing to prepare
+                const int sl = i * 6 + t;
+                WN_SCHED_FENCE_ALU();
+                if (sl < 6) {
+                    const int p = sl >> 1;
+                    const unsigned src = (unsigned)((kc * 3 + p) * g.Mpad + m0) * 32u + ((sl & 1) ? 4096u : 0u);
+                    wn_buf_load_lds16(Ar, sda + p * (WN_G6_BM * 32) + ((sl & 1) ? 4096 : 0), a_voff, src);
+                } else if (sl < 14) {
+                    const int e = sl - 6;
+                    int r = fb_rr + 8 * bkh_u + e;
+                    r = r < rlast ? r : rlast;
+                    rbn[e] = wn_buf_load(Br, voff, r * (int)g.ldb * 4);
+                } else if (sl < 22) {
+                    const int q = (sl - 14) >> 1;
+                    if (((sl - 14) & 1) == 0) {
+                        const float x0 = rb[2 * q] * fs, x1 = rb[2 * q + 1] * fs;
+                        h[q] = wn_pk_bf16(x0, x1);
+                        r0[q] = x0 - wn_bits_f32(h[q] << 16);
+                        r1[q] = x1 - wn_bits_f32(h[q] & 0xffff0000u);
+                    } else {
+                        md[q] = wn_pk_bf16(r0[q], r1[q]);
+                        lo[q] = wn_pk_bf16(r0[q] - wn_bits_f32(md[q] << 16), r1[q] - wn_bits_f32(md[q] & 0xffff0000u));
+                    }
+                } else if (sl == 22) {
+                    write_pieces(stn, h, md, lo);
+                }
+                WN_SCHED_FENCE_ALU();
+            }
+        }
+        if (!last) {   // next step of the activation loads; a step past the end stays on the last one (its data is not used)
+            const bool more = fb_k0 + 16 < nk * 16;
+            const bool wrap = fb_rr + 16 >= seg_rows;
+            fb_k0 = more ? fb_k0 + 16 : fb_k0;
+            fb_seg = (more && wrap) ? fb_seg + 1 : fb_seg;
+            fb_rr = more ? (wrap ? 0 : fb_rr + 16) : fb_rr;
+        }
+    };
+#else
     auto step = [&](int st, int stn, const float (&rb)[8], float (&rbn)[8], int ka, bool last) {
         const char* sa = smem_raw + st * ST_BYTES;
         const char* sb = sa + A_BYTES;
@@ -292,6 +366,7 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
         }
         if (!last) write_pieces(stn, h, md, lo);
     };
+#endif
     // Steps are processed in pairs with the two register sets swapping roles.  Entering a pair (kb, kb + 1): LDS stage 0
     // holds step kb (weights and split activations), rb1 the activations of step kb + 1, rb0 is free.
     fetch_a(0, 0);

@@ -17,6 +17,12 @@ OUT = os.path.join(HERE, "_build")
 SOURCES = ["wn_gemm.hip", "wn_gemm6.hip", "wn_elem.hip", "wn_fused.hip", "wn_decode.hip", "wn_prof.hip", "wn_api.hip"]
 LIB = os.path.join(OUT, "libwavenet_emu.so")
 FLAGS = ["-O2", "-std=c++17", "-fPIC", "-DWN_EMU", "-Wno-psabi", "-mfma", "-ffp-contract=off", "-I", HERE, "-I", CSRC, "-x", "c++"]
+# A/B build macros of the kernel sources (e.g. WN_EMU_EXTRA_FLAGS="-DWN_G6_FINE") get their own build directory
+_EXTRA = os.environ.get("WN_EMU_EXTRA_FLAGS", "").split()
+if _EXTRA:
+    FLAGS = FLAGS[:4] + _EXTRA + FLAGS[4:]
+    OUT = os.path.join(HERE, "_build", "variant_" + hashlib.sha256(" ".join(_EXTRA).encode()).hexdigest()[:10])
+    LIB = os.path.join(OUT, "libwavenet_emu.so")
 
 
 def _digest():

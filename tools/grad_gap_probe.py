@@ -23,11 +23,17 @@ DEV = "cuda:0"
 
 
 def main():
-    B, T = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (2, 9600)
-    cfg_t = (256, 80, 64, 256, 10, 3, 2, 80)
+    # grad_gap_probe.py [B T [kernel_size upsampling [seed]]]   (configs[3] geometry: 2 6656 3 256 6 = the reduced-size test)
+    a = [int(v) for v in sys.argv[1:]]
+    B, T = (a[0], a[1]) if len(a) > 1 else (2, 9600)
+    K, U = (a[2], a[3]) if len(a) > 3 else (2, 80)
+    seed = a[4] if len(a) > 4 else 101
+    cfg_t = (256, 80, 64, 256, 10, 3, K, U)
     cfg = O.OracleConfig(*cfg_t)
-    params = O.random_params(cfg, 101, scale=0.05)
-    x, h, t = O.synthetic_batch(cfg, B, T, 102)
+    params = O.random_params(cfg, seed, scale=0.05)
+    x, h, t = O.synthetic_batch(cfg, B, T, seed + 1)
+    print("model K=%d U=%d rf=%d, B=%d T=%d (%d loss positions per sequence), seed %d" % (K, U, cfg.receptive_field, B, T,
+                                                                                          T - cfg.receptive_field, seed))
     eng = WaveNetEngine(*cfg_t, device=DEV, library=L.load_library())
     load_state_into_flat(eng, params)
     eng.flags = DEFAULT_FLAGS
