@@ -33,7 +33,6 @@ typedef struct WnGemm6Args {
     int nbatch;
     const char* tag;
     int no_interior;            // set by wn_gemm6_launch (tuning knob WN_G6_INTERIOR=0)
-    int flip;                   // 1: odd column tiles contract -B and negate the result (k_gemm6: cancels the matrix core's truncation bias over positions)
     int stagger;                // set by wn_gemm6_launch (WN_G6_STAGGER): head start, in s_sleep(127) units, of the first block of a CU over its co-resident
     // Gate epilogues of the any-size residual block (R % 128 == 0): the contraction's result never goes to memory.
     // gate_S != NULL (forward, reference wavenet.py:529-532): M = 2R rows packed with wn_gemm6_pack(..., gate_R = R), so that
@@ -67,7 +66,7 @@ typedef struct WnGemm6Args {
 
 static inline void wn_gemm6_no_gate(WnGemm6Args* a) {
     a->gate_R = 0; a->gate_S = 0; a->gate_Gt = 0; a->gate_Z = 0; a->gate_G = 0; a->gate_gb = 0; a->gate_F = 0; a->gate_U = 1;
-    a->gate_upw = 0; a->gate_cvec = 0; a->gbw_S = 0; a->gbw_Gt = 0; a->gbw_dP = 0; a->no_interior = 0; a->stagger = 0; a->flip = 0;
+    a->gate_upw = 0; a->gate_cvec = 0; a->gbw_S = 0; a->gbw_Gt = 0; a->gbw_dP = 0; a->no_interior = 0; a->stagger = 0;
     a->ce_target = 0; a->ce_tstride = 0; a->ce_t_start = 0; a->ce_gs = 0.f; a->ce_partial = 0;
 }
 

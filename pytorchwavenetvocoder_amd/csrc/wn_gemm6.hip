@@ -160,11 +160,14 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
     const float* __restrict__ Bz = g.B + (long)b * g.b_zstride;
     const int nk = (g.K + 15) / 16;
     const bool one_seg = g.b_seg_len >= g.K;
-    // Sign of this column tile's arithmetic (g.flip): odd column tiles contract -B and negate the result.  The matrix core
-    // aligns the products of a step against the accumulator by truncation, which leaves a small bias of CONSTANT sign on
-    // every output; with the operand negated the bias changes sign with it, so over the positions of a sequence -- and
-    // every parameter gradient is a sum over positions -- it cancels instead of adding up.
-    const float fs = (g.flip && (blk.x & 1)) ? -1.0f : 1.0f;
+    // Sign of this column tile's arithmetic: odd column tiles contract -B and negate the result.  The matrix core aligns the
+    // products of a step against the accumulator by truncation, which leaves a small bias of CONSTANT (negative) sign on every
+    // output -- measured on the recipe-size backward pass: -1e-7 of the mean magnitude after a K = 2048 contraction, -1.4e-8
+    // more per layer, which a bias-type gradient (a sum over every position) turned into 6.2e-5 of its maximum
+    // (profiles/r04/wide_drift_*.txt).  With the operand negated the bias changes sign with it, so over the positions of a
+    // sequence it cancels instead of adding up (same probe: 9.0e-6).  Exact in every other respect: -x splits into the
+    // negated pieces of x.
+    const float fs = (blk.x & 1) ? -1.0f : 1.0f;
     // De-phase the two blocks that share a CU (WN_G6_STAGGER, A/B knob).  They start together, do the same work and so
     // stay in lock step: both in their prologue (HBM latency) and both in their epilogue (stores) at the same time, with the
     // matrix pipe idle.  The second resident of the first round -- its waves sit in wave slot 1 of their SIMDs -- starts
@@ -258,10 +261,14 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
     // The fences pin this order for VALU, MFMA and memory instructions; LDS reads (the next row tile's fragments) and scalar
     // instructions may cross them.  The slab is issued BEFORE the activation loads, so "at most 8 loads outstanding" at the
     // end of the step == "the weight slab has landed in LDS" (vmcnt retires in order).
-#ifdef WN_G6_FINE
-    // Fine interleave (A/B build): ONE piece of the step's other work after every pair of MFMAs (24 slots per step) instead of
-    // one slice after every 12: the MFMAs of a row tile otherwise issue as a burst, and the wave then issues its 20 - 50
-    // loads / VALU instructions with the matrix pipe draining behind it.  Same MFMAs in the same order: bit-identical.
+    // One k-step.  The 48 MFMAs on LDS stage `st` carry everything else of the step in their shadow, ONE piece after every pair
+    // of MFMAs (24 slots per step).  A wave's own independent VALU / memory instructions issue between its MFMAs for free
+    // (tools/microbench/mfma_valu.hip), but only if they really sit BETWEEN them: with one slice per row tile (round 2/3) the
+    // ISA showed the 12 MFMAs of a tile issued as a burst and the slice's 20 - 50 instructions behind them with the matrix pipe
+    // draining (round 4, same box: fwd_skip_sum 0.78 -> 0.70 ms, recipe-size step 134.8 -> 128.7 ms,
+    // profiles/r04/ab_gemm6_fine_noslp.txt).  The fences pin the order for VALU, MFMA and memory instructions; LDS reads (the
+    // next row tile's fragments) and scalar instructions may cross them.  The weight slab is issued BEFORE the activation
+    // loads, so "at most 8 loads outstanding" at the end of the step == "the slab has landed in LDS" (vmcnt retires in order).
     //   slots 0-5: the weight slab (6 LDS-DMA pieces)   6-13: the 8 activation loads   14-21: the operand split, half a pair
     //   per slot   22: the three LDS writes of the split pieces
     auto step = [&](int st, int stn, const float (&rb)[8], float (&rbn)[8], int ka, bool last) {
@@ -331,42 +338,6 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
             fb_rr = more ? (wrap ? 0 : fb_rr + 16) : fb_rr;
         }
     };
-#else
-    auto step = [&](int st, int stn, const float (&rb)[8], float (&rbn)[8], int ka, bool last) {
-        const char* sa = smem_raw + st * ST_BYTES;
-        const char* sb = sa + A_BYTES;
-        unsigned h[4], md[4], lo[4];
-        wn_f4 bf[3][2];
-        WN_UNROLL
-        for (int p = 0; p < 3; ++p) {
-            WN_UNROLL
-            for (int j = 0; j < 2; ++j)
-                bf[p][j] = *reinterpret_cast<const wn_f4*>(sb + p * (WN_G6_BN * 32) + wn_frag_off(64 * wn + 32 * j + li, hi));
-        }
-        WN_UNROLL
-        for (int i = 0; i < 4; ++i) {
-            wn_f4 af[3];
-            WN_UNROLL
-            for (int p = 0; p < 3; ++p)
-                af[p] = *reinterpret_cast<const wn_f4*>(sa + p * (WN_G6_BM * 32) + wn_frag_off(128 * wm + 32 * i + li, hi));
-            // small terms first; the two column tiles alternate so that back-to-back MFMAs never
-            // depend on each other (a dependent 32x32x16 issues ~25% slower)
-            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
-            WN_UNROLL
-            for (int t = 0; t < 6; ++t) {
-                WN_UNROLL
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(af[PA[t]], bf[PB[t]][j], acc[i][j]);
-            }
-            if (last) continue;   // the final step has nothing to prepare
-            WN_SCHED_FENCE_ALU();
-            if (i == 0) fetch_a(ka, stn);
-            if (i == 1) fetch_b(rbn);
-            split_pair(i, rb, h, md, lo);
-            WN_SCHED_FENCE_ALU();
-        }
-        if (!last) write_pieces(stn, h, md, lo);
-    };
-#endif
     // Steps are processed in pairs with the two register sets swapping roles.  Entering a pair (kb, kb + 1): LDS stage 0
     // holds step kb (weights and split activations), rb1 the activations of step kb + 1, rb0 is free.
     fetch_a(0, 0);
@@ -430,8 +401,8 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
                 WN_UNROLL
                 for (int r = 0; r < 16; ++r) {
                     const int c = cb + mfma32_row(r, 0);
-                    const float pa = acc[i][j][r] + (wj * ga[r] + g.gate_cvec[c]);
-                    const float pg = acc[i + 2][j][r] + (wj * gg[r] + g.gate_cvec[R + c]);
+                    const float pa = acc[i][j][r] * fs + (wj * ga[r] + g.gate_cvec[c]);
+                    const float pg = acc[i + 2][j][r] * fs + (wj * gg[r] + g.gate_cvec[R + c]);
                     const float sv = wn_sigmoid(pa), gv = wn_tanh(pg);
                     const int off = ok ? (cb * (int)g.ldc + col) * 4 : 0x7ffffff0;
                     wn_buf_store(Sr, sv, off, mfma32_row(r, 0) * T4);
@@ -511,7 +482,7 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
                 WN_UNROLL
                 for (int r = 0; r < 16; ++r) {
                     const int row = 128 * wm + 32 * i + mfma32_row(r, hi);
-                    float v = acc[i][j][r] + bv[r];
+                    float v = acc[i][j][r] * fs + bv[r];
                     v = row < g.M ? v : NEG;
                     acc[i][j][r] = v;
                     mx[j] = fmaxf(mx[j], v);
@@ -681,9 +652,6 @@ int wn_gemm6_launch(const WnGemm6Args* gp, wn_stream_t st) {
         // ~4000 cycles per 16-k step with two blocks per CU; one s_sleep(127) = 8128 cycles
         g.stagger = g.K <= 512 ? (int)(((long)pct * ((g.K + 15) / 16) * 4000L) / (100L * 8128L)) : 0;
     }
-#ifdef WN_G6_FLIP   // experiment build (tools/wide_drift_probe.py): alternating-sign column tiles for the backward-dX type launches
-    g.flip = (g.tag && g.tag[0] == 'b' && g.tag[1] == 'w' && g.tag[2] == 'd' && !g.ce_target && !g.gate_S) ? 1 : 0;
-#endif
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.nbatch <= 0) return 1;
     if (g.b_seg_len < g.K && (g.b_seg_len % 16) != 0) return 2;
     if (g.ce_target && (g.Mpad != WN_G6_BM || !g.ce_partial || g.gate_S || g.gbw_dP || g.E || g.D || g.accumulate || g.relu)) return 4;
@@ -777,6 +745,10 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 4 ? 2 : 3)) void k_gemm6_dw(WnGemm
     const bool a_tile_ok = (m0 + BM) <= g.M, b_tile_ok = (n0 + BN) <= g.N;
     float rowsum = 0.f;
     const float b_floor = g.b_relu ? 0.f : -__builtin_inff();
+    // Odd (batch, k-chunk) partials contract -A and are stored negated: the matrix core's truncation bias (see k_gemm6)
+    // changes sign with the operand, so it cancels in the fixed-order sum of the partials instead of adding up over time.
+    // (The bias row sums are fp32 VALU sums of the un-negated values.)
+    const unsigned a_sign = WN_UNIFORM((zr & 1) ? 0x80008000u : 0u);   // applied to the three bf16 pieces of A at their LDS write
 
     auto fetch = [&](int k0, float (&ra)[AE], float (&rb)[BE]) {
         const bool full = (k0 + 16) <= kend;
@@ -808,7 +780,7 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 4 ? 2 : 3)) void k_gemm6_dw(WnGemm
         }
     };
     // split E consecutive-k values and write the three pieces of row `row` at k offset `kofs`
-    auto split_store = [&](char* base, int rows, int row, int kofs, const float* v, int E) {
+    auto split_store = [&](char* base, int rows, int row, int kofs, const float* v, int E, unsigned sign = 0u) {
         unsigned h[8], md[8], lo[8];  // E <= 16
         for (int q = 0; q < E / 2; ++q) {
             const float x0 = v[2 * q], x1 = v[2 * q + 1];
@@ -822,7 +794,7 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 4 ? 2 : 3)) void k_gemm6_dw(WnGemm
             char* d = base + p * rows * 32;
             for (int q = 0; q < E / 2; ++q) {   // dword kq of the row: k half kq >> 2 (placement: wn_frag_off), dword kq & 3 of it
                 const int kq = (kofs >> 1) + q;
-                *reinterpret_cast<unsigned*>(d + wn_frag_off(row, kq >> 2) + (kq & 3) * 4) = src[p][q];
+                *reinterpret_cast<unsigned*>(d + wn_frag_off(row, kq >> 2) + (kq & 3) * 4) = src[p][q] ^ sign;
             }
         }
     };
@@ -834,7 +806,7 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 4 ? 2 : 3)) void k_gemm6_dw(WnGemm
             for (int e = 0; e < AE; ++e) rs += ra[e];
             rowsum += counted ? rs : 0.f;
         }
-        split_store(sa, BM, a_row, a_k, ra, AE);
+        split_store(sa, BM, a_row, a_k, ra, AE, a_sign);
         // the optional ReLU on B is a floor applied HERE, not at the load: anything that touches the loaded registers
         // right after the load makes the wait for them land before the MFMAs they were supposed to hide under
         float rbf[BE];
@@ -938,13 +910,14 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 4 ? 2 : 3)) void k_gemm6_dw(WnGemm
             md = wn_pk_bf16(r0, r1);
             lo = wn_pk_bf16(r0 - wn_bits_f32(md << 16), r1 - wn_bits_f32(md & 0xffff0000u));
         };
-        auto put = [&](char* base, int rows, int row, int kofs, const unsigned* h, const unsigned* md, const unsigned* lo, int np) {
+        auto put = [&](char* base, int rows, int row, int kofs, const unsigned* h, const unsigned* md, const unsigned* lo, int np,
+                       unsigned sign) {
             const unsigned* src[3] = {h, md, lo};
             for (int p = 0; p < 3; ++p) {
                 char* d = base + p * rows * 32;
                 for (int q = 0; q < np; ++q) {
                     const int kq = (kofs >> 1) + q;
-                    *reinterpret_cast<unsigned*>(d + wn_frag_off(row, kq >> 2) + (kq & 3) * 4) = src[p][q];
+                    *reinterpret_cast<unsigned*>(d + wn_frag_off(row, kq >> 2) + (kq & 3) * 4) = src[p][q] ^ sign;
                 }
             }
         };
@@ -959,11 +932,11 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 4 ? 2 : 3)) void k_gemm6_dw(WnGemm
                 if (q < NPA) {
                     pair(ra[2 * q], ra[2 * q + 1], ha[q], ma[q], la[q]);
                     if (g.a_rowsum != nullptr) rowsum += counted ? ra[2 * q] + ra[2 * q + 1] : 0.f;
-                    if (q == NPA - 1) put(da, BM, a_row, a_k, ha, ma, la, NPA);
+                    if (q == NPA - 1) put(da, BM, a_row, a_k, ha, ma, la, NPA, a_sign);
                 } else if (q < NPA + NPB) {
                     const int qb = q - NPA;
                     pair(fmaxf(rb[2 * qb], b_floor), fmaxf(rb[2 * qb + 1], b_floor), hb[qb], mb[qb], lb[qb]);
-                    if (qb == NPB - 1) put(da + A_BYTES, BN, b_row, b_k, hb, mb, lb, NPB);
+                    if (qb == NPB - 1) put(da + A_BYTES, BN, b_row, b_k, hb, mb, lb, NPB, 0u);
                 }
             }
         };
@@ -1049,7 +1022,8 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 4 ? 2 : 3)) void k_gemm6_dw(WnGemm
             WN_UNROLL
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * TM + i) * 32 + mfma32_row(r, hi);
-                wn_buf_store(Cr, acc[i][j][r], (m < g.M && n < g.N) ? (m * (int)g.ldc + n) * 4 : 0x7ffffff0, 0);
+                const float v = wn_bits_f32(__builtin_bit_cast(unsigned, (float)acc[i][j][r]) ^ (a_sign & 0x80000000u));   // * (+-1)
+                wn_buf_store(Cr, v, (m < g.M && n < g.N) ? (m * (int)g.ldc + n) * 4 : 0x7ffffff0, 0);
             }
         }
     }

@@ -27,7 +27,7 @@ except ImportError:  # pragma: no cover
     h5py = None
 
 __all__ = ["check_hdf5", "read_hdf5", "shape_hdf5", "write_hdf5", "find_files", "read_txt",
-           "BackgroundGenerator", "background", "extend_time"]
+           "BackgroundGenerator", "background", "extend_time", "make_feat_transform"]
 
 
 def _is_npz(path):

@@ -2,6 +2,9 @@
 # One GPU visit: parity tests, smoke, bench (A/B of the bucket structure), rocprofv3 kernel stats of the same command, PMC
 # passes, the recipe's stage 4/5, the 2-rank control flow on one GPU.  Each part has its own timeout and log under gpurun_out/.
 #   gpurun --timeout 1500 -- 'bash tools/gpu_visit.sh [parts...]'      parts: tests smoke bench lpb abk rocprof pmc recipe tworank recipesize
+#   round 4 added: micro (tools/microbench/handoff.hip, built into tools/exp/ beforehand), drift (tools/wide_drift_probe.py),
+#   gap (tools/grad_gap_probe.py on the configs[3] reduced case), pmc3 (counter passes of the configs[3] geometry), seltests
+#   (pytest -m gpu -k "$WN_TEST_K")
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 cd "$ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
 OUT="$ROOT/gpurun_out"
@@ -77,6 +80,24 @@ print({k: v for k, v in d.items() if k != "kernels"})
 for k, v in list(d["kernels"].items())[:14]:
     print("%-24s %3d launches %8.3f ms  tflops %s  GB/s %s" % (k, v["launches"], v["ms"], v["tflops"] and round(v["tflops"], 1), v["GBps"] and round(v["GBps"])))
 P
+fi
+if has micro; then
+  [ -x tools/exp/handoff ] || hipcc --offload-arch=gfx950 -O3 -o tools/exp/handoff tools/microbench/handoff.hip
+  timeout 120 tools/exp/handoff > $OUT/handoff.txt 2>&1; echo "handoff rc=$?"; cat $OUT/handoff.txt
+fi
+if has drift; then
+  timeout 400 python tools/wide_drift_probe.py $WN_DRIFT_ARGS > $OUT/wide_drift.txt 2>&1; echo "drift rc=$?"; tail -8 $OUT/wide_drift.txt
+fi
+if has gap; then
+  timeout 300 python tools/grad_gap_probe.py 2 6656 3 256 6 > $OUT/grad_gap_config4_b2.txt 2>&1; echo "gap rc=$?"; cat $OUT/grad_gap_config4_b2.txt
+fi
+if has pmc3; then
+  WN_PMC_NAME=config4 WN_PMC_STEPS=4 WN_PMC_CMD="python tools/recipe_bench.py --resch 64 --kernel-size 3 --upsampling 256 --T 26112 --batch 8 --steps 1" \
+    bash tools/pmc_traffic.sh > $OUT/pmc_config4.txt 2>&1; tail -25 $OUT/pmc_config4.txt
+fi
+if has seltests; then
+  timeout 1200 python -m pytest tests -q -m gpu -s -k "$WN_TEST_K" > $OUT/pytest_gpu_sel.txt 2>&1; echo "pytest(selected) rc=$?"; tail -5 $OUT/pytest_gpu_sel.txt
+  grep -h "vs oracle\|vs own\|err \|STATED\|TIMED\|FULL SIZE" $OUT/pytest_gpu_sel.txt | head -20
 fi
 if has recipe; then
   timeout 300 bash tools/recipe_stage45.sh run > $OUT/recipe_stage45.txt 2>&1; echo "recipe rc=$?"; tail -3 $OUT/recipe_stage45.txt
