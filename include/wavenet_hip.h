@@ -296,6 +296,14 @@ int wn_decode_steps(const WnConfig* cfg, int B, const float* params, const float
  * same state with params == NULL keeps the packed weights and only projects the given window of h (a decode
  * without an upsampling layer projects one window of aux columns per chunk of steps). */
 int64_t wn_decode_layered_state_floats(const WnConfig* cfg, int B);
+/* Since ABI v7: for models the plan of csrc/wn_dlp.h covers (n_resch % 32 == 0, kernel_size 2 or 3, B <= 64, softmax head)
+ * wn_decode_layered_steps runs the whole range of steps as ONE launch of n_resch / 16 workgroups that hand their vectors to
+ * each other as 8-byte {value, tag} granules (the recipes' n_resch = 512 model: 66 dependent launches per step before).
+ * `mode | WN_DECODE_BY_LAUNCHES` keeps the layer-wise launches (independent check, A/B).  The persistent launch bounds every
+ * wait; wn_decode_layered_error_offset() is the float offset in `state` of an int that is non-zero afterwards if a wait
+ * timed out (-1: this model / B decodes by launches). */
+#define WN_DECODE_BY_LAUNCHES 256
+int64_t wn_decode_layered_error_offset(const WnConfig* cfg, int B);
 int wn_decode_layered_prepare(const WnConfig* cfg, int B, int F, const float* params, const float* h, float* G, float* state,
                               int64_t state_floats, void* stream);
 int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* params, const float* G, int F, int n_pad,

@@ -75,6 +75,7 @@ FLAG_AUX_FUSED = 32  # wn_backward: aux-gradient partial sums in the gate kernel
 FLAG_BWD_OVERLAP_HEAD = 16  # with FLAG_BWD_OVERLAP: only the post-net / skip weight gradients on the side stream
 FLAG_FWD_OVERLAP = 8  # wn_forward: chunked skip-sum on the side stream beside the residual stack (opt-in)
 FLAG_WS_FINITE = 1 << 16  # wn_forward_loss: the workspace holds only finite values (the engine allocates it zero-filled)
+DECODE_BY_LAUNCHES = 256  # wn_decode_layered_steps: mode bit that keeps the layer-wise launches (csrc/wn_dlp.hip otherwise)
 FLAG_REPACK = 1 << 17  # wn_backward: rebuild the packed / pre-split weight sets from the params given to that call
 
 
@@ -92,7 +93,7 @@ EXPORTS = [
     "wn_softmax_ce_loss", "wn_forward_loss_fused", "wn_forward_loss", "wn_backward", "wn_backward_window", "wn_adam_step", "wn_op_front", "wn_op_causal_conv", "wn_op_gemm", "wn_prof_enable", "wn_prof_report", "wn_prof_sequence",
     "wn_decode_supported", "wn_decode_pack_floats", "wn_decode_state_floats", "wn_decode_pack", "wn_decode_aux",
     "wn_decode_steps", "wn_decode_stream_bytes",
-    "wn_decode_layered_state_floats", "wn_decode_layered_prepare", "wn_decode_layered_steps", "wn_mol_loss",
+    "wn_decode_layered_state_floats", "wn_decode_layered_error_offset", "wn_decode_layered_prepare", "wn_decode_layered_steps", "wn_mol_loss",
     "wn_decode_ctx_aux", "wn_decode_prefill_workspace_bytes", "wn_decode_prefill",
 ]
 
@@ -153,6 +154,8 @@ class WnLibrary(object):
         L.wn_mol_loss.argtypes = [cfgp, i, i, vp, vp, i, f, f, i, f, vp, vp, vp, sz, vp]
         L.wn_decode_layered_state_floats.argtypes = [cfgp, i]
         L.wn_decode_layered_state_floats.restype = i64
+        L.wn_decode_layered_error_offset.argtypes = [cfgp, i]
+        L.wn_decode_layered_error_offset.restype = i64
         L.wn_decode_layered_prepare.argtypes = [cfgp, i, i, vp, vp, vp, vp, i64, vp]
         L.wn_decode_layered_steps.argtypes = [cfgp, i, vp, vp, i, i, vp, i64, vp, vp, i, i, vp, i64, vp, vp, i, vp, f, vp]
         L.wn_decode_ctx_aux.argtypes = [cfgp, i, i, i, i, i, vp, vp, vp, vp]

@@ -10,6 +10,7 @@
 
 #include "../../include/wavenet_hip.h"
 #include "wn_decode.h"
+#include "wn_dlp.h"
 #include "wn_elem.h"
 #include "wn_fused.h"
 #include "wn_gemm.h"
@@ -622,7 +623,10 @@ struct CeEpi {   // softmax cross-entropy as the epilogue of the contraction tha
     float gs;
     float* partial;
 };
-static int fw_gemm(const Ctx& c, const WnGemmArgs& g, const GateEpi* ge = nullptr, const CeEpi* ce = nullptr) {
+// n_origin: index of column 0 of this launch in the caller's full (B, C, T) tensor (a loss-window launch starts at t0): the
+// alternating tile signs of k_gemm6 follow the ABSOLUTE column, so a windowed launch produces bit for bit what the full one
+// produces on those columns (same ReLU masks in the training step's and the module's forward).
+static int fw_gemm(const Ctx& c, const WnGemmArgs& g, const GateEpi* ge = nullptr, const CeEpi* ce = nullptr, int n_origin = 0) {
     const bool ok = c.split_bf16 && g.M >= 128 && !g.a_kmajor && !g.b_kmajor &&
                     (g.b_seg_len >= g.K || g.b_seg_len % 16 == 0) && g.ksplit == 1 && g.nlayer == 1 && !g.b_relu &&
                     !g.b_index && g.a_zstride == 0 && !g.a_rowsum &&
@@ -649,6 +653,7 @@ static int fw_gemm(const Ctx& c, const WnGemmArgs& g, const GateEpi* ge = nullpt
     a.C = g.C; a.ldc = g.ldc; a.c_zstride = g.c_zstride;
     a.bias = g.bias; a.E = g.E; a.lde = g.lde; a.e_zstride = g.e_zstride; a.relu = g.relu;
     a.nbatch = g.nbatch; a.tag = g.tag;
+    a.n_phase = (n_origin / WN_G6_BN) & 1;
     if (ce) {
         a.ce_target = reinterpret_cast<const long long*>(ce->target); a.ce_tstride = g.ldc; a.ce_t_start = ce->t_start;
         a.ce_gs = ce->gs; a.ce_partial = ce->partial;
@@ -764,7 +769,7 @@ static int skip_sum(const Ctx& c, int lo, int hi, bool last, int t0 = 0) {   // 
     if (lo == 0) g.bias = ws + w.bskip;
     else { g.D = ws + w.O1 + t0; g.ldd = c.T; g.d_zstride = (long)d.S * c.T; }  // in place: an element is read by the lane that writes it
     g.relu = last ? 1 : 0; g.nbatch = c.B; g.tag = "fwd_skip_sum";
-    return fw_gemm(c, g);
+    return fw_gemm(c, g, nullptr, nullptr, t0);
 }
 
 // `side` != nullptr (fused path only): the skip-sum of every `chunk` finished layers is issued on cs->st
@@ -899,7 +904,7 @@ static int forward_impl(const WnConfig* cfg, int B, int T, const float* params, 
         g.B = ws + w.O1 + t0; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = Tw;
         g.C = ws + w.O2 + t0; g.ldc = T; g.c_zstride = (long)d.S * T;
         g.bias = params + y.post1_b; g.relu = 1; g.nbatch = B; g.tag = "fwd_post1";
-        WN_TRY(fw_gemm(c, g));
+        WN_TRY(fw_gemm(c, g, nullptr, nullptr, t0));
     }
     {   // conv_post_2  (wavenet.py:522)
         WnGemmArgs g = wn_gemm_default();
@@ -914,10 +919,10 @@ static int forward_impl(const WnConfig* cfg, int B, int T, const float* params, 
             ce.t_start = ce_in->t_start - t0;
             ce.partial = ws + w.loss_partial;
             g.tag = "fwd_post2_ce";
-            WN_TRY(fw_gemm(c, g, nullptr, &ce));   // g.C = the caller's dlogits (or NULL)
+            WN_TRY(fw_gemm(c, g, nullptr, &ce, t0));   // g.C = the caller's dlogits (or NULL)
             if (logits && t0 > 0) WN_TRY(wn_fill_cols(logits, (long)B * d.Qo, T, t0, c.st));
         } else {
-            WN_TRY(fw_gemm(c, g));
+            WN_TRY(fw_gemm(c, g, nullptr, nullptr, t0));
         }
     }
     return rt_check(who);
@@ -1116,7 +1121,7 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
         g.C = ws + w.dO2 + t0; g.ldc = T; g.c_zstride = (long)d.S * T;
         g.E = ws + w.O2 + t0; g.lde = T; g.e_zstride = (long)d.S * T;
         g.nbatch = B; g.tag = "bwd_post2_dx";
-        WN_TRY(fw_gemm(c, g));
+        WN_TRY(fw_gemm(c, g, nullptr, nullptr, t0));
     }
     {   // dSkip = W1^T dO2, masked by relu'(skip-sum)
         WnGemmArgs g = wn_gemm_default();
@@ -1126,7 +1131,7 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
         g.C = ws + w.dSk + t0; g.ldc = T; g.c_zstride = (long)d.S * T;
         g.E = ws + w.O1 + t0; g.lde = T; g.e_zstride = (long)d.S * T;
         g.nbatch = B; g.tag = "bwd_post1_dx";
-        WN_TRY(fw_gemm(c, g));
+        WN_TRY(fw_gemm(c, g, nullptr, nullptr, t0));
         if (t0 > 0) WN_TRY(wn_fill_cols(ws + w.dSk, (long)B * d.S, T, t0, c.st));
     }
     WN_TRY(side_link(side.rt, c.st, cs.st));  // fork: dO2, dSkip (and everything before this call) are ready
@@ -1188,7 +1193,7 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
         g.B = ws + w.dSk + t0; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = Tw;
         g.C = ws + w.dZs + t0; g.ldc = T; g.c_zstride = zs_bstride;
         g.nbatch = B; g.tag = "bwd_dz_skip_all";
-        WN_TRY(fw_gemm(c, g));
+        WN_TRY(fw_gemm(c, g, nullptr, nullptr, t0));
         // dZs[.., t < t0] stays unwritten: the chain kernel takes it as zero without reading it (ChainArgs.zs_t0)
     }
     // WN_FLAG_BWD_OVERLAP_HEAD: only the post-net / skip weight gradients (matrix-bound) go to the side stream, the
@@ -1616,6 +1621,9 @@ struct DlLay {
     Ws w;  // packed-weight region of a (B=1, T=Ue) training workspace
     long queues, xin, P, Sg, Gt, Zcat, gstep, skpart, O1, O2, logits, total;
     long qfloats_per_utt;
+    // persistent path (wn_dlp.hip), when the plan covers the model and nb <= WN_DLP_BMAX
+    WnDlpPlan dlp;
+    long dlp_w, dlp_post, dlp_cfold, dlp_fold, dlp_gz, dlp_gx, dlp_gs, dlp_go, dlp_gl, dlp_pq, dlp_err;
 };
 
 static int dl_layout(const WnConfig* cfg, const Dims& d, int nb, DlLay* y) {
@@ -1639,6 +1647,22 @@ static int dl_layout(const WnConfig* cfg, const Dims& d, int nb, DlLay* y) {
     DCARVE(O1, (long)d.S * nb);
     DCARVE(O2, (long)d.S * nb);
     DCARVE(logits, (long)d.Qo * nb);
+    wn_dlp_make_plan(d.Q, d.Qo, d.R, d.S, d.L, d.K, &y->dlp);
+    if (nb > WN_DLP_BMAX) y->dlp.ok = 0;
+    if (y->dlp.ok) {
+        const WnDlpPlan& pl = y->dlp;
+        DCARVE(dlp_w, (long)(d.L + 1) * pl.NU * pl.stage_floats);
+        DCARVE(dlp_post, (long)pl.NU * pl.post_floats);
+        DCARVE(dlp_cfold, (long)d.L * 2 * d.R);
+        DCARVE(dlp_fold, (long)2 * d.R * d.R);
+        DCARVE(dlp_gz, 2L * 2 * d.R * nb);   // 8-byte granules: two floats each
+        DCARVE(dlp_gx, 2L * 2 * d.R * nb);
+        DCARVE(dlp_gs, 2L * d.S * nb);
+        DCARVE(dlp_go, 2L * d.S * nb);
+        DCARVE(dlp_gl, 2L * d.Qo * nb);
+        DCARVE(dlp_pq, (long)pl.NU * y->qfloats_per_utt * nb);
+        DCARVE(dlp_err, 64);
+    }
 #undef DCARVE
     y->total = o;
     return 0;
@@ -1669,6 +1693,16 @@ extern "C" int64_t wn_decode_layered_state_floats(const WnConfig* cfg, int B) {
     return y.total;
 }
 
+// Float offset inside `state` of the error word of the persistent path (an int: non-zero after a launch whose workgroups
+// timed out waiting for each other), or -1 when wn_decode_layered_steps runs as layer-wise launches for this model / B.
+extern "C" int64_t wn_decode_layered_error_offset(const WnConfig* cfg, int B) {
+    Dims d;
+    if (check_cfg(cfg, &d) || B < 1) return -1;
+    DlLay y;
+    if (dl_layout(cfg, d, B, &y) || !y.dlp.ok) return -1;
+    return y.dlp_err;
+}
+
 // Packs the weights into `state` (which must be zero-filled first: the queues start from zero history) and
 // computes the aux projections G (B, F, L*2R) of all layers at the aux rate.  params == NULL: `state` already holds the
 // weights packed by an earlier call (same cfg, B and parameters) -- only the projection of this window of h is computed
@@ -1685,6 +1719,34 @@ extern "C" int wn_decode_layered_prepare(const WnConfig* cfg, int B, int F, cons
     Ctx c;
     dl_ctx(&c, cfg, d, y, B, state, stream);
     if (params) WN_TRY(pack_weights(c, params));
+    if (params && y.dlp.ok) {   // persistent path: per-stage weight images with the res 1x1 folded into the next layer's newest tap
+        const Lay& lay = c.y;
+        const long lb0 = layer_base(lay, d, 0), lstep = -lay.LB;
+        for (int s = 0; s <= d.L; ++s) {
+            if (s >= 1 && s < d.L) {   // fold[o'][i] = sum_j Wd_new(s)[o'][j] Wres(s-1)[j][i]
+                WnGemmArgs f = wn_gemm_default();
+                f.M = 2 * d.R; f.N = d.R; f.K = d.R;
+                f.A = state + y.w.wd_f + (long)s * d.K * d.R * 2 * d.R + (long)(d.K - 1) * d.R * 2 * d.R; f.lda = 2 * d.R;
+                f.B = params + layer_base(lay, d, s - 1) + lay.o_res_w; f.ldb = d.R; f.b_clen = d.R;
+                f.C = state + y.dlp_fold; f.ldc = d.R;
+                f.nbatch = 1; f.tag = "dlp_fold";
+                WN_TRY(wn_gemm_launch(&f, c.st));
+            }
+            WnDlpPackArgs pa;
+            pa.R = d.R; pa.S = d.S; pa.Qo = d.Qo; pa.L = d.L; pa.K = d.K; pa.plan = y.dlp; pa.stage = s;
+            pa.params = params;
+            pa.lb_s = s < d.L ? layer_base(lay, d, s) : 0;
+            pa.lb_prev = s >= 1 ? layer_base(lay, d, s - 1) : 0;
+            pa.o_dsig_w = lay.o_dsig_w; pa.o_dtanh_w = lay.o_dtanh_w; pa.o_res_w = lay.o_res_w;
+            pa.skip_prev = s >= 1 ? lay.skip0 + (long)(s - 1) * lay.ls_skip : 0;
+            pa.fold = state + y.dlp_fold;
+            pa.dst = state + y.dlp_w + (long)s * y.dlp.NU * y.dlp.stage_floats;
+            WN_TRY(wn_dlp_pack_stage(&pa, c.st));
+        }
+        WN_TRY(wn_dlp_pack_post(params, lay.post1_w, lay.post2_w, d.S, d.Qo, &y.dlp, state + y.dlp_post, c.st));
+        WN_TRY(wn_dlp_cfold(params, state + y.w.cvec, state + y.w.wd_f, lb0, lstep, lay.o_res_b, d.L, d.R, d.K, state + y.dlp_cfold,
+                            c.st));
+    }
     const int nG = d.L * 2 * d.R;
     WnGemmArgs g = wn_gemm_default();  // G[b] (F x nG) = h[b]^T (F x A) . waux_f (A x nG)
     g.M = F; g.N = nG; g.K = d.A;
@@ -1706,6 +1768,8 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
     if (!params || !G || !samples || !t_forced || !t_end || !state) return fail(1, "NULL argument");
     if (B <= 0 || F <= 0 || n_pad < 0 || p0 < 0 || p1 < p0 || Ttot <= 0 || p1 > Ttot - 1)
         return fail(1, "bad decode range: B=%d F=%d n_pad=%d steps [%d,%d) Ttot=%ld", B, F, n_pad, p0, p1, (long)Ttot);
+    const bool by_launches = (mode & WN_DECODE_BY_LAUNCHES) != 0;
+    mode &= ~WN_DECODE_BY_LAUNCHES;
     if (mode != 0 && mode != 1 && mode != 2) return fail(1, "mode should be 0 (argmax), 1 (sampling) or 2 (mixture of logistics)");
     if (mode != 0 && !uniforms) return fail(1, "sampling modes need the uniform draws");
     if (mode == 2 && (d.Qo % 3 != 0 || d.Qo == d.Q)) return fail(1, "mode 2 needs out_channels = 3 * n_mixture");
@@ -1718,6 +1782,29 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
     const Ws& w = y.w;
     float* ws = state;
     const int nb = B;
+    if (y.dlp.ok && mode != 2 && !by_launches) {
+        // persistent path: ONE launch for the whole range of steps (wn_dlp.hip); the softmax head's two modes
+        if (p1 == p0) return 0;
+        WnDlpArgs a;
+        a.Q = d.Q; a.Qo = d.Qo; a.R = d.R; a.S = d.S; a.L = d.L; a.K = d.K; a.depth = cfg->dilation_depth; a.nG = d.L * 2 * d.R;
+        a.plan = y.dlp; a.B = nb;
+        a.wpk = ws + y.dlp_w; a.wpost = ws + y.dlp_post; a.cfold = ws + y.dlp_cfold; a.bskip = ws + w.bskip;
+        a.params = params; a.off_causal_w = lay.causal_w; a.off_causal_b = lay.causal_b;
+        a.off_res_b0 = layer_base(lay, d, 0) + lay.o_res_b; a.res_b_lstride = -lay.LB;
+        a.off_post1_b = lay.post1_b; a.off_post2_b = lay.post2_b;
+        a.upw = d.U > 0 ? params + lay.up_w : ws + w.one; a.Ue = d.U > 0 ? d.U : 1; a.F = F; a.n_pad = n_pad;
+        a.G = G; a.samples = samples; a.Ttot = Ttot; a.t_forced = t_forced; a.t_end = t_end; a.uniforms = uniforms;
+        a.logits_out = logits_out; a.mode = mode; a.p0 = p0; a.p1 = p1;
+        a.gz = reinterpret_cast<unsigned long long*>(ws + y.dlp_gz); a.gx = reinterpret_cast<unsigned long long*>(ws + y.dlp_gx);
+        a.gs = reinterpret_cast<unsigned long long*>(ws + y.dlp_gs); a.go = reinterpret_cast<unsigned long long*>(ws + y.dlp_go);
+        a.gl = reinterpret_cast<unsigned long long*>(ws + y.dlp_gl);
+        a.pq = ws + y.dlp_pq; a.pq_unit_stride = y.qfloats_per_utt * nb;
+        a.queues = ws + y.queues; a.qfloats = y.qfloats_per_utt;
+        a.err = reinterpret_cast<int*>(ws + y.dlp_err);
+        const int rc = wn_dlp_launch(&a, c.st);
+        if (rc != 0) return fail(3, "wn_dlp_launch failed (rc=%d)", rc);
+        return rt_check("wn_decode_layered_steps");
+    }
     WnDlArgs a;
     a.nb = nb; a.L = d.L; a.K = d.K; a.R = d.R; a.Q = d.Q; a.depth = cfg->dilation_depth; a.nG = d.L * 2 * d.R;
     a.n_pad = n_pad; a.Ue = d.U > 0 ? d.U : 1; a.F = F;

@@ -19,6 +19,9 @@ typedef emu::f32x16_t f32x16;
 typedef void* wn_stream_t;
 #define WN_LAUNCH(kernel, grid, block, smem, stream, ...) \
     emu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
+// launch whose workgroups wait for each other inside the kernel (all of them resident at once; wn_dlp.hip)
+#define WN_LAUNCH_COOP(kernel, grid, block, smem, stream, ...) \
+    emu::launch_coop((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
 #define WN_DYN_SMEM(name) char* name = emu::S().dyn_smem
 static inline f32x16 mfma32(float a, float b, f32x16 c) { return emu::mfma_f32_32x32x2f32(a, b, c); }
 #define WN_UNROLL
@@ -65,6 +68,13 @@ static inline void wn_buf_load_lds16(wn_rsrc_t r, char* lds_wave_base, int voff,
 #define WN_LDS_BARRIER() __syncthreads()
 // load that must observe earlier stores of other waves of the same workgroup (bypasses the L1)
 static inline float wn_ld_coherent(const float* p) { return *p; }
+// 8-byte granule {value, tag} handed from one workgroup to another: ONE agent-scope store, ONE agent-scope load
+static inline void wn_granule_store(unsigned long long* p, float v, unsigned tag) {
+    unsigned b;
+    memcpy(&b, &v, 4);
+    *p = ((unsigned long long)tag << 32) | b;
+}
+static inline unsigned long long wn_granule_load(const unsigned long long* p) { return *p; }
 // v + the value of lane (l ^ m); all lanes of an aligned group of 2m hold the same partial sums
 static inline float wn_xor_add(float v, int m) { return v + __shfl_xor(v, m, 64); }
 // bf16 matrix-core step (v_mfma_f32_32x32x16_bf16): a / b = 8 bf16 per lane packed in a float4
@@ -97,6 +107,10 @@ static inline f32x2 wn_pk_fma(f32x2 a, f32x2 b, f32x2 c) { return f32x2{fmaf(a.x
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef hipStream_t wn_stream_t;
 #define WN_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kernel, (grid), (block), (smem), (stream), __VA_ARGS__)
+// A launch whose workgroups wait for each other inside the kernel: a plain launch of a grid that is resident as a whole (at
+// most one workgroup per CU here; MI355X_MICROARCH.md: plain, cooperative and graph launches give the same residency)
+#define WN_LAUNCH_COOP(kernel, grid, block, smem, stream, ...) \
     hipLaunchKernelGGL(kernel, (grid), (block), (smem), (stream), __VA_ARGS__)
 #define WN_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 static __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -157,6 +171,15 @@ static __device__ __forceinline__ float4 wn_buf_load4(wn_rsrc_t r, int voff, uns
 // global loads stay outstanding (a __syncthreads() would also wait for vmcnt(0)).
 #define WN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 static __device__ __forceinline__ float wn_ld_coherent(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// 8-byte granule {value, tag} handed from one workgroup to another (MI355X_MICROARCH.md, hand-off price list): ONE relaxed
+// agent-scope store (global_store_dwordx2 sc1) per lane, the consumer polls the granule itself with relaxed agent-scope loads
+// -- valid across XCDs without fences (measured: 0 stale words, 0.7 - 0.8 us per hop, profiles/r04/handoff_microbench.txt)
+static __device__ __forceinline__ void wn_granule_store(unsigned long long* p, float v, unsigned tag) {
+    __hip_atomic_store(p, ((unsigned long long)tag << 32) | __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static __device__ __forceinline__ unsigned long long wn_granule_load(const unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // v + partner value, partner in the other half of the aligned 2m-lane group.  m = 1,2,4,8 are DPP

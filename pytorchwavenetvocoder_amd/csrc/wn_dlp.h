@@ -1,0 +1,78 @@
+// wn_dlp.h -- persistent any-size decode (wn_dlp.hip): the queue algorithm of the reference (wavenet.py:355-385, 538-549) for
+// models too large for the one-workgroup kernel of wn_decode.hip (the recipes' n_resch = 512), as ONE launch per chunk of
+// steps instead of ~66 dependent launches per step.
+//
+// R / 16 workgroups ("units") each own 16 residual channels.  A step is a chain of L + 3 dependent stages; a stage's output
+// vectors travel from workgroup to workgroup as 8-byte granules {value, tag} (one agent-scope store per lane, the consumer
+// polls the granules themselves: 0.7 - 0.8 us per hop, profiles/r04/handoff_microbench.txt) -- no grid barrier, no fences.
+#pragma once
+#include "wn_device.h"
+
+#define WN_DLP_T 512     // threads per workgroup (8 waves: 2 per SIMD, 256 VGPRs each for the stage's weights)
+#define WN_DLP_NW 8
+#define WN_DLP_CG 16     // channels per unit
+#define WN_DLP_CB 16     // utterance columns per block of the 32-column MFMA tile
+#define WN_DLP_BMAX 64   // utterances per launch
+
+typedef struct WnDlpPlan {
+    int ok;
+    int cls;                 // compiled class: NSP / NSX k-steps per wave of the two tiles
+    int NSP, NSX;
+    int NU, SU, QU, KP;      // units, skip rows per unit, output rows per unit, K of the gate tile = (K + 1) * R
+    long stage_floats;       // packed floats of one (stage, unit): 512 * (NSP + NSX)
+    long post_floats;        // packed floats of one unit's two post tiles: 2 * 512 * NSX
+    long lds_bytes;
+} WnDlpPlan;
+// ok = 0: the model is not covered (R % 32, S / Qo rows per unit, kernel_size, class sizes)
+void wn_dlp_make_plan(int Q, int Qo, int R, int S, int L, int K, WnDlpPlan* plan);
+
+typedef struct WnDlpArgs {
+    int Q, Qo, R, S, L, K, depth, nG;
+    WnDlpPlan plan;
+    int B;
+    const float* wpk;        // [stage 0..L][unit][tile P | tile X]
+    const float* wpost;      // [unit][post1 tile | post2 tile]
+    const float* cfold;      // [L][2R] constant part of the gate pre-activation (incl. the folded res bias)
+    const float* bskip;      // [S] sum of the skip biases
+    const float* params;
+    long off_causal_w, off_causal_b, off_res_b0, res_b_lstride, off_post1_b, off_post2_b;
+    const float* upw;
+    int Ue, F, n_pad;
+    const float* G;          // (B, F, nG)
+    int64_t* samples;        // (B, Ttot)
+    long Ttot;
+    const int* t_forced;
+    const int* t_end;
+    const float* uniforms;   // mode 1: (B, Ttot)
+    float* logits_out;       // nullable (B, Ttot, Qo)
+    int mode;                // 0 argmax, 1 sampling
+    int p0, p1;
+    unsigned long long* gz;  // granules [2][R][B]
+    unsigned long long* gx;  // [2][R][B]
+    unsigned long long* gs;  // [S][B]   relu(skip sum)
+    unsigned long long* go;  // [S][B]   relu(post1)
+    unsigned long long* gl;  // [Qo][B]  logits
+    float* pq;               // private queue copies [unit][qfloats][B]
+    long pq_unit_stride;
+    float* queues;           // shared rings [qfloats][B] (prefill / the launch path's layout)
+    long qfloats;
+    int* err;                // set to 1 when a poll timed out
+} WnDlpArgs;
+
+struct WnDlpPackArgs {
+    int R, S, Qo, L, K;
+    WnDlpPlan plan;
+    int stage;               // 0 .. L
+    const float* params;
+    long lb_s, lb_prev;      // layer blocks of layers `stage` and `stage - 1` in the flat parameter buffer
+    long o_dsig_w, o_dtanh_w, o_res_w;
+    long skip_prev;          // skip_1x1.(stage-1).weight
+    const float* fold;       // [2R][R] = Wd_new(stage) . Wres(stage-1), stage >= 1
+    float* dst;              // wpk + stage * NU * stage_floats
+};
+int wn_dlp_pack_stage(const WnDlpPackArgs* a, wn_stream_t st);
+int wn_dlp_pack_post(const float* params, long post1_w, long post2_w, int S, int Qo, const WnDlpPlan* plan, float* dst, wn_stream_t st);
+// cfold[s][o'] = cvec[s][o'] + sum_j Wd_new(s)[o'][j] * b_res(s-1)[j]   (second term for s >= 1)
+int wn_dlp_cfold(const float* params, const float* cvec, const float* wd_f, long lb0, long lstep, long o_res_b, int L, int R, int K,
+                 float* cfold, wn_stream_t st);
+int wn_dlp_launch(const WnDlpArgs* a, wn_stream_t st);

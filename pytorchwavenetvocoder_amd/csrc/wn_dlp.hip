@@ -1,0 +1,490 @@
+// wn_dlp.hip -- persistent any-size decode: the reference's queue algorithm (wavenet.py:355-385 fast_generate's step loop,
+// :538-549 _generate_residual_forward, :518-523 _postprocess) for models the one-workgroup kernel cannot hold, as ONE
+// launch per chunk of steps.  See wn_dlp.h.
+//
+// Decomposition.  Unit u (one workgroup, 512 threads) owns the residual channels [16u, 16u + 16).  Folding the res 1x1 of
+// layer s-1 into the newest tap of layer s,
+//      M_s = Wd_new(s) . Wres(s-1),      c_s = cvec_s + Wd_new(s) . b_res(s-1),
+// makes layer s ONE dependent stage: from (z_{s-1}, x_{s-1}) -- both complete vectors of the previous stage -- a unit computes
+//      gate rows:  P = M_s z_{s-1} + Wd_new(s) x_{s-1} + sum_older-taps Wd_tap(s) x_s[t - ..] + aux + c_s,   z_s = sigmoid(P_a) tanh(P_b)
+//      x rows:     x_s = Wres(s-1) z_{s-1} + b_res(s-1) + x_{s-1}
+//      skip rows:  skip += Wskip(s-1) z_{s-1}                      (its share of the n_skipch rows)
+// for its 16 channels as two 32-row f32-MFMA tiles (utterances = MFMA columns), the K range split over the 8 waves, partial
+// tiles summed through LDS in a fixed order.  The stage's weights (256 KB per unit at n_resch 512) are requested into
+// registers FIRST, then the inputs are gathered: the previous stage's vectors arrive as 8-byte granules {value, tag} that the
+// consumer polls (tag = step and stage, so a granule is its own ready flag), the older taps come from the unit's PRIVATE copy
+// of the dilation queues (every unit sees every x_s anyway and pushes it into its own rings: no cross-workgroup traffic on
+// plain memory at all).  The weight stream and the hand-off latency overlap; nothing but granules crosses workgroups.
+// After the last layer: skip sum -> conv_post_1 -> conv_post_2 as three more stages, then EVERY unit picks the token itself
+// from the gathered logits (argmax / inverse-CDF on the caller's uniforms: deterministic), so the next step starts without
+// another hop.  Every poll is bounded; a timeout sets `err` and drains the launch.
+#include "wn_dlp.h"
+
+#include "wn_prof.h"
+
+typedef unsigned long long u64;
+
+void wn_dlp_make_plan(int Q, int Qo, int R, int S, int L, int K, WnDlpPlan* p) {
+    p->ok = 0;
+    if (R < 32 || R % 32 != 0 || S % 16 != 0 || K < 2 || K > 3 || L < 1 || Q < 2) return;
+    p->NU = R / WN_DLP_CG;
+    if (p->NU > 240) return;                       // one workgroup per CU, all resident
+    p->SU = (S + p->NU - 1) / p->NU;
+    p->QU = (Qo + p->NU - 1) / p->NU;
+    if (p->SU > 16 || p->QU > 32) return;
+    p->KP = (K + 1) * R;
+    const int nsp = p->KP / 16, nsx = R / 16, nsq = S / 16;   // k-steps (of 2) per wave
+    static const int cls[][2] = {{24, 8}, {96, 32}, {128, 32}};
+    for (int c = 0; c < 3; ++c) {
+        if (nsp <= cls[c][0] && nsx <= cls[c][1] && nsq <= cls[c][1] && 16 * cls[c][0] >= S && 16 * cls[c][0] >= Qo) {
+            p->cls = c; p->NSP = cls[c][0]; p->NSX = cls[c][1];
+            p->stage_floats = 512L * (p->NSP + p->NSX);
+            p->post_floats = 2L * 512 * p->NSX;
+            long region0 = 16L * p->NSP * WN_DLP_CB;           // input staging [16 NSP][CB]
+            if (region0 < 2L * 8 * 32 * 16) region0 = 2L * 8 * 32 * 16;   // ... aliased by the two partial-tile buffers
+            p->lds_bytes = (region0 + 16 * WN_DLP_BMAX + 16 * WN_DLP_BMAX + 4 * WN_DLP_BMAX + 64) * 4;
+            p->ok = 1;
+            return;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// packing (once per decode call)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_dlp_pack_stage(WnDlpPackArgs a) {
+    const int NSP = a.plan.NSP, NSX = a.plan.NSX, R = a.R, K = a.K;
+    const long per_unit = a.plan.stage_floats;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= per_unit * a.plan.NU) return;
+    const int u = (int)(idx / per_unit);
+    long r = idx % per_unit;
+    const bool isP = r < 512L * NSP;
+    if (!isP) r -= 512L * NSP;
+    const int NS = isP ? NSP : NSX;
+    const int lane = (int)(r & 63);
+    const int t = (int)((r >> 6) % NS), w = (int)((r >> 6) / NS);
+    const int row = lane & 31, k = (w * NS + t) * 2 + (lane >> 5);
+    const int s = a.stage;
+    float v = 0.0f;
+    if (isP) {
+        if (s < a.L && k < a.plan.KP) {
+            const int c = u * WN_DLP_CG + (row & 15), half = row >> 4;
+            const long wbase = a.lb_s + (half ? a.o_dtanh_w : a.o_dsig_w);
+            if (k < R) v = (s >= 1) ? a.fold[((long)half * R + c) * R + k] : 0.0f;
+            else if (k < 2 * R) v = a.params[wbase + ((long)c * R + (k - R)) * K + (K - 1)];
+            else {
+                const int j = (k - 2 * R) / R, i = (k - 2 * R) % R;
+                v = a.params[wbase + ((long)c * R + i) * K + j];
+            }
+        }
+    } else if (s >= 1 && k < R) {
+        if (row < 16) {
+            if (s < a.L) v = a.params[a.lb_prev + a.o_res_w + (long)(u * WN_DLP_CG + row) * R + k];
+        } else if (row < 16 + a.plan.SU) {
+            const int srow = u * a.plan.SU + (row - 16);
+            if (srow < a.S) v = a.params[a.skip_prev + (long)srow * R + k];
+        }
+    }
+    a.dst[idx] = v;
+}
+
+int wn_dlp_pack_stage(const WnDlpPackArgs* a, wn_stream_t st) {
+    WN_PROF("dlp_pack", 0.0, 0.0, st);
+    const long n = a->plan.stage_floats * a->plan.NU;
+    WN_LAUNCH(k_dlp_pack_stage, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, *a);
+    return 0;
+}
+
+__global__ void k_dlp_pack_post(const float* params, long post1_w, long post2_w, int S, int Qo, WnDlpPlan plan, float* dst) {
+    const int NSX = plan.NSX;
+    const long per_unit = plan.post_floats;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= per_unit * plan.NU) return;
+    const int u = (int)(idx / per_unit);
+    long r = idx % per_unit;
+    const int tile = (int)(r / (512L * NSX));
+    r -= (long)tile * 512 * NSX;
+    const int lane = (int)(r & 63);
+    const int t = (int)((r >> 6) % NSX), w = (int)((r >> 6) / NSX);
+    const int row = lane & 31, k = (w * NSX + t) * 2 + (lane >> 5);
+    float v = 0.0f;
+    if (k < S) {
+        if (tile == 0) {
+            const int o = u * plan.SU + row;
+            if (row < plan.SU && o < S) v = params[post1_w + (long)o * S + k];
+        } else {
+            const int o = u * plan.QU + row;
+            if (row < plan.QU && o < Qo) v = params[post2_w + (long)o * S + k];
+        }
+    }
+    dst[idx] = v;
+}
+
+int wn_dlp_pack_post(const float* params, long post1_w, long post2_w, int S, int Qo, const WnDlpPlan* plan, float* dst, wn_stream_t st) {
+    WN_PROF("dlp_pack", 0.0, 0.0, st);
+    const long n = plan->post_floats * plan->NU;
+    WN_LAUNCH(k_dlp_pack_post, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, params, post1_w, post2_w, S, Qo, *plan, dst);
+    return 0;
+}
+
+// wd_f[l][(tap*R + i)*2R + o'] (wn_api.hip pack_weights): newest tap = K-1
+__global__ void k_dlp_cfold(const float* params, const float* cvec, const float* wd_f, long lb0, long lstep, long o_res_b, int L, int R,
+                            int K, float* cfold) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)L * 2 * R) return;
+    const int s = (int)(idx / (2 * R)), o = (int)(idx % (2 * R));
+    float v = cvec[idx];
+    if (s >= 1) {
+        const float* wn = wd_f + (long)s * K * R * 2 * R + (long)(K - 1) * R * 2 * R;
+        const float* b = params + lb0 + (long)(s - 1) * lstep + o_res_b;
+        float acc = 0.0f;
+        for (int j = 0; j < R; ++j) acc = fmaf(wn[(long)j * 2 * R + o], b[j], acc);
+        v += acc;
+    }
+    cfold[idx] = v;
+}
+
+int wn_dlp_cfold(const float* params, const float* cvec, const float* wd_f, long lb0, long lstep, long o_res_b, int L, int R, int K,
+                 float* cfold, wn_stream_t st) {
+    WN_PROF("dlp_pack", 0.0, 0.0, st);
+    const long n = (long)L * 2 * R;
+    WN_LAUNCH(k_dlp_cfold, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, params, cvec, wd_f, lb0, lstep, o_res_b, L, R, K, cfold);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the step kernel
+// ---------------------------------------------------------------------------------------------
+static __device__ __forceinline__ long dlp_queue_off(int l, int depth, int K, int R) {
+    const long cyc = l / depth, in = l % depth;
+    return (long)R * (K - 1) * (cyc * ((1L << depth) - 1) + ((1L << in) - 1));
+}
+#define DLP_SPIN_MAX (1 << 22)
+
+template <int NSP, int NSX>
+__global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
+    WN_DYN_SMEM(smem_raw);
+    constexpr int CB = WN_DLP_CB, BM = WN_DLP_BMAX;
+    constexpr int KPAD = 16 * NSP;                                    // padded K of the gate tile (rows of the staging buffer)
+    constexpr int REG0 = (KPAD * CB > 2 * 8 * 32 * 16) ? KPAD * CB : 2 * 8 * 32 * 16;
+    float* s_in = reinterpret_cast<float*>(smem_raw);                 // [KPAD][CB] inputs of the stage  | aliased after the MFMAs by
+    float* s_red = s_in;                                              // [2][8][32][16] partial tiles
+    float* s_xown = s_in + REG0;                                      // [16][BM] x of the unit's own channels (previous stage)
+    float* s_sk = s_xown + 16 * BM;                                   // [16][BM] skip accumulators of the unit's rows
+    int* s_tok = reinterpret_cast<int*>(s_sk + 16 * BM);              // [3][BM] the newest K tokens of every utterance
+    int* s_flag = s_tok + 4 * BM;                                     // [0] a poll timed out
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = WN_UNIFORM(tid >> 6);
+    const int li = lane & 31, hi = lane >> 5;
+    const int u = blockIdx.x;
+    const int R = a.R, S = a.S, L = a.L, K = a.K, B = a.B, Qo = a.Qo;
+    const int c0 = u * WN_DLP_CG;
+    const int SU = a.plan.SU, QU = a.plan.QU, KP = a.plan.KP;
+    const int ncb = (B + CB - 1) / CB;
+    float* pq = a.pq + (long)u * a.pq_unit_stride;
+
+    // ---- set-up: private copy of the dilation queues, zero the staging rows beyond K, tokens of the context ----
+    for (long i = tid; i < a.qfloats * B; i += WN_DLP_T) pq[i] = a.queues[i];
+    for (int i = tid; i < REG0; i += WN_DLP_T) s_in[i] = 0.0f;
+    for (int i = tid; i < 16 * BM; i += WN_DLP_T) { s_xown[i] = 0.0f; s_sk[i] = 0.0f; }
+    for (int i = tid; i < K * B; i += WN_DLP_T) {
+        const int j = i / B, b = i % B;
+        const long pos = (long)a.p0 - (K - 1 - j);
+        long long tok = pos >= 0 ? a.samples[(long)b * a.Ttot + pos] % a.Q : 0;
+        if (tok < 0) tok += a.Q;
+        s_tok[j * BM + b] = pos >= 0 ? (int)tok : -1;
+    }
+    if (tid == 0) s_flag[0] = 0;
+    __syncthreads();
+
+    // x_0[c][b] of the current step: front conv as a gather of K weight columns (wavenet.py:355-356, 513-516)
+    auto x0_of = [&](int c, int b) -> float {
+        float v = a.params[a.off_causal_b + c];
+        for (int k = 0; k < K; ++k) {
+            const int tok = s_tok[k * BM + b];
+            if (tok >= 0) v += a.params[a.off_causal_w + ((long)c * a.Q + tok) * K + k];
+        }
+        return v;
+    };
+    // bounded poll of one granule for `tag`
+    auto wait_granule = [&](const u64* p, unsigned tag) -> float {
+        u64 v = wn_granule_load(p);
+        int spin = 0;
+        while ((unsigned)(v >> 32) != tag) {
+            if (++spin > DLP_SPIN_MAX || s_flag[0]) { s_flag[0] = 1; break; }
+            WN_SLEEP(1);
+            v = wn_granule_load(p);
+        }
+        return wn_bits_f32((unsigned)v);
+    };
+
+    float wP[NSP], wX[NSX];
+    for (int p = a.p0; p < a.p1; ++p) {
+        const unsigned tag0 = (unsigned)(p + 1) * (unsigned)(L + 4) + 1u;    // tag of (step p, stage s) = tag0 + s
+        for (int s = 0; s <= L; ++s) {
+            const bool hasP = s < L, hasX = s >= 1;
+            {   // (1) the stage's weights: requested first, they stream while the inputs are gathered
+                const float* img = a.wpk + ((long)s * a.plan.NU + u) * a.plan.stage_floats;
+                if (hasP) {
+                    WN_UNROLL
+                    for (int t = 0; t < NSP; ++t) wP[t] = img[((long)wave * NSP + t) * 64 + lane];
+                }
+                if (hasX) {
+                    const float* imx = img + 512L * NSP;
+                    WN_UNROLL
+                    for (int t = 0; t < NSX; ++t) wX[t] = imx[((long)wave * NSX + t) * 64 + lane];
+                }
+            }
+            const int d = 1 << (s % a.depth), Dq = (K - 1) * d;
+            const long qoff_s = hasP ? dlp_queue_off(s, a.depth, K, R) : 0;
+            for (int cb = 0; cb < ncb; ++cb) {
+                // (2) gather [z_{s-1} | x_{s-1} | older taps of x_s] of the block's utterances into s_in[k][uc]: every thread
+                // requests up to four elements before it looks at the first tag (one round trip for the whole gather)
+                const int krows = hasP ? KP : 2 * R;       // stage L: z for the skip rows, x only for the queue push
+                const int nbc = (B - cb * CB) < CB ? (B - cb * CB) : CB;   // utterances of this block
+                for (int base = tid; base < krows * nbc; base += 4 * WN_DLP_T) {
+                    const u64* gp[4];
+                    u64 gv[4];
+                    float fv[4];
+                    WN_UNROLL
+                    for (int j = 0; j < 4; ++j) {
+                        const int idx = base + j * WN_DLP_T;
+                        gp[j] = nullptr;
+                        fv[j] = 0.0f;
+                        gv[j] = 0;
+                        if (idx < krows * nbc) {
+                            const int k = idx / nbc, b = cb * CB + idx % nbc;
+                            if (k < R) {
+                                if (s >= 1) gp[j] = a.gz + ((long)((s - 1) & 1) * R + k) * B + b;
+                            } else if (k < 2 * R) {
+                                if (s <= 1) fv[j] = x0_of(k - R, b);
+                                else gp[j] = a.gx + ((long)((s - 1) & 1) * R + (k - R)) * B + b;
+                            } else {
+                                const int jt = (k - 2 * R) / R, c = (k - 2 * R) % R;
+                                int slot = (p - (K - 1 - jt) * d) % Dq;
+                                if (slot < 0) slot += Dq;
+                                fv[j] = pq[(qoff_s + (long)slot * R + c) * B + b];
+                            }
+                            if (gp[j]) gv[j] = wn_granule_load(gp[j]);
+                        }
+                    }
+                    WN_UNROLL
+                    for (int j = 0; j < 4; ++j) {
+                        const int idx = base + j * WN_DLP_T;
+                        if (idx < krows * nbc) {
+                            const int k = idx / nbc, uc = idx % nbc, b = cb * CB + uc;
+                            float v = fv[j];
+                            if (gp[j]) {
+                                const unsigned tag = tag0 + (unsigned)(s - 1);
+                                int spin = 0;
+                                while ((unsigned)(gv[j] >> 32) != tag) {
+                                    if (++spin > DLP_SPIN_MAX || s_flag[0]) { s_flag[0] = 1; break; }
+                                    WN_SLEEP(1);
+                                    gv[j] = wn_granule_load(gp[j]);
+                                }
+                                v = wn_bits_f32((unsigned)gv[j]);
+                            }
+                            if (k >= R && k < 2 * R && s >= 1) {   // x_{s-1} of this step goes into the unit's own ring of layer s-1
+                                const int dp = 1 << ((s - 1) % a.depth), Dp = (K - 1) * dp;
+                                pq[(dlp_queue_off(s - 1, a.depth, K, R) + (long)(p % Dp) * R + (k - R)) * B + b] = v;
+                            }
+                            if (hasP || k < R) s_in[k * CB + uc] = v;
+                        }
+                    }
+                }
+                __syncthreads();
+                // (3) the two tiles: rows = [16 sigmoid | 16 tanh] and [16 x | skip rows], columns = utterances
+                f32x16 accP = f32x16_zero(), accX = f32x16_zero();
+                if (hasP) {
+                    WN_UNROLL
+                    for (int t = 0; t < NSP; ++t) {
+                        const int k = (wave * NSP + t) * 2 + hi;
+                        const float bv = li < CB ? s_in[k * CB + li] : 0.0f;
+                        accP = mfma32(wP[t], bv, accP);
+                    }
+                }
+                if (hasX) {
+                    WN_UNROLL
+                    for (int t = 0; t < NSX; ++t) {
+                        const int k = (wave * NSX + t) * 2 + hi;
+                        const float bv = li < CB ? s_in[k * CB + li] : 0.0f;
+                        accX = mfma32(wX[t], bv, accX);
+                    }
+                }
+                __syncthreads();   // every wave is done with the staged inputs: the partial tiles take their place
+                if (li < CB) {
+                    WN_UNROLL
+                    for (int r = 0; r < 16; ++r) {
+                        s_red[((0 * 8 + wave) * 32 + mfma32_row(r, hi)) * 16 + li] = accP[r];
+                        s_red[((1 * 8 + wave) * 32 + mfma32_row(r, hi)) * 16 + li] = accX[r];
+                    }
+                }
+                __syncthreads();
+                // (4) fixed-order sum of the 8 partial tiles + epilogues; one output element per thread and kind
+                auto tile_sum = [&](int tile, int row, int uc) -> float {
+                    const float* q = s_red + ((tile * 8) * 32 + row) * 16 + uc;
+                    return ((q[0] + q[1 * 512]) + (q[2 * 512] + q[3 * 512])) + ((q[4 * 512] + q[5 * 512]) + (q[6 * 512] + q[7 * 512]));
+                };
+                {
+                    const int e = tid & 255, c = e >> 4, uc = e & 15, b = cb * CB + uc;
+                    if (tid < 256) {
+                        if (hasP && b < B) {   // gate (wavenet.py:542-544)
+                            const int t = p > a.n_pad ? p - a.n_pad : 0;   // replicated first column inside the left padding
+                            int f = t / a.Ue;
+                            const float wj = a.upw[t - f * a.Ue];
+                            if (f > a.F - 1) f = a.F - 1;
+                            const float* Gs = a.G + ((long)b * a.F + f) * a.nG + (long)s * 2 * R;
+                            const float ps = tile_sum(0, c, uc) + (wj * Gs[c0 + c] + a.cfold[(long)s * 2 * R + c0 + c]);
+                            const float pt = tile_sum(0, 16 + c, uc) + (wj * Gs[R + c0 + c] + a.cfold[(long)s * 2 * R + R + c0 + c]);
+                            wn_granule_store(a.gz + ((long)(s & 1) * R + c0 + c) * B + b, wn_sigmoid(ps) * wn_tanh(pt), tag0 + (unsigned)s);
+                        }
+                    } else if (b < B) {
+                        float xs;
+                        bool have = false;
+                        if (s == 0) {   // x_0 of the unit's own channels
+                            xs = x0_of(c0 + c, b);
+                            have = true;
+                        } else if (s < L) {   // x_s = res_1x1(z_{s-1}) + x_{s-1}   (wavenet.py:546-548)
+                            xs = tile_sum(1, c, uc) + a.params[a.off_res_b0 + (long)(s - 1) * a.res_b_lstride + c0 + c] + s_xown[c * BM + b];
+                            wn_granule_store(a.gx + ((long)(s & 1) * R + c0 + c) * B + b, xs, tag0 + (unsigned)s);
+                            have = true;
+                        }
+                        if (have) {
+                            s_xown[c * BM + b] = xs;
+                            if (K >= 2)   // the shared rings stay current for the next launch (and the launch path)
+                                a.queues[(dlp_queue_off(s, a.depth, K, R) + (long)(p % Dq) * R + c0 + c) * B + b] = xs;
+                        }
+                    }
+                    if (hasX && tid < SU * 16) {   // the unit's rows of the skip sum (wavenet.py:545, 365)
+                        const int r = tid >> 4, ub = cb * CB + (tid & 15);
+                        if (ub < B) s_sk[r * BM + ub] += tile_sum(1, 16 + r, tid & 15);
+                    }
+                }
+                __syncthreads();   // the partial tiles are consumed: the next gather may overwrite them
+            }
+        }
+        // ---- post net (wavenet.py:518-523): relu(skip sum) -> conv_post_1 + relu -> conv_post_2, three more hops ----
+        for (int i = tid; i < SU * B; i += WN_DLP_T) {
+            const int r = i / B, b = i % B, row = u * SU + r;
+            if (row < S) wn_granule_store(a.gs + (long)row * B + b, fmaxf(s_sk[r * BM + b] + a.bskip[row], 0.0f), tag0 + (unsigned)(L + 1));
+            s_sk[r * BM + b] = 0.0f;
+        }
+        const float* pimg = a.wpost + (long)u * a.plan.post_floats;
+        for (int stage = 0; stage < 2; ++stage) {
+            WN_UNROLL
+            for (int t = 0; t < NSX; ++t) wX[t] = pimg[(long)stage * 512 * NSX + ((long)wave * NSX + t) * 64 + lane];
+            const u64* src = stage == 0 ? a.gs : a.go;
+            for (int cb = 0; cb < ncb; ++cb) {
+                const int nbc = (B - cb * CB) < CB ? (B - cb * CB) : CB;
+                for (int idx = tid; idx < S * nbc; idx += WN_DLP_T) {
+                    const int k = idx / nbc, uc = idx % nbc;
+                    s_in[k * CB + uc] = wait_granule(src + (long)k * B + cb * CB + uc, tag0 + (unsigned)(L + 1 + stage));
+                }
+                __syncthreads();
+                f32x16 acc = f32x16_zero();
+                WN_UNROLL
+                for (int t = 0; t < NSX; ++t) {
+                    const int k = (wave * NSX + t) * 2 + hi;
+                    const float bv = li < CB ? s_in[k * CB + li] : 0.0f;
+                    acc = mfma32(wX[t], bv, acc);
+                }
+                __syncthreads();
+                if (li < CB) {
+                    WN_UNROLL
+                    for (int r = 0; r < 16; ++r) s_red[(wave * 32 + mfma32_row(r, hi)) * 16 + li] = acc[r];
+                }
+                __syncthreads();
+                {
+                    const int r = tid >> 4, uc = tid & 15, b = cb * CB + uc;   // 32 rows x 16 columns = 512 threads
+                    const float* q = s_red + r * 16 + uc;
+                    const float v = ((q[0] + q[1 * 512]) + (q[2 * 512] + q[3 * 512])) + ((q[4 * 512] + q[5 * 512]) + (q[6 * 512] + q[7 * 512]));
+                    if (b < B) {
+                        if (stage == 0) {
+                            const int row = u * SU + r;
+                            if (r < SU && row < S)
+                                wn_granule_store(a.go + (long)row * B + b, fmaxf(v + a.params[a.off_post1_b + row], 0.0f), tag0 + (unsigned)(L + 2));
+                        } else {
+                            const int row = u * QU + r;
+                            if (r < QU && row < Qo)
+                                wn_granule_store(a.gl + (long)row * B + b, v + a.params[a.off_post2_b + row], tag0 + (unsigned)(L + 3));
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // ---- token choice, by every unit for itself (wavenet.py:371-381): first-max argmax or inverse CDF on the caller's draw ----
+        for (int cb = 0; cb < ncb; ++cb) {
+            const int nbc = (B - cb * CB) < CB ? (B - cb * CB) : CB;
+            for (int idx = tid; idx < Qo * nbc; idx += WN_DLP_T) {
+                const int q = idx / nbc, uc = idx % nbc;
+                s_in[q * CB + uc] = wait_granule(a.gl + (long)q * B + cb * CB + uc, tag0 + (unsigned)(L + 3));
+            }
+            __syncthreads();
+            if (tid < CB && cb * CB + tid < B) {
+                const int b = cb * CB + tid;
+                float best = -3.0e38f;
+                int bi = 0;
+                for (int q = 0; q < Qo; ++q) {
+                    const float v = s_in[q * CB + tid];
+                    if (u == 0 && a.logits_out) a.logits_out[((long)b * a.Ttot + p) * Qo + q] = v;
+                    if (v > best) { best = v; bi = q; }
+                }
+                int chosen = bi;
+                if (a.mode == 1 && a.uniforms != nullptr) {
+                    float total = 0.0f;
+                    for (int q = 0; q < Qo; ++q) total += expf(s_in[q * CB + tid] - best);
+                    const float target = a.uniforms[(long)b * a.Ttot + p + 1] * total;
+                    float run = 0.0f;
+                    int cand = -1;
+                    for (int q = 0; q < Qo; ++q) {
+                        run += expf(s_in[q * CB + tid] - best);
+                        if (cand < 0 && run >= target) cand = q;
+                    }
+                    if (cand >= 0) chosen = cand;
+                }
+                const bool gen = p + 1 >= a.t_forced[b] && p + 1 < a.t_end[b];
+                long long nxt = chosen;
+                if (!gen && p + 1 < a.Ttot) {   // teacher forced / finished utterance: the token that is in the buffer
+                    nxt = a.samples[(long)b * a.Ttot + p + 1] % a.Q;
+                    if (nxt < 0) nxt += a.Q;
+                }
+                if (gen && u == 0) a.samples[(long)b * a.Ttot + p + 1] = chosen;
+                for (int j = 0; j + 1 < K; ++j) s_tok[j * BM + b] = s_tok[(j + 1) * BM + b];
+                s_tok[(K - 1) * BM + b] = (int)nxt;
+            }
+            __syncthreads();
+        }
+        if (s_flag[0]) break;
+    }
+    if (tid == 0 && s_flag[0]) a.err[0] = 1;
+}
+
+template <int NSP, int NSX>
+static int launch_cls(const WnDlpArgs& a, wn_stream_t st) {
+#ifndef WN_EMU
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_dlp<NSP, NSX>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)a.plan.lds_bytes) != hipSuccess)
+            return 3;
+        attr_set = true;
+    }
+#endif
+    WN_LAUNCH_COOP((k_dlp<NSP, NSX>), dim3((unsigned)a.plan.NU), dim3(WN_DLP_T), (size_t)a.plan.lds_bytes, st, a);
+    return 0;
+}
+
+int wn_dlp_launch(const WnDlpArgs* ap, wn_stream_t st) {
+    const WnDlpArgs& a = *ap;
+    if (!a.plan.ok || a.B < 1 || a.B > WN_DLP_BMAX || a.p1 < a.p0) return 1;
+    if (a.mode != 0 && a.mode != 1) return 2;
+    WN_PROF("dlp_steps", 0.0, 0.0, st);
+    switch (a.plan.cls) {
+        case 0: return launch_cls<24, 8>(a, st);
+        case 1: return launch_cls<96, 32>(a, st);
+        case 2: return launch_cls<128, 32>(a, st);
+    }
+    return 1;
+}

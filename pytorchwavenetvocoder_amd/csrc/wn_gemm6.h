@@ -33,6 +33,8 @@ typedef struct WnGemm6Args {
     int nbatch;
     const char* tag;
     int no_interior;            // set by wn_gemm6_launch (tuning knob WN_G6_INTERIOR=0)
+    int n_phase;                // parity of the 128-column tile that column 0 of this launch is in the caller's full tensor: the sign
+                                // of a column tile's arithmetic (k_gemm6) then does not depend on where a column WINDOW starts
     int stagger;                // set by wn_gemm6_launch (WN_G6_STAGGER): head start, in s_sleep(127) units, of the first block of a CU over its co-resident
     // Gate epilogues of the any-size residual block (R % 128 == 0): the contraction's result never goes to memory.
     // gate_S != NULL (forward, reference wavenet.py:529-532): M = 2R rows packed with wn_gemm6_pack(..., gate_R = R), so that
@@ -66,7 +68,7 @@ typedef struct WnGemm6Args {
 
 static inline void wn_gemm6_no_gate(WnGemm6Args* a) {
     a->gate_R = 0; a->gate_S = 0; a->gate_Gt = 0; a->gate_Z = 0; a->gate_G = 0; a->gate_gb = 0; a->gate_F = 0; a->gate_U = 1;
-    a->gate_upw = 0; a->gate_cvec = 0; a->gbw_S = 0; a->gbw_Gt = 0; a->gbw_dP = 0; a->no_interior = 0; a->stagger = 0;
+    a->gate_upw = 0; a->gate_cvec = 0; a->gbw_S = 0; a->gbw_Gt = 0; a->gbw_dP = 0; a->no_interior = 0; a->stagger = 0; a->n_phase = 0;
     a->ce_target = 0; a->ce_tstride = 0; a->ce_t_start = 0; a->ce_gs = 0.f; a->ce_partial = 0;
 }
 

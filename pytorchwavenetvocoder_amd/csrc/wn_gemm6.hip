@@ -167,7 +167,7 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
     // (profiles/r04/wide_drift_*.txt).  With the operand negated the bias changes sign with it, so over the positions of a
     // sequence it cancels instead of adding up (same probe: 9.0e-6).  Exact in every other respect: -x splits into the
     // negated pieces of x.
-    const float fs = (blk.x & 1) ? -1.0f : 1.0f;
+    const float fs = ((blk.x + g.n_phase) & 1) ? -1.0f : 1.0f;
     // De-phase the two blocks that share a CU (WN_G6_STAGGER, A/B knob).  They start together, do the same work and so
     // stay in lock step: both in their prologue (HBM latency) and both in their epilogue (stores) at the same time, with the
     // matrix pipe idle.  The second resident of the first round -- its waves sit in wave slot 1 of their SIMDs -- starts

@@ -316,8 +316,10 @@ class WaveNetEngine(object):
         generated tokens as a list of LongTensors (utterance order) [and the per-step logits].
 
         Two kernels implement it: the persistent one-workgroup-per-utterance kernel (model sizes covered by
-        ``decode_supported()``) and the any-size layer-wise path (``layered=True``; chosen automatically
-        when the first does not apply, e.g. the n_resch = 512 recipe default).
+        ``decode_supported()``) and the any-size path (``layered=True``; chosen automatically when the first does not
+        apply, e.g. the n_resch = 512 recipe default).  The any-size path is itself ONE persistent launch per chunk of
+        steps where csrc/wn_dlp.hip covers the model (n_resch / 16 workgroups handing their vectors to each other) and
+        layer-wise launches otherwise; ``layered="launches"`` forces the launches (independent check, A/B).
 
         ``prefill``: how the dilation queues of the context are built.  "parallel" (default) does what the
         reference does (wavenet.py:338-349): one forward of the residual stack over the whole padded context
@@ -349,6 +351,8 @@ class WaveNetEngine(object):
         Ttot = Tctx + n_max
         if layered is None:
             layered = not self.decode_supported()
+        by_launches = _lib.DECODE_BY_LAUNCHES if layered == "launches" else 0
+        layered = bool(layered)
         if prefill not in ("parallel", "walk"):
             raise ValueError("prefill should be parallel or walk")
         st = _stream_handle(self.device)
@@ -424,7 +428,8 @@ class WaveNetEngine(object):
             if layered:
                 rc = self.lib.wn_decode_layered_steps(cfg, B, _ptr(self.flat_params), _ptr(G), Fw, pad_w, _ptr(samples), Ttot,
                                                       _ptr(t_forced), _ptr(t_end), p, p1, _ptr(state), state.numel(),
-                                                      _ptr(uniforms), _ptr(logits), {"argmax": 0, "sampling": 1, "mol": 2}[mode],
+                                                      _ptr(uniforms), _ptr(logits),
+                                                      {"argmax": 0, "sampling": 1, "mol": 2}[mode] | by_launches,
                                                       _ptr(wave), float(log_scale_min), st)
                 self.lib.check(rc, "wn_decode_layered_steps")
             else:
@@ -436,6 +441,11 @@ class WaveNetEngine(object):
             p = p1
             if progress is not None:
                 progress(max(p + 1 - Tctx, 0), n_max)
+        if layered:   # the persistent launch bounds every wait between its workgroups and reports a timeout here
+            eoff = self.lib.wn_decode_layered_error_offset(cfg, B)
+            if eoff >= 0 and int(state[eoff:eoff + 1].view(torch.int32).item()) != 0:
+                raise _lib.WnError("the persistent decode launch timed out waiting between its workgroups (not all of them "
+                                   "were resident?); layered=\"launches\" decodes with layer-wise launches")
         out = [samples[b, Tctx:Tctx + int(n)] for b, n in enumerate(n_samples_list)]
         self.last_wave = None if wave is None else [wave[b, Tctx:Tctx + int(n)] for b, n in enumerate(n_samples_list)]
         self.last_uniforms = uniforms

@@ -62,10 +62,14 @@ struct State {
     std::function<void()> body;
 };
 
-inline State& S() {
-    static State s;
-    return s;
+// The state of the block that is executing.  Ordinary launches run their blocks one after another on ONE State;
+// launch_coop() (below) keeps one State per block alive and points this at the block whose fibers are being scheduled.
+inline State*& cur_state_() {
+    static State base;
+    static State* p = &base;
+    return p;
 }
+inline State& S() { return *cur_state_(); }
 
 inline void yield_() {
     State& s = S();
@@ -124,14 +128,15 @@ inline void fiber_entry() {
 }
 
 static const size_t kStack = 256 * 1024;
+static const size_t kStackCoop = 64 * 1024;   // cooperative launches keep EVERY block's fibers alive: smaller stacks
 
-inline void run_block() {
+inline void init_block(size_t stack_bytes = kStack) {
     State& s = S();
     int n = s.nthreads;
     if ((int)s.fibers.size() < n) {
         size_t old = s.fibers.size();
         s.fibers.resize(n);
-        for (size_t i = old; i < (size_t)n; ++i) s.fibers[i].stack = (char*)malloc(kStack);
+        for (size_t i = old; i < (size_t)n; ++i) s.fibers[i].stack = (char*)malloc(stack_bytes);
     }
     int nw = (n + 63) / 64;
     s.wv_arrived.assign(nw, 0);
@@ -148,19 +153,31 @@ inline void run_block() {
         f.done = false;
         getcontext(&f.ctx);
         f.ctx.uc_stack.ss_sp = f.stack;
-        f.ctx.uc_stack.ss_size = kStack;
+        f.ctx.uc_stack.ss_size = stack_bytes;
         f.ctx.uc_link = &s.sched_ctx;
         makecontext(&f.ctx, (void (*)())fiber_entry, 0);
     }
+}
+
+// one round-robin pass over the live fibers of the current block
+inline void pass_block() {
+    State& s = S();
+    const int n = s.nthreads;
     unsigned bx = s.blockDim_.x, by = s.blockDim_.y;
+    for (int t = 0; t < n; ++t) {
+        if (s.fibers[t].done) continue;
+        s.cur = t;
+        s.threadIdx_ = dim3(t % bx, (t / bx) % by, t / (bx * by));
+        swapcontext(&s.sched_ctx, &s.fibers[t].ctx);
+    }
+}
+
+inline void run_block() {
+    State& s = S();
+    init_block();
     while (s.alive > 0) {
         long before = s.progress;
-        for (int t = 0; t < n; ++t) {
-            if (s.fibers[t].done) continue;
-            s.cur = t;
-            s.threadIdx_ = dim3(t % bx, (t / bx) % by, t / (bx * by));
-            swapcontext(&s.sched_ctx, &s.fibers[t].ctx);
-        }
+        pass_block();
         if (s.progress == before && s.alive > 0) {
             fprintf(stderr, "[hip_emu] DEADLOCK in block (%u,%u,%u): divergent barrier / wave op\n",
                     s.blockIdx_.x, s.blockIdx_.y, s.blockIdx_.z);
@@ -183,6 +200,57 @@ inline void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> bod
                 s.blockIdx_ = dim3(x, y, z);
                 run_block();
             }
+}
+
+// Cooperative launch: every block of the grid is alive at the same time, so blocks may wait for each other through global
+// memory (the persistent any-size decode kernel hands vectors from workgroup to workgroup inside one launch).  Each block has
+// its own State (fibers, barrier counters, dynamic LDS); the scheduler gives every block one pass over its fibers in turn.
+// A fiber that polls memory must yield (WN_SLEEP / emu::yield_()).  Static `__shared__` arrays are ONE object for all blocks
+// here: kernels launched this way use dynamic shared memory only.  A grid in which nothing progresses for a long time is
+// reported as a deadlock.
+inline void launch_coop(dim3 grid, dim3 block, size_t smem, std::function<void()> body) {
+    State*& cur = cur_state_();
+    State* const saved = cur;
+    const int nb = (int)(grid.x * grid.y * grid.z);
+    std::vector<State*> st(nb);
+    std::vector<std::vector<char>> dyn(nb);
+    for (int b = 0; b < nb; ++b) {
+        State* s = new State();
+        st[b] = s;
+        s->gridDim_ = grid;
+        s->blockDim_ = block;
+        s->nthreads = (int)(block.x * block.y * block.z);
+        s->body = body;
+        dyn[b].assign(smem + 64, 0);
+        s->dyn_smem = (char*)(((uintptr_t)dyn[b].data() + 15) & ~(uintptr_t)15);
+        s->blockIdx_ = dim3(b % grid.x, (b / grid.x) % grid.y, b / (grid.x * grid.y));
+        cur = s;
+        init_block(kStackCoop);
+    }
+    long idle_passes = 0;
+    for (;;) {
+        int alive = 0;
+        long progress = 0;
+        for (int b = 0; b < nb; ++b) {
+            if (st[b]->alive <= 0) continue;
+            cur = st[b];
+            const long before = st[b]->progress;
+            pass_block();
+            progress += st[b]->progress - before;
+            alive += st[b]->alive > 0;
+        }
+        if (alive == 0) break;
+        idle_passes = progress ? 0 : idle_passes + 1;
+        if (idle_passes > 200000) {
+            fprintf(stderr, "[hip_emu] DEADLOCK in a cooperative launch: no block made progress for %ld passes\n", idle_passes);
+            abort();
+        }
+    }
+    for (int b = 0; b < nb; ++b) {
+        for (auto& f : st[b]->fibers) free(f.stack);
+        delete st[b];
+    }
+    cur = saved;
 }
 
 // ---- cross-lane exchange ---------------------------------------------------------------

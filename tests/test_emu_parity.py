@@ -581,6 +581,45 @@ def test_windowed_forward_loss_workspace_and_the_parameter_guard():
         eng.backward(dl)
 
 
+def test_any_size_decode_as_one_persistent_launch():
+    """csrc/wn_dlp.hip on the emulator's cooperative launch (every workgroup alive at once; they hand their vectors to each
+    other as tagged granules): a 32-channel model = 2 workgroups, kernel_size 2 and 3, one utterance, three ragged ones and
+    18 (two column blocks) -- logits within 1e-4 of the queue algorithm (oracle; the res 1x1 is folded into the next layer's
+    newest tap, so the rounding differs from the layer-wise launches), tokens equal to the oracle's and to the launches', the
+    launch log shows ONE dlp_steps launch per chunk and no layer-wise launch, and inverse-CDF sampling on the same draws picks
+    the same tokens as the launches."""
+    import numpy as np
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd.nets import WaveNet
+    for K, B in ((2, 1), (3, 3), (2, 18)):
+        cfg_t = (32, 4, 32, 32, 3, 2, K, 4)
+        cfg = O.OracleConfig(*cfg_t)
+        params = O.random_params(cfg, 9 + K, scale=0.3)
+        model = WaveNet(*cfg_t, _library=emu_library())
+        model.load_state_dict(params)   # (a size the one-workgroup kernel covers as well: layered=True selects the any-size path)
+        rs = np.random.RandomState(12 + B)
+        xs = torch.from_numpy(rs.randint(0, 32, (B, 5))).long()
+        hs = torch.from_numpy(rs.standard_normal((B, 4, 8)).astype(np.float32))
+        ns = [9 - (b % 3) for b in range(B)]
+        out = {}
+        log = PC.launch_log(emu_library(), lambda: out.update(p=model.engine.decode(xs, hs, ns, chunk=4, return_logits=True, layered=True)))
+        assert log.get("dlp_steps", 0) >= 2 and "dl_dilated" not in log and "dl_res" not in log, log
+        tp, lp = out["p"]
+        tl, ll = model.engine.decode(xs, hs, ns, chunk=4, return_logits=True, layered="launches")
+        for b in range(B):
+            rt, rl = O.fast_generate(cfg, params, xs[b:b + 1], hs[b:b + 1], ns[b], return_logits=True)
+            assert float((lp[b] - rl).abs().max()) <= 1e-4, (K, B, b)
+            top2 = rl.topk(2, dim=1).values
+            safe = ((top2[:, 0] - top2[:, 1]) > 1e-3).numpy()
+            assert (tp[b].numpy()[safe] == np.asarray(rt)[safe]).all() and (tp[b].numpy()[safe] == tl[b].numpy()[safe]).all(), (K, B, b)
+        if B == 3:
+            torch.manual_seed(5)
+            sp = model.engine.decode(xs, hs, ns, mode="sampling", layered=True)
+            torch.manual_seed(5)
+            sl = model.engine.decode(xs, hs, ns, mode="sampling", layered="launches")
+            assert all(torch.equal(a, b) for a, b in zip(sp, sl))
+
+
 def test_front_conv_weight_gradient_on_the_matrix_cores():
     """k_front_dw_mfma (R in {32, 64}, K * Q <= 1024): the front conv's weight gradient as a contraction over time with a
     one-hot B operand built from the token indices, instead of LDS float atomics.  256 classes x 2 taps (all 16 column

@@ -300,6 +300,44 @@ def test_decode_wide_model_layered_path_long_k():
             assert (toks[b].cpu().numpy()[safe] == ref[b][safe]).all(), (prefill, b)
 
 
+def test_decode_any_size_persistent_launch_vs_oracle_and_launches():
+    """csrc/wn_dlp.hip: the any-size decode as ONE launch of n_resch / 16 workgroups that hand their vectors to each other as
+    tagged granules (wavenet.py:355-385, 538-549, 518-523 with the res 1x1 folded into the next layer's newest tap).  A
+    128-channel model (8 workgroups, the small class; kernel_size 3; 20 utterances = two column blocks of ragged lengths) and
+    the recipes' own size (n_resch 512 / n_skipch 256: 32 workgroups, 256 KB of weights per workgroup and stage): logits within
+    1e-4 of the queue algorithm (oracle), tokens equal wherever the oracle's argmax is not a near-tie, the same against the
+    layer-wise launches it replaces, both ways of building the context queues, and the sampling mode runs."""
+    from pytorchwavenetvocoder_amd.nets import WaveNet
+    for cfg_t, B, n, scale, seed in (((64, 4, 128, 128, 3, 2, 3, 4), 20, 26, 0.1, 21), ((256, 80, 512, 256, 10, 3, 2, 80), 2, 12, 0.02, 22)):
+        cfg = O.OracleConfig(*cfg_t)
+        params = O.random_params(cfg, seed, scale=scale)
+        model = WaveNet(*cfg_t)
+        model.load_state_dict(params)
+        model.to(DEV)
+        assert not model.engine.decode_supported()
+        import ctypes
+        assert model.engine.lib.wn_decode_layered_error_offset(ctypes.byref(model.engine.cfg), B) >= 0   # the persistent path applies
+        rs = np.random.RandomState(seed)
+        x = torch.from_numpy(rs.randint(0, cfg.n_quantize, (B, 4))).long()
+        U = max(cfg.upsampling_factor, 1)
+        h = torch.from_numpy(rs.standard_normal((B, cfg.n_aux, (4 + n) // U + 2)).astype(np.float32))
+        ns = [n - (b % 5) for b in range(B)]
+        ref, ref_lg = O.batch_fast_generate(cfg, params, x, h, ns, return_logits=True)
+        order = sorted(range(B), key=lambda i: (ns[i], i))   # oracle order: shortest first
+        tl, ll = model.engine.decode(x.to(DEV), h.to(DEV), ns, return_logits=True, layered="launches")
+        for prefill in ("parallel", "walk"):
+            tp, lp = model.engine.decode(x.to(DEV), h.to(DEV), ns, return_logits=True, prefill=prefill, chunk=7)
+            for k, i in enumerate(order):
+                assert float((lp[i].cpu() - ref_lg[k]).abs().max()) <= 1e-4, (cfg_t, prefill, i)
+                assert float((lp[i] - ll[i]).abs().max()) <= 1e-4, (cfg_t, prefill, i)
+                top2 = ref_lg[k].topk(2, dim=1).values
+                safe = ((top2[:, 0] - top2[:, 1]) > 1e-3).numpy()
+                assert (tp[i].cpu().numpy()[safe] == ref[k][safe]).all(), (cfg_t, prefill, i)
+                assert (tp[i].cpu().numpy()[safe] == tl[i].cpu().numpy()[safe]).all(), (cfg_t, prefill, i)
+        ts = model.engine.decode(x.to(DEV), h.to(DEV), ns, mode="sampling")
+        assert all(int(t.min()) >= 0 and int(t.max()) < cfg.n_quantize and len(t) == k for t, k in zip(ts, ns))
+
+
 def test_decode_any_size_model_uses_the_layered_path():
     """n_resch = 128 is outside the compiled classes of the persistent decode kernel: fast_generate /
     batch_fast_generate run the layer-wise path and must reproduce the queue algorithm (oracle)."""
