@@ -11,8 +11,8 @@
 #define WN_DLP_T 512     // threads per workgroup (8 waves: 2 per SIMD, 256 VGPRs each for the stage's weights)
 #define WN_DLP_NW 8
 #define WN_DLP_CG 16     // channels per unit
-#define WN_DLP_CB 16     // utterance columns per block of the 32-column MFMA tile
-#define WN_DLP_BMAX 64   // utterances per launch
+#define WN_DLP_CB 4      // utterance columns per block (one 16-byte LDS read per k)
+#define WN_DLP_BMAX 8    // utterances per launch (larger batches amortise the layer-wise launches better: profiles/r04)
 
 typedef struct WnDlpPlan {
     int ok;

@@ -9,8 +9,11 @@
 //      gate rows:  P = M_s z_{s-1} + Wd_new(s) x_{s-1} + sum_older-taps Wd_tap(s) x_s[t - ..] + aux + c_s,   z_s = sigmoid(P_a) tanh(P_b)
 //      x rows:     x_s = Wres(s-1) z_{s-1} + b_res(s-1) + x_{s-1}
 //      skip rows:  skip += Wskip(s-1) z_{s-1}                      (its share of the n_skipch rows)
-// for its 16 channels as two 32-row f32-MFMA tiles (utterances = MFMA columns), the K range split over the 8 waves, partial
-// tiles summed through LDS in a fixed order.  The stage's weights (256 KB per unit at n_resch 512) are requested into
+// for its 16 channels as two sets of 32 rows: a lane owns one row and one k parity of a wave's slice of K (the weights sit in
+// its registers in that layout) and multiplies them with the staged input columns on the fp32 VALU -- at up to 8 utterances
+// per launch only the columns that exist are computed, where an f32 MFMA tile would spend 64 cycles per 2 k on 32 columns
+// (measured: 546 us per step with MFMA tiles at B = 1, profiles/r04) --, the 16 partial sums per row are added through LDS in a
+// fixed order.  The stage's weights (256 KB per unit at n_resch 512) are requested into
 // registers FIRST, then the inputs are gathered: the previous stage's vectors arrive as 8-byte granules {value, tag} that the
 // consumer polls (tag = step and stage, so a granule is its own ready flag), the older taps come from the unit's PRIVATE copy
 // of the dilation queues (every unit sees every x_s anyway and pushes it into its own rings: no cross-workgroup traffic on
@@ -19,6 +22,8 @@
 // from the gathered logits (argmax / inverse-CDF on the caller's uniforms: deterministic), so the next step starts without
 // another hop.  Every poll is bounded; a timeout sets `err` and drains the launch.
 #include "wn_dlp.h"
+
+#include <type_traits>
 
 #include "wn_prof.h"
 
@@ -41,7 +46,7 @@ void wn_dlp_make_plan(int Q, int Qo, int R, int S, int L, int K, WnDlpPlan* p) {
             p->stage_floats = 512L * (p->NSP + p->NSX);
             p->post_floats = 2L * 512 * p->NSX;
             long region0 = 16L * p->NSP * WN_DLP_CB;           // input staging [16 NSP][CB]
-            if (region0 < 2L * 8 * 32 * 16) region0 = 2L * 8 * 32 * 16;   // ... aliased by the two partial-tile buffers
+            if (region0 < 2L * 16 * 32 * WN_DLP_CB) region0 = 2L * 16 * 32 * WN_DLP_CB;   // ... aliased by the partial sums
             p->lds_bytes = (region0 + 16 * WN_DLP_BMAX + 16 * WN_DLP_BMAX + 4 * WN_DLP_BMAX + 64) * 4;
             p->ok = 1;
             return;
@@ -166,10 +171,11 @@ template <int NSP, int NSX>
 __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
     WN_DYN_SMEM(smem_raw);
     constexpr int CB = WN_DLP_CB, BM = WN_DLP_BMAX;
-    constexpr int KPAD = 16 * NSP;                                    // padded K of the gate tile (rows of the staging buffer)
-    constexpr int REG0 = (KPAD * CB > 2 * 8 * 32 * 16) ? KPAD * CB : 2 * 8 * 32 * 16;
-    float* s_in = reinterpret_cast<float*>(smem_raw);                 // [KPAD][CB] inputs of the stage  | aliased after the MFMAs by
-    float* s_red = s_in;                                              // [2][8][32][16] partial tiles
+    constexpr int KPAD = 16 * NSP;                                    // padded K of the gate rows (rows of the staging buffer)
+    constexpr int RED = 2 * 16 * 32 * CB;                             // partial sums [2 row sets][8 waves x 2 k parities][32 rows][CB]
+    constexpr int REG0 = (KPAD * CB > RED) ? KPAD * CB : RED;
+    float* s_in = reinterpret_cast<float*>(smem_raw);                 // [KPAD][CB] inputs of the stage  | aliased after the FMAs by
+    float* s_red = s_in;                                              // the partial sums
     float* s_xown = s_in + REG0;                                      // [16][BM] x of the unit's own channels (previous stage)
     float* s_sk = s_xown + 16 * BM;                                   // [16][BM] skip accumulators of the unit's rows
     int* s_tok = reinterpret_cast<int*>(s_sk + 16 * BM);              // [3][BM] the newest K tokens of every utterance
@@ -218,6 +224,36 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
         }
         return wn_bits_f32((unsigned)v);
     };
+    // One row set: lane (row li, k parity hi) of wave w holds the weights W[li][(w NS + t) 2 + hi], t < NS, and accumulates its
+    // slice of the dot products of row li with the staged input columns (one 16-byte LDS read = the CB utterances of one k:
+    // fp32 VALU at the f32-MFMA rate, and only the columns that exist are computed); 16 partial sums per row go to s_red.
+    auto partial_dots = [&](const auto& w, auto ns_c, bool on, float (&acc)[CB]) {
+        constexpr int ns = decltype(ns_c)::value;
+        WN_UNROLL
+        for (int q = 0; q < CB; ++q) acc[q] = 0.0f;
+        if (!on) return;
+        WN_UNROLL
+        for (int t = 0; t < ns; ++t) {
+            const int k = (wave * ns + t) * 2 + hi;
+            const wn_f4 v = *reinterpret_cast<const wn_f4*>(s_in + k * CB);
+            acc[0] = fmaf(w[t], v.x, acc[0]); acc[1] = fmaf(w[t], v.y, acc[1]);
+            acc[2] = fmaf(w[t], v.z, acc[2]); acc[3] = fmaf(w[t], v.w, acc[3]);
+        }
+    };
+    auto put_partials = [&](int set, const float (&acc)[CB]) {
+        wn_f4 v;
+        v.x = acc[0]; v.y = acc[1]; v.z = acc[2]; v.w = acc[3];
+        *reinterpret_cast<wn_f4*>(s_red + ((set * 16 + wave * 2 + hi) * 32 + li) * CB) = v;
+    };
+    auto row_sum = [&](int set, int row, int uc) -> float {   // fixed-order sum of the 16 partial sums of a row
+        const float* q = s_red + (set * 16 * 32 + row) * CB + uc;
+        float sum = 0.0f;
+        WN_UNROLL
+        for (int i = 0; i < 16; i += 4)
+            sum += (q[(i + 0) * 32 * CB] + q[(i + 1) * 32 * CB]) + (q[(i + 2) * 32 * CB] + q[(i + 3) * 32 * CB]);
+        return sum;
+    };
+    static_assert(CB == 4, "one 16-byte LDS read per k");
 
     float wP[NSP], wX[NSX];
     for (int p = a.p0; p < a.p1; ++p) {
@@ -240,15 +276,15 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
             const long qoff_s = hasP ? dlp_queue_off(s, a.depth, K, R) : 0;
             for (int cb = 0; cb < ncb; ++cb) {
                 // (2) gather [z_{s-1} | x_{s-1} | older taps of x_s] of the block's utterances into s_in[k][uc]: every thread
-                // requests up to four elements before it looks at the first tag (one round trip for the whole gather)
+                // requests up to eight elements before it looks at the first tag (one round trip for most of the gather)
                 const int krows = hasP ? KP : 2 * R;       // stage L: z for the skip rows, x only for the queue push
                 const int nbc = (B - cb * CB) < CB ? (B - cb * CB) : CB;   // utterances of this block
-                for (int base = tid; base < krows * nbc; base += 4 * WN_DLP_T) {
-                    const u64* gp[4];
-                    u64 gv[4];
-                    float fv[4];
+                for (int base = tid; base < krows * nbc; base += 8 * WN_DLP_T) {
+                    const u64* gp[8];
+                    u64 gv[8];
+                    float fv[8];
                     WN_UNROLL
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < 8; ++j) {
                         const int idx = base + j * WN_DLP_T;
                         gp[j] = nullptr;
                         fv[j] = 0.0f;
@@ -270,7 +306,7 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                         }
                     }
                     WN_UNROLL
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < 8; ++j) {
                         const int idx = base + j * WN_DLP_T;
                         if (idx < krows * nbc) {
                             const int k = idx / nbc, uc = idx % nbc, b = cb * CB + uc;
@@ -294,74 +330,46 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                     }
                 }
                 __syncthreads();
-                // (3) the two tiles: rows = [16 sigmoid | 16 tanh] and [16 x | skip rows], columns = utterances
-                f32x16 accP = f32x16_zero(), accX = f32x16_zero();
-                if (hasP) {
-                    WN_UNROLL
-                    for (int t = 0; t < NSP; ++t) {
-                        const int k = (wave * NSP + t) * 2 + hi;
-                        const float bv = li < CB ? s_in[k * CB + li] : 0.0f;
-                        accP = mfma32(wP[t], bv, accP);
-                    }
-                }
-                if (hasX) {
-                    WN_UNROLL
-                    for (int t = 0; t < NSX; ++t) {
-                        const int k = (wave * NSX + t) * 2 + hi;
-                        const float bv = li < CB ? s_in[k * CB + li] : 0.0f;
-                        accX = mfma32(wX[t], bv, accX);
-                    }
-                }
-                __syncthreads();   // every wave is done with the staged inputs: the partial tiles take their place
-                if (li < CB) {
-                    WN_UNROLL
-                    for (int r = 0; r < 16; ++r) {
-                        s_red[((0 * 8 + wave) * 32 + mfma32_row(r, hi)) * 16 + li] = accP[r];
-                        s_red[((1 * 8 + wave) * 32 + mfma32_row(r, hi)) * 16 + li] = accX[r];
-                    }
-                }
+                // (3) the two row sets: [16 sigmoid | 16 tanh] rows over all of K, [16 x | skip rows] over the z part
+                float accP[CB], accX[CB];
+                partial_dots(wP, std::integral_constant<int, NSP>(), hasP, accP);
+                partial_dots(wX, std::integral_constant<int, NSX>(), hasX, accX);
+                __syncthreads();   // every wave is done with the staged inputs: the partial sums take their place
+                put_partials(0, accP);
+                put_partials(1, accX);
                 __syncthreads();
-                // (4) fixed-order sum of the 8 partial tiles + epilogues; one output element per thread and kind
-                auto tile_sum = [&](int tile, int row, int uc) -> float {
-                    const float* q = s_red + ((tile * 8) * 32 + row) * 16 + uc;
-                    return ((q[0] + q[1 * 512]) + (q[2 * 512] + q[3 * 512])) + ((q[4 * 512] + q[5 * 512]) + (q[6 * 512] + q[7 * 512]));
-                };
-                {
-                    const int e = tid & 255, c = e >> 4, uc = e & 15, b = cb * CB + uc;
-                    if (tid < 256) {
-                        if (hasP && b < B) {   // gate (wavenet.py:542-544)
-                            const int t = p > a.n_pad ? p - a.n_pad : 0;   // replicated first column inside the left padding
-                            int f = t / a.Ue;
-                            const float wj = a.upw[t - f * a.Ue];
-                            if (f > a.F - 1) f = a.F - 1;
-                            const float* Gs = a.G + ((long)b * a.F + f) * a.nG + (long)s * 2 * R;
-                            const float ps = tile_sum(0, c, uc) + (wj * Gs[c0 + c] + a.cfold[(long)s * 2 * R + c0 + c]);
-                            const float pt = tile_sum(0, 16 + c, uc) + (wj * Gs[R + c0 + c] + a.cfold[(long)s * 2 * R + R + c0 + c]);
-                            wn_granule_store(a.gz + ((long)(s & 1) * R + c0 + c) * B + b, wn_sigmoid(ps) * wn_tanh(pt), tag0 + (unsigned)s);
-                        }
-                    } else if (b < B) {
+                // (4) epilogues, one output element per thread
+                if (tid < 16 * CB) {
+                    const int c = tid / CB, uc = tid % CB, b = cb * CB + uc;
+                    if (hasP && b < B) {   // gate (wavenet.py:542-544)
+                        const int t = p > a.n_pad ? p - a.n_pad : 0;   // replicated first column inside the left padding
+                        int f = t / a.Ue;
+                        const float wj = a.upw[t - f * a.Ue];
+                        if (f > a.F - 1) f = a.F - 1;
+                        const float* Gs = a.G + ((long)b * a.F + f) * a.nG + (long)s * 2 * R;
+                        const float ps = row_sum(0, c, uc) + (wj * Gs[c0 + c] + a.cfold[(long)s * 2 * R + c0 + c]);
+                        const float pt = row_sum(0, 16 + c, uc) + (wj * Gs[R + c0 + c] + a.cfold[(long)s * 2 * R + R + c0 + c]);
+                        wn_granule_store(a.gz + ((long)(s & 1) * R + c0 + c) * B + b, wn_sigmoid(ps) * wn_tanh(pt), tag0 + (unsigned)s);
+                    }
+                } else if (tid < 32 * CB) {
+                    const int e = tid - 16 * CB, c = e / CB, uc = e % CB, b = cb * CB + uc;
+                    if (b < B && s < L) {
                         float xs;
-                        bool have = false;
                         if (s == 0) {   // x_0 of the unit's own channels
                             xs = x0_of(c0 + c, b);
-                            have = true;
-                        } else if (s < L) {   // x_s = res_1x1(z_{s-1}) + x_{s-1}   (wavenet.py:546-548)
-                            xs = tile_sum(1, c, uc) + a.params[a.off_res_b0 + (long)(s - 1) * a.res_b_lstride + c0 + c] + s_xown[c * BM + b];
+                        } else {        // x_s = res_1x1(z_{s-1}) + x_{s-1}   (wavenet.py:546-548)
+                            xs = row_sum(1, c, uc) + a.params[a.off_res_b0 + (long)(s - 1) * a.res_b_lstride + c0 + c] + s_xown[c * BM + b];
                             wn_granule_store(a.gx + ((long)(s & 1) * R + c0 + c) * B + b, xs, tag0 + (unsigned)s);
-                            have = true;
                         }
-                        if (have) {
-                            s_xown[c * BM + b] = xs;
-                            if (K >= 2)   // the shared rings stay current for the next launch (and the launch path)
-                                a.queues[(dlp_queue_off(s, a.depth, K, R) + (long)(p % Dq) * R + c0 + c) * B + b] = xs;
-                        }
+                        s_xown[c * BM + b] = xs;
+                        if (K >= 2)   // the shared rings stay current for the next launch (and the launch path)
+                            a.queues[(dlp_queue_off(s, a.depth, K, R) + (long)(p % Dq) * R + c0 + c) * B + b] = xs;
                     }
-                    if (hasX && tid < SU * 16) {   // the unit's rows of the skip sum (wavenet.py:545, 365)
-                        const int r = tid >> 4, ub = cb * CB + (tid & 15);
-                        if (ub < B) s_sk[r * BM + ub] += tile_sum(1, 16 + r, tid & 15);
-                    }
+                } else if (tid < 32 * CB + SU * CB) {   // the unit's rows of the skip sum (wavenet.py:545, 365)
+                    const int e = tid - 32 * CB, r = e / CB, uc = e % CB, b = cb * CB + uc;
+                    if (hasX && b < B) s_sk[r * BM + b] += row_sum(1, 16 + r, uc);
                 }
-                __syncthreads();   // the partial tiles are consumed: the next gather may overwrite them
+                __syncthreads();   // the partial sums are consumed: the next gather may overwrite them
             }
         }
         // ---- post net (wavenet.py:518-523): relu(skip sum) -> conv_post_1 + relu -> conv_post_2, three more hops ----
@@ -382,24 +390,15 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                     s_in[k * CB + uc] = wait_granule(src + (long)k * B + cb * CB + uc, tag0 + (unsigned)(L + 1 + stage));
                 }
                 __syncthreads();
-                f32x16 acc = f32x16_zero();
-                WN_UNROLL
-                for (int t = 0; t < NSX; ++t) {
-                    const int k = (wave * NSX + t) * 2 + hi;
-                    const float bv = li < CB ? s_in[k * CB + li] : 0.0f;
-                    acc = mfma32(wX[t], bv, acc);
-                }
+                float acc[CB];
+                partial_dots(wX, std::integral_constant<int, NSX>(), true, acc);
                 __syncthreads();
-                if (li < CB) {
-                    WN_UNROLL
-                    for (int r = 0; r < 16; ++r) s_red[(wave * 32 + mfma32_row(r, hi)) * 16 + li] = acc[r];
-                }
+                put_partials(0, acc);
                 __syncthreads();
-                {
-                    const int r = tid >> 4, uc = tid & 15, b = cb * CB + uc;   // 32 rows x 16 columns = 512 threads
-                    const float* q = s_red + r * 16 + uc;
-                    const float v = ((q[0] + q[1 * 512]) + (q[2 * 512] + q[3 * 512])) + ((q[4 * 512] + q[5 * 512]) + (q[6 * 512] + q[7 * 512]));
+                if (tid < 32 * CB) {
+                    const int r = tid / CB, uc = tid % CB, b = cb * CB + uc;
                     if (b < B) {
+                        const float v = row_sum(0, r, uc);
                         if (stage == 0) {
                             const int row = u * SU + r;
                             if (r < SU && row < S)

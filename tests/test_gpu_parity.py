@@ -303,12 +303,12 @@ def test_decode_wide_model_layered_path_long_k():
 def test_decode_any_size_persistent_launch_vs_oracle_and_launches():
     """csrc/wn_dlp.hip: the any-size decode as ONE launch of n_resch / 16 workgroups that hand their vectors to each other as
     tagged granules (wavenet.py:355-385, 538-549, 518-523 with the res 1x1 folded into the next layer's newest tap).  A
-    128-channel model (8 workgroups, the small class; kernel_size 3; 20 utterances = two column blocks of ragged lengths) and
+    128-channel model (8 workgroups, the small class; kernel_size 3; 7 utterances = two column blocks, ragged lengths) and
     the recipes' own size (n_resch 512 / n_skipch 256: 32 workgroups, 256 KB of weights per workgroup and stage): logits within
     1e-4 of the queue algorithm (oracle), tokens equal wherever the oracle's argmax is not a near-tie, the same against the
     layer-wise launches it replaces, both ways of building the context queues, and the sampling mode runs."""
     from pytorchwavenetvocoder_amd.nets import WaveNet
-    for cfg_t, B, n, scale, seed in (((64, 4, 128, 128, 3, 2, 3, 4), 20, 26, 0.1, 21), ((256, 80, 512, 256, 10, 3, 2, 80), 2, 12, 0.02, 22)):
+    for cfg_t, B, n, scale, seed in (((64, 4, 128, 128, 3, 2, 3, 4), 7, 26, 0.1, 21), ((256, 80, 512, 256, 10, 3, 2, 80), 2, 12, 0.02, 22)):
         cfg = O.OracleConfig(*cfg_t)
         params = O.random_params(cfg, seed, scale=scale)
         model = WaveNet(*cfg_t)
