@@ -1661,7 +1661,7 @@ static int dl_layout(const WnConfig* cfg, const Dims& d, int nb, DlLay* y) {
         DCARVE(dlp_go, 2L * d.S * nb);
         DCARVE(dlp_gl, 2L * d.Qo * nb);
         DCARVE(dlp_pq, (long)pl.NU * y->qfloats_per_utt * nb);
-        DCARVE(dlp_err, 64);
+        DCARVE(dlp_err, 1024);   // error word (+ the stamps of a timing build)
     }
 #undef DCARVE
     y->total = o;

@@ -80,6 +80,7 @@ static inline float wn_xor_add(float v, int m) { return v + __shfl_xor(v, m, 64)
 // bf16 matrix-core step (v_mfma_f32_32x32x16_bf16): a / b = 8 bf16 per lane packed in a float4
 typedef float4 wn_f4;  // 16-byte register quad
 static inline wn_f4 wn_ld4_unaligned(const float* p) { return wn_f4{p[0], p[1], p[2], p[3]}; }
+static inline wn_f4 wn_ld4_stream(const wn_f4* p) { return *p; }
 static inline f32x16 mfma_bf16(const wn_f4& a, const wn_f4& b, f32x16 c) {
     return emu::mfma_f32_32x32x16bf16(reinterpret_cast<const uint16_t*>(&a), reinterpret_cast<const uint16_t*>(&b), c);
 }
@@ -206,6 +207,8 @@ static __device__ __forceinline__ wn_f4 wn_ld4_unaligned(const float* p) {
     typedef float v4u __attribute__((ext_vector_type(4), aligned(4)));
     return *reinterpret_cast<const v4u*>(p);
 }
+// 16-byte load of data that is read once (a weight stream): non-temporal
+static __device__ __forceinline__ wn_f4 wn_ld4_stream(const wn_f4* p) { return __builtin_nontemporal_load(p); }
 static __device__ __forceinline__ f32x16 mfma_bf16(wn_f4 a, wn_f4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wn_bf16x8, a), __builtin_bit_cast(wn_bf16x8, b), c, 0, 0, 0);
 }

@@ -67,8 +67,9 @@ __global__ void k_dlp_pack_stage(WnDlpPackArgs a) {
     const bool isP = r < 512L * NSP;
     if (!isP) r -= 512L * NSP;
     const int NS = isP ? NSP : NSX;
-    const int lane = (int)(r & 63);
-    const int t = (int)((r >> 6) % NS), w = (int)((r >> 6) / NS);
+    // a lane's weights travel as 16-byte loads: [wave][t / 4][lane][t % 4]
+    const int lane = (int)((r >> 2) & 63);
+    const int t = (int)(((r >> 8) % (NS / 4)) * 4 + (r & 3)), w = (int)((r >> 8) / (NS / 4));
     const int row = lane & 31, k = (w * NS + t) * 2 + (lane >> 5);
     const int s = a.stage;
     float v = 0.0f;
@@ -110,8 +111,8 @@ __global__ void k_dlp_pack_post(const float* params, long post1_w, long post2_w,
     long r = idx % per_unit;
     const int tile = (int)(r / (512L * NSX));
     r -= (long)tile * 512 * NSX;
-    const int lane = (int)(r & 63);
-    const int t = (int)((r >> 6) % NSX), w = (int)((r >> 6) / NSX);
+    const int lane = (int)((r >> 2) & 63);
+    const int t = (int)(((r >> 8) % (NSX / 4)) * 4 + (r & 3)), w = (int)((r >> 8) / (NSX / 4));
     const int row = lane & 31, k = (w * NSX + t) * 2 + (lane >> 5);
     float v = 0.0f;
     if (k < S) {
@@ -166,6 +167,18 @@ static __device__ __forceinline__ long dlp_queue_off(int l, int depth, int K, in
     return (long)R * (K - 1) * (cyc * ((1L << depth) - 1) + ((1L << in) - 1));
 }
 #define DLP_SPIN_MAX (1 << 22)
+// Timing builds (-DWN_DLP_TIMING, tools/dlp_timing.py): wall-clock stamps (100 MHz) of unit 0's phases, step p0 + 3, into the
+// words behind the error flag: [stage][phase] 0 stage start, 1 inputs gathered, 2 after the barrier, 3 dot products done
+// (the stage's weights have landed), 4 partial sums in LDS, 5 outputs published, 6 end of the stage
+#ifdef WN_DLP_TIMING
+#define DLP_STAMP(stage, ph)                                                                                         \
+    do {                                                                                                             \
+        if (tid == 0 && u == 0 && p == a.p0 + 3 && (stage) < 40)                                                     \
+            reinterpret_cast<long long*>(a.err + 16)[(stage) * 8 + (ph)] = (long long)wall_clock64();                \
+    } while (0)
+#else
+#define DLP_STAMP(stage, ph)
+#endif
 
 template <int NSP, int NSX>
 __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
@@ -224,6 +237,16 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
         }
         return wn_bits_f32((unsigned)v);
     };
+    // a wave's slice of a row set's weights: NS / 4 non-temporal 16-byte loads per lane (every weight is read once per step)
+    auto load_weights = [&](auto& w, auto ns_c, const float* img) {
+        constexpr int ns = decltype(ns_c)::value;
+        const wn_f4* src = reinterpret_cast<const wn_f4*>(img) + (long)wave * (ns / 4) * 64 + lane;
+        WN_UNROLL
+        for (int t4 = 0; t4 < ns / 4; ++t4) {
+            const wn_f4 v = wn_ld4_stream(src + (long)t4 * 64);
+            w[4 * t4] = v.x; w[4 * t4 + 1] = v.y; w[4 * t4 + 2] = v.z; w[4 * t4 + 3] = v.w;
+        }
+    };
     // One row set: lane (row li, k parity hi) of wave w holds the weights W[li][(w NS + t) 2 + hi], t < NS, and accumulates its
     // slice of the dot products of row li with the staged input columns (one 16-byte LDS read = the CB utterances of one k:
     // fp32 VALU at the f32-MFMA rate, and only the columns that exist are computed); 16 partial sums per row go to s_red.
@@ -260,17 +283,11 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
         const unsigned tag0 = (unsigned)(p + 1) * (unsigned)(L + 4) + 1u;    // tag of (step p, stage s) = tag0 + s
         for (int s = 0; s <= L; ++s) {
             const bool hasP = s < L, hasX = s >= 1;
+            DLP_STAMP(s, 0);
             {   // (1) the stage's weights: requested first, they stream while the inputs are gathered
                 const float* img = a.wpk + ((long)s * a.plan.NU + u) * a.plan.stage_floats;
-                if (hasP) {
-                    WN_UNROLL
-                    for (int t = 0; t < NSP; ++t) wP[t] = img[((long)wave * NSP + t) * 64 + lane];
-                }
-                if (hasX) {
-                    const float* imx = img + 512L * NSP;
-                    WN_UNROLL
-                    for (int t = 0; t < NSX; ++t) wX[t] = imx[((long)wave * NSX + t) * 64 + lane];
-                }
+                if (hasP) load_weights(wP, std::integral_constant<int, NSP>(), img);
+                if (hasX) load_weights(wX, std::integral_constant<int, NSX>(), img + 512L * NSP);
             }
             const int d = 1 << (s % a.depth), Dq = (K - 1) * d;
             const long qoff_s = hasP ? dlp_queue_off(s, a.depth, K, R) : 0;
@@ -329,15 +346,19 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                         }
                     }
                 }
+                DLP_STAMP(s, 1);
                 __syncthreads();
+                DLP_STAMP(s, 2);
                 // (3) the two row sets: [16 sigmoid | 16 tanh] rows over all of K, [16 x | skip rows] over the z part
                 float accP[CB], accX[CB];
                 partial_dots(wP, std::integral_constant<int, NSP>(), hasP, accP);
                 partial_dots(wX, std::integral_constant<int, NSX>(), hasX, accX);
+                DLP_STAMP(s, 3);
                 __syncthreads();   // every wave is done with the staged inputs: the partial sums take their place
                 put_partials(0, accP);
                 put_partials(1, accX);
                 __syncthreads();
+                DLP_STAMP(s, 4);
                 // (4) epilogues, one output element per thread
                 if (tid < 16 * CB) {
                     const int c = tid / CB, uc = tid % CB, b = cb * CB + uc;
@@ -369,9 +390,12 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                     const int e = tid - 32 * CB, r = e / CB, uc = e % CB, b = cb * CB + uc;
                     if (hasX && b < B) s_sk[r * BM + b] += row_sum(1, 16 + r, uc);
                 }
+                DLP_STAMP(s, 5);
                 __syncthreads();   // the partial sums are consumed: the next gather may overwrite them
+                DLP_STAMP(s, 6);
             }
         }
+        DLP_STAMP(L + 1, 0);
         // ---- post net (wavenet.py:518-523): relu(skip sum) -> conv_post_1 + relu -> conv_post_2, three more hops ----
         for (int i = tid; i < SU * B; i += WN_DLP_T) {
             const int r = i / B, b = i % B, row = u * SU + r;
@@ -380,8 +404,7 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
         }
         const float* pimg = a.wpost + (long)u * a.plan.post_floats;
         for (int stage = 0; stage < 2; ++stage) {
-            WN_UNROLL
-            for (int t = 0; t < NSX; ++t) wX[t] = pimg[(long)stage * 512 * NSX + ((long)wave * NSX + t) * 64 + lane];
+            load_weights(wX, std::integral_constant<int, NSX>(), pimg + (long)stage * 512 * NSX);
             const u64* src = stage == 0 ? a.gs : a.go;
             for (int cb = 0; cb < ncb; ++cb) {
                 const int nbc = (B - cb * CB) < CB ? (B - cb * CB) : CB;
@@ -455,6 +478,7 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
             }
             __syncthreads();
         }
+        DLP_STAMP(L + 2, 0);
         if (s_flag[0]) break;
     }
     if (tid == 0 && s_flag[0]) a.err[0] = 1;

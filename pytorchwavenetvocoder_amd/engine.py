@@ -441,6 +441,7 @@ class WaveNetEngine(object):
             p = p1
             if progress is not None:
                 progress(max(p + 1 - Tctx, 0), n_max)
+        self.last_decode_state = state if layered else None   # (tools/dlp_timing.py reads a timing build's stamps from it)
         if layered:   # the persistent launch bounds every wait between its workgroups and reports a timeout here
             eoff = self.lib.wn_decode_layered_error_offset(cfg, B)
             if eoff >= 0 and int(state[eoff:eoff + 1].view(torch.int32).item()) != 0:
