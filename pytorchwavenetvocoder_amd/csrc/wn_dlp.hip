@@ -45,8 +45,7 @@ void wn_dlp_make_plan(int Q, int Qo, int R, int S, int L, int K, WnDlpPlan* p) {
             p->cls = c; p->NSP = cls[c][0]; p->NSX = cls[c][1];
             p->stage_floats = 512L * (p->NSP + p->NSX);
             p->post_floats = 2L * 512 * p->NSX;
-            long region0 = 16L * p->NSP * WN_DLP_CB;           // input staging [16 NSP][CB]
-            if (region0 < 2L * 16 * 32 * WN_DLP_CB) region0 = 2L * 16 * 32 * WN_DLP_CB;   // ... aliased by the partial sums
+            const long region0 = 16L * p->NSP * WN_DLP_CB + 2L * 16 * 32 * WN_DLP_CB;   // input staging [CB][16 NSP] + partial sums
             p->lds_bytes = (region0 + 16 * WN_DLP_BMAX + 16 * WN_DLP_BMAX + 4 * WN_DLP_BMAX + 64) * 4;
             p->ok = 1;
             return;
@@ -70,7 +69,7 @@ __global__ void k_dlp_pack_stage(WnDlpPackArgs a) {
     // a lane's weights travel as 16-byte loads: [wave][t / 4][lane][t % 4]
     const int lane = (int)((r >> 2) & 63);
     const int t = (int)(((r >> 8) % (NS / 4)) * 4 + (r & 3)), w = (int)((r >> 8) / (NS / 4));
-    const int row = lane & 31, k = (w * NS + t) * 2 + (lane >> 5);
+    const int row = lane & 31, k = (w * 2 + (lane >> 5)) * NS + t;   // a (wave, k half) owns NS consecutive k
     const int s = a.stage;
     float v = 0.0f;
     if (isP) {
@@ -113,7 +112,7 @@ __global__ void k_dlp_pack_post(const float* params, long post1_w, long post2_w,
     r -= (long)tile * 512 * NSX;
     const int lane = (int)((r >> 2) & 63);
     const int t = (int)(((r >> 8) % (NSX / 4)) * 4 + (r & 3)), w = (int)((r >> 8) / (NSX / 4));
-    const int row = lane & 31, k = (w * NSX + t) * 2 + (lane >> 5);
+    const int row = lane & 31, k = (w * 2 + (lane >> 5)) * NSX + t;
     float v = 0.0f;
     if (k < S) {
         if (tile == 0) {
@@ -185,11 +184,12 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
     WN_DYN_SMEM(smem_raw);
     constexpr int CB = WN_DLP_CB, BM = WN_DLP_BMAX;
     constexpr int KPAD = 16 * NSP;                                    // padded K of the gate rows (rows of the staging buffer)
-    constexpr int RED = 2 * 16 * 32 * CB;                             // partial sums [2 row sets][8 waves x 2 k parities][32 rows][CB]
-    constexpr int REG0 = (KPAD * CB > RED) ? KPAD * CB : RED;
-    float* s_in = reinterpret_cast<float*>(smem_raw);                 // [KPAD][CB] inputs of the stage  | aliased after the FMAs by
-    float* s_red = s_in;                                              // the partial sums
-    float* s_xown = s_in + REG0;                                      // [16][BM] x of the unit's own channels (previous stage)
+    constexpr int RED = 2 * 16 * 32 * CB;                             // partial sums [2 row sets][8 waves x 2 k halves][32 rows][CB]
+    constexpr int REG0 = KPAD * CB;
+    float* s_in = reinterpret_cast<float*>(smem_raw);                 // [CB][KPAD] inputs of the stage, k contiguous per utterance
+    float* s_red = s_in + REG0;                                       // the partial sums (their own region: no barrier between a
+                                                                      // stage's epilogue and the next stage's gather)
+    float* s_xown = s_red + RED;                                      // [16][BM] x of the unit's own channels (previous stage)
     float* s_sk = s_xown + 16 * BM;                                   // [16][BM] skip accumulators of the unit's rows
     int* s_tok = reinterpret_cast<int*>(s_sk + 16 * BM);              // [3][BM] the newest K tokens of every utterance
     int* s_flag = s_tok + 4 * BM;                                     // [0] a poll timed out
@@ -247,20 +247,28 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
             w[4 * t4] = v.x; w[4 * t4 + 1] = v.y; w[4 * t4 + 2] = v.z; w[4 * t4 + 3] = v.w;
         }
     };
-    // One row set: lane (row li, k parity hi) of wave w holds the weights W[li][(w NS + t) 2 + hi], t < NS, and accumulates its
-    // slice of the dot products of row li with the staged input columns (one 16-byte LDS read = the CB utterances of one k:
-    // fp32 VALU at the f32-MFMA rate, and only the columns that exist are computed); 16 partial sums per row go to s_red.
-    auto partial_dots = [&](const auto& w, auto ns_c, bool on, float (&acc)[CB]) {
+    // One row set: lane (row li, k half hi) of wave w holds the weights W[li][(2 w + hi) NS + t], t < NS -- NS consecutive k --
+    // and accumulates its slice of the dot products of row li with the staged inputs of the block's utterances on the fp32
+    // VALU (one 16-byte LDS read = 4 consecutive k of one utterance; only the utterances that exist are computed); 16
+    // partial sums per row go to s_red.
+    auto partial_dots = [&](const auto& w, auto ns_c, bool on, int nb, float (&acc)[CB]) {
         constexpr int ns = decltype(ns_c)::value;
         WN_UNROLL
         for (int q = 0; q < CB; ++q) acc[q] = 0.0f;
         if (!on) return;
+        const float* src = s_in + (wave * 2 + hi) * ns;
         WN_UNROLL
-        for (int t = 0; t < ns; ++t) {
-            const int k = (wave * ns + t) * 2 + hi;
-            const wn_f4 v = *reinterpret_cast<const wn_f4*>(s_in + k * CB);
-            acc[0] = fmaf(w[t], v.x, acc[0]); acc[1] = fmaf(w[t], v.y, acc[1]);
-            acc[2] = fmaf(w[t], v.z, acc[2]); acc[3] = fmaf(w[t], v.w, acc[3]);
+        for (int q = 0; q < CB; ++q) {
+            if (q < nb) {   // block-uniform
+                float a0 = 0.0f, a1 = 0.0f;
+                WN_UNROLL
+                for (int t4 = 0; t4 < ns / 4; ++t4) {
+                    const wn_f4 v = *reinterpret_cast<const wn_f4*>(src + q * KPAD + 4 * t4);
+                    a0 = fmaf(w[4 * t4], v.x, a0); a1 = fmaf(w[4 * t4 + 1], v.y, a1);
+                    a0 = fmaf(w[4 * t4 + 2], v.z, a0); a1 = fmaf(w[4 * t4 + 3], v.w, a1);
+                }
+                acc[q] = a0 + a1;
+            }
         }
     };
     auto put_partials = [&](int set, const float (&acc)[CB]) {
@@ -342,7 +350,7 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                                 const int dp = 1 << ((s - 1) % a.depth), Dp = (K - 1) * dp;
                                 pq[(dlp_queue_off(s - 1, a.depth, K, R) + (long)(p % Dp) * R + (k - R)) * B + b] = v;
                             }
-                            if (hasP || k < R) s_in[k * CB + uc] = v;
+                            if (hasP || k < R) s_in[uc * KPAD + k] = v;
                         }
                     }
                 }
@@ -351,10 +359,9 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                 DLP_STAMP(s, 2);
                 // (3) the two row sets: [16 sigmoid | 16 tanh] rows over all of K, [16 x | skip rows] over the z part
                 float accP[CB], accX[CB];
-                partial_dots(wP, std::integral_constant<int, NSP>(), hasP, accP);
-                partial_dots(wX, std::integral_constant<int, NSX>(), hasX, accX);
+                partial_dots(wP, std::integral_constant<int, NSP>(), hasP, nbc, accP);
+                partial_dots(wX, std::integral_constant<int, NSX>(), hasX, nbc, accX);
                 DLP_STAMP(s, 3);
-                __syncthreads();   // every wave is done with the staged inputs: the partial sums take their place
                 put_partials(0, accP);
                 put_partials(1, accX);
                 __syncthreads();
@@ -391,11 +398,12 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                     if (hasX && b < B) s_sk[r * BM + b] += row_sum(1, 16 + r, uc);
                 }
                 DLP_STAMP(s, 5);
-                __syncthreads();   // the partial sums are consumed: the next gather may overwrite them
+                if (ncb > 1) __syncthreads();   // (several blocks per stage: the next block's gather re-uses s_in at once)
                 DLP_STAMP(s, 6);
             }
         }
         DLP_STAMP(L + 1, 0);
+        __syncthreads();   // the skip accumulators of the last stage's epilogue are complete
         // ---- post net (wavenet.py:518-523): relu(skip sum) -> conv_post_1 + relu -> conv_post_2, three more hops ----
         for (int i = tid; i < SU * B; i += WN_DLP_T) {
             const int r = i / B, b = i % B, row = u * SU + r;
@@ -410,12 +418,11 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                 const int nbc = (B - cb * CB) < CB ? (B - cb * CB) : CB;
                 for (int idx = tid; idx < S * nbc; idx += WN_DLP_T) {
                     const int k = idx / nbc, uc = idx % nbc;
-                    s_in[k * CB + uc] = wait_granule(src + (long)k * B + cb * CB + uc, tag0 + (unsigned)(L + 1 + stage));
+                    s_in[uc * KPAD + k] = wait_granule(src + (long)k * B + cb * CB + uc, tag0 + (unsigned)(L + 1 + stage));
                 }
                 __syncthreads();
                 float acc[CB];
-                partial_dots(wX, std::integral_constant<int, NSX>(), true, acc);
-                __syncthreads();
+                partial_dots(wX, std::integral_constant<int, NSX>(), true, nbc, acc);
                 put_partials(0, acc);
                 __syncthreads();
                 if (tid < 32 * CB) {
@@ -441,7 +448,7 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
             const int nbc = (B - cb * CB) < CB ? (B - cb * CB) : CB;
             for (int idx = tid; idx < Qo * nbc; idx += WN_DLP_T) {
                 const int q = idx / nbc, uc = idx % nbc;
-                s_in[q * CB + uc] = wait_granule(a.gl + (long)q * B + cb * CB + uc, tag0 + (unsigned)(L + 3));
+                s_in[uc * KPAD + q] = wait_granule(a.gl + (long)q * B + cb * CB + uc, tag0 + (unsigned)(L + 3));
             }
             __syncthreads();
             if (tid < CB && cb * CB + tid < B) {
@@ -449,19 +456,19 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                 float best = -3.0e38f;
                 int bi = 0;
                 for (int q = 0; q < Qo; ++q) {
-                    const float v = s_in[q * CB + tid];
+                    const float v = s_in[tid * KPAD + q];
                     if (u == 0 && a.logits_out) a.logits_out[((long)b * a.Ttot + p) * Qo + q] = v;
                     if (v > best) { best = v; bi = q; }
                 }
                 int chosen = bi;
                 if (a.mode == 1 && a.uniforms != nullptr) {
                     float total = 0.0f;
-                    for (int q = 0; q < Qo; ++q) total += expf(s_in[q * CB + tid] - best);
+                    for (int q = 0; q < Qo; ++q) total += expf(s_in[tid * KPAD + q] - best);
                     const float target = a.uniforms[(long)b * a.Ttot + p + 1] * total;
                     float run = 0.0f;
                     int cand = -1;
                     for (int q = 0; q < Qo; ++q) {
-                        run += expf(s_in[q * CB + tid] - best);
+                        run += expf(s_in[tid * KPAD + q] - best);
                         if (cand < 0 && run >= target) cand = q;
                     }
                     if (cand >= 0) chosen = cand;
