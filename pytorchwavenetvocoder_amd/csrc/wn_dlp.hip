@@ -286,30 +286,37 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
     };
     static_assert(CB == 4, "one 16-byte LDS read per k");
 
+    // The weight registers of a stage are dead the moment its dot products are done, so the NEXT stage's weights are
+    // requested right there: they stream under the partial sums, the epilogue, the hand-off of the outputs and the gather of
+    // the next stage (memory returns in order, so the gather's polls simply come back behind them).  For that to cost the
+    // epilogue nothing, everything the epilogue reads from memory (aux projection, constants, biases) is requested BEFORE the
+    // dot products -- those loads are ahead of the weight stream in the return order.
     float wP[NSP], wX[NSX];
+    auto issue_stage_weights = [&](int sn) {   // stage sn in [0, L]
+        const float* img = a.wpk + ((long)sn * a.plan.NU + u) * a.plan.stage_floats;
+        if (sn < L) load_weights(wP, std::integral_constant<int, NSP>(), img);
+        if (sn >= 1) load_weights(wX, std::integral_constant<int, NSX>(), img + 512L * NSP);
+    };
+    const float* pimg = a.wpost + (long)u * a.plan.post_floats;
+    issue_stage_weights(0);
     for (int p = a.p0; p < a.p1; ++p) {
         const unsigned tag0 = (unsigned)(p + 1) * (unsigned)(L + 4) + 1u;    // tag of (step p, stage s) = tag0 + s
         for (int s = 0; s <= L; ++s) {
             const bool hasP = s < L, hasX = s >= 1;
             DLP_STAMP(s, 0);
-            {   // (1) the stage's weights: requested first, they stream while the inputs are gathered
-                const float* img = a.wpk + ((long)s * a.plan.NU + u) * a.plan.stage_floats;
-                if (hasP) load_weights(wP, std::integral_constant<int, NSP>(), img);
-                if (hasX) load_weights(wX, std::integral_constant<int, NSX>(), img + 512L * NSP);
-            }
             const int d = 1 << (s % a.depth), Dq = (K - 1) * d;
             const long qoff_s = hasP ? dlp_queue_off(s, a.depth, K, R) : 0;
             for (int cb = 0; cb < ncb; ++cb) {
                 // (2) gather [z_{s-1} | x_{s-1} | older taps of x_s] of the block's utterances into s_in[k][uc]: every thread
-                // requests up to eight elements before it looks at the first tag (one round trip for most of the gather)
+                // requests up to four elements before it looks at the first tag (one round trip for most of the gather)
                 const int krows = hasP ? KP : 2 * R;       // stage L: z for the skip rows, x only for the queue push
                 const int nbc = (B - cb * CB) < CB ? (B - cb * CB) : CB;   // utterances of this block
-                for (int base = tid; base < krows * nbc; base += 8 * WN_DLP_T) {
-                    const u64* gp[8];
-                    u64 gv[8];
-                    float fv[8];
+                for (int base = tid; base < krows * nbc; base += 4 * WN_DLP_T) {
+                    const u64* gp[4];
+                    u64 gv[4];
+                    float fv[4];
                     WN_UNROLL
-                    for (int j = 0; j < 8; ++j) {
+                    for (int j = 0; j < 4; ++j) {
                         const int idx = base + j * WN_DLP_T;
                         gp[j] = nullptr;
                         fv[j] = 0.0f;
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                         }
                     }
                     WN_UNROLL
-                    for (int j = 0; j < 8; ++j) {
+                    for (int j = 0; j < 4; ++j) {
                         const int idx = base + j * WN_DLP_T;
                         if (idx < krows * nbc) {
                             const int k = idx / nbc, uc = idx % nbc, b = cb * CB + uc;
@@ -355,12 +362,33 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                     }
                 }
                 DLP_STAMP(s, 1);
+                // what this thread's epilogue reads from memory, requested ahead of the next stage's weight stream
+                float e0 = 0.0f, e1 = 0.0f;
+                if (tid < 16 * CB) {
+                    const int c = tid / CB, b = cb * CB + tid % CB;
+                    if (hasP && b < B) {
+                        const int t = p > a.n_pad ? p - a.n_pad : 0;   // replicated first column inside the left padding
+                        int f = t / a.Ue;
+                        const float wj = a.upw[t - f * a.Ue];
+                        if (f > a.F - 1) f = a.F - 1;
+                        const float* Gs = a.G + ((long)b * a.F + f) * a.nG + (long)s * 2 * R;
+                        e0 = wj * Gs[c0 + c] + a.cfold[(long)s * 2 * R + c0 + c];
+                        e1 = wj * Gs[R + c0 + c] + a.cfold[(long)s * 2 * R + R + c0 + c];
+                    }
+                } else if (tid < 32 * CB) {
+                    const int e = tid - 16 * CB, c = e / CB, b = cb * CB + e % CB;
+                    if (b < B && s < L) e0 = s == 0 ? x0_of(c0 + c, b) : a.params[a.off_res_b0 + (long)(s - 1) * a.res_b_lstride + c0 + c];
+                }
                 __syncthreads();
                 DLP_STAMP(s, 2);
                 // (3) the two row sets: [16 sigmoid | 16 tanh] rows over all of K, [16 x | skip rows] over the z part
                 float accP[CB], accX[CB];
                 partial_dots(wP, std::integral_constant<int, NSP>(), hasP, nbc, accP);
                 partial_dots(wX, std::integral_constant<int, NSX>(), hasX, nbc, accX);
+                if (cb == ncb - 1) {   // the registers are free: the next weights (next stage, or the post net's first set)
+                    if (s < L) issue_stage_weights(s + 1);
+                    else load_weights(wX, std::integral_constant<int, NSX>(), pimg);
+                }
                 DLP_STAMP(s, 3);
                 put_partials(0, accP);
                 put_partials(1, accX);
@@ -370,13 +398,8 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                 if (tid < 16 * CB) {
                     const int c = tid / CB, uc = tid % CB, b = cb * CB + uc;
                     if (hasP && b < B) {   // gate (wavenet.py:542-544)
-                        const int t = p > a.n_pad ? p - a.n_pad : 0;   // replicated first column inside the left padding
-                        int f = t / a.Ue;
-                        const float wj = a.upw[t - f * a.Ue];
-                        if (f > a.F - 1) f = a.F - 1;
-                        const float* Gs = a.G + ((long)b * a.F + f) * a.nG + (long)s * 2 * R;
-                        const float ps = row_sum(0, c, uc) + (wj * Gs[c0 + c] + a.cfold[(long)s * 2 * R + c0 + c]);
-                        const float pt = row_sum(0, 16 + c, uc) + (wj * Gs[R + c0 + c] + a.cfold[(long)s * 2 * R + R + c0 + c]);
+                        const float ps = row_sum(0, c, uc) + e0;
+                        const float pt = row_sum(0, 16 + c, uc) + e1;
                         wn_granule_store(a.gz + ((long)(s & 1) * R + c0 + c) * B + b, wn_sigmoid(ps) * wn_tanh(pt), tag0 + (unsigned)s);
                     }
                 } else if (tid < 32 * CB) {
@@ -384,9 +407,9 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                     if (b < B && s < L) {
                         float xs;
                         if (s == 0) {   // x_0 of the unit's own channels
-                            xs = x0_of(c0 + c, b);
+                            xs = e0;
                         } else {        // x_s = res_1x1(z_{s-1}) + x_{s-1}   (wavenet.py:546-548)
-                            xs = row_sum(1, c, uc) + a.params[a.off_res_b0 + (long)(s - 1) * a.res_b_lstride + c0 + c] + s_xown[c * BM + b];
+                            xs = row_sum(1, c, uc) + e0 + s_xown[c * BM + b];
                             wn_granule_store(a.gx + ((long)(s & 1) * R + c0 + c) * B + b, xs, tag0 + (unsigned)s);
                         }
                         s_xown[c * BM + b] = xs;
@@ -410,9 +433,7 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
             if (row < S) wn_granule_store(a.gs + (long)row * B + b, fmaxf(s_sk[r * BM + b] + a.bskip[row], 0.0f), tag0 + (unsigned)(L + 1));
             s_sk[r * BM + b] = 0.0f;
         }
-        const float* pimg = a.wpost + (long)u * a.plan.post_floats;
         for (int stage = 0; stage < 2; ++stage) {
-            load_weights(wX, std::integral_constant<int, NSX>(), pimg + (long)stage * 512 * NSX);
             const u64* src = stage == 0 ? a.gs : a.go;
             for (int cb = 0; cb < ncb; ++cb) {
                 const int nbc = (B - cb * CB) < CB ? (B - cb * CB) : CB;
@@ -420,9 +441,18 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                     const int k = idx / nbc, uc = idx % nbc;
                     s_in[uc * KPAD + k] = wait_granule(src + (long)k * B + cb * CB + uc, tag0 + (unsigned)(L + 1 + stage));
                 }
+                float pb = 0.0f;   // the row's bias, ahead of the next weight stream
+                if (tid < 32 * CB) {
+                    const int r = tid / CB, row = u * (stage == 0 ? SU : QU) + r;
+                    if (stage == 0 ? (r < SU && row < S) : (r < QU && row < Qo)) pb = a.params[(stage == 0 ? a.off_post1_b : a.off_post2_b) + row];
+                }
                 __syncthreads();
                 float acc[CB];
                 partial_dots(wX, std::integral_constant<int, NSX>(), true, nbc, acc);
+                if (cb == ncb - 1) {
+                    if (stage == 0) load_weights(wX, std::integral_constant<int, NSX>(), pimg + 512L * NSX);
+                    else if (p + 1 < a.p1) issue_stage_weights(0);
+                }
                 put_partials(0, acc);
                 __syncthreads();
                 if (tid < 32 * CB) {
@@ -431,12 +461,10 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                         const float v = row_sum(0, r, uc);
                         if (stage == 0) {
                             const int row = u * SU + r;
-                            if (r < SU && row < S)
-                                wn_granule_store(a.go + (long)row * B + b, fmaxf(v + a.params[a.off_post1_b + row], 0.0f), tag0 + (unsigned)(L + 2));
+                            if (r < SU && row < S) wn_granule_store(a.go + (long)row * B + b, fmaxf(v + pb, 0.0f), tag0 + (unsigned)(L + 2));
                         } else {
                             const int row = u * QU + r;
-                            if (r < QU && row < Qo)
-                                wn_granule_store(a.gl + (long)row * B + b, v + a.params[a.off_post2_b + row], tag0 + (unsigned)(L + 3));
+                            if (r < QU && row < Qo) wn_granule_store(a.gl + (long)row * B + b, v + pb, tag0 + (unsigned)(L + 3));
                         }
                     }
                 }
