@@ -2,7 +2,7 @@
 // models too large for the one-workgroup kernel of wn_decode.hip (the recipes' n_resch = 512), as ONE launch per chunk of
 // steps instead of ~66 dependent launches per step.
 //
-// R / 16 workgroups ("units") each own 16 residual channels.  A step is a chain of L + 3 dependent stages; a stage's output
+// R / CG workgroups ("units") each own CG = 4 (8, 16 for very wide models) residual channels.  A step is a chain of L + 3 dependent stages; a stage's output
 // vectors travel from workgroup to workgroup as 8-byte granules {value, tag} (one agent-scope store per lane, the consumer
 // polls the granules themselves: 0.7 - 0.8 us per hop, profiles/r04/handoff_microbench.txt) -- no grid barrier, no fences.
 #pragma once
@@ -10,13 +10,13 @@
 
 #define WN_DLP_T 512     // threads per workgroup (8 waves: 2 per SIMD, 256 VGPRs each for the stage's weights)
 #define WN_DLP_NW 8
-#define WN_DLP_CG 16     // channels per unit
 #define WN_DLP_CB 4      // utterance columns per block (one 16-byte LDS read per k)
 #define WN_DLP_BMAX 8    // utterances per launch (larger batches amortise the layer-wise launches better: profiles/r04)
 
 typedef struct WnDlpPlan {
     int ok;
     int cls;                 // compiled class: NSP / NSX k-steps per wave of the two tiles
+    int RS;                  // rows per set = 2 x channels per unit (8, 16 or 32)
     int NSP, NSX;
     int NU, SU, QU, KP;      // units, skip rows per unit, output rows per unit, K of the gate tile = (K + 1) * R
     long stage_floats;       // packed floats of one (stage, unit): 512 * (NSP + NSX)

@@ -32,24 +32,26 @@ typedef unsigned long long u64;
 void wn_dlp_make_plan(int Q, int Qo, int R, int S, int L, int K, WnDlpPlan* p) {
     p->ok = 0;
     if (R < 32 || R % 32 != 0 || S % 16 != 0 || K < 2 || K > 3 || L < 1 || Q < 2) return;
-    p->NU = R / WN_DLP_CG;
-    if (p->NU > 240) return;                       // one workgroup per CU, all resident
-    p->SU = (S + p->NU - 1) / p->NU;
-    p->QU = (Qo + p->NU - 1) / p->NU;
-    if (p->SU > 16 || p->QU > 32) return;
-    p->KP = (K + 1) * R;
-    const int nsp = p->KP / 16, nsx = R / 16, nsq = S / 16;   // k-steps (of 2) per wave
-    static const int cls[][2] = {{24, 8}, {96, 32}, {128, 32}};
-    for (int c = 0; c < 3; ++c) {
-        if (nsp <= cls[c][0] && nsx <= cls[c][1] && nsq <= cls[c][1] && 16 * cls[c][0] >= S && 16 * cls[c][0] >= Qo) {
-            p->cls = c; p->NSP = cls[c][0]; p->NSX = cls[c][1];
-            p->stage_floats = 512L * (p->NSP + p->NSX);
-            p->post_floats = 2L * 512 * p->NSX;
-            const long region0 = 16L * p->NSP * WN_DLP_CB + 2L * 16 * 32 * WN_DLP_CB;   // input staging [CB][16 NSP] + partial sums
-            p->lds_bytes = (region0 + 16 * WN_DLP_BMAX + 16 * WN_DLP_BMAX + 4 * WN_DLP_BMAX + 64) * 4;
-            p->ok = 1;
-            return;
-        }
+    // As many units as the chip has room for: the weight stream of a stage is what one CU can pull (~60 GB/s measured), so
+    // the fewer channels a unit owns the shorter the stage.  Channels per unit CG in {4, 8, 16} <-> rows per set RS = 2 CG.
+    static const int cls[][3] = {{8, 24, 8}, {8, 32, 8}, {16, 48, 16}, {16, 64, 16}, {32, 96, 32}, {32, 128, 32}};   // RS, NSP, NSX
+    for (int c = 0; c < 6; ++c) {
+        const int RS = cls[c][0], CG = RS / 2, KQ = 64 / RS, slices = 8 * KQ;
+        if (R % CG != 0) continue;
+        const int NU = R / CG;
+        if (NU > 240) continue;                    // one workgroup per CU, all resident
+        const int SU = (S + NU - 1) / NU, QU = (Qo + NU - 1) / NU, KP = (K + 1) * R;
+        if (CG + SU > RS || QU > RS || SU > RS) continue;
+        const int kpad = slices * cls[c][1], xpad = slices * cls[c][2];
+        if (KP > kpad || R > xpad || S > xpad || S > kpad || Qo > kpad) continue;
+        p->cls = c; p->RS = RS; p->NSP = cls[c][1]; p->NSX = cls[c][2];
+        p->NU = NU; p->SU = SU; p->QU = QU; p->KP = KP;
+        p->stage_floats = 512L * (p->NSP + p->NSX);
+        p->post_floats = 2L * 512 * p->NSX;
+        const long region0 = (long)kpad * WN_DLP_CB + 2L * 8 * 64 * WN_DLP_CB;   // input staging [CB][kpad] + partial sums
+        p->lds_bytes = (region0 + 16 * WN_DLP_BMAX + 16 * WN_DLP_BMAX + 4 * WN_DLP_BMAX + 64) * 4;
+        p->ok = 1;
+        return;
     }
 }
 
@@ -69,12 +71,13 @@ __global__ void k_dlp_pack_stage(WnDlpPackArgs a) {
     // a lane's weights travel as 16-byte loads: [wave][t / 4][lane][t % 4]
     const int lane = (int)((r >> 2) & 63);
     const int t = (int)(((r >> 8) % (NS / 4)) * 4 + (r & 3)), w = (int)((r >> 8) / (NS / 4));
-    const int row = lane & 31, k = (w * 2 + (lane >> 5)) * NS + t;   // a (wave, k half) owns NS consecutive k
+    const int RS = a.plan.RS, CG = RS / 2, KQ = 64 / RS;
+    const int row = lane % RS, k = (w * KQ + lane / RS) * NS + t;   // a (wave, k part) owns NS consecutive k
     const int s = a.stage;
     float v = 0.0f;
     if (isP) {
         if (s < a.L && k < a.plan.KP) {
-            const int c = u * WN_DLP_CG + (row & 15), half = row >> 4;
+            const int c = u * CG + (row % CG), half = row / CG;
             const long wbase = a.lb_s + (half ? a.o_dtanh_w : a.o_dsig_w);
             if (k < R) v = (s >= 1) ? a.fold[((long)half * R + c) * R + k] : 0.0f;
             else if (k < 2 * R) v = a.params[wbase + ((long)c * R + (k - R)) * K + (K - 1)];
@@ -84,10 +87,10 @@ __global__ void k_dlp_pack_stage(WnDlpPackArgs a) {
             }
         }
     } else if (s >= 1 && k < R) {
-        if (row < 16) {
-            if (s < a.L) v = a.params[a.lb_prev + a.o_res_w + (long)(u * WN_DLP_CG + row) * R + k];
-        } else if (row < 16 + a.plan.SU) {
-            const int srow = u * a.plan.SU + (row - 16);
+        if (row < CG) {
+            if (s < a.L) v = a.params[a.lb_prev + a.o_res_w + (long)(u * CG + row) * R + k];
+        } else if (row < CG + a.plan.SU) {
+            const int srow = u * a.plan.SU + (row - CG);
             if (srow < a.S) v = a.params[a.skip_prev + (long)srow * R + k];
         }
     }
@@ -112,7 +115,8 @@ __global__ void k_dlp_pack_post(const float* params, long post1_w, long post2_w,
     r -= (long)tile * 512 * NSX;
     const int lane = (int)((r >> 2) & 63);
     const int t = (int)(((r >> 8) % (NSX / 4)) * 4 + (r & 3)), w = (int)((r >> 8) / (NSX / 4));
-    const int row = lane & 31, k = (w * 2 + (lane >> 5)) * NSX + t;
+    const int RS = plan.RS, KQ = 64 / RS;
+    const int row = lane % RS, k = (w * KQ + lane / RS) * NSX + t;
     float v = 0.0f;
     if (k < S) {
         if (tile == 0) {
@@ -179,12 +183,13 @@ static __device__ __forceinline__ long dlp_queue_off(int l, int depth, int K, in
 #define DLP_STAMP(stage, ph)
 #endif
 
-template <int NSP, int NSX>
+template <int RS, int NSP, int NSX>
 __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
     WN_DYN_SMEM(smem_raw);
     constexpr int CB = WN_DLP_CB, BM = WN_DLP_BMAX;
-    constexpr int KPAD = 16 * NSP;                                    // padded K of the gate rows (rows of the staging buffer)
-    constexpr int RED = 2 * 16 * 32 * CB;                             // partial sums [2 row sets][8 waves x 2 k halves][32 rows][CB]
+    constexpr int CG = RS / 2, KQ = 64 / RS, SL = 8 * KQ;             // channels per unit, k parts per wave, k slices per row
+    constexpr int KPAD = SL * NSP;                                    // padded K of the gate rows (length of a staged input vector)
+    constexpr int RED = 2 * SL * RS * CB;                             // partial sums [2 row sets][slice][row][CB]
     constexpr int REG0 = KPAD * CB;
     float* s_in = reinterpret_cast<float*>(smem_raw);                 // [CB][KPAD] inputs of the stage, k contiguous per utterance
     float* s_red = s_in + REG0;                                       // the partial sums (their own region: no barrier between a
@@ -195,10 +200,10 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
     int* s_flag = s_tok + 4 * BM;                                     // [0] a poll timed out
 
     const int tid = threadIdx.x, lane = tid & 63, wave = WN_UNIFORM(tid >> 6);
-    const int li = lane & 31, hi = lane >> 5;
+    const int lr = lane % RS, kq = lane / RS;   // this lane's row of a set and its k part of the wave's slice
     const int u = blockIdx.x;
     const int R = a.R, S = a.S, L = a.L, K = a.K, B = a.B, Qo = a.Qo;
-    const int c0 = u * WN_DLP_CG;
+    const int c0 = u * CG;
     const int SU = a.plan.SU, QU = a.plan.QU, KP = a.plan.KP;
     const int ncb = (B + CB - 1) / CB;
     float* pq = a.pq + (long)u * a.pq_unit_stride;
@@ -247,16 +252,16 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
             w[4 * t4] = v.x; w[4 * t4 + 1] = v.y; w[4 * t4 + 2] = v.z; w[4 * t4 + 3] = v.w;
         }
     };
-    // One row set: lane (row li, k half hi) of wave w holds the weights W[li][(2 w + hi) NS + t], t < NS -- NS consecutive k --
+    // One row set: lane (row lr, k part kq) of wave w holds the weights W[lr][(KQ w + kq) NS + t], t < NS -- NS consecutive k --
     // and accumulates its slice of the dot products of row li with the staged inputs of the block's utterances on the fp32
-    // VALU (one 16-byte LDS read = 4 consecutive k of one utterance; only the utterances that exist are computed); 16
+    // VALU (one 16-byte LDS read = 4 consecutive k of one utterance; only the utterances that exist are computed); 8 KQ
     // partial sums per row go to s_red.
     auto partial_dots = [&](const auto& w, auto ns_c, bool on, int nb, float (&acc)[CB]) {
         constexpr int ns = decltype(ns_c)::value;
         WN_UNROLL
         for (int q = 0; q < CB; ++q) acc[q] = 0.0f;
         if (!on) return;
-        const float* src = s_in + (wave * 2 + hi) * ns;
+        const float* src = s_in + (wave * KQ + kq) * ns;
         WN_UNROLL
         for (int q = 0; q < CB; ++q) {
             if (q < nb) {   // block-uniform
@@ -274,14 +279,14 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
     auto put_partials = [&](int set, const float (&acc)[CB]) {
         wn_f4 v;
         v.x = acc[0]; v.y = acc[1]; v.z = acc[2]; v.w = acc[3];
-        *reinterpret_cast<wn_f4*>(s_red + ((set * 16 + wave * 2 + hi) * 32 + li) * CB) = v;
+        *reinterpret_cast<wn_f4*>(s_red + ((set * SL + wave * KQ + kq) * RS + lr) * CB) = v;
     };
-    auto row_sum = [&](int set, int row, int uc) -> float {   // fixed-order sum of the 16 partial sums of a row
-        const float* q = s_red + (set * 16 * 32 + row) * CB + uc;
+    auto row_sum = [&](int set, int row, int uc) -> float {   // fixed-order sum of the SL partial sums of a row
+        const float* q = s_red + (set * SL * RS + row) * CB + uc;
         float sum = 0.0f;
         WN_UNROLL
-        for (int i = 0; i < 16; i += 4)
-            sum += (q[(i + 0) * 32 * CB] + q[(i + 1) * 32 * CB]) + (q[(i + 2) * 32 * CB] + q[(i + 3) * 32 * CB]);
+        for (int i = 0; i < SL; i += 4)
+            sum += (q[(i + 0) * RS * CB] + q[(i + 1) * RS * CB]) + (q[(i + 2) * RS * CB] + q[(i + 3) * RS * CB]);
         return sum;
     };
     static_assert(CB == 4, "one 16-byte LDS read per k");
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                 DLP_STAMP(s, 1);
                 // what this thread's epilogue reads from memory, requested ahead of the next stage's weight stream
                 float e0 = 0.0f, e1 = 0.0f;
-                if (tid < 16 * CB) {
+                if (tid < CG * CB) {
                     const int c = tid / CB, b = cb * CB + tid % CB;
                     if (hasP && b < B) {
                         const int t = p > a.n_pad ? p - a.n_pad : 0;   // replicated first column inside the left padding
@@ -375,13 +380,13 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                         e0 = wj * Gs[c0 + c] + a.cfold[(long)s * 2 * R + c0 + c];
                         e1 = wj * Gs[R + c0 + c] + a.cfold[(long)s * 2 * R + R + c0 + c];
                     }
-                } else if (tid < 32 * CB) {
-                    const int e = tid - 16 * CB, c = e / CB, b = cb * CB + e % CB;
+                } else if (tid < 2 * CG * CB) {
+                    const int e = tid - CG * CB, c = e / CB, b = cb * CB + e % CB;
                     if (b < B && s < L) e0 = s == 0 ? x0_of(c0 + c, b) : a.params[a.off_res_b0 + (long)(s - 1) * a.res_b_lstride + c0 + c];
                 }
                 __syncthreads();
                 DLP_STAMP(s, 2);
-                // (3) the two row sets: [16 sigmoid | 16 tanh] rows over all of K, [16 x | skip rows] over the z part
+                // (3) the two row sets: [CG sigmoid | CG tanh] rows over all of K, [CG x | skip rows] over the z part
                 float accP[CB], accX[CB];
                 partial_dots(wP, std::integral_constant<int, NSP>(), hasP, nbc, accP);
                 partial_dots(wX, std::integral_constant<int, NSX>(), hasX, nbc, accX);
@@ -395,15 +400,15 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                 __syncthreads();
                 DLP_STAMP(s, 4);
                 // (4) epilogues, one output element per thread
-                if (tid < 16 * CB) {
+                if (tid < CG * CB) {
                     const int c = tid / CB, uc = tid % CB, b = cb * CB + uc;
                     if (hasP && b < B) {   // gate (wavenet.py:542-544)
                         const float ps = row_sum(0, c, uc) + e0;
-                        const float pt = row_sum(0, 16 + c, uc) + e1;
+                        const float pt = row_sum(0, CG + c, uc) + e1;
                         wn_granule_store(a.gz + ((long)(s & 1) * R + c0 + c) * B + b, wn_sigmoid(ps) * wn_tanh(pt), tag0 + (unsigned)s);
                     }
-                } else if (tid < 32 * CB) {
-                    const int e = tid - 16 * CB, c = e / CB, uc = e % CB, b = cb * CB + uc;
+                } else if (tid < 2 * CG * CB) {
+                    const int e = tid - CG * CB, c = e / CB, uc = e % CB, b = cb * CB + uc;
                     if (b < B && s < L) {
                         float xs;
                         if (s == 0) {   // x_0 of the unit's own channels
@@ -416,9 +421,9 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                         if (K >= 2)   // the shared rings stay current for the next launch (and the launch path)
                             a.queues[(dlp_queue_off(s, a.depth, K, R) + (long)(p % Dq) * R + c0 + c) * B + b] = xs;
                     }
-                } else if (tid < 32 * CB + SU * CB) {   // the unit's rows of the skip sum (wavenet.py:545, 365)
-                    const int e = tid - 32 * CB, r = e / CB, uc = e % CB, b = cb * CB + uc;
-                    if (hasX && b < B) s_sk[r * BM + b] += row_sum(1, 16 + r, uc);
+                } else if (tid < 2 * CG * CB + SU * CB) {   // the unit's rows of the skip sum (wavenet.py:545, 365)
+                    const int e = tid - 2 * CG * CB, r = e / CB, uc = e % CB, b = cb * CB + uc;
+                    if (hasX && b < B) s_sk[r * BM + b] += row_sum(1, CG + r, uc);
                 }
                 DLP_STAMP(s, 5);
                 if (ncb > 1) __syncthreads();   // (several blocks per stage: the next block's gather re-uses s_in at once)
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                     s_in[uc * KPAD + k] = wait_granule(src + (long)k * B + cb * CB + uc, tag0 + (unsigned)(L + 1 + stage));
                 }
                 float pb = 0.0f;   // the row's bias, ahead of the next weight stream
-                if (tid < 32 * CB) {
+                if (tid < RS * CB) {
                     const int r = tid / CB, row = u * (stage == 0 ? SU : QU) + r;
                     if (stage == 0 ? (r < SU && row < S) : (r < QU && row < Qo)) pb = a.params[(stage == 0 ? a.off_post1_b : a.off_post2_b) + row];
                 }
@@ -455,7 +460,7 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                 }
                 put_partials(0, acc);
                 __syncthreads();
-                if (tid < 32 * CB) {
+                if (tid < RS * CB) {
                     const int r = tid / CB, uc = tid % CB, b = cb * CB + uc;
                     if (b < B) {
                         const float v = row_sum(0, r, uc);
@@ -519,18 +524,18 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
     if (tid == 0 && s_flag[0]) a.err[0] = 1;
 }
 
-template <int NSP, int NSX>
+template <int RS, int NSP, int NSX>
 static int launch_cls(const WnDlpArgs& a, wn_stream_t st) {
 #ifndef WN_EMU
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_dlp<NSP, NSX>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_dlp<RS, NSP, NSX>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)a.plan.lds_bytes) != hipSuccess)
             return 3;
         attr_set = true;
     }
 #endif
-    WN_LAUNCH_COOP((k_dlp<NSP, NSX>), dim3((unsigned)a.plan.NU), dim3(WN_DLP_T), (size_t)a.plan.lds_bytes, st, a);
+    WN_LAUNCH_COOP((k_dlp<RS, NSP, NSX>), dim3((unsigned)a.plan.NU), dim3(WN_DLP_T), (size_t)a.plan.lds_bytes, st, a);
     return 0;
 }
 
@@ -540,9 +545,12 @@ int wn_dlp_launch(const WnDlpArgs* ap, wn_stream_t st) {
     if (a.mode != 0 && a.mode != 1) return 2;
     WN_PROF("dlp_steps", 0.0, 0.0, st);
     switch (a.plan.cls) {
-        case 0: return launch_cls<24, 8>(a, st);
-        case 1: return launch_cls<96, 32>(a, st);
-        case 2: return launch_cls<128, 32>(a, st);
+        case 0: return launch_cls<8, 24, 8>(a, st);
+        case 1: return launch_cls<8, 32, 8>(a, st);
+        case 2: return launch_cls<16, 48, 16>(a, st);
+        case 3: return launch_cls<16, 64, 16>(a, st);
+        case 4: return launch_cls<32, 96, 32>(a, st);
+        case 5: return launch_cls<32, 128, 32>(a, st);
     }
     return 1;
 }
