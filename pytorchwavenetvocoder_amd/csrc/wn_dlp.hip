@@ -188,6 +188,8 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
     WN_DYN_SMEM(smem_raw);
     constexpr int CB = WN_DLP_CB, BM = WN_DLP_BMAX;
     constexpr int CG = RS / 2, KQ = 64 / RS, SL = 8 * KQ;             // channels per unit, k parts per wave, k slices per row
+    constexpr int NPASS = ((3 * CG + RS / 2) * CB * 8 + WN_DLP_T - 1) / WN_DLP_T;   // passes of 512 lanes over the row sums (8 lanes each)
+    constexpr int GB = RS >= 32 ? 4 : 8;                             // elements a thread requests per gather round
     constexpr int KPAD = SL * NSP;                                    // padded K of the gate rows (length of a staged input vector)
     constexpr int RED = 2 * SL * RS * CB;                             // partial sums [2 row sets][slice][row][CB]
     constexpr int REG0 = KPAD * CB;
@@ -281,14 +283,6 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
         v.x = acc[0]; v.y = acc[1]; v.z = acc[2]; v.w = acc[3];
         *reinterpret_cast<wn_f4*>(s_red + ((set * SL + wave * KQ + kq) * RS + lr) * CB) = v;
     };
-    auto row_sum = [&](int set, int row, int uc) -> float {   // fixed-order sum of the SL partial sums of a row
-        const float* q = s_red + (set * SL * RS + row) * CB + uc;
-        float sum = 0.0f;
-        WN_UNROLL
-        for (int i = 0; i < SL; i += 4)
-            sum += (q[(i + 0) * RS * CB] + q[(i + 1) * RS * CB]) + (q[(i + 2) * RS * CB] + q[(i + 3) * RS * CB]);
-        return sum;
-    };
     static_assert(CB == 4, "one 16-byte LDS read per k");
 
     // The weight registers of a stage are dead the moment its dot products are done, so the NEXT stage's weights are
@@ -313,15 +307,15 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
             const long qoff_s = hasP ? dlp_queue_off(s, a.depth, K, R) : 0;
             for (int cb = 0; cb < ncb; ++cb) {
                 // (2) gather [z_{s-1} | x_{s-1} | older taps of x_s] of the block's utterances into s_in[k][uc]: every thread
-                // requests up to four elements before it looks at the first tag (one round trip for most of the gather)
+                // requests up to GB elements before it looks at the first tag (one round trip for most of the gather)
                 const int krows = hasP ? KP : 2 * R;       // stage L: z for the skip rows, x only for the queue push
                 const int nbc = (B - cb * CB) < CB ? (B - cb * CB) : CB;   // utterances of this block
-                for (int base = tid; base < krows * nbc; base += 4 * WN_DLP_T) {
-                    const u64* gp[4];
-                    u64 gv[4];
-                    float fv[4];
+                for (int base = tid; base < krows * nbc; base += GB * WN_DLP_T) {
+                    const u64* gp[GB];
+                    u64 gv[GB];
+                    float fv[GB];
                     WN_UNROLL
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < GB; ++j) {
                         const int idx = base + j * WN_DLP_T;
                         gp[j] = nullptr;
                         fv[j] = 0.0f;
@@ -343,7 +337,7 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                         }
                     }
                     WN_UNROLL
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < GB; ++j) {
                         const int idx = base + j * WN_DLP_T;
                         if (idx < krows * nbc) {
                             const int k = idx / nbc, uc = idx % nbc, b = cb * CB + uc;
@@ -367,22 +361,34 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                     }
                 }
                 DLP_STAMP(s, 1);
-                // what this thread's epilogue reads from memory, requested ahead of the next stage's weight stream
-                float e0 = 0.0f, e1 = 0.0f;
-                if (tid < CG * CB) {
-                    const int c = tid / CB, b = cb * CB + tid % CB;
-                    if (hasP && b < B) {
-                        const int t = p > a.n_pad ? p - a.n_pad : 0;   // replicated first column inside the left padding
-                        int f = t / a.Ue;
-                        const float wj = a.upw[t - f * a.Ue];
-                        if (f > a.F - 1) f = a.F - 1;
-                        const float* Gs = a.G + ((long)b * a.F + f) * a.nG + (long)s * 2 * R;
-                        e0 = wj * Gs[c0 + c] + a.cfold[(long)s * 2 * R + c0 + c];
-                        e1 = wj * Gs[R + c0 + c] + a.cfold[(long)s * 2 * R + R + c0 + c];
+                // The stage's outputs: (3 CG + SU) x CB row sums of SL partial sums each.  Eight adjacent lanes share a row sum
+                // (lane g adds the partial sums of slices [g SL/8, (g+1) SL/8), then three butterfly steps: a fixed order),
+                // and lane g = 0 of the group runs the output's epilogue -- so what that lane reads from memory (aux
+                // projection, constants, biases) is requested HERE, ahead of the next stage's weight stream.
+                float e0[NPASS], e1[NPASS];
+                WN_UNROLL
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    const int w8 = tid + WN_DLP_T * ps, rs = w8 >> 3;
+                    e0[ps] = 0.0f;
+                    e1[ps] = 0.0f;
+                    if ((w8 & 7) == 0) {
+                        if (rs < 2 * CG * CB) {
+                            const int zi = rs >> 1, c = zi / CB, b = cb * CB + zi % CB;
+                            if (hasP && (rs & 1) == 0 && b < B) {
+                                const int t = p > a.n_pad ? p - a.n_pad : 0;   // replicated first column inside the left padding
+                                int f = t / a.Ue;
+                                const float wj = a.upw[t - f * a.Ue];
+                                if (f > a.F - 1) f = a.F - 1;
+                                const float* Gs = a.G + ((long)b * a.F + f) * a.nG + (long)s * 2 * R;
+                                e0[ps] = wj * Gs[c0 + c] + a.cfold[(long)s * 2 * R + c0 + c];
+                                e1[ps] = wj * Gs[R + c0 + c] + a.cfold[(long)s * 2 * R + R + c0 + c];
+                            }
+                        } else if (rs < 3 * CG * CB) {
+                            const int e = rs - 2 * CG * CB, c = e / CB, b = cb * CB + e % CB;
+                            if (b < B && s < L)
+                                e0[ps] = s == 0 ? x0_of(c0 + c, b) : a.params[a.off_res_b0 + (long)(s - 1) * a.res_b_lstride + c0 + c];
+                        }
                     }
-                } else if (tid < 2 * CG * CB) {
-                    const int e = tid - CG * CB, c = e / CB, b = cb * CB + e % CB;
-                    if (b < B && s < L) e0 = s == 0 ? x0_of(c0 + c, b) : a.params[a.off_res_b0 + (long)(s - 1) * a.res_b_lstride + c0 + c];
                 }
                 __syncthreads();
                 DLP_STAMP(s, 2);
@@ -399,31 +405,53 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                 put_partials(1, accX);
                 __syncthreads();
                 DLP_STAMP(s, 4);
-                // (4) epilogues, one output element per thread
-                if (tid < CG * CB) {
-                    const int c = tid / CB, uc = tid % CB, b = cb * CB + uc;
-                    if (hasP && b < B) {   // gate (wavenet.py:542-544)
-                        const float ps = row_sum(0, c, uc) + e0;
-                        const float pt = row_sum(0, CG + c, uc) + e1;
-                        wn_granule_store(a.gz + ((long)(s & 1) * R + c0 + c) * B + b, wn_sigmoid(ps) * wn_tanh(pt), tag0 + (unsigned)s);
+                // (4) row sums and epilogues
+                WN_UNROLL
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    const int w8 = tid + WN_DLP_T * ps, rs = w8 >> 3, g = w8 & 7;
+                    int set = 1, row = 0, uc = 0, kind = 3;   // kind 0: gate row, 1: x row, 2: skip row, 3: none
+                    if (rs < 2 * CG * CB) {
+                        const int zi = rs >> 1;
+                        kind = 0; set = 0; row = (rs & 1) * CG + zi / CB; uc = zi % CB;
+                    } else if (rs < 3 * CG * CB) {
+                        const int e = rs - 2 * CG * CB;
+                        kind = 1; row = e / CB; uc = e % CB;
+                    } else if (rs < (3 * CG + SU) * CB) {
+                        const int e = rs - 3 * CG * CB;
+                        kind = 2; row = CG + e / CB; uc = e % CB;
                     }
-                } else if (tid < 2 * CG * CB) {
-                    const int e = tid - CG * CB, c = e / CB, uc = e % CB, b = cb * CB + uc;
-                    if (b < B && s < L) {
-                        float xs;
-                        if (s == 0) {   // x_0 of the unit's own channels
-                            xs = e0;
-                        } else {        // x_s = res_1x1(z_{s-1}) + x_{s-1}   (wavenet.py:546-548)
-                            xs = row_sum(1, c, uc) + e0 + s_xown[c * BM + b];
-                            wn_granule_store(a.gx + ((long)(s & 1) * R + c0 + c) * B + b, xs, tag0 + (unsigned)s);
+                    float sum = 0.0f;
+                    if (kind != 3) {
+                        const float* q = s_red + ((set * SL + g * (SL / 8)) * RS + row) * CB + uc;
+                        WN_UNROLL
+                        for (int i = 0; i < SL / 8; ++i) sum += q[i * RS * CB];
+                    }
+                    sum += __shfl_xor(sum, 1, 64);
+                    sum += __shfl_xor(sum, 2, 64);
+                    sum += __shfl_xor(sum, 4, 64);
+                    const float other = __shfl_down(sum, 8, 64);   // a gate output's sigmoid lane takes the tanh row's sum
+                    const int b = cb * CB + uc;
+                    if (g == 0 && b < B) {
+                        if (kind == 0 && (rs & 1) == 0 && hasP) {   // gate (wavenet.py:542-544)
+                            const int c = row;
+                            wn_granule_store(a.gz + ((long)(s & 1) * R + c0 + c) * B + b, wn_sigmoid(sum + e0[ps]) * wn_tanh(other + e1[ps]),
+                                             tag0 + (unsigned)s);
+                        } else if (kind == 1 && s < L) {
+                            const int c = row;
+                            float xs;
+                            if (s == 0) {   // x_0 of the unit's own channels
+                                xs = e0[ps];
+                            } else {        // x_s = res_1x1(z_{s-1}) + x_{s-1}   (wavenet.py:546-548)
+                                xs = sum + e0[ps] + s_xown[c * BM + b];
+                                wn_granule_store(a.gx + ((long)(s & 1) * R + c0 + c) * B + b, xs, tag0 + (unsigned)s);
+                            }
+                            s_xown[c * BM + b] = xs;
+                            if (K >= 2)   // the shared rings stay current for the next launch (and the launch path)
+                                a.queues[(dlp_queue_off(s, a.depth, K, R) + (long)(p % Dq) * R + c0 + c) * B + b] = xs;
+                        } else if (kind == 2 && hasX) {   // the unit's rows of the skip sum (wavenet.py:545, 365)
+                            s_sk[(row - CG) * BM + b] += sum;
                         }
-                        s_xown[c * BM + b] = xs;
-                        if (K >= 2)   // the shared rings stay current for the next launch (and the launch path)
-                            a.queues[(dlp_queue_off(s, a.depth, K, R) + (long)(p % Dq) * R + c0 + c) * B + b] = xs;
                     }
-                } else if (tid < 2 * CG * CB + SU * CB) {   // the unit's rows of the skip sum (wavenet.py:545, 365)
-                    const int e = tid - 2 * CG * CB, r = e / CB, uc = e % CB, b = cb * CB + uc;
-                    if (hasX && b < B) s_sk[r * BM + b] += row_sum(1, CG + r, uc);
                 }
                 DLP_STAMP(s, 5);
                 if (ncb > 1) __syncthreads();   // (several blocks per stage: the next block's gather re-uses s_in at once)
@@ -446,10 +474,14 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                     const int k = idx / nbc, uc = idx % nbc;
                     s_in[uc * KPAD + k] = wait_granule(src + (long)k * B + cb * CB + uc, tag0 + (unsigned)(L + 1 + stage));
                 }
-                float pb = 0.0f;   // the row's bias, ahead of the next weight stream
-                if (tid < RS * CB) {
-                    const int r = tid / CB, row = u * (stage == 0 ? SU : QU) + r;
-                    if (stage == 0 ? (r < SU && row < S) : (r < QU && row < Qo)) pb = a.params[(stage == 0 ? a.off_post1_b : a.off_post2_b) + row];
+                constexpr int PPASS = (RS * CB * 8 + WN_DLP_T - 1) / WN_DLP_T;
+                float pb[PPASS];   // the row's bias, ahead of the next weight stream
+                WN_UNROLL
+                for (int ps = 0; ps < PPASS; ++ps) {
+                    const int w8 = tid + WN_DLP_T * ps, r = (w8 >> 3) / CB, row = u * (stage == 0 ? SU : QU) + r;
+                    pb[ps] = 0.0f;
+                    if ((w8 & 7) == 0 && (stage == 0 ? (r < SU && row < S) : (r < QU && row < Qo)))
+                        pb[ps] = a.params[(stage == 0 ? a.off_post1_b : a.off_post2_b) + row];
                 }
                 __syncthreads();
                 float acc[CB];
@@ -460,16 +492,26 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                 }
                 put_partials(0, acc);
                 __syncthreads();
-                if (tid < RS * CB) {
-                    const int r = tid / CB, uc = tid % CB, b = cb * CB + uc;
-                    if (b < B) {
-                        const float v = row_sum(0, r, uc);
+                WN_UNROLL
+                for (int ps = 0; ps < PPASS; ++ps) {   // 8 lanes per row sum, as in the layer stages
+                    const int w8 = tid + WN_DLP_T * ps, rs = w8 >> 3, g = w8 & 7;
+                    const int r = rs / CB, uc = rs % CB, b = cb * CB + uc;
+                    float sum = 0.0f;
+                    if (r < RS) {
+                        const float* q = s_red + ((g * (SL / 8)) * RS + r) * CB + uc;
+                        WN_UNROLL
+                        for (int i = 0; i < SL / 8; ++i) sum += q[i * RS * CB];
+                    }
+                    sum += __shfl_xor(sum, 1, 64);
+                    sum += __shfl_xor(sum, 2, 64);
+                    sum += __shfl_xor(sum, 4, 64);
+                    if (g == 0 && r < RS && b < B) {
                         if (stage == 0) {
                             const int row = u * SU + r;
-                            if (r < SU && row < S) wn_granule_store(a.go + (long)row * B + b, fmaxf(v + pb, 0.0f), tag0 + (unsigned)(L + 2));
+                            if (r < SU && row < S) wn_granule_store(a.go + (long)row * B + b, fmaxf(sum + pb[ps], 0.0f), tag0 + (unsigned)(L + 2));
                         } else {
                             const int row = u * QU + r;
-                            if (r < QU && row < Qo) wn_granule_store(a.gl + (long)row * B + b, v + pb, tag0 + (unsigned)(L + 3));
+                            if (r < QU && row < Qo) wn_granule_store(a.gl + (long)row * B + b, sum + pb[ps], tag0 + (unsigned)(L + 3));
                         }
                     }
                 }
