@@ -162,6 +162,24 @@ def decode_report(model, device, with_cpu):
     out["stream_bytes_per_step"] = stream_bytes
     out["stream_GBps_per_workgroup"] = stream_bytes / (out["batch1"]["us_per_step"] * 1e-6) / 1e9
     out["stream_note"] = "one CU sustains ~112 GB/s on a 5 MB cyclic read (tools/stream_probe.hip, profiles/r01/stream_probe.txt)"
+    # the recipes' own model size (n_resch 512 / n_skipch 256, egs/arctic/sd/run.sh:46-52; decode.py:274-327): the any-size path --
+    # ONE persistent launch of 128 workgroups per chunk of steps up to 8 utterances (csrc/wn_dlp.hip), layer-wise launches above
+    try:
+        from pytorchwavenetvocoder_amd.nets import WaveNet, initialize
+        torch.manual_seed(1)
+        big = WaveNet(256, 80, 512, 256, 10, 3, 2, 80)
+        big.apply(initialize)
+        big.to(device)
+        rs = {"model": "512/256, A=80, K=2, U=80, 30 layers (the recipes' default size)"}
+        for B, n, lay in ((1, 400, True), (4, 400, True), (64, 200, "launches")):
+            m = decode_bench.measure(big, B, n, device, layered=lay)
+            rs["batch%d" % B] = {k: m[k] for k in ("us_per_step", "samples_per_sec_per_utt", "samples_per_sec", "context_s")}
+            rs["batch%d" % B]["path"] = "one persistent launch (wn_dlp)" if lay is True else "layer-wise launches"
+        out["recipe_size"] = rs
+        del big
+        torch.cuda.empty_cache()
+    except Exception as e:  # noqa: BLE001 -- never takes the headline line down
+        out["recipe_size"] = {"error": repr(e)}
     if with_cpu:
         # CPU leg: the reference's OWN fast_generate (wavenet.py:309-395, build-time copy in oracle/_ref -> kind "reference"),
         # else the restatement (kind "port"); a few samples after the context, 8 threads (the per-sample work is ~500 tiny ops)

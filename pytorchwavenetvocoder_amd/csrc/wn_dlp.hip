@@ -2,25 +2,29 @@
 // :538-549 _generate_residual_forward, :518-523 _postprocess) for models the one-workgroup kernel cannot hold, as ONE
 // launch per chunk of steps.  See wn_dlp.h.
 //
-// Decomposition.  Unit u (one workgroup, 512 threads) owns the residual channels [16u, 16u + 16).  Folding the res 1x1 of
-// layer s-1 into the newest tap of layer s,
+// Decomposition.  Unit u (one workgroup of 512 threads on its own CU) owns CG residual channels -- CG = 4 for n_resch up to
+// 960 (n_resch 512: 128 units), 8 / 16 beyond: the weight stream of a stage is what ONE CU can pull (~60 GB/s measured), so
+// the fewer channels a unit owns, the shorter the stage.  Folding the res 1x1 of layer s-1 into the newest tap of layer s,
 //      M_s = Wd_new(s) . Wres(s-1),      c_s = cvec_s + Wd_new(s) . b_res(s-1),
 // makes layer s ONE dependent stage: from (z_{s-1}, x_{s-1}) -- both complete vectors of the previous stage -- a unit computes
 //      gate rows:  P = M_s z_{s-1} + Wd_new(s) x_{s-1} + sum_older-taps Wd_tap(s) x_s[t - ..] + aux + c_s,   z_s = sigmoid(P_a) tanh(P_b)
 //      x rows:     x_s = Wres(s-1) z_{s-1} + b_res(s-1) + x_{s-1}
 //      skip rows:  skip += Wskip(s-1) z_{s-1}                      (its share of the n_skipch rows)
-// for its 16 channels as two sets of 32 rows: a lane owns one row and one k parity of a wave's slice of K (the weights sit in
-// its registers in that layout) and multiplies them with the staged input columns on the fp32 VALU -- at up to 8 utterances
-// per launch only the columns that exist are computed, where an f32 MFMA tile would spend 64 cycles per 2 k on 32 columns
-// (measured: 546 us per step with MFMA tiles at B = 1, profiles/r04) --, the 16 partial sums per row are added through LDS in a
-// fixed order.  The stage's weights (256 KB per unit at n_resch 512) are requested into
-// registers FIRST, then the inputs are gathered: the previous stage's vectors arrive as 8-byte granules {value, tag} that the
-// consumer polls (tag = step and stage, so a granule is its own ready flag), the older taps come from the unit's PRIVATE copy
-// of the dilation queues (every unit sees every x_s anyway and pushes it into its own rings: no cross-workgroup traffic on
-// plain memory at all).  The weight stream and the hand-off latency overlap; nothing but granules crosses workgroups.
+// as two sets of RS = 2 CG rows.  A lane owns one row and one slice of consecutive k of a set (the weights sit in its registers,
+// 16-byte non-temporal loads) and multiplies them with the staged input vectors on the fp32 VALU -- only the utterances
+// that exist are computed: an f32 MFMA tile spends 64 cycles per 2 k on 32 columns, which measured 546 us per step at B = 1
+// (profiles/r04/NOTES.md) --, the partial sums of a row are added through LDS by 8 lanes in a fixed butterfly order.
+// The previous stage's vectors arrive as 8-byte granules {value, tag} that the consumer polls (tag = step and stage, so a
+// granule is its own ready flag; measured 0.7 - 0.8 us per hop with 0 stale words, same or other XCD); the older taps come
+// from the unit's PRIVATE copy of the dilation queues (every unit sees every x_s anyway and pushes it into its own rings), so
+// nothing but granules crosses workgroups: no grid barrier, no fence.  The next stage's weights are requested right after a
+// stage's dot products (their registers are dead): they stream under the epilogue, the hand-off and the next gather;
+// everything the epilogue reads from memory is requested before them (memory returns in order).
 // After the last layer: skip sum -> conv_post_1 -> conv_post_2 as three more stages, then EVERY unit picks the token itself
 // from the gathered logits (argmax / inverse-CDF on the caller's uniforms: deterministic), so the next step starts without
 // another hop.  Every poll is bounded; a timeout sets `err` and drains the launch.
+// Measured, n_resch 512 / n_skipch 256 (profiles/r04/recipe_decode_probe.txt, dlp_timing_b1.txt): 190 us per step for one
+// utterance (the 66 layer-wise launches: 620), 342 for four; a stage is 5.4 us, 3 of them the hand-off + poll.
 #include "wn_dlp.h"
 
 #include <type_traits>

@@ -17,21 +17,21 @@ sys.path.insert(0, ROOT)
 from pytorchwavenetvocoder_amd.nets import WaveNet, initialize  # noqa: E402
 
 
-def measure(model, B, n, device):
+def measure(model, B, n, device, layered=None):
     """Returns (generated samples/s per utterance stream, total, seconds) with the context walk
     (receptive-field prefill, wavenet.py:338-349) timed separately."""
     eng = model.engine
     x = torch.full((B, 1), 128, dtype=torch.int64, device=device)
     nf = (n + 1 + 79) // 80
     h = torch.randn(B, 80, nf, device=device)
-    eng.decode(x, h, [8] * B)  # warm-up (packs weights, loads the kernel)
+    eng.decode(x, h, [8] * B, layered=layered)  # warm-up (packs weights, loads the kernel)
     torch.cuda.synchronize(device)
     t0 = time.time()
-    eng.decode(x, h, [1] * B)   # context only: rf steps
+    eng.decode(x, h, [1] * B, layered=layered)   # context only: rf steps
     torch.cuda.synchronize(device)
     t_ctx = time.time() - t0
     t0 = time.time()
-    eng.decode(x, h, [n] * B)
+    eng.decode(x, h, [n] * B, layered=layered)
     torch.cuda.synchronize(device)
     t_all = time.time() - t0
     gen = max(t_all - t_ctx, 1e-9)
