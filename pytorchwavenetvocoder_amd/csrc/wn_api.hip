@@ -385,6 +385,8 @@ struct Ws {
     long red_scratch_floats;
     long apk_floats;
     long apk_pre[6];   // the six weight sets of a training step, split ONCE per step (pack_weights): offsets, -1 = none
+    long apk_wide[5];  // wide models (n_resch % 128 == 0, any-size path): the five per-layer weight sets of a step, all layers, split
+    long apk_wide_l[5];   // once per step as well (round 3: 149 little pack launches per step); offset of layer 0 / floats per layer
     long front_partial, front_partial_floats;
     long total;
     int F;  // frames (T/U, or T without upsampling)
@@ -392,7 +394,7 @@ struct Ws {
 
 static inline long al64(long n) { return (n + 63) / 64 * 64; }
 
-static int make_ws(const Dims& d, int B, int T, Ws* w) {
+static int make_ws(const Dims& d, int B, int T, Ws* w, bool training = true) {
     if (B < 1 || T < 1) return fail(1, "B and T must be positive");
     const int Ue = d.U > 0 ? d.U : 1;
     if (T % Ue != 0) return fail(1, "T=%d is not a multiple of upsampling_factor=%d", T, d.U);
@@ -491,6 +493,17 @@ static int make_ws(const Dims& d, int B, int T, Ws* w) {
             o += al64((wn_gemm6_apk_elems(pre[i][0], pre[i][1]) + 1) / 2);
         }
     }
+        {   // (same order as wide_jobs())
+            const bool wide = training && d.R % 128 == 0 && !wn_fused_supported(d.R, d.K, d.S);
+            const int mk[5][2] = {{2 * d.R, d.K * d.R}, {d.R, d.R}, {d.R, d.S}, {d.R, d.R}, {d.R, d.K * 2 * d.R}};
+            for (int i = 0; i < 5; ++i) {
+                w->apk_wide[i] = -1;
+                w->apk_wide_l[i] = al64((wn_gemm6_apk_elems(mk[i][0], mk[i][1]) + 1) / 2);
+                if (!wide) continue;
+                w->apk_wide[i] = o;
+                o += w->apk_wide_l[i] * d.L;
+            }
+        }
 #undef CARVE
     w->total = o;
     return 0;
@@ -603,11 +616,41 @@ static int pre_jobs(const Ctx& c, const float* params, PreJob (&j)[6]) {
         if (all[i].A && all[i].off >= 0) j[n++] = all[i];
     return n;
 }
-static long prepacked_offset(const Ctx& c, const WnGemmArgs& g) {
-    PreJob j[6];
-    const int n = pre_jobs(c, c.params, j);
-    for (int i = 0; i < n; ++i)
-        if (j[i].A == g.A && j[i].lda == g.lda && j[i].M == g.M && j[i].K == g.K) return j[i].off;
+// The per-layer weight sets of a wide model's step (any-size path with the split contractions, n_resch % 128 == 0): layer l of
+// set i lives at A + l * lstride (floats) and its split form at apk_wide[i] + l * apk_wide_l[i].  Set 0 is packed with the
+// gate row permutation (gate_R = R: the forward gate epilogue), the others plainly.
+struct WideJob { const float* A; long lstride, lda; int M, K, gate_R, nl; long off, off_l; };
+static int wide_jobs(const Ctx& c, const float* params, WideJob (&j)[5]) {
+    const Dims& d = c.d;
+    const Lay& y = c.y;
+    const Ws& w = c.w;
+    if (!c.have_pre || !c.split_bf16 || c.fused || w.apk_wide[0] < 0 || !params) return 0;
+    const long lb0 = layer_base(y, d, 0);
+    const WideJob all[5] = {
+        {c.ws + w.wd_f, (long)d.K * d.R * 2 * d.R, 2 * d.R, 2 * d.R, d.K * d.R, d.R, d.L, w.apk_wide[0], w.apk_wide_l[0]},   // fwd_dilated_gate
+        {c.ws + w.wres_f, (long)d.R * d.R, d.R, d.R, d.R, 0, d.L, w.apk_wide[1], w.apk_wide_l[1]},                          // fwd_res
+        {params + y.skip0, y.ls_skip, d.R, d.R, d.S, 0, d.L, w.apk_wide[2], w.apk_wide_l[2]},                               // bwd_dz_skip
+        {params + lb0 + y.o_res_w, -y.LB, d.R, d.R, d.R, 0, d.L, w.apk_wide[3], w.apk_wide_l[3]},                           // bwd_dz_res
+        {c.ws + w.wd_b, (long)d.K * 2 * d.R * d.R, d.R, d.R, d.K * 2 * d.R, 0, d.L, w.apk_wide[4], w.apk_wide_l[4]}};      // bwd_dx_dilated
+    for (int i = 0; i < 5; ++i) j[i] = all[i];
+    return 5;
+}
+static long prepacked_offset(const Ctx& c, const WnGemmArgs& g, int gate_R = 0) {
+    if (gate_R == 0) {
+        PreJob j[6];
+        const int n = pre_jobs(c, c.params, j);
+        for (int i = 0; i < n; ++i)
+            if (j[i].A == g.A && j[i].lda == g.lda && j[i].M == g.M && j[i].K == g.K) return j[i].off;
+    }
+    WideJob wj[5];
+    const int nw = wide_jobs(c, c.params, wj);
+    for (int i = 0; i < nw; ++i) {
+        if (wj[i].lda != g.lda || wj[i].M != g.M || wj[i].K != g.K || wj[i].gate_R != gate_R || wj[i].lstride == 0) continue;
+        const long diff = g.A - wj[i].A;
+        if (diff % wj[i].lstride != 0) continue;
+        const long l = diff / wj[i].lstride;
+        if (l >= 0 && l < wj[i].nl) return wj[i].off + l * wj[i].off_l;
+    }
     return -1;
 }
 
@@ -633,7 +676,7 @@ static int fw_gemm(const Ctx& c, const WnGemmArgs& g, const GateEpi* ge = nullpt
                     wn_gemm6_apk_elems(g.M, g.K) <= 2 * c.w.apk_floats && (long)g.M * g.ldc * 4 < 0x7ffffff0L;
     if (!ok) return (ge || ce) ? fail(3, "gate / loss epilogue needs the split contraction") : wn_gemm_launch(&g, c.st);
     unsigned short* apk = reinterpret_cast<unsigned short*>(c.ws + c.w.apk);
-    const long pre = ge ? -1 : prepacked_offset(c, g);
+    const long pre = prepacked_offset(c, g, ge ? ge->gate_R : 0);   // (gate' epilogues use the plain packing: gate_R = 0)
     if (pre >= 0)
         apk = reinterpret_cast<unsigned short*>(c.ws + pre);   // split once per step by pack_weights
     else
@@ -735,12 +778,22 @@ static int pack_weights(const Ctx& c, const float* params) {
     {   // the split form of the weight sets every step contracts with: one launch (after the re-layouts above)
         PreJob pj[6];
         const int n = pre_jobs(c, params, pj);
-        if (n > 0) {
+        WideJob wj[5];
+        const int nw = wide_jobs(c, c.params, wj);   // (only the training entry points declare their params: the look-up side needs them)
+        if (n + nw > 0) {
             WnGemm6PackJobs jobs;
-            jobs.njobs = n;
+            jobs.njobs = n + nw;
             for (int i = 0; i < n; ++i) {
                 jobs.src[i] = pj[i].A; jobs.lda[i] = pj[i].lda; jobs.M[i] = pj[i].M; jobs.K[i] = pj[i].K;
                 jobs.dst[i] = reinterpret_cast<unsigned short*>(ws + pj[i].off);
+                wn_gemm6_pack_job_single(&jobs, i);
+            }
+            for (int i = 0; i < nw; ++i) {   // every layer of a wide model's five per-layer sets: one launch instead of 5 L - 1
+                const int q = n + i;
+                jobs.src[q] = wj[i].A; jobs.lda[q] = wj[i].lda; jobs.M[q] = wj[i].M; jobs.K[q] = wj[i].K;
+                jobs.dst[q] = reinterpret_cast<unsigned short*>(ws + wj[i].off);
+                jobs.nl[q] = wj[i].nl; jobs.src_lstride[q] = wj[i].lstride; jobs.dst_lstride[q] = 2 * wj[i].off_l;
+                jobs.gate_R[q] = wj[i].gate_R;
             }
             WN_TRY(wn_gemm6_pack_batch(&jobs, c.st));
         }
@@ -1621,6 +1674,9 @@ struct DlLay {
     Ws w;  // packed-weight region of a (B=1, T=Ue) training workspace
     long queues, xin, P, Sg, Gt, Zcat, gstep, skpart, O1, O2, logits, total;
     long qfloats_per_utt;
+    // folded layer-wise launches (n_resch % 16 == 0): ONE launch per layer -- stage matrices [fold^T | taps] (K+1)R x 2R per
+    // layer, the constant part of the gate incl. the folded res bias, per-stage operand windows [z | older taps | x]
+    long fs_A, fs_cf, fs_in;
     // persistent path (wn_dlp.hip), when the plan covers the model and nb <= WN_DLP_BMAX
     WnDlpPlan dlp;
     long dlp_w, dlp_post, dlp_cfold, dlp_fold, dlp_gz, dlp_gx, dlp_gs, dlp_go, dlp_gl, dlp_pq, dlp_err;
@@ -1628,7 +1684,7 @@ struct DlLay {
 
 static int dl_layout(const WnConfig* cfg, const Dims& d, int nb, DlLay* y) {
     const int Ue = d.U > 0 ? d.U : 1;
-    WN_TRY(make_ws(d, 1, Ue, &y->w));
+    WN_TRY(make_ws(d, 1, Ue, &y->w, /*training*/ false));
     long sumd = 0;
     for (int l = 0; l < d.L; ++l) sumd += dilation_of(cfg, l);
     y->qfloats_per_utt = (long)(d.K - 1) * sumd * d.R;
@@ -1647,6 +1703,12 @@ static int dl_layout(const WnConfig* cfg, const Dims& d, int nb, DlLay* y) {
     DCARVE(O1, (long)d.S * nb);
     DCARVE(O2, (long)d.S * nb);
     DCARVE(logits, (long)d.Qo * nb);
+    y->fs_A = y->fs_cf = y->fs_in = -1;
+    if (d.R % 16 == 0 && d.K >= 2) {
+        DCARVE(fs_A, (long)d.L * (d.K + 1) * d.R * 2 * d.R);
+        DCARVE(fs_cf, (long)d.L * 2 * d.R);
+        DCARVE(fs_in, (long)(d.L + 1) * (d.K + 1) * d.R * nb);
+    }
     wn_dlp_make_plan(d.Q, d.Qo, d.R, d.S, d.L, d.K, &y->dlp);
     if (nb > WN_DLP_BMAX) y->dlp.ok = 0;
     if (y->dlp.ok) {
@@ -1719,6 +1781,28 @@ extern "C" int wn_decode_layered_prepare(const WnConfig* cfg, int B, int F, cons
     Ctx c;
     dl_ctx(&c, cfg, d, y, B, state, stream);
     if (params) WN_TRY(pack_weights(c, params));
+    if (params && y.fs_A >= 0) {
+        // folded launches: As[s] = [ (Wd_new(s) Wres(s-1))^T | wd_f[s] ]  ((K+1)R x 2R, k-major like every packed weight), s >= 1;
+        // As[0] keeps zero rows for the z part (the state arrives zero-filled)
+        const Lay& lay = c.y;
+        const long sA = (long)(d.K + 1) * d.R * 2 * d.R, sW = (long)d.K * d.R * 2 * d.R;
+        WnCopy4 cp;
+        cp.n0 = 1; cp.n1 = 1; cp.n2 = (int)sW; cp.nl = d.L;
+        cp.s0 = 0; cp.s1 = 0; cp.s2 = 1; cp.sl = sW;
+        cp.d0 = 0; cp.d1 = 0; cp.d2 = 1; cp.dl = sA;
+        WN_TRY(wn_copy4(state + y.fs_A + (long)d.R * 2 * d.R, state + y.w.wd_f, &cp, c.st));
+        for (int s = 1; s < d.L; ++s) {
+            WnGemmArgs f = wn_gemm_default();   // C[i][o'] = sum_j Wres(s-1)[j][i] Wd_new(s)[o'][j]
+            f.M = d.R; f.N = 2 * d.R; f.K = d.R;
+            f.A = params + layer_base(lay, d, s - 1) + lay.o_res_w; f.lda = d.R;
+            f.B = state + y.w.wd_f + (long)s * sW + (long)(d.K - 1) * d.R * 2 * d.R; f.ldb = 2 * d.R; f.b_clen = 2 * d.R;
+            f.C = state + y.fs_A + (long)s * sA; f.ldc = 2 * d.R;
+            f.nbatch = 1; f.tag = "dl_fold";
+            WN_TRY(wn_gemm_launch(&f, c.st));
+        }
+        WN_TRY(wn_dlp_cfold(params, state + y.w.cvec, state + y.w.wd_f, layer_base(lay, d, 0), -lay.LB, lay.o_res_b, d.L, d.R, d.K,
+                            state + y.fs_cf, c.st));
+    }
     if (params && y.dlp.ok) {   // persistent path: per-stage weight images with the res 1x1 folded into the next layer's newest tap
         const Lay& lay = c.y;
         const long lb0 = layer_base(lay, d, 0), lstep = -lay.LB;
@@ -1814,15 +1898,44 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
     a.queues = ws + y.queues; a.xin = ws + y.xin; a.gstep = ws + y.gstep;
     const long RB = (long)d.R * nb;
     const bool gate_fused = d.R % 16 == 0;
+    const bool folded = y.fs_A >= 0;
+    a.xin_lstride = (long)d.K * RB; a.hist_off = 0; a.x_off = (long)(d.K - 1) * RB; a.folded = 0;
+    if (folded) {   // [z | older taps | x] windows, one per stage (+ one behind the last stage for its outputs)
+        a.xin = ws + y.fs_in; a.xin_lstride = (long)(d.K + 1) * RB; a.hist_off = RB; a.x_off = (long)d.K * RB; a.folded = 1;
+    }
     for (int p = p0; p < p1; ++p) {
         a.p = p;
         WN_TRY(wn_dl_inputs(&a, c.st));
-        for (int l = 0; l < d.L; ++l) {
+        for (int l = 0; folded && l < d.L; ++l) {
+            // ONE launch per layer (round 4): gate rows from [z_{l-1} | taps of x_l | x_{l-1}] with the res 1x1 of layer l-1
+            // folded into the newest tap, and x_l = res_1x1(z_{l-1}) + x_{l-1} as the launch's second contraction
+            // (wavenet.py:540-548); both outputs land in the window of stage l + 1
+            float* win = ws + y.fs_in + (long)l * a.xin_lstride;
+            float* nxt = win + a.xin_lstride;
+            WnDlMmArgs g;
+            wn_dl_mm_no_stage(&g);
+            g.M = 2 * d.R; g.K = (d.K + 1) * d.R; g.nb = nb;
+            g.A = ws + y.fs_A + (long)l * (d.K + 1) * d.R * 2 * d.R; g.lda = 2 * d.R; g.a_zstride = 0;
+            g.B = win; g.ldb = nb; g.b_zstride = 0;
+            g.C = nxt; g.ldc = nb; g.c_zstride = 0;
+            g.bias = nullptr; g.D = nullptr; g.ldd = 0; g.relu = 0; g.nz = 1; g.tag = "dl_stage";
+            g.gate_R = d.R; g.gate_g = ws + y.gstep + (long)l * 2 * RB; g.gate_c = ws + y.fs_cf + (long)l * 2 * d.R;
+            if (l >= 1) {
+                g.x_tiles = (d.R + 31) / 32;
+                g.A2 = ws + w.wres_f + (long)(l - 1) * d.R * d.R; g.lda2 = d.R; g.M2 = d.R; g.K2 = d.R;
+                g.bias2 = params + layer_base(lay, d, l - 1) + lay.o_res_b;
+                g.D2 = win + a.x_off; g.ldd2 = nb;
+                g.C2 = nxt + a.x_off; g.ldc2 = nb;
+            }
+            WN_TRY(wn_dl_mm(&g, c.st));
+        }
+        for (int l = 0; !folded && l < d.L; ++l) {
             const long lb = layer_base(lay, d, l);
             float* xin_l = ws + y.xin + (long)l * d.K * RB;
             float* z_l = ws + y.Zcat + (long)l * RB;
             {   // both rows of the gate: taps [history | newest] x packed dilated weights  (wavenet.py:540-541)
                 WnDlMmArgs g;
+                wn_dl_mm_no_stage(&g);
                 g.M = 2 * d.R; g.K = d.K * d.R; g.nb = nb;
                 g.A = ws + w.wd_f + (long)l * d.K * d.R * 2 * d.R; g.lda = 2 * d.R; g.a_zstride = 0;
                 g.B = xin_l; g.ldb = nb; g.b_zstride = 0;
@@ -1840,6 +1953,7 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
                                    ws + y.Sg, ws + y.Gt, z_l, 1, nb, d.R, 1, nb, c.st));
             if (l + 1 < d.L) {  // next layer input = res_1x1(z) + x  (wavenet.py:546-548)
                 WnDlMmArgs r;
+                wn_dl_mm_no_stage(&r);
                 r.M = d.R; r.K = d.R; r.nb = nb;
                 r.A = ws + w.wres_f + (long)l * d.R * d.R; r.lda = d.R; r.a_zstride = 0;
                 r.B = z_l; r.ldb = nb; r.b_zstride = 0;
@@ -1853,9 +1967,11 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
         }
         {   // skip-sum over all layers + relu (wavenet.py:545,365-366): one launch over the layers, then a fixed-order sum
             WnDlMmArgs g;
+            wn_dl_mm_no_stage(&g);
             g.M = d.S; g.K = d.R; g.nb = nb;
             g.A = ws + w.wskip_f; g.lda = d.S; g.a_zstride = (long)d.R * d.S;
             g.B = ws + y.Zcat; g.ldb = nb; g.b_zstride = RB;
+            if (folded) { g.B = ws + y.fs_in + a.xin_lstride; g.b_zstride = a.xin_lstride; }   // z_l = the z part of window l + 1
             g.C = ws + y.skpart; g.ldc = nb; g.c_zstride = (long)d.S * nb;
             g.bias = nullptr; g.D = nullptr; g.ldd = 0; g.relu = 0; g.nz = d.L; g.tag = "dl_skip";
             g.gate_R = 0; g.gate_g = nullptr; g.gate_c = nullptr;
@@ -1864,6 +1980,7 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
         }
         {
             WnDlMmArgs g;
+            wn_dl_mm_no_stage(&g);
             g.M = d.S; g.K = d.S; g.nb = nb;
             g.A = ws + w.w1_f; g.lda = d.S; g.a_zstride = 0;
             g.B = ws + y.O1; g.ldb = nb; g.b_zstride = 0;
@@ -1874,6 +1991,7 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
         }
         {
             WnDlMmArgs g;
+            wn_dl_mm_no_stage(&g);
             g.M = d.Qo; g.K = d.S; g.nb = nb;
             g.A = ws + w.w2_f; g.lda = d.Qo; g.a_zstride = 0;
             g.B = ws + y.O2; g.ldb = nb; g.b_zstride = 0;

@@ -81,7 +81,7 @@ static inline long wn_gemm6_apk_elems(int M, int K) {
 // rows followed by the 64 tanh rows of the same channels (the pairing of the forward gate epilogue).
 int wn_gemm6_pack(const float* src, long lda, int M, int K, unsigned short* Apk, int gate_R, wn_stream_t st);
 // several weight sets in ONE launch (the six of a training step are split once per step: wn_api.hip pack_weights)
-#define WN_G6_PACK_MAXJOBS 8
+#define WN_G6_PACK_MAXJOBS 12
 typedef struct WnGemm6PackJobs {
     int njobs;
     int blk0[WN_G6_PACK_MAXJOBS + 1];   // first block of job j (filled by wn_gemm6_pack_batch)
@@ -89,7 +89,15 @@ typedef struct WnGemm6PackJobs {
     long lda[WN_G6_PACK_MAXJOBS];
     int M[WN_G6_PACK_MAXJOBS], K[WN_G6_PACK_MAXJOBS];
     unsigned short* dst[WN_G6_PACK_MAXJOBS];
+    // a job may cover `nl` weight sets of the same shape (the layers of a wide model): set i reads src + i * src_lstride
+    // (floats) and writes dst + i * dst_lstride (bf16 elements); gate_R as wn_gemm6_pack
+    int nl[WN_G6_PACK_MAXJOBS];
+    long src_lstride[WN_G6_PACK_MAXJOBS], dst_lstride[WN_G6_PACK_MAXJOBS];
+    int gate_R[WN_G6_PACK_MAXJOBS];
 } WnGemm6PackJobs;
+static inline void wn_gemm6_pack_job_single(WnGemm6PackJobs* j, int i) {
+    j->nl[i] = 1; j->src_lstride[i] = 0; j->dst_lstride[i] = 0; j->gate_R[i] = 0;
+}
 int wn_gemm6_pack_batch(WnGemm6PackJobs* jobs, wn_stream_t st);
 static __host__ __device__ inline int wn_gemm6_gate_row(int p, int R) {
     const int mb = p >> 8, wmi = (p >> 7) & 1, i = (p >> 5) & 3, rr = p & 31;

@@ -37,7 +37,10 @@ __global__ void k_gemm6_pack_batch(WnGemm6PackJobs a) {
     int j = 0;
     while (j + 1 < a.njobs && (int)blockIdx.x >= a.blk0[j + 1]) ++j;   // block-uniform
     const int Mpad = (a.M[j] + WN_G6_BM - 1) / WN_G6_BM * WN_G6_BM;
-    gemm6_pack_elem(a.src[j], a.lda[j], a.M[j], a.K[j], Mpad, a.dst[j], 0, (long)((int)blockIdx.x - a.blk0[j]) * 256 + threadIdx.x);
+    const int per = (int)(((long)((a.K[j] + 15) / 16) * Mpad + 255) / 256);   // blocks per weight set of this job
+    const int rel = (int)blockIdx.x - a.blk0[j], li = rel / per;
+    gemm6_pack_elem(a.src[j] + (long)li * a.src_lstride[j], a.lda[j], a.M[j], a.K[j], Mpad, a.dst[j] + (long)li * a.dst_lstride[j],
+                    a.gate_R[j], (long)(rel - li * per) * 256 + threadIdx.x);
 }
 static __device__ __forceinline__ void gemm6_pack_elem(const float* src, long lda, int M, int K, int Mpad, unsigned short* Apk,
                                                        int gate_R, long idx) {
@@ -69,7 +72,7 @@ int wn_gemm6_pack_batch(WnGemm6PackJobs* jobs, wn_stream_t st) {
     for (int j = 0; j < jobs->njobs; ++j) {
         const int Mpad = (jobs->M[j] + WN_G6_BM - 1) / WN_G6_BM * WN_G6_BM;
         jobs->blk0[j] = nblk;
-        nblk += (int)(((long)((jobs->K[j] + 15) / 16) * Mpad + 255) / 256);
+        nblk += (int)(((long)((jobs->K[j] + 15) / 16) * Mpad + 255) / 256) * jobs->nl[j];
     }
     jobs->blk0[jobs->njobs] = nblk;
     if (nblk <= 0) return 0;
@@ -651,6 +654,9 @@ int wn_gemm6_launch(const WnGemm6Args* gp, wn_stream_t st) {
         const int pct = 50;
         // ~4000 cycles per 16-k step with two blocks per CU; one s_sleep(127) = 8128 cycles
         g.stagger = g.K <= 512 ? (int)(((long)pct * ((g.K + 15) / 16) * 4000L) / (100L * 8128L)) : 0;
+#ifdef WN_G6_STAGGER_EPI   // A/B build: also for the long contractions with a heavy (gate / gate') epilogue
+        if ((g.gate_S || g.gbw_dP) && g.K > 512) g.stagger = (int)(((long)pct * ((g.K + 15) / 16) * 3500L) / (100L * 8128L));
+#endif
     }
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.nbatch <= 0) return 1;
     if (g.b_seg_len < g.K && (g.b_seg_len % 16) != 0) return 2;

@@ -380,6 +380,9 @@ def test_gate_epilogues_of_the_wide_model_path():
     log = PC.launch_log(emu_library(), step)
     assert log.get("fwd_dilated_gate") == 4 and log.get("bwd_dz_res_gate") == 3 and log.get("bwd_dz_skip_gate") == 1, log
     assert "gate_fwd" not in log and "gate_bwd" not in log and "fwd_dilated_layered" not in log, log
+    # round 4: the per-layer weight sets of the wide path are split ONCE per step by the batched launch of pack_weights
+    # (one gemm6_pack launch in the whole step: round 3 issued one per contraction, 149 per step at the recipe size)
+    assert log.get("gemm6_pack") == 1, log
 
 
 def test_launch_sequence_of_the_default_training_step():
@@ -605,7 +608,11 @@ def test_any_size_decode_as_one_persistent_launch():
         log = PC.launch_log(emu_library(), lambda: out.update(p=model.engine.decode(xs, hs, ns, chunk=4, return_logits=True, layered=True)))
         assert log.get("dlp_steps", 0) >= 2 and "dl_dilated" not in log and "dl_res" not in log, log
         tp, lp = out["p"]
-        tl, ll = model.engine.decode(xs, hs, ns, chunk=4, return_logits=True, layered="launches")
+        log2 = PC.launch_log(emu_library(), lambda: out.update(l=model.engine.decode(xs, hs, ns, chunk=4, return_logits=True, layered="launches")))
+        tl, ll = out["l"]
+        # the layer-wise launches are folded too (round 4): ONE launch per layer and step, no separate res 1x1 launch
+        n_steps = max(ns) - 1 + 1   # parallel prefill: decoding resumes at the last context position
+        assert log2.get("dl_stage") == n_steps * len(cfg.dilations) and "dl_res" not in log2 and "dlp_steps" not in log2, log2
         for b in range(B):
             rt, rl = O.fast_generate(cfg, params, xs[b:b + 1], hs[b:b + 1], ns[b], return_logits=True)
             assert float((lp[b] - rl).abs().max()) <= 1e-4, (K, B, b)

@@ -53,14 +53,19 @@ def engine_flags_of(log_path):
 
 def main():
     fetch, write, steps = summarize([sys.argv[1]]), summarize([sys.argv[2]]), float(sys.argv[3])
-    per, total = {}, 0.0
+    per, total, setup = {}, 0.0, 0.0
     for k in sorted(set(fetch) | set(write)):
         f = fetch.get(k, {}).get("FETCH_SIZE", 0.0)
         w = write.get(k, {}).get("WRITE_SIZE", 0.0)
         n = max(fetch.get(k, {}).get("launches", 0), write.get(k, {}).get("launches", 0))
         b = (2.0 * f + w) * 1024.0
         per[k[:80]] = b
-        total += b * n
+        # torch's fill kernels are SET-UP (the zero-filled workspace / gradient / moment buffers, allocated once per run: the
+        # engine zero-fills its 11.3 GB workspace since round 4), not traffic of a training step
+        if k.startswith("void at::native::") and "FillFunctor" in k:
+            setup += b * n
+        else:
+            total += b * n
     out = {}
     for tag, names in TAGS.items():
         name = find_kernel(names, fetch, write)
@@ -98,6 +103,7 @@ def main():
     except OSError:
         out["_commit"] = None
     out["_step_total_bytes"] = total / steps
+    out["_setup_fill_bytes_excluded"] = setup
     out["_per_kernel_bytes_per_launch"] = per
     out["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/pmc_traffic.sh); bytes = "
                     "(2*FETCH_SIZE + WRITE_SIZE)*1024, see tools/pmc_traffic.py; the step total includes the model "
