@@ -1674,9 +1674,6 @@ struct DlLay {
     Ws w;  // packed-weight region of a (B=1, T=Ue) training workspace
     long queues, xin, P, Sg, Gt, Zcat, gstep, skpart, O1, O2, logits, total;
     long qfloats_per_utt;
-    // folded layer-wise launches (n_resch % 16 == 0): ONE launch per layer -- stage matrices [fold^T | taps] (K+1)R x 2R per
-    // layer, the constant part of the gate incl. the folded res bias, per-stage operand windows [z | older taps | x]
-    long fs_A, fs_cf, fs_in;
     // persistent path (wn_dlp.hip), when the plan covers the model and nb <= WN_DLP_BMAX
     WnDlpPlan dlp;
     long dlp_w, dlp_post, dlp_cfold, dlp_fold, dlp_gz, dlp_gx, dlp_gs, dlp_go, dlp_gl, dlp_pq, dlp_err;
@@ -1703,12 +1700,6 @@ static int dl_layout(const WnConfig* cfg, const Dims& d, int nb, DlLay* y) {
     DCARVE(O1, (long)d.S * nb);
     DCARVE(O2, (long)d.S * nb);
     DCARVE(logits, (long)d.Qo * nb);
-    y->fs_A = y->fs_cf = y->fs_in = -1;
-    if (d.R % 16 == 0 && d.K >= 2) {
-        DCARVE(fs_A, (long)d.L * (d.K + 1) * d.R * 2 * d.R);
-        DCARVE(fs_cf, (long)d.L * 2 * d.R);
-        DCARVE(fs_in, (long)(d.L + 1) * (d.K + 1) * d.R * nb);
-    }
     wn_dlp_make_plan(d.Q, d.Qo, d.R, d.S, d.L, d.K, &y->dlp);
     if (nb > WN_DLP_BMAX) y->dlp.ok = 0;
     if (y->dlp.ok) {
@@ -1781,28 +1772,6 @@ extern "C" int wn_decode_layered_prepare(const WnConfig* cfg, int B, int F, cons
     Ctx c;
     dl_ctx(&c, cfg, d, y, B, state, stream);
     if (params) WN_TRY(pack_weights(c, params));
-    if (params && y.fs_A >= 0) {
-        // folded launches: As[s] = [ (Wd_new(s) Wres(s-1))^T | wd_f[s] ]  ((K+1)R x 2R, k-major like every packed weight), s >= 1;
-        // As[0] keeps zero rows for the z part (the state arrives zero-filled)
-        const Lay& lay = c.y;
-        const long sA = (long)(d.K + 1) * d.R * 2 * d.R, sW = (long)d.K * d.R * 2 * d.R;
-        WnCopy4 cp;
-        cp.n0 = 1; cp.n1 = 1; cp.n2 = (int)sW; cp.nl = d.L;
-        cp.s0 = 0; cp.s1 = 0; cp.s2 = 1; cp.sl = sW;
-        cp.d0 = 0; cp.d1 = 0; cp.d2 = 1; cp.dl = sA;
-        WN_TRY(wn_copy4(state + y.fs_A + (long)d.R * 2 * d.R, state + y.w.wd_f, &cp, c.st));
-        for (int s = 1; s < d.L; ++s) {
-            WnGemmArgs f = wn_gemm_default();   // C[i][o'] = sum_j Wres(s-1)[j][i] Wd_new(s)[o'][j]
-            f.M = d.R; f.N = 2 * d.R; f.K = d.R;
-            f.A = params + layer_base(lay, d, s - 1) + lay.o_res_w; f.lda = d.R;
-            f.B = state + y.w.wd_f + (long)s * sW + (long)(d.K - 1) * d.R * 2 * d.R; f.ldb = 2 * d.R; f.b_clen = 2 * d.R;
-            f.C = state + y.fs_A + (long)s * sA; f.ldc = 2 * d.R;
-            f.nbatch = 1; f.tag = "dl_fold";
-            WN_TRY(wn_gemm_launch(&f, c.st));
-        }
-        WN_TRY(wn_dlp_cfold(params, state + y.w.cvec, state + y.w.wd_f, layer_base(lay, d, 0), -lay.LB, lay.o_res_b, d.L, d.R, d.K,
-                            state + y.fs_cf, c.st));
-    }
     if (params && y.dlp.ok) {   // persistent path: per-stage weight images with the res 1x1 folded into the next layer's newest tap
         const Lay& lay = c.y;
         const long lb0 = layer_base(lay, d, 0), lstep = -lay.LB;
@@ -1898,44 +1867,15 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
     a.queues = ws + y.queues; a.xin = ws + y.xin; a.gstep = ws + y.gstep;
     const long RB = (long)d.R * nb;
     const bool gate_fused = d.R % 16 == 0;
-    const bool folded = y.fs_A >= 0;
-    a.xin_lstride = (long)d.K * RB; a.hist_off = 0; a.x_off = (long)(d.K - 1) * RB; a.folded = 0;
-    if (folded) {   // [z | older taps | x] windows, one per stage (+ one behind the last stage for its outputs)
-        a.xin = ws + y.fs_in; a.xin_lstride = (long)(d.K + 1) * RB; a.hist_off = RB; a.x_off = (long)d.K * RB; a.folded = 1;
-    }
     for (int p = p0; p < p1; ++p) {
         a.p = p;
         WN_TRY(wn_dl_inputs(&a, c.st));
-        for (int l = 0; folded && l < d.L; ++l) {
-            // ONE launch per layer (round 4): gate rows from [z_{l-1} | taps of x_l | x_{l-1}] with the res 1x1 of layer l-1
-            // folded into the newest tap, and x_l = res_1x1(z_{l-1}) + x_{l-1} as the launch's second contraction
-            // (wavenet.py:540-548); both outputs land in the window of stage l + 1
-            float* win = ws + y.fs_in + (long)l * a.xin_lstride;
-            float* nxt = win + a.xin_lstride;
-            WnDlMmArgs g;
-            wn_dl_mm_no_stage(&g);
-            g.M = 2 * d.R; g.K = (d.K + 1) * d.R; g.nb = nb;
-            g.A = ws + y.fs_A + (long)l * (d.K + 1) * d.R * 2 * d.R; g.lda = 2 * d.R; g.a_zstride = 0;
-            g.B = win; g.ldb = nb; g.b_zstride = 0;
-            g.C = nxt; g.ldc = nb; g.c_zstride = 0;
-            g.bias = nullptr; g.D = nullptr; g.ldd = 0; g.relu = 0; g.nz = 1; g.tag = "dl_stage";
-            g.gate_R = d.R; g.gate_g = ws + y.gstep + (long)l * 2 * RB; g.gate_c = ws + y.fs_cf + (long)l * 2 * d.R;
-            if (l >= 1) {
-                g.x_tiles = (d.R + 31) / 32;
-                g.A2 = ws + w.wres_f + (long)(l - 1) * d.R * d.R; g.lda2 = d.R; g.M2 = d.R; g.K2 = d.R;
-                g.bias2 = params + layer_base(lay, d, l - 1) + lay.o_res_b;
-                g.D2 = win + a.x_off; g.ldd2 = nb;
-                g.C2 = nxt + a.x_off; g.ldc2 = nb;
-            }
-            WN_TRY(wn_dl_mm(&g, c.st));
-        }
-        for (int l = 0; !folded && l < d.L; ++l) {
+        for (int l = 0; l < d.L; ++l) {
             const long lb = layer_base(lay, d, l);
             float* xin_l = ws + y.xin + (long)l * d.K * RB;
             float* z_l = ws + y.Zcat + (long)l * RB;
             {   // both rows of the gate: taps [history | newest] x packed dilated weights  (wavenet.py:540-541)
                 WnDlMmArgs g;
-                wn_dl_mm_no_stage(&g);
                 g.M = 2 * d.R; g.K = d.K * d.R; g.nb = nb;
                 g.A = ws + w.wd_f + (long)l * d.K * d.R * 2 * d.R; g.lda = 2 * d.R; g.a_zstride = 0;
                 g.B = xin_l; g.ldb = nb; g.b_zstride = 0;
@@ -1953,7 +1893,6 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
                                    ws + y.Sg, ws + y.Gt, z_l, 1, nb, d.R, 1, nb, c.st));
             if (l + 1 < d.L) {  // next layer input = res_1x1(z) + x  (wavenet.py:546-548)
                 WnDlMmArgs r;
-                wn_dl_mm_no_stage(&r);
                 r.M = d.R; r.K = d.R; r.nb = nb;
                 r.A = ws + w.wres_f + (long)l * d.R * d.R; r.lda = d.R; r.a_zstride = 0;
                 r.B = z_l; r.ldb = nb; r.b_zstride = 0;
@@ -1967,11 +1906,9 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
         }
         {   // skip-sum over all layers + relu (wavenet.py:545,365-366): one launch over the layers, then a fixed-order sum
             WnDlMmArgs g;
-            wn_dl_mm_no_stage(&g);
             g.M = d.S; g.K = d.R; g.nb = nb;
             g.A = ws + w.wskip_f; g.lda = d.S; g.a_zstride = (long)d.R * d.S;
             g.B = ws + y.Zcat; g.ldb = nb; g.b_zstride = RB;
-            if (folded) { g.B = ws + y.fs_in + a.xin_lstride; g.b_zstride = a.xin_lstride; }   // z_l = the z part of window l + 1
             g.C = ws + y.skpart; g.ldc = nb; g.c_zstride = (long)d.S * nb;
             g.bias = nullptr; g.D = nullptr; g.ldd = 0; g.relu = 0; g.nz = d.L; g.tag = "dl_skip";
             g.gate_R = 0; g.gate_g = nullptr; g.gate_c = nullptr;
@@ -1980,7 +1917,6 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
         }
         {
             WnDlMmArgs g;
-            wn_dl_mm_no_stage(&g);
             g.M = d.S; g.K = d.S; g.nb = nb;
             g.A = ws + w.w1_f; g.lda = d.S; g.a_zstride = 0;
             g.B = ws + y.O1; g.ldb = nb; g.b_zstride = 0;
@@ -1991,7 +1927,6 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
         }
         {
             WnDlMmArgs g;
-            wn_dl_mm_no_stage(&g);
             g.M = d.Qo; g.K = d.S; g.nb = nb;
             g.A = ws + w.w2_f; g.lda = d.Qo; g.a_zstride = 0;
             g.B = ws + y.O2; g.ldb = nb; g.b_zstride = 0;

@@ -135,11 +135,8 @@ typedef struct WnDlArgs {
     const int64_t* samples;  // (nb, Ttot)
     long Ttot;
     float* queues;        // layer l at qoff(l)*nb: [slot][R][nb]
-    float* xin;           // per-layer operand windows: layer l at xin + l * xin_lstride; history tap j at + hist_off + j*R*nb, the
-    float* gstep;         // [nG][nb]          newest tap (x_l) at + x_off.  Plain layout [L][K][R][nb]: lstride K*R*nb, hist_off 0,
-    long xin_lstride, hist_off, x_off;   //    x_off (K-1)*R*nb.  Folded layout (wn_api.hip): [z | taps | x] per stage.
-    int folded;           // 1: x_l of layer l >= 1 lives in the window of stage l + 1 (the stage that consumes it), and x_0 is
-                          //    written into the windows of stages 0 AND 1
+    float* xin;           // [L][K][R][nb]
+    float* gstep;         // [nG][nb]
 } WnDlArgs;
 int wn_dl_inputs(const WnDlArgs* a, wn_stream_t st);
 // After the step: push the layer inputs of position p into the queue rings.
@@ -169,18 +166,7 @@ typedef struct WnDlMmArgs {
     int gate_R;
     const float* gate_g;  // [2R][nb] aux pre-activations of this layer and step
     const float* gate_c;  // [2R] constant part
-    // Folded stage (x_tiles > 0; wn_api.hip): the launch carries a SECOND contraction on the first K2 rows of the same B
-    // operand -- tiles blockIdx.x >= gate_R / 16 are plain 32-row tiles of C2 = A2 . B[0:K2] + bias2 + D2 (the residual
-    // output x_s = res_1x1(z_{s-1}) + b + x_{s-1}, wavenet.py:546-548, beside the gate rows of the same stage)
-    int x_tiles;
-    const float* A2; long lda2; int M2, K2;
-    const float* bias2;
-    const float* D2; long ldd2;
-    float* C2; long ldc2;
 } WnDlMmArgs;
-static inline void wn_dl_mm_no_stage(WnDlMmArgs* a) {
-    a->x_tiles = 0; a->A2 = 0; a->lda2 = 0; a->M2 = 0; a->K2 = 0; a->bias2 = 0; a->D2 = 0; a->ldd2 = 0; a->C2 = 0; a->ldc2 = 0;
-}
 int wn_dl_mm(const WnDlMmArgs* a, wn_stream_t st);
 // out[m][u] = relu?( sum_z part[z][m][u] + bias[m] )
 int wn_dl_sum(const float* part, int nz, long zstride, int M, int nb, const float* bias, int relu, float* out, wn_stream_t st);

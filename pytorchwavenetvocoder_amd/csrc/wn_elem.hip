@@ -1001,8 +1001,7 @@ __global__ __launch_bounds__(WN_TPB) void k_dl_inputs(WnDlArgs a) {
         const int d = 1 << (l % a.depth), Dq = (K - 1) * d;
         int slot = (a.p - (K - 1 - j) * d) % Dq;
         if (slot < 0) slot += Dq;  // not written yet in this run: zero history
-        a.xin[(long)l * a.xin_lstride + a.hist_off + ((long)j * R + c) * nb + u] =
-            a.queues[(dl_queue_off(l, a.depth, K, R) + (long)slot * R + c) * nb + u];
+        a.xin[(((long)l * K + j) * R + c) * nb + u] = a.queues[(dl_queue_off(l, a.depth, K, R) + (long)slot * R + c) * nb + u];
     } else if (i < n_hist + n_aux) {
         const long q = i - n_hist;
         const int u = (int)(q % nb), row = (int)(q / nb);
@@ -1023,8 +1022,7 @@ __global__ __launch_bounds__(WN_TPB) void k_dl_inputs(WnDlArgs a) {
                 x0 += a.params[a.off_causal_w + ((long)c * a.Q + tok) * K + k];
             }
         }
-        a.xin[a.x_off + (long)c * nb + u] = x0;
-        if (a.folded && a.L > 1) a.xin[a.xin_lstride + a.x_off + (long)c * nb + u] = x0;   // stage 1 consumes x_0 as well
+        a.xin[((long)(K - 1) * R + c) * nb + u] = x0;
     }
 }
 
@@ -1044,8 +1042,7 @@ __global__ __launch_bounds__(WN_TPB) void k_dl_push(WnDlArgs a) {
     long r = i / nb;
     const int c = (int)(r % R), l = (int)(r / R);
     const int Dq = (K - 1) << (l % a.depth);
-    const int lw = (a.folded && l >= 1) ? l + 1 : l;   // the window that holds x_l
-    a.queues[(dl_queue_off(l, a.depth, K, R) + (long)(a.p % Dq) * R + c) * nb + u] = a.xin[(long)lw * a.xin_lstride + a.x_off + (long)c * nb + u];
+    a.queues[(dl_queue_off(l, a.depth, K, R) + (long)(a.p % Dq) * R + c) * nb + u] = a.xin[(((long)l * K + (K - 1)) * R + c) * nb + u];
 }
 
 int wn_dl_push(const WnDlArgs* a, wn_stream_t st) {
@@ -1100,22 +1097,16 @@ __global__ __launch_bounds__(NW * 64) void k_dl_mm(WnDlMmArgs a) {
     __shared__ float red[NW][32 * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
-    const int n0 = blockIdx.y * 32, z = blockIdx.z;
-    // a folded stage's second contraction: the tiles behind the gate tiles (block-uniform)
-    const bool xt = a.x_tiles > 0 && (int)blockIdx.x >= a.gate_R / 16;
-    const int bx = xt ? (int)blockIdx.x - a.gate_R / 16 : (int)blockIdx.x;
-    const int m0 = bx * 32;
-    const int aK = xt ? a.K2 : a.K, aM = xt ? a.M2 : a.M, gR = xt ? 0 : a.gate_R;
-    const long alda = xt ? a.lda2 : a.lda;
-    const float* __restrict__ Az = xt ? a.A2 : a.A + (long)z * a.a_zstride;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32, z = blockIdx.z;
+    const float* __restrict__ Az = a.A + (long)z * a.a_zstride;
     const float* __restrict__ Bz = a.B + (long)z * a.b_zstride;
     // this wave's k range (multiples of 2)
-    const int kq = ((aK + 2 * NW - 1) / (2 * NW)) * 2;
-    const int k0 = wave * kq, k1 = (k0 + kq < aK) ? k0 + kq : aK;
+    const int kq = ((a.K + 2 * NW - 1) / (2 * NW)) * 2;
+    const int k0 = wave * kq, k1 = (k0 + kq < a.K) ? k0 + kq : a.K;
     // row of the weight matrix behind tile row li: plain tiles are 32 consecutive rows; gate tiles pair the
     // sigmoid and the tanh row of 16 channels
-    const int mrow = gR > 0 ? ((li < 16) ? bx * 16 + li : gR + bx * 16 + (li - 16)) : m0 + li;
-    const bool m_ok = mrow < aM, u_ok = (n0 + li) < a.nb;
+    const int mrow = a.gate_R > 0 ? ((li < 16) ? blockIdx.x * 16 + li : a.gate_R + blockIdx.x * 16 + (li - 16)) : m0 + li;
+    const bool m_ok = mrow < a.M, u_ok = (n0 + li) < a.nb;
     const float* pa = Az + (m_ok ? mrow : 0);
     const float* pb = Bz + (u_ok ? n0 + li : 0);
     f32x16 acc = f32x16_zero();
@@ -1128,7 +1119,7 @@ __global__ __launch_bounds__(NW * 64) void k_dl_mm(WnDlMmArgs a) {
                 const int kk = kg + 16 * g + 2 * s + hi;
                 const bool ok = kk < k1;
                 const int kc = ok ? kk : k0;   // k0 < k1 here: a valid address for the dead lanes
-                av[g][s] = pa[(long)kc * alda];
+                av[g][s] = pa[(long)kc * a.lda];
                 bv[g][s] = pb[(long)kc * a.ldb];
                 if (!ok || !m_ok) av[g][s] = 0.0f;
                 if (!ok || !u_ok) bv[g][s] = 0.0f;
@@ -1147,21 +1138,6 @@ __global__ __launch_bounds__(NW * 64) void k_dl_mm(WnDlMmArgs a) {
     for (int r = 0; r < 16; ++r) red[wave][mfma32_row(r, hi) * 32 + li] = acc[r];
     __syncthreads();
     float* Cz = a.C + (long)z * a.c_zstride;
-    if (xt) {
-        for (int i = tid; i < 32 * 32; i += NW * 64) {
-            const int row = i >> 5, col = i & 31;
-            const int m = m0 + row, u = n0 + col;
-            if (m < aM && u < a.nb) {
-                float v = 0.0f;
-                WN_UNROLL
-                for (int w = 0; w < NW; w += 4) v += (red[w][i] + red[w + 1][i]) + (red[w + 2][i] + red[w + 3][i]);
-                if (a.bias2) v += a.bias2[m];
-                if (a.D2) v += a.D2[(long)m * a.ldd2 + u];
-                a.C2[(long)m * a.ldc2 + u] = v;
-            }
-        }
-        return;
-    }
     if (a.gate_R > 0) {
         const int R = a.gate_R;
         for (int i = tid; i < 16 * 32; i += NW * 64) {
@@ -1200,9 +1176,7 @@ int wn_dl_mm(const WnDlMmArgs* a, wn_stream_t st) {
     WN_PROF(a->tag ? a->tag : "dl_mm", 2.0 * a->M * (double)a->K * a->nb * a->nz, (double)a->M * a->K * 4.0 * a->nz, st);
     if (a->M <= 0 || a->K <= 0 || a->nb <= 0 || a->nz <= 0) return 1;
     if (a->gate_R > 0 && (a->gate_R % 16 != 0 || a->M != 2 * a->gate_R || !a->gate_g || !a->gate_c)) return 1;
-    if (a->x_tiles > 0 && (a->gate_R <= 0 || a->nz != 1 || !a->A2 || !a->C2)) return 1;
-    dim3 grid((unsigned)((a->gate_R > 0 ? a->gate_R / 16 : (a->M + 31) / 32) + (a->x_tiles > 0 ? a->x_tiles : 0)),
-              (unsigned)((a->nb + 31) / 32), (unsigned)a->nz);
+    dim3 grid((unsigned)(a->gate_R > 0 ? a->gate_R / 16 : (a->M + 31) / 32), (unsigned)((a->nb + 31) / 32), (unsigned)a->nz);
     // few tiles and a long K: 16 waves per tile keep every wave's range at one group of requests
     const long tiles = (long)grid.x * grid.y * grid.z;
     if (a->K >= 512 && tiles <= 512) {

@@ -654,9 +654,6 @@ int wn_gemm6_launch(const WnGemm6Args* gp, wn_stream_t st) {
         const int pct = 50;
         // ~4000 cycles per 16-k step with two blocks per CU; one s_sleep(127) = 8128 cycles
         g.stagger = g.K <= 512 ? (int)(((long)pct * ((g.K + 15) / 16) * 4000L) / (100L * 8128L)) : 0;
-#ifdef WN_G6_STAGGER_EPI   // A/B build: also for the long contractions with a heavy (gate / gate') epilogue
-        if ((g.gate_S || g.gbw_dP) && g.K > 512) g.stagger = (int)(((long)pct * ((g.K + 15) / 16) * 3500L) / (100L * 8128L));
-#endif
     }
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.nbatch <= 0) return 1;
     if (g.b_seg_len < g.K && (g.b_seg_len % 16) != 0) return 2;
