@@ -240,6 +240,10 @@ int wn_op_front(const float* weight, const float* bias, const int64_t* x, float*
 int wn_op_causal_conv(const float* weight, const float* bias, const float* x /*(B,Cin,T)*/, float* y /*(B,Cout,T)*/,
                       float* scratch, int B, int T, int Cin, int Cout, int K, int dilation, void* stream);
 
+/* UpSampling.forward (wavenet.py:124-154, since ABI v7): y (B, C, F*U) = x (B, C, F) through the (1, U) transposed
+ * convolution with ONE kernel `weight` [U] and scalar `bias` (nullable) shared by all channels. */
+int wn_op_upsampling(const float* weight, const float* bias, const float* x, float* y, int B, int C, int F, int U, void* stream);
+
 /* Generic C[z] = A.B contraction on the f32 matrix cores; argument block: wavenet_hip_gemm.h (struct WnGemmArgs,
  * the inline helper wn_gemm_default fills the neutral values). */
 int wn_op_gemm(const struct WnGemmArgs* args, void* stream);

@@ -1518,6 +1518,16 @@ extern "C" int wn_op_causal_conv(const float* weight, const float* bias, const f
     return rt_check("wn_op_causal_conv");
 }
 
+// UpSampling.forward (wavenet.py:141-154): y[b][c][f U + j] = x[b][c][f] w[j] + bias  (ConvTranspose2d (1,U)/(1,U), one kernel
+// shared by all channels); weight [U], bias [1] or NULL.
+extern "C" int wn_op_upsampling(const float* weight, const float* bias, const float* x, float* y, int B, int C, int F, int U,
+                                void* stream) {
+    api_enter();
+    if (!weight || !x || !y || B < 1 || C < 1 || F < 1 || U < 1) return fail(1, "bad argument");
+    WN_TRY(wn_decode_ctx_aux_rows(x, weight, bias, y, B, C, F, U, F * U, 0, 0, (wn_stream_t)stream));
+    return rt_check("wn_op_upsampling");
+}
+
 // ------------------------------------------------------------------------------------------
 // autoregressive decode (wavenet.py:309-511, 538-549)
 // ------------------------------------------------------------------------------------------

@@ -1370,7 +1370,7 @@ __global__ __launch_bounds__(WN_TPB) void k_decode_ctx_aux(const float* __restri
         int f = t / U;
         const float w = upw[t - f * U];
         if (f > F - 1) f = F - 1;
-        v = w * hr[f] + upb[0];
+        v = w * hr[f] + (upb ? upb[0] : 0.0f);
     } else {
         v = hr[t < F ? t : F - 1];
     }

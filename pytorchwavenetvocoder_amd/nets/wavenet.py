@@ -128,7 +128,21 @@ class UpSampling(nn.Module):
                                        stride=(1, self.upsampling_factor), bias=self.bias)
 
     def forward(self, x):
-        """x (B, C, T) -> (B, C, T * upsampling_factor)  (closed form, device-agnostic glue)."""
+        """x (B, C, T) -> (B, C, T * upsampling_factor).  On the GPU: the HIP op ``wn_op_upsampling`` (inference-only like
+        ``CausalConv1d.forward``; what ``generate()`` calls); on the CPU the closed form below (shape tests of the reference)."""
+        if x.is_cuda:
+            import ctypes
+            lib = _lib.load_library()
+            x = x.contiguous().float()
+            B, C, F_ = x.shape
+            U = self.upsampling_factor
+            w = self.conv.weight.detach().reshape(-1).contiguous()
+            b = self.conv.bias.detach().contiguous() if self.conv.bias is not None else None
+            y = torch.empty(B, C, F_ * U, device=x.device, dtype=torch.float32)
+            st = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+            rc = lib.wn_op_upsampling(w.data_ptr(), b.data_ptr() if b is not None else None, x.data_ptr(), y.data_ptr(), B, C, F_, U, st)
+            lib.check(rc, "wn_op_upsampling")
+            return y
         w = self.conv.weight.view(-1)
         y = x.unsqueeze(-1) * w
         if self.conv.bias is not None:

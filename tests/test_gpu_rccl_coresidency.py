@@ -1,0 +1,100 @@
+# -*- coding: utf-8 -*-
+"""Does a 16-workgroup collective kernel really fit beside the persistent 240-workgroup grids of the backward pass?
+
+DESIGN.md section 7 caps RCCL at 16 channels because the fused chain kernels need a whole CU per workgroup and use 240 of the
+256 CUs: an all-reduce kernel with more workgroups than the 16 CUs left would take CUs a chain kernel is about to claim, and
+the unplaced part of a persistent grid only starts when the rest of it retires (measured with a side-stream contraction in
+round 1).  With one GPU there is no peer (a one-rank in-place all-reduce launches no kernel at all), so this test uses a
+STAND-IN of the same shape -- 16 workgroups of 256 threads streaming over a buffer of the gradient's size
+(tests/gpu_helpers/occupy.hip, compiled here with hipcc) -- on the reducer's side stream, released by the first gradient-bucket
+event of a full-size backward pass (B = 8, T = 23040: the bucket that is final BEFORE the chain starts), exactly where
+GradientReducer would issue the first all-reduce.  Asserted on device wall-clock stamps: every stand-in workgroup STARTS while
+the backward pass is still running (milliseconds before its end: it was not held back until the persistent grids retired),
+and the backward pass is not slowed by it.  What this cannot show is a transfer over xGMI."""
+import ctypes
+import os
+import shutil
+import subprocess
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda:0"
+
+
+def _helper():
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available to build the stand-in kernel")
+    out_dir = os.path.join(ROOT, "tests", "emu", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "gpu_occupy.so")
+    src = os.path.join(ROOT, "tests", "gpu_helpers", "occupy.hip")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-o", so, src])
+    lib = ctypes.CDLL(so)
+    lib.occupy_launch.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    lib.stamp_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    return lib
+
+
+def test_a_16_workgroup_kernel_runs_beside_the_full_size_backward_chain():
+    from pytorchwavenetvocoder_amd.nets import WaveNet, initialize
+    lib = _helper()
+    dev = torch.device(DEV)
+    torch.manual_seed(1)
+    cfg_t = (256, 80, 64, 256, 10, 3, 2, 80)
+    model = WaveNet(*cfg_t)
+    model.apply(initialize)
+    model.to(dev)
+    B, T = 8, 23040
+    g = torch.Generator().manual_seed(5)
+    xx = torch.randint(0, 256, (B, T + 1), generator=g)
+    x, t = xx[:, :-1].contiguous().to(dev), xx[:, 1:].contiguous().to(dev)
+    h = torch.randn(B, 80, T // 80, generator=g).to(dev)
+    eng = model.engine
+    nb = len(eng.bucket_ranges(eng.n_layers))
+    events = [torch.cuda.Event() for _ in range(nb)]
+    main = torch.cuda.current_stream(dev)
+    for e in events:
+        e.record(main)
+    side = torch.cuda.Stream(device=dev)
+    buf = torch.zeros(eng.n_params, dtype=torch.float32, device=dev)           # a buffer of the gradient's size (6.4 MB)
+    stamps = torch.zeros(2 * 16, dtype=torch.int64, device=dev)
+    marks = torch.zeros(3, dtype=torch.int64, device=dev)
+    t_ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+
+    def backward_pass(with_side):
+        loss, dl = eng.forward_loss(x, h, t)
+        torch.cuda.synchronize(dev)
+        t_ev[0 if with_side else 2].record(main)
+        lib.stamp_launch(marks.data_ptr(), main.cuda_stream)
+        eng.backward(dl, events=[e.cuda_event for e in events], layers_per_bucket=eng.n_layers)
+        if with_side:   # where GradientReducer issues the all-reduce of bucket 0
+            side.wait_event(events[0])
+            rc = lib.occupy_launch(buf.data_ptr(), buf.numel(), 20, stamps.data_ptr(), 16, side.cuda_stream)
+            assert rc == 0
+        lib.stamp_launch(marks.data_ptr() + 8, main.cuda_stream)
+        t_ev[1 if with_side else 3].record(main)
+        main.wait_stream(side)
+        torch.cuda.synchronize(dev)
+
+    backward_pass(False)   # warm-up
+    backward_pass(True)
+    ms_with = t_ev[0].elapsed_time(t_ev[1])
+    s = stamps.cpu().view(16, 2)
+    m = marks.cpu()
+    start_first = (int(s[:, 0].min()) - int(m[0])) * 1e-5      # ms after the backward pass began (100 MHz ticks)
+    start_last = (int(s[:, 0].max()) - int(m[0])) * 1e-5
+    end_last = (int(s[:, 1].max()) - int(m[0])) * 1e-5
+    bwd = (int(m[1]) - int(m[0])) * 1e-5
+    backward_pass(False)
+    ms_without = t_ev[2].elapsed_time(t_ev[3])
+    print("backward pass %.2f ms (%.2f without the side kernel); stand-in workgroups started %.2f .. %.2f ms after its begin, "
+          "last one ended at %.2f ms" % (ms_with, ms_without, start_first, start_last, end_last))
+    assert bwd > 3.0                                   # the full-size backward pass (chain + weight gradients)
+    assert start_last < bwd - 2.0, (start_last, bwd)   # every workgroup was placed while the chain was running, not after it
+    assert ms_with <= 1.05 * ms_without + 0.1, (ms_with, ms_without)
