@@ -75,7 +75,7 @@ def test_a_16_workgroup_kernel_runs_beside_the_full_size_backward_chain():
         eng.backward(dl, events=[e.cuda_event for e in events], layers_per_bucket=eng.n_layers)
         if with_side:   # where GradientReducer issues the all-reduce of bucket 0
             side.wait_event(events[0])
-            rc = lib.occupy_launch(buf.data_ptr(), buf.numel(), 20, stamps.data_ptr(), 16, side.cuda_stream)
+            rc = lib.occupy_launch(buf.data_ptr(), buf.numel(), 2, stamps.data_ptr(), 16, side.cuda_stream)   # ~25 MB of traffic: a ring all-reduce of 6.4 MB moves ~11 MB per GPU
             assert rc == 0
         lib.stamp_launch(marks.data_ptr() + 8, main.cuda_stream)
         t_ev[1 if with_side else 3].record(main)
@@ -97,4 +97,4 @@ def test_a_16_workgroup_kernel_runs_beside_the_full_size_backward_chain():
           "last one ended at %.2f ms" % (ms_with, ms_without, start_first, start_last, end_last))
     assert bwd > 3.0                                   # the full-size backward pass (chain + weight gradients)
     assert start_last < bwd - 2.0, (start_last, bwd)   # every workgroup was placed while the chain was running, not after it
-    assert ms_with <= 1.05 * ms_without + 0.1, (ms_with, ms_without)
+    assert ms_with <= 1.03 * ms_without + 0.1, (ms_with, ms_without)
