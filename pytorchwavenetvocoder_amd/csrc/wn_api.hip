@@ -338,7 +338,7 @@ struct DwPlan {
 static DwPlan dw_plan(int M, int N, int Kdim, int nbatch) {
     const int tm = (M + (M > 64 ? 127 : 63)) / (M > 64 ? 128 : 64);
     // column tile width the kernel will use (the 256-row tiles of wn_gemm6_dw_tall always come with 128 columns)
-    const int tnw = wn_gemm6_dw_tall(M, N) ? 128 : 64 * wn_gemm6_dw_tn(N);
+    const int tnw = wn_gemm6_dw_tall(M, N) ? 128 : 64 * wn_gemm6_dw_tn(M, N);
     const int tn = (N + tnw - 1) / tnw;
     const long tiles = (long)tm * tn * nbatch;
     // 128 x 128 tiles (k_gemm6_dw<2,2>, 3 workgroups per CU): as many k-chunks as fit ONE resident round of 768
@@ -349,6 +349,8 @@ static DwPlan dw_plan(int M, int N, int Kdim, int nbatch) {
     if (wn_gemm6_dw_tall(M, N)) {   // 256 x 128 tiles (k_gemm6_dw<4,2>, 2 workgroups per CU): one resident round of 512
         const long tall = (long)(M / 256) * tn * nbatch;
         ks = 512 / tall;
+    } else if (M > 64 && tnw == 192) {   // 128 x 192 tiles (k_gemm6_dw<2,3>, 2 workgroups per CU): one resident round of 512
+        ks = 512 / tiles;
     } else if (M > 64 && tnw == 128) {
         ks = 768 / tiles;
     } else {

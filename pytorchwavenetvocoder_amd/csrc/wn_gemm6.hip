@@ -692,6 +692,9 @@ template <int TM, int TN>
 __global__ __launch_bounds__(G6_T, (TM * TN > 4 ? 2 : 3)) void k_gemm6_dw(WnGemmArgs g, int order G6_DBG_PARAM) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int AE = BM / 16, BE = BN / 16;            // fp32 elements per thread and step
+    // 192-column tiles (TN = 3: kernel_size 3 at 64 channels, N = 3 x 64) give a thread three B rows of 4 consecutive k each
+    // (rows r, r + 64, r + 128) instead of one row of BE
+    constexpr int BR = (TN == 3) ? 3 : 1, BEr = BE / BR;
     constexpr int A_BYTES = 3 * BM * 32, B_BYTES = 3 * BN * 32, ST_BYTES = A_BYTES + B_BYTES;
     WN_DYN_SMEM(smem_raw);
     __shared__ long b_rowoff[BN];
@@ -740,11 +743,16 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 4 ? 2 : 3)) void k_gemm6_dw(WnGemm
 
     // this thread's slice of the operand tiles
     const int a_row = tid / (16 / AE), a_k = (tid % (16 / AE)) * AE;
-    const int b_row = tid / (16 / BE), b_k = (tid % (16 / BE)) * BE;
+    const int b_row = tid / (16 / BEr), b_k = (tid % (16 / BEr)) * BEr;   // (TN = 3: the first of the thread's three rows)
     const long a_off = (long)(m0 + a_row) * g.lda;
     const bool a_row_ok = (m0 + a_row) < g.M;
-    const long b_off = b_rowoff[b_row];
-    const int b_sh = b_rowshift[b_row];
+    long b_off[BR];
+    int b_sh[BR];
+    WN_UNROLL
+    for (int u = 0; u < BR; ++u) {
+        b_off[u] = b_rowoff[b_row + 64 * u];
+        b_sh[u] = b_rowshift[b_row + 64 * u];
+    }
     const bool a_tile_ok = (m0 + BM) <= g.M, b_tile_ok = (n0 + BN) <= g.N;
     float rowsum = 0.f;
     const float b_floor = g.b_relu ? 0.f : -__builtin_inff();
@@ -771,14 +779,16 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 4 ? 2 : 3)) void k_gemm6_dw(WnGemm
         if (b_tile_ok && full && (k0 - b_shmax) >= 0 && (k0 + 16 - b_shmin) <= g.b_clen) {
             WN_UNROLL
             for (int q = 0; q < BE / 4; ++q) {
-                const wn_f4 v = wn_ld4_unaligned(Bz + b_off + (k0 + b_k + 4 * q - b_sh));
+                const int u = q / (BEr / 4), qq = q % (BEr / 4);
+                const wn_f4 v = wn_ld4_unaligned(Bz + b_off[u] + (k0 + b_k + 4 * qq - b_sh[u]));
                 rb[4 * q] = v.x; rb[4 * q + 1] = v.y; rb[4 * q + 2] = v.z; rb[4 * q + 3] = v.w;
             }
         } else {
             WN_UNROLL
             for (int e = 0; e < BE; ++e) {
-                const int k = k0 + b_k + e, cc = k - b_sh;
-                rb[e] = (b_off >= 0 && k < kend && cc >= 0 && cc < g.b_clen) ? Bz[b_off + cc] : 0.f;
+                const int u = e / BEr;
+                const int k = k0 + b_k + e % BEr, cc = k - b_sh[u];
+                rb[e] = (b_off[u] >= 0 && k < kend && cc >= 0 && cc < g.b_clen) ? Bz[b_off[u] + cc] : 0.f;
             }
         }
     };
@@ -815,7 +825,8 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 4 ? 2 : 3)) void k_gemm6_dw(WnGemm
         float rbf[BE];
         WN_UNROLL
         for (int e = 0; e < BE; ++e) rbf[e] = fmaxf(rb[e], b_floor);
-        split_store(sa + A_BYTES, BN, b_row, b_k, rbf, BE);
+        WN_UNROLL
+        for (int u = 0; u < BR; ++u) split_store(sa + A_BYTES, BN, b_row + 64 * u, b_k, rbf + u * BEr, BEr);
     };
 
     f32x16 acc[TM][TN];
@@ -862,7 +873,8 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 4 ? 2 : 3)) void k_gemm6_dw(WnGemm
         }
         WN_UNROLL
         for (int q = 0; q < BE / 4; ++q) {
-            const wn_f4 v = wn_ld4_unaligned(Bz + b_off + (k0 + b_k + 4 * q - b_sh));
+            const int u = q / (BEr / 4), qq = q % (BEr / 4);
+            const wn_f4 v = wn_ld4_unaligned(Bz + b_off[u] + (k0 + b_k + 4 * qq - b_sh[u]));
             rb[4 * q] = v.x; rb[4 * q + 1] = v.y; rb[4 * q + 2] = v.z; rb[4 * q + 3] = v.w;
         }
     };
@@ -939,7 +951,11 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 4 ? 2 : 3)) void k_gemm6_dw(WnGemm
                 } else if (q < NPA + NPB) {
                     const int qb = q - NPA;
                     pair(fmaxf(rb[2 * qb], b_floor), fmaxf(rb[2 * qb + 1], b_floor), hb[qb], mb[qb], lb[qb]);
-                    if (qb == NPB - 1) put(da + A_BYTES, BN, b_row, b_k, hb, mb, lb, NPB, 0u);
+                    constexpr int PR = BEr / 2;   // pairs per B row of this thread
+                    if ((qb + 1) % PR == 0) {
+                        const int u = qb / PR;
+                        put(da + A_BYTES, BN, b_row + 64 * u, b_k, hb + u * PR, mb + u * PR, lb + u * PR, PR, 0u);
+                    }
                 }
             }
         };
@@ -1041,7 +1057,13 @@ int wn_gemm6_dw_tall(int M, int N) { return M >= 512 && (M % 256 == 0) && N >= 5
 // Column tiles of the weight-gradient kernel: 128 wide unless the last one would be at most half full -- kernel_size 3 has
 // N = 3 * 64 = 192 columns: with 128-wide tiles the second one is ragged, i.e. never takes the branch-free interior pass
 // (5.05 ms for dw_dilated of the configs[3] geometry against 1.1 ms at kernel_size 2, profiles/r03) -- then 64 wide.
-int wn_gemm6_dw_tn(int N) { return (N > 64 && (N % 128 == 0 || N % 128 > 64)) ? 2 : 1; }
+int wn_gemm6_dw_tn(int M, int N) {
+    // N = 192 (kernel_size 3 at 64 channels: three taps of 64 rows): ONE 192-column tile, so that the A operand (dP, two thirds
+    // of the launch's bytes) is read once -- with three 64-column tiles it was read three times (PMC: 11.1 GB per launch for
+    // 4.8 GB of operands, profiles/r04/pmc_traffic_config4_before.json)
+    if (N == 192 && M > 64) return 3;
+    return (N > 64 && (N % 128 == 0 || N % 128 > 64)) ? 2 : 1;
+}
 
 int wn_gemm6_dw_eligible(const WnGemmArgs* g) {
     return g->a_kmajor && g->b_kmajor && !g->b_index && !g->bias && !g->D && !g->E && !g->relu && !g->accumulate &&
@@ -1063,8 +1085,9 @@ int wn_gemm6_dw_launch(const WnGemmArgs* gp, wn_stream_t st) {
     if (g.K < 0 || g.nbatch <= 0 || g.ksplit <= 0 || g.nlayer <= 0 || g.b_seg_len <= 0 || g.kchunk <= 0) return 2;
     WN_PROF(g.tag ? g.tag : "gemm6_dw", 2.0 * g.M * g.N * (double)g.K * g.nbatch * g.nlayer,
             ((double)g.M * g.K * 4.0 + (double)g.K * 4.0 * g.N + (double)g.M * g.N * 4.0) * g.nbatch * g.nlayer, st);
-    const int tm = g.M > 64 ? 2 : 1, tn = wn_gemm6_dw_tn(g.N);
+    const int tm = g.M > 64 ? 2 : 1, tn = wn_gemm6_dw_tn(g.M, g.N);
     if (wn_gemm6_dw_tall(g.M, g.N)) return launch_dw<4, 2>(g, st);   // 256 x 128 tiles: every B row is read once per 256 A rows
+    if (tm == 2 && tn == 3) return launch_dw<2, 3>(g, st);
     if (tm == 2 && tn == 2) return launch_dw<2, 2>(g, st);
     if (tm == 2) return launch_dw<2, 1>(g, st);
     if (tn == 2) return launch_dw<1, 2>(g, st);

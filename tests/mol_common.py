@@ -37,9 +37,12 @@ def check_mol_loss_op(lib, device):
     loss, dout = eng.mol_loss(out.to(device), y.to(device), t_start=5)
     dk = dout.transpose(1, 2).cpu()
     den = float(g64.abs().max())
-    assert abs(float(loss.cpu()) - l32) <= 1e-4 * abs(l32)
-    assert float((dk - g32).abs().max()) / den <= 1e-4          # same arithmetic as the fp32 oracle
-    assert float((dk - g64).abs().max()) / den <= 2e-3          # fp32 conditioning of the published formula
+    assert abs(float(loss.cpu()) - l64) <= 1e-5 * abs(l64) and abs(l32 - l64) <= 1e-4 * abs(l64)
+    # the kernel takes a bin's mass without subtracting two sigmoids one bin apart (wn_elem.hip: mol_component), so it sits on
+    # the fp64 evaluation of the published formula; the fp32 evaluation of the same formula is the one that is ~1e-3 off
+    e32 = float((g32 - g64).abs().max()) / den
+    assert float((dk - g64).abs().max()) / den <= 2e-5
+    assert float((dk - g32).abs().max()) / den <= e32 + 2e-5
     assert float(dk[0, 20:30, 2 * nm:].abs().max()) == 0.0      # clamped log-scales get no gradient
     assert float(dk[:, :5].abs().max()) == 0.0                  # positions before t_start
 
@@ -73,13 +76,13 @@ def check_mol_training_step(lib, device):
     loss = model.mol_loss_and_backward(x.to(device), h.to(device), y.to(device))
     assert abs(float(loss.cpu()) - l64) <= 1e-4 * abs(l64)
     # With 65536 classes the published formula (differences of sigmoids one bin apart) carries ~1e-3 relative
-    # noise in fp32: the kernel must be as close to the fp64 evaluation as the fp32 evaluation of the oracle is.
+    # noise in fp32: the kernel (which avoids the subtraction) must be closer to the fp64 evaluation than that.
     for k, p in model.named_parameters():
         if p.grad is None:
             assert g64[k] is None or float(g64[k].abs().max()) == 0.0, k
             continue
         ek, eo = PC.rel_to_max(p.grad.cpu(), g64[k]), PC.rel_to_max(g32[k], g64[k])
-        assert ek <= 1e-2 and ek <= 3.0 * eo + 5e-4, (k, ek, eo)
+        assert ek <= 1e-4 + eo, (k, ek, eo)
 
 
 def check_mol_generation(lib, device):

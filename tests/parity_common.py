@@ -228,15 +228,17 @@ def run_fullsize_vs_oracle(cfg_tuple, B, T, seed, lib, device, flag_sets, scale=
     return out
 
 
-def run_mol_vs_restatement(cfg_tuple, n_mix, B, T, seed, lib, device, scale=0.05, threads=32, tol_grad=3e-3):
+def run_mol_vs_restatement(cfg_tuple, n_mix, B, T, seed, lib, device, scale=0.05, threads=32, tol_grad=TOL_GRAD):
     """Mixture-of-logistics head (NOT in the reference: parity unpinned by it) against this repo's own restatement of the
-    published formula (oracle.mol_nll): network output and loss against the oracle's; the head's gradient d(loss)/d(output)
-    against the restatement evaluated ON THE KERNEL'S OWN network output in fp32 (2e-3: the kernel's hardware exp2 / rcp against
-    torch's expf / division, through the same ill-conditioned formula) and in fp64 (the formula's fp32 conditioning: 1e-2) -- with 65536 classes the gradient of a bin's mass is a
-    difference of sigmoids one bin apart, so 1e-6 of network-output noise moves it by per cent, which is why the comparison of
-    the two NETWORKS' head gradients is reported but not gated; every parameter gradient against the oracle's fp32 autograd
-    with the HIP path's own ReLU sub-gradient choice (run_fullsize_vs_oracle's method), gate ``tol_grad`` of a tensor's
-    maximum (sums over all positions average the head's noise down to ~1e-3)."""
+    published formula (oracle.mol_nll).  With 65536 classes the published formula takes a bin's mass as the DIFFERENCE of two
+    sigmoids one part in 1e5 apart, so its fp32 evaluation carries up to per cent of rounding error in the gradient; the kernel
+    computes the same mass without the subtraction (wn_elem.hip: mol_component), which makes the fp64 evaluation of the
+    restatement the checker and the fp32 one a reported figure:
+      * network output and loss against the oracle's (fp32 network, fp32 restatement);
+      * d(loss)/d(output) against the restatement in fp64 ON THE KERNEL'S OWN network output: 1e-4 of the maximum;
+        against the fp32 restatement: no further than that evaluation is from fp64 itself (+1e-4);
+      * every parameter gradient against the oracle's fp32 autograd of the network, fed the fp64 head gradient at ITS output,
+        with the HIP path's own ReLU sub-gradient choice (run_fullsize_vs_oracle's method): ``tol_grad`` of a tensor's maximum."""
     import os
     import numpy as np
     cfg = O.OracleConfig(*cfg_tuple, out_channels=3 * n_mix)
@@ -251,6 +253,13 @@ def run_mol_vs_restatement(cfg_tuple, n_mix, B, T, seed, lib, device, scale=0.05
     grads = flat_to_state(eng, eng.backward(dout, t_first=rf).cpu(), O.param_shapes(cfg))
     m_skip = (eng.saved(_lib.WS_RELU_SKIP) > 0).float().cpu()
     m_post = (eng.saved(_lib.WS_RELU_POST1) > 0).float().cpu()
+
+    def head(o, dt):
+        oi = o.detach().clone().to(dt).requires_grad_(True)
+        l = O.mol_nll(oi, y.to(dt), start=rf)
+        l.backward()
+        return float(l.detach()), oi.grad.float()
+
     try:
         navail = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -260,26 +269,22 @@ def run_mol_vs_restatement(cfg_tuple, n_mix, B, T, seed, lib, device, scale=0.05
     try:
         leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
         out_ref = O.forward(cfg, leaves, x, h, relu_masks=(m_skip, m_post))      # (B, T, 3 n_mix)
-        out_ref.retain_grad()
-        loss_ref = O.mol_nll(out_ref, y, start=rf)
-        loss_ref.backward()
+        loss_ref, g_ref = head(out_ref, torch.float64)
+        out_ref.backward(gradient=g_ref)
+        ok = out.transpose(1, 2).cpu().contiguous()
+        _, g64 = head(ok, torch.float64)
+        loss32, g32 = head(ok, torch.float32)
     finally:
         torch.set_num_threads(old_threads)
     r = {}
-    r["out"] = float((out.transpose(1, 2).cpu() - out_ref.detach()).abs().max())
-    r["loss_rel"] = abs(float(loss.cpu()) - float(loss_ref.detach())) / abs(float(loss_ref.detach()))
-    g_out = out_ref.grad
-    r["dout_vs_oracle_network"] = float((dout.transpose(1, 2).cpu() - g_out).abs().max()) / float(g_out.abs().max())
-    # the head alone, on identical inputs (the kernel's own network output)
-    ok = out.transpose(1, 2).cpu().contiguous()
-    heads = {}
-    for dt in (torch.float32, torch.float64):
-        oi = ok.clone().to(dt).requires_grad_(True)
-        O.mol_nll(oi, y.to(dt), start=rf).backward()
-        heads[dt] = oi.grad.float()
-    den = float(heads[torch.float64].abs().max())
-    r["dout"] = float((dout.transpose(1, 2).cpu() - heads[torch.float32]).abs().max()) / den
-    r["dout_vs_fp64"] = float((dout.transpose(1, 2).cpu() - heads[torch.float64]).abs().max()) / den
+    dk = dout.transpose(1, 2).cpu()
+    den = float(g64.abs().max())
+    r["out"] = float((ok - out_ref.detach()).abs().max())
+    r["loss_rel"] = abs(float(loss.cpu()) - loss_ref) / abs(loss_ref)
+    r["dout_vs_fp64"] = float((dk - g64).abs().max()) / den
+    r["dout_vs_fp32"] = float((dk - g32).abs().max()) / den
+    r["fp32_restatement_vs_fp64"] = float((g32 - g64).abs().max()) / den
+    r["dout_vs_oracle_network"] = float((dk - g_ref).abs().max()) / float(g_ref.abs().max())
     r["grad"], r["grad_key"] = 0.0, None
     for k, v in leaves.items():
         if v.grad is None or float(v.grad.abs().max()) == 0.0:
@@ -288,7 +293,8 @@ def run_mol_vs_restatement(cfg_tuple, n_mix, B, T, seed, lib, device, scale=0.05
         e = rel_to_max(grads[k], v.grad)
         if e > r["grad"]:
             r["grad"], r["grad_key"] = e, k
-    assert r["out"] <= TOL_LOGITS and r["loss_rel"] <= 1e-4 and r["dout"] <= 2e-3 and r["dout_vs_fp64"] <= 1e-2 and r["grad"] <= tol_grad, r
+    assert r["out"] <= TOL_LOGITS and r["loss_rel"] <= 1e-4 and r["dout_vs_fp64"] <= 1e-4, r
+    assert r["dout_vs_fp32"] <= r["fp32_restatement_vs_fp64"] + 1e-4 and r["grad"] <= tol_grad, r
     return r
 
 

@@ -66,5 +66,6 @@ def test_mol_vs_restatement_harness_emulator():
     """The harness of the stated-size GPU test (tests/test_gpu_fullsize.py::test_config4_mol_head_stated_size...) on a toy
     geometry with kernel_size 3 and an upsampling layer, on the emulator."""
     from tests import parity_common as PC
-    r = PC.run_mol_vs_restatement((32, 4, 8, 12, 3, 2, 3, 4), 4, 2, 64, 31, emu_library(), "cpu", scale=0.3, threads=4, tol_grad=5e-3)
+    r = PC.run_mol_vs_restatement((32, 4, 8, 12, 3, 2, 3, 4), 4, 2, 64, 31, emu_library(), "cpu", scale=0.3, threads=4)
+    print(r)
     assert r["grad_key"] is not None
