@@ -163,7 +163,8 @@ def decode_report(model, device, with_cpu):
     out["stream_GBps_per_workgroup"] = stream_bytes / (out["batch1"]["us_per_step"] * 1e-6) / 1e9
     out["stream_note"] = "one CU sustains ~112 GB/s on a 5 MB cyclic read (tools/stream_probe.hip, profiles/r01/stream_probe.txt)"
     # the recipes' own model size (n_resch 512 / n_skipch 256, egs/arctic/sd/run.sh:46-52; decode.py:274-327): the any-size path --
-    # ONE persistent launch of 128 workgroups per chunk of steps up to 8 utterances (csrc/wn_dlp.hip), layer-wise launches above
+    # ONE persistent launch per chunk of steps: 128 workgroups up to 4 utterances (csrc/wn_dlp.hip, fp32 VALU), 64 workgroups per
+    # block of 16 utterances up to 48 (csrc/wn_dlpm.hip, 16x16x4 matrix-core tiles); layer-wise launches above
     try:
         from pytorchwavenetvocoder_amd.nets import WaveNet, initialize
         torch.manual_seed(1)
@@ -171,10 +172,11 @@ def decode_report(model, device, with_cpu):
         big.apply(initialize)
         big.to(device)
         rs = {"model": "512/256, A=80, K=2, U=80, 30 layers (the recipes' default size)"}
-        for B, n, lay in ((1, 400, True), (4, 400, True), (64, 200, "launches")):
+        for B, n, lay in ((1, 400, True), (4, 400, True), (16, 300, True), (32, 300, True), (48, 300, True), (64, 200, "launches")):
             m = decode_bench.measure(big, B, n, device, layered=lay)
             rs["batch%d" % B] = {k: m[k] for k in ("us_per_step", "samples_per_sec_per_utt", "samples_per_sec", "context_s")}
-            rs["batch%d" % B]["path"] = "one persistent launch (wn_dlp)" if lay is True else "layer-wise launches"
+            rs["batch%d" % B]["path"] = (("one persistent launch (wn_dlp)" if B <= 4 else "one persistent launch (wn_dlpm)")
+                                         if lay is True else "layer-wise launches")
         out["recipe_size"] = rs
         del big
         torch.cuda.empty_cache()

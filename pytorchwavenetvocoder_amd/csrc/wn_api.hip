@@ -1712,8 +1712,11 @@ static int dl_layout(const WnConfig* cfg, const Dims& d, int nb, DlLay* y) {
     DCARVE(O1, (long)d.S * nb);
     DCARVE(O2, (long)d.S * nb);
     DCARVE(logits, (long)d.Qo * nb);
-    wn_dlp_make_plan(d.Q, d.Qo, d.R, d.S, d.L, d.K, &y->dlp);
-    if (nb > WN_DLP_BMAX) y->dlp.ok = 0;
+    // up to WN_DLP_BMAX utterances: the VALU kernel (wn_dlp.hip); up to WN_DLPM_BMAX: the matrix-core kernel (wn_dlpm.hip)
+    wn_dlp_make_plan(d.Q, d.Qo, d.R, d.S, d.L, d.K, nb >= WN_DLPM_BMIN ? 1 : 0, &y->dlp);
+    if (nb > (y->dlp.wide ? WN_DLPM_BMAX : WN_DLP_BMAX)) y->dlp.ok = 0;
+    const int dlp_blocks = y->dlp.wide ? (nb + WN_DLPM_CB - 1) / WN_DLPM_CB : 1;   // k_dlpm: a set of units per block of 16 utterances
+    if (y->dlp.ok && y->dlp.NU * dlp_blocks > WN_DLPM_MAXWG) y->dlp.ok = 0;
     if (y->dlp.ok) {
         const WnDlpPlan& pl = y->dlp;
         DCARVE(dlp_w, (long)(d.L + 1) * pl.NU * pl.stage_floats);
@@ -1725,7 +1728,7 @@ static int dl_layout(const WnConfig* cfg, const Dims& d, int nb, DlLay* y) {
         DCARVE(dlp_gs, 2L * d.S * nb);
         DCARVE(dlp_go, 2L * d.S * nb);
         DCARVE(dlp_gl, 2L * d.Qo * nb);
-        DCARVE(dlp_pq, (long)pl.NU * y->qfloats_per_utt * nb);
+        DCARVE(dlp_pq, pl.wide ? (long)pl.NU * dlp_blocks * y->qfloats_per_utt * WN_DLPM_CB : (long)pl.NU * y->qfloats_per_utt * nb);
         DCARVE(dlp_err, 1024);   // error word (+ the stamps of a timing build)
     }
 #undef DCARVE
@@ -1863,11 +1866,11 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
         a.gz = reinterpret_cast<unsigned long long*>(ws + y.dlp_gz); a.gx = reinterpret_cast<unsigned long long*>(ws + y.dlp_gx);
         a.gs = reinterpret_cast<unsigned long long*>(ws + y.dlp_gs); a.go = reinterpret_cast<unsigned long long*>(ws + y.dlp_go);
         a.gl = reinterpret_cast<unsigned long long*>(ws + y.dlp_gl);
-        a.pq = ws + y.dlp_pq; a.pq_unit_stride = y.qfloats_per_utt * nb;
+        a.pq = ws + y.dlp_pq; a.pq_unit_stride = y.qfloats_per_utt * (y.dlp.wide ? WN_DLPM_CB : nb);
         a.queues = ws + y.queues; a.qfloats = y.qfloats_per_utt;
         a.err = reinterpret_cast<int*>(ws + y.dlp_err);
-        const int rc = wn_dlp_launch(&a, c.st);
-        if (rc != 0) return fail(3, "wn_dlp_launch failed (rc=%d)", rc);
+        const int rc = y.dlp.wide ? wn_dlpm_launch(&a, c.st) : wn_dlp_launch(&a, c.st);
+        if (rc != 0) return fail(3, "wn_dlp%s_launch failed (rc=%d)", y.dlp.wide ? "m" : "", rc);
         return rt_check("wn_decode_layered_steps");
     }
     WnDlArgs a;

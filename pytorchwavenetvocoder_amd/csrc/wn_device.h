@@ -24,6 +24,8 @@ typedef void* wn_stream_t;
     emu::launch_coop((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
 #define WN_DYN_SMEM(name) char* name = emu::S().dyn_smem
 static inline f32x16 mfma32(float a, float b, f32x16 c) { return emu::mfma_f32_32x32x2f32(a, b, c); }
+typedef emu::f32x4_t f32x4;
+static inline f32x4 mfma16(float a, float b, f32x4 c) { return emu::mfma_f32_16x16x4f32(a, b, c); }
 #define WN_UNROLL
 #define WN_UNROLL_N(n)
 // buffer access: base (wave-uniform) + per-lane byte offset (voff) + wave-uniform byte offset (soff)
@@ -98,6 +100,11 @@ static inline float wn_bits_f32(unsigned u) {
     memcpy(&f, &u, 4);
     return f;
 }
+static inline unsigned wn_f32_bits(float f) {
+    unsigned u;
+    memcpy(&u, &f, 4);
+    return u;
+}
 // two-lane fp32 vector for v_pk_fma_f32
 struct f32x2 {
     float x, y;
@@ -116,6 +123,12 @@ typedef hipStream_t wn_stream_t;
 #define WN_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 static __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// v_mfma_f32_16x16x4_f32 (exact f32, 8 passes): lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; its 4
+// accumulator registers hold D[row = 4 (l >> 4) + r][col = l & 15]
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 // Buffer access (CDNA "MUBUF"): the 128-bit resource descriptor and the scalar offset live in SGPRs,
 // only the per-lane byte offset needs a VGPR -> a tile's 32 channel rows cost ONE address VGPR
@@ -219,6 +232,7 @@ static __device__ __forceinline__ unsigned wn_pk_bf16(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, wn_bf16x2));
 }
 static __device__ __forceinline__ float wn_bits_f32(unsigned u) { return __builtin_bit_cast(float, u); }
+static __device__ __forceinline__ unsigned wn_f32_bits(float f) { return __builtin_bit_cast(unsigned, f); }
 // two-lane fp32 vector: fma on it is one v_pk_fma_f32
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ f32x2 wn_pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }

@@ -11,10 +11,17 @@
 #define WN_DLP_T 512     // threads per workgroup (8 waves: 2 per SIMD, 256 VGPRs each for the stage's weights)
 #define WN_DLP_NW 8
 #define WN_DLP_CB 4      // utterance columns per block (one 16-byte LDS read per k)
-#define WN_DLP_BMAX 8    // utterances per launch (larger batches amortise the layer-wise launches better: profiles/r04)
+#define WN_DLP_BMAX 4    // utterances per launch of the VALU kernel (k_dlp): one column block; from 5 on the matrix-core kernel
+#define WN_DLPM_CB 16    // utterance columns per block of the matrix-core kernel (k_dlpm, wn_dlpm.hip): one 16x16x4 tile
+#define WN_DLPM_BMAX 48  // utterances per launch of the matrix-core kernel: up to 3 column blocks, each with its own units
+#define WN_DLPM_MAXWG 240 // workgroups of one launch (all resident at once: one per CU, a few CUs left to whatever else runs)
+#ifndef WN_DLPM_BMIN
+#define WN_DLPM_BMIN 5   // smallest batch that takes the matrix-core kernel (372 us per step at any batch up to 16; the VALU kernel: 365 at 4, 655 at 8)
+#endif
 
 typedef struct WnDlpPlan {
     int ok;
+    int wide;                // 1: plan of the matrix-core kernel (RS = 16, batches of 9 .. 32 utterances)
     int cls;                 // compiled class: NSP / NSX k-steps per wave of the two tiles
     int RS;                  // rows per set = 2 x channels per unit (8, 16 or 32)
     int NSP, NSX;
@@ -24,7 +31,8 @@ typedef struct WnDlpPlan {
     long lds_bytes;
 } WnDlpPlan;
 // ok = 0: the model is not covered (R % 32, S / Qo rows per unit, kernel_size, class sizes)
-void wn_dlp_make_plan(int Q, int Qo, int R, int S, int L, int K, WnDlpPlan* plan);
+// wide = 0: the VALU kernel's plan (as many units as fit: B <= WN_DLP_BMAX); wide = 1: the matrix-core kernel's (16 rows per set)
+void wn_dlp_make_plan(int Q, int Qo, int R, int S, int L, int K, int wide, WnDlpPlan* plan);
 
 typedef struct WnDlpArgs {
     int Q, Qo, R, S, L, K, depth, nG;
@@ -76,3 +84,4 @@ int wn_dlp_pack_post(const float* params, long post1_w, long post2_w, int S, int
 int wn_dlp_cfold(const float* params, const float* cvec, const float* wd_f, long lb0, long lstep, long o_res_b, int L, int R, int K,
                  float* cfold, wn_stream_t st);
 int wn_dlp_launch(const WnDlpArgs* a, wn_stream_t st);
+int wn_dlpm_launch(const WnDlpArgs* a, wn_stream_t st);   // plan.wide == 1, B <= WN_DLPM_BMAX

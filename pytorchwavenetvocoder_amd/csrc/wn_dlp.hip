@@ -33,14 +33,16 @@
 
 typedef unsigned long long u64;
 
-void wn_dlp_make_plan(int Q, int Qo, int R, int S, int L, int K, WnDlpPlan* p) {
+void wn_dlp_make_plan(int Q, int Qo, int R, int S, int L, int K, int wide, WnDlpPlan* p) {
     p->ok = 0;
+    p->wide = wide;
     if (R < 32 || R % 32 != 0 || S % 16 != 0 || K < 2 || K > 3 || L < 1 || Q < 2) return;
     // As many units as the chip has room for: the weight stream of a stage is what one CU can pull (~60 GB/s measured), so
     // the fewer channels a unit owns the shorter the stage.  Channels per unit CG in {4, 8, 16} <-> rows per set RS = 2 CG.
     static const int cls[][3] = {{8, 24, 8}, {8, 32, 8}, {16, 48, 16}, {16, 64, 16}, {32, 96, 32}, {32, 128, 32}};   // RS, NSP, NSX
     for (int c = 0; c < 6; ++c) {
         const int RS = cls[c][0], CG = RS / 2, KQ = 64 / RS, slices = 8 * KQ;
+        if (wide && (RS != 16 || S % 32 != 0)) continue;   // k_dlpm: one 16x16x4 tile per row set
         if (R % CG != 0) continue;
         const int NU = R / CG;
         if (NU > 240) continue;                    // one workgroup per CU, all resident
@@ -54,6 +56,8 @@ void wn_dlp_make_plan(int Q, int Qo, int R, int S, int L, int K, WnDlpPlan* p) {
         p->post_floats = 2L * 512 * p->NSX;
         const long region0 = (long)kpad * WN_DLP_CB + 2L * 8 * 64 * WN_DLP_CB;   // input staging [CB][kpad] + partial sums
         p->lds_bytes = (region0 + 16 * WN_DLP_BMAX + 16 * WN_DLP_BMAX + 4 * WN_DLP_BMAX + 64) * 4;
+        if (wide)   // k_dlpm: inputs [kpad][17] (+ 64), partial tiles [2][8][16][16], x / skip [8][16] each, tokens, flag
+            p->lds_bytes = ((long)kpad * 17 + 64 + 4096 + 8 * WN_DLPM_CB + 8 * WN_DLPM_CB + 4 * WN_DLPM_CB + 64) * 4;
         p->ok = 1;
         return;
     }
@@ -215,7 +219,20 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
     float* pq = a.pq + (long)u * a.pq_unit_stride;
 
     // ---- set-up: private copy of the dilation queues, zero the staging rows beyond K, tokens of the context ----
-    for (long i = tid; i < a.qfloats * B; i += WN_DLP_T) pq[i] = a.queues[i];
+    {   // (16-byte copies, 8 per thread in flight: 200 MB per unit at the recipes' size and 32 utterances)
+        const wn_f4* q4 = reinterpret_cast<const wn_f4*>(a.queues);
+        wn_f4* p4 = reinterpret_cast<wn_f4*>(pq);
+        const long n4 = a.qfloats * B / 4;   // qfloats is a multiple of R, R of 32
+        for (long i = tid; i < n4; i += 8 * WN_DLP_T) {
+            wn_f4 v[8];
+            WN_UNROLL
+            for (int j = 0; j < 8; ++j)
+                if (i + j * WN_DLP_T < n4) v[j] = q4[i + j * WN_DLP_T];
+            WN_UNROLL
+            for (int j = 0; j < 8; ++j)
+                if (i + j * WN_DLP_T < n4) p4[i + j * WN_DLP_T] = v[j];
+        }
+    }
     for (int i = tid; i < REG0; i += WN_DLP_T) s_in[i] = 0.0f;
     for (int i = tid; i < 16 * BM; i += WN_DLP_T) { s_xown[i] = 0.0f; s_sk[i] = 0.0f; }
     for (int i = tid; i < K * B; i += WN_DLP_T) {
@@ -237,16 +254,43 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
         }
         return v;
     };
-    // bounded poll of one granule for `tag`
-    auto wait_granule = [&](const u64* p, unsigned tag) -> float {
-        u64 v = wn_granule_load(p);
+    // Bounded poll of the N granules a thread has requested: whatever is not there yet is requested again TOGETHER.  (A unit
+    // that is early finds none of its granules ready; polled one after the other that was one memory round trip per element:
+    // 21.7 us per stage in the first build of wn_dlpm.hip, profiles/r04/NOTES.md.)
+    auto poll_all = [&](auto n_c, const u64* const* gp, u64* gv, unsigned tag) {
+        constexpr int N = decltype(n_c)::value;
         int spin = 0;
-        while ((unsigned)(v >> 32) != tag) {
+        for (;;) {
+            bool all = true;
+            WN_UNROLL
+            for (int j = 0; j < N; ++j) all = all && (gp[j] == nullptr || (unsigned)(gv[j] >> 32) == tag);
+            if (all) break;
             if (++spin > DLP_SPIN_MAX || s_flag[0]) { s_flag[0] = 1; break; }
             WN_SLEEP(1);
-            v = wn_granule_load(p);
+            WN_UNROLL
+            for (int j = 0; j < N; ++j)
+                if (gp[j] != nullptr && (unsigned)(gv[j] >> 32) != tag) gv[j] = wn_granule_load(gp[j]);
         }
-        return wn_bits_f32((unsigned)v);
+    };
+    // gather of a complete vector (post net, logits) into s_in[uc][k]: 4 granules per thread in flight
+    auto gather_vec = [&](const u64* src, int rows, int nbc, int cb, unsigned tag) {
+        for (int base = tid; base < rows * nbc; base += 4 * WN_DLP_T) {
+            const u64* gp[4];
+            u64 gv[4];
+            WN_UNROLL
+            for (int j = 0; j < 4; ++j) {
+                const int idx = base + j * WN_DLP_T;
+                gp[j] = idx < rows * nbc ? src + (long)(idx / nbc) * B + cb * CB + idx % nbc : nullptr;
+                gv[j] = 0;
+                if (gp[j]) gv[j] = wn_granule_load(gp[j]);
+            }
+            poll_all(std::integral_constant<int, 4>(), gp, gv, tag);
+            WN_UNROLL
+            for (int j = 0; j < 4; ++j) {
+                const int idx = base + j * WN_DLP_T;
+                if (gp[j]) s_in[(idx % nbc) * KPAD + idx / nbc] = wn_bits_f32((unsigned)gv[j]);
+            }
+        }
     };
     // a wave's slice of a row set's weights: NS / 4 non-temporal 16-byte loads per lane (every weight is read once per step)
     auto load_weights = [&](auto& w, auto ns_c, const float* img) {
@@ -340,22 +384,14 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
                             if (gp[j]) gv[j] = wn_granule_load(gp[j]);
                         }
                     }
+                    poll_all(std::integral_constant<int, GB>(), gp, gv, tag0 + (unsigned)(s - 1));
                     WN_UNROLL
                     for (int j = 0; j < GB; ++j) {
                         const int idx = base + j * WN_DLP_T;
                         if (idx < krows * nbc) {
                             const int k = idx / nbc, uc = idx % nbc, b = cb * CB + uc;
                             float v = fv[j];
-                            if (gp[j]) {
-                                const unsigned tag = tag0 + (unsigned)(s - 1);
-                                int spin = 0;
-                                while ((unsigned)(gv[j] >> 32) != tag) {
-                                    if (++spin > DLP_SPIN_MAX || s_flag[0]) { s_flag[0] = 1; break; }
-                                    WN_SLEEP(1);
-                                    gv[j] = wn_granule_load(gp[j]);
-                                }
-                                v = wn_bits_f32((unsigned)gv[j]);
-                            }
+                            if (gp[j]) v = wn_bits_f32((unsigned)gv[j]);
                             if (k >= R && k < 2 * R && s >= 1) {   // x_{s-1} of this step goes into the unit's own ring of layer s-1
                                 const int dp = 1 << ((s - 1) % a.depth), Dp = (K - 1) * dp;
                                 pq[(dlp_queue_off(s - 1, a.depth, K, R) + (long)(p % Dp) * R + (k - R)) * B + b] = v;
@@ -474,10 +510,7 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
             const u64* src = stage == 0 ? a.gs : a.go;
             for (int cb = 0; cb < ncb; ++cb) {
                 const int nbc = (B - cb * CB) < CB ? (B - cb * CB) : CB;
-                for (int idx = tid; idx < S * nbc; idx += WN_DLP_T) {
-                    const int k = idx / nbc, uc = idx % nbc;
-                    s_in[uc * KPAD + k] = wait_granule(src + (long)k * B + cb * CB + uc, tag0 + (unsigned)(L + 1 + stage));
-                }
+                gather_vec(src, S, nbc, cb, tag0 + (unsigned)(L + 1 + stage));
                 constexpr int PPASS = (RS * CB * 8 + WN_DLP_T - 1) / WN_DLP_T;
                 float pb[PPASS];   // the row's bias, ahead of the next weight stream
                 WN_UNROLL
@@ -525,10 +558,7 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
         // ---- token choice, by every unit for itself (wavenet.py:371-381): first-max argmax or inverse CDF on the caller's draw ----
         for (int cb = 0; cb < ncb; ++cb) {
             const int nbc = (B - cb * CB) < CB ? (B - cb * CB) : CB;
-            for (int idx = tid; idx < Qo * nbc; idx += WN_DLP_T) {
-                const int q = idx / nbc, uc = idx % nbc;
-                s_in[uc * KPAD + q] = wait_granule(a.gl + (long)q * B + cb * CB + uc, tag0 + (unsigned)(L + 3));
-            }
+            gather_vec(a.gl, Qo, nbc, cb, tag0 + (unsigned)(L + 3));
             __syncthreads();
             if (tid < CB && cb * CB + tid < B) {
                 const int b = cb * CB + tid;

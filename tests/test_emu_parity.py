@@ -587,14 +587,14 @@ def test_windowed_forward_loss_workspace_and_the_parameter_guard():
 def test_any_size_decode_as_one_persistent_launch():
     """csrc/wn_dlp.hip on the emulator's cooperative launch (every workgroup alive at once; they hand their vectors to each
     other as tagged granules): a 32-channel model = 2 workgroups, kernel_size 2 and 3, one utterance, three ragged ones and
-    7 (two column blocks of 4) -- logits within 1e-4 of the queue algorithm (oracle; the res 1x1 is folded into the next layer's
+    4 (a full column block; from 5 on the batch goes to wn_dlpm.hip, next test) -- logits within 1e-4 of the queue algorithm (oracle; the res 1x1 is folded into the next layer's
     newest tap, so the rounding differs from the layer-wise launches), tokens equal to the oracle's and to the launches', the
     launch log shows ONE dlp_steps launch per chunk and no layer-wise launch, and inverse-CDF sampling on the same draws picks
     the same tokens as the launches."""
     import numpy as np
     from oracle import wavenet_oracle as O
     from pytorchwavenetvocoder_amd.nets import WaveNet
-    for K, B in ((2, 1), (3, 3), (2, 7)):
+    for K, B in ((2, 1), (3, 3), (2, 4)):
         cfg_t = (32, 4, 32, 32, 3, 2, K, 4)
         cfg = O.OracleConfig(*cfg_t)
         params = O.random_params(cfg, 9 + K, scale=0.3)
@@ -616,6 +616,45 @@ def test_any_size_decode_as_one_persistent_launch():
             safe = ((top2[:, 0] - top2[:, 1]) > 1e-3).numpy()
             assert (tp[b].numpy()[safe] == np.asarray(rt)[safe]).all() and (tp[b].numpy()[safe] == tl[b].numpy()[safe]).all(), (K, B, b)
         if B == 3:
+            torch.manual_seed(5)
+            sp = model.engine.decode(xs, hs, ns, mode="sampling", layered=True)
+            torch.manual_seed(5)
+            sl = model.engine.decode(xs, hs, ns, mode="sampling", layered="launches")
+            assert all(torch.equal(a, b) for a, b in zip(sp, sl))
+
+
+def test_any_size_decode_of_wide_batches_on_the_matrix_cores():
+    """csrc/wn_dlpm.hip (batches of 5 .. 48 utterances: 16-row sets x 16-column blocks on v_mfma_f32_16x16x4_f32, 8 channels per
+    workgroup, one set of workgroups per column block) on the emulator's cooperative launch: a 32-channel model = 4 workgroups
+    per block, kernel_size 2 with 12 ragged utterances (one ragged column block) and kernel_size 3 with 19 (a full block and a
+    block of 3: 8 workgroups) -- logits within 1e-4 of the queue
+    algorithm (oracle), tokens equal to the oracle's and to the layer-wise launches', ONE dlpm_steps launch per chunk and no
+    layer-wise launch in the log, inverse-CDF sampling on the same draws equal to the launches'."""
+    import numpy as np
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd.nets import WaveNet
+    for K, B in ((2, 12), (3, 19)):
+        cfg_t = (32, 4, 32, 32, 3, 2, K, 4)
+        cfg = O.OracleConfig(*cfg_t)
+        params = O.random_params(cfg, 9 + K, scale=0.3)
+        model = WaveNet(*cfg_t, _library=emu_library())
+        model.load_state_dict(params)
+        rs = np.random.RandomState(12 + B)
+        xs = torch.from_numpy(rs.randint(0, 32, (B, 5))).long()
+        hs = torch.from_numpy(rs.standard_normal((B, 4, 8)).astype(np.float32))
+        ns = [8 - (b % 3) for b in range(B)]
+        out = {}
+        log = PC.launch_log(emu_library(), lambda: out.update(p=model.engine.decode(xs, hs, ns, chunk=4, return_logits=True, layered=True)))
+        assert log.get("dlpm_steps", 0) >= 2 and "dlp_steps" not in log and "dl_dilated" not in log and "dl_res" not in log, log
+        tp, lp = out["p"]
+        tl, ll = model.engine.decode(xs, hs, ns, chunk=4, return_logits=True, layered="launches")
+        for b in range(B):
+            rt, rl = O.fast_generate(cfg, params, xs[b:b + 1], hs[b:b + 1], ns[b], return_logits=True)
+            assert float((lp[b] - rl).abs().max()) <= 1e-4, (K, B, b)
+            top2 = rl.topk(2, dim=1).values
+            safe = ((top2[:, 0] - top2[:, 1]) > 1e-3).numpy()
+            assert (tp[b].numpy()[safe] == np.asarray(rt)[safe]).all() and (tp[b].numpy()[safe] == tl[b].numpy()[safe]).all(), (K, B, b)
+        if K == 2:
             torch.manual_seed(5)
             sp = model.engine.decode(xs, hs, ns, mode="sampling", layered=True)
             torch.manual_seed(5)

@@ -301,10 +301,10 @@ def test_decode_wide_model_layered_path_long_k():
 
 
 def test_decode_any_size_persistent_launch_vs_oracle_and_launches():
-    """csrc/wn_dlp.hip: the any-size decode as ONE launch of n_resch / 16 workgroups that hand their vectors to each other as
+    """csrc/wn_dlp.hip / wn_dlpm.hip: the any-size decode as ONE launch of workgroups that hand their vectors to each other as
     tagged granules (wavenet.py:355-385, 538-549, 518-523 with the res 1x1 folded into the next layer's newest tap).  A
-    128-channel model (8 workgroups, the small class; kernel_size 3; 7 utterances = two column blocks, ragged lengths) and
-    the recipes' own size (n_resch 512 / n_skipch 256: 32 workgroups, 256 KB of weights per workgroup and stage): logits within
+    128-channel model (kernel_size 3; 7 ragged utterances: from 5 on the batch takes the matrix-core kernel wn_dlpm.hip, 16
+    workgroups) and the recipes' own size (n_resch 512 / n_skipch 256, 2 utterances: the VALU kernel, 128 workgroups): logits within
     1e-4 of the queue algorithm (oracle), tokens equal wherever the oracle's argmax is not a near-tie, the same against the
     layer-wise launches it replaces, both ways of building the context queues, and the sampling mode runs."""
     from pytorchwavenetvocoder_amd.nets import WaveNet
@@ -336,6 +336,47 @@ def test_decode_any_size_persistent_launch_vs_oracle_and_launches():
                 assert (tp[i].cpu().numpy()[safe] == tl[i].cpu().numpy()[safe]).all(), (cfg_t, prefill, i)
         ts = model.engine.decode(x.to(DEV), h.to(DEV), ns, mode="sampling")
         assert all(int(t.min()) >= 0 and int(t.max()) < cfg.n_quantize and len(t) == k for t, k in zip(ts, ns))
+
+
+def test_decode_any_size_wide_batches_on_the_matrix_cores():
+    """csrc/wn_dlpm.hip (5 .. 48 utterances: 16 x 16 tiles of v_mfma_f32_16x16x4_f32, one set of n_resch / 8 workgroups per block
+    of 16 utterances) at the recipes' own size (n_resch 512 / n_skipch 256): 18 ragged utterances = 2 blocks = 128 workgroups.
+    Every utterance against the layer-wise launches it replaces (logits 1e-4, tokens equal away from near-ties), the first
+    one, the last one of block 0 and the last one of block 1 against the queue algorithm (oracle) as well; the launch log shows
+    the persistent kernel and no layer-wise launch; the sampling mode draws the same tokens as the launches."""
+    from pytorchwavenetvocoder_amd.nets import WaveNet
+    from tests import parity_common as PC
+    cfg_t, B, n, seed = (256, 80, 512, 256, 10, 3, 2, 80), 18, 10, 23
+    cfg = O.OracleConfig(*cfg_t)
+    params = O.random_params(cfg, seed, scale=0.02)
+    model = WaveNet(*cfg_t)
+    model.load_state_dict(params)
+    model.to(DEV)
+    rs = np.random.RandomState(seed)
+    x = torch.from_numpy(rs.randint(0, cfg.n_quantize, (B, 4))).long()
+    h = torch.from_numpy(rs.standard_normal((B, cfg.n_aux, (4 + n) // 80 + 2)).astype(np.float32))
+    ns = [n - (b % 4) for b in range(B)]
+    out = {}
+    log = PC.launch_log(model.engine.lib, lambda: out.update(p=model.engine.decode(x.to(DEV), h.to(DEV), ns, return_logits=True)))
+    assert log.get("dlpm_steps", 0) >= 1 and "dl_dilated" not in log and "dlp_steps" not in log, log
+    tp, lp = out["p"]
+    tl, ll = model.engine.decode(x.to(DEV), h.to(DEV), ns, return_logits=True, layered="launches")
+    for i in range(B):
+        assert float((lp[i] - ll[i]).abs().max()) <= 1e-4, i
+        top2 = ll[i].topk(2, dim=1).values
+        safe = ((top2[:, 0] - top2[:, 1]) > 1e-3).cpu().numpy()
+        assert (tp[i].cpu().numpy()[safe] == tl[i].cpu().numpy()[safe]).all(), i
+    for i in (0, 15, 17):
+        rt, rl = O.fast_generate(cfg, params, x[i:i + 1], h[i:i + 1], ns[i], return_logits=True)
+        assert float((lp[i].cpu() - rl).abs().max()) <= 1e-4, i
+        top2 = rl.topk(2, dim=1).values
+        safe = ((top2[:, 0] - top2[:, 1]) > 1e-3).numpy()
+        assert (tp[i].cpu().numpy()[safe] == np.asarray(rt)[safe]).all(), i
+    torch.manual_seed(5)
+    sp = model.engine.decode(x.to(DEV), h.to(DEV), ns, mode="sampling")
+    torch.manual_seed(5)
+    sl = model.engine.decode(x.to(DEV), h.to(DEV), ns, mode="sampling", layered="launches")
+    assert all(torch.equal(a, b) for a, b in zip(sp, sl))
 
 
 def test_decode_any_size_model_uses_the_layered_path():
