@@ -61,7 +61,7 @@ LAYERS_PER_BUCKET = 30      # gradient buckets = weight-gradient launch groups; 
 #   dX             write dx_l (its inputs dP never leave the chip)       1R
 ALG_BYTES_PER_TIMESTEP_OF = {"fused_resblock_fwd": 4 * 64 * 4, "fused_bwd_gate": 3 * 64 * 4, "fused_bwd_dx": 64 * 4,
                              "fused_bwd_chain": 4 * 64 * 4}
-PMC_FILES = ["profiles/r03/pmc_traffic.json", "profiles/r02/pmc_traffic.json"]
+PMC_FILES = ["profiles/r04/pmc_traffic.json", "profiles/r03/pmc_traffic.json", "profiles/r02/pmc_traffic.json"]
 
 
 def geometry(rf, batch_length, U):
