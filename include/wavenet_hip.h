@@ -300,9 +300,11 @@ int wn_decode_steps(const WnConfig* cfg, int B, const float* params, const float
  * same state with params == NULL keeps the packed weights and only projects the given window of h (a decode
  * without an upsampling layer projects one window of aux columns per chunk of steps). */
 int64_t wn_decode_layered_state_floats(const WnConfig* cfg, int B);
-/* Since ABI v7: for models the plan of csrc/wn_dlp.h covers (n_resch % 32 == 0, kernel_size 2 or 3, B <= 8, softmax head)
- * wn_decode_layered_steps runs the whole range of steps as ONE launch of n_resch / 16 workgroups that hand their vectors to
- * each other as 8-byte {value, tag} granules (the recipes' n_resch = 512 model: 66 dependent launches per step before).
+/* Since ABI v7: for models the plan of csrc/wn_dlp.h covers (n_resch % 32 == 0, kernel_size 2 or 3, B <= 48, softmax head)
+ * wn_decode_layered_steps runs the whole range of steps as ONE launch of workgroups that hand their vectors to each other as
+ * 8-byte {value, tag} granules (the recipes' n_resch = 512 model: 66 dependent launches per step before): n_resch / 4
+ * workgroups with fp32 VALU dot products up to 4 utterances (wn_dlp.hip), n_resch / 8 workgroups per block of 16 utterances with
+ * v_mfma_f32_16x16x4_f32 tiles from 5 to 48 (wn_dlpm.hip; all workgroups must be resident: at most 240).
  * `mode | WN_DECODE_BY_LAUNCHES` keeps the layer-wise launches (independent check, A/B).  The persistent launch bounds every
  * wait; wn_decode_layered_error_offset() is the float offset in `state` of an int that is non-zero afterwards if a wait
  * timed out (-1: this model / B decodes by launches). */

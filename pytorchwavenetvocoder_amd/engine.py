@@ -318,8 +318,8 @@ class WaveNetEngine(object):
         Two kernels implement it: the persistent one-workgroup-per-utterance kernel (model sizes covered by
         ``decode_supported()``) and the any-size path (``layered=True``; chosen automatically when the first does not
         apply, e.g. the n_resch = 512 recipe default).  The any-size path is itself ONE persistent launch per chunk of
-        steps where csrc/wn_dlp.hip covers the model (n_resch / 16 workgroups handing their vectors to each other) and
-        layer-wise launches otherwise; ``layered="launches"`` forces the launches (independent check, A/B).
+        steps where csrc/wn_dlp.hip / wn_dlpm.hip cover the model and the batch (up to 48 utterances: workgroups handing
+        their vectors to each other) and layer-wise launches otherwise; ``layered="launches"`` forces the launches (independent check, A/B).
 
         ``prefill``: how the dilation queues of the context are built.  "parallel" (default) does what the
         reference does (wavenet.py:338-349): one forward of the residual stack over the whole padded context
