@@ -260,6 +260,18 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
     auto poll_all = [&](auto n_c, const u64* const* gp, u64* gv, unsigned tag) {
         constexpr int N = decltype(n_c)::value;
         int spin = 0;
+#ifdef WN_DLP_SEQ_POLL   // A/B: one element after the other (the round-4 first build)
+        WN_UNROLL
+        for (int j = 0; j < N; ++j) {
+            if (gp[j] == nullptr) continue;
+            while ((unsigned)(gv[j] >> 32) != tag) {
+                if (++spin > DLP_SPIN_MAX || s_flag[0]) { s_flag[0] = 1; break; }
+                WN_SLEEP(1);
+                gv[j] = wn_granule_load(gp[j]);
+            }
+        }
+        return;
+#endif
         for (;;) {
             bool all = true;
             WN_UNROLL
