@@ -243,6 +243,10 @@ int wn_op_causal_conv(const float* weight, const float* bias, const float* x /*(
 /* UpSampling.forward (wavenet.py:124-154, since ABI v7): y (B, C, F*U) = x (B, C, F) through the (1, U) transposed
  * convolution with ONE kernel `weight` [U] and scalar `bias` (nullable) shared by all channels. */
 int wn_op_upsampling(const float* weight, const float* bias, const float* x, float* y, int B, int C, int F, int U, void* stream);
+/* dst (B, C, R) = src (B, R, C) with the last two axes swapped (LDS-tiled): the reference's logits are (B, T, n_quantize)
+ * (wavenet.py:522), the kernels' (B, n_quantize, T) -- used for a gradient handed back by an external loss (train.py:534-538
+ * through autograd).  src != dst. */
+int wn_op_transpose_last2(const float* src, float* dst, int B, int R, int C, void* stream);
 
 /* Generic C[z] = A.B contraction on the f32 matrix cores; argument block: wavenet_hip_gemm.h (struct WnGemmArgs,
  * the inline helper wn_gemm_default fills the neutral values). */

@@ -1530,6 +1530,15 @@ extern "C" int wn_op_upsampling(const float* weight, const float* bias, const fl
     return rt_check("wn_op_upsampling");
 }
 
+// dst (B, C, R) = src (B, R, C) transposed: the layout change between the reference's logits (B, T, Q) (wavenet.py:522) and the
+// kernels' (B, Q, T), for a gradient that arrives from an external loss (nets/wavenet.py: the autograd bridge).
+extern "C" int wn_op_transpose_last2(const float* src, float* dst, int B, int R, int C, void* stream) {
+    api_enter();
+    if (!src || !dst || src == dst || B < 1 || R < 1 || C < 1 || (long)((R + 31) / 32) > 65535 || B > 65535) return fail(1, "bad argument");
+    WN_TRY(wn_transpose_last2(src, dst, B, R, C, (wn_stream_t)stream));
+    return rt_check("wn_op_transpose_last2");
+}
+
 // ------------------------------------------------------------------------------------------
 // autoregressive decode (wavenet.py:309-511, 538-549)
 // ------------------------------------------------------------------------------------------

@@ -199,3 +199,5 @@ int wn_decode_ctx_aux_rows(const float* h, const float* upw, const float* upb, f
 // position of column 0 of X), dst[(queue_off(l) + slot*R + c) * elem_stride + b * utt_stride] = X[l][b][c][q].
 int wn_decode_fill_queues(const float* X, float* dst, int L, int B, int R, int T, int K, int depth, int P0, int pos0,
                           long elem_stride, long utt_stride, wn_stream_t st);
+// (B, R, C) -> (B, C, R)
+int wn_transpose_last2(const float* src, float* dst, int B, int R, int C, wn_stream_t st);

@@ -981,6 +981,34 @@ int wn_front_dw(const float* dX0, const int64_t* x, float* partial, float* dW, f
 }
 
 // ---------------------------------------------------------------------------------------------
+// (B, R, C) -> (B, C, R): 32 x 32 tiles through LDS (rows padded to 33 words), both sides in full 128-byte segments.  The
+// autograd bridge's gradient arrives as (B, T, Q) (the reference's logits layout, wavenet.py:522); the kernels take (B, Q, T).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_transpose_last2(const float* __restrict__ src, float* __restrict__ dst, int R, int C) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const long zb = (long)blockIdx.z * R * C;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    WN_UNROLL
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (r < R && c < C) ? src[zb + (long)r * C + c] : 0.0f;
+    }
+    __syncthreads();
+    WN_UNROLL
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (r < R && c < C) dst[zb + (long)c * R + r] = tile[tx][ty + 8 * i];
+    }
+}
+
+int wn_transpose_last2(const float* src, float* dst, int B, int R, int C, wn_stream_t st) {
+    WN_PROF("transpose", 0.0, (double)B * R * C * 8.0, st);
+    WN_LAUNCH(k_transpose_last2, dim3((unsigned)((C + 31) / 32), (unsigned)((R + 31) / 32), (unsigned)B), dim3(256), 0, st, src, dst, R, C);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // any-size decode helpers (see wn_elem.h)
 // ---------------------------------------------------------------------------------------------
 static __device__ __forceinline__ long dl_queue_off(int l, int depth, int K, int R) {

@@ -22,7 +22,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import _lib
-from ..engine import WaveNetEngine, key_to_kind
+from ..engine import WaveNetEngine, _stream_handle, key_to_kind
 
 
 def encode_mu_law(x, mu=256):
@@ -168,8 +168,15 @@ class _WaveNetFunction(torch.autograd.Function):
         if ctx.serial != model._fwd_serial:
             raise _lib.WnError("WaveNet backward after a newer forward: the HIP path keeps the activations "
                                "of the latest forward only")
-        dl = grad_out.transpose(1, 2).contiguous()
-        flat = model._engine.backward(dl).clone()
+        eng = model._engine
+        if grad_out.is_contiguous() and grad_out.dtype == torch.float32:   # (B, T, Q) -> the kernels' (B, Q, T) on the HIP op
+            B, T, Q = grad_out.shape
+            dl = torch.empty((B, Q, T), dtype=torch.float32, device=grad_out.device)
+            st = _stream_handle(grad_out.device)
+            eng.lib.check(eng.lib.wn_op_transpose_last2(grad_out.data_ptr(), dl.data_ptr(), B, T, Q, st), "wn_op_transpose_last2")
+        else:   # a view that already is (B, Q, T) underneath (e.g. the transposed logits themselves), or another dtype
+            dl = grad_out.transpose(1, 2).contiguous().float()
+        flat = eng.backward(dl).clone()
         grads = []
         for (off, n, shape, dead) in model._param_slices:
             grads.append(None if dead else flat[off:off + n].view(shape))

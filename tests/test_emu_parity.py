@@ -677,3 +677,14 @@ def test_front_conv_weight_gradient_on_the_matrix_cores():
             log["err"] = (e, g)
         counts = PC.launch_log(emu_library(), run)
         assert counts.get("dw_front_scatter") == 1 and "dw_front_onehot" not in counts, counts
+
+
+def test_transpose_op_on_the_emulator():
+    """wn_op_transpose_last2 ((B, R, C) -> (B, C, R), the autograd bridge's layout change): bit-exact, ragged tiles."""
+    lib = emu_library()
+    for B, R, C in ((2, 37, 70), (1, 64, 32)):
+        x = torch.randn(B, R, C)
+        y = torch.empty(B, C, R)
+        lib.check(lib.wn_op_transpose_last2(x.data_ptr(), y.data_ptr(), B, R, C, None), "wn_op_transpose_last2")
+        assert torch.equal(y, x.transpose(1, 2).contiguous())
+    assert lib.wn_op_transpose_last2(x.data_ptr(), x.data_ptr(), 1, 4, 4, None) != 0   # in place: refused

@@ -62,3 +62,41 @@ def test_upsampling_module_on_the_gpu_vs_reference_vector():
     out = conv(aux.to(DEV)).cpu()
     assert out.shape[-1] == aux.shape[-1] * 10
     assert torch.equal(out, aux.repeat_interleave(10, dim=2))
+
+
+def test_transpose_op_and_the_autograd_bridge_with_an_external_loss():
+    """wn_op_transpose_last2 ((B, R, C) -> (B, C, R): bit-exact, ragged tiles) and what it is for: ``model(x, h)`` under an
+    EXTERNAL loss (the reference's own training step, train.py:534-538 -- nn.CrossEntropyLoss on the (B, T, Q) logits) hands a
+    (B, T, Q) gradient back through autograd; the bridge moves it into the kernels' (B, Q, T) layout with this op."""
+    lib = _lib()
+    import ctypes
+    for B, R, C in ((2, 37, 70), (1, 64, 32), (3, 5, 257)):
+        x = torch.randn(B, R, C, device=DEV)
+        y = torch.empty(B, C, R, device=DEV)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        lib.check(lib.wn_op_transpose_last2(x.data_ptr(), y.data_ptr(), B, R, C, st), "wn_op_transpose_last2")
+        assert torch.equal(y, x.transpose(1, 2).contiguous())
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd.nets import WaveNet
+    cfg_t = (32, 4, 32, 32, 3, 1, 2, 4)
+    cfg = O.OracleConfig(*cfg_t)
+    params = O.random_params(cfg, 7, scale=0.2)
+    xb, hb, tb = O.synthetic_batch(cfg, 2, 48, 8)
+    model = WaveNet(*cfg_t)
+    model.load_state_dict(params)
+    model.to(DEV)
+    out = model(xb.to(DEV), hb.to(DEV))                       # (B, T, Q)
+    loss = torch.nn.functional.cross_entropy(out[:, cfg.receptive_field:].reshape(-1, cfg.n_quantize),
+                                             tb[:, cfg.receptive_field:].reshape(-1).to(DEV))
+    loss.backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = torch.nn.functional.cross_entropy(O.forward(cfg, leaves, xb, hb)[:, cfg.receptive_field:].reshape(-1, cfg.n_quantize),
+                                            tb[:, cfg.receptive_field:].reshape(-1))
+    ref.backward()
+    assert abs(float(loss) - float(ref)) <= 1e-5
+    for k, p in model.named_parameters():
+        g = leaves[k].grad
+        if p.grad is None:
+            assert g is None or float(g.abs().max()) == 0.0, k
+            continue
+        assert float((p.grad.cpu() - g).abs().max()) <= 1e-4 * max(float(g.abs().max()), 1e-12) + 1e-7, k
