@@ -654,8 +654,11 @@ int wn_fill_cols(float* p, long rows, long stride, int ncols, wn_stream_t st) {
 // ---------------------------------------------------------------------------------------------
 // front-conv weight gradient as a scatter (see wn_elem.h)
 // ---------------------------------------------------------------------------------------------
-static void front_dw_grid(int B, int T, int* nchunk, int* chunk) {
-    int nc = 256 / (B > 0 ? B : 1);  // one workgroup per CU (the table fills its LDS)
+static bool front_dw_mfma_ok(int R, int K, int Q);
+// row groups of the matrix-core kernel: a workgroup contracts 64 rows of dX0 (all of them up to 64 channels)
+static int front_dw_row_groups(int R, int K, int Q) { return (front_dw_mfma_ok(R, K, Q) && R > 64) ? R / 64 : 1; }
+static void front_dw_grid(int B, int T, int RG, int* nchunk, int* chunk) {
+    int nc = 256 / ((B > 0 ? B : 1) * RG);  // one workgroup per CU (the table fills its LDS)
     if (nc < 1) nc = 1;
     int ch = (T + nc - 1) / nc;
     ch = (ch + 63) / 64 * 64;
@@ -664,7 +667,6 @@ static void front_dw_grid(int B, int T, int* nchunk, int* chunk) {
     *nchunk = (T + ch - 1) / ch;
 }
 
-static bool front_dw_mfma_ok(int R, int K, int Q);
 // the matrix-core kernel (small LDS), or the scatter kernel with its [R][K*Q] table in LDS
 int wn_front_dw_supported(int R, int K, int Q) {
     return (front_dw_mfma_ok(R, K, Q) || ((long)R * K * Q + R) * 4 <= 150 * 1024) && K <= 8;
@@ -672,7 +674,7 @@ int wn_front_dw_supported(int R, int K, int Q) {
 
 long wn_front_dw_partial_floats(int B, int T, int R, int K, int Q) {
     int nc, ch;
-    front_dw_grid(B, T, &nc, &ch);
+    front_dw_grid(B, T, front_dw_row_groups(R, K, Q), &nc, &ch);
     return (long)B * nc * ((long)R * K * Q + R);
 }
 
@@ -787,7 +789,9 @@ __global__ __launch_bounds__(FD_T) void k_front_dw_scatter(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
-// The same partial tables on the matrix cores, without atomics (R <= 64, K Q <= 512: the benchmark's front conv).
+// The same partial tables on the matrix cores, without atomics (R = 32 or a multiple of 64 -- blockIdx.z = group of 64 rows --,
+// K Q <= 1024: the benchmark's front conv, and the recipes' n_resch = 512, where the one-hot contraction through k_gemm6_dw took
+// 0.9 ms per step).
 // LDS float atomics retire about one lane per 3 cycles on gfx950: the 1 536 wave-atomics of a k_front_dw_scatter workgroup
 // cost 125 us, two thirds of that launch (profiles/r02/front_dw_probe.txt).  Here the table of a workgroup's time chunk is
 //      acc[c][(k, q)] = sum_t dX0[c][t] * onehot(x[t - (K-1-k)])[q]
@@ -808,8 +812,9 @@ __global__ __launch_bounds__(FM_T) void k_front_dw_mfma(const float* __restrict_
     const int b = blockIdx.y, t0 = blockIdx.x * chunk;
     const int t1 = (t0 + chunk < T) ? t0 + chunk : T;
     const int KQ = K * Q;
+    const int r0 = 64 * (int)blockIdx.z;   // this workgroup's rows of dX0 / of the table
     const int64_t* xb = x + (long)b * T;
-    const float* db = dX0 + (long)b * R * T;
+    const float* db = dX0 + ((long)b * R + r0) * T;
     float* out = partial + ((long)b * gridDim.x + blockIdx.x) * ((long)R * KQ + R);
     // tokens of positions [t0 - (K-1), t1): index i <-> position t0 - (K-1) + i; -1 in front of the sequence
     for (int i = tid; i < (t1 - t0) + K - 1; i += FM_T) {
@@ -850,11 +855,11 @@ __global__ __launch_bounds__(FM_T) void k_front_dw_mfma(const float* __restrict_
         acc[ct][0] = f32x16_zero();
         acc[ct][1] = f32x16_zero();
     }
-    const int nrt = R >> 5;
+    const int nrt = (R - r0) >= 64 ? 2 : (R - r0) >> 5;
     auto stage_pair = [&](int ts, int buf) {
         const int t = ts + 2 * pkq;
-        const float x0 = (prow < R && t < t1) ? prowp[t] : 0.0f;
-        const float x1 = (prow < R && t + 1 < t1) ? prowp[t + 1] : 0.0f;
+        const float x0 = (r0 + prow < R && t < t1) ? prowp[t] : 0.0f;
+        const float x1 = (r0 + prow < R && t + 1 < t1) ? prowp[t + 1] : 0.0f;
         rsum += x0 + x1;
         const unsigned h = wn_pk_bf16(x0, x1);
         const float r0 = x0 - wn_bits_f32(h << 16), r1 = x1 - wn_bits_f32(h & 0xffff0000u);
@@ -906,18 +911,18 @@ __global__ __launch_bounds__(FM_T) void k_front_dw_mfma(const float* __restrict_
         for (int rt = 0; rt < 2; ++rt) {
             if (rt < nrt) {
                 WN_UNROLL
-                for (int r = 0; r < 16; ++r) out[(long)(32 * rt + mfma32_row(r, hi)) * KQ + col[ct]] = acc[ct][rt][r];
+                for (int r = 0; r < 16; ++r) out[(long)(r0 + 32 * rt + mfma32_row(r, hi)) * KQ + col[ct]] = acc[ct][rt][r];
             }
         }
     }
     // bias gradient: the 16 threads of a row are adjacent lanes
     for (int m = 1; m < 16; m <<= 1) rsum += __shfl_xor(rsum, m, 64);
-    if (pkq == 0 && prow < R) out[(long)R * KQ + prow] = rsum;
+    if (pkq == 0 && r0 + prow < R) out[(long)R * KQ + r0 + prow] = rsum;
 }
 
 static bool front_dw_mfma_ok(int R, int K, int Q) {
     // (other shapes keep the LDS-atomic scatter kernel: 0.18 vs 0.07 ms at the benchmark's size, profiles/r02/front_dw_probe.txt)
-    return (R == 32 || R == 64) && Q % 32 == 0 && K * Q <= 1024 && K <= 8;
+    return (R == 32 || R % 64 == 0) && R <= 64 * 1024 && Q % 32 == 0 && K * Q <= 1024 && K <= 8;
 }
 
 // dW[c][q][k] = sum_blk partial[blk][c][k*Q+q] ; db[c] = sum_blk partial[blk][R*KQ + c]
@@ -962,7 +967,8 @@ int wn_front_dw(const float* dX0, const int64_t* x, float* partial, float* dW, f
     WN_PROF("dw_front_scatter", 0.0, (double)B * R * T * 4.0, st);
     if (!wn_front_dw_supported(R, K, Q)) return 1;
     int nc, ch;
-    front_dw_grid(B, T, &nc, &ch);
+    const int RG = front_dw_row_groups(R, K, Q);
+    front_dw_grid(B, T, RG, &nc, &ch);
     const size_t lds = ((size_t)R * K * Q + R) * 4;
 #ifndef WN_EMU
     if (!front_dw_mfma_ok(R, K, Q) && lds > 64 * 1024 &&
@@ -972,7 +978,7 @@ int wn_front_dw(const float* dX0, const int64_t* x, float* partial, float* dW, f
 #endif
     if (front_dw_mfma_ok(R, K, Q)) {
         const size_t lds_m = 2 * 2 * 3 * 2048 + (size_t)(ch + K) * 4;
-        WN_LAUNCH(k_front_dw_mfma, dim3((unsigned)nc, (unsigned)B), dim3(FM_T), lds_m, st, dX0, x, partial, T, R, K, Q, ch);
+        WN_LAUNCH(k_front_dw_mfma, dim3((unsigned)nc, (unsigned)B, (unsigned)RG), dim3(FM_T), lds_m, st, dX0, x, partial, T, R, K, Q, ch);
     } else
     WN_LAUNCH(k_front_dw_scatter, dim3((unsigned)nc, (unsigned)B), dim3(FD_T), lds, st, dX0, x, partial, T, R, K, Q, ch);
     const long per = (long)R * K * Q + R;

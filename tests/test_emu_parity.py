@@ -663,13 +663,14 @@ def test_any_size_decode_of_wide_batches_on_the_matrix_cores():
 
 
 def test_front_conv_weight_gradient_on_the_matrix_cores():
-    """k_front_dw_mfma (R in {32, 64}, K * Q <= 1024): the front conv's weight gradient as a contraction over time with a
+    """k_front_dw_mfma (R = 32 or a multiple of 64, K * Q <= 1024): the front conv's weight gradient as a contraction over time with a
     one-hot B operand built from the token indices, instead of LDS float atomics.  256 classes x 2 taps (all 16 column
     tiles), a chunk that ends inside a 32-step iteration (T % 32 != 0), two sequences, R = 32 (one row tile) and
     kernel_size 1 / 3 tables, and 256 classes x 3 taps (24 column tiles: the first 8 waves take two; the configs[3] front
     conv) -- every gradient against the oracle (the front conv's is causal.weight / causal.bias)."""
     for cfg_t, B, T, seed in (((256, 4, 64, 32, 2, 1, 2, 8), 2, 72, 81), ((128, 4, 32, 32, 2, 1, 3, 0), 1, 45, 82),
-                              ((256, 4, 64, 32, 2, 1, 1, 8), 1, 40, 83), ((256, 4, 64, 32, 2, 1, 3, 8), 1, 48, 84)):
+                              ((256, 4, 64, 32, 2, 1, 1, 8), 1, 40, 83), ((256, 4, 64, 32, 2, 1, 3, 8), 1, 48, 84),
+                              ((256, 4, 128, 32, 2, 1, 2, 8), 2, 40, 85)):   # 128 channels: two groups of 64 rows (blockIdx.z)
         log = {}
 
         def run():
