@@ -21,7 +21,7 @@ from pytorchwavenetvocoder_amd.optim import FusedAdam  # noqa: E402
 
 
 def measure(resch=512, kernel_size=2, upsampling=80, T=23040, batch=4, steps=5, aux=80, device="cuda:0", with_kernels=True,
-            n_mixture=0):
+            n_mixture=0, layers_per_bucket=0):
     """Median-free quick timing of one training step (forward + CE + backward + Adam) of a 30-layer model of the given
     geometry on synthetic data; returns a dict (ms_per_step, samples_per_sec, approx_train_tflops, per-kernel table)."""
     dev = torch.device(device)
@@ -39,7 +39,8 @@ def measure(resch=512, kernel_size=2, upsampling=80, T=23040, batch=4, steps=5, 
     opt = FusedAdam(model, lr=1e-4)
 
     def step():
-        loss = model.mol_loss_and_backward(x, h, y) if n_mixture > 0 else model.loss_and_backward(x, h, t)
+        loss = (model.mol_loss_and_backward(x, h, y, layers_per_bucket=layers_per_bucket) if n_mixture > 0
+                else model.loss_and_backward(x, h, t, layers_per_bucket=layers_per_bucket))
         opt.step()
         return loss
 
@@ -84,10 +85,11 @@ def main():
     ap.add_argument("--kernel-size", type=int, default=2)
     ap.add_argument("--upsampling", type=int, default=80)
     ap.add_argument("--T", type=int, default=23040, help="model inputs per window (BASELINE configs[3]: 26112)")
+    ap.add_argument("--lpb", type=int, default=0, help="layers per gradient bucket / weight-gradient launch group (0: all layers)")
     ap.add_argument("--n-mixture", type=int, default=0, help="mixture-of-logistics head with this many components (0: softmax)")
     args = ap.parse_args()
     print(json.dumps(measure(args.resch, args.kernel_size, args.upsampling, args.T, args.batch, args.steps, args.aux,
-                             n_mixture=args.n_mixture)))
+                             n_mixture=args.n_mixture, layers_per_bucket=args.lpb)))
 
 
 if __name__ == "__main__":
