@@ -52,31 +52,34 @@ __global__ __launch_bounds__(WN_TPB) void k_front_gather(const int64_t* __restri
 // lane: 64 cache lines per load instruction, K R of them per thread -- bound by the texture addresser (63 us for the
 // benchmark's 47 MB of output).  Here one 1024-thread workgroup per CU copies the table (K Q R floats: 128 KB for the
 // benchmark's model) into LDS once, rows padded to R + 1 words so that the lanes' rows fall into different banks, and walks
-// a chunk of one sequence.  Same additions in the same order: bit-identical output.
+// a chunk of one sequence.  Same additions in the same order: bit-identical output.  Tables too large for one CU's LDS (the
+// recipes' n_resch = 512: 1 MB) are cut into groups of RG output rows on blockIdx.z (a [K Q][RG + 1] slice each).
 #define FG_T 1024
 __global__ __launch_bounds__(FG_T) void k_front_gather_lds(const int64_t* __restrict__ x, const float* __restrict__ wc_f,
                                                            const float* __restrict__ bias, float* __restrict__ x0, int T,
-                                                           int Q, int R, int K, int chunk) {
+                                                           int Q, int R, int K, int chunk, int RG) {
     WN_DYN_SMEM(smem_raw);
-    float* tab = reinterpret_cast<float*>(smem_raw);   // [K * Q][R + 1]
-    const int RP = R + 1;
+    float* tab = reinterpret_cast<float*>(smem_raw);   // [K * Q][RG + 1]
+    const int RP = RG + 1;
+    const int r_lo = (int)blockIdx.z * RG;
     const int tid = threadIdx.x;
     const int b = blockIdx.y, t0 = blockIdx.x * chunk;
     const int t1 = (t0 + chunk < T) ? t0 + chunk : T;
     {   // table copy: 8 independent 16-byte loads in flight per thread (a dependent load per iteration made it latency bound)
-        const int n4 = (K * Q * R) >> 2;   // R % 4 == 0 (launcher): the 4 elements of a load share a table row
+        const int n4 = (K * Q * RG) >> 2;   // RG % 4 == 0 (launcher): the 4 elements of a load share a table row
         for (int base = 0; base < n4; base += 8 * FG_T) {
             float4 v[8];
             WN_UNROLL
             for (int u = 0; u < 8; ++u) {
                 const int i4 = base + u * FG_T + tid;
-                v[u] = i4 < n4 ? reinterpret_cast<const float4*>(wc_f)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int e = i4 << 2, row = e / RG, r = e - row * RG;
+                v[u] = i4 < n4 ? *reinterpret_cast<const float4*>(wc_f + (long)row * R + r_lo + r) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             WN_UNROLL
             for (int u = 0; u < 8; ++u) {
                 const int i4 = base + u * FG_T + tid;
                 if (i4 < n4) {
-                    const int e = i4 << 2, row = e / R, r = e - row * R;
+                    const int e = i4 << 2, row = e / RG, r = e - row * RG;
                     float* d = tab + row * RP + r;
                     d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
                 }
@@ -99,10 +102,10 @@ __global__ __launch_bounds__(FG_T) void k_front_gather_lds(const int64_t* __rest
             }
             q[tap] = v;
         }
-        for (int r0 = 0; r0 < R; r0 += 4) {   // R % 4 == 0; 4 K LDS reads in flight
+        for (int r0 = 0; r0 < RG; r0 += 4) {   // RG % 4 == 0; 4 K LDS reads in flight
             float v[4];
             WN_UNROLL
-            for (int u = 0; u < 4; ++u) v[u] = bias[r0 + u];
+            for (int u = 0; u < 4; ++u) v[u] = bias[r_lo + r0 + u];
             for (int tap = 0; tap < K; ++tap) {
                 if (q[tap] >= 0) {
                     WN_UNROLL
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(FG_T) void k_front_gather_lds(const int64_t* __rest
                 }
             }
             WN_UNROLL
-            for (int u = 0; u < 4; ++u) x0[((long)b * R + r0 + u) * T + t] = v[u];
+            for (int u = 0; u < 4; ++u) x0[((long)b * R + r_lo + r0 + u) * T + t] = v[u];
         }
     }
 }
@@ -119,9 +122,11 @@ int wn_front_gather(const int64_t* x, const float* wc_f, const float* bias, floa
                     wn_stream_t st) {
     WN_PROF("front_gather", 0.0, 0.0, st);
     if (K > 8 || K < 1) return 1;
-    const size_t lds = (size_t)K * Q * (R + 1) * 4;
-    if (lds <= 150 * 1024 && R % 4 == 0 && (long)B * T >= 16384) {   // (small calls: the table copy would dominate)
-        int nc = 256 / B;
+    int RG = R;   // output rows per workgroup: all of them if the table fits one CU's LDS, else groups of 64 / 32 / 16
+    while (RG > 16 && ((size_t)K * Q * (RG + 1) * 4 > 150 * 1024 || R % RG != 0)) RG = RG > 64 ? 64 : RG / 2;
+    const size_t lds = (size_t)K * Q * (RG + 1) * 4;
+    if (lds <= 150 * 1024 && R % RG == 0 && RG % 4 == 0 && (long)B * T >= 16384) {   // (small calls: the table copy would dominate)
+        int nc = 256 / (B * (R / RG));
         if (nc < 1) nc = 1;
         int ch = (T + nc - 1) / nc;
         ch = (ch + 63) / 64 * 64;
@@ -132,7 +137,7 @@ int wn_front_gather(const int64_t* x, const float* wc_f, const float* bias, floa
                                 (int)lds) != hipSuccess)
             return 2;
 #endif
-        WN_LAUNCH(k_front_gather_lds, dim3((unsigned)nc, (unsigned)B), dim3(FG_T), lds, st, x, wc_f, bias, x0, T, Q, R, K, ch);
+        WN_LAUNCH(k_front_gather_lds, dim3((unsigned)nc, (unsigned)B, (unsigned)(R / RG)), dim3(FG_T), lds, st, x, wc_f, bias, x0, T, Q, R, K, ch, RG);
         return 0;
     }
     dim3 grid((T + WN_TPB - 1) / WN_TPB, B);

@@ -8,10 +8,11 @@ import torch
 
 from oracle import wavenet_oracle as O
 
-# the last three have B * T >= 16384: the LDS-table variant of the gather (k_front_gather_lds), incl. a ragged last chunk,
-# a table that does not fit the LDS (Q = 256, R = 64, K = 3 -> the plain gather) and negative / out-of-range indices
+# the last five have B * T >= 16384: the LDS-table variant of the gather (k_front_gather_lds), incl. a ragged last chunk,
+# tables that do not fit one CU's LDS and are cut into groups of output rows (Q = 256, R = 64, K = 3: two groups of 32;
+# R = 128: two of 64; R = 96: three of 32) and negative / out-of-range indices
 FRONT_CASES = [(256, 64, 2, 2, 1000), (256, 64, 3, 1, 333), (37, 12, 2, 3, 77), (256, 512, 2, 1, 257),
-               (256, 64, 2, 3, 5501), (64, 32, 3, 2, 8200), (256, 64, 3, 2, 8200)]
+               (256, 64, 2, 3, 5501), (64, 32, 3, 2, 8200), (256, 64, 3, 2, 8200), (256, 128, 2, 2, 8200), (256, 96, 2, 2, 8200)]
 CONV_CASES = [(64, 64, 2, 1, 2, 500), (64, 128, 2, 16, 1, 300), (64, 64, 3, 4, 2, 257), (12, 20, 3, 7, 3, 91),
               (64, 64, 2, 512, 1, 300), (256, 64, 2, 1, 1, 200)]
 

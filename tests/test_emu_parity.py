@@ -248,7 +248,7 @@ def test_fused_adam_skips_live_parameters_without_a_gradient_like_torch_adam():
 def test_op_level_entry_points():
     """wn_op_front / wn_op_causal_conv (a subset of the GPU cases of tests/test_gpu_ops.py) on the host-compiled kernels."""
     from tests import ops_common as OC
-    for case in OC.FRONT_CASES[1:3] + [OC.FRONT_CASES[5]]:   # the last one: the LDS-table gather (B * T >= 16384)
+    for case in OC.FRONT_CASES[1:3] + [OC.FRONT_CASES[5], OC.FRONT_CASES[8]]:   # the last two: the LDS-table gather (B * T >= 16384), whole table / three row groups
         OC.check_op_front(emu_library(), "cpu", *case)
     for case in (OC.CONV_CASES[2], OC.CONV_CASES[3], (64, 64, 2, 512, 1, 150)):
         OC.check_op_causal_conv(emu_library(), "cpu", *case)
