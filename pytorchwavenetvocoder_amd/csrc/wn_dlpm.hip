@@ -233,12 +233,32 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlpm(WnDlpArgs a) {
                 const int dp = 1 << ((s >= 1 ? s - 1 : 0) % a.depth), Dp = (K - 1) * dp;
                 char* rb = reinterpret_cast<char*>(pq + (dlpm_queue_off(s >= 1 ? s - 1 : 0, a.depth, K, R) + (long)(p % Dp) * R) * CB);
                 for (int j0 = 0; j0 < nr; j0 += GJ) {
-                    if (s <= 1) {   // (no unrolling: two stages per step)
-                        for (int jj = 0; jj < GJ; ++jj) {
-                            if (j0 + jj < nr && live) {
-                                const float v = x0_of(kk + 32 * (j0 + jj), col);
-                                if (s == 1) *reinterpret_cast<float*>(rb + (j0 + jj) * sq4 + (size_t)(lq * 4u)) = v;
-                                s_in[sin_off(R + kk + 32 * (j0 + jj)) + col] = v;
+                    if (s <= 1) {   // x_0 = x0_of(row, col), eight rows' table reads in flight (one row after the other these two
+                                    // stages took 18 - 20 us instead of 11)
+                        int tk[3];
+                        WN_UNROLL
+                        for (int k = 0; k < 3; ++k) tk[k] = k < K ? s_tok[k * CB + col] : -1;
+                        for (int j1 = 0; j1 < GJ; j1 += 8) {
+                            float bv[8], wv[8][3];
+                            WN_UNROLL
+                            for (int jj = 0; jj < 8; ++jj) {
+                                const int c = kk + 32 * (j0 + j1 + jj);
+                                const bool ok = j0 + j1 + jj < nr && live;
+                                bv[jj] = ok ? a.params[a.off_causal_b + c] : 0.0f;
+                                WN_UNROLL
+                                for (int k = 0; k < 3; ++k)
+                                    wv[jj][k] = (ok && tk[k] >= 0) ? a.params[a.off_causal_w + ((long)c * a.Q + tk[k]) * K + k] : 0.0f;
+                            }
+                            WN_UNROLL
+                            for (int jj = 0; jj < 8; ++jj) {
+                                if (j0 + j1 + jj < nr && live) {
+                                    float v = bv[jj];
+                                    WN_UNROLL
+                                    for (int k = 0; k < 3; ++k)
+                                        if (tk[k] >= 0) v += wv[jj][k];   // the order of x0_of
+                                    if (s == 1) *reinterpret_cast<float*>(rb + (j0 + j1 + jj) * sq4 + (size_t)(lq * 4u)) = v;
+                                    s_in[sin_off(R + kk + 32 * (j0 + j1 + jj)) + col] = v;
+                                }
                             }
                         }
                     } else {
@@ -374,14 +394,29 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlpm(WnDlpArgs a) {
                     if (live && j0 + jj < nq) s_in[sin_off(kk + 32 * (j0 + jj)) + col] = wn_bits_f32((unsigned)gv[jj]);
             }
             __syncthreads();
+            // first-max argmax: a thread scans its own logit rows kk + 32 j (ascending), the 32 candidates of a column are
+            // compared by one thread (larger value, then smaller index); unit 0 writes the logits out, a thread its own rows
+            {
+                float best = -3.0e38f;
+                int bi = 0x7fffffff;
+                for (int j = 0; j < nq; ++j) {
+                    const int qi = kk + 32 * j;
+                    const float v = live ? s_in[sin_off(qi) + col] : -3.0e38f;
+                    if (live && u == 0 && a.logits_out) a.logits_out[((long)b * a.Ttot + p) * Qo + qi] = v;
+                    if (v > best) { best = v; bi = qi; }
+                }
+                s_red[(kk * CB + col) * 2] = best;
+                reinterpret_cast<int*>(s_red)[(kk * CB + col) * 2 + 1] = bi;
+            }
+            __syncthreads();
             if (tid < nbc) {
                 const int bb = cblk * CB + tid;
                 float best = -3.0e38f;
                 int bi = 0;
-                for (int qi = 0; qi < Qo; ++qi) {
-                    const float v = s_in[sin_off(qi) + tid];
-                    if (u == 0 && a.logits_out) a.logits_out[((long)bb * a.Ttot + p) * Qo + qi] = v;
-                    if (v > best) { best = v; bi = qi; }
+                for (int r = 0; r < 32; ++r) {
+                    const float v = s_red[(r * CB + tid) * 2];
+                    const int qi = reinterpret_cast<const int*>(s_red)[(r * CB + tid) * 2 + 1];
+                    if (v > best || (v == best && qi < bi)) { best = v; bi = qi; }
                 }
                 int chosen = bi;
                 if (a.mode == 1 && a.uniforms != nullptr) {
