@@ -163,8 +163,9 @@ def decode_report(model, device, with_cpu):
     out["stream_GBps_per_workgroup"] = stream_bytes / (out["batch1"]["us_per_step"] * 1e-6) / 1e9
     out["stream_note"] = "one CU sustains ~112 GB/s on a 5 MB cyclic read (tools/stream_probe.hip, profiles/r01/stream_probe.txt)"
     # the recipes' own model size (n_resch 512 / n_skipch 256, egs/arctic/sd/run.sh:46-52; decode.py:274-327): the any-size path --
-    # ONE persistent launch per chunk of steps: 128 workgroups up to 4 utterances (csrc/wn_dlp.hip, fp32 VALU), 64 workgroups per
-    # block of 16 utterances up to 48 (csrc/wn_dlpm.hip, 16x16x4 matrix-core tiles); layer-wise launches above
+    # ONE persistent launch per chunk of steps: 128 workgroups with fp32 VALU dot products for one utterance (csrc/wn_dlp.hip), 64
+    # workgroups per block of 16 utterances with 16x16x4 matrix-core tiles from 2 to 48 (csrc/wn_dlpf.hip: plain vectors + one
+    # flag per workgroup and stage, inputs by global -> LDS transfers); layer-wise launches above
     try:
         from pytorchwavenetvocoder_amd.nets import WaveNet, initialize
         torch.manual_seed(1)
@@ -175,7 +176,7 @@ def decode_report(model, device, with_cpu):
         for B, n, lay in ((1, 400, True), (4, 400, True), (16, 300, True), (32, 300, True), (48, 300, True), (64, 200, "launches")):
             m = decode_bench.measure(big, B, n, device, layered=lay)
             rs["batch%d" % B] = {k: m[k] for k in ("us_per_step", "samples_per_sec_per_utt", "samples_per_sec", "context_s")}
-            rs["batch%d" % B]["path"] = (("one persistent launch (wn_dlp)" if B <= 4 else "one persistent launch (wn_dlpm)")
+            rs["batch%d" % B]["path"] = (("one persistent launch (wn_dlp)" if B <= 1 else "one persistent launch (wn_dlpf)")
                                          if lay is True else "layer-wise launches")
         out["recipe_size"] = rs
         del big

@@ -306,13 +306,19 @@ int wn_decode_steps(const WnConfig* cfg, int B, const float* params, const float
 int64_t wn_decode_layered_state_floats(const WnConfig* cfg, int B);
 /* Since ABI v7: for models the plan of csrc/wn_dlp.h covers (n_resch % 32 == 0, kernel_size 2 or 3, B <= 48, softmax head)
  * wn_decode_layered_steps runs the whole range of steps as ONE launch of workgroups that hand their vectors to each other as
- * 8-byte {value, tag} granules (the recipes' n_resch = 512 model: 66 dependent launches per step before): n_resch / 4
- * workgroups with fp32 VALU dot products up to 4 utterances (wn_dlp.hip), n_resch / 8 workgroups per block of 16 utterances with
- * v_mfma_f32_16x16x4_f32 tiles from 5 to 48 (wn_dlpm.hip; all workgroups must be resident: at most 240).
+ * 8-byte {value, tag} granules or as plain vectors + one flag per workgroup and stage (the recipes' n_resch = 512 model: 66
+ * dependent launches per step before): n_resch / 4 workgroups with fp32 VALU dot products for one utterance (wn_dlp.hip),
+ * n_resch / 8 workgroups per block of 16 utterances with v_mfma_f32_16x16x4_f32 tiles up to 48 (wn_dlpf.hip / wn_dlpm.hip; all
+ * workgroups must be resident: at most 240).
  * `mode | WN_DECODE_BY_LAUNCHES` keeps the layer-wise launches (independent check, A/B).  The persistent launch bounds every
  * wait; wn_decode_layered_error_offset() is the float offset in `state` of an int that is non-zero afterwards if a wait
  * timed out (-1: this model / B decodes by launches). */
 #define WN_DECODE_BY_LAUNCHES 256
+/* A/B and test knob (process-wide): 1 = the persistent launches hand their vectors over as 8-byte granules everywhere, 0 (default)
+ * = as plain vectors + one flag per workgroup and stage where wn_dlpf.hip covers the plan (kernel_size 2 classes, 5 - 48
+ * utterances).  The state layout depends on it: set it before wn_decode_layered_state_floats and leave it alone until the decode
+ * is over.  Returns the previous setting. */
+int wn_decode_set_handoff(int granules);
 int64_t wn_decode_layered_error_offset(const WnConfig* cfg, int B);
 int wn_decode_layered_prepare(const WnConfig* cfg, int B, int F, const float* params, const float* h, float* G, float* state,
                               int64_t state_floats, void* stream);

@@ -90,7 +90,7 @@ ABI_VERSION = 7
 EXPORTS = [
     "wn_abi_version", "wn_last_error", "wn_receptive_field", "wn_num_layers", "wn_param_count", "wn_param_offset",
     "wn_num_buckets", "wn_bucket_range", "wn_dead_param_range", "wn_workspace_bytes", "wn_workspace_region", "wn_forward",
-    "wn_softmax_ce_loss", "wn_forward_loss_fused", "wn_forward_loss", "wn_backward", "wn_backward_window", "wn_adam_step", "wn_op_front", "wn_op_causal_conv", "wn_op_upsampling", "wn_op_transpose_last2", "wn_op_gemm", "wn_prof_enable", "wn_prof_report", "wn_prof_sequence",
+    "wn_softmax_ce_loss", "wn_forward_loss_fused", "wn_forward_loss", "wn_backward", "wn_backward_window", "wn_adam_step", "wn_op_front", "wn_op_causal_conv", "wn_op_upsampling", "wn_op_transpose_last2", "wn_decode_set_handoff", "wn_op_gemm", "wn_prof_enable", "wn_prof_report", "wn_prof_sequence",
     "wn_decode_supported", "wn_decode_pack_floats", "wn_decode_state_floats", "wn_decode_pack", "wn_decode_aux",
     "wn_decode_steps", "wn_decode_stream_bytes",
     "wn_decode_layered_state_floats", "wn_decode_layered_error_offset", "wn_decode_layered_prepare", "wn_decode_layered_steps", "wn_mol_loss",
@@ -139,6 +139,7 @@ class WnLibrary(object):
         L.wn_op_causal_conv.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
         L.wn_op_upsampling.argtypes = [vp, vp, vp, vp, i, i, i, i, vp]
         L.wn_op_transpose_last2.argtypes = [vp, vp, i, i, i, vp]
+        L.wn_decode_set_handoff.argtypes = [i]
         L.wn_op_gemm.argtypes = [ctypes.POINTER(WnGemmArgs), vp]
         L.wn_prof_enable.argtypes = [i]
         L.wn_prof_report.argtypes = [ctypes.c_char_p, sz]

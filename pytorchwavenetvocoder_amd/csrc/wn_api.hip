@@ -1539,6 +1539,16 @@ extern "C" int wn_op_transpose_last2(const float* src, float* dst, int B, int R,
     return rt_check("wn_op_transpose_last2");
 }
 
+// A/B and test knob of the persistent any-size decode: 1 = hand its vectors over as 8-byte granules everywhere (wn_dlp.hip,
+// wn_dlpm.hip), 0 (default) = plain vectors + flags where wn_dlpf.hip covers the plan.  Process-wide; the state layout depends
+// on it, so it must not change between wn_decode_layered_state_floats / _prepare / _steps of one decode.
+static int g_decode_granules = 0;
+extern "C" int wn_decode_set_handoff(int granules) {
+    const int old = g_decode_granules;
+    g_decode_granules = granules ? 1 : 0;
+    return old;
+}
+
 // ------------------------------------------------------------------------------------------
 // autoregressive decode (wavenet.py:309-511, 538-549)
 // ------------------------------------------------------------------------------------------
@@ -1697,7 +1707,8 @@ struct DlLay {
     long qfloats_per_utt;
     // persistent path (wn_dlp.hip), when the plan covers the model and nb <= WN_DLP_BMAX
     WnDlpPlan dlp;
-    long dlp_w, dlp_post, dlp_cfold, dlp_fold, dlp_gz, dlp_gx, dlp_gs, dlp_go, dlp_gl, dlp_pq, dlp_err;
+    long dlp_w, dlp_post, dlp_cfold, dlp_fold, dlp_gz, dlp_gx, dlp_gs, dlp_go, dlp_gl, dlp_flags, dlp_pq, dlp_err;
+    int dlp_flags_on;        // 1: wn_dlpf.hip (plain vectors + flags) runs this model / batch
 };
 
 static int dl_layout(const WnConfig* cfg, const Dims& d, int nb, DlLay* y) {
@@ -1722,22 +1733,37 @@ static int dl_layout(const WnConfig* cfg, const Dims& d, int nb, DlLay* y) {
     DCARVE(O2, (long)d.S * nb);
     DCARVE(logits, (long)d.Qo * nb);
     // up to WN_DLP_BMAX utterances: the VALU kernel (wn_dlp.hip); up to WN_DLPM_BMAX: the matrix-core kernel (wn_dlpm.hip)
-    wn_dlp_make_plan(d.Q, d.Qo, d.R, d.S, d.L, d.K, nb >= WN_DLPM_BMIN ? 1 : 0, &y->dlp);
+    // (the flag hand-off kernel wn_dlpf.hip costs the same ~250 us per step for 2 .. 16 utterances at n_resch 512, the VALU kernel
+    // 252 / 321 / 366 for 2 / 3 / 4: from 2 utterances on where wn_dlpf.hip covers the matrix-core plan, from WN_DLPM_BMIN otherwise)
+    int wide = nb >= WN_DLPM_BMIN ? 1 : 0;
+    if (!wide && nb >= 2 && WN_DLPF_ENABLE && !g_decode_granules) {
+        WnDlpPlan pw;
+        wn_dlp_make_plan(d.Q, d.Qo, d.R, d.S, d.L, d.K, 1, &pw);
+        if (wn_dlpf_covers(&pw)) wide = 1;
+    }
+    wn_dlp_make_plan(d.Q, d.Qo, d.R, d.S, d.L, d.K, wide, &y->dlp);
     if (nb > (y->dlp.wide ? WN_DLPM_BMAX : WN_DLP_BMAX)) y->dlp.ok = 0;
     const int dlp_blocks = y->dlp.wide ? (nb + WN_DLPM_CB - 1) / WN_DLPM_CB : 1;   // k_dlpm: a set of units per block of 16 utterances
     if (y->dlp.ok && y->dlp.NU * dlp_blocks > WN_DLPM_MAXWG) y->dlp.ok = 0;
+    y->dlp_flags_on = 0;
     if (y->dlp.ok) {
         const WnDlpPlan& pl = y->dlp;
         DCARVE(dlp_w, (long)(d.L + 1) * pl.NU * pl.stage_floats);
         DCARVE(dlp_post, (long)pl.NU * pl.post_floats);
         DCARVE(dlp_cfold, (long)d.L * 2 * d.R);
         DCARVE(dlp_fold, (long)2 * d.R * d.R);
-        DCARVE(dlp_gz, 2L * 2 * d.R * nb);   // 8-byte granules: two floats each
-        DCARVE(dlp_gx, 2L * 2 * d.R * nb);
-        DCARVE(dlp_gs, 2L * d.S * nb);
-        DCARVE(dlp_go, 2L * d.S * nb);
-        DCARVE(dlp_gl, 2L * d.Qo * nb);
-        DCARVE(dlp_pq, pl.wide ? (long)pl.NU * dlp_blocks * y->qfloats_per_utt * WN_DLPM_CB : (long)pl.NU * y->qfloats_per_utt * nb);
+        // hand-off regions: 8-byte granules (two floats each) [rows][nb], or -- wn_dlpf.hip: plain vectors + one flag per unit and
+        // block -- floats [rows][Bp], Bp = 16 * blocks (which fit the same regions carved with Bp columns)
+        y->dlp_flags_on = (WN_DLPF_ENABLE && !g_decode_granules && wn_dlpf_covers(&pl)) ? 1 : 0;
+        const long Bp = pl.wide ? (long)dlp_blocks * WN_DLPM_CB : nb;
+        DCARVE(dlp_gz, 2L * 2 * d.R * Bp);
+        DCARVE(dlp_gx, 2L * 2 * d.R * Bp);
+        DCARVE(dlp_gs, 2L * d.S * Bp);
+        DCARVE(dlp_go, 2L * d.S * Bp);
+        DCARVE(dlp_gl, 2L * d.Qo * Bp);
+        DCARVE(dlp_flags, 2L * pl.NU * dlp_blocks);
+        // private copies of the dilation queues (not with the flag hand-off: its shared rings are read by every unit)
+        DCARVE(dlp_pq, y->dlp_flags_on ? 64 : (pl.wide ? (long)pl.NU * dlp_blocks * y->qfloats_per_utt * WN_DLPM_CB : (long)pl.NU * y->qfloats_per_utt * nb));
         DCARVE(dlp_err, 1024);   // error word (+ the stamps of a timing build)
     }
 #undef DCARVE
@@ -1878,8 +1904,10 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
         a.pq = ws + y.dlp_pq; a.pq_unit_stride = y.qfloats_per_utt * (y.dlp.wide ? WN_DLPM_CB : nb);
         a.queues = ws + y.queues; a.qfloats = y.qfloats_per_utt;
         a.err = reinterpret_cast<int*>(ws + y.dlp_err);
-        const int rc = y.dlp.wide ? wn_dlpm_launch(&a, c.st) : wn_dlp_launch(&a, c.st);
-        if (rc != 0) return fail(3, "wn_dlp%s_launch failed (rc=%d)", y.dlp.wide ? "m" : "", rc);
+        a.handoff = y.dlp_flags_on; a.Bp = y.dlp.wide ? ((nb + WN_DLPM_CB - 1) / WN_DLPM_CB) * WN_DLPM_CB : nb;
+        a.flags = reinterpret_cast<unsigned long long*>(ws + y.dlp_flags);
+        const int rc = y.dlp_flags_on ? wn_dlpf_launch(&a, c.st) : (y.dlp.wide ? wn_dlpm_launch(&a, c.st) : wn_dlp_launch(&a, c.st));
+        if (rc != 0) return fail(3, "wn_dlp%s_launch failed (rc=%d)", y.dlp_flags_on ? "f" : (y.dlp.wide ? "m" : ""), rc);
         return rt_check("wn_decode_layered_steps");
     }
     WnDlArgs a;

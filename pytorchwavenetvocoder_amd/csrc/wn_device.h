@@ -28,6 +28,7 @@ typedef emu::f32x4_t f32x4;
 static inline f32x4 mfma16(float a, float b, f32x4 c) { return emu::mfma_f32_16x16x4f32(a, b, c); }
 #define WN_UNROLL
 #define WN_UNROLL_N(n)
+#define WN_NOUNROLL
 // buffer access: base (wave-uniform) + per-lane byte offset (voff) + wave-uniform byte offset (soff)
 // like the hardware, accesses beyond num_records read 0 / are dropped
 struct wn_rsrc_t {
@@ -55,6 +56,13 @@ static inline void wn_buf_load_lds16(wn_rsrc_t r, char* lds_wave_base, int voff,
     const float4 v = wn_buf_load4(r, voff, soff);
     memcpy(lds_wave_base + 16 * (threadIdx.x & 63), &v, 16);
 }
+static inline void wn_buf_load_lds16_coherent(wn_rsrc_t r, char* lds_wave_base, int voff, unsigned soff) { wn_buf_load_lds16(r, lds_wave_base, voff, soff); }
+static inline void wn_store_coherent(float* p, float v) { *p = v; }
+// global -> LDS, 4 bytes per lane: lane l of the wave writes at lds_wave_base + 4*l (inactive lanes write nothing)
+static inline void wn_buf_load_lds4(wn_rsrc_t r, char* lds_wave_base, int voff, unsigned soff) {
+    const float v = wn_buf_load(r, voff, (int)soff);
+    memcpy(lds_wave_base + 4 * (threadIdx.x & 63), &v, 4);
+}
 #define WN_WAIT_VMCNT(n)
 #define WN_UNIFORM(x) (x)
 #define WN_SCHED_BARRIER()
@@ -77,6 +85,10 @@ static inline void wn_granule_store(unsigned long long* p, float v, unsigned tag
     *p = ((unsigned long long)tag << 32) | b;
 }
 static inline unsigned long long wn_granule_load(const unsigned long long* p) { return *p; }
+// producer / consumer flag of a hand-off of PLAIN data (wn_dlpf.hip): release store after the workgroup's data stores (and a
+// workgroup barrier), acquire fence before the consumer's data loads
+static inline void wn_flag_release(unsigned long long* p, unsigned long long v) { *p = v; }
+static inline void wn_fence_acquire() {}
 // v + the value of lane (l ^ m); all lanes of an aligned group of 2m hold the same partial sums
 static inline float wn_xor_add(float v, int m) { return v + __shfl_xor(v, m, 64); }
 // bf16 matrix-core step (v_mfma_f32_32x32x16_bf16): a / b = 8 bf16 per lane packed in a float4
@@ -159,6 +171,18 @@ static __device__ __forceinline__ float wn_buf_load_once(wn_rsrc_t r, int voff, 
 static __device__ __forceinline__ void wn_buf_load_lds16(wn_rsrc_t r, char* lds_wave_base, int voff, unsigned soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, (int)soff, 0, 0);
 }
+// the same with the agent-scope cache policy (sc1): never served from a stale line of this XCD's L2 -- the read side of a
+// hand-off whose data was written with wn_store_coherent (write-through) by a workgroup on another XCD
+static __device__ __forceinline__ void wn_buf_load_lds16_coherent(wn_rsrc_t r, char* lds_wave_base, int voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, (int)soff, 0, 16);
+}
+static __device__ __forceinline__ void wn_store_coherent(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the same with 4 bytes per lane: lane l writes at lds_wave_base + 4*l
+static __device__ __forceinline__ void wn_buf_load_lds4(wn_rsrc_t r, char* lds_wave_base, int voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 4, voff, (int)soff, 0, 0);
+}
 // s_waitcnt vmcnt(n) only (n <= 15)
 #define WN_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | (n))
 // 16-byte load: per-lane byte offset in a VGPR, wave-uniform byte offset in an SGPR (no 64-bit
@@ -196,6 +220,17 @@ static __device__ __forceinline__ void wn_granule_store(unsigned long long* p, f
 static __device__ __forceinline__ unsigned long long wn_granule_load(const unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// producer / consumer flag of a hand-off of PLAIN data (wn_dlpf.hip).  Release at agent scope = write back this XCD's L2 and
+// wait for the wave's stores before the flag store; acquire = invalidate the non-coherent lines of L1 / L2 after the flag load:
+// the memory model's own sequences, 1.6 us per hop across XCDs with 0 stale words (profiles/r04/handoff_microbench.txt)
+// (the sequence tools/microbench/handoff.hip validated: every wave has waited for its own stores and passed a workgroup barrier
+// before ONE thread calls wn_flag_release; the consumer polls with wn_granule_load, then wn_fence_acquire, then a barrier)
+static __device__ __forceinline__ void wn_flag_release(unsigned long long* p, unsigned long long v) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static __device__ __forceinline__ void wn_fence_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 // v + partner value, partner in the other half of the aligned 2m-lane group.  m = 1,2,4,8 are DPP
 // moves (quad_perm / row_half_mirror / row_mirror: valid because after the previous steps every
 // lane of an m-lane group holds the same partial sum); larger m goes through ds_bpermute.
@@ -237,6 +272,7 @@ static __device__ __forceinline__ unsigned wn_f32_bits(float f) { return __built
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ f32x2 wn_pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 #define WN_UNROLL _Pragma("unroll")
+#define WN_NOUNROLL _Pragma("unroll 1")
 #define WN_PRAGMA(x) _Pragma(#x)
 #define WN_UNROLL_N(n) WN_PRAGMA(unroll n)
 #endif

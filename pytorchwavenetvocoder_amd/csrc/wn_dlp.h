@@ -11,12 +11,16 @@
 #define WN_DLP_T 512     // threads per workgroup (8 waves: 2 per SIMD, 256 VGPRs each for the stage's weights)
 #define WN_DLP_NW 8
 #define WN_DLP_CB 4      // utterance columns per block (one 16-byte LDS read per k)
-#define WN_DLP_BMAX 4    // utterances per launch of the VALU kernel (k_dlp): one column block; from 5 on the matrix-core kernel
+#define WN_DLP_BMAX 4    // utterances per launch of the VALU kernel (k_dlp): one column block
 #define WN_DLPM_CB 16    // utterance columns per block of the matrix-core kernel (k_dlpm, wn_dlpm.hip): one 16x16x4 tile
 #define WN_DLPM_BMAX 48  // utterances per launch of the matrix-core kernel: up to 3 column blocks, each with its own units
 #define WN_DLPM_MAXWG 240 // workgroups of one launch (all resident at once: one per CU, a few CUs left to whatever else runs)
+#ifndef WN_DLPF_ENABLE
+#define WN_DLPF_ENABLE 1   // 1: the flag hand-off kernel (wn_dlpf.hip) where it covers the plan; 0: granules everywhere (A/B builds)
+#endif
 #ifndef WN_DLPM_BMIN
-#define WN_DLPM_BMIN 5   // smallest batch that takes the matrix-core kernel (372 us per step at any batch up to 16; the VALU kernel: 365 at 4, 655 at 8)
+#define WN_DLPM_BMIN 5   // smallest batch that takes the matrix-core kernel with the granule hand-off (365 us per step at any batch up to 32; the VALU kernel:
+                         // 366 at 4); where wn_dlpf.hip covers the plan the matrix-core kernel is used from 2 utterances on (wn_api.hip)
 #endif
 
 typedef struct WnDlpPlan {
@@ -65,6 +69,12 @@ typedef struct WnDlpArgs {
     float* queues;           // shared rings [qfloats][B] (prefill / the launch path's layout)
     long qfloats;
     int* err;                // set to 1 when a poll timed out
+    // wn_dlpf.hip (hand-off of plain vectors + one flag per producer; plan.wide, NSP = 48): the granule regions hold plain
+    // floats -- gz: [2][2R][Bp] z | x of the previous stage, gs / go / gl: [rows][Bp] --, no private queues (`queues` is read
+    // by everyone, written by the owner of a channel)
+    int handoff;             // 0: granules (wn_dlp.hip, wn_dlpm.hip), 1: flags (wn_dlpf.hip)
+    int Bp;                  // row stride of the plain vectors: 16 * blocks
+    unsigned long long* flags;   // [blocks][NU]: the tag of the latest stage the unit has published
 } WnDlpArgs;
 
 struct WnDlpPackArgs {
@@ -85,3 +95,5 @@ int wn_dlp_cfold(const float* params, const float* cvec, const float* wd_f, long
                  float* cfold, wn_stream_t st);
 int wn_dlp_launch(const WnDlpArgs* a, wn_stream_t st);
 int wn_dlpm_launch(const WnDlpArgs* a, wn_stream_t st);   // plan.wide == 1, B <= WN_DLPM_BMAX
+int wn_dlpf_launch(const WnDlpArgs* a, wn_stream_t st);   // the same with a.handoff == 1
+int wn_dlpf_covers(const WnDlpPlan* plan);                 // 1: wn_dlpf.hip has a kernel for this plan

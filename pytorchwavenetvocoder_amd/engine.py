@@ -307,6 +307,19 @@ class WaveNetEngine(object):
 
     def decode(self, x, h, n_samples_list, mode="argmax", chunk=4096, return_logits=False, progress=None, layered=None,
                prefill="parallel", prefill_batch=32, log_scale_min=-7.0):
+        """See ``_decode``.  ``layered="granules"``: the any-size path with its persistent launches handing their vectors over
+        as 8-byte granules everywhere (csrc/wn_dlp.hip, wn_dlpm.hip) instead of plain vectors + flags where csrc/wn_dlpf.hip
+        covers the model -- an A/B and test knob (process-wide in the library: set for the duration of this call)."""
+        granules = layered == "granules"
+        old = self.lib.wn_decode_set_handoff(1 if granules else 0)
+        try:
+            return self._decode(x, h, n_samples_list, mode, chunk, return_logits, progress, True if granules else layered,
+                                prefill, prefill_batch, log_scale_min)
+        finally:
+            self.lib.wn_decode_set_handoff(old)
+
+    def _decode(self, x, h, n_samples_list, mode="argmax", chunk=4096, return_logits=False, progress=None, layered=None,
+                prefill="parallel", prefill_batch=32, log_scale_min=-7.0):
         """Queue-based sample-by-sample generation on the HIP decode kernel.
 
         x (B,T0) int64 context, h (B, n_aux, frames | samples) aux features covering T0 + max(n)
@@ -318,8 +331,8 @@ class WaveNetEngine(object):
         Two kernels implement it: the persistent one-workgroup-per-utterance kernel (model sizes covered by
         ``decode_supported()``) and the any-size path (``layered=True``; chosen automatically when the first does not
         apply, e.g. the n_resch = 512 recipe default).  The any-size path is itself ONE persistent launch per chunk of
-        steps where csrc/wn_dlp.hip / wn_dlpm.hip cover the model and the batch (up to 48 utterances: workgroups handing
-        their vectors to each other) and layer-wise launches otherwise; ``layered="launches"`` forces the launches (independent check, A/B).
+        steps where csrc/wn_dlp.hip / wn_dlpm.hip / wn_dlpf.hip cover the model and the batch (up to 48 utterances: workgroups
+        handing their vectors to each other) and layer-wise launches otherwise; ``layered="launches"`` forces the launches (independent check, A/B).
 
         ``prefill``: how the dilation queues of the context are built.  "parallel" (default) does what the
         reference does (wavenet.py:338-349): one forward of the residual stack over the whole padded context

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "pytorchwavenetvocoder_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
-SOURCES = ["wn_gemm.hip", "wn_gemm6.hip", "wn_elem.hip", "wn_fused.hip", "wn_decode.hip", "wn_dlp.hip", "wn_dlpm.hip", "wn_prof.hip", "wn_api.hip"]
+SOURCES = ["wn_gemm.hip", "wn_gemm6.hip", "wn_elem.hip", "wn_fused.hip", "wn_decode.hip", "wn_dlp.hip", "wn_dlpm.hip", "wn_dlpf.hip", "wn_prof.hip", "wn_api.hip"]
 LIB = os.path.join(OUT, "libwavenet_emu.so")
 FLAGS = ["-O2", "-std=c++17", "-fPIC", "-DWN_EMU", "-Wno-psabi", "-mfma", "-ffp-contract=off", "-I", HERE, "-I", CSRC, "-x", "c++"]
 # A/B build macros of the kernel sources (e.g. WN_EMU_EXTRA_FLAGS="-DWN_G6_FINE") get their own build directory

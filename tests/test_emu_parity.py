@@ -587,7 +587,8 @@ def test_windowed_forward_loss_workspace_and_the_parameter_guard():
 def test_any_size_decode_as_one_persistent_launch():
     """csrc/wn_dlp.hip on the emulator's cooperative launch (every workgroup alive at once; they hand their vectors to each
     other as tagged granules): a 32-channel model = 2 workgroups, kernel_size 2 and 3, one utterance, three ragged ones and
-    4 (a full column block; from 5 on the batch goes to wn_dlpm.hip, next test) -- logits within 1e-4 of the queue algorithm (oracle; the res 1x1 is folded into the next layer's
+    4 (a full column block) through ``layered="granules"`` (by default batches of 2 and more go to wn_dlpf.hip where it covers
+    the model, next test; with the granule hand-off to wn_dlpm.hip from 5 on) -- logits within 1e-4 of the queue algorithm (oracle; the res 1x1 is folded into the next layer's
     newest tap, so the rounding differs from the layer-wise launches), tokens equal to the oracle's and to the launches', the
     launch log shows ONE dlp_steps launch per chunk and no layer-wise launch, and inverse-CDF sampling on the same draws picks
     the same tokens as the launches."""
@@ -605,7 +606,7 @@ def test_any_size_decode_as_one_persistent_launch():
         hs = torch.from_numpy(rs.standard_normal((B, 4, 8)).astype(np.float32))
         ns = [9 - (b % 3) for b in range(B)]
         out = {}
-        log = PC.launch_log(emu_library(), lambda: out.update(p=model.engine.decode(xs, hs, ns, chunk=4, return_logits=True, layered=True)))
+        log = PC.launch_log(emu_library(), lambda: out.update(p=model.engine.decode(xs, hs, ns, chunk=4, return_logits=True, layered="granules")))
         assert log.get("dlp_steps", 0) >= 2 and "dl_dilated" not in log and "dl_res" not in log, log
         tp, lp = out["p"]
         tl, ll = model.engine.decode(xs, hs, ns, chunk=4, return_logits=True, layered="launches")
@@ -617,15 +618,16 @@ def test_any_size_decode_as_one_persistent_launch():
             assert (tp[b].numpy()[safe] == np.asarray(rt)[safe]).all() and (tp[b].numpy()[safe] == tl[b].numpy()[safe]).all(), (K, B, b)
         if B == 3:
             torch.manual_seed(5)
-            sp = model.engine.decode(xs, hs, ns, mode="sampling", layered=True)
+            sp = model.engine.decode(xs, hs, ns, mode="sampling", layered="granules")
             torch.manual_seed(5)
             sl = model.engine.decode(xs, hs, ns, mode="sampling", layered="launches")
             assert all(torch.equal(a, b) for a, b in zip(sp, sl))
 
 
 def test_any_size_decode_of_wide_batches_on_the_matrix_cores():
-    """csrc/wn_dlpm.hip (batches of 5 .. 48 utterances: 16-row sets x 16-column blocks on v_mfma_f32_16x16x4_f32, 8 channels per
-    workgroup, one set of workgroups per column block) on the emulator's cooperative launch: a 32-channel model = 4 workgroups
+    """csrc/wn_dlpf.hip and wn_dlpm.hip (batches of 5 .. 48 utterances: 16-row sets x 16-column blocks on v_mfma_f32_16x16x4_f32,
+    8 channels per workgroup, one set of workgroups per column block; hand-off by flags + plain vectors / by granules) on the
+    emulator's cooperative launch: a 32-channel model = 4 workgroups
     per block, kernel_size 2 with 12 ragged utterances (one ragged column block) and kernel_size 3 with 19 (a full block and a
     block of 3: 8 workgroups) -- logits within 1e-4 of the queue
     algorithm (oracle), tokens equal to the oracle's and to the layer-wise launches', ONE dlpm_steps launch per chunk and no
@@ -645,7 +647,14 @@ def test_any_size_decode_of_wide_batches_on_the_matrix_cores():
         ns = [8 - (b % 3) for b in range(B)]
         out = {}
         log = PC.launch_log(emu_library(), lambda: out.update(p=model.engine.decode(xs, hs, ns, chunk=4, return_logits=True, layered=True)))
-        assert log.get("dlpm_steps", 0) >= 2 and "dlp_steps" not in log and "dl_dilated" not in log and "dl_res" not in log, log
+        # (both plans are of the class wn_dlpf.hip covers: plain vectors + one flag per unit, inputs by global -> LDS transfers,
+        # shared queue rings)
+        assert log.get("dlpf_steps", 0) >= 2 and "dlp_steps" not in log and "dl_dilated" not in log and "dl_res" not in log, log
+        # the same through the granule kernel (wn_dlpm.hip: the recipes' kernel_size 3 class, and the A/B partner)
+        log2 = PC.launch_log(emu_library(), lambda: out.update(g=model.engine.decode(xs, hs, ns, chunk=4, return_logits=True, layered="granules")))
+        assert log2.get("dlpm_steps", 0) >= 2 and "dlpf_steps" not in log2 and "dl_dilated" not in log2, log2
+        for b in range(B):
+            assert float((out["g"][1][b] - out["p"][1][b]).abs().max()) <= 1e-5 and torch.equal(out["g"][0][b], out["p"][0][b]), (K, B, b)
         tp, lp = out["p"]
         tl, ll = model.engine.decode(xs, hs, ns, chunk=4, return_logits=True, layered="launches")
         for b in range(B):

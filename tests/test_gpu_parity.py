@@ -303,8 +303,9 @@ def test_decode_wide_model_layered_path_long_k():
 def test_decode_any_size_persistent_launch_vs_oracle_and_launches():
     """csrc/wn_dlp.hip / wn_dlpm.hip: the any-size decode as ONE launch of workgroups that hand their vectors to each other as
     tagged granules (wavenet.py:355-385, 538-549, 518-523 with the res 1x1 folded into the next layer's newest tap).  A
-    128-channel model (kernel_size 3; 7 ragged utterances: from 5 on the batch takes the matrix-core kernel wn_dlpm.hip, 16
-    workgroups) and the recipes' own size (n_resch 512 / n_skipch 256, 2 utterances: the VALU kernel, 128 workgroups): logits within
+    128-channel model (kernel_size 3; 7 ragged utterances) and the recipes' own size (n_resch 512 / n_skipch 256, 2 utterances):
+    by default both through wn_dlpf.hip (plain vectors + flags), with ``layered="granules"`` through wn_dlpm.hip / the fp32 VALU
+    kernel wn_dlp.hip: logits within
     1e-4 of the queue algorithm (oracle), tokens equal wherever the oracle's argmax is not a near-tie, the same against the
     layer-wise launches it replaces, both ways of building the context queues, and the sampling mode runs."""
     from pytorchwavenetvocoder_amd.nets import WaveNet
@@ -336,11 +337,19 @@ def test_decode_any_size_persistent_launch_vs_oracle_and_launches():
                 assert (tp[i].cpu().numpy()[safe] == tl[i].cpu().numpy()[safe]).all(), (cfg_t, prefill, i)
         ts = model.engine.decode(x.to(DEV), h.to(DEV), ns, mode="sampling")
         assert all(int(t.min()) >= 0 and int(t.max()) < cfg.n_quantize and len(t) == k for t, k in zip(ts, ns))
+        # the granule hand-off: the fp32 VALU kernel wn_dlp.hip up to 4 utterances, wn_dlpm.hip from 5 on
+        tg, lg = model.engine.decode(x.to(DEV), h.to(DEV), ns, return_logits=True, layered="granules")
+        for i in range(B):
+            assert float((lg[i] - ll[i]).abs().max()) <= 1e-4, (cfg_t, "granules", i)
+            top2 = ll[i].topk(2, dim=1).values
+            safe = ((top2[:, 0] - top2[:, 1]) > 1e-3).cpu().numpy()
+            assert (tg[i].cpu().numpy()[safe] == tl[i].cpu().numpy()[safe]).all(), (cfg_t, "granules", i)
 
 
 def test_decode_any_size_wide_batches_on_the_matrix_cores():
-    """csrc/wn_dlpm.hip (5 .. 48 utterances: 16 x 16 tiles of v_mfma_f32_16x16x4_f32, one set of n_resch / 8 workgroups per block
-    of 16 utterances) at the recipes' own size (n_resch 512 / n_skipch 256): 18 ragged utterances = 2 blocks = 128 workgroups.
+    """csrc/wn_dlpf.hip / wn_dlpm.hip (5 .. 48 utterances: 16 x 16 tiles of v_mfma_f32_16x16x4_f32, one set of n_resch / 8
+    workgroups per block of 16 utterances; hand-off by plain vectors + flags / by granules) at the recipes' own size (n_resch 512
+    / n_skipch 256): 18 ragged utterances = 2 blocks = 128 workgroups.
     Every utterance against the layer-wise launches it replaces (logits 1e-4, tokens equal away from near-ties), the first
     one, the last one of block 0 and the last one of block 1 against the queue algorithm (oracle) as well; the launch log shows
     the persistent kernel and no layer-wise launch; the sampling mode draws the same tokens as the launches."""
@@ -358,8 +367,13 @@ def test_decode_any_size_wide_batches_on_the_matrix_cores():
     ns = [n - (b % 4) for b in range(B)]
     out = {}
     log = PC.launch_log(model.engine.lib, lambda: out.update(p=model.engine.decode(x.to(DEV), h.to(DEV), ns, return_logits=True)))
-    assert log.get("dlpm_steps", 0) >= 1 and "dl_dilated" not in log and "dlp_steps" not in log, log
+    assert log.get("dlpf_steps", 0) >= 1 and "dl_dilated" not in log and "dlp_steps" not in log and "dlpm_steps" not in log, log
     tp, lp = out["p"]
+    # the same through the granule hand-off (wn_dlpm.hip: the kernel of the classes wn_dlpf.hip does not cover)
+    log = PC.launch_log(model.engine.lib, lambda: out.update(g=model.engine.decode(x.to(DEV), h.to(DEV), ns, return_logits=True, layered="granules")))
+    assert log.get("dlpm_steps", 0) >= 1 and "dlpf_steps" not in log and "dl_dilated" not in log, log
+    for i in range(B):
+        assert float((out["g"][1][i] - lp[i]).abs().max()) <= 1e-5 and torch.equal(out["g"][0][i], tp[i]), i
     tl, ll = model.engine.decode(x.to(DEV), h.to(DEV), ns, return_logits=True, layered="launches")
     for i in range(B):
         assert float((lp[i] - ll[i]).abs().max()) <= 1e-4, i

@@ -8,7 +8,7 @@ NAME="$1"; FLAGS="$2"; shift 2
 SRCS="${@:-wn_fused.hip}"
 mkdir -p "$ROOT/tools/exp"
 OBJS=""
-for f in wn_gemm wn_gemm6 wn_elem wn_fused wn_decode wn_dlp wn_dlpm wn_prof wn_api; do
+for f in wn_gemm wn_gemm6 wn_elem wn_fused wn_decode wn_dlp wn_dlpm wn_dlpf wn_prof wn_api; do
   if echo " $SRCS " | grep -q " $f.hip "; then
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $FLAGS -c "$CSRC/$f.hip" -o "$ROOT/tools/exp/$f.$NAME.o"
     OBJS="$OBJS $ROOT/tools/exp/$f.$NAME.o"

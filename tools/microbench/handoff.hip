@@ -64,7 +64,8 @@ __global__ __launch_bounds__(512) void k_granule(u64* ab, u64* ba, int G, int it
 }
 
 // ---- mode B: tile + flag ----------------------------------------------------------------------------------------------------
-// release: 0 = none (vmcnt(0) only), 1 = agent-scope release fence by lane 0 after the barrier
+// release: 0 = none (vmcnt(0) only), 1 = agent-scope release fence by lane 0 after the barrier, 2 = write-through (sc1) data
+// stores and sc1 loads, no fence on either side
 __global__ __launch_bounds__(512) void k_tile(float* ab, float* ba, unsigned* flag_ab, unsigned* flag_ba, int nfloat, int iters,
                                                int release, int blk_a, int blk_b, Report* rep) {
     const int me = (int)blockIdx.x == blk_a ? 0 : ((int)blockIdx.x == blk_b ? 1 : -1);
@@ -81,11 +82,15 @@ __global__ __launch_bounds__(512) void k_tile(float* ab, float* ba, unsigned* fl
     unsigned bad = 0;
     u64 t0 = 0;
     auto publish = [&](int it) {
-        for (int i = tid; i < nfloat; i += 512) out[i] = (float)(it * 7 + (i & 1023));
+        if (release == 2) {   // write-through stores (agent scope: sc1), no fence: is "store acknowledged" == "visible to the other XCDs"?
+            for (int i = tid; i < nfloat; i += 512) __hip_atomic_store(out + i, (float)(it * 7 + (i & 1023)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            for (int i = tid; i < nfloat; i += 512) out[i] = (float)(it * 7 + (i & 1023));
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
-            if (release) {
+            if (release == 1) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -97,11 +102,16 @@ __global__ __launch_bounds__(512) void k_tile(float* ab, float* ba, unsigned* fl
             int spin = 0;
             while (__hip_atomic_load(fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)it && ++spin < SPIN_MAX) __builtin_amdgcn_s_sleep(1);
             if (spin >= SPIN_MAX) s_to = 1;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (release != 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
-        for (int i = tid; i < nfloat; i += 512)
-            if (in[i] != (float)(it * 7 + (i & 1023))) bad++;
+        if (release == 2) {   // sc1 loads (they do not take a stale line of this XCD's L2), no invalidate
+            for (int i = tid; i < nfloat; i += 512)
+                if (__hip_atomic_load(in + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (float)(it * 7 + (i & 1023))) bad++;
+        } else {
+            for (int i = tid; i < nfloat; i += 512)
+                if (in[i] != (float)(it * 7 + (i & 1023))) bad++;
+        }
     };
     for (int it = 1; it <= iters + 8; ++it) {
         if (it == 9 && me == 0 && tid == 0) t0 = wall_clock64();
@@ -162,12 +172,12 @@ int main() {
             show(w, 2);
         }
         for (int nf : {64, 2048, 6144, 16384}) {
-            for (int rel = 0; rel < 2; ++rel) {
+            for (int rel = 0; rel < 3; ++rel) {
                 CK(hipMemset(rep, 0, sizeof(Report))); CK(hipMemset(flags, 0, 256));
                 hipLaunchKernelGGL(k_tile, dim3(256), dim3(512), 0, 0, tab, tba, flags, flags + 32, nf, iters, rel, pairs[pi][0], pairs[pi][1], rep);
                 CK(hipDeviceSynchronize());
                 char w[128];
-                snprintf(w, sizeof(w), "B tile %6d B plain stores + flag, %s (blocks %d, %d)", nf * 4, rel ? "release fence" : "no release   ", pairs[pi][0], pairs[pi][1]);
+                snprintf(w, sizeof(w), "B tile %6d B %s (blocks %d, %d)", nf * 4, rel == 2 ? "sc1 stores + flag, sc1 loads, no fence" : (rel ? "plain stores + flag, release fence" : "plain stores + flag, no release   "), pairs[pi][0], pairs[pi][1]);
                 show(w, 2);
             }
         }
