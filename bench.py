@@ -173,11 +173,14 @@ def decode_report(model, device, with_cpu):
         big.apply(initialize)
         big.to(device)
         rs = {"model": "512/256, A=80, K=2, U=80, 30 layers (the recipes' default size)"}
-        for B, n, lay in ((1, 400, True), (4, 400, True), (16, 300, True), (32, 300, True), (48, 300, True), (64, 200, "launches")):
+        for B, n, lay in ((1, 400, True), (4, 400, True), (16, 300, True), (32, 300, True), (48, 300, True), (64, 200, True),
+                          (64, 200, "launches")):
             m = decode_bench.measure(big, B, n, device, layered=lay)
-            rs["batch%d" % B] = {k: m[k] for k in ("us_per_step", "samples_per_sec_per_utt", "samples_per_sec", "context_s")}
-            rs["batch%d" % B]["path"] = (("one persistent launch (wn_dlp)" if B <= 1 else "one persistent launch (wn_dlpf)")
-                                         if lay is True else "layer-wise launches")
+            key = "batch%d" % B if lay is True else "batch%d_by_launches" % B
+            rs[key] = {k: m[k] for k in ("us_per_step", "samples_per_sec_per_utt", "samples_per_sec", "context_s")}
+            rs[key]["path"] = (("one persistent launch (wn_dlp)" if B <= 1 else
+                                "one persistent launch (wn_dlpf)" if B <= 48 else "persistent launches (wn_dlpf), groups of 48 utterances")
+                               if lay is True else "layer-wise launches")
         out["recipe_size"] = rs
         del big
         torch.cuda.empty_cache()

@@ -671,6 +671,35 @@ def test_any_size_decode_of_wide_batches_on_the_matrix_cores():
             assert all(torch.equal(a, b) for a, b in zip(sp, sl))
 
 
+def test_any_size_decode_of_more_utterances_than_one_persistent_launch_takes():
+    """52 utterances (one persistent launch takes 48): the engine sends the batch through the persistent launch in groups
+    (48 + 4) -- tokens equal to the layer-wise launches' on the whole batch, in the sampling mode too (the draws are made for
+    the whole batch before it is cut)."""
+    import numpy as np
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd.nets import WaveNet
+    cfg_t = (32, 4, 32, 32, 3, 2, 2, 4)
+    cfg = O.OracleConfig(*cfg_t)
+    model = WaveNet(*cfg_t, _library=emu_library())
+    model.load_state_dict(O.random_params(cfg, 11, scale=0.3))
+    B = 52
+    rs = np.random.RandomState(3)
+    xs = torch.from_numpy(rs.randint(0, 32, (B, 5))).long()
+    hs = torch.from_numpy(rs.standard_normal((B, 4, 8)).astype(np.float32))
+    ns = [6 - (b % 3) for b in range(B)]
+    assert model.engine._persistent_groups(B, True, "argmax") == [(0, 48), (48, 52)]
+    out = {}
+    log = PC.launch_log(emu_library(), lambda: out.update(p=model.engine.decode(xs, hs, ns, layered=True)))
+    assert log.get("dlpf_steps", 0) == 2 and "dl_dilated" not in log, log
+    tl = model.engine.decode(xs, hs, ns, layered="launches")
+    assert all(torch.equal(a, b) for a, b in zip(out["p"], tl))
+    torch.manual_seed(5)
+    sp = model.engine.decode(xs, hs, ns, mode="sampling", layered=True)
+    torch.manual_seed(5)
+    sl = model.engine.decode(xs, hs, ns, mode="sampling", layered="launches")
+    assert all(torch.equal(a, b) for a, b in zip(sp, sl))
+
+
 def test_front_conv_weight_gradient_on_the_matrix_cores():
     """k_front_dw_mfma (R = 32 or a multiple of 64, K * Q <= 1024): the front conv's weight gradient as a contraction over time with a
     one-hot B operand built from the token indices, instead of LDS float atomics.  256 classes x 2 taps (all 16 column

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Decode speed of the recipe-size model (n_resch = 512, n_skipch = 256: egs/arctic/sd/run.sh:46-52; the one-workgroup kernel
-does not cover it) through the any-size path: the persistent launch of csrc/wn_dlp.hip / wn_dlpm.hip (B <= 48) and, beside it, the
+does not cover it) through the any-size path: the persistent launch of csrc/wn_dlp.hip / wn_dlpf.hip (in groups of 48 utterances beyond that) and, beside it, the
 layer-wise launches it replaces (``layered="launches"``); tokens of the two compared.
 
     python tools/recipe_decode_probe.py [--kernel-size 2] [--steps 400]            (GPU)
@@ -53,7 +53,7 @@ def main():
     assert not m.engine.decode_supported()
     for B in [int(v) for v in a.batches.split(",")]:
         row = {"model": "512/256 recipe size, K=%d" % a.kernel_size, "batch": B}
-        modes = (("persistent", True), ("launches", "launches")) if B <= 48 else (("launches", "launches"),)
+        modes = (("persistent", True), ("launches", "launches"))   # (more than 48 utterances: persistent launches in groups of 48)
         toks = {}
         for name, lay in modes:
             row[name], toks[name] = measure(m, B, a.steps, dev, lay)
