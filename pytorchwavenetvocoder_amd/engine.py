@@ -318,9 +318,8 @@ class WaveNetEngine(object):
             if groups is None:
                 return self._decode(x, h, n_samples_list, mode, chunk, return_logits, progress, lay, prefill, prefill_batch,
                                     log_scale_min)
-            # More utterances than ONE persistent launch takes (48): the batch goes through it in groups -- the utterances are
-            # independent, and a group of 48 decodes at twice the rate of the layer-wise launches for the whole batch (n_resch
-            # 512: 187 K against 90 K samples/s at 64).  The sampling mode's draws are made for the whole batch first, so the
+            # More utterances than ONE persistent launch takes (48), up to two launches' worth: the batch goes through it in two
+            # groups -- the utterances are independent (n_resch 512: 126 K against 90 K samples/s at 64, 185 K against 132 K at 96).  The sampling mode's draws are made for the whole batch first, so the
             # tokens do not depend on the grouping.
             T0 = x.size(1)
             n_pad = max(self.receptive_field - T0, 0)
@@ -356,8 +355,9 @@ class WaveNetEngine(object):
         gs = 48
         while gs > 1 and self.lib.wn_decode_layered_error_offset(cfg, gs) < 0:
             gs //= 2
-        if gs <= 1 or B <= gs:
-            return None
+        if gs <= 1 or B <= gs or B > 2 * gs:
+            return None   # (three groups and more: the layer-wise launches on the whole batch are as fast or faster -- n_resch 512:
+                          # 777 against 751 us per step at 128 utterances, 1575 against 837 at 256; 509 against 710 at 64)
         return [(g0, min(g0 + gs, B)) for g0 in range(0, B, gs)]
 
     def _decode(self, x, h, n_samples_list, mode="argmax", chunk=4096, return_logits=False, progress=None, layered=None,
