@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Phase stamps of one step of the persistent any-size decode (csrc/wn_dlp.hip), recipe-size model.  Needs a timing build:
-    bash tools/build_variant.sh dlptiming "-DWN_DLP_TIMING -fno-slp-vectorize" wn_dlp.hip
+"""Phase stamps of one step of the persistent any-size decode (csrc/wn_dlp.hip, wn_dlpm.hip, wn_dlpf.hip -- whichever the batch
+takes), recipe-size model.  Needs a timing build:
+    bash tools/build_variant.sh dlptiming "-DWN_DLP_TIMING -fno-slp-vectorize" wn_dlp.hip wn_dlpm.hip wn_dlpf.hip
     WN_LIB_PATH=tools/exp/libwn_dlptiming.so python tools/dlp_timing.py [B]                      (GPU)
 Prints, per stage of step p0 + 3 of unit 0: microseconds spent in gather / barrier / dot products (incl. the wait for the
 stage's weights) / partial sums / epilogue + publish / closing barrier."""
