@@ -18,8 +18,9 @@
 // units are still reading during the stage itself.
 // LDS: the stage's inputs in the order the tiles read them -- tile step i of wave w contracts the k of its four lane groups
 // q, k = (4 w + q) NS + i, and finds their 16 columns at rows 4 (w NS + i) + q: 64 consecutive floats, one conflict-free read per
-// lane, and exactly what one transfer instruction writes (lane = (q, column)).  The x / skip row set has its own copy of the z
-// part in ITS order.  148 KB for kernel_size 2 (the only class built: NSP = 48).
+// lane, and 16 such rows are what one transfer instruction writes.  The x / skip row set has its own copy of the z part in ITS
+// order where the LDS has room (kernel_size 2 class, NSP = 48: 148 KB); the kernel_size 3 class (NSP = 64) reads z where the gate
+// set's order put it.
 #include "wn_dlp.h"
 
 #include <type_traits>
@@ -48,9 +49,15 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlpf(WnDlpArgs a) {
     WN_DYN_SMEM(smem_raw);
     constexpr int CG = 8, SL = 32, CB = WN_DLPM_CB;
     constexpr int KPAD = SL * NSP, XPAD = SL * NSX;
+    // XCOPY: the x / skip row set has its own copy of the z part in ITS tile order (kernel_size 2 class: 148 KB of LDS).  The
+    // kernel_size 3 class (NSP = 64: 128 KB of inputs) has no room for it: that set reads the z part where the gate set's order
+    // put it -- the k of its lane group q sit 64 floats apart there as well (NSP = 4 NSX), but the four groups are 16 rows apart
+    // in every tile step: 4-way bank conflicts on 16 of the 80 tile steps.
+    constexpr bool XCOPY = NSP * 3 <= 160;
+    static_assert(XCOPY || NSP == 4 * NSX, "without its own copy the x / skip set reads the gate set's order: NSP = 4 NSX");
     float* s_p = reinterpret_cast<float*>(smem_raw);   // [KPAD][CB] inputs in the order of the gate row set's tile steps
     float* s_x = s_p + KPAD * CB;                      // [XPAD][CB] the z part (post net: the vector) in the x / skip set's order
-    float* s_red = s_x + XPAD * CB;                    // partial tiles [2 sets][8 waves][16 rows][16 columns]
+    float* s_red = s_x + (XCOPY ? XPAD * CB : 0);      // partial tiles [2 sets][8 waves][16 rows][16 columns]
     float* s_xown = s_red + 4096;                      // [8][CB] x of the unit's own channels (previous stage)
     float* s_sk = s_xown + 8 * CB;                     // [8][CB] skip accumulators of the unit's rows
     int* s_tok = reinterpret_cast<int*>(s_sk + 8 * CB);   // [3][CB] the newest K tokens of the block's utterances
@@ -76,7 +83,7 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlpf(WnDlpArgs a) {
     const wn_rsrc_t rQ = wn_make_buf(a.queues, (unsigned)(a.qfloats * B * 4 + 64));   // (+ the 16 floats a ragged block's last row reads past B; the region is carved with 64)
     auto posP = [&](int k) -> int { const int g = k / NSP, i = k - g * NSP; return (((g >> 2) * NSP + i) * 4 + (g & 3)) * CB; };
 
-    for (int i = tid; i < KPAD * CB + XPAD * CB; i += WN_DLP_T) s_p[i] = 0.0f;
+    for (int i = tid; i < KPAD * CB + (XCOPY ? XPAD * CB : 0); i += WN_DLP_T) s_p[i] = 0.0f;
     for (int i = tid; i < 8 * CB; i += WN_DLP_T) { s_xown[i] = 0.0f; s_sk[i] = 0.0f; }
     for (int i = tid; i < K * CB; i += WN_DLP_T) {
         const int j = i / CB, c = i % CB;
@@ -126,10 +133,9 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlpf(WnDlpArgs a) {
         }
     };
     // one row set times the staged column block: tile step i of this wave reads the 64 consecutive floats behind it
-    auto tile = [&](const auto& w, auto ns_c, const float* region, int set, bool on) {
+    auto tile = [&](const auto& w, auto ns_c, const float* src, int set, bool on) {   // src: this lane's element of tile step 0
         constexpr int ns = decltype(ns_c)::value;
         if (!on) return;
-        const float* src = region + (wave * ns) * 64 + lane;
         f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
         constexpr int G = 8;
         static_assert(ns % G == 0, "groups of 8 tile steps");
@@ -162,8 +168,27 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlpf(WnDlpArgs a) {
         for (int w = 0; w < 8; ++w) s += pp[w * 256];
         return s;
     };
-    // rows [0, rows) of a plain [rows][Bp] vector into s_x in the x / skip set's order
+    // rows [lo, hi) of a plain [..][Bp] array (row0 = its row of k = 0) into the gate set's order (s_p).  One transfer instruction
+    // moves 16 bytes per lane = 4 tile steps x 4 lane groups x 16 columns (1 KB of LDS in tile order): lane l carries columns
+    // 4 (l % 4) .. + 3 of the row  k = (4 wave + qd) NSP + i4 + id,  qd = (l / 4) % 4,  id = l / 16.
+    auto fetch_p = [&](wn_rsrc_t rs, int row0, int lo, int hi) {
+        if (4 * wave * NSP >= hi || 4 * (wave + 1) * NSP <= lo) return;   // (wave-uniform) none of the wave's four groups reaches the range
+        const int qd = (lane >> 2) & 3, id = lane >> 4, c4 = (lane & 3) * 4;
+        const int k0 = (4 * wave + qd) * NSP + id;
+        unsigned voff = (unsigned)(((row0 + k0) * Bp + cblk * CB + c4) * 4);
+        WN_NOUNROLL
+        for (int i4 = 0; i4 < NSP; i4 += 4) {
+            if (k0 + i4 >= lo && k0 + i4 < hi)
+                wn_buf_load_lds16_coherent(rs, reinterpret_cast<char*>(s_p + (wave * NSP + i4) * 64), (int)voff, 0u);
+            voff += (unsigned)(4 * Bp * 4);
+        }
+    };
+    // rows [0, rows) of a plain [rows][Bp] vector for the x / skip row set: into its own order (s_x), or where the gate set has them
     auto fetch_vector_x = [&](wn_rsrc_t rs, int row0, int rows) {
+        if (!XCOPY) {
+            fetch_p(rs, row0, 0, rows);
+            return;
+        }
         const int qd = (lane >> 2) & 3, id = lane >> 4, c4 = (lane & 3) * 4;
         const int k0 = (4 * wave + qd) * NSX + id;
         WN_NOUNROLL
@@ -172,6 +197,9 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlpf(WnDlpArgs a) {
                 wn_buf_load_lds16_coherent(rs, reinterpret_cast<char*>(s_x + (wave * NSX + i4) * 64), ((row0 + k0 + i4) * Bp + cblk * CB + c4) * 4, 0u);
         }
     };
+    // this lane's element of tile step 0 of the two row sets
+    const float* srcP = s_p + (wave * NSP) * 64 + lane;
+    const float* srcX = XCOPY ? s_x + (wave * NSX) * 64 + lane : s_p + posP((4 * wave + q) * NSX) + lc;
 
     float wP[NSP], wX[NSX];
     auto issue_stage_weights = [&](int sn) {   // stage sn in [0, L]
@@ -208,16 +236,8 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlpf(WnDlpArgs a) {
                 const int qd = (lane >> 2) & 3, id = lane >> 4, c4 = (lane & 3) * 4;
                 const int k0 = (4 * wave + qd) * NSP + id;   // + i4
                 const int kw_lo = 4 * wave * NSP, kw_hi = kw_lo + 4 * NSP;     // (wave-uniform) k range of the wave's groups
-                const int need_lo = s >= 1 ? 0 : R, need_hi = s >= 2 ? 2 * R : (s >= 1 ? R : 0);   // rows of [z | x] that are handed over
-                if (kw_lo < need_hi && kw_hi > need_lo) {
-                    unsigned voff = (unsigned)(((par * 2 * R + k0) * Bp + cblk * CB + c4) * 4);
-                    WN_NOUNROLL
-                    for (int i4 = 0; i4 < NSP; i4 += 4) {
-                        if (k0 + i4 >= need_lo && k0 + i4 < need_hi)
-                            wn_buf_load_lds16_coherent(rZX, reinterpret_cast<char*>(s_p + (wave * NSP + i4) * 64), (int)voff, 0u);
-                        voff += (unsigned)(4 * Bp * 4);
-                    }
-                }
+                // rows of [z | x] that are handed over: z from stage 1 on, x from stage 2 on
+                fetch_p(rZX, par * 2 * R, s >= 1 ? 0 : R, s >= 2 ? 2 * R : (s >= 1 ? R : 0));
                 if (kw_hi > 2 * R && kw_lo < KP) {
                     // (rows of a [..][B] ring are 4 B bytes apart: 16-byte transfers from 4-byte aligned addresses; the columns of a
                     // ragged last block past B read the next row's first floats, which nobody uses)
@@ -266,7 +286,8 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlpf(WnDlpArgs a) {
                     }
                 }
             }
-            if (hasX) fetch_vector_x(rZX, par * 2 * R, R);   // x / skip row set: the z part in its own order
+            if (hasX && (XCOPY || !hasP)) fetch_vector_x(rZX, par * 2 * R, R);   // x / skip row set: the z part in its own order (without a
+                                                                                 // copy it is where the gate set's transfers put it)
             // (2) what this thread's output reads from memory.  Output row kk: 0 .. 7 gate of channel c0 + kk, 8 .. 15 x of
             // channel c0 + kk - 8, 16 .. 16 + SU - 1 skip rows
             float e0 = 0.0f, e1 = 0.0f;
@@ -290,8 +311,8 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlpf(WnDlpArgs a) {
             __syncthreads();
             DLPF_STAMP(s, 2);
             // (3) the two row sets on the matrix cores
-            tile(wP, std::integral_constant<int, NSP>(), s_p, 0, hasP);
-            tile(wX, std::integral_constant<int, NSX>(), s_x, 1, hasX);
+            tile(wP, std::integral_constant<int, NSP>(), srcP, 0, hasP);
+            tile(wX, std::integral_constant<int, NSX>(), srcX, 1, hasX);
             DLPF_STAMP(s, 3);
             __syncthreads();
             DLPF_STAMP(s, 4);
@@ -346,7 +367,7 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlpf(WnDlpArgs a) {
             }
             WN_WAIT_VMCNT(0);
             __syncthreads();
-            tile(wX, std::integral_constant<int, NSX>(), s_x, 0, true);
+            tile(wX, std::integral_constant<int, NSX>(), srcX, 0, true);
             __syncthreads();
             if (live && kk < 16) {
                 if (stage == 0) {
@@ -425,18 +446,9 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlpf(WnDlpArgs a) {
     if (tid == 0 && s_flag[0]) a.err[0] = 1;
 }
 
-int wn_dlpf_covers(const WnDlpPlan* plan) { return plan->ok && plan->wide && plan->RS == 16 && plan->NSP == 48 && plan->NSX == 16; }
-
-int wn_dlpf_launch(const WnDlpArgs* ap, wn_stream_t st) {
-    const WnDlpArgs& a = *ap;
-    if (!wn_dlpf_covers(&a.plan) || !a.handoff || !a.flags || a.B < 1 || a.B > WN_DLPM_BMAX || a.p1 < a.p0) return 1;
-    const int nblk = (a.B + WN_DLPM_CB - 1) / WN_DLPM_CB;
-    if (a.Bp != nblk * WN_DLPM_CB || a.plan.NU * nblk > WN_DLPM_MAXWG) return 1;
-    if (a.mode != 0 && a.mode != 1) return 2;
-    if ((long)2 * 2 * a.R * a.Bp * 4 > 0x7fffffffL || a.qfloats * a.B * 4 > 0xffffffffL) return 1;
-    WN_PROF("dlpf_steps", 0.0, 0.0, st);
-    constexpr int NSP = 48, NSX = 16;
-    const size_t lds = ((size_t)32 * NSP * 16 + 32 * NSX * 16 + 4096 + 8 * 16 + 8 * 16 + 4 * 16 + 64) * 4;
+template <int NSP, int NSX>
+static int launch_flags(const WnDlpArgs& a, int nblk, wn_stream_t st) {
+    const size_t lds = ((size_t)32 * NSP * 16 + (NSP * 3 <= 160 ? 32 * NSX * 16 : 0) + 4096 + 8 * 16 + 8 * 16 + 4 * 16 + 64) * 4;
 #ifndef WN_EMU
     static bool attr_set = false;
     if (!attr_set) {
@@ -449,3 +461,17 @@ int wn_dlpf_launch(const WnDlpArgs* ap, wn_stream_t st) {
     WN_LAUNCH_COOP((k_dlpf<NSP, NSX>), dim3((unsigned)(a.plan.NU * nblk)), dim3(WN_DLP_T), lds, st, a);
     return 0;
 }
+
+int wn_dlpf_covers(const WnDlpPlan* plan) { return plan->ok && plan->wide && plan->RS == 16 && (plan->NSP == 48 || plan->NSP == 64) && plan->NSX == 16; }
+
+int wn_dlpf_launch(const WnDlpArgs* ap, wn_stream_t st) {
+    const WnDlpArgs& a = *ap;
+    if (!wn_dlpf_covers(&a.plan) || !a.handoff || !a.flags || a.B < 1 || a.B > WN_DLPM_BMAX || a.p1 < a.p0) return 1;
+    const int nblk = (a.B + WN_DLPM_CB - 1) / WN_DLPM_CB;
+    if (a.Bp != nblk * WN_DLPM_CB || a.plan.NU * nblk > WN_DLPM_MAXWG) return 1;
+    if (a.mode != 0 && a.mode != 1) return 2;
+    if ((long)2 * 2 * a.R * a.Bp * 4 > 0x7fffffffL || a.qfloats * a.B * 4 > 0xffffffffL) return 1;
+    WN_PROF("dlpf_steps", 0.0, 0.0, st);
+    return a.plan.NSP == 48 ? launch_flags<48, 16>(a, nblk, st) : launch_flags<64, 16>(a, nblk, st);
+}
+

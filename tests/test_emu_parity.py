@@ -700,6 +700,33 @@ def test_any_size_decode_of_more_utterances_than_one_persistent_launch_takes():
     assert all(torch.equal(a, b) for a, b in zip(sp, sl))
 
 
+def test_any_size_decode_flag_hand_off_kernel_size_3_class():
+    """The kernel_size 3 class of csrc/wn_dlpf.hip (64 tile steps per wave: (K + 1) n_resch > 1536 -- the ljspeech recipes'
+    n_resch 512 / kernel_size 3; no room in LDS for the x / skip set's own copy of z, it reads the gate set's order): 416 channels,
+    2 layers, 3 ragged utterances on the emulator's cooperative launch (52 workgroups) -- logits within 1e-5 of the queue algorithm
+    (oracle), tokens equal to the layer-wise launches'."""
+    import numpy as np
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd.nets import WaveNet
+    cfg_t = (32, 4, 416, 32, 2, 1, 3, 4)
+    cfg = O.OracleConfig(*cfg_t)
+    params = O.random_params(cfg, 13, scale=0.05)
+    model = WaveNet(*cfg_t, _library=emu_library())
+    model.load_state_dict(params)
+    rs = np.random.RandomState(3)
+    xs = torch.from_numpy(rs.randint(0, 32, (3, 4))).long()
+    hs = torch.from_numpy(rs.standard_normal((3, 4, 4)).astype(np.float32))
+    ns = [4, 3, 4]
+    out = {}
+    log = PC.launch_log(emu_library(), lambda: out.update(p=model.engine.decode(xs, hs, ns, return_logits=True, layered=True)))
+    assert log.get("dlpf_steps", 0) == 1 and "dl_dilated" not in log and "dlpm_steps" not in log, log
+    tl, ll = model.engine.decode(xs, hs, ns, return_logits=True, layered="launches")
+    for b in range(3):
+        rt, rl = O.fast_generate(cfg, params, xs[b:b + 1], hs[b:b + 1], ns[b], return_logits=True)
+        assert float((out["p"][1][b] - rl).abs().max()) <= 1e-5, b
+        assert torch.equal(out["p"][0][b], tl[b]), b
+
+
 def test_front_conv_weight_gradient_on_the_matrix_cores():
     """k_front_dw_mfma (R = 32 or a multiple of 64, K * Q <= 1024): the front conv's weight gradient as a contraction over time with a
     one-hot B operand built from the token indices, instead of LDS float atomics.  256 classes x 2 taps (all 16 column
