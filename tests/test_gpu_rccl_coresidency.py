@@ -101,5 +101,6 @@ def test_a_16_workgroup_kernel_runs_beside_the_full_size_backward_chain():
           "last one ended at %.2f ms" % (ms_with, ms_without, start_first, start_last, end_last))
     assert bwd > 3.0                                   # the full-size backward pass (chain + weight gradients)
     assert start_last < bwd - 2.0, (start_last, bwd)   # every workgroup was placed while the chain was running, not after it
-    # the foreign kernel costs the pass what its traffic and its 16 CUs cost (measured 3 - 6 %), not its own duration in series
-    assert ms_with <= 1.10 * ms_without + 0.1, (ms_with, ms_without)
+    # the foreign kernel costs the pass what its traffic and its 16 CUs cost (measured 1 - 6 % from box to box); the bound only
+    # catches a pathology (the two starving each other), the placement assertions above are the point of the test
+    assert ms_with <= 1.25 * ms_without + 0.2, (ms_with, ms_without)
