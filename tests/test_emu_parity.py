@@ -756,3 +756,30 @@ def test_transpose_op_on_the_emulator():
         lib.check(lib.wn_op_transpose_last2(x.data_ptr(), y.data_ptr(), B, R, C, None), "wn_op_transpose_last2")
         assert torch.equal(y, x.transpose(1, 2).contiguous())
     assert lib.wn_op_transpose_last2(x.data_ptr(), x.data_ptr(), 1, 4, 4, None) != 0   # in place: refused
+
+
+def test_persistent_decode_dispatch_rules():
+    """Which path a batch takes at the recipes' size (n_resch 512; no launch: plan queries only): one persistent launch up to 48
+    utterances, two groups up to 96, the layer-wise launches beyond and for explicit requests; the kernel_size 3 class likewise;
+    1024 channels are outside the compiled classes (launches at any batch)."""
+    import ctypes
+    from pytorchwavenetvocoder_amd.engine import WaveNetEngine
+    lib = emu_library()
+    for K in (2, 3):
+        eng = WaveNetEngine(256, 80, 512, 256, 10, 3, K, 80, device="cpu", library=lib)
+        cfg = ctypes.byref(eng.cfg)
+        assert not eng.decode_supported()
+        for B in (1, 2, 5, 16, 17, 48):
+            assert lib.wn_decode_layered_error_offset(cfg, B) >= 0, (K, B)      # one persistent launch
+            assert eng._persistent_groups(B, None, "argmax") is None
+        assert lib.wn_decode_layered_error_offset(cfg, 49) < 0
+        assert eng._persistent_groups(49, None, "argmax") == [(0, 48), (48, 49)]
+        assert eng._persistent_groups(96, True, "sampling") == [(0, 48), (48, 96)]
+        assert eng._persistent_groups(97, None, "argmax") is None                  # three groups: the launches are as fast
+        assert eng._persistent_groups(64, "launches", "argmax") is None
+        assert eng._persistent_groups(64, None, "mol") is None
+    # 1024 channels: (K + 1) n_resch exceeds every compiled class -- layer-wise launches at any batch
+    big = WaveNetEngine(256, 80, 1024, 256, 10, 3, 2, 80, device="cpu", library=lib)
+    assert lib.wn_decode_layered_error_offset(ctypes.byref(big.cfg), 1) < 0 and big._persistent_groups(64, None, "argmax") is None
+    small = WaveNetEngine(256, 80, 64, 256, 10, 3, 2, 80, device="cpu", library=lib)
+    assert small.decode_supported() and small._persistent_groups(64, None, "argmax") is None   # the one-workgroup kernel takes it
