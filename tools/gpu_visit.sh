@@ -18,6 +18,14 @@ fi
 if has smoke; then
   timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1; echo "smoke rc=$?"
 fi
+if has pmc; then
+  # BEFORE the bench part: bench.py quotes the counter file of the newest profiles/rNN (PMC_FILES) and checks its source digest;
+  # within a visit the fresh summary is copied there on the box, so that the bench line of the same visit says traffic_same_build
+  # (the copy on the box is lost with it: copy gpurun_out/pmc_traffic.json into profiles/ and commit it as well)
+  bash tools/pmc_traffic.sh
+  NEWEST=$(ls -d profiles/r[0-9][0-9] 2>/dev/null | sort | tail -1)
+  [ -n "$NEWEST" ] && [ -f $OUT/pmc_traffic.json ] && cp $OUT/pmc_traffic.json $NEWEST/pmc_traffic.json
+fi
 if has bench; then
   timeout 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cut -c1-400 $OUT/bench.json
 fi
@@ -58,9 +66,6 @@ if has rocprof; then
   python tools/kernel_gaps.py $OUT/prof_stats > $OUT/kernel_gaps.txt 2>&1; cat $OUT/kernel_gaps.txt
   find $OUT/prof_stats -name "*kernel_trace.csv" -delete
   head -12 $OUT/rocprofv3_kernel_stats.csv
-fi
-if has pmc; then
-  bash tools/pmc_traffic.sh
 fi
 if has recipesize; then
   # BASELINE configs[3] geometry (kernel_size 3, upsampling 256, T = 26112), softmax head
