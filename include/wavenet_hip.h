@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define WN_ABI_VERSION 7
+#define WN_ABI_VERSION 8
 
 /* Same fields as the constructor WaveNet(n_quantize, n_aux, n_resch, n_skipch, dilation_depth,
  * dilation_repeat, kernel_size, upsampling_factor)  -- reference wavenet.py:172-173. */
@@ -299,29 +299,37 @@ int wn_decode_steps(const WnConfig* cfg, int B, const float* params, const float
 /* Any-size variant of the same decode (layer-wise launches of the contraction kernels on [channels x B]
  * operands: one pass over the weights per step serves the whole batch).  Same positions / teacher forcing
  * / mode / uniforms / logits_out conventions as wn_decode_steps.  `state` is ONE caller-owned buffer of
- * wn_decode_layered_state_floats(cfg, B) floats, zero-filled before wn_decode_layered_prepare, which packs
+ * wn_decode_layered_state_floats(cfg, B, mode) floats, zero-filled before wn_decode_layered_prepare, which packs
  * the weights into it and computes G (B, F, L*2R) from h (B, n_aux, F).  A later wn_decode_layered_prepare on the
  * same state with params == NULL keeps the packed weights and only projects the given window of h (a decode
  * without an upsampling layer projects one window of aux columns per chunk of steps). */
-int64_t wn_decode_layered_state_floats(const WnConfig* cfg, int B);
+int64_t wn_decode_layered_state_floats(const WnConfig* cfg, int B, int mode);
 /* Since ABI v7: for models the plan of csrc/wn_dlp.h covers (n_resch % 32 == 0, kernel_size 2 or 3, B <= 48, softmax head)
  * wn_decode_layered_steps runs the whole range of steps as ONE launch of workgroups that hand their vectors to each other as
  * 8-byte {value, tag} granules or as plain vectors + one flag per workgroup and stage (the recipes' n_resch = 512 model: 66
  * dependent launches per step before): n_resch / 4 workgroups with fp32 VALU dot products for one utterance (wn_dlp.hip),
- * n_resch / 8 workgroups per block of 16 utterances with v_mfma_f32_16x16x4_f32 tiles up to 48 (wn_dlpf.hip / wn_dlpm.hip; all
- * workgroups must be resident: at most 240).
- * `mode | WN_DECODE_BY_LAUNCHES` keeps the layer-wise launches (independent check, A/B).  The persistent launch bounds every
- * wait; wn_decode_layered_error_offset() is the float offset in `state` of an int that is non-zero afterwards if a wait
- * timed out (-1: this model / B decodes by launches). */
+ * n_resch / 8 workgroups per block of 16 utterances with v_mfma_f32_16x16x4_f32 tiles up to 48 (wn_dlpf.hip / wn_dlpm.hip).
+ * Every workgroup of such a launch waits for the others, so ALL of them must be resident at once: the library asks the device
+ * (occupancy of the chosen kernel x compute units, since ABI v8) when it chooses the path, and a grid that does not fit -- a
+ * partitioned GPU, a part with fewer CUs -- decodes by layer-wise launches; wn_decode_layered_residency() reports the numbers.
+ * Mode bits (the SAME bits go to every call of one decode -- state_floats / error_offset / prepare / steps, and OR-ed into
+ * `layered` of wn_decode_prefill -- because the layout of `state` depends on them):
+ *   WN_DECODE_BY_LAUNCHES  wn_decode_layered_steps keeps the layer-wise launches (independent check, A/B, fall-back);
+ *   WN_DECODE_GRANULES     (since ABI v8; replaces the process-wide wn_decode_set_handoff of v7) the persistent launches hand
+ *                          their vectors over as 8-byte granules everywhere instead of plain vectors + one flag per workgroup
+ *                          and stage where wn_dlpf.hip covers the plan (A/B, tests).
+ * The persistent launch bounds every wait; wn_decode_layered_error_offset() is the float offset in `state` of an int that is
+ * non-zero afterwards if a wait timed out (-1: this model / B / device decodes by launches).  A launch that finds the word
+ * non-zero returns at once, so a caller may check it after any chunk of steps. */
 #define WN_DECODE_BY_LAUNCHES 256
-/* A/B and test knob (process-wide): 1 = the persistent launches hand their vectors over as 8-byte granules everywhere, 0 (default)
- * = as plain vectors + one flag per workgroup and stage where wn_dlpf.hip covers the plan (kernel_size 2 classes, 5 - 48
- * utterances).  The state layout depends on it: set it before wn_decode_layered_state_floats and leave it alone until the decode
- * is over.  Returns the previous setting. */
-int wn_decode_set_handoff(int granules);
-int64_t wn_decode_layered_error_offset(const WnConfig* cfg, int B);
+#define WN_DECODE_GRANULES 512
+int64_t wn_decode_layered_error_offset(const WnConfig* cfg, int B, int mode);
+/* 1: wn_decode_layered_steps(cfg, B, mode) runs as one persistent launch on the current device, 0: as layer-wise launches;
+ * *workgroups (nullable) = the grid the plan asks for (0: no plan covers this model / B), *capacity (nullable) = workgroups of
+ * that kernel the device keeps resident at once.  < 0: bad argument. */
+int wn_decode_layered_residency(const WnConfig* cfg, int B, int mode, int* workgroups, int* capacity);
 int wn_decode_layered_prepare(const WnConfig* cfg, int B, int F, const float* params, const float* h, float* G, float* state,
-                              int64_t state_floats, void* stream);
+                              int64_t state_floats, int mode, void* stream);
 int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* params, const float* G, int F, int n_pad,
                             int64_t* samples, int64_t Ttot, const int32_t* t_forced, const int32_t* t_end, int p0, int p1,
                             float* state, int64_t state_floats, const float* uniforms, float* logits_out, int mode,
@@ -339,8 +347,9 @@ int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* params, con
  *                       replicating the first upsampled column (wavenet.py:336, 425);
  *   wn_decode_prefill   runs the residual stack of the training forward on x_ctx (B, Tctx) / h_ctx and copies
  *                       the newest (K-1)*d_l layer inputs of every layer into the dilation queues of `state`
- *                       (layered = 0: the (B, wn_decode_state_floats) state of wn_decode_steps; 1: the state of
- *                       wn_decode_layered_steps, after wn_decode_layered_prepare).  The B utterances of the call
+ *                       (layered = 0: the (B, wn_decode_state_floats) state of wn_decode_steps; 1 [| WN_DECODE_GRANULES
+ *                       when the decode runs with that bit]: the state of wn_decode_layered_steps, after
+ *                       wn_decode_layered_prepare).  The B utterances of the call
  *                       are utterances [state_b0, state_b0 + B) of a state built for state_B utterances, so a
  *                       large batch can be walked in groups with a bounded workspace.  Decoding then resumes
  *                       with p0 = Tctx-1, the last context position, whose logits choose the first new sample.

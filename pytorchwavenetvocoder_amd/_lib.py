@@ -75,7 +75,8 @@ FLAG_AUX_FUSED = 32  # wn_backward: aux-gradient partial sums in the gate kernel
 FLAG_BWD_OVERLAP_HEAD = 16  # with FLAG_BWD_OVERLAP: only the post-net / skip weight gradients on the side stream
 FLAG_FWD_OVERLAP = 8  # wn_forward: chunked skip-sum on the side stream beside the residual stack (opt-in)
 FLAG_WS_FINITE = 1 << 16  # wn_forward_loss: the workspace holds only finite values (the engine allocates it zero-filled)
-DECODE_BY_LAUNCHES = 256  # wn_decode_layered_steps: mode bit that keeps the layer-wise launches (csrc/wn_dlp.hip otherwise)
+DECODE_BY_LAUNCHES = 256  # wn_decode_layered_*: mode bit that keeps the layer-wise launches (csrc/wn_dlp.hip otherwise)
+DECODE_GRANULES = 512  # wn_decode_layered_*: mode bit, the persistent launches hand over 8-byte granules everywhere (A/B, tests)
 FLAG_REPACK = 1 << 17  # wn_backward: rebuild the packed / pre-split weight sets from the params given to that call
 
 
@@ -84,13 +85,13 @@ def flag_dw_flush(n):
     return (int(n) & 0xff) << 8
 
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # every symbol include/wavenet_hip.h declares
 EXPORTS = [
     "wn_abi_version", "wn_last_error", "wn_receptive_field", "wn_num_layers", "wn_param_count", "wn_param_offset",
     "wn_num_buckets", "wn_bucket_range", "wn_dead_param_range", "wn_workspace_bytes", "wn_workspace_region", "wn_forward",
-    "wn_softmax_ce_loss", "wn_forward_loss_fused", "wn_forward_loss", "wn_backward", "wn_backward_window", "wn_adam_step", "wn_op_front", "wn_op_causal_conv", "wn_op_upsampling", "wn_op_transpose_last2", "wn_decode_set_handoff", "wn_op_gemm", "wn_prof_enable", "wn_prof_report", "wn_prof_sequence",
+    "wn_softmax_ce_loss", "wn_forward_loss_fused", "wn_forward_loss", "wn_backward", "wn_backward_window", "wn_adam_step", "wn_op_front", "wn_op_causal_conv", "wn_op_upsampling", "wn_op_transpose_last2", "wn_decode_layered_residency", "wn_op_gemm", "wn_prof_enable", "wn_prof_report", "wn_prof_sequence",
     "wn_decode_supported", "wn_decode_pack_floats", "wn_decode_state_floats", "wn_decode_pack", "wn_decode_aux",
     "wn_decode_steps", "wn_decode_stream_bytes",
     "wn_decode_layered_state_floats", "wn_decode_layered_error_offset", "wn_decode_layered_prepare", "wn_decode_layered_steps", "wn_mol_loss",
@@ -100,6 +101,10 @@ EXPORTS = [
 
 class WnError(RuntimeError):
     pass
+
+
+class WnDecodeTimeout(WnError):
+    """The persistent decode launch gave up waiting between its workgroups (they were not all resident at once)."""
 
 
 class WnLibrary(object):
@@ -139,7 +144,6 @@ class WnLibrary(object):
         L.wn_op_causal_conv.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
         L.wn_op_upsampling.argtypes = [vp, vp, vp, vp, i, i, i, i, vp]
         L.wn_op_transpose_last2.argtypes = [vp, vp, i, i, i, vp]
-        L.wn_decode_set_handoff.argtypes = [i]
         L.wn_op_gemm.argtypes = [ctypes.POINTER(WnGemmArgs), vp]
         L.wn_prof_enable.argtypes = [i]
         L.wn_prof_report.argtypes = [ctypes.c_char_p, sz]
@@ -155,11 +159,12 @@ class WnLibrary(object):
         L.wn_decode_aux.argtypes = [cfgp, i, i, vp, vp, vp, vp]
         L.wn_decode_steps.argtypes = [cfgp, i, vp, vp, vp, i, i, vp, i64, vp, vp, i, i, vp, vp, vp, i, vp, f, vp]
         L.wn_mol_loss.argtypes = [cfgp, i, i, vp, vp, i, f, f, i, f, vp, vp, vp, sz, vp]
-        L.wn_decode_layered_state_floats.argtypes = [cfgp, i]
+        L.wn_decode_layered_state_floats.argtypes = [cfgp, i, i]
         L.wn_decode_layered_state_floats.restype = i64
-        L.wn_decode_layered_error_offset.argtypes = [cfgp, i]
+        L.wn_decode_layered_error_offset.argtypes = [cfgp, i, i]
         L.wn_decode_layered_error_offset.restype = i64
-        L.wn_decode_layered_prepare.argtypes = [cfgp, i, i, vp, vp, vp, vp, i64, vp]
+        L.wn_decode_layered_residency.argtypes = [cfgp, i, i, ctypes.POINTER(i), ctypes.POINTER(i)]
+        L.wn_decode_layered_prepare.argtypes = [cfgp, i, i, vp, vp, vp, vp, i64, i, vp]
         L.wn_decode_layered_steps.argtypes = [cfgp, i, vp, vp, i, i, vp, i64, vp, vp, i, i, vp, i64, vp, vp, i, vp, f, vp]
         L.wn_decode_ctx_aux.argtypes = [cfgp, i, i, i, i, i, vp, vp, vp, vp]
         L.wn_decode_prefill_workspace_bytes.argtypes = [cfgp, i, i]

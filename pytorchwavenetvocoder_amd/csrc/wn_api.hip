@@ -1539,16 +1539,6 @@ extern "C" int wn_op_transpose_last2(const float* src, float* dst, int B, int R,
     return rt_check("wn_op_transpose_last2");
 }
 
-// A/B and test knob of the persistent any-size decode: 1 = hand its vectors over as 8-byte granules everywhere (wn_dlp.hip,
-// wn_dlpm.hip), 0 (default) = plain vectors + flags where wn_dlpf.hip covers the plan.  Process-wide; the state layout depends
-// on it, so it must not change between wn_decode_layered_state_floats / _prepare / _steps of one decode.
-static int g_decode_granules = 0;
-extern "C" int wn_decode_set_handoff(int granules) {
-    const int old = g_decode_granules;
-    g_decode_granules = granules ? 1 : 0;
-    return old;
-}
-
 // ------------------------------------------------------------------------------------------
 // autoregressive decode (wavenet.py:309-511, 538-549)
 // ------------------------------------------------------------------------------------------
@@ -1709,9 +1699,13 @@ struct DlLay {
     WnDlpPlan dlp;
     long dlp_w, dlp_post, dlp_cfold, dlp_fold, dlp_gz, dlp_gx, dlp_gs, dlp_go, dlp_gl, dlp_flags, dlp_pq, dlp_err;
     int dlp_flags_on;        // 1: wn_dlpf.hip (plain vectors + flags) runs this model / batch
+    int dlp_grid, dlp_capacity;   // workgroups of the persistent launch the plan asks for / the device keeps resident at once
 };
 
-static int dl_layout(const WnConfig* cfg, const Dims& d, int nb, DlLay* y) {
+// granules (mode bit WN_DECODE_GRANULES): the persistent launches hand their vectors over as 8-byte granules everywhere
+// (wn_dlp.hip, wn_dlpm.hip) instead of plain vectors + flags where wn_dlpf.hip covers the plan -- the state layout depends on it,
+// so every call of one decode passes the same bit.
+static int dl_layout(const WnConfig* cfg, const Dims& d, int nb, bool granules, DlLay* y) {
     const int Ue = d.U > 0 ? d.U : 1;
     WN_TRY(make_ws(d, 1, Ue, &y->w, /*training*/ false));
     long sumd = 0;
@@ -1736,7 +1730,7 @@ static int dl_layout(const WnConfig* cfg, const Dims& d, int nb, DlLay* y) {
     // (the flag hand-off kernel wn_dlpf.hip costs the same ~250 us per step for 2 .. 16 utterances at n_resch 512, the VALU kernel
     // 252 / 321 / 366 for 2 / 3 / 4: from 2 utterances on where wn_dlpf.hip covers the matrix-core plan, from WN_DLPM_BMIN otherwise)
     int wide = nb >= WN_DLPM_BMIN ? 1 : 0;
-    if (!wide && nb >= 2 && WN_DLPF_ENABLE && !g_decode_granules) {
+    if (!wide && nb >= 2 && WN_DLPF_ENABLE && !granules) {
         WnDlpPlan pw;
         wn_dlp_make_plan(d.Q, d.Qo, d.R, d.S, d.L, d.K, 1, &pw);
         if (wn_dlpf_covers(&pw)) wide = 1;
@@ -1745,7 +1739,16 @@ static int dl_layout(const WnConfig* cfg, const Dims& d, int nb, DlLay* y) {
     if (nb > (y->dlp.wide ? WN_DLPM_BMAX : WN_DLP_BMAX)) y->dlp.ok = 0;
     const int dlp_blocks = y->dlp.wide ? (nb + WN_DLPM_CB - 1) / WN_DLPM_CB : 1;   // k_dlpm: a set of units per block of 16 utterances
     if (y->dlp.ok && y->dlp.NU * dlp_blocks > WN_DLPM_MAXWG) y->dlp.ok = 0;
-    y->dlp_flags_on = 0;
+    y->dlp_flags_on = (y->dlp.ok && WN_DLPF_ENABLE && !granules && wn_dlpf_covers(&y->dlp)) ? 1 : 0;
+    y->dlp_grid = y->dlp_capacity = 0;
+    if (y->dlp.ok) {
+        // every workgroup of the launch waits for the others: all of them must be resident at once.  Asked of the device (occupancy
+        // of the chosen kernel x CUs) here, where the path is chosen -- a grid that does not fit (a partitioned GPU, fewer CUs)
+        // decodes by layer-wise launches instead of running its polls into their time-outs.
+        y->dlp_grid = y->dlp.NU * dlp_blocks;
+        y->dlp_capacity = y->dlp_flags_on ? wn_dlpf_capacity(&y->dlp) : (y->dlp.wide ? wn_dlpm_capacity(&y->dlp) : wn_dlp_capacity(&y->dlp));
+        if (y->dlp_grid > y->dlp_capacity) { y->dlp.ok = 0; y->dlp_flags_on = 0; }
+    }
     if (y->dlp.ok) {
         const WnDlpPlan& pl = y->dlp;
         DCARVE(dlp_w, (long)(d.L + 1) * pl.NU * pl.stage_floats);
@@ -1754,7 +1757,6 @@ static int dl_layout(const WnConfig* cfg, const Dims& d, int nb, DlLay* y) {
         DCARVE(dlp_fold, (long)2 * d.R * d.R);
         // hand-off regions: 8-byte granules (two floats each) [rows][nb], or -- wn_dlpf.hip: plain vectors + one flag per unit and
         // block -- floats [rows][Bp], Bp = 16 * blocks (which fit the same regions carved with Bp columns)
-        y->dlp_flags_on = (WN_DLPF_ENABLE && !g_decode_granules && wn_dlpf_covers(&pl)) ? 1 : 0;
         const long Bp = pl.wide ? (long)dlp_blocks * WN_DLPM_CB : nb;
         DCARVE(dlp_gz, 2L * 2 * d.R * Bp);
         DCARVE(dlp_gx, 2L * 2 * d.R * Bp);
@@ -1788,22 +1790,37 @@ static void dl_ctx(Ctx* c, const WnConfig* cfg, const Dims& d, const DlLay& y, i
     c->have_pre = false;
 }
 
-extern "C" int64_t wn_decode_layered_state_floats(const WnConfig* cfg, int B) {
+extern "C" int64_t wn_decode_layered_state_floats(const WnConfig* cfg, int B, int mode) {
     Dims d;
     if (check_cfg(cfg, &d) || B < 1) return -1;
     DlLay y;
-    if (dl_layout(cfg, d, B, &y)) return -1;
+    if (dl_layout(cfg, d, B, (mode & WN_DECODE_GRANULES) != 0, &y)) return -1;
     return y.total;
 }
 
 // Float offset inside `state` of the error word of the persistent path (an int: non-zero after a launch whose workgroups
 // timed out waiting for each other), or -1 when wn_decode_layered_steps runs as layer-wise launches for this model / B.
-extern "C" int64_t wn_decode_layered_error_offset(const WnConfig* cfg, int B) {
+extern "C" int64_t wn_decode_layered_error_offset(const WnConfig* cfg, int B, int mode) {
     Dims d;
     if (check_cfg(cfg, &d) || B < 1) return -1;
     DlLay y;
-    if (dl_layout(cfg, d, B, &y) || !y.dlp.ok) return -1;
+    if (dl_layout(cfg, d, B, (mode & WN_DECODE_GRANULES) != 0, &y) || !y.dlp.ok) return -1;
     return y.dlp_err;
+}
+
+// What the persistent launch of (cfg, B, mode) needs and what the current device offers: *workgroups = its grid (0: no plan
+// covers this model / B), *capacity = workgroups of that kernel resident at once (occupancy x CUs).  Returns 1 when the
+// persistent path will be used (grid <= capacity), 0 when wn_decode_layered_steps decodes by layer-wise launches, < 0 on a bad
+// argument.
+extern "C" int wn_decode_layered_residency(const WnConfig* cfg, int B, int mode, int* workgroups, int* capacity) {
+    api_enter();
+    Dims d;
+    if (check_cfg(cfg, &d) || B < 1) return -1;
+    DlLay y;
+    if (dl_layout(cfg, d, B, (mode & WN_DECODE_GRANULES) != 0, &y)) return -1;
+    if (workgroups) *workgroups = y.dlp_grid;
+    if (capacity) *capacity = y.dlp_capacity;
+    return y.dlp.ok ? 1 : 0;
 }
 
 // Packs the weights into `state` (which must be zero-filled first: the queues start from zero history) and
@@ -1811,13 +1828,13 @@ extern "C" int64_t wn_decode_layered_error_offset(const WnConfig* cfg, int B) {
 // weights packed by an earlier call (same cfg, B and parameters) -- only the projection of this window of h is computed
 // (windowed decoding without an upsampling layer calls this once per chunk of steps).
 extern "C" int wn_decode_layered_prepare(const WnConfig* cfg, int B, int F, const float* params, const float* h, float* G,
-                                         float* state, int64_t state_floats, void* stream) {
+                                         float* state, int64_t state_floats, int mode, void* stream) {
     api_enter();
     Dims d;
     WN_TRY(check_cfg(cfg, &d));
     if (!h || !G || !state || B < 1 || F < 1) return fail(1, "bad argument");
     DlLay y;
-    WN_TRY(dl_layout(cfg, d, B, &y));
+    WN_TRY(dl_layout(cfg, d, B, (mode & WN_DECODE_GRANULES) != 0, &y));
     if (state_floats < y.total) return fail(1, "decode state too small: %ld < %ld floats", (long)state_floats, y.total);
     Ctx c;
     dl_ctx(&c, cfg, d, y, B, state, stream);
@@ -1871,13 +1888,13 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
     if (!params || !G || !samples || !t_forced || !t_end || !state) return fail(1, "NULL argument");
     if (B <= 0 || F <= 0 || n_pad < 0 || p0 < 0 || p1 < p0 || Ttot <= 0 || p1 > Ttot - 1)
         return fail(1, "bad decode range: B=%d F=%d n_pad=%d steps [%d,%d) Ttot=%ld", B, F, n_pad, p0, p1, (long)Ttot);
-    const bool by_launches = (mode & WN_DECODE_BY_LAUNCHES) != 0;
-    mode &= ~WN_DECODE_BY_LAUNCHES;
+    const bool by_launches = (mode & WN_DECODE_BY_LAUNCHES) != 0, granules = (mode & WN_DECODE_GRANULES) != 0;
+    mode &= ~(WN_DECODE_BY_LAUNCHES | WN_DECODE_GRANULES);
     if (mode != 0 && mode != 1 && mode != 2) return fail(1, "mode should be 0 (argmax), 1 (sampling) or 2 (mixture of logistics)");
     if (mode != 0 && !uniforms) return fail(1, "sampling modes need the uniform draws");
     if (mode == 2 && (d.Qo % 3 != 0 || d.Qo == d.Q)) return fail(1, "mode 2 needs out_channels = 3 * n_mixture");
     DlLay y;
-    WN_TRY(dl_layout(cfg, d, B, &y));
+    WN_TRY(dl_layout(cfg, d, B, granules, &y));
     if (state_floats < y.total) return fail(1, "decode state too small: %ld < %ld floats", (long)state_floats, y.total);
     Ctx c;
     dl_ctx(&c, cfg, d, y, B, state, stream);
@@ -1907,6 +1924,9 @@ extern "C" int wn_decode_layered_steps(const WnConfig* cfg, int B, const float* 
         a.handoff = y.dlp_flags_on; a.Bp = y.dlp.wide ? ((nb + WN_DLPM_CB - 1) / WN_DLPM_CB) * WN_DLPM_CB : nb;
         a.flags = reinterpret_cast<unsigned long long*>(ws + y.dlp_flags);
         const int rc = y.dlp_flags_on ? wn_dlpf_launch(&a, c.st) : (y.dlp.wide ? wn_dlpm_launch(&a, c.st) : wn_dlp_launch(&a, c.st));
+        if (rc == 4)
+            return fail(4, "the persistent decode launch needs %d workgroups resident at once, the device keeps %d: "
+                           "mode | WN_DECODE_BY_LAUNCHES decodes by layer-wise launches", y.dlp_grid, y.dlp_capacity);
         if (rc != 0) return fail(3, "wn_dlp%s_launch failed (rc=%d)", y.dlp_flags_on ? "f" : (y.dlp.wide ? "m" : ""), rc);
         return rt_check("wn_decode_layered_steps");
     }
@@ -2051,7 +2071,7 @@ extern "C" int wn_decode_prefill(const WnConfig* cfg, int B, int Tctx, int pos0,
         Dims dm;
         WN_TRY(check_cfg(cfg, &dm));
         DlLay y;
-        WN_TRY(dl_layout(cfg, dm, state_B, &y));
+        WN_TRY(dl_layout(cfg, dm, state_B, (layered & WN_DECODE_GRANULES) != 0, &y));
         if (state_floats < y.total) return fail(1, "decode state too small: %ld < %ld floats", (long)state_floats, y.total);
         qdst = state + y.queues + state_b0; elem_stride = state_B; utt_stride = 1;
     } else {

@@ -22,6 +22,17 @@ typedef void* wn_stream_t;
 // launch whose workgroups wait for each other inside the kernel (all of them resident at once; wn_dlp.hip)
 #define WN_LAUNCH_COOP(kernel, grid, block, smem, stream, ...) \
     emu::launch_coop((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
+// workgroups of `kernel` the device keeps resident at once (the emulator keeps any grid alive); WN_COOP_CAPACITY: test knob
+#include <stdlib.h>
+static inline int wn_coop_capacity_override() {
+    const char* e = getenv("WN_COOP_CAPACITY");
+    return e && *e ? atoi(e) : -1;
+}
+template <typename Kn>
+static inline int wn_coop_capacity(Kn, int, size_t) {
+    const int o = wn_coop_capacity_override();
+    return o >= 0 ? o : 0x7fffffff;
+}
 #define WN_DYN_SMEM(name) char* name = emu::S().dyn_smem
 static inline f32x16 mfma32(float a, float b, f32x16 c) { return emu::mfma_f32_32x32x2f32(a, b, c); }
 typedef emu::f32x4_t f32x4;
@@ -132,6 +143,25 @@ typedef hipStream_t wn_stream_t;
 // most one workgroup per CU here; MI355X_MICROARCH.md: plain, cooperative and graph launches give the same residency)
 #define WN_LAUNCH_COOP(kernel, grid, block, smem, stream, ...) \
     hipLaunchKernelGGL(kernel, (grid), (block), (smem), (stream), __VA_ARGS__)
+// Workgroups of `kernel` (block threads, `lds` bytes of dynamic LDS) the current device keeps resident at once = occupancy per
+// CU x CUs: the bound a WN_LAUNCH_COOP grid is checked against BEFORE it is launched (a partitioned GPU -- CPX / DPX --, a part
+// with fewer CUs).  0 when the query fails.  The caller caches the value per kernel (the devices of a node are alike).
+// WN_COOP_CAPACITY=<n> in the environment overrides the query (test knob: the error / fall-back paths on a full chip).
+#include <stdlib.h>
+static inline int wn_coop_capacity_override() {
+    const char* e = getenv("WN_COOP_CAPACITY");
+    return e && *e ? atoi(e) : -1;
+}
+template <typename Kn>
+static inline int wn_coop_capacity(Kn kernel, int block, size_t lds) {
+    const int o = wn_coop_capacity_override();
+    if (o >= 0) return o;
+    int dev = 0, cus = 0, per = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kernel, block, lds) != hipSuccess) return 0;
+    return per * cus;
+}
 #define WN_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 static __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);

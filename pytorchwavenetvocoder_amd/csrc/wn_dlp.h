@@ -97,3 +97,8 @@ int wn_dlp_launch(const WnDlpArgs* a, wn_stream_t st);
 int wn_dlpm_launch(const WnDlpArgs* a, wn_stream_t st);   // plan.wide == 1, B <= WN_DLPM_BMAX
 int wn_dlpf_launch(const WnDlpArgs* a, wn_stream_t st);   // the same with a.handoff == 1
 int wn_dlpf_covers(const WnDlpPlan* plan);                 // 1: wn_dlpf.hip has a kernel for this plan
+// Workgroups of the plan's kernel the current device keeps resident at once (occupancy x CUs; cached per kernel class; 0: no
+// kernel for the plan / the query failed).  A launch whose grid exceeds it is refused (rc 4) instead of timing out.
+int wn_dlp_capacity(const WnDlpPlan* plan);
+int wn_dlpm_capacity(const WnDlpPlan* plan);
+int wn_dlpf_capacity(const WnDlpPlan* plan);

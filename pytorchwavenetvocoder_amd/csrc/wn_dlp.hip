@@ -194,6 +194,7 @@ static __device__ __forceinline__ long dlp_queue_off(int l, int depth, int K, in
 template <int RS, int NSP, int NSX>
 __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
     WN_DYN_SMEM(smem_raw);
+    if (a.err[0] != 0) return;   // an earlier launch on this state timed out (or this one already has): nothing to continue from
     constexpr int CB = WN_DLP_CB, BM = WN_DLP_BMAX;
     constexpr int CG = RS / 2, KQ = 64 / RS, SL = 8 * KQ;             // channels per unit, k parts per wave, k slices per row
     constexpr int NPASS = ((3 * CG + RS / 2) * CB * 8 + WN_DLP_T - 1) / WN_DLP_T;   // passes of 512 lanes over the row sums (8 lanes each)
@@ -612,18 +613,41 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
     if (tid == 0 && s_flag[0]) a.err[0] = 1;
 }
 
+// LDS attribute (once) and the number of workgroups of this class the device keeps resident (cached; 0: the query failed)
 template <int RS, int NSP, int NSX>
-static int launch_cls(const WnDlpArgs& a, wn_stream_t st) {
+static int capacity_cls(long lds_bytes) {
+    static int cap = -1;
 #ifndef WN_EMU
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_dlp<RS, NSP, NSX>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)a.plan.lds_bytes) != hipSuccess)
-            return 3;
+                                (int)lds_bytes) != hipSuccess)
+            return 0;
         attr_set = true;
     }
 #endif
+    if (wn_coop_capacity_override() >= 0) return wn_coop_capacity_override();
+    if (cap < 0) cap = wn_coop_capacity(k_dlp<RS, NSP, NSX>, WN_DLP_T, (size_t)lds_bytes);
+    return cap;
+}
+
+template <int RS, int NSP, int NSX>
+static int launch_cls(const WnDlpArgs& a, wn_stream_t st) {
+    if (a.plan.NU > capacity_cls<RS, NSP, NSX>(a.plan.lds_bytes)) return 4;   // not all workgroups would be resident: no launch
     WN_LAUNCH_COOP((k_dlp<RS, NSP, NSX>), dim3((unsigned)a.plan.NU), dim3(WN_DLP_T), (size_t)a.plan.lds_bytes, st, a);
+    return 0;
+}
+
+int wn_dlp_capacity(const WnDlpPlan* plan) {
+    if (!plan->ok || plan->wide) return 0;
+    switch (plan->cls) {
+        case 0: return capacity_cls<8, 24, 8>(plan->lds_bytes);
+        case 1: return capacity_cls<8, 32, 8>(plan->lds_bytes);
+        case 2: return capacity_cls<16, 48, 16>(plan->lds_bytes);
+        case 3: return capacity_cls<16, 64, 16>(plan->lds_bytes);
+        case 4: return capacity_cls<32, 96, 32>(plan->lds_bytes);
+        case 5: return capacity_cls<32, 128, 32>(plan->lds_bytes);
+    }
     return 0;
 }
 

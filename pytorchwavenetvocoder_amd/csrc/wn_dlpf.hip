@@ -47,6 +47,7 @@ static __device__ __forceinline__ long dlpf_queue_off(int l, int depth, int K, i
 template <int NSP, int NSX>
 __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlpf(WnDlpArgs a) {
     WN_DYN_SMEM(smem_raw);
+    if (a.err[0] != 0) return;   // an earlier launch on this state timed out (or this one already has): nothing to continue from
     constexpr int CG = 8, SL = 32, CB = WN_DLPM_CB;
     constexpr int KPAD = SL * NSP, XPAD = SL * NSX;
     // XCOPY: the x / skip row set has its own copy of the z part in ITS tile order (kernel_size 2 class: 148 KB of LDS).  The
@@ -447,22 +448,42 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlpf(WnDlpArgs a) {
 }
 
 template <int NSP, int NSX>
-static int launch_flags(const WnDlpArgs& a, int nblk, wn_stream_t st) {
-    const size_t lds = ((size_t)32 * NSP * 16 + (NSP * 3 <= 160 ? 32 * NSX * 16 : 0) + 4096 + 8 * 16 + 8 * 16 + 4 * 16 + 64) * 4;
+static constexpr size_t lds_flags() {
+    return ((size_t)32 * NSP * 16 + (NSP * 3 <= 160 ? 32 * NSX * 16 : 0) + 4096 + 8 * 16 + 8 * 16 + 4 * 16 + 64) * 4;
+}
+
+template <int NSP, int NSX>
+static int capacity_flags() {   // as capacity_cls of wn_dlp.hip
+    static int cap = -1;
+    constexpr size_t lds = lds_flags<NSP, NSX>();
 #ifndef WN_EMU
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_dlpf<NSP, NSX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess)
-            return 3;
+            return 0;
         attr_set = true;
     }
 #endif
+    if (wn_coop_capacity_override() >= 0) return wn_coop_capacity_override();
+    if (cap < 0) cap = wn_coop_capacity(k_dlpf<NSP, NSX>, WN_DLP_T, lds);
+    return cap;
+}
+
+template <int NSP, int NSX>
+static int launch_flags(const WnDlpArgs& a, int nblk, wn_stream_t st) {
+    if (a.plan.NU * nblk > capacity_flags<NSP, NSX>()) return 4;   // not all workgroups would be resident: no launch
+    constexpr size_t lds = lds_flags<NSP, NSX>();
     WN_LAUNCH_COOP((k_dlpf<NSP, NSX>), dim3((unsigned)(a.plan.NU * nblk)), dim3(WN_DLP_T), lds, st, a);
     return 0;
 }
 
 int wn_dlpf_covers(const WnDlpPlan* plan) { return plan->ok && plan->wide && plan->RS == 16 && (plan->NSP == 48 || plan->NSP == 64) && plan->NSX == 16; }
+
+int wn_dlpf_capacity(const WnDlpPlan* plan) {
+    if (!wn_dlpf_covers(plan)) return 0;
+    return plan->NSP == 48 ? capacity_flags<48, 16>() : capacity_flags<64, 16>();
+}
 
 int wn_dlpf_launch(const WnDlpArgs* ap, wn_stream_t st) {
     const WnDlpArgs& a = *ap;
@@ -474,4 +495,3 @@ int wn_dlpf_launch(const WnDlpArgs* ap, wn_stream_t st) {
     WN_PROF("dlpf_steps", 0.0, 0.0, st);
     return a.plan.NSP == 48 ? launch_flags<48, 16>(a, nblk, st) : launch_flags<64, 16>(a, nblk, st);
 }
-

@@ -42,6 +42,7 @@ static __device__ __forceinline__ long dlpm_queue_off(int l, int depth, int K, i
 template <int NSP, int NSX>
 __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlpm(WnDlpArgs a) {
     WN_DYN_SMEM(smem_raw);
+    if (a.err[0] != 0) return;   // an earlier launch on this state timed out (or this one already has): nothing to continue from
     constexpr int CG = 8, SL = 32, CB = WN_DLPM_CB, STR = 17, GJ = 16;
     constexpr int KPAD = SL * NSP;
     constexpr int PADQ = ((NSP * STR) % 64 == 0) ? 16 : 0;   // shift of k group (k / NSP) & 3
@@ -450,18 +451,36 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlpm(WnDlpArgs a) {
 }
 
 template <int NSP, int NSX>
-static int launch_wide(const WnDlpArgs& a, wn_stream_t st) {
+static int capacity_wide(long lds_bytes) {   // as capacity_cls of wn_dlp.hip
+    static int cap = -1;
 #ifndef WN_EMU
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_dlpm<NSP, NSX>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)a.plan.lds_bytes) != hipSuccess)
-            return 3;
+                                (int)lds_bytes) != hipSuccess)
+            return 0;
         attr_set = true;
     }
 #endif
+    if (wn_coop_capacity_override() >= 0) return wn_coop_capacity_override();
+    if (cap < 0) cap = wn_coop_capacity(k_dlpm<NSP, NSX>, WN_DLP_T, (size_t)lds_bytes);
+    return cap;
+}
+
+template <int NSP, int NSX>
+static int launch_wide(const WnDlpArgs& a, wn_stream_t st) {
     const int nblk = (a.B + WN_DLPM_CB - 1) / WN_DLPM_CB;
+    if (a.plan.NU * nblk > capacity_wide<NSP, NSX>(a.plan.lds_bytes)) return 4;   // not all workgroups would be resident: no launch
     WN_LAUNCH_COOP((k_dlpm<NSP, NSX>), dim3((unsigned)(a.plan.NU * nblk)), dim3(WN_DLP_T), (size_t)a.plan.lds_bytes, st, a);
+    return 0;
+}
+
+int wn_dlpm_capacity(const WnDlpPlan* plan) {
+    if (!plan->ok || !plan->wide || plan->RS != 16) return 0;
+    switch (plan->cls) {
+        case 2: return capacity_wide<48, 16>(plan->lds_bytes);
+        case 3: return capacity_wide<64, 16>(plan->lds_bytes);
+    }
     return 0;
 }
 

@@ -60,6 +60,11 @@ class GradientReducer(object):
                 e.record(torch.cuda.current_stream(self.eng.device))
         else:
             self.side, self.events = None, None
+        # opt-in measurement of the EXPOSED part of the exchange (bench.py's `comm` block): an event after the last backward
+        # launch and one after the caller's stream has joined the side stream; their distance is what the all-reduces did NOT
+        # hide under the backward kernels
+        self.measure_exposed = False
+        self._exposed = []
 
     @property
     def grad_scale(self):
@@ -88,9 +93,32 @@ class GradientReducer(object):
         loss = self._step(x, h, t, y, t_start=t_start, grad_scale=gscale, events=handles,
                           layers_per_bucket=self.lpb)
         flat = self.eng.grads()
+        main = torch.cuda.current_stream(self.eng.device)
+        pair = None
+        if self.measure_exposed:
+            pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            pair[0].record(main)     # behind the last backward launch
         with torch.cuda.stream(self.side):
             for (lo, hi), ev in zip(self.ranges, self.events):
                 self.side.wait_event(ev)
                 dist.all_reduce(flat[lo:hi], group=self.group)
-        torch.cuda.current_stream(self.eng.device).wait_stream(self.side)
+        main.wait_stream(self.side)
+        if pair is not None:
+            pair[1].record(main)     # the caller's stream has joined the exchange
+            self._exposed.append(pair)
         return loss
+
+    def comm_report(self):
+        """What the exchange looked like (after a synchronize): ranks and backend as torch.distributed reports them, bucket
+        sizes, the RCCL channel cap in effect, and -- over the steps taken with ``measure_exposed`` -- the time the caller's
+        stream waited for the side stream after its last backward launch (exposed exchange per step, ms)."""
+        rep = {"world": self.world, "backend": dist.get_backend(self.group) if dist.is_initialized() else None,
+               "buckets": len(self.ranges), "bucket_bytes": [4 * int(hi - lo) for lo, hi in self.ranges],
+               "layers_per_bucket": self.lpb, "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"),
+               "exchange": "one in-place all-reduce per bucket on a side stream, released by the bucket's HIP event"
+                           if (self.world > 1 or self.exchange_alone) else "none (one rank)"}
+        if self._exposed:
+            ms = [a.elapsed_time(b) for a, b in self._exposed]
+            rep["exposed_ms_per_step"] = {"mean": sum(ms) / len(ms), "min": min(ms), "max": max(ms), "steps": len(ms)}
+            self._exposed = []
+        return rep

@@ -7,6 +7,7 @@ PyTorch is used here only for device memory, streams and (in ``DataParallelReduc
 """
 import ctypes
 import os
+import warnings
 
 import torch
 
@@ -309,37 +310,65 @@ class WaveNetEngine(object):
                prefill="parallel", prefill_batch=32, log_scale_min=-7.0):
         """See ``_decode``.  ``layered="granules"``: the any-size path with its persistent launches handing their vectors over
         as 8-byte granules everywhere (csrc/wn_dlp.hip, wn_dlpm.hip) instead of plain vectors + flags where csrc/wn_dlpf.hip
-        covers the model -- an A/B and test knob (process-wide in the library: set for the duration of this call)."""
-        granules = layered == "granules"
-        old = self.lib.wn_decode_set_handoff(1 if granules else 0)
-        try:
-            lay = True if granules else layered
-            groups = self._persistent_groups(x.size(0), lay, mode)
-            if groups is None:
-                return self._decode(x, h, n_samples_list, mode, chunk, return_logits, progress, lay, prefill, prefill_batch,
-                                    log_scale_min)
-            # More utterances than ONE persistent launch takes (48), up to two launches' worth: the batch goes through it in two
-            # groups -- the utterances are independent (n_resch 512: 126 K against 90 K samples/s at 64, 185 K against 132 K at 96).  The sampling mode's draws are made for the whole batch first, so the
-            # tokens do not depend on the grouping.
-            T0 = x.size(1)
-            n_pad = max(self.receptive_field - T0, 0)
-            Ttot = T0 + n_pad + int(max(n_samples_list))
-            draws = torch.rand((x.size(0), Ttot), dtype=torch.float32, device=self.device) if mode == "sampling" else None
-            toks, lgs = [], []
-            for g0, g1 in groups:
-                ns = list(n_samples_list[g0:g1])
-                u = None if draws is None else draws[g0:g1, :T0 + n_pad + int(max(ns))].contiguous()
-                r = self._decode(x[g0:g1].contiguous(), h[g0:g1].contiguous(), ns, mode, chunk, return_logits, progress, lay, prefill,
-                                 prefill_batch, log_scale_min, _uniforms=u)
-                toks += r[0] if return_logits else r
-                if return_logits:
-                    lgs += r[1]
-            self.last_uniforms = draws
-            return (toks, lgs) if return_logits else toks
-        finally:
-            self.lib.wn_decode_set_handoff(old)
+        covers the model -- an A/B and test knob (the mode bit WN_DECODE_GRANULES of every library call of this decode).
 
-    def _persistent_groups(self, B, layered, mode):
+        A persistent launch that gives up waiting between its workgroups (they were not all resident: another kernel held
+        compute units) raises ``WnDecodeTimeout`` inside; the decode is then done again by layer-wise launches (HIP kernels
+        as well; a warning says so) -- context, aux features and, in the sampling mode, the uniform draws are the same, so
+        the tokens are those the persistent launch would have produced."""
+        granules = layered == "granules"
+        lay = True if granules else layered
+        mbits = _lib.DECODE_GRANULES if granules else 0
+        draws = None
+        if mode == "sampling":   # drawn once for the whole batch: neither the grouping nor a fall-back changes the tokens
+            n_pad = max(self.receptive_field - x.size(1), 0)
+            draws = torch.rand((x.size(0), x.size(1) + n_pad + int(max(n_samples_list))), dtype=torch.float32, device=self.device)
+        try:
+            return self._decode_groups(x, h, n_samples_list, mode, chunk, return_logits, progress, lay, prefill, prefill_batch,
+                                       log_scale_min, mbits, draws)
+        except _lib.WnDecodeTimeout as e:
+            warnings.warn("%s -- decoding again by layer-wise launches" % e, RuntimeWarning)
+            return self._decode_groups(x, h, n_samples_list, mode, chunk, return_logits, progress, "launches", prefill,
+                                       prefill_batch, log_scale_min, 0, draws)
+
+    def _decode_groups(self, x, h, n_samples_list, mode, chunk, return_logits, progress, lay, prefill, prefill_batch, log_scale_min,
+                       mbits, draws):
+        groups = self._persistent_groups(x.size(0), lay, mode, mbits)
+        if groups is None:
+            return self._decode(x, h, n_samples_list, mode, chunk, return_logits, progress, lay, prefill, prefill_batch,
+                                log_scale_min, _uniforms=draws, _mbits=mbits)
+        # More utterances than ONE persistent launch takes (48), up to two launches' worth: the batch goes through it in two
+        # groups -- the utterances are independent (n_resch 512: 126 K against 90 K samples/s at 64, 185 K against 132 K at 96).
+        T0 = x.size(1)
+        n_pad = max(self.receptive_field - T0, 0)
+        toks, lgs = [], []
+        total = sum(int(max(n_samples_list[g0:g1])) for g0, g1 in groups)
+        done = 0
+        for g0, g1 in groups:
+            ns = list(n_samples_list[g0:g1])
+            u = None if draws is None else draws[g0:g1, :T0 + n_pad + int(max(ns))].contiguous()
+            prog = None if progress is None else (lambda d, n, base=done: progress(base + d, total))   # steps over all groups
+            r = self._decode(x[g0:g1].contiguous(), h[g0:g1].contiguous(), ns, mode, chunk, return_logits, prog, lay, prefill,
+                             prefill_batch, log_scale_min, _uniforms=u, _mbits=mbits)
+            done += int(max(ns))
+            toks += r[0] if return_logits else r
+            if return_logits:
+                lgs += r[1]
+        self.last_uniforms = draws
+        return (toks, lgs) if return_logits else toks
+
+    def decode_residency(self, B, layered=None):
+        """(persistent, workgroups, capacity) of the any-size decode of B utterances on this device: whether it runs as ONE
+        persistent launch, the workgroups that launch needs resident at once and how many the device keeps
+        (``wn_decode_layered_residency``)."""
+        wg, cap = ctypes.c_int(0), ctypes.c_int(0)
+        rc = self.lib.wn_decode_layered_residency(ctypes.byref(self.cfg), int(B), _lib.DECODE_GRANULES if layered == "granules" else 0,
+                                                  ctypes.byref(wg), ctypes.byref(cap))
+        if rc < 0:
+            raise _lib.WnError("wn_decode_layered_residency: %s" % self.lib.wn_last_error().decode())
+        return bool(rc), wg.value, cap.value
+
+    def _persistent_groups(self, B, layered, mode, mbits=0):
         """[(begin, end)] when a batch of B utterances should go through the persistent any-size launch in groups, else None: the
         any-size path is asked for (or chosen because the one-workgroup kernel does not cover the model), B is more than one
         launch takes, and a launch of the group size exists."""
@@ -350,18 +379,20 @@ class WaveNetEngine(object):
         if layered is not None and not layered:
             return None
         cfg = ctypes.byref(self.cfg)
-        if self.lib.wn_decode_layered_error_offset(cfg, B) >= 0:
+        if self.lib.wn_decode_layered_error_offset(cfg, B, mbits) >= 0:
             return None   # one launch takes the whole batch
-        gs = 48
-        while gs > 1 and self.lib.wn_decode_layered_error_offset(cfg, gs) < 0:
-            gs //= 2
+        gs = 0
+        for cand in (48, 32, 16, 8, 4, 2):   # whole column blocks of 16 first; what the device keeps resident decides (wn_dlp.h)
+            if self.lib.wn_decode_layered_error_offset(cfg, cand, mbits) >= 0:
+                gs = cand
+                break
         if gs <= 1 or B <= gs or B > 2 * gs:
             return None   # (three groups and more: the layer-wise launches on the whole batch are as fast or faster -- n_resch 512:
                           # 777 against 751 us per step at 128 utterances, 1575 against 837 at 256; 509 against 710 at 64)
         return [(g0, min(g0 + gs, B)) for g0 in range(0, B, gs)]
 
     def _decode(self, x, h, n_samples_list, mode="argmax", chunk=4096, return_logits=False, progress=None, layered=None,
-                prefill="parallel", prefill_batch=32, log_scale_min=-7.0, _uniforms=None):
+                prefill="parallel", prefill_batch=32, log_scale_min=-7.0, _uniforms=None, _mbits=0):
         """Queue-based sample-by-sample generation on the HIP decode kernel.
 
         x (B,T0) int64 context, h (B, n_aux, frames | samples) aux features covering T0 + max(n)
@@ -406,7 +437,7 @@ class WaveNetEngine(object):
         Ttot = Tctx + n_max
         if layered is None:
             layered = not self.decode_supported()
-        by_launches = _lib.DECODE_BY_LAUNCHES if layered == "launches" else 0
+        mbits = (_lib.DECODE_BY_LAUNCHES if layered == "launches" else 0) | int(_mbits)   # the same bits to every call of this decode
         layered = bool(layered)
         if prefill not in ("parallel", "walk"):
             raise ValueError("prefill should be parallel or walk")
@@ -423,7 +454,7 @@ class WaveNetEngine(object):
             chunk = max(1, min(int(chunk), (1 << 30) // (4 * nG * B)))
         wpack = None
         if layered:
-            nst = self.lib.wn_decode_layered_state_floats(cfg, B)
+            nst = self.lib.wn_decode_layered_state_floats(cfg, B, mbits)
             if nst <= 0:
                 raise _lib.WnError("wn_decode_layered_state_floats: %s" % self.lib.wn_last_error().decode())
             state = torch.zeros(nst, dtype=torch.float32, device=dev)
@@ -444,7 +475,7 @@ class WaveNetEngine(object):
             Gw = torch.empty((B, c1 - c0, nG), dtype=torch.float32, device=dev)
             if layered:
                 self.lib.check(self.lib.wn_decode_layered_prepare(cfg, B, c1 - c0, None if packed[0] else _ptr(self.flat_params),
-                                                                  _ptr(hw), _ptr(Gw), _ptr(state), nst, st),
+                                                                  _ptr(hw), _ptr(Gw), _ptr(state), nst, mbits, st),
                                "wn_decode_layered_prepare")
                 packed[0] = True
             else:
@@ -467,9 +498,12 @@ class WaveNetEngine(object):
                     raise ValueError("uniforms must be (B, Ttot)")
             wave = None
         logits = torch.zeros((B, Ttot, self.out_channels), dtype=torch.float32, device=dev) if return_logits else None
+        eoff = -1   # float offset of the persistent launch's error word in the state (-1: layer-wise launches / other kernel)
+        if layered and not (mbits & _lib.DECODE_BY_LAUNCHES) and mode != "mol":
+            eoff = self.lib.wn_decode_layered_error_offset(cfg, B, mbits)
         p = 0
         if prefill == "parallel" and Tctx >= 2:
-            self._decode_prefill(samples, h, F, Tctx, n_pad, state, layered, int(prefill_batch), st)
+            self._decode_prefill(samples, h, F, Tctx, n_pad, state, (1 | int(_mbits)) if layered else 0, int(prefill_batch), st)
             p = Tctx - 1
         while p < Ttot - 1:
             p1 = min(p + chunk, Ttot - 1)
@@ -488,9 +522,14 @@ class WaveNetEngine(object):
                 rc = self.lib.wn_decode_layered_steps(cfg, B, _ptr(self.flat_params), _ptr(G), Fw, pad_w, _ptr(samples), Ttot,
                                                       _ptr(t_forced), _ptr(t_end), p, p1, _ptr(state), state.numel(),
                                                       _ptr(uniforms), _ptr(logits),
-                                                      {"argmax": 0, "sampling": 1, "mol": 2}[mode] | by_launches,
+                                                      {"argmax": 0, "sampling": 1, "mol": 2}[mode] | mbits,
                                                       _ptr(wave), float(log_scale_min), st)
                 self.lib.check(rc, "wn_decode_layered_steps")
+                # the persistent launch bounds every wait between its workgroups and reports a time-out in the state; a launch
+                # that finds the word set returns at once, so it is looked at after every chunk (one word, once per chunk)
+                if eoff >= 0 and int(state[eoff:eoff + 1].view(torch.int32).item()) != 0:
+                    raise _lib.WnDecodeTimeout("the persistent decode launch timed out waiting between its workgroups (not all "
+                                               "of them were resident at once: another kernel on the device?)")
             else:
                 rc = self.lib.wn_decode_steps(cfg, B, _ptr(self.flat_params), _ptr(wpack), _ptr(G), Fw, pad_w, _ptr(samples),
                                               Ttot, _ptr(t_forced), _ptr(t_end), p, p1, _ptr(state), _ptr(uniforms),
@@ -501,11 +540,6 @@ class WaveNetEngine(object):
             if progress is not None:
                 progress(max(p + 1 - Tctx, 0), n_max)
         self.last_decode_state = state if layered else None   # (tools/dlp_timing.py reads a timing build's stamps from it)
-        if layered:   # the persistent launch bounds every wait between its workgroups and reports a timeout here
-            eoff = self.lib.wn_decode_layered_error_offset(cfg, B)
-            if eoff >= 0 and int(state[eoff:eoff + 1].view(torch.int32).item()) != 0:
-                raise _lib.WnError("the persistent decode launch timed out waiting between its workgroups (not all of them "
-                                   "were resident?); layered=\"launches\" decodes with layer-wise launches")
         out = [samples[b, Tctx:Tctx + int(n)] for b, n in enumerate(n_samples_list)]
         self.last_wave = None if wave is None else [wave[b, Tctx:Tctx + int(n)] for b, n in enumerate(n_samples_list)]
         self.last_uniforms = uniforms
@@ -539,7 +573,7 @@ class WaveNetEngine(object):
                 ws = None
                 ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
             rc = self.lib.wn_decode_prefill(cfg, nb, Tpre, pos0, _ptr(self.flat_params), _ptr(x_ctx), _ptr(h_ctx), _ptr(ws),
-                                            ws.numel() * 4, _ptr(state), state.numel(), B, b0, 1 if layered else 0, self.flags,
+                                            ws.numel() * 4, _ptr(state), state.numel(), B, b0, int(layered), self.flags,
                                             st)
             self.lib.check(rc, "wn_decode_prefill")
 

@@ -128,26 +128,54 @@ class UpSampling(nn.Module):
                                        stride=(1, self.upsampling_factor), bias=self.bias)
 
     def forward(self, x):
-        """x (B, C, T) -> (B, C, T * upsampling_factor).  On the GPU: the HIP op ``wn_op_upsampling`` (inference-only like
-        ``CausalConv1d.forward``; what ``generate()`` calls); on the CPU the closed form below (shape tests of the reference)."""
+        """x (B, C, T) -> (B, C, T * upsampling_factor).  On the GPU: the HIP op ``wn_op_upsampling`` (what ``generate()``
+        calls); when a gradient is asked for (x or the conv parameters require grad under an enabled grad mode) through
+        ``_UpSamplingFunction``, whose backward is the closed form of the transposed convolution -- the stand-alone module stays
+        differentiable as in the reference.  On the CPU the closed form below (shape tests of the reference)."""
         if x.is_cuda:
-            import ctypes
-            lib = _lib.load_library()
-            x = x.contiguous().float()
-            B, C, F_ = x.shape
-            U = self.upsampling_factor
-            w = self.conv.weight.detach().reshape(-1).contiguous()
-            b = self.conv.bias.detach().contiguous() if self.conv.bias is not None else None
-            y = torch.empty(B, C, F_ * U, device=x.device, dtype=torch.float32)
-            st = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-            rc = lib.wn_op_upsampling(w.data_ptr(), b.data_ptr() if b is not None else None, x.data_ptr(), y.data_ptr(), B, C, F_, U, st)
-            lib.check(rc, "wn_op_upsampling")
-            return y
+            w, b = self.conv.weight, self.conv.bias
+            if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or (b is not None and b.requires_grad)):
+                return _UpSamplingFunction.apply(x, w, b, self.upsampling_factor)
+            return _upsampling_hip(x, w.detach(), None if b is None else b.detach(), self.upsampling_factor)
         w = self.conv.weight.view(-1)
         y = x.unsqueeze(-1) * w
         if self.conv.bias is not None:
             y = y + self.conv.bias
         return y.reshape(x.size(0), x.size(1), -1)
+
+
+def _upsampling_hip(x, w, b, U):
+    import ctypes
+    lib = _lib.load_library()
+    x = x.contiguous().float()
+    B, C, F_ = x.shape
+    w = w.reshape(-1).contiguous()
+    b = b.contiguous() if b is not None else None
+    y = torch.empty(B, C, F_ * U, device=x.device, dtype=torch.float32)
+    st = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    rc = lib.wn_op_upsampling(w.data_ptr(), b.data_ptr() if b is not None else None, x.data_ptr(), y.data_ptr(), B, C, F_, U, st)
+    lib.check(rc, "wn_op_upsampling")
+    return y
+
+
+class _UpSamplingFunction(torch.autograd.Function):
+    """``UpSampling.forward`` with a gradient: forward = wn_op_upsampling; y[b, c, f U + j] = x[b, c, f] w[j] + bias, so
+    dx = sum_j w[j] dy[.., f, j], dw[j] = sum x dy[.., j], dbias = sum dy (three reductions of (B, C, F, U) views)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, U):
+        ctx.save_for_backward(x, w)
+        ctx.U, ctx.has_bias = U, b is not None
+        return _upsampling_hip(x.detach(), w.detach(), None if b is None else b.detach(), U)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy4 = dy.reshape(x.size(0), x.size(1), x.size(2), ctx.U)
+        dx = (dy4 * w.reshape(-1)).sum(-1) if ctx.needs_input_grad[0] else None
+        dw = (dy4 * x.float().unsqueeze(-1)).sum((0, 1, 2)).reshape(w.shape) if ctx.needs_input_grad[1] else None
+        db = dy.sum().reshape(1) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None
 
 
 class _WaveNetFunction(torch.autograd.Function):

@@ -770,9 +770,9 @@ def test_persistent_decode_dispatch_rules():
         cfg = ctypes.byref(eng.cfg)
         assert not eng.decode_supported()
         for B in (1, 2, 5, 16, 17, 48):
-            assert lib.wn_decode_layered_error_offset(cfg, B) >= 0, (K, B)      # one persistent launch
+            assert lib.wn_decode_layered_error_offset(cfg, B, 0) >= 0, (K, B)      # one persistent launch
             assert eng._persistent_groups(B, None, "argmax") is None
-        assert lib.wn_decode_layered_error_offset(cfg, 49) < 0
+        assert lib.wn_decode_layered_error_offset(cfg, 49, 0) < 0
         assert eng._persistent_groups(49, None, "argmax") == [(0, 48), (48, 49)]
         assert eng._persistent_groups(96, True, "sampling") == [(0, 48), (48, 96)]
         assert eng._persistent_groups(97, None, "argmax") is None                  # three groups: the launches are as fast
@@ -780,6 +780,86 @@ def test_persistent_decode_dispatch_rules():
         assert eng._persistent_groups(64, None, "mol") is None
     # 1024 channels: (K + 1) n_resch exceeds every compiled class -- layer-wise launches at any batch
     big = WaveNetEngine(256, 80, 1024, 256, 10, 3, 2, 80, device="cpu", library=lib)
-    assert lib.wn_decode_layered_error_offset(ctypes.byref(big.cfg), 1) < 0 and big._persistent_groups(64, None, "argmax") is None
+    assert lib.wn_decode_layered_error_offset(ctypes.byref(big.cfg), 1, 0) < 0 and big._persistent_groups(64, None, "argmax") is None
     small = WaveNetEngine(256, 80, 64, 256, 10, 3, 2, 80, device="cpu", library=lib)
     assert small.decode_supported() and small._persistent_groups(64, None, "argmax") is None   # the one-workgroup kernel takes it
+
+
+def test_persistent_decode_residency_check_and_fall_backs(monkeypatch):
+    """Every workgroup of the persistent decode launch waits for the others, so all of them must be resident at once.  The
+    library asks the device (occupancy x CUs; here the test knob WN_COOP_CAPACITY stands in for a small / partitioned part)
+    where it chooses the path: a grid that does not fit decodes by layer-wise launches, same tokens.  And the other way a
+    launch can fail -- resident in principle, but another kernel held the CUs, the bounded polls time out, the error word in
+    the state is set --: the next launch returns at once, the engine raises WnDecodeTimeout inside, warns and decodes again by
+    layer-wise launches with the same draws."""
+    import ctypes
+    import warnings
+    import numpy as np
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd import _lib as L
+    from pytorchwavenetvocoder_amd.engine import WaveNetEngine
+    from pytorchwavenetvocoder_amd.nets import WaveNet
+    lib = emu_library()
+    big = WaveNetEngine(256, 80, 512, 256, 10, 3, 2, 80, device="cpu", library=lib)
+    assert big.decode_residency(2) == (True, 64, 0x7fffffff) and big.decode_residency(48)[:2] == (True, 192)
+    assert big.decode_residency(1)[:2] == (True, 128) and big.decode_residency(49)[:2] == (False, 0)
+    monkeypatch.setenv("WN_COOP_CAPACITY", "100")
+    assert big.decode_residency(2) == (True, 64, 100) and big.decode_residency(17) == (False, 128, 100)
+    assert big.decode_residency(1) == (False, 128, 100)
+    assert lib.wn_decode_layered_error_offset(ctypes.byref(big.cfg), 17, 0) < 0
+    assert big._persistent_groups(40, None, "argmax") is None                    # three groups: the launches
+    assert big._persistent_groups(30, None, "argmax") == [(0, 16), (16, 30)]     # groups of what DOES fit
+    monkeypatch.delenv("WN_COOP_CAPACITY")
+
+    cfg_t = (32, 4, 32, 32, 3, 2, 2, 4)
+    cfg = O.OracleConfig(*cfg_t)
+    model = WaveNet(*cfg_t, _library=lib)
+    model.load_state_dict(O.random_params(cfg, 11, scale=0.3))
+    rs = np.random.RandomState(3)
+    B = 3
+    xs = torch.from_numpy(rs.randint(0, 32, (B, 5))).long()
+    hs = torch.from_numpy(rs.standard_normal((B, 4, 8)).astype(np.float32))
+    ns = [6, 5, 4]
+    out = {}
+    log = PC.launch_log(lib, lambda: out.update(p=model.engine.decode(xs, hs, ns, chunk=3, return_logits=True, layered=True)))
+    assert log.get("dlpf_steps", 0) >= 2 and "dl_dilated" not in log, log
+    # (1) a device that keeps fewer workgroups resident than the launch needs: layer-wise launches, chosen by the library
+    monkeypatch.setenv("WN_COOP_CAPACITY", "3")
+    log = PC.launch_log(lib, lambda: out.update(c=model.engine.decode(xs, hs, ns, chunk=3, return_logits=True, layered=True)))
+    assert "dlpf_steps" not in log and "dlp_steps" not in log and log.get("dl_dilated", 0) > 0, log
+    monkeypatch.delenv("WN_COOP_CAPACITY")
+    for b in range(B):
+        assert torch.equal(out["c"][0][b], out["p"][0][b]) and float((out["c"][1][b] - out["p"][1][b]).abs().max()) <= 1e-5
+    # (2) a time-out: the error word is set before the first persistent launch of the decode
+    real = lib.lib.wn_decode_layered_steps
+    calls = []
+
+    def steps(cfgp, Bn, params, G, F, n_pad, samples, Ttot, tf, te, p0, p1, state, nst, uni, lo, mode, wave, lsm, st):
+        if not (mode & L.DECODE_BY_LAUNCHES):
+            eoff = lib.wn_decode_layered_error_offset(cfgp, Bn, mode & L.DECODE_GRANULES)
+            assert eoff >= 0
+            ctypes.c_int.from_address(state.value + 4 * eoff).value = 1
+            calls.append("persistent")
+        else:
+            calls.append("launches")
+        return real(cfgp, Bn, params, G, F, n_pad, samples, Ttot, tf, te, p0, p1, state, nst, uni, lo, mode, wave, lsm, st)
+    lib.wn_decode_layered_steps = steps
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            tf_, lf = model.engine.decode(xs, hs, ns, chunk=3, return_logits=True, layered=True)
+            assert any("layer-wise launches" in str(x.message) for x in w)
+        assert calls[0] == "persistent" and calls.count("persistent") == 1 and calls.count("launches") >= 2, calls
+        for b in range(B):
+            assert torch.equal(tf_[b], out["p"][0][b]) and float((lf[b] - out["p"][1][b]).abs().max()) <= 1e-5
+        torch.manual_seed(5)
+        del calls[:]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sf = model.engine.decode(xs, hs, ns, mode="sampling", layered=True)
+        assert calls[0] == "persistent"
+    finally:
+        del lib.wn_decode_layered_steps
+    torch.manual_seed(5)
+    sp = model.engine.decode(xs, hs, ns, mode="sampling", layered=True)
+    assert all(torch.equal(a, b) for a, b in zip(sf, sp))

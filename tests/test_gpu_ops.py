@@ -62,6 +62,25 @@ def test_upsampling_module_on_the_gpu_vs_reference_vector():
     out = conv(aux.to(DEV)).cpu()
     assert out.shape[-1] == aux.shape[-1] * 10
     assert torch.equal(out, aux.repeat_interleave(10, dim=2))
+    # with a gradient asked for the module stays differentiable (forward still the HIP op): x, weight and bias gradients
+    # against torch's own ConvTranspose2d on the CPU (what the reference's module is, wavenet.py:141-154)
+    up2 = UpSampling(8)
+    ref = torch.nn.ConvTranspose2d(1, 1, kernel_size=(1, 8), stride=(1, 8))
+    up2.conv.load_state_dict(ref.state_dict())
+    up2.to(DEV)
+    xc = torch.randn(2, 5, 7, requires_grad=True)
+    xg = xc.detach().to(DEV).requires_grad_(True)
+    gy = torch.randn(2, 5, 56)
+    yr = ref(xc.unsqueeze(1)).squeeze(1)
+    yr.backward(gy)
+    yg = up2(xg)
+    assert yg.grad_fn is not None and float((yg.detach().cpu() - yr.detach()).abs().max()) <= 1e-6
+    yg.backward(gy.to(DEV))
+    assert float((xg.grad.cpu() - xc.grad).abs().max()) <= 1e-5
+    assert float((up2.conv.weight.grad.cpu() - ref.weight.grad).abs().max()) <= 1e-4
+    assert float((up2.conv.bias.grad.cpu() - ref.bias.grad).abs().max()) <= 1e-4
+    with torch.no_grad():
+        assert up2(xg).grad_fn is None
 
 
 def test_transpose_op_and_the_autograd_bridge_with_an_external_loss():

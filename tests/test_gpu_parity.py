@@ -317,7 +317,7 @@ def test_decode_any_size_persistent_launch_vs_oracle_and_launches():
         model.to(DEV)
         assert not model.engine.decode_supported()
         import ctypes
-        assert model.engine.lib.wn_decode_layered_error_offset(ctypes.byref(model.engine.cfg), B) >= 0   # the persistent path applies
+        assert model.engine.lib.wn_decode_layered_error_offset(ctypes.byref(model.engine.cfg), B, 0) >= 0   # the persistent path applies
         rs = np.random.RandomState(seed)
         x = torch.from_numpy(rs.randint(0, cfg.n_quantize, (B, 4))).long()
         U = max(cfg.upsampling_factor, 1)

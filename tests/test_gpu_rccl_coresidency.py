@@ -83,24 +83,29 @@ def test_a_16_workgroup_kernel_runs_beside_the_full_size_backward_chain():
         torch.cuda.synchronize(dev)
 
     backward_pass(False)   # warm-up
-    ms_with = 1e9
-    for _ in range(3):   # (single timings of a 7 ms pass scatter by several per cent from box to box: best of three each)
+    backward_pass(True)
+    # interleaved pairs, median of five each (single timings of a 7 ms pass scatter by several per cent from box to box)
+    with_, without = [], []
+    for _ in range(5):
         backward_pass(True)
-        ms_with = min(ms_with, t_ev[0].elapsed_time(t_ev[1]))
-    s = stamps.cpu().view(16, 2)
-    m = marks.cpu()
+        with_.append(t_ev[0].elapsed_time(t_ev[1]))
+        if _ == 0:   # placement stamps of one pass with the side kernel
+            s = stamps.cpu().view(16, 2)
+            m = marks.cpu()
+        backward_pass(False)
+        without.append(t_ev[2].elapsed_time(t_ev[3]))
+    ms_with, ms_without = sorted(with_)[2], sorted(without)[2]
     start_first = (int(s[:, 0].min()) - int(m[0])) * 1e-5      # ms after the backward pass began (100 MHz ticks)
     start_last = (int(s[:, 0].max()) - int(m[0])) * 1e-5
     end_last = (int(s[:, 1].max()) - int(m[0])) * 1e-5
     bwd = (int(m[1]) - int(m[0])) * 1e-5
-    ms_without = 1e9
-    for _ in range(3):
-        backward_pass(False)
-        ms_without = min(ms_without, t_ev[2].elapsed_time(t_ev[3]))
-    print("backward pass %.2f ms (%.2f without the side kernel); stand-in workgroups started %.2f .. %.2f ms after its begin, "
-          "last one ended at %.2f ms" % (ms_with, ms_without, start_first, start_last, end_last))
+    slow = ms_with / ms_without - 1.0
+    print("backward pass median of 5: %.3f ms with the side kernel, %.3f without = %+.1f %% (all: %s | %s); stand-in workgroups "
+          "started %.2f .. %.2f ms after its begin, last one ended at %.2f ms"
+          % (ms_with, ms_without, 100.0 * slow, " ".join("%.2f" % v for v in with_), " ".join("%.2f" % v for v in without),
+             start_first, start_last, end_last))
     assert bwd > 3.0                                   # the full-size backward pass (chain + weight gradients)
     assert start_last < bwd - 2.0, (start_last, bwd)   # every workgroup was placed while the chain was running, not after it
-    # the foreign kernel costs the pass what its traffic and its 16 CUs cost (measured 1 - 6 % from box to box); the bound only
-    # catches a pathology (the two starving each other), the placement assertions above are the point of the test
-    assert ms_with <= 1.25 * ms_without + 0.2, (ms_with, ms_without)
+    # the foreign kernel costs the pass what its traffic and its 16 CUs cost (measured 1 - 6 % from box to box): the median of
+    # five interleaved passes must stay within 10 %
+    assert ms_with <= 1.10 * ms_without, (ms_with, ms_without)

@@ -28,7 +28,7 @@ def main():
     m.engine.decode(x, h, [40] * B, layered=True)
     torch.cuda.synchronize()
     st = m.engine.last_decode_state
-    eoff = m.engine.lib.wn_decode_layered_error_offset(ctypes.byref(m.engine.cfg), B)
+    eoff = m.engine.lib.wn_decode_layered_error_offset(ctypes.byref(m.engine.cfg), B, 0)
     stamps = st[eoff + 16:eoff + 16 + 2 * 8 * 40].view(torch.int64).view(40, 8).cpu()
     L = m.engine.n_layers
     print("B = %d; us per phase (100 MHz wall clock): stage | gather  barrier  dots(+weights)  partials  epilogue  barrier | total" % B)

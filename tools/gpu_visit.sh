@@ -5,6 +5,8 @@
 #   round 4 added: micro (tools/microbench/handoff.hip, built into tools/exp/ beforehand), drift (tools/wide_drift_probe.py),
 #   gap (tools/grad_gap_probe.py on the configs[3] reduced case), pmc3 (counter passes of the configs[3] geometry), seltests
 #   (pytest -m gpu -k "$WN_TEST_K")
+#   round 5 added: pins (tests/test_gpu_decode_pins.py + ops + co-residency, verbose), soak (tools/microbench/handoff_soak.hip),
+#   pmcrecipe (counter passes of the recipe-size training step), k3probe (recipe-size decode speed, kernel_size 3 and 2)
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 cd "$ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
 OUT="$ROOT/gpurun_out"
@@ -103,6 +105,25 @@ fi
 if has seltests; then
   timeout 1200 python -m pytest tests -q -m gpu -s -k "$WN_TEST_K" > $OUT/pytest_gpu_sel.txt 2>&1; echo "pytest(selected) rc=$?"; tail -5 $OUT/pytest_gpu_sel.txt
   grep -h "vs oracle\|vs own\|err \|STATED\|TIMED\|FULL SIZE" $OUT/pytest_gpu_sel.txt | head -20
+fi
+if has pins; then
+  # round 5: the persistent-decode pins + what else changed (stand-alone modules, co-residency gate), verbose
+  timeout 900 python -m pytest tests/test_gpu_decode_pins.py tests/test_gpu_ops.py tests/test_gpu_rccl_coresidency.py -q -m gpu -s -x > $OUT/pytest_gpu_pins.txt 2>&1; echo "pytest(pins) rc=$?"; tail -5 $OUT/pytest_gpu_pins.txt
+  grep -h "LONG HORIZON\|WALKED\|SOAK\|k_dlpf<\|residency:\|backward pass median" $OUT/pytest_gpu_pins.txt | head -40
+fi
+if has soak; then
+  [ -x tools/exp/handoff_soak ] || hipcc --offload-arch=gfx950 -O3 -o tools/exp/handoff_soak tools/microbench/handoff_soak.hip
+  timeout 200 tools/exp/handoff_soak ${WN_SOAK_STAGES:-1000000} 1 > $OUT/handoff_soak.txt 2>&1; echo "soak rc=$?"; cat $OUT/handoff_soak.txt
+  timeout 100 tools/exp/handoff_soak 200000 0 >> $OUT/handoff_soak.txt 2>&1; echo "soak(idle) rc=$?"; tail -2 $OUT/handoff_soak.txt
+fi
+if has pmcrecipe; then
+  # counter passes of the recipe-size training step (n_resch 512, B = 4 x T = 23040: 2 warm-up + 1 timed + 1 event-logged step)
+  WN_PMC_NAME=recipe WN_PMC_STEPS=4 WN_PMC_CMD="python tools/recipe_bench.py --resch 512 --batch 4 --steps 1" \
+    bash tools/pmc_traffic.sh > $OUT/pmc_recipe.txt 2>&1; tail -25 $OUT/pmc_recipe.txt
+fi
+if has k3probe; then
+  timeout 300 python tools/recipe_decode_probe.py --kernel-size 3 --steps 300 --batches 1,2,16,32,48,64 > $OUT/recipe_decode_probe_k3.txt 2>&1; echo "k3 decode probe rc=$?"; cat $OUT/recipe_decode_probe_k3.txt
+  timeout 300 python tools/recipe_decode_probe.py --kernel-size 2 --steps 300 --batches 1,2,16,32,48,64,96 > $OUT/recipe_decode_probe_k2.txt 2>&1; echo "k2 decode probe rc=$?"; cat $OUT/recipe_decode_probe_k2.txt
 fi
 if has recipe; then
   timeout 300 bash tools/recipe_stage45.sh run > $OUT/recipe_stage45.txt 2>&1; echo "recipe rc=$?"; tail -3 $OUT/recipe_stage45.txt
