@@ -116,6 +116,11 @@ enum {
 #define WN_FLAG_REPACK (1 << 17)    /* wn_backward / wn_backward_window (since ABI v7): re-build the re-laid-out / pre-split weight
                                * sets in the workspace from the `params` given to THIS call before using them (for callers that
                                * modified params after the forward call; costs one pack pass, ~0.05 ms at the BASELINE size) */
+#define WN_FLAG_DW_3PRODUCT (1 << 18) /* wn_backward / wn_backward_window (since ABI v8, opt-in): the weight-gradient contractions -- LEAF results:
+                               * sums over every position of the minibatch that no other layer consumes -- take three of the six
+                               * products of the 3-way operand split (h h + h m + m h; two bf16 pieces per operand: relative error
+                               * ~2^-16 per product, random in sign, instead of 2^-24).  Never applied to a contraction whose
+                               * output feeds another layer.  Default off: every contraction fp32-equivalent. */
 #define WN_FLAG_DW_FLUSH(n) (((n) & 0xff) << 8) /* wn_backward: issue the weight gradients of at most n walked layers per
                                * launch group (0 = default: a whole gradient bucket; 5 layers with WN_FLAG_BWD_OVERLAP).
                                * Groups never straddle a bucket.  The split-K plan of a group depends on its size, so

@@ -77,6 +77,7 @@ FLAG_FWD_OVERLAP = 8  # wn_forward: chunked skip-sum on the side stream beside t
 FLAG_WS_FINITE = 1 << 16  # wn_forward_loss: the workspace holds only finite values (the engine allocates it zero-filled)
 DECODE_BY_LAUNCHES = 256  # wn_decode_layered_*: mode bit that keeps the layer-wise launches (csrc/wn_dlp.hip otherwise)
 DECODE_GRANULES = 512  # wn_decode_layered_*: mode bit, the persistent launches hand over 8-byte granules everywhere (A/B, tests)
+FLAG_DW_3PRODUCT = 1 << 18  # wn_backward: weight gradients (leaf results) with 3 of the 6 products of the operand split (opt-in)
 FLAG_REPACK = 1 << 17  # wn_backward: rebuild the packed / pre-split weight sets from the params given to that call
 
 

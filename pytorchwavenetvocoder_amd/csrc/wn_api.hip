@@ -557,6 +557,7 @@ struct Ctx {
     wn_stream_t st;
     bool fused;
     bool split_bf16;  // forward-type contractions on the bf16 matrix cores (3-way split, fp32-equivalent)
+    int dw_products;  // products per multiply of the weight-gradient contractions: 6, or 3 with WN_FLAG_DW_3PRODUCT
     const float* params;   // set by the training entry points: lets fw_gemm recognise the pre-split weight sets
     bool have_pre;         // apk_pre[] of this workspace is valid (regular layout, not the decode state)
 };
@@ -575,6 +576,7 @@ static int make_ctx(Ctx* c, const WnConfig* cfg, int B, int T, void* ws, size_t 
     c->st = (wn_stream_t)stream;
     c->fused = wn_fused_supported(c->d.R, c->d.K, c->d.S) && !(flags & WN_FLAG_NO_FUSED);
     c->split_bf16 = !(flags & WN_FLAG_EXACT_MFMA);
+    c->dw_products = (flags & WN_FLAG_DW_3PRODUCT) ? 3 : 6;
     c->params = nullptr;
     c->have_pre = true;
     return 0;
@@ -1108,7 +1110,7 @@ static int dw_gemm(const Ctx& c, WnGemmArgs g, const DwOut& o, int nl = 1) {
     g.C = c.ws + c.w.partial; g.ldc = g.N; g.c_zstride = (long)g.M * g.N;
     g.a_rowsum = o.rowsum_out ? c.ws + c.w.rs_partial : nullptr;
     if (c.split_bf16 && wn_gemm6_dw_eligible(&g))
-        WN_TRY(wn_gemm6_dw_launch(&g, c.st));
+        WN_TRY(wn_gemm6_dw_launch(&g, c.dw_products, c.st));
     else
         WN_TRY(wn_gemm_launch(&g, c.st));
     return dw_reduce(c, c.ws + c.w.partial, c.ws + c.w.rs_partial, nz_layer, g.M, g.N, o, nl);
@@ -1786,6 +1788,7 @@ static void dl_ctx(Ctx* c, const WnConfig* cfg, const Dims& d, const DlLay& y, i
     // exact f32 MFMA here: with a handful of utterance columns the contractions are weight-streaming bound and
     // the split path would re-split (or stream 1.5x the bytes of) the weights on every step
     c->split_bf16 = false;
+    c->dw_products = 6;
     c->params = nullptr;
     c->have_pre = false;
 }

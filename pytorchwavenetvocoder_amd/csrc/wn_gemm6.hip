@@ -688,14 +688,20 @@ int wn_gemm6_launch(const WnGemm6Args* gp, wn_stream_t st) {
 // alignment), split into the three bf16 pieces in registers, one 16 (8) byte LDS write per piece
 // into the fragment layout [piece][row][16 k].  The loads run two steps ahead of the MFMAs (two
 // register sets), LDS is double buffered.
-template <int TM, int TN>
+// NP = bf16 pieces per operand: 3 (x = h + m + l, the six products above 2^-24 |ab|: fp32-equivalent) or 2 (x ~ h + m, the three
+// products h h + h m + m h: relative error ~2^-16 per product, random in sign).  NP = 2 is for LEAF results only -- a weight
+// gradient is a sum over every position of the minibatch that feeds nothing downstream --, opt-in (WN_FLAG_DW_3PRODUCT),
+// never for a contraction whose output another layer consumes.
+template <int TM, int TN, int NP>
 __global__ __launch_bounds__(G6_T, (TM * TN > 4 ? 2 : 3)) void k_gemm6_dw(WnGemmArgs g, int order G6_DBG_PARAM) {
+    static_assert(NP == 2 || NP == 3, "two or three bf16 pieces per operand");
+    constexpr int NPROD = NP == 3 ? 6 : 3;
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int AE = BM / 16, BE = BN / 16;            // fp32 elements per thread and step
     // 192-column tiles (TN = 3: kernel_size 3 at 64 channels, N = 3 x 64) give a thread three B rows of 4 consecutive k each
     // (rows r, r + 64, r + 128) instead of one row of BE
     constexpr int BR = (TN == 3) ? 3 : 1, BEr = BE / BR;
-    constexpr int A_BYTES = 3 * BM * 32, B_BYTES = 3 * BN * 32, ST_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_BYTES = NP * BM * 32, B_BYTES = NP * BN * 32, ST_BYTES = A_BYTES + B_BYTES;
     WN_DYN_SMEM(smem_raw);
     __shared__ long b_rowoff[BN];
     __shared__ int b_rowshift[BN];
@@ -800,10 +806,10 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 4 ? 2 : 3)) void k_gemm6_dw(WnGemm
             h[q] = wn_pk_bf16(x0, x1);
             const float r0 = x0 - wn_bits_f32(h[q] << 16), r1 = x1 - wn_bits_f32(h[q] & 0xffff0000u);
             md[q] = wn_pk_bf16(r0, r1);
-            lo[q] = wn_pk_bf16(r0 - wn_bits_f32(md[q] << 16), r1 - wn_bits_f32(md[q] & 0xffff0000u));
+            lo[q] = NP == 3 ? wn_pk_bf16(r0 - wn_bits_f32(md[q] << 16), r1 - wn_bits_f32(md[q] & 0xffff0000u)) : 0u;
         }
         const unsigned* src[3] = {h, md, lo};
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
             char* d = base + p * rows * 32;
             for (int q = 0; q < E / 2; ++q) {   // dword kq of the row: k half kq >> 2 (placement: wn_frag_off), dword kq & 3 of it
                 const int kq = (kofs >> 1) + q;
@@ -838,22 +844,24 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 4 ? 2 : 3)) void k_gemm6_dw(WnGemm
     auto compute = [&](int st) {
         const char* sa = smem_raw + st * ST_BYTES;
         const char* sb = sa + A_BYTES;
-        wn_f4 bf[3][TN];
+        wn_f4 bf[NP][TN];
         WN_UNROLL
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
             WN_UNROLL
             for (int j = 0; j < TN; ++j)
                 bf[p][j] = *reinterpret_cast<const wn_f4*>(sb + p * (BN * 32) + wn_frag_off((wn * TN + j) * 32 + li, hi));
         }
         WN_UNROLL
         for (int i = 0; i < TM; ++i) {
-            wn_f4 af[3];
+            wn_f4 af[NP];
             WN_UNROLL
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < NP; ++p)
                 af[p] = *reinterpret_cast<const wn_f4*>(sa + p * (BM * 32) + wn_frag_off((wm * TM + i) * 32 + li, hi));
-            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+            // small terms first; NP = 2: h m, m h, h h
+            constexpr int PA[6] = {0, NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0};
+            constexpr int PB[6] = {NP == 3 ? 2 : 1, 0, NP == 3 ? 1 : 0, 1, 0, 0};
             WN_UNROLL
-            for (int t = 0; t < 6; ++t) {
+            for (int t = 0; t < NPROD; ++t) {
                 WN_UNROLL
                 for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(af[PA[t]], bf[PB[t]][j], acc[i][j]);
             }
@@ -916,19 +924,19 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 4 ? 2 : 3)) void k_gemm6_dw(WnGemm
         const char* sa = smem_raw + st * ST_BYTES;
         const char* sb = sa + A_BYTES;
         char* da = smem_raw + stn * ST_BYTES;
-        constexpr int NPA = AE / 2, NPB = BE / 2, NSL = TM * 6;             // pairs of A, of B; slices
+        constexpr int NPA = AE / 2, NPB = BE / 2, NSL = TM * NPROD;         // pairs of A, of B; slices
         constexpr int PPS = (NPA + NPB + NSL - 2) / (NSL - 1);              // pairs per slice (slice 0 is the loads)
         unsigned ha[NPA], ma[NPA], la[NPA], hb[NPB], mb[NPB], lb[NPB];
         auto pair = [&](float x0, float x1, unsigned& h, unsigned& md, unsigned& lo) {
             h = wn_pk_bf16(x0, x1);
             const float r0 = x0 - wn_bits_f32(h << 16), r1 = x1 - wn_bits_f32(h & 0xffff0000u);
             md = wn_pk_bf16(r0, r1);
-            lo = wn_pk_bf16(r0 - wn_bits_f32(md << 16), r1 - wn_bits_f32(md & 0xffff0000u));
+            lo = NP == 3 ? wn_pk_bf16(r0 - wn_bits_f32(md << 16), r1 - wn_bits_f32(md & 0xffff0000u)) : 0u;
         };
         auto put = [&](char* base, int rows, int row, int kofs, const unsigned* h, const unsigned* md, const unsigned* lo, int np,
                        unsigned sign) {
             const unsigned* src[3] = {h, md, lo};
-            for (int p = 0; p < 3; ++p) {
+            for (int p = 0; p < NP; ++p) {
                 char* d = base + p * rows * 32;
                 for (int q = 0; q < np; ++q) {
                     const int kq = (kofs >> 1) + q;
@@ -959,26 +967,28 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 4 ? 2 : 3)) void k_gemm6_dw(WnGemm
                 }
             }
         };
-        wn_f4 bf[3][TN];
+        wn_f4 bf[NP][TN];
         WN_UNROLL
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
             WN_UNROLL
             for (int j = 0; j < TN; ++j)
                 bf[p][j] = *reinterpret_cast<const wn_f4*>(sb + p * (BN * 32) + wn_frag_off((wn * TN + j) * 32 + li, hi));
         }
         WN_UNROLL
         for (int i = 0; i < TM; ++i) {
-            wn_f4 af[3];
+            wn_f4 af[NP];
             WN_UNROLL
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < NP; ++p)
                 af[p] = *reinterpret_cast<const wn_f4*>(sa + p * (BM * 32) + wn_frag_off((wm * TM + i) * 32 + li, hi));
-            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+            // small terms first; NP = 2: h m, m h, h h
+            constexpr int PA[6] = {0, NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0};
+            constexpr int PB[6] = {NP == 3 ? 2 : 1, 0, NP == 3 ? 1 : 0, 1, 0, 0};
             WN_UNROLL
-            for (int t = 0; t < 6; ++t) {
+            for (int t = 0; t < NPROD; ++t) {
                 WN_UNROLL
                 for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(af[PA[t]], bf[PB[t]][j], acc[i][j]);
                 WN_SCHED_FENCE_ALU();
-                slice(i * 6 + t);
+                slice(i * NPROD + t);
                 WN_SCHED_FENCE_ALU();
             }
         }
@@ -1071,25 +1081,32 @@ int wn_gemm6_dw_eligible(const WnGemmArgs* g) {
 }
 
 template <int TM, int TN>
-static int launch_dw(const WnGemmArgs& g, wn_stream_t st) {
-    constexpr int lds = 2 * (3 * 64 * TM * 32 + 3 * 64 * TN * 32);
+static int launch_dw(const WnGemmArgs& g, int products, wn_stream_t st) {
     dim3 grid((unsigned)((g.N + 64 * TN - 1) / (64 * TN)), (unsigned)((g.M + 64 * TM - 1) / (64 * TM)),
               (unsigned)(g.nlayer * g.nbatch * g.ksplit));
-    WN_LAUNCH((k_gemm6_dw<TM, TN>), grid, dim3(G6_T), lds, st, g, xcd_block_order() G6_DBG_ARG(g.tag));
+    if (products == 3) {
+        constexpr int lds = 2 * (2 * 64 * TM * 32 + 2 * 64 * TN * 32);
+        WN_LAUNCH((k_gemm6_dw<TM, TN, 2>), grid, dim3(G6_T), lds, st, g, xcd_block_order() G6_DBG_ARG(g.tag));
+    } else {
+        constexpr int lds = 2 * (3 * 64 * TM * 32 + 3 * 64 * TN * 32);
+        WN_LAUNCH((k_gemm6_dw<TM, TN, 3>), grid, dim3(G6_T), lds, st, g, xcd_block_order() G6_DBG_ARG(g.tag));
+    }
     return 0;
 }
 
-int wn_gemm6_dw_launch(const WnGemmArgs* gp, wn_stream_t st) {
+// products: 6 (default: fp32-equivalent) or 3 (h h + h m + m h: leaf results only, see k_gemm6_dw)
+int wn_gemm6_dw_launch(const WnGemmArgs* gp, int products, wn_stream_t st) {
     const WnGemmArgs& g = *gp;
+    if (products != 3 && products != 6) return 2;
     if (!wn_gemm6_dw_eligible(gp)) return 1;
     if (g.K < 0 || g.nbatch <= 0 || g.ksplit <= 0 || g.nlayer <= 0 || g.b_seg_len <= 0 || g.kchunk <= 0) return 2;
     WN_PROF(g.tag ? g.tag : "gemm6_dw", 2.0 * g.M * g.N * (double)g.K * g.nbatch * g.nlayer,
             ((double)g.M * g.K * 4.0 + (double)g.K * 4.0 * g.N + (double)g.M * g.N * 4.0) * g.nbatch * g.nlayer, st);
     const int tm = g.M > 64 ? 2 : 1, tn = wn_gemm6_dw_tn(g.M, g.N);
-    if (wn_gemm6_dw_tall(g.M, g.N)) return launch_dw<4, 2>(g, st);   // 256 x 128 tiles: every B row is read once per 256 A rows
-    if (tm == 2 && tn == 3) return launch_dw<2, 3>(g, st);
-    if (tm == 2 && tn == 2) return launch_dw<2, 2>(g, st);
-    if (tm == 2) return launch_dw<2, 1>(g, st);
-    if (tn == 2) return launch_dw<1, 2>(g, st);
-    return launch_dw<1, 1>(g, st);
+    if (wn_gemm6_dw_tall(g.M, g.N)) return launch_dw<4, 2>(g, products, st);   // 256 x 128 tiles: every B row is read once per 256 A rows
+    if (tm == 2 && tn == 3) return launch_dw<2, 3>(g, products, st);
+    if (tm == 2 && tn == 2) return launch_dw<2, 2>(g, products, st);
+    if (tm == 2) return launch_dw<2, 1>(g, products, st);
+    if (tn == 2) return launch_dw<1, 2>(g, products, st);
+    return launch_dw<1, 1>(g, products, st);
 }

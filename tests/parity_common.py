@@ -307,6 +307,8 @@ def launch_log(lib, fn):
         fn()
     finally:
         lib.wn_prof_enable(0)
+    if not getattr(lib, "is_emulator", False) and torch.cuda.is_available():
+        torch.cuda.synchronize()   # the report reads HIP events: the launches must have completed
     need = lib.wn_prof_report(None, 0)
     buf = ctypes.create_string_buffer(max(need, 16))
     lib.wn_prof_report(buf, len(buf))

@@ -26,13 +26,28 @@ def _lib():
     return lib
 
 
+TOL_GRAD_3PRODUCT = 3e-5   # gate of the opt-in 3-product weight gradients (WN_FLAG_DW_3PRODUCT): tighter than the 1e-4 of every mode
+
+
+def _three_product_gate(what, res, flags):
+    """WN_FLAG_DW_3PRODUCT: the weight-gradient contractions (leaf results) take three of the six products of the operand
+    split.  Its worst gradient tensor against the oracle at this size must stay within 3e-5 of the tensor's maximum."""
+    worst, key = res["grads"][flags]
+    base = res["grads"][min(res["grads"])]
+    print("%s, weight gradients with 3 products (WN_FLAG_DW_3PRODUCT): worst gradient %.3g (%s); six products: %.3g (%s)"
+          % (what, worst, key, base[0], base[1]))
+    assert worst <= TOL_GRAD_3PRODUCT, (what, worst, key)
+
+
 def test_cfg2_full_size_vs_oracle():
     from pytorchwavenetvocoder_amd import _lib as L
     from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS
     cfg_t = (256, 80, 64, 256, 10, 3, 2, 80)
     res = PC.run_fullsize_vs_oracle(cfg_t, 8, 23040, 101, _lib(), DEV,
-                                    flag_sets=[DEFAULT_FLAGS, DEFAULT_FLAGS ^ L.FLAG_AUX_FUSED, DEFAULT_FLAGS | L.FLAG_NO_CHAIN],
+                                    flag_sets=[DEFAULT_FLAGS, DEFAULT_FLAGS ^ L.FLAG_AUX_FUSED, DEFAULT_FLAGS | L.FLAG_NO_CHAIN,
+                                               DEFAULT_FLAGS | L.FLAG_DW_3PRODUCT],
                                     scale=0.05)
+    _three_product_gate("cfg2 FULL SIZE", res, DEFAULT_FLAGS | L.FLAG_DW_3PRODUCT)
     print("cfg2 FULL SIZE (B=8, T=23040) vs oracle: logits %.3g, loss %.3g, layer inputs %.3g, grads %s; "
           "%d ReLU inputs within 1e-5 of the kink, %d sub-gradient choices differing from the oracle's sign"
           % (res["logits"], res["loss"], res["layer_inputs"], res["grads"], res["near_kink_1e-5"], res["kink_flips"]))
@@ -90,7 +105,9 @@ def test_config4_stated_size_vs_oracle():
     from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS
     cfg_t = (256, 80, 64, 256, 10, 3, 3, 256)
     assert O.batch_geometry(6139, 20000, 256)["T"] == 26112
-    res = PC.run_fullsize_vs_oracle(cfg_t, 8, 26112, 111, _lib(), DEV, flag_sets=[DEFAULT_FLAGS], scale=0.05)
+    from pytorchwavenetvocoder_amd import _lib as L
+    res = PC.run_fullsize_vs_oracle(cfg_t, 8, 26112, 111, _lib(), DEV, flag_sets=[DEFAULT_FLAGS, DEFAULT_FLAGS | L.FLAG_DW_3PRODUCT], scale=0.05)
+    _three_product_gate("configs[3] STATED SIZE", res, DEFAULT_FLAGS | L.FLAG_DW_3PRODUCT)
     print("configs[3] STATED SIZE (K=3, U=256, B=8, T=26112) vs oracle: logits %.3g, loss %.3g, layer inputs %.3g, grads %s, "
           "%d kink flips" % (res["logits"], res["loss"], res["layer_inputs"], res["grads"], res["kink_flips"]))
 
@@ -101,7 +118,9 @@ def test_recipe_size_model_at_the_timed_size_vs_oracle():
     the full length and batch.  (Round 3 checked B = 2 of the 4 windows.)"""
     from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS
     cfg_t = (256, 80, 512, 256, 10, 3, 2, 80)
-    res = PC.run_fullsize_vs_oracle(cfg_t, 4, 23040, 112, _lib(), DEV, flag_sets=[DEFAULT_FLAGS], scale=0.02)
+    from pytorchwavenetvocoder_amd import _lib as L
+    res = PC.run_fullsize_vs_oracle(cfg_t, 4, 23040, 112, _lib(), DEV, flag_sets=[DEFAULT_FLAGS, DEFAULT_FLAGS | L.FLAG_DW_3PRODUCT], scale=0.02)
+    _three_product_gate("recipe-size TIMED SIZE", res, DEFAULT_FLAGS | L.FLAG_DW_3PRODUCT)
     print("recipe-size model at the TIMED SIZE (B=4, T=23040) vs oracle: logits %.3g, loss %.3g, layer inputs %.3g, grads %s, "
           "%d kink flips" % (res["logits"], res["loss"], res["layer_inputs"], res["grads"], res["kink_flips"]))
 
