@@ -346,7 +346,10 @@ static DwPlan dw_plan(int M, int N, int Kdim, int nbatch) {
     // launches, 768 instead of 1024 for the post-net ones): same time for dw_dilated / dw_skip, -15 % for dw_post1/2 and
     // for the reductions of the fewer partials.  64-wide tiles keep the old rule (dw_res: 0.54 vs 0.59 ms).
     long ks;
-    if (wn_gemm6_dw_tall(M, N)) {   // 256 x 128 tiles (k_gemm6_dw<4,2>, 2 workgroups per CU): one resident round of 512
+    if (wn_gemm6_dw_big(M, N)) {    // 256 x 256 tiles (k_gemm6_dw<4,4>, 1 workgroup per CU): one resident round of 256
+        const long big = (long)(M / 256) * (N / 256) * nbatch;
+        ks = 256 / big;
+    } else if (wn_gemm6_dw_tall(M, N)) {   // 256 x 128 tiles (k_gemm6_dw<4,2>, 2 workgroups per CU): one resident round of 512
         const long tall = (long)(M / 256) * tn * nbatch;
         ks = 512 / tall;
     } else if (M > 64 && tnw == 192) {   // 128 x 192 tiles (k_gemm6_dw<2,3>, 2 workgroups per CU): one resident round of 512

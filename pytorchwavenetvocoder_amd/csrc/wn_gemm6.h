@@ -111,6 +111,7 @@ int wn_gemm6_launch(const WnGemm6Args* g, wn_stream_t st);
 struct WnGemmArgs;
 int wn_gemm6_dw_eligible(const struct WnGemmArgs* g);
 // The split-K plan of the caller (wn_api.hip dw_plan) must count tiles with the same two rules the launcher applies:
+int wn_gemm6_dw_big(int M, int N);    // 1: 256 x 256 tiles, one wave per SIMD (k_gemm6_dw<4,4>); checked first
 int wn_gemm6_dw_tall(int M, int N);   // 1: 256 x 128 tiles (k_gemm6_dw<4,2>) for this output shape
 int wn_gemm6_dw_tn(int M, int N);            // otherwise: 3 = one 192-column tile (N = 192), 2 = 128-column tiles, 1 = 64-column tiles
 int wn_gemm6_dw_launch(const struct WnGemmArgs* g, int products, wn_stream_t st);   // products: 6, or 3 for leaf results (weight gradients)

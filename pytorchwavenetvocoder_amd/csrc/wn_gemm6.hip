@@ -692,8 +692,12 @@ int wn_gemm6_launch(const WnGemm6Args* gp, wn_stream_t st) {
 // products h h + h m + m h: relative error ~2^-16 per product, random in sign).  NP = 2 is for LEAF results only -- a weight
 // gradient is a sum over every position of the minibatch that feeds nothing downstream --, opt-in (WN_FLAG_DW_3PRODUCT),
 // never for a contraction whose output another layer consumes.
+// TM x TN = 4 x 4 (round 5): a 256 x 256 block tile, ONE wave per SIMD (its 128 x 128 wave tile is 256 accumulator registers: the
+// unified 512-register file of a lone wave), for the square weight gradients of wide models (n_resch 512: 1024 x 1024 and
+// 512 x 512 outputs) -- every operand row is read once per 256 rows of the other operand (the 256 x 128 tile moved 50.8 GB per
+// launch for 22.6 GB of operands, profiles/r05/pmc_traffic_recipe.json) and a wave reads 1.5 x fewer fragment bytes per MFMA.
 template <int TM, int TN, int NP>
-__global__ __launch_bounds__(G6_T, (TM * TN > 4 ? 2 : 3)) void k_gemm6_dw(WnGemmArgs g, int order G6_DBG_PARAM) {
+__global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) void k_gemm6_dw(WnGemmArgs g, int order G6_DBG_PARAM) {
     static_assert(NP == 2 || NP == 3, "two or three bf16 pieces per operand");
     constexpr int NPROD = NP == 3 ? 6 : 3;
     constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -1029,7 +1033,27 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 4 ? 2 : 3)) void k_gemm6_dw(WnGemm
             s_b = lo + ((hi_s - lo) & ~1);
         }
     }
-    if (s_b > s_a) {
+    // the 256 x 256 tile has no registers for the general pass's second operand set beside its 256 accumulators (it spilled 540
+    // of them): its few non-interior steps (zero history of the shifted taps, the ragged end) go one at a time
+    auto pass_simple = [&](int k_lo, int n) {
+        for (int kb = 0; kb < n; ++kb) {
+            float ra[AE], rb[BE];
+            fetch(k_lo + kb * 16, ra, rb);
+            stage(0, ra, rb);
+            __syncthreads();
+            compute(0);
+            __syncthreads();
+        }
+    };
+    if (TM * TN > 8) {
+        if (s_b > s_a) {
+            pass_simple(kbeg, s_a);
+            pass_fast(kbeg + 16 * s_a, s_b - s_a);
+            pass_simple(kbeg + 16 * s_b, nk - s_b);
+        } else {
+            pass_simple(kbeg, nk);
+        }
+    } else if (s_b > s_a) {
         pass_general(kbeg, s_a);
         pass_fast(kbeg + 16 * s_a, s_b - s_a);
         pass_general(kbeg + 16 * s_b, nk - s_b);
@@ -1063,6 +1087,11 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 4 ? 2 : 3)) void k_gemm6_dw(WnGemm
 // 0.06 - 0.1 ms SLOWER than 128 x 128 tiles at 3 workgroups per CU, so those keep the square tile.  The split-K plan of
 // the caller must use the same rule.
 int wn_gemm6_dw_tall(int M, int N) { return M >= 512 && (M % 256 == 0) && N >= 512; }
+// 256 x 256 tiles, one wave per SIMD (k_gemm6_dw<4,4>): square weight gradients of wide models (-DWN_DW_BIG=0: A/B builds)
+#ifndef WN_DW_BIG
+#define WN_DW_BIG 1
+#endif
+int wn_gemm6_dw_big(int M, int N) { return WN_DW_BIG && M >= 512 && N >= 512 && (M % 256 == 0) && (N % 256 == 0); }
 
 // Column tiles of the weight-gradient kernel: 128 wide unless the last one would be at most half full -- kernel_size 3 has
 // N = 3 * 64 = 192 columns: with 128-wide tiles the second one is ragged, i.e. never takes the branch-free interior pass
@@ -1086,9 +1115,23 @@ static int launch_dw(const WnGemmArgs& g, int products, wn_stream_t st) {
               (unsigned)(g.nlayer * g.nbatch * g.ksplit));
     if (products == 3) {
         constexpr int lds = 2 * (2 * 64 * TM * 32 + 2 * 64 * TN * 32);
+#ifndef WN_EMU
+        static bool attr_set = false;
+        if (lds > 65536 && !attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm6_dw<TM, TN, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 3;
+            attr_set = true;
+        }
+#endif
         WN_LAUNCH((k_gemm6_dw<TM, TN, 2>), grid, dim3(G6_T), lds, st, g, xcd_block_order() G6_DBG_ARG(g.tag));
     } else {
         constexpr int lds = 2 * (3 * 64 * TM * 32 + 3 * 64 * TN * 32);
+#ifndef WN_EMU
+        static bool attr_set = false;
+        if (lds > 65536 && !attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm6_dw<TM, TN, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 3;
+            attr_set = true;
+        }
+#endif
         WN_LAUNCH((k_gemm6_dw<TM, TN, 3>), grid, dim3(G6_T), lds, st, g, xcd_block_order() G6_DBG_ARG(g.tag));
     }
     return 0;
@@ -1103,6 +1146,7 @@ int wn_gemm6_dw_launch(const WnGemmArgs* gp, int products, wn_stream_t st) {
     WN_PROF(g.tag ? g.tag : "gemm6_dw", 2.0 * g.M * g.N * (double)g.K * g.nbatch * g.nlayer,
             ((double)g.M * g.K * 4.0 + (double)g.K * 4.0 * g.N + (double)g.M * g.N * 4.0) * g.nbatch * g.nlayer, st);
     const int tm = g.M > 64 ? 2 : 1, tn = wn_gemm6_dw_tn(g.M, g.N);
+    if (wn_gemm6_dw_big(g.M, g.N)) return launch_dw<4, 4>(g, products, st);     // 256 x 256 tiles, one wave per SIMD
     if (wn_gemm6_dw_tall(g.M, g.N)) return launch_dw<4, 2>(g, products, st);   // 256 x 128 tiles: every B row is read once per 256 A rows
     if (tm == 2 && tn == 3) return launch_dw<2, 3>(g, products, st);
     if (tm == 2 && tn == 2) return launch_dw<2, 2>(g, products, st);

@@ -126,17 +126,18 @@ if has k3probe; then
   timeout 300 python tools/recipe_decode_probe.py --kernel-size 2 --steps 300 --batches 1,2,16,32,48,64,96 > $OUT/recipe_decode_probe_k2.txt 2>&1; echo "k2 decode probe rc=$?"; cat $OUT/recipe_decode_probe_k2.txt
 fi
 if has dw3; then
-  # 3-product weight gradients (WN_FLAG_DW_3PRODUCT = 1 << 18, with the default WN_FLAG_AUX_FUSED = 32): same-box A/B, interleaved
+  # weight-gradient variants at the recipe size and the configs[3] geometry: same-box A/B, interleaved.  A variant = comma-separated
+  # environment settings (WN_ENGINE_FLAGS: 32 = default, 262176 = + WN_FLAG_DW_3PRODUCT; WN_LIB_PATH = a variant build)
   for rep in 1 2; do
-    for fl in 32 262176; do
-      WN_ENGINE_FLAGS=$fl timeout 300 python tools/recipe_bench.py --resch 512 --batch 4 --steps 3 > $OUT/dw3_recipe_$fl.json 2>> $OUT/dw3.err
-      WN_ENGINE_FLAGS=$fl timeout 300 python tools/recipe_bench.py --resch 64 --kernel-size 3 --upsampling 256 --T 26112 --batch 8 --steps 10 > $OUT/dw3_config4_$fl.json 2>> $OUT/dw3.err
+    for cfg in ${WN_DW3_VARIANTS:-WN_ENGINE_FLAGS=32 WN_ENGINE_FLAGS=262176}; do
+      env $(echo $cfg | tr ',' ' ') timeout 300 python tools/recipe_bench.py --resch 512 --batch 4 --steps 3 > $OUT/dw3_recipe.json 2>> $OUT/dw3.err
+      env $(echo $cfg | tr ',' ' ') timeout 300 python tools/recipe_bench.py --resch 64 --kernel-size 3 --upsampling 256 --T 26112 --batch 8 --steps 10 > $OUT/dw3_config4.json 2>> $OUT/dw3.err
       python - <<P
 import json
 for name in ("recipe", "config4"):
-    d = json.load(open("$OUT/dw3_%s_$fl.json" % name))
+    d = json.load(open("$OUT/dw3_%s.json" % name))
     ks = d["kernels"]
-    print("flags %-7s %-8s %8.3f ms/step | " % ("$fl", name, d["ms_per_step"]) + " ".join("%s %.3f" % (k, v["ms"]) for k, v in ks.items() if k.startswith("dw_")))
+    print("%-64s %-8s %8.3f ms/step | " % ("$cfg", name, d["ms_per_step"]) + " ".join("%s %.3f" % (k, v["ms"]) for k, v in ks.items() if k.startswith("dw_")))
 P
     done
   done | tee $OUT/dw3_probe.txt
