@@ -1741,7 +1741,10 @@ static int dl_layout(const WnConfig* cfg, const Dims& d, int nb, bool granules, 
         if (wn_dlpf_covers(&pw)) wide = 1;
     }
     wn_dlp_make_plan(d.Q, d.Qo, d.R, d.S, d.L, d.K, wide, &y->dlp);
-    if (nb > (y->dlp.wide ? WN_DLPM_BMAX : WN_DLP_BMAX)) y->dlp.ok = 0;
+    {
+        const bool flags_ok = WN_DLPF_ENABLE && !granules && wn_dlpf_covers(&y->dlp);
+        if (nb > (y->dlp.wide ? (flags_ok ? WN_DLPF_BMAX : WN_DLPM_BMAX) : WN_DLP_BMAX)) y->dlp.ok = 0;
+    }
     const int dlp_blocks = y->dlp.wide ? (nb + WN_DLPM_CB - 1) / WN_DLPM_CB : 1;   // k_dlpm: a set of units per block of 16 utterances
     if (y->dlp.ok && y->dlp.NU * dlp_blocks > WN_DLPM_MAXWG) y->dlp.ok = 0;
     y->dlp_flags_on = (y->dlp.ok && WN_DLPF_ENABLE && !granules && wn_dlpf_covers(&y->dlp)) ? 1 : 0;

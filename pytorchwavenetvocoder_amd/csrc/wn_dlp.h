@@ -13,8 +13,9 @@
 #define WN_DLP_CB 4      // utterance columns per block (one 16-byte LDS read per k)
 #define WN_DLP_BMAX 4    // utterances per launch of the VALU kernel (k_dlp): one column block
 #define WN_DLPM_CB 16    // utterance columns per block of the matrix-core kernel (k_dlpm, wn_dlpm.hip): one 16x16x4 tile
-#define WN_DLPM_BMAX 48  // utterances per launch of the matrix-core kernel: up to 3 column blocks, each with its own units
-#define WN_DLPM_MAXWG 240 // workgroups of one launch (all resident at once: one per CU, a few CUs left to whatever else runs)
+#define WN_DLPM_BMAX 48  // utterances per launch of the matrix-core kernel with the granule hand-off (wn_dlpm.hip: private queue copies per unit)
+#define WN_DLPF_BMAX 64  // utterances per launch of the flag hand-off kernel (wn_dlpf.hip): up to 4 column blocks, each with its own units
+#define WN_DLPM_MAXWG 256 // workgroups of one launch (all resident at once, one per CU: what the device really keeps is asked before the launch)
 #ifndef WN_DLPF_ENABLE
 #define WN_DLPF_ENABLE 1   // 1: the flag hand-off kernel (wn_dlpf.hip) where it covers the plan; 0: granules everywhere (A/B builds)
 #endif

@@ -487,7 +487,7 @@ int wn_dlpf_capacity(const WnDlpPlan* plan) {
 
 int wn_dlpf_launch(const WnDlpArgs* ap, wn_stream_t st) {
     const WnDlpArgs& a = *ap;
-    if (!wn_dlpf_covers(&a.plan) || !a.handoff || !a.flags || a.B < 1 || a.B > WN_DLPM_BMAX || a.p1 < a.p0) return 1;
+    if (!wn_dlpf_covers(&a.plan) || !a.handoff || !a.flags || a.B < 1 || a.B > WN_DLPF_BMAX || a.p1 < a.p0) return 1;
     const int nblk = (a.B + WN_DLPM_CB - 1) / WN_DLPM_CB;
     if (a.Bp != nblk * WN_DLPM_CB || a.plan.NU * nblk > WN_DLPM_MAXWG) return 1;
     if (a.mode != 0 && a.mode != 1) return 2;

@@ -337,8 +337,8 @@ class WaveNetEngine(object):
         if groups is None:
             return self._decode(x, h, n_samples_list, mode, chunk, return_logits, progress, lay, prefill, prefill_batch,
                                 log_scale_min, _uniforms=draws, _mbits=mbits)
-        # More utterances than ONE persistent launch takes (48), up to two launches' worth: the batch goes through it in two
-        # groups -- the utterances are independent (n_resch 512: 126 K against 90 K samples/s at 64, 185 K against 132 K at 96).
+        # More utterances than ONE persistent launch takes (64 with the flag hand-off: four column blocks = 256 workgroups), up to
+        # two launches' worth: the batch goes through it in two groups -- the utterances are independent.
         T0 = x.size(1)
         n_pad = max(self.receptive_field - T0, 0)
         toks, lgs = [], []
@@ -382,7 +382,7 @@ class WaveNetEngine(object):
         if self.lib.wn_decode_layered_error_offset(cfg, B, mbits) >= 0:
             return None   # one launch takes the whole batch
         gs = 0
-        for cand in (48, 32, 16, 8, 4, 2):   # whole column blocks of 16 first; what the device keeps resident decides (wn_dlp.h)
+        for cand in (64, 48, 32, 16, 8, 4, 2):   # whole column blocks of 16 first; what the device keeps resident decides (wn_dlp.h)
             if self.lib.wn_decode_layered_error_offset(cfg, cand, mbits) >= 0:
                 gs = cand
                 break

@@ -672,8 +672,8 @@ def test_any_size_decode_of_wide_batches_on_the_matrix_cores():
 
 
 def test_any_size_decode_of_more_utterances_than_one_persistent_launch_takes():
-    """52 utterances (one persistent launch takes 48): the engine sends the batch through the persistent launch in groups
-    (48 + 4) -- tokens equal to the layer-wise launches' on the whole batch, in the sampling mode too (the draws are made for
+    """70 utterances (one persistent launch of the flag hand-off kernel takes 64 = four column blocks): the engine sends the batch
+    through the persistent launch in groups (64 + 6) -- tokens equal to the layer-wise launches' on the whole batch, in the sampling mode too (the draws are made for
     the whole batch before it is cut)."""
     import numpy as np
     from oracle import wavenet_oracle as O
@@ -682,12 +682,12 @@ def test_any_size_decode_of_more_utterances_than_one_persistent_launch_takes():
     cfg = O.OracleConfig(*cfg_t)
     model = WaveNet(*cfg_t, _library=emu_library())
     model.load_state_dict(O.random_params(cfg, 11, scale=0.3))
-    B = 52
+    B = 70
     rs = np.random.RandomState(3)
     xs = torch.from_numpy(rs.randint(0, 32, (B, 5))).long()
     hs = torch.from_numpy(rs.standard_normal((B, 4, 8)).astype(np.float32))
     ns = [3 - (b % 2) for b in range(B)]
-    assert model.engine._persistent_groups(B, True, "argmax") == [(0, 48), (48, 52)]
+    assert model.engine._persistent_groups(B, True, "argmax") == [(0, 64), (64, 70)]
     out = {}
     log = PC.launch_log(emu_library(), lambda: out.update(p=model.engine.decode(xs, hs, ns, layered=True)))
     assert log.get("dlpf_steps", 0) == 2 and "dl_dilated" not in log, log
@@ -759,23 +759,25 @@ def test_transpose_op_on_the_emulator():
 
 
 def test_persistent_decode_dispatch_rules():
-    """Which path a batch takes at the recipes' size (n_resch 512; no launch: plan queries only): one persistent launch up to 48
-    utterances, two groups up to 96, the layer-wise launches beyond and for explicit requests; the kernel_size 3 class likewise;
+    """Which path a batch takes at the recipes' size (n_resch 512; no launch: plan queries only): one persistent launch up to 64
+    utterances (flag hand-off; 48 with the granule hand-off), two groups up to 128, the layer-wise launches beyond and for explicit requests; the kernel_size 3 class likewise;
     1024 channels are outside the compiled classes (launches at any batch)."""
     import ctypes
+    from pytorchwavenetvocoder_amd import _lib as L
     from pytorchwavenetvocoder_amd.engine import WaveNetEngine
     lib = emu_library()
     for K in (2, 3):
         eng = WaveNetEngine(256, 80, 512, 256, 10, 3, K, 80, device="cpu", library=lib)
         cfg = ctypes.byref(eng.cfg)
         assert not eng.decode_supported()
-        for B in (1, 2, 5, 16, 17, 48):
+        for B in (1, 2, 5, 16, 17, 48, 49, 64):
             assert lib.wn_decode_layered_error_offset(cfg, B, 0) >= 0, (K, B)      # one persistent launch
             assert eng._persistent_groups(B, None, "argmax") is None
-        assert lib.wn_decode_layered_error_offset(cfg, 49, 0) < 0
-        assert eng._persistent_groups(49, None, "argmax") == [(0, 48), (48, 49)]
-        assert eng._persistent_groups(96, True, "sampling") == [(0, 48), (48, 96)]
-        assert eng._persistent_groups(97, None, "argmax") is None                  # three groups: the launches are as fast
+        assert lib.wn_decode_layered_error_offset(cfg, 65, 0) < 0
+        assert lib.wn_decode_layered_error_offset(cfg, 49, L.DECODE_GRANULES) < 0  # the granule kernels take 48
+        assert eng._persistent_groups(65, None, "argmax") == [(0, 64), (64, 65)]
+        assert eng._persistent_groups(128, True, "sampling") == [(0, 64), (64, 128)]
+        assert eng._persistent_groups(129, None, "argmax") is None                 # three groups: the launches are as fast
         assert eng._persistent_groups(64, "launches", "argmax") is None
         assert eng._persistent_groups(64, None, "mol") is None
     # 1024 channels: (K + 1) n_resch exceeds every compiled class -- layer-wise launches at any batch
@@ -802,7 +804,7 @@ def test_persistent_decode_residency_check_and_fall_backs(monkeypatch):
     lib = emu_library()
     big = WaveNetEngine(256, 80, 512, 256, 10, 3, 2, 80, device="cpu", library=lib)
     assert big.decode_residency(2) == (True, 64, 0x7fffffff) and big.decode_residency(48)[:2] == (True, 192)
-    assert big.decode_residency(1)[:2] == (True, 128) and big.decode_residency(49)[:2] == (False, 0)
+    assert big.decode_residency(1)[:2] == (True, 128) and big.decode_residency(64)[:2] == (True, 256) and big.decode_residency(65)[:2] == (False, 0)
     monkeypatch.setenv("WN_COOP_CAPACITY", "100")
     assert big.decode_residency(2) == (True, 64, 100) and big.decode_residency(17) == (False, 128, 100)
     assert big.decode_residency(1) == (False, 128, 100)

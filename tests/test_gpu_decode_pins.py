@@ -7,7 +7,7 @@ wavenet.py:355-385, 397-511, 538-549) at the recipes' own size on the GPU:
 * LONG horizons: more generated steps than the longest dilation ring holds (kernel_size 2: > 1024, kernel_size 3: > 2048), every
   per-step logit row against the TRAINING forward of the same library on the same tokens (two very different sets of kernels;
   the training forward itself is pinned to the oracle at full size, tests/test_gpu_fullsize.py) -- one utterance (wn_dlp.hip),
-  2 / 17 / 48 (wn_dlpf.hip, 1 - 3 column blocks), 64 (two groups), and the context walked by the persistent launch itself;
+  2 / 17 / 48 / 64 (wn_dlpf.hip, 1 - 4 column blocks), 70 (two groups), and the context walked by the persistent launch itself;
 * 300 steps of every batch class against the layer-wise launches (the in-suite form of tools/decode_equivalence_soak.py);
 * the residency check in front of the launch (occupancy x CUs) and the path it chooses on a device that is too small.
 """
@@ -113,13 +113,13 @@ def _teacher_forced(cfg_t, B, T0, n, prefill, chunk=4096):
     return worst, scale, log
 
 
-@pytest.mark.parametrize("B", [1, 2, 17, 48, 64])
+@pytest.mark.parametrize("B", [1, 2, 17, 48, 64, 70])
 def test_long_horizon_teacher_forced_kernel_size_2(B):
     """n_resch 512, kernel_size 2 (rings of up to 512 positions): 1120 generated steps from a 3200-token context -- every ring
     wraps twice inside ONE decode call and across its chunk boundaries (chunk 500: three launches)."""
     worst, scale, log = _teacher_forced(RECIPE_K2, B, 3200, 1120, "parallel", chunk=500)
     kern = "dlp_steps" if B == 1 else "dlpf_steps"
-    assert log.get(kern, 0) >= (3 if B <= 48 else 6) and "dl_dilated" not in log, log
+    assert log.get(kern, 0) >= 3 and "dl_dilated" not in log, log   # (64 utterances: four column blocks = 256 workgroups in ONE launch)
     print("LONG HORIZON K=2 B=%d: 1120 steps, per-step logits vs training forward worst %.3g (max |logit| %.3g)" % (B, worst, scale))
 
 
