@@ -567,7 +567,11 @@ def main():
                                     "materialised: same loss / dlogits as the separate kernel to 1e-7)",
                        "timing": "median of %d regions of %d steps" % (len(regions), args.steps),
                        "arithmetic": "fp32 storage and accumulation; contractions on the bf16 matrix cores with a 3-way "
-                                     "operand split (6 products, fp32-equivalent to round-off); "
+                                     "operand split (6 products, fp32-equivalent to round-off); " +
+                                     ("the weight-gradient contractions (leaf results: sums over every position that feed nothing "
+                                      "downstream) take 3 of the 6 products (WN_FLAG_DW_3PRODUCT; gate: worst gradient vs the oracle "
+                                      "at the timed sizes <= 3e-5 of the tensor's maximum, measured 6.3e-6 here); "
+                                      if (model.engine.flags & _lib.FLAG_DW_3PRODUCT) else "") +
                                      "WN_FLAG_EXACT_MFMA selects the f32 MFMA everywhere"},
             "timesteps_per_sec": world * timesteps_per_s_gpu, "final_loss": final_loss,
             "roofline": roofline, "comm": comm, "kernels": kernels,

@@ -700,12 +700,17 @@ template <int TM, int TN, int NP>
 __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) void k_gemm6_dw(WnGemmArgs g, int order G6_DBG_PARAM) {
     static_assert(NP == 2 || NP == 3, "two or three bf16 pieces per operand");
     constexpr int NPROD = NP == 3 ? 6 : 3;
-    constexpr bool BIG = TM * TN > 8;   // the 256 x 256 tile (one wave per SIMD): step barrier inside the step, see step_fast
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int AE = BM / 16, BE = BN / 16;            // fp32 elements per thread and step
     // 192-column tiles (TN = 3: kernel_size 3 at 64 channels, N = 3 x 64) give a thread three B rows of 4 consecutive k each
     // (rows r, r + 64, r + 128) instead of one row of BE
-    constexpr int BR = (TN == 3) ? 3 : 1, BEr = BE / BR;
+    // 256 x 256 tile (the wide models' square weight gradients; round 5): a thread takes 4 consecutive k of AR = 4 A rows (rows r,
+    // r + 64, ...) and of BR = 4 B rows instead of 16 consecutive k of ONE row -- 4 lanes then cover 64 contiguous bytes of a
+    // row and a wave's load instruction 16 rows x 64 B, where one row per lane made every 16-byte load its own cache line (64
+    // lines per instruction: the vector L1 serialises them, and with 512 rows x 128 B per step the 32 KB L1 lost each line
+    // before its second half was used).
+    constexpr int AR = (TM == 4 && TN == 4) ? 4 : 1, AEr = AE / AR;
+    constexpr int BR = (TN == 3) ? 3 : ((TM == 4 && TN == 4) ? 4 : 1), BEr = BE / BR;
     constexpr int A_BYTES = NP * BM * 32, B_BYTES = NP * BN * 32, ST_BYTES = A_BYTES + B_BYTES;
     WN_DYN_SMEM(smem_raw);
     __shared__ long b_rowoff[BN];
@@ -753,10 +758,15 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
     __syncthreads();
 
     // this thread's slice of the operand tiles
-    const int a_row = tid / (16 / AE), a_k = (tid % (16 / AE)) * AE;
+    const int a_row = tid / (16 / AEr), a_k = (tid % (16 / AEr)) * AEr;   // (AR > 1: the first of the thread's rows a_row + 64 u)
     const int b_row = tid / (16 / BEr), b_k = (tid % (16 / BEr)) * BEr;   // (TN = 3: the first of the thread's three rows)
-    const long a_off = (long)(m0 + a_row) * g.lda;
-    const bool a_row_ok = (m0 + a_row) < g.M;
+    long a_off[AR];
+    bool a_row_ok[AR];
+    WN_UNROLL
+    for (int u = 0; u < AR; ++u) {
+        a_off[u] = (long)(m0 + a_row + 64 * u) * g.lda;
+        a_row_ok[u] = (m0 + a_row + 64 * u) < g.M;
+    }
     long b_off[BR];
     int b_sh[BR];
     WN_UNROLL
@@ -765,7 +775,9 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
         b_sh[u] = b_rowshift[b_row + 64 * u];
     }
     const bool a_tile_ok = (m0 + BM) <= g.M, b_tile_ok = (n0 + BN) <= g.N;
-    float rowsum = 0.f;
+    float rowsum[AR];
+    WN_UNROLL
+    for (int u = 0; u < AR; ++u) rowsum[u] = 0.f;
     const float b_floor = g.b_relu ? 0.f : -__builtin_inff();
     // Odd (batch, k-chunk) partials contract -A and are stored negated: the matrix core's truncation bias (see k_gemm6)
     // changes sign with the operand, so it cancels in the fixed-order sum of the partials instead of adding up over time.
@@ -777,14 +789,16 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
         if (a_tile_ok && full) {
             WN_UNROLL
             for (int q = 0; q < AE / 4; ++q) {
-                const wn_f4 v = wn_ld4_unaligned(Az + a_off + k0 + a_k + 4 * q);
+                const int u = q / (AEr / 4), qq = q % (AEr / 4);
+                const wn_f4 v = wn_ld4_unaligned(Az + a_off[u] + k0 + a_k + 4 * qq);
                 ra[4 * q] = v.x; ra[4 * q + 1] = v.y; ra[4 * q + 2] = v.z; ra[4 * q + 3] = v.w;
             }
         } else {
             WN_UNROLL
             for (int e = 0; e < AE; ++e) {
-                const int k = k0 + a_k + e;
-                ra[e] = (a_row_ok && k < kend) ? Az[a_off + k] : 0.f;
+                const int u = e / AEr;
+                const int k = k0 + a_k + e % AEr;
+                ra[e] = (a_row_ok[u] && k < kend) ? Az[a_off[u] + k] : 0.f;
             }
         }
         if (b_tile_ok && full && (k0 - b_shmax) >= 0 && (k0 + 16 - b_shmin) <= g.b_clen) {
@@ -825,12 +839,16 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
     auto stage = [&](int st, const float (&ra)[AE], const float (&rb)[BE], bool counted = true) {
         char* sa = smem_raw + st * ST_BYTES;
         if (g.a_rowsum != nullptr) {
-            float rs = 0.f;
             WN_UNROLL
-            for (int e = 0; e < AE; ++e) rs += ra[e];
-            rowsum += counted ? rs : 0.f;
+            for (int u = 0; u < AR; ++u) {
+                float rs = 0.f;
+                WN_UNROLL
+                for (int e = 0; e < AEr; ++e) rs += ra[u * AEr + e];
+                rowsum[u] += counted ? rs : 0.f;
+            }
         }
-        split_store(sa, BM, a_row, a_k, ra, AE, a_sign);
+        WN_UNROLL
+        for (int u = 0; u < AR; ++u) split_store(sa, BM, a_row + 64 * u, a_k, ra + u * AEr, AEr, a_sign);
         // the optional ReLU on B is a floor applied HERE, not at the load: anything that touches the loaded registers
         // right after the load makes the wait for them land before the MFMAs they were supposed to hide under
         float rbf[BE];
@@ -881,7 +899,8 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
     auto fetch_fast = [&](int k0, float (&ra)[AE], float (&rb)[BE]) {
         WN_UNROLL
         for (int q = 0; q < AE / 4; ++q) {
-            const wn_f4 v = wn_ld4_unaligned(Az + a_off + k0 + a_k + 4 * q);
+            const int u = q / (AEr / 4), qq = q % (AEr / 4);
+            const wn_f4 v = wn_ld4_unaligned(Az + a_off[u] + k0 + a_k + 4 * qq);
             ra[4 * q] = v.x; ra[4 * q + 1] = v.y; ra[4 * q + 2] = v.z; ra[4 * q + 3] = v.w;
         }
         WN_UNROLL
@@ -924,14 +943,8 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
     // first the loads of the step after next, then the split of the next step's operands pair by pair (A, then B), each
     // operand's three LDS writes right after its last pair.  The fences pin this order for VALU, MFMA and memory
     // instructions; LDS reads (the next row tile's fragments) and scalar instructions may cross them.
-    // BIG (the 256 x 256 tile: ONE wave per SIMD, nobody to hide this wave's latencies): the step's barrier sits INSIDE the step,
-    // behind the last fragment read of LDS stage `st` and the last piece written to stage `stn` (slice (TM - 1) NPROD + 1), and the
-    // first fragments of the NEXT step (all of B, row tile 0 of A) are read from `stn` under the step's last MFMAs into the second
-    // fragment register set -- a step then starts with its operands in registers instead of a barrier followed by an exposed LDS
-    // round trip.  (Reads of `st` are all issued before any wave passes the barrier, writes to `st` only come after it: the LDS
-    // serves them in issue order.)
     auto step_fast = [&](int st, int stn, const float (&ra)[AE], const float (&rb)[BE], float (&ran)[AE], float (&rbn)[BE],
-                         int k_next, bool counted, wn_f4 (&bfc)[NP][TN], wn_f4 (&afc)[NP], wn_f4 (&bfn)[NP][TN], wn_f4 (&afn)[NP]) {
+                         int k_next, bool counted) {
         const char* sa = smem_raw + st * ST_BYTES;
         const char* sb = sa + A_BYTES;
         char* da = smem_raw + stn * ST_BYTES;
@@ -964,9 +977,13 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
             for (int u = 0; u < PPS; ++u) {
                 const int q = (sl - 1) * PPS + u;
                 if (q < NPA) {
+                    constexpr int PRA = AEr / 2;   // pairs per A row of this thread
                     pair(ra[2 * q], ra[2 * q + 1], ha[q], ma[q], la[q]);
-                    if (g.a_rowsum != nullptr) rowsum += counted ? ra[2 * q] + ra[2 * q + 1] : 0.f;
-                    if (q == NPA - 1) put(da, BM, a_row, a_k, ha, ma, la, NPA, a_sign);
+                    if (g.a_rowsum != nullptr) rowsum[q / PRA] += counted ? ra[2 * q] + ra[2 * q + 1] : 0.f;
+                    if ((q + 1) % PRA == 0) {
+                        const int u = q / PRA;
+                        put(da, BM, a_row + 64 * u, a_k, ha + u * PRA, ma + u * PRA, la + u * PRA, PRA, a_sign);
+                    }
                 } else if (q < NPA + NPB) {
                     const int qb = q - NPA;
                     pair(fmaxf(rb[2 * qb], b_floor), fmaxf(rb[2 * qb + 1], b_floor), hb[qb], mb[qb], lb[qb]);
@@ -983,14 +1000,14 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
         for (int p = 0; p < NP; ++p) {
             WN_UNROLL
             for (int j = 0; j < TN; ++j)
-                bf[p][j] = BIG ? bfc[p][j] : *reinterpret_cast<const wn_f4*>(sb + p * (BN * 32) + wn_frag_off((wn * TN + j) * 32 + li, hi));
+                bf[p][j] = *reinterpret_cast<const wn_f4*>(sb + p * (BN * 32) + wn_frag_off((wn * TN + j) * 32 + li, hi));
         }
         WN_UNROLL
         for (int i = 0; i < TM; ++i) {
             wn_f4 af[NP];
             WN_UNROLL
             for (int p = 0; p < NP; ++p)
-                af[p] = (BIG && i == 0) ? afc[p] : *reinterpret_cast<const wn_f4*>(sa + p * (BM * 32) + wn_frag_off((wm * TM + i) * 32 + li, hi));
+                af[p] = *reinterpret_cast<const wn_f4*>(sa + p * (BM * 32) + wn_frag_off((wm * TM + i) * 32 + li, hi));
             // small terms first; NP = 2: h m, m h, h h
             constexpr int PA[6] = {0, NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0};
             constexpr int PB[6] = {NP == 3 ? 2 : 1, 0, NP == 3 ? 1 : 0, 1, 0, 0};
@@ -1000,54 +1017,30 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
                 for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(af[PA[t]], bf[PB[t]][j], acc[i][j]);
                 WN_SCHED_FENCE_ALU();
                 slice(i * NPROD + t);
-                if (BIG && i == TM - 1 && t == 1) {
-                    static_assert(!BIG || ((NPA + NPB + PPS - 1) / PPS + 1 <= (TM - 1) * NPROD + 1), "every piece is written before the barrier");
-                    __syncthreads();   // every wave has read what it needs of `st` and written its part of `stn`
-                    const char* na = smem_raw + stn * ST_BYTES;
-                    const char* nb = na + A_BYTES;
-                    WN_UNROLL
-                    for (int p = 0; p < NP; ++p) {
-                        WN_UNROLL
-                        for (int j = 0; j < TN; ++j)
-                            bfn[p][j] = *reinterpret_cast<const wn_f4*>(nb + p * (BN * 32) + wn_frag_off((wn * TN + j) * 32 + li, hi));
-                        afn[p] = *reinterpret_cast<const wn_f4*>(na + p * (BM * 32) + wn_frag_off((wm * TM) * 32 + li, hi));
-                    }
-                }
                 WN_SCHED_FENCE_ALU();
             }
         }
     };
     auto pass_fast = [&](int k_lo, int n) {   // n even, >= 2
         float ra0[AE], rb0[BE], ra1[AE], rb1[BE];
-        wn_f4 bfA[NP][TN], afA[NP], bfB[NP][TN], afB[NP];   // BIG: the two fragment register sets (this step's / the next step's)
         const int k_last = k_lo + (n - 1) * 16;
         fetch_fast(k_lo, ra0, rb0);
         fetch_fast(k_lo + 16, ra1, rb1);
         stage(0, ra0, rb0);
         __syncthreads();
-        if (BIG) {
-            WN_UNROLL
-            for (int p = 0; p < NP; ++p) {
-                WN_UNROLL
-                for (int j = 0; j < TN; ++j)
-                    bfA[p][j] = *reinterpret_cast<const wn_f4*>(smem_raw + A_BYTES + p * (BN * 32) + wn_frag_off((wn * TN + j) * 32 + li, hi));
-                afA[p] = *reinterpret_cast<const wn_f4*>(smem_raw + p * (BM * 32) + wn_frag_off((wm * TM) * 32 + li, hi));
-            }
-        }
         for (int kb = 0; kb < n; kb += 2) {
             const int ka = k_lo + (kb + 2) * 16, kc = k_lo + (kb + 3) * 16;
             G6_STAMP(kb, 0);
-            step_fast(0, 1, ra1, rb1, ra0, rb0, ka < k_last ? ka : k_last, true, bfA, afA, bfB, afB);
+            step_fast(0, 1, ra1, rb1, ra0, rb0, ka < k_last ? ka : k_last, true);
             G6_STAMP(kb, 3);
-            if (!BIG) __syncthreads();
+            __syncthreads();
             G6_STAMP(kb, 5);
             // past the end the staged step is a copy of the last one that nobody reads (nor counts)
-            step_fast(1, 0, ra0, rb0, ra1, rb1, kc < k_last ? kc : k_last, kb + 2 < n, bfB, afB, bfA, afA);
+            step_fast(1, 0, ra0, rb0, ra1, rb1, kc < k_last ? kc : k_last, kb + 2 < n);
             G6_STAMP(kb + 1, 3);
-            if (!BIG) __syncthreads();
+            __syncthreads();
             G6_STAMP(kb + 1, 5);
         }
-        if (BIG) __syncthreads();   // (the last step's fragment prefetch of its `stn` is over before anybody stages again)
     };
     // interior steps of this block's k-chunk: [k_a, k_b) in units of 16 from kbeg
     const int nk = (kend > kbeg) ? (kend - kbeg + 15) / 16 : 0;
@@ -1093,9 +1086,13 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
     }
 
     if (g.a_rowsum != nullptr) {
-        // the 16/AE threads of a row are adjacent lanes
-        for (int m = 1; m < 16 / AE; m <<= 1) rowsum += __shfl_xor(rowsum, m, 64);
-        if (bx == 0 && a_k == 0 && a_row_ok) g.a_rowsum[(long)z * g.M + m0 + a_row] = rowsum;
+        // the 16 / AEr threads of a row are adjacent lanes
+        WN_UNROLL
+        for (int u = 0; u < AR; ++u) {
+            float rs = rowsum[u];
+            for (int m = 1; m < 16 / AEr; m <<= 1) rs += __shfl_xor(rs, m, 64);
+            if (bx == 0 && a_k == 0 && a_row_ok[u]) g.a_rowsum[(long)z * g.M + m0 + a_row + 64 * u] = rs;
+        }
     }
     const wn_rsrc_t Cr = wn_make_buf(g.C + (long)z * g.c_zstride, (unsigned)((long)g.M * g.ldc * 4));
     WN_UNROLL

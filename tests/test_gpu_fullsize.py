@@ -26,7 +26,7 @@ def _lib():
     return lib
 
 
-TOL_GRAD_3PRODUCT = 3e-5   # gate of the opt-in 3-product weight gradients (WN_FLAG_DW_3PRODUCT): tighter than the 1e-4 of every mode
+TOL_GRAD_3PRODUCT = 3e-5   # gate of the 3-product weight gradients (WN_FLAG_DW_3PRODUCT, the engine's default): tighter than the 1e-4 of every mode
 
 
 def _three_product_gate(what, res, flags):
@@ -43,11 +43,11 @@ def test_cfg2_full_size_vs_oracle():
     from pytorchwavenetvocoder_amd import _lib as L
     from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS
     cfg_t = (256, 80, 64, 256, 10, 3, 2, 80)
+    SIX = DEFAULT_FLAGS & ~L.FLAG_DW_3PRODUCT
     res = PC.run_fullsize_vs_oracle(cfg_t, 8, 23040, 101, _lib(), DEV,
-                                    flag_sets=[DEFAULT_FLAGS, DEFAULT_FLAGS ^ L.FLAG_AUX_FUSED, DEFAULT_FLAGS | L.FLAG_NO_CHAIN,
-                                               DEFAULT_FLAGS | L.FLAG_DW_3PRODUCT],
+                                    flag_sets=[SIX, SIX ^ L.FLAG_AUX_FUSED, SIX | L.FLAG_NO_CHAIN, SIX | L.FLAG_DW_3PRODUCT],
                                     scale=0.05)
-    _three_product_gate("cfg2 FULL SIZE", res, DEFAULT_FLAGS | L.FLAG_DW_3PRODUCT)
+    _three_product_gate("cfg2 FULL SIZE", res, SIX | L.FLAG_DW_3PRODUCT)
     print("cfg2 FULL SIZE (B=8, T=23040) vs oracle: logits %.3g, loss %.3g, layer inputs %.3g, grads %s; "
           "%d ReLU inputs within 1e-5 of the kink, %d sub-gradient choices differing from the oracle's sign"
           % (res["logits"], res["loss"], res["layer_inputs"], res["grads"], res["near_kink_1e-5"], res["kink_flips"]))
@@ -106,8 +106,9 @@ def test_config4_stated_size_vs_oracle():
     cfg_t = (256, 80, 64, 256, 10, 3, 3, 256)
     assert O.batch_geometry(6139, 20000, 256)["T"] == 26112
     from pytorchwavenetvocoder_amd import _lib as L
-    res = PC.run_fullsize_vs_oracle(cfg_t, 8, 26112, 111, _lib(), DEV, flag_sets=[DEFAULT_FLAGS, DEFAULT_FLAGS | L.FLAG_DW_3PRODUCT], scale=0.05)
-    _three_product_gate("configs[3] STATED SIZE", res, DEFAULT_FLAGS | L.FLAG_DW_3PRODUCT)
+    SIX = DEFAULT_FLAGS & ~L.FLAG_DW_3PRODUCT
+    res = PC.run_fullsize_vs_oracle(cfg_t, 8, 26112, 111, _lib(), DEV, flag_sets=[SIX, SIX | L.FLAG_DW_3PRODUCT], scale=0.05)
+    _three_product_gate("configs[3] STATED SIZE", res, SIX | L.FLAG_DW_3PRODUCT)
     print("configs[3] STATED SIZE (K=3, U=256, B=8, T=26112) vs oracle: logits %.3g, loss %.3g, layer inputs %.3g, grads %s, "
           "%d kink flips" % (res["logits"], res["loss"], res["layer_inputs"], res["grads"], res["kink_flips"]))
 
@@ -119,8 +120,9 @@ def test_recipe_size_model_at_the_timed_size_vs_oracle():
     from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS
     cfg_t = (256, 80, 512, 256, 10, 3, 2, 80)
     from pytorchwavenetvocoder_amd import _lib as L
-    res = PC.run_fullsize_vs_oracle(cfg_t, 4, 23040, 112, _lib(), DEV, flag_sets=[DEFAULT_FLAGS, DEFAULT_FLAGS | L.FLAG_DW_3PRODUCT], scale=0.02)
-    _three_product_gate("recipe-size TIMED SIZE", res, DEFAULT_FLAGS | L.FLAG_DW_3PRODUCT)
+    SIX = DEFAULT_FLAGS & ~L.FLAG_DW_3PRODUCT
+    res = PC.run_fullsize_vs_oracle(cfg_t, 4, 23040, 112, _lib(), DEV, flag_sets=[SIX, SIX | L.FLAG_DW_3PRODUCT], scale=0.02)
+    _three_product_gate("recipe-size TIMED SIZE", res, SIX | L.FLAG_DW_3PRODUCT)
     print("recipe-size model at the TIMED SIZE (B=4, T=23040) vs oracle: logits %.3g, loss %.3g, layer inputs %.3g, grads %s, "
           "%d kink flips" % (res["logits"], res["loss"], res["layer_inputs"], res["grads"], res["kink_flips"]))
 
