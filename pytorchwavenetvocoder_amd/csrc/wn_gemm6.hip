@@ -1015,8 +1015,16 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
             for (int t = 0; t < NPROD; ++t) {
                 WN_UNROLL
                 for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(af[PA[t]], bf[PB[t]][j], acc[i][j]);
-                WN_SCHED_FENCE_ALU();
                 slice(i * NPROD + t);
+                // One scheduling region = the TN MFMAs + their slice, issued as MFMA, <= 6 VALU, MFMA, <= 6 VALU, ...: a wave's own
+                // VALU instructions are free under an MFMA only up to 6 per MFMA (tools/microbench/mfma_valu.hip: 34.5 cycles per
+                // slot with 6, 47.8 with 8) -- issued as a block BEHIND the TN MFMAs (round 4) only the last MFMA covered them: the
+                // 256 x 256 tile's step body took 2650 cycles for 1536 of MFMAs (profiles/r05/dw_timing_big_tile_before_interleave.txt).
+                WN_UNROLL
+                for (int j = 0; j < TN; ++j) {
+                    WN_SGB_MFMA(1);
+                    WN_SGB_VALU(6);
+                }
                 WN_SCHED_FENCE_ALU();
             }
         }
