@@ -700,7 +700,6 @@ template <int TM, int TN, int NP>
 __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) void k_gemm6_dw(WnGemmArgs g, int order G6_DBG_PARAM) {
     static_assert(NP == 2 || NP == 3, "two or three bf16 pieces per operand");
     constexpr int NPROD = NP == 3 ? 6 : 3;
-    constexpr bool BIG = TM * TN > 8;   // the 256 x 256 tile (one wave per SIMD): fragment prefetch + the step barrier inside the step
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int AE = BM / 16, BE = BN / 16;            // fp32 elements per thread and step
     // 192-column tiles (TN = 3: kernel_size 3 at 64 channels, N = 3 x 64) give a thread three B rows of 4 consecutive k each
@@ -944,14 +943,8 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
     // first the loads of the step after next, then the split of the next step's operands pair by pair (A, then B), each
     // operand's three LDS writes right after its last pair.  The fences pin this order for VALU, MFMA and memory
     // instructions; LDS reads (the next row tile's fragments) and scalar instructions may cross them.
-    // BIG (the 256 x 256 tile: ONE wave per SIMD, nobody to hide this wave's LDS round trips): (1) the A fragments of row tile
-    // i + 1 are read while tile i's MFMAs run (second fragment register set); (2) the step's barrier sits INSIDE the step, behind
-    // the last fragment read of LDS stage `st` and the last piece written to stage `stn`, and the first fragments of the NEXT step
-    // (all of B, row tile 0 of A) are read from `stn` under the step's last MFMAs -- a step starts with its operands in registers
-    // instead of a barrier followed by an exposed LDS round trip.  (Every read of `st` is issued before any wave passes the
-    // barrier, writes to `st` only come after it, and the LDS serves a CU's requests in order.)
     auto step_fast = [&](int st, int stn, const float (&ra)[AE], const float (&rb)[BE], float (&ran)[AE], float (&rbn)[BE],
-                         int k_next, bool counted, wn_f4 (&bfc)[NP][TN], wn_f4 (&afc)[NP], wn_f4 (&bfn)[NP][TN], wn_f4 (&afn)[NP]) {
+                         int k_next, bool counted) {
         const char* sa = smem_raw + st * ST_BYTES;
         const char* sb = sa + A_BYTES;
         char* da = smem_raw + stn * ST_BYTES;
@@ -1007,20 +1000,14 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
         for (int p = 0; p < NP; ++p) {
             WN_UNROLL
             for (int j = 0; j < TN; ++j)
-                bf[p][j] = BIG ? bfc[p][j] : *reinterpret_cast<const wn_f4*>(sb + p * (BN * 32) + wn_frag_off((wn * TN + j) * 32 + li, hi));
+                bf[p][j] = *reinterpret_cast<const wn_f4*>(sb + p * (BN * 32) + wn_frag_off((wn * TN + j) * 32 + li, hi));
         }
-        wn_f4 afx[2][NP];   // BIG: row tile i in afx[i & 1], tile i + 1 on its way into the other set
-        if (BIG) {
-            WN_UNROLL
-            for (int p = 0; p < NP; ++p) afx[0][p] = afc[p];
-        }
-        constexpr int T_BAR = NPROD - 2;   // slot of the last row tile behind which the barrier sits (every piece is written by then)
         WN_UNROLL
         for (int i = 0; i < TM; ++i) {
             wn_f4 af[NP];
             WN_UNROLL
             for (int p = 0; p < NP; ++p)
-                af[p] = BIG ? afx[i & 1][p] : *reinterpret_cast<const wn_f4*>(sa + p * (BM * 32) + wn_frag_off((wm * TM + i) * 32 + li, hi));
+                af[p] = *reinterpret_cast<const wn_f4*>(sa + p * (BM * 32) + wn_frag_off((wm * TM + i) * 32 + li, hi));
             // small terms first; NP = 2: h m, m h, h h
             constexpr int PA[6] = {0, NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0};
             constexpr int PB[6] = {NP == 3 ? 2 : 1, 0, NP == 3 ? 1 : 0, 1, 0, 0};
@@ -1028,25 +1015,7 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
             for (int t = 0; t < NPROD; ++t) {
                 WN_UNROLL
                 for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(af[PA[t]], bf[PB[t]][j], acc[i][j]);
-                if (BIG && t == 0 && i + 1 < TM) {   // next row tile's A fragments, a whole tile ahead of their first use
-                    WN_UNROLL
-                    for (int p = 0; p < NP; ++p)
-                        afx[(i + 1) & 1][p] = *reinterpret_cast<const wn_f4*>(sa + p * (BM * 32) + wn_frag_off((wm * TM + i + 1) * 32 + li, hi));
-                }
                 slice(i * NPROD + t);
-                if (BIG && i == TM - 1 && t == T_BAR) {
-                    static_assert(!BIG || ((NPA + NPB + PPS - 1) / PPS + 1 <= (TM - 1) * NPROD + T_BAR), "every piece is written before the barrier");
-                    __syncthreads();   // every wave has read what it needs of `st` and written its part of `stn`
-                    const char* na = smem_raw + stn * ST_BYTES;
-                    const char* nb = na + A_BYTES;
-                    WN_UNROLL
-                    for (int p = 0; p < NP; ++p) {
-                        WN_UNROLL
-                        for (int j = 0; j < TN; ++j)
-                            bfn[p][j] = *reinterpret_cast<const wn_f4*>(nb + p * (BN * 32) + wn_frag_off((wn * TN + j) * 32 + li, hi));
-                        afn[p] = *reinterpret_cast<const wn_f4*>(na + p * (BM * 32) + wn_frag_off((wm * TM) * 32 + li, hi));
-                    }
-                }
                 // One scheduling region = the TN MFMAs + their slice, issued as MFMA, <= 6 VALU, MFMA, <= 6 VALU, ...: a wave's own
                 // VALU instructions are free under an MFMA only up to 6 per MFMA (tools/microbench/mfma_valu.hip: 34.5 cycles per
                 // slot with 6, 47.8 with 8) -- issued as a block BEHIND the TN MFMAs (round 4) only the last MFMA covered them: the
@@ -1062,35 +1031,24 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
     };
     auto pass_fast = [&](int k_lo, int n) {   // n even, >= 2
         float ra0[AE], rb0[BE], ra1[AE], rb1[BE];
-        wn_f4 bfA[NP][TN], afA[NP], bfB[NP][TN], afB[NP];   // BIG: the two fragment register sets (this step's / the next step's)
         const int k_last = k_lo + (n - 1) * 16;
         fetch_fast(k_lo, ra0, rb0);
         fetch_fast(k_lo + 16, ra1, rb1);
         stage(0, ra0, rb0);
         __syncthreads();
-        if (BIG) {
-            WN_UNROLL
-            for (int p = 0; p < NP; ++p) {
-                WN_UNROLL
-                for (int j = 0; j < TN; ++j)
-                    bfA[p][j] = *reinterpret_cast<const wn_f4*>(smem_raw + A_BYTES + p * (BN * 32) + wn_frag_off((wn * TN + j) * 32 + li, hi));
-                afA[p] = *reinterpret_cast<const wn_f4*>(smem_raw + p * (BM * 32) + wn_frag_off((wm * TM) * 32 + li, hi));
-            }
-        }
         for (int kb = 0; kb < n; kb += 2) {
             const int ka = k_lo + (kb + 2) * 16, kc = k_lo + (kb + 3) * 16;
             G6_STAMP(kb, 0);
-            step_fast(0, 1, ra1, rb1, ra0, rb0, ka < k_last ? ka : k_last, true, bfA, afA, bfB, afB);
+            step_fast(0, 1, ra1, rb1, ra0, rb0, ka < k_last ? ka : k_last, true);
             G6_STAMP(kb, 3);
-            if (!BIG) __syncthreads();
+            __syncthreads();
             G6_STAMP(kb, 5);
             // past the end the staged step is a copy of the last one that nobody reads (nor counts)
-            step_fast(1, 0, ra0, rb0, ra1, rb1, kc < k_last ? kc : k_last, kb + 2 < n, bfB, afB, bfA, afA);
+            step_fast(1, 0, ra0, rb0, ra1, rb1, kc < k_last ? kc : k_last, kb + 2 < n);
             G6_STAMP(kb + 1, 3);
-            if (!BIG) __syncthreads();
+            __syncthreads();
             G6_STAMP(kb + 1, 5);
         }
-        if (BIG) __syncthreads();   // (the last step's fragment prefetch of its `stn` is over before anybody stages again)
     };
     // interior steps of this block's k-chunk: [k_a, k_b) in units of 16 from kbeg
     const int nk = (kend > kbeg) ? (kend - kbeg + 15) / 16 : 0;
