@@ -34,6 +34,9 @@ static __device__ __forceinline__ long dlpf_queue_off(int l, int depth, int K, i
     return (long)R * (K - 1) * (cyc * ((1L << depth) - 1) + ((1L << in) - 1));
 }
 #define DLPF_SPIN_MAX (1 << 22)
+#ifndef WN_DLPF_TAP_PREFETCH
+#define WN_DLPF_TAP_PREFETCH 1   // the older taps of a stage are requested a stage early (0: with the stage's other inputs; A/B builds)
+#endif
 #ifdef WN_DLP_TIMING   // stamps of wn_dlp.hip / wn_dlpm.hip (tools/dlp_timing.py): unit 0 of block 0, step p0 + 3
 #define DLPF_STAMP(stage, ph)                                                                                        \
     do {                                                                                                             \
@@ -198,6 +201,39 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlpf(WnDlpArgs a) {
                 wn_buf_load_lds16_coherent(rs, reinterpret_cast<char*>(s_x + (wave * NSX + i4) * 64), ((row0 + k0 + i4) * Bp + cblk * CB + c4) * 4, 0u);
         }
     };
+    // The older taps of layer sn at step pp (rows k >= 2 R of the gate set's input) from the shared rings into their rows of s_p.
+    // They were written a whole step ago (one stage after they were computed), so they do NOT wait for the flags of the previous
+    // stage: with WN_DLPF_TAP_PREFETCH they are requested a stage early -- right after the tiles of stage sn - 1 have released the
+    // rows (behind that stage's publish and the next stage's weight requests) --, a third (kernel_size 2) or half (kernel_size 3)
+    // of a stage's input bytes whose round trip then runs beside the flag wait instead of after it.  (The slot a tap is read
+    // from is overwritten at stage sn + 1 of this step, after the flags of stage sn: every unit has its copy by then.)
+    auto fetch_taps = [&](int sn, int pp) {
+        if (sn >= L) return;
+        const int qd = (lane >> 2) & 3, id = lane >> 4, c4 = (lane & 3) * 4;
+        const int k0 = (4 * wave + qd) * NSP + id;   // + i4
+        const int kw_lo = 4 * wave * NSP, kw_hi = kw_lo + 4 * NSP;     // (wave-uniform) k range of the wave's groups
+        if (!(kw_hi > 2 * R && kw_lo < KP)) return;
+        const int d = 1 << (sn % a.depth), Dq = (K - 1) * d;
+        const long qoff = dlpf_queue_off(sn, a.depth, K, R);
+        // (rows of a [..][B] ring are 4 B bytes apart: 16-byte transfers from 4-byte aligned addresses; the columns of a
+        // ragged last block past B read the next row's first floats, which nobody uses)
+        unsigned tbase[2];   // byte offset of row c = 0 of tap jt (kernel_size <= 3: two older taps at most)
+        WN_UNROLL
+        for (int jt = 0; jt < 2; ++jt) {
+            int slot = (pp - (K - 1 - jt) * d) % Dq;
+            if (slot < 0) slot += Dq;
+            tbase[jt] = (unsigned)(((qoff + (long)slot * R) * B + cblk * CB + c4) * 4);
+        }
+        WN_NOUNROLL
+        for (int i4 = 0; i4 < NSP; i4 += 4) {
+            const int kt = k0 + i4 - 2 * R;   // row of the tap part
+            if (kt >= 0 && k0 + i4 < KP) {
+                const int jt = kt >= R ? 1 : 0;
+                wn_buf_load_lds16_coherent(rQ, reinterpret_cast<char*>(s_p + (wave * NSP + i4) * 64),
+                                  (int)(tbase[jt] + (unsigned)((kt - jt * R) * B * 4)), 0u);
+            }
+        }
+    };
     // this lane's element of tile step 0 of the two row sets
     const float* srcP = s_p + (wave * NSP) * 64 + lane;
     const float* srcX = XCOPY ? s_x + (wave * NSX) * 64 + lane : s_p + posP((4 * wave + q) * NSX) + lc;
@@ -210,6 +246,7 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlpf(WnDlpArgs a) {
     };
     const float* pimg = a.wpost + (long)u * a.plan.post_floats;
     issue_stage_weights(0);
+    if (WN_DLPF_TAP_PREFETCH) fetch_taps(0, a.p0);
     for (int p = a.p0; p < a.p1; ++p) {
         const unsigned tag0 = (unsigned)(p + 1) * (unsigned)(L + 4) + 1u;    // tag of (step p, stage s) = tag0 + s
         for (int s = 0; s <= L; ++s) {
@@ -234,31 +271,9 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlpf(WnDlpArgs a) {
                 // id = l / 16.  Two loops, one per source array (an instruction takes ONE wave-uniform resource): [z | x] rows
                 // k < 2 R of the previous stage's vector, older taps k >= 2 R from the rings; a wave runs a loop only if one of its
                 // groups reaches into that part.
-                const int qd = (lane >> 2) & 3, id = lane >> 4, c4 = (lane & 3) * 4;
-                const int k0 = (4 * wave + qd) * NSP + id;   // + i4
-                const int kw_lo = 4 * wave * NSP, kw_hi = kw_lo + 4 * NSP;     // (wave-uniform) k range of the wave's groups
                 // rows of [z | x] that are handed over: z from stage 1 on, x from stage 2 on
                 fetch_p(rZX, par * 2 * R, s >= 1 ? 0 : R, s >= 2 ? 2 * R : (s >= 1 ? R : 0));
-                if (kw_hi > 2 * R && kw_lo < KP) {
-                    // (rows of a [..][B] ring are 4 B bytes apart: 16-byte transfers from 4-byte aligned addresses; the columns of a
-                    // ragged last block past B read the next row's first floats, which nobody uses)
-                    unsigned tbase[2];   // byte offset of row c = 0 of tap jt (kernel_size <= 3: two older taps at most)
-                    WN_UNROLL
-                    for (int jt = 0; jt < 2; ++jt) {
-                        int slot = (p - (K - 1 - jt) * d) % Dq;
-                        if (slot < 0) slot += Dq;
-                        tbase[jt] = (unsigned)(((qoff_s + (long)slot * R) * B + cblk * CB + c4) * 4);
-                    }
-                    WN_NOUNROLL
-                    for (int i4 = 0; i4 < NSP; i4 += 4) {
-                        const int kt = k0 + i4 - 2 * R;   // row of the tap part
-                        if (kt >= 0 && k0 + i4 < KP) {
-                            const int jt = kt >= R ? 1 : 0;
-                            wn_buf_load_lds16_coherent(rQ, reinterpret_cast<char*>(s_p + (wave * NSP + i4) * 64),
-                                              (int)(tbase[jt] + (unsigned)((kt - jt * R) * B * 4)), 0u);
-                        }
-                    }
-                }
+                if (!WN_DLPF_TAP_PREFETCH) fetch_taps(s, p);
                 if (s <= 1) {   // x_0 is every unit's own gather of the front-conv table (eight rows' reads in flight)
                     int tk[3];
                     WN_UNROLL
@@ -344,6 +359,7 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlpf(WnDlpArgs a) {
             if (s < L) {
                 publish(tag0 + (unsigned)s);
                 issue_stage_weights(s + 1);
+                if (WN_DLPF_TAP_PREFETCH) fetch_taps(s + 1, p);
             }
             DLPF_STAMP(s, 6);
         }
@@ -441,6 +457,8 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlpf(WnDlpArgs a) {
             }
             __syncthreads();
         }
+        // (only now: the token choice staged the logits in the first rows of s_p, which a small model's tap rows overlap)
+        if (WN_DLPF_TAP_PREFETCH && p + 1 < a.p1) fetch_taps(0, p + 1);
         DLPF_STAMP(L + 2, 0);
         if (s_flag[0]) break;
     }

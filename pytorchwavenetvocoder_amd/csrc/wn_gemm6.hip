@@ -778,7 +778,10 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
     float rowsum[AR];
     WN_UNROLL
     for (int u = 0; u < AR; ++u) rowsum[u] = 0.f;
-    const float b_floor = g.b_relu ? 0.f : -__builtin_inff();
+    // (b_relu is not taken here: wn_gemm6_dw_eligible -- no caller of the weight-gradient path uses it, and a floor applied to every
+    // B element cost 2 VALU instructions per element in the k-step whether it was on or not)
+    // the bias row sums of A are written by the blocks of column tile 0 only: the others do not add them up either
+    const bool do_rowsum = g.a_rowsum != nullptr && bx == 0;
     // Odd (batch, k-chunk) partials contract -A and are stored negated: the matrix core's truncation bias (see k_gemm6)
     // changes sign with the operand, so it cancels in the fixed-order sum of the partials instead of adding up over time.
     // (The bias row sums are fp32 VALU sums of the un-negated values.)
@@ -838,7 +841,7 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
     };
     auto stage = [&](int st, const float (&ra)[AE], const float (&rb)[BE], bool counted = true) {
         char* sa = smem_raw + st * ST_BYTES;
-        if (g.a_rowsum != nullptr) {
+        if (do_rowsum) {
             WN_UNROLL
             for (int u = 0; u < AR; ++u) {
                 float rs = 0.f;
@@ -849,13 +852,8 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
         }
         WN_UNROLL
         for (int u = 0; u < AR; ++u) split_store(sa, BM, a_row + 64 * u, a_k, ra + u * AEr, AEr, a_sign);
-        // the optional ReLU on B is a floor applied HERE, not at the load: anything that touches the loaded registers
-        // right after the load makes the wait for them land before the MFMAs they were supposed to hide under
-        float rbf[BE];
         WN_UNROLL
-        for (int e = 0; e < BE; ++e) rbf[e] = fmaxf(rb[e], b_floor);
-        WN_UNROLL
-        for (int u = 0; u < BR; ++u) split_store(sa + A_BYTES, BN, b_row + 64 * u, b_k, rbf + u * BEr, BEr);
+        for (int u = 0; u < BR; ++u) split_store(sa + A_BYTES, BN, b_row + 64 * u, b_k, rb + u * BEr, BEr);
     };
 
     f32x16 acc[TM][TN];
@@ -959,6 +957,9 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
         };
         auto put = [&](char* base, int rows, int row, int kofs, const unsigned* h, const unsigned* md, const unsigned* lo, int np,
                        unsigned sign) {
+#ifdef WN_DWX_NOPUT
+            return;
+#endif
             const unsigned* src[3] = {h, md, lo};
             for (int p = 0; p < NP; ++p) {
                 char* d = base + p * rows * 32;
@@ -970,23 +971,28 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
         };
         auto slice = [&](int sl) {
             if (sl == 0) {
+#ifndef WN_DWX_NOLOAD   // (timing experiments only: tools/dw_timing.py)
                 fetch_fast(k_next, ran, rbn);
+#endif
                 return;
             }
+#ifdef WN_DWX_NOSPLIT
+            return;
+#endif
             WN_UNROLL
             for (int u = 0; u < PPS; ++u) {
                 const int q = (sl - 1) * PPS + u;
                 if (q < NPA) {
                     constexpr int PRA = AEr / 2;   // pairs per A row of this thread
                     pair(ra[2 * q], ra[2 * q + 1], ha[q], ma[q], la[q]);
-                    if (g.a_rowsum != nullptr) rowsum[q / PRA] += counted ? ra[2 * q] + ra[2 * q + 1] : 0.f;
+                    if (do_rowsum) rowsum[q / PRA] += counted ? ra[2 * q] + ra[2 * q + 1] : 0.f;
                     if ((q + 1) % PRA == 0) {
                         const int u = q / PRA;
                         put(da, BM, a_row + 64 * u, a_k, ha + u * PRA, ma + u * PRA, la + u * PRA, PRA, a_sign);
                     }
                 } else if (q < NPA + NPB) {
                     const int qb = q - NPA;
-                    pair(fmaxf(rb[2 * qb], b_floor), fmaxf(rb[2 * qb + 1], b_floor), hb[qb], mb[qb], lb[qb]);
+                    pair(rb[2 * qb], rb[2 * qb + 1], hb[qb], mb[qb], lb[qb]);
                     constexpr int PR = BEr / 2;   // pairs per B row of this thread
                     if ((qb + 1) % PR == 0) {
                         const int u = qb / PR;
@@ -1093,13 +1099,13 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
         pass_general(kbeg, nk);
     }
 
-    if (g.a_rowsum != nullptr) {
+    if (do_rowsum) {
         // the 16 / AEr threads of a row are adjacent lanes
         WN_UNROLL
         for (int u = 0; u < AR; ++u) {
             float rs = rowsum[u];
             for (int m = 1; m < 16 / AEr; m <<= 1) rs += __shfl_xor(rs, m, 64);
-            if (bx == 0 && a_k == 0 && a_row_ok[u]) g.a_rowsum[(long)z * g.M + m0 + a_row + 64 * u] = rs;
+            if (a_k == 0 && a_row_ok[u]) g.a_rowsum[(long)z * g.M + m0 + a_row + 64 * u] = rs;
         }
     }
     const wn_rsrc_t Cr = wn_make_buf(g.C + (long)z * g.c_zstride, (unsigned)((long)g.M * g.ldc * 4));
@@ -1141,7 +1147,7 @@ int wn_gemm6_dw_tn(int M, int N) {
 }
 
 int wn_gemm6_dw_eligible(const WnGemmArgs* g) {
-    return g->a_kmajor && g->b_kmajor && !g->b_index && !g->bias && !g->D && !g->E && !g->relu && !g->accumulate &&
+    return g->a_kmajor && g->b_kmajor && !g->b_index && !g->b_relu && !g->bias && !g->D && !g->E && !g->relu && !g->accumulate &&
            (long)g->M * g->ldc * 4 < 0x7ffffff0L && g->M > 0 && g->N > 0;
 }
 

@@ -15,15 +15,17 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXP = os.path.join(ROOT, "tools", "exp")
-SO = os.path.join(EXP, "libwn_dwtiming.so")
+VARIANT = os.environ.get("WN_DWT_VARIANT", "")   # "", NOLOAD, NOSPLIT, NOPUT: what-if builds that drop one part of the k-step (timing only)
+SO = os.path.join(EXP, "libwn_dwtiming%s.so" % VARIANT)
 CSRC = os.path.join(ROOT, "pytorchwavenetvocoder_amd", "csrc")
 
 
 def build():
     os.makedirs(EXP, exist_ok=True)
-    obj = os.path.join(EXP, "wn_gemm6.dwtiming.o")
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-DWN_TIMING", "-c",
-                           os.path.join(CSRC, "wn_gemm6.hip"), "-o", obj])
+    obj = os.path.join(EXP, "wn_gemm6.dwtiming%s.o" % VARIANT)
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-DWN_TIMING"] +
+                          (["-DWN_DWX_" + VARIANT] if VARIANT else []) +
+                          ["-c", os.path.join(CSRC, "wn_gemm6.hip"), "-o", obj])
     objs = [obj if n == "wn_gemm6" else os.path.join(CSRC, n + ".o")
             for n in ("wn_gemm", "wn_gemm6", "wn_elem", "wn_fused", "wn_decode", "wn_dlp", "wn_dlpm", "wn_dlpf", "wn_prof", "wn_api")]
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs)
@@ -58,7 +60,7 @@ for tag in tags:
     torch.cuda.synchronize()
     lib.lib.wn_debug_gemm6(None, b"")
     d = dbg.cpu().view(4, 32, 8)
-    print("== %s (engine flags %d)" % (tag, m.engine.flags))
+    print("== %s (engine flags %d) %s" % (tag, m.engine.flags, VARIANT and ("what-if build: " + VARIANT)))
     for w in range(4):
         rows = []
         for s in range(2, 22):
