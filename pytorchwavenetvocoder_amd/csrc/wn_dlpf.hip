@@ -35,7 +35,11 @@ static __device__ __forceinline__ long dlpf_queue_off(int l, int depth, int K, i
 }
 #define DLPF_SPIN_MAX (1 << 22)
 #ifndef WN_DLPF_TAP_PREFETCH
-#define WN_DLPF_TAP_PREFETCH 1   // the older taps of a stage are requested a stage early (0: with the stage's other inputs; A/B builds)
+// 1: the older taps of a stage are requested a stage early (behind the previous stage's publish and weight requests) instead of
+// with the stage's other inputs.  Measured SLOWER on MI355X (profiles/r05/decode_tap_ab.txt: kernel_size 2, 16 utterances 244 ->
+// 264 us per step; kernel_size 3: 275 -> 305): the flag poll of the next stage waits for every outstanding load of the wave
+// (vmcnt is in order), so the early requests sit in front of the poll instead of beside it.  Kept as an A/B switch, default off.
+#define WN_DLPF_TAP_PREFETCH 0
 #endif
 #ifdef WN_DLP_TIMING   // stamps of wn_dlp.hip / wn_dlpm.hip (tools/dlp_timing.py): unit 0 of block 0, step p0 + 3
 #define DLPF_STAMP(stage, ph)                                                                                        \

@@ -709,8 +709,12 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
     // row and a wave's load instruction 16 rows x 64 B, where one row per lane made every 16-byte load its own cache line (64
     // lines per instruction: the vector L1 serialises them, and with 512 rows x 128 B per step the 32 KB L1 lost each line
     // before its second half was used).
-    constexpr int AR = (TM == 4 && TN == 4) ? 4 : 1, AEr = AE / AR;
-    constexpr int BR = (TN == 3) ? 3 : ((TM == 4 && TN == 4) ? 4 : 1), BEr = BE / BR;
+#ifndef WN_DW_TALL_COALESCED
+#define WN_DW_TALL_COALESCED 0   // 1: the same mapping for the 256 x 128 tile (A/B builds; it spills a few registers there)
+#endif
+    constexpr bool COAL = (TM == 4 && TN == 4) || (WN_DW_TALL_COALESCED && TM == 4 && TN == 2);
+    constexpr int AR = COAL ? 4 : 1, AEr = AE / AR;
+    constexpr int BR = (TN == 3) ? 3 : (COAL ? TN : 1), BEr = BE / BR;
     constexpr int A_BYTES = NP * BM * 32, B_BYTES = NP * BN * 32, ST_BYTES = A_BYTES + B_BYTES;
     WN_DYN_SMEM(smem_raw);
     __shared__ long b_rowoff[BN];
