@@ -49,8 +49,13 @@ static __device__ __forceinline__ void gemm6_pack_elem(const float* src, long ld
     if (idx >= (long)nkb * Mpad) return;
     const int kb = (int)(idx / Mpad), m = (int)(idx % Mpad);
     const int ms = (gate_R > 0 && m < M) ? wn_gemm6_gate_row(m, gate_R) : m;   // source row of packed row m
+    // the row's 3 x 32 bytes are collected in registers and written as 16-byte stores: with one 4-byte store per pair a wave wrote
+    // 4 bytes into each of 64 rows per instruction (3.5 GB of traffic for 190 MB of weights at n_resch 512, profiles/r05)
+    unsigned hh[8], mm[8], ll[8];
+    WN_UNROLL
     for (int e = 0; e < 16; e += 2) {
         float x[2];
+        WN_UNROLL
         for (int u = 0; u < 2; ++u) {
             const int k = kb * 16 + e + u;
             x[u] = (m < M && k < K) ? src[(long)k * lda + ms] : 0.f;
@@ -58,11 +63,22 @@ static __device__ __forceinline__ void gemm6_pack_elem(const float* src, long ld
         const unsigned h = wn_pk_bf16(x[0], x[1]);
         const float r0 = x[0] - wn_bits_f32(h << 16), r1 = x[1] - wn_bits_f32(h & 0xffff0000u);
         const unsigned md = wn_pk_bf16(r0, r1);
-        const unsigned lo = wn_pk_bf16(r0 - wn_bits_f32(md << 16), r1 - wn_bits_f32(md & 0xffff0000u));
-        unsigned* d = reinterpret_cast<unsigned*>(Apk);
-        d[(((long)kb * 3 + 0) * Mpad + m) * 8 + e / 2] = h;
-        d[(((long)kb * 3 + 1) * Mpad + m) * 8 + e / 2] = md;
-        d[(((long)kb * 3 + 2) * Mpad + m) * 8 + e / 2] = lo;
+        hh[e / 2] = h;
+        mm[e / 2] = md;
+        ll[e / 2] = wn_pk_bf16(r0 - wn_bits_f32(md << 16), r1 - wn_bits_f32(md & 0xffff0000u));
+    }
+    unsigned* d = reinterpret_cast<unsigned*>(Apk);
+    const unsigned* src3[3] = {hh, mm, ll};
+    WN_UNROLL
+    for (int p = 0; p < 3; ++p) {
+        wn_f4* dst = reinterpret_cast<wn_f4*>(d + (((long)kb * 3 + p) * Mpad + m) * 8);   // 32-byte rows: 16-byte aligned
+        WN_UNROLL
+        for (int q = 0; q < 2; ++q) {
+            wn_f4 v;
+            v.x = wn_bits_f32(src3[p][4 * q]); v.y = wn_bits_f32(src3[p][4 * q + 1]);
+            v.z = wn_bits_f32(src3[p][4 * q + 2]); v.w = wn_bits_f32(src3[p][4 * q + 3]);
+            dst[q] = v;
+        }
     }
 }
 
@@ -704,17 +720,15 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
     constexpr int AE = BM / 16, BE = BN / 16;            // fp32 elements per thread and step
     // 192-column tiles (TN = 3: kernel_size 3 at 64 channels, N = 3 x 64) give a thread three B rows of 4 consecutive k each
     // (rows r, r + 64, r + 128) instead of one row of BE
-    // 256 x 256 tile (the wide models' square weight gradients; round 5): a thread takes 4 consecutive k of AR = 4 A rows (rows r,
-    // r + 64, ...) and of BR = 4 B rows instead of 16 consecutive k of ONE row -- 4 lanes then cover 64 contiguous bytes of a
-    // row and a wave's load instruction 16 rows x 64 B, where one row per lane made every 16-byte load its own cache line (64
-    // lines per instruction: the vector L1 serialises them, and with 512 rows x 128 B per step the 32 KB L1 lost each line
-    // before its second half was used).
-#ifndef WN_DW_TALL_COALESCED
-#define WN_DW_TALL_COALESCED 0   // 1: the same mapping for the 256 x 128 tile (A/B builds; it spills a few registers there)
-#endif
-    constexpr bool COAL = (TM == 4 && TN == 4) || (WN_DW_TALL_COALESCED && TM == 4 && TN == 2);
-    constexpr int AR = COAL ? 4 : 1, AEr = AE / AR;
-    constexpr int BR = (TN == 3) ? 3 : (COAL ? TN : 1), BEr = BE / BR;
+    // Round 5: a thread takes 4 consecutive k of TM A rows (rows r, r + 64, ...) and of TN B rows instead of AE (BE) consecutive k of
+    // ONE row: 4 lanes then cover 64 contiguous bytes of a row and a wave's load instruction 16 rows x 64 B -- with one row per lane
+    // (TM = 4) or two lanes per row (TM = 2) every 16-byte load was its own cache line (64 / 32 lines per instruction: the vector L1
+    // serialises them, and with 512 rows x 128 B per step the 32 KB L1 lost each line before its second half was used).  Same
+    // box: recipe size dw_dilated 20.0 -> 17.2 ms (256 x 256 tile), 26.9 -> 17.5 (256 x 128); headline 9.18 -> 9.00 ms per step with
+    // the 128-row tiles (profiles/r05/dw3_probe_*.txt, abk_headline_coalesced.txt).
+    constexpr int AR = TM, AEr = AE / AR;   // = 4
+    constexpr int BR = TN, BEr = BE / BR;   // = 4
+    static_assert(AEr == 4 && BEr == 4, "4 consecutive k per row and thread");
     constexpr int A_BYTES = NP * BM * 32, B_BYTES = NP * BN * 32, ST_BYTES = A_BYTES + B_BYTES;
     WN_DYN_SMEM(smem_raw);
     __shared__ long b_rowoff[BN];
