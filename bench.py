@@ -568,9 +568,8 @@ def main():
                        "timing": "median of %d regions of %d steps" % (len(regions), args.steps),
                        "arithmetic": "fp32 storage and accumulation; contractions on the bf16 matrix cores with a 3-way "
                                      "operand split (6 products, fp32-equivalent to round-off); " +
-                                     ("the weight-gradient contractions (leaf results: sums over every position that feed nothing "
-                                      "downstream) take 3 of the 6 products (WN_FLAG_DW_3PRODUCT; gate: worst gradient vs the oracle "
-                                      "at the timed sizes <= 3e-5 of the tensor's maximum, measured 6.3e-6 here); "
+                                     ("the weight-gradient contractions (leaf results) take 3 of the 6 products (WN_FLAG_DW_3PRODUCT, "
+                                      "opt-in: it misses the golden after-Adam gate); "
                                       if (model.engine.flags & _lib.FLAG_DW_3PRODUCT) else "") +
                                      "WN_FLAG_EXACT_MFMA selects the f32 MFMA everywhere"},
             "timesteps_per_sec": world * timesteps_per_s_gpu, "final_loss": final_loss,
@@ -583,7 +582,43 @@ def main():
         if not args.no_decode and world == 1:
             out["decode"] = decode_report(model, device, not args.no_cpu_baseline)
         if not args.no_extras and world == 1:
+            # the opt-in 3-product weight gradients on the SAME step (not the metric: the mode meets the gradient gates but not the
+            # golden after-Adam gate, engine.py / DESIGN.md 3.3), then the other workloads
+            dw3 = None
+            try:
+                base_flags = model.engine.flags
+                model.engine.flags = base_flags | _lib.FLAG_DW_3PRODUCT
+                for _ in range(3):
+                    step()
+                reg = []
+                for _ in range(3):
+                    barrier()
+                    t0 = time.perf_counter()
+                    for _ in range(args.steps):
+                        step()
+                    barrier()
+                    reg.append((time.perf_counter() - t0) / args.steps * 1e3)
+                model.engine.flags = base_flags
+                dw3 = {"ms_per_step": sorted(reg)[1], "samples_per_sec": B * (T - rf) / (sorted(reg)[1] * 1e-3),
+                       "engine_flags": int(base_flags | _lib.FLAG_DW_3PRODUCT),
+                       "note": "WN_FLAG_DW_3PRODUCT (opt-in): weight-gradient contractions (leaf results) with 3 of the 6 products; "
+                               "worst gradient vs the oracle at the timed sizes 6.3e-6 / 6.3e-6 / 1.5e-5 of the tensor's maximum (gate 3e-5, "
+                               "tests/test_gpu_fullsize.py), but the golden after-Adam gate (1e-2 lr) is missed by 2x on the small golden "
+                               "cases -- therefore NOT the default and not the metric"}
+            except Exception as e:  # noqa: BLE001
+                dw3 = {"error": repr(e)}
             out["extras"] = extra_workloads(model, opt, red)
+            out["extras"]["dw_3product"] = dw3
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import recipe_bench
+                os.environ["WN_ENGINE_FLAGS"] = str(int(model.engine.flags | _lib.FLAG_DW_3PRODUCT))
+                r3 = recipe_bench.measure(resch=512, kernel_size=2, upsampling=80, T=23040, batch=4, steps=3, with_kernels=False)
+                out["extras"]["recipe_size_dw_3product"] = {k: r3[k] for k in ("model", "B", "T", "ms_per_step", "samples_per_sec")}
+            except Exception as e:  # noqa: BLE001
+                out["extras"]["recipe_size_dw_3product"] = {"error": repr(e)}
+            finally:
+                os.environ.pop("WN_ENGINE_FLAGS", None)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

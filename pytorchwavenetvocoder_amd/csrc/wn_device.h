@@ -69,6 +69,8 @@ static inline void wn_buf_load_lds16(wn_rsrc_t r, char* lds_wave_base, int voff,
 }
 static inline void wn_buf_load_lds16_coherent(wn_rsrc_t r, char* lds_wave_base, int voff, unsigned soff) { wn_buf_load_lds16(r, lds_wave_base, voff, soff); }
 static inline void wn_store_coherent(float* p, float v) { *p = v; }
+static inline void wn_store_coherent_int(int* p, int v) { *p = v; }
+static inline int wn_load_coherent_int(const int* p) { return *p; }
 // global -> LDS, 4 bytes per lane: lane l of the wave writes at lds_wave_base + 4*l (inactive lanes write nothing)
 static inline void wn_buf_load_lds4(wn_rsrc_t r, char* lds_wave_base, int voff, unsigned soff) {
     const float v = wn_buf_load(r, voff, (int)soff);
@@ -208,6 +210,14 @@ static __device__ __forceinline__ void wn_buf_load_lds16_coherent(wn_rsrc_t r, c
 }
 static __device__ __forceinline__ void wn_store_coherent(float* p, float v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the error word of a persistent launch: written by workgroups that gave up, read by workgroups that start later -- possibly on
+// another XCD, whose L2 would not see a plain store before the kernel ends
+static __device__ __forceinline__ void wn_store_coherent_int(int* p, int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static __device__ __forceinline__ int wn_load_coherent_int(const int* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // the same with 4 bytes per lane: lane l writes at lds_wave_base + 4*l
 static __device__ __forceinline__ void wn_buf_load_lds4(wn_rsrc_t r, char* lds_wave_base, int voff, unsigned soff) {

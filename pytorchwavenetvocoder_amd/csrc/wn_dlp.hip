@@ -194,7 +194,7 @@ static __device__ __forceinline__ long dlp_queue_off(int l, int depth, int K, in
 template <int RS, int NSP, int NSX>
 __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
     WN_DYN_SMEM(smem_raw);
-    if (a.err[0] != 0) return;   // an earlier launch on this state timed out (or this one already has): nothing to continue from
+    if (wn_load_coherent_int(a.err) != 0) return;   // an earlier launch on this state timed out (or this one already has): nothing to continue from
     constexpr int CB = WN_DLP_CB, BM = WN_DLP_BMAX;
     constexpr int CG = RS / 2, KQ = 64 / RS, SL = 8 * KQ;             // channels per unit, k parts per wave, k slices per row
     constexpr int NPASS = ((3 * CG + RS / 2) * CB * 8 + WN_DLP_T - 1) / WN_DLP_T;   // passes of 512 lanes over the row sums (8 lanes each)
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
         DLP_STAMP(L + 2, 0);
         if (s_flag[0]) break;
     }
-    if (tid == 0 && s_flag[0]) a.err[0] = 1;
+    if (tid == 0 && s_flag[0]) wn_store_coherent_int(a.err, 1);
 }
 
 // LDS attribute (once) and the number of workgroups of this class the device keeps resident (cached; 0: the query failed)

@@ -54,7 +54,7 @@ static __device__ __forceinline__ long dlpf_queue_off(int l, int depth, int K, i
 template <int NSP, int NSX>
 __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlpf(WnDlpArgs a) {
     WN_DYN_SMEM(smem_raw);
-    if (a.err[0] != 0) return;   // an earlier launch on this state timed out (or this one already has): nothing to continue from
+    if (wn_load_coherent_int(a.err) != 0) return;   // an earlier launch on this state timed out (or this one already has): nothing to continue from
     constexpr int CG = 8, SL = 32, CB = WN_DLPM_CB;
     constexpr int KPAD = SL * NSP, XPAD = SL * NSX;
     // XCOPY: the x / skip row set has its own copy of the z part in ITS tile order (kernel_size 2 class: 148 KB of LDS).  The
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlpf(WnDlpArgs a) {
         DLPF_STAMP(L + 2, 0);
         if (s_flag[0]) break;
     }
-    if (tid == 0 && s_flag[0]) a.err[0] = 1;
+    if (tid == 0 && s_flag[0]) wn_store_coherent_int(a.err, 1);
 }
 
 template <int NSP, int NSX>

@@ -312,7 +312,7 @@ def test_backward_chain_kernel_modes():
     from pytorchwavenetvocoder_amd import _lib
     from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS, WaveNetEngine, load_state_into_flat
     A, NC = _lib.FLAG_AUX_FUSED, _lib.FLAG_NO_CHAIN
-    assert DEFAULT_FLAGS == A | _lib.FLAG_DW_3PRODUCT   # chain + aux partials (+ 3-product weight gradients) is what every default-flag test runs
+    assert DEFAULT_FLAGS == A      # chain + aux partials is what every default-flag test runs
     for flags in (0, A, NC, A | NC):
         PC.check_golden_case(GoldenCase("r64_k2_up"), emu_library(), "cpu", flags=flags)
     PC.run_oracle_vs_engine((64, 6, 64, 32, 3, 1, 1, 16), 2, 48, 41, emu_library(), "cpu", flags=A, scale=0.2)   # K = 1

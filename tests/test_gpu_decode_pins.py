@@ -196,3 +196,73 @@ def test_residency_is_asked_of_the_device_before_the_launch(monkeypatch):
         assert float((out["c"][1][b] - lp[b]).abs().max()) <= 1e-4
         safe = _safe(lp[b])
         assert bool((out["c"][0][b][safe] == tp[b][safe]).all())
+
+
+def _hog_helper():
+    import ctypes
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available to build the stand-in kernel")
+    out_dir = os.path.join(root, "tests", "emu", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "gpu_hog.so")
+    src = os.path.join(root, "tests", "gpu_helpers", "hog.hip")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-o", so, src])
+    lib = ctypes.CDLL(so)
+    lib.hog_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p]
+    return lib
+
+
+def test_a_launch_that_cannot_be_resident_times_out_and_the_decode_is_redone_by_layer_wise_launches():
+    """What the occupancy query cannot see: another kernel holds compute units when the persistent launch starts.  A stand-in
+    (tests/gpu_helpers/hog.hip: one workgroup per CU with 150 KB of LDS, on a side stream) keeps all but 32 CUs busy; the
+    16-utterance launch needs 64 workgroups at once, so half of them poll for flags nobody can publish until their bounded
+    polls run out: the error word is set, the workgroups that start afterwards return at once, ``WaveNetEngine.decode`` sees the
+    word after the chunk, warns and decodes again by layer-wise launches (which need no co-residency) -- same tokens as the
+    undisturbed persistent launch.  Everything is bounded: the stand-in stops on a word the test sets (or after 40 s)."""
+    import time
+    import warnings
+    hog = _hog_helper()
+    cfg, params, model = _model(RECIPE_K2)
+    eng = model.engine
+    rs = np.random.RandomState(9)
+    B = 16
+    x = torch.from_numpy(rs.randint(0, 256, (B, 4))).long().to(DEV)
+    h = torch.from_numpy(rs.standard_normal((B, 80, 2)).astype(np.float32)).to(DEV)
+    ns = [5] * B
+    ok, wg, cap = eng.decode_residency(B)
+    assert ok and wg == 64
+    ref_t, ref_l = eng.decode(x, h, ns, return_logits=True)          # the undisturbed persistent launch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    stop = torch.zeros(1, dtype=torch.int32, device=DEV)
+    started = torch.zeros(1, dtype=torch.int64, device=DEV)
+    side = torch.cuda.Stream(device=DEV)
+    torch.cuda.synchronize()
+    n_hog = cus - 32
+    rc = hog.hog_launch(n_hog, 150 * 1024, stop.data_ptr(), 40 * 100000000, started.data_ptr(), side.cuda_stream)
+    assert rc == 0
+    t0 = time.time()
+    while int(started.item()) < n_hog and time.time() - t0 < 5.0:   # (the copy engine reads the counter: no CU needed)
+        time.sleep(0.01)
+    assert int(started.item()) == n_hog, "the stand-in did not get its %d compute units" % n_hog
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            t0 = time.time()
+            toks, lg = eng.decode(x, h, ns, return_logits=True)
+            dt = time.time() - t0
+    finally:
+        stop.fill_(1)
+        torch.cuda.synchronize()
+    assert any("layer-wise launches" in str(m.message) for m in w), [str(m.message) for m in w]
+    for b in range(B):
+        assert float((lg[b] - ref_l[b]).abs().max()) <= 1e-4
+        safe = _safe(ref_l[b])
+        assert bool((toks[b][safe] == ref_t[b][safe]).all())
+    print("TIME-OUT PATH: %d of %d CUs held by another kernel; the 64-workgroup launch gave up and the decode was redone by "
+          "layer-wise launches in %.1f s, tokens equal" % (n_hog, cus, dt))

@@ -26,7 +26,7 @@ def _lib():
     return lib
 
 
-TOL_GRAD_3PRODUCT = 3e-5   # gate of the 3-product weight gradients (WN_FLAG_DW_3PRODUCT, the engine's default): tighter than the 1e-4 of every mode
+TOL_GRAD_3PRODUCT = 3e-5   # gate of the opt-in 3-product weight gradients (WN_FLAG_DW_3PRODUCT): tighter than the 1e-4 of every mode
 
 
 def _three_product_gate(what, res, flags):
