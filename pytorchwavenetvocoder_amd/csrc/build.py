@@ -13,7 +13,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["wn_gemm.hip", "wn_gemm6.hip", "wn_elem.hip", "wn_fused.hip", "wn_decode.hip", "wn_dlp.hip", "wn_dlpm.hip", "wn_dlpf.hip", "wn_prof.hip", "wn_api.hip"]
-HEADERS = ["wn_device.h", "wn_gemm.h", "wn_gemm6.h", "wn_elem.h", "wn_fused.h", "wn_decode.h", "wn_dlp.h", "wn_prof.h", "../../include/wavenet_hip.h", "../../include/wavenet_hip_gemm.h"]
+HEADERS = ["wn_api_backward.inl", "wn_api_ops.inl", "wn_api_decode.inl", "wn_device.h", "wn_gemm.h", "wn_gemm6.h", "wn_elem.h", "wn_fused.h", "wn_decode.h", "wn_dlp.h", "wn_prof.h", "../../include/wavenet_hip.h", "../../include/wavenet_hip_gemm.h"]
 LIB = os.path.join(HERE, "libwavenet_hip.so")
 STAMP = os.path.join(HERE, ".libwavenet_hip.stamp")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

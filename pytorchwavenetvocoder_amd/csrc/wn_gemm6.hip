@@ -322,7 +322,9 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
                 for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(af[PA[t]], bf[PB[t]][j], acc[i][j]);
                 if (last) continue;   // the final step has nothing to prepare
                 const int sl = i * 6 + t;
+#ifndef WN_G6_PAIR_INTERLEAVE
                 WN_SCHED_FENCE_ALU();
+#endif
                 if (sl < 6) {
                     const int p = sl >> 1;
                     const unsigned src = (unsigned)((kc * 3 + p) * g.Mpad + m0) * 32u + ((sl & 1) ? 4096u : 0u);
@@ -346,6 +348,11 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
                 } else if (sl == 22) {
                     write_pieces(stn, h, md, lo);
                 }
+#ifdef WN_G6_PAIR_INTERLEAVE   // (A/B builds: the pair of MFMAs and its piece as MFMA, <= 6 VALU, MFMA, the rest)
+                WN_SGB_MFMA(1);
+                WN_SGB_VALU(6);
+                WN_SGB_MFMA(1);
+#endif
                 WN_SCHED_FENCE_ALU();
             }
         }

@@ -27,7 +27,7 @@ if _EXTRA:
 
 def _digest():
     h = hashlib.sha256()
-    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h", ".inl"))]
     files += [os.path.join(HERE, "hip_emu.h"), os.path.join(ROOT, "include", "wavenet_hip.h"),
               os.path.join(ROOT, "include", "wavenet_hip_gemm.h"), __file__]
     for f in files:
