@@ -322,7 +322,7 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
                 for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(af[PA[t]], bf[PB[t]][j], acc[i][j]);
                 if (last) continue;   // the final step has nothing to prepare
                 const int sl = i * 6 + t;
-#ifndef WN_G6_PAIR_INTERLEAVE
+#ifdef WN_G6_NO_PAIR_INTERLEAVE   // (round 4's order: the pair of MFMAs, then its piece)
                 WN_SCHED_FENCE_ALU();
 #endif
                 if (sl < 6) {
@@ -348,7 +348,8 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
                 } else if (sl == 22) {
                     write_pieces(stn, h, md, lo);
                 }
-#ifdef WN_G6_PAIR_INTERLEAVE   // (A/B builds: the pair of MFMAs and its piece as MFMA, <= 6 VALU, MFMA, the rest)
+#ifndef WN_G6_NO_PAIR_INTERLEAVE   // the pair of MFMAs and its piece as MFMA, <= 6 VALU, MFMA, the rest (round 5: -1 % on the long
+                                   // contractions of the recipe-size model, profiles/r05/ab_gemm6_pair_interleave.txt)
                 WN_SGB_MFMA(1);
                 WN_SGB_VALU(6);
                 WN_SGB_MFMA(1);

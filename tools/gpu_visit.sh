@@ -6,7 +6,8 @@
 #   gap (tools/grad_gap_probe.py on the configs[3] reduced case), pmc3 (counter passes of the configs[3] geometry), seltests
 #   (pytest -m gpu -k "$WN_TEST_K")
 #   round 5 added: pins (tests/test_gpu_decode_pins.py + ops + co-residency, verbose), soak (tools/microbench/handoff_soak.hip),
-#   pmcrecipe (counter passes of the recipe-size training step), k3probe (recipe-size decode speed, kernel_size 3 and 2)
+#   pmcrecipe (counter passes of the recipe-size training step), k3probe (recipe-size decode speed, kernel_size 3 and 2),
+#   dw3 (weight-gradient variants, same-box A/B), rocprofextra (rocprofv3 kernel stats of the recipe-size / configs[3] workloads)
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 cd "$ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
 OUT="$ROOT/gpurun_out"
@@ -68,6 +69,17 @@ if has rocprof; then
   python tools/kernel_gaps.py $OUT/prof_stats > $OUT/kernel_gaps.txt 2>&1; cat $OUT/kernel_gaps.txt
   find $OUT/prof_stats -name "*kernel_trace.csv" -delete
   head -12 $OUT/rocprofv3_kernel_stats.csv
+fi
+if has rocprofextra; then
+  # rocprofv3 kernel stats of the two other training workloads (recipe-size model, configs[3] geometry)
+  for w in recipe_size config4; do
+    rm -rf $OUT/prof_$w
+    if [ $w = recipe_size ]; then A="--resch 512 --batch 4 --steps 2"; else A="--resch 64 --kernel-size 3 --upsampling 256 --T 26112 --batch 8 --steps 3"; fi
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$w -- python $ROOT/tools/recipe_bench.py $A > $OUT/${w}_under_rocprofv3.json 2> $OUT/rocprof_$w.err); echo "rocprof $w rc=$?"
+    find $OUT/prof_$w -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${w}_rocprofv3_kernel_stats.csv
+    find $OUT/prof_$w -name "*kernel_trace.csv" -delete
+    head -8 $OUT/${w}_rocprofv3_kernel_stats.csv
+  done
 fi
 if has recipesize; then
   # BASELINE configs[3] geometry (kernel_size 3, upsampling 256, T = 26112), softmax head
