@@ -167,8 +167,9 @@ def decode_report(model, device, with_cpu):
     out["stream_note"] = "one CU sustains ~112 GB/s on a 5 MB cyclic read (tools/stream_probe.hip, profiles/r01/stream_probe.txt)"
     # the recipes' own model size (n_resch 512 / n_skipch 256, egs/arctic/sd/run.sh:46-52; decode.py:274-327): the any-size path --
     # ONE persistent launch per chunk of steps: 128 workgroups with fp32 VALU dot products for one utterance (csrc/wn_dlp.hip), 64
-    # workgroups per block of 16 utterances with 16x16x4 matrix-core tiles from 2 to 48 (csrc/wn_dlpf.hip: plain vectors + one
-    # flag per workgroup and stage, inputs by global -> LDS transfers); layer-wise launches above
+    # workgroups per block of 16 utterances with 16x16x4 matrix-core tiles from 2 to 64 (csrc/wn_dlpf.hip: plain vectors + one
+    # flag per workgroup and stage, inputs by global -> LDS transfers; 64 = 256 workgroups, resident all at once: asked of the
+    # device first); two groups up to 128, layer-wise launches above
     try:
         from pytorchwavenetvocoder_amd.nets import WaveNet, initialize
         torch.manual_seed(1)
@@ -182,7 +183,8 @@ def decode_report(model, device, with_cpu):
             key = "batch%d" % B if lay is True else "batch%d_by_launches" % B
             rs[key] = {k: m[k] for k in ("us_per_step", "samples_per_sec_per_utt", "samples_per_sec", "context_s")}
             rs[key]["path"] = (("one persistent launch (wn_dlp)" if B <= 1 else
-                                "one persistent launch (wn_dlpf)" if B <= 48 else "persistent launches (wn_dlpf), groups of 48 utterances")
+                                "one persistent launch (wn_dlpf: %d column blocks)" % ((B + 15) // 16) if B <= 64 else
+                                "persistent launches (wn_dlpf), groups of 64 utterances")
                                if lay is True else "layer-wise launches")
         out["recipe_size"] = rs
         del big
