@@ -309,11 +309,11 @@ int wn_decode_steps(const WnConfig* cfg, int B, const float* params, const float
  * same state with params == NULL keeps the packed weights and only projects the given window of h (a decode
  * without an upsampling layer projects one window of aux columns per chunk of steps). */
 int64_t wn_decode_layered_state_floats(const WnConfig* cfg, int B, int mode);
-/* Since ABI v7: for models the plan of csrc/wn_dlp.h covers (n_resch % 32 == 0, kernel_size 2 or 3, B <= 48, softmax head)
+/* Since ABI v7: for models the plan of csrc/wn_dlp.h covers (n_resch % 32 == 0, kernel_size 2 or 3, B <= 64 (48 with the granule hand-off), softmax head)
  * wn_decode_layered_steps runs the whole range of steps as ONE launch of workgroups that hand their vectors to each other as
  * 8-byte {value, tag} granules or as plain vectors + one flag per workgroup and stage (the recipes' n_resch = 512 model: 66
  * dependent launches per step before): n_resch / 4 workgroups with fp32 VALU dot products for one utterance (wn_dlp.hip),
- * n_resch / 8 workgroups per block of 16 utterances with v_mfma_f32_16x16x4_f32 tiles up to 48 (wn_dlpf.hip / wn_dlpm.hip).
+ * n_resch / 8 workgroups per block of 16 utterances with v_mfma_f32_16x16x4_f32 tiles up to 64 (wn_dlpf.hip; wn_dlpm.hip: 48).
  * Every workgroup of such a launch waits for the others, so ALL of them must be resident at once: the library asks the device
  * (occupancy of the chosen kernel x compute units, since ABI v8) when it chooses the path, and a grid that does not fit -- a
  * partitioned GPU, a part with fewer CUs -- decodes by layer-wise launches; wn_decode_layered_residency() reports the numbers.

@@ -413,7 +413,7 @@ class WaveNetEngine(object):
         Two kernels implement it: the persistent one-workgroup-per-utterance kernel (model sizes covered by
         ``decode_supported()``) and the any-size path (``layered=True``; chosen automatically when the first does not
         apply, e.g. the n_resch = 512 recipe default).  The any-size path is itself ONE persistent launch per chunk of
-        steps where csrc/wn_dlp.hip / wn_dlpm.hip / wn_dlpf.hip cover the model and the batch (up to 48 utterances: workgroups
+        steps where csrc/wn_dlp.hip / wn_dlpm.hip / wn_dlpf.hip cover the model and the batch (up to 64 utterances: workgroups
         handing their vectors to each other) and layer-wise launches otherwise; ``layered="launches"`` forces the launches (independent check, A/B).
 
         ``prefill``: how the dilation queues of the context are built.  "parallel" (default) does what the

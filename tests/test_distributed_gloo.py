@@ -51,6 +51,10 @@ def _worker(rank, world, port, out_path, btot):
                                          grad_scale=(hi - lo) / float(btot))
             opt.step()
             losses.append(float(loss))
+        rep = red.comm_report()   # what bench.py's `comm` block prints for N > 1 (the exposed-exchange events are CUDA-only)
+        assert rep["world"] == world and rep["backend"] == "gloo" and rep["buckets"] == len(red.ranges)
+        assert rep["bucket_bytes"] == [4 * (b - a) for a, b in red.ranges] and sum(rep["bucket_bytes"]) == 4 * model.engine.n_params
+        assert rep["exchange"].startswith("one in-place all-reduce per bucket") and "exposed_ms_per_step" not in rep
         if rank == 0:
             torch.save({"params": model.engine.flat_params.clone(), "losses": losses}, out_path)
     finally:
