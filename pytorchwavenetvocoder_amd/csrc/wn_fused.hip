@@ -708,67 +708,35 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_s(FwdArgs a) {
         f32x16 acc[4];
         WN_UNROLL
         for (int q = 0; q < 4; ++q) acc[q] = f32x16_zero();
-        // dilated taps with history (shift > 0).  Round 5 (-DWN_FWD_NO_SPLIT_PIPELINE restores round 4's order): the operand split
-        // of 16-k block n + 1 (~45 VALU instructions) is issued BETWEEN the 12 MFMAs of block n -- one MFMA, <= 4 VALU, one MFMA, ...
-        // -- instead of as one block in front of its own MFMAs, where nothing of this wave covered it (a wave's own VALU is free
-        // only under its MFMAs, <= 6 per MFMA: tools/microbench/mfma_valu.hip).
-        constexpr int PAh[6] = {0, 2, 1, 0, 1, 0}, PBh[6] = {2, 0, 1, 1, 0, 0};  // small terms first
-        constexpr int NH = (K - 1) * 4;   // 16-k blocks of the history taps
-        auto hist_x8 = [&](int blk, float (&x8)[8]) {
-            const int tap = blk >> 2, kb = blk & 3;
-            WN_UNROLL
-            for (int e = 0; e < 8; ++e) x8[e] = okh[tap] ? xh[tap][8 * kb + e] : 0.0f;
-        };
-        auto tap_mfmas = [&](const char* Wl, const wn_f4 (&bf)[3]) {
-            WN_UNROLL
-            for (int qh = 0; qh < 4; qh += 2) {  // two row tiles at a time (register budget)
-                wn_f4 af[2][3];
-                WN_UNROLL
-                for (int q = 0; q < 2; ++q) {
-                    WN_UNROLL
-                    for (int p = 0; p < 3; ++p)
-                        af[q][p] = *reinterpret_cast<const wn_f4*>(Wl + p * (128 * 32) + (qh + q) * 1024);
-                }
-                WN_UNROLL
-                for (int t6 = 0; t6 < 6; ++t6) {
-                    acc[qh] = mfma_bf16(af[0][PAh[t6]], bf[PBh[t6]], acc[qh]);
-                    acc[qh + 1] = mfma_bf16(af[1][PAh[t6]], bf[PBh[t6]], acc[qh + 1]);
-                }
-            }
-        };
-#ifdef WN_FWD_NO_SPLIT_PIPELINE
+        // dilated taps with history (shift > 0)
         WN_UNROLL
-        for (int blk = 0; blk < NH; ++blk) {
-            float x8[8];
-            hist_x8(blk, x8);
-            wn_f4 bf[3];
-            split8(x8, bf);
-            tap_mfmas(Wd + blk * WD_BLK + wn_frag_off(li, hi), bf);
-        }
-#else
-        wn_f4 bfx[2][3];
-        if (NH > 0) {
-            float x8[8];
-            hist_x8(0, x8);
-            split8(x8, bfx[0]);
-        }
-        WN_UNROLL
-        for (int blk = 0; blk < NH; ++blk) {
-            WN_SCHED_FENCE_ALU();
-            if (blk + 1 < NH) {
+        for (int tap = 0; tap + 1 < K; ++tap) {
+            WN_UNROLL
+            for (int kb = 0; kb < 4; ++kb) {
                 float x8[8];
-                hist_x8(blk + 1, x8);
-                split8(x8, bfx[(blk + 1) & 1]);
-            }
-            tap_mfmas(Wd + blk * WD_BLK + wn_frag_off(li, hi), bfx[blk & 1]);
-            WN_UNROLL
-            for (int m = 0; m < 12; ++m) {
-                WN_SGB_MFMA(1);
-                WN_SGB_VALU(4);
+                WN_UNROLL
+                for (int e = 0; e < 8; ++e) x8[e] = okh[tap] ? xh[tap][8 * kb + e] : 0.0f;
+                wn_f4 bf[3];
+                split8(x8, bf);
+                const char* Wl = Wd + (tap * 4 + kb) * WD_BLK + wn_frag_off(li, hi);
+                constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};  // small terms first
+                WN_UNROLL
+                for (int qh = 0; qh < 4; qh += 2) {  // two row tiles at a time (register budget)
+                    wn_f4 af[2][3];
+                    WN_UNROLL
+                    for (int q = 0; q < 2; ++q) {
+                        WN_UNROLL
+                        for (int p = 0; p < 3; ++p)
+                            af[q][p] = *reinterpret_cast<const wn_f4*>(Wl + p * (128 * 32) + (qh + q) * 1024);
+                    }
+                    WN_UNROLL
+                    for (int t6 = 0; t6 < 6; ++t6) {
+                        acc[qh] = mfma_bf16(af[0][PA[t6]], bf[PB[t6]], acc[qh]);
+                        acc[qh + 1] = mfma_bf16(af[1][PA[t6]], bf[PB[t6]], acc[qh + 1]);
+                    }
+                }
             }
         }
-        WN_SCHED_FENCE_ALU();
-#endif
         WN_STAMP(1);  // after history-tap MFMAs
         // aux / gate inputs (frame rate, L2 resident), first 32 gate channels
         const int fr = tc / a.U;
@@ -786,43 +754,31 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_s(FwdArgs a) {
         WN_SCHED_BARRIER();
         // current tap; xc is also the residual input, already in D layout
         {
-            auto cur_x8 = [&](int kb, float (&x8)[8]) {
+            WN_UNROLL
+            for (int kb = 0; kb < 4; ++kb) {
+                float x8[8];
                 WN_UNROLL
                 for (int e = 0; e < 8; ++e) x8[e] = inb ? xc[8 * kb + e] : 0.0f;
-            };
-#ifdef WN_FWD_NO_SPLIT_PIPELINE
-            WN_UNROLL
-            for (int kb = 0; kb < 4; ++kb) {
-                float x8[8];
-                cur_x8(kb, x8);
                 wn_f4 bf[3];
                 split8(x8, bf);
-                tap_mfmas(Wd + ((K - 1) * 4 + kb) * WD_BLK + wn_frag_off(li, hi), bf);
-            }
-#else
-            wn_f4 bfc[2][3];
-            {
-                float x8[8];
-                cur_x8(0, x8);
-                split8(x8, bfc[0]);
-            }
-            WN_UNROLL
-            for (int kb = 0; kb < 4; ++kb) {
-                WN_SCHED_FENCE_ALU();
-                if (kb + 1 < 4) {
-                    float x8[8];
-                    cur_x8(kb + 1, x8);
-                    split8(x8, bfc[(kb + 1) & 1]);
-                }
-                tap_mfmas(Wd + ((K - 1) * 4 + kb) * WD_BLK + wn_frag_off(li, hi), bfc[kb & 1]);
+                const char* Wl = Wd + ((K - 1) * 4 + kb) * WD_BLK + wn_frag_off(li, hi);
+                constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
                 WN_UNROLL
-                for (int m = 0; m < 12; ++m) {
-                    WN_SGB_MFMA(1);
-                    WN_SGB_VALU(4);
+                for (int qh = 0; qh < 4; qh += 2) {  // two row tiles at a time (register budget)
+                    wn_f4 af[2][3];
+                    WN_UNROLL
+                    for (int q = 0; q < 2; ++q) {
+                        WN_UNROLL
+                        for (int p = 0; p < 3; ++p)
+                            af[q][p] = *reinterpret_cast<const wn_f4*>(Wl + p * (128 * 32) + (qh + q) * 1024);
+                    }
+                    WN_UNROLL
+                    for (int t6 = 0; t6 < 6; ++t6) {
+                        acc[qh] = mfma_bf16(af[0][PA[t6]], bf[PB[t6]], acc[qh]);
+                        acc[qh + 1] = mfma_bf16(af[1][PA[t6]], bf[PB[t6]], acc[qh + 1]);
+                    }
                 }
             }
-            WN_SCHED_FENCE_ALU();
-#endif
         }
         WN_SCHED_BARRIER();
         WN_PRIO(WN_PRIO_GATE);
