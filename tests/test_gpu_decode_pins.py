@@ -239,6 +239,8 @@ def test_a_launch_that_cannot_be_resident_times_out_and_the_decode_is_redone_by_
     assert ok and wg == 64
     ref_t, ref_l = eng.decode(x, h, ns, return_logits=True)          # the undisturbed persistent launch
     cus = torch.cuda.get_device_properties(0).multi_processor_count
+    if cus < 128 or cap < 64:
+        pytest.skip("needs a device that keeps the 64-workgroup launch resident with CUs to spare")
     stop = torch.zeros(1, dtype=torch.int32, device=DEV)
     started = torch.zeros(1, dtype=torch.int64, device=DEV)
     side = torch.cuda.Stream(device=DEV)
