@@ -22,11 +22,15 @@ def build():
     os.makedirs(EXP, exist_ok=True)
     csrc = os.path.join(ROOT, "pytorchwavenetvocoder_amd", "csrc")
     objs = []
-    for name in ("wn_gemm", "wn_gemm6", "wn_elem", "wn_fused", "wn_decode", "wn_prof", "wn_api"):
+    procs = []
+    for name in ("wn_gemm", "wn_gemm6", "wn_elem", "wn_fused", "wn_decode", "wn_dlp", "wn_dlpm", "wn_dlpf", "wn_prof", "wn_api"):
         obj = os.path.join(EXP, name + ".timing.o")
-        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DWN_TIMING", "-c",
-                               os.path.join(csrc, name + ".hip"), "-o", obj])
+        procs.append(subprocess.Popen(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-DWN_TIMING", "-c",
+                                       os.path.join(csrc, name + ".hip"), "-o", obj]))
         objs.append(obj)
+    for pr in procs:
+        if pr.wait() != 0:
+            raise SystemExit("hipcc failed")
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs)
 
 
@@ -41,9 +45,13 @@ import torch  # noqa: E402
 from pytorchwavenetvocoder_amd.nets import WaveNet, initialize
 dev = "cuda:0"
 torch.manual_seed(1)
-m = WaveNet(256, 80, 64, 256, 10, 3, 2, 80); m.apply(initialize); m.to(dev)
-B, T = 8, 23040
-x = torch.randint(0, 256, (B, T), device=dev); h = torch.randn(B, 80, T // 80, device=dev)
+# python tools/phase_timing.py [kernel_size upsampling T]   (default 2 80 23040; configs[3]: 3 256 26112)
+_a = [int(v) for v in sys.argv[1:] if v.isdigit()]
+KS, UP, T = (_a + [2, 80, 23040])[:3] if len(_a) >= 3 else (2, 80, 23040)
+m = WaveNet(256, 80, 64, 256, 10, 3, KS, UP); m.apply(initialize); m.to(dev)
+B = 8
+print("kernel_size %d, upsampling %d, B = %d, T = %d" % (KS, UP, B, T))
+x = torch.randint(0, 256, (B, T), device=dev); h = torch.randn(B, 80, T // UP, device=dev)
 dbg = torch.zeros(8 * 4 * 16 + 256 * 4, dtype=torch.int64, device=dev)
 lib = m.engine.lib
 lib.lib.wn_debug_set_buffer.argtypes = [ctypes.c_void_p]
