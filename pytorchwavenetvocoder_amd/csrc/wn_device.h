@@ -366,21 +366,6 @@ static __device__ __forceinline__ float wn_tanh(float x) {
     return copysignf(t, x);
 }
 
-// The gate of a residual block (wavenet.py:529-532), s = sigmoid(pa) and z = s * tanh(pg), with THREE transcendentals (two exp2,
-// one rcp) instead of four: with E1 = e^-pa, E2 = e^-2|pg|:  R = 1 / ((1 + E1)(1 + E2)),  s = (1 + E2) R,  z = sign(pg) (1 - E2) R.
-// Transcendentals issue at a quarter of the VALU rate and the gate is the longest phase of the fused forward block (9 - 11 K of a
-// tile's 24 - 28 K cycles, profiles/r05/fwd_phase_timing_k2.txt).  E1 <= e^80, E2 <= 1: the product stays finite.
-static __device__ __forceinline__ void wn_gate(float pa, float pg, float& s, float& z) {
-    const float ac = fminf(fmaxf(pa, -80.0f), 80.0f);
-    const float e1 = wn_exp2(-1.4426950408889634f * ac);
-    const float ag = fminf(fabsf(pg), 40.0f);
-    const float e2 = wn_exp2(-2.8853900817779268f * ag);
-    const float p2 = 1.0f + e2;
-    const float r = wn_rcp((1.0f + e1) * p2);
-    s = p2 * r;
-    z = copysignf((1.0f - e2) * r, pg);
-}
-
 static __device__ __forceinline__ float wave_reduce_sum(float v) {
     WN_UNROLL
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);

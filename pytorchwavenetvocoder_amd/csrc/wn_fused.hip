@@ -379,14 +379,9 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd(FwdArgs a) {
                     ga[r] = wn_buf_load(Gr, vg, (32 + mfma32_row(r, 0)) * F4);
                     gg[r] = wn_buf_load(Gr, vg, (96 + mfma32_row(r, 0)) * F4);
                 }
-                float s, g = 0.0f, zz;
-                if (KEEP_G) {
-                    s = wn_sigmoid(pa);
-                    g = wn_tanh(pg);
-                    zz = s * g;
-                } else {
-                    wn_gate(pa, pg, s, zz);   // three transcendentals instead of four (the tanh half itself is not saved)
-                }
+                const float s = wn_sigmoid(pa);
+                const float g = wn_tanh(pg);
+                const float zz = s * g;
                 z[q][r] = zz;
                 // unconditional stores: lanes past T carry an out-of-range offset (dropped by the buffer range check), and
                 // the tanh half goes through the same instruction stream only when it is kept -- a lane- or kernel-
@@ -835,14 +830,9 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_s(FwdArgs a) {
                     ga[r] = wn_buf_load(Gr, vg, (32 + mfma32_row(r, 0)) * F4);
                     gg[r] = wn_buf_load(Gr, vg, (96 + mfma32_row(r, 0)) * F4);
                 }
-                float s, g = 0.0f, zz;
-                if (KEEP_G) {
-                    s = wn_sigmoid(pa);
-                    g = wn_tanh(pg);
-                    zz = s * g;
-                } else {
-                    wn_gate(pa, pg, s, zz);   // three transcendentals instead of four (the tanh half itself is not saved)
-                }
+                const float s = wn_sigmoid(pa);
+                const float g = wn_tanh(pg);
+                const float zz = s * g;
                 z[q][r] = zz;
                 // unconditional stores: lanes past T carry an out-of-range offset (dropped by the buffer range check), and
                 // the tanh half goes through the same instruction stream only when it is kept -- a lane- or kernel-
