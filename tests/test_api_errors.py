@@ -102,6 +102,29 @@ def test_decode_argument_checks():
         m.engine.decode(x, h, [4, 4], mode="mol")           # softmax model
 
 
+def test_decode_residency_query_and_mode_bits_through_the_c_abi(monkeypatch):
+    """ABI v8: wn_decode_layered_residency reports the grid of the persistent launch and what the device keeps resident, bad
+    arguments return < 0, and the layout of the decode state depends on the per-call mode bits (not on process-wide state)."""
+    lib = emu_library()
+    m = WaveNet(_library=lib, n_quantize=256, n_aux=80, n_resch=512, n_skipch=256, dilation_depth=10, dilation_repeat=3,
+                kernel_size=2, upsampling_factor=80)
+    cfg = ctypes.byref(m.engine.cfg)
+    wg, cap = ctypes.c_int(-1), ctypes.c_int(-1)
+    assert lib.wn_decode_layered_residency(None, 2, 0, ctypes.byref(wg), ctypes.byref(cap)) < 0
+    assert lib.wn_decode_layered_residency(cfg, 0, 0, ctypes.byref(wg), ctypes.byref(cap)) < 0
+    assert lib.wn_decode_layered_residency(cfg, 2, 0, None, None) == 1                       # NULL outputs are allowed
+    assert lib.wn_decode_layered_residency(cfg, 2, 0, ctypes.byref(wg), ctypes.byref(cap)) == 1 and wg.value == 64
+    assert lib.wn_decode_layered_residency(cfg, 2, _lib.DECODE_GRANULES, ctypes.byref(wg), ctypes.byref(cap)) == 1 and wg.value == 128
+    # flags / granules / launches: three different state layouts for the same model and batch
+    n_flags = lib.wn_decode_layered_state_floats(cfg, 17, 0)
+    n_gran = lib.wn_decode_layered_state_floats(cfg, 17, _lib.DECODE_GRANULES)
+    assert n_gran > n_flags > 0                                                              # (private queue copies per unit)
+    assert lib.wn_decode_layered_error_offset(cfg, 17, 0) != lib.wn_decode_layered_error_offset(cfg, 17, _lib.DECODE_GRANULES)
+    monkeypatch.setenv("WN_COOP_CAPACITY", "10")                                             # a device that keeps 10 workgroups
+    assert lib.wn_decode_layered_residency(cfg, 2, 0, ctypes.byref(wg), ctypes.byref(cap)) == 0 and (wg.value, cap.value) == (64, 10)
+    assert lib.wn_decode_layered_error_offset(cfg, 2, 0) < 0 and 0 < lib.wn_decode_layered_state_floats(cfg, 17, 0) < n_flags
+
+
 def test_missing_library_fails_loudly():
     """No HIP library -> import of the product path raises; nothing silently takes over."""
     code = ("import os; os.environ['WN_LIB_PATH'] = '/nonexistent/libwavenet_hip.so'\n"
