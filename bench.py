@@ -51,6 +51,7 @@ HBM_PEAK = 8.0e12          # B/s  (MI355X_MICROARCH.md)
 F32_MFMA_PEAK = 157.3e12   # FLOP/s dense f32 matrix = f32 vector peak
 BF16_MFMA_PEAK = 2.5e15     # FLOP/s dense bf16 matrix (MI355X_MICROARCH.md); the 3-way split spends 6 bf16
 SPLIT_PRODUCTS = 6.0        # MFMAs per fp32-equivalent product -> 417 TFLOP/s of fp32-equivalent work
+DW_PRODUCTS = 3.0           # ... of the weight-gradient contractions (a third of the step's FLOPs) with WN_FLAG_DW_F16PAIR / _3PRODUCT
 LAYERS_PER_BUCKET = 30      # gradient buckets = weight-gradient launch groups; N = 1 runs the SAME launch structure as N > 1.
 # 30 (= all layers of this model, GradientReducer's default) = [post-net + skip] [all residual layers] [front + upsampling]: measured 11.64 vs 11.80 ms/step for groups of 10
 # layers on the same box (profiles/r02/ab_probe.txt); 40 % of the gradient bytes (the first bucket) are exchanged under
@@ -455,6 +456,8 @@ def main():
     if rank == 0:
         pmc = load_pmc_traffic(model.engine.flags)
         alg_step = B * T * ALG_BYTES_PER_TIMESTEP
+        dw_half = bool(model.engine.flags & (_lib.FLAG_DW_F16PAIR | _lib.FLAG_DW_3PRODUCT))
+        step_products = (2.0 * SPLIT_PRODUCTS + (DW_PRODUCTS if dw_half else SPLIT_PRODUCTS)) / 3.0
         step_traffic = pmc.get("_step_total_bytes") if pmc else None
         roofline = {
             "bound": "hbm", "achieved": timesteps_per_s_gpu * ALG_BYTES_PER_TIMESTEP / 1e9, "peak": HBM_PEAK / 1e9,
@@ -475,12 +478,15 @@ def main():
             # the OTHER roof of this arithmetic: 9.27 MFLOP per timestep of fp32-equivalent work on the bf16 matrix cores with six
             # products per multiply (2.5 PFLOP/s / 6 = 417 TFLOP/s) -- with the split in place the step cannot beat matrix_roof_ms,
             # i.e. `frac` cannot exceed hbm-roof time / matrix_roof_ms whatever the kernels do
-            "matrix_roof_ms": B * T * ALG_FLOP_PER_TIMESTEP / (BF16_MFMA_PEAK / SPLIT_PRODUCTS) * 1e3,
-            "matrix_roof_frac": (B * T * ALG_FLOP_PER_TIMESTEP / (BF16_MFMA_PEAK / SPLIT_PRODUCTS) * 1e3) / ms_per_step,
-            "frac_ceiling_under_split": (alg_step / HBM_PEAK) / (B * T * ALG_FLOP_PER_TIMESTEP / (BF16_MFMA_PEAK / SPLIT_PRODUCTS)),
-            "matrix_roof_note": "fp32-equivalent FLOPs of the step (SURVEY 8d: 9.27 MFLOP per timestep) at 2.5 PFLOP/s dense bf16 / 6 "
-                                "products of the 3-way operand split = 417 TFLOP/s: the binding roof of this arithmetic is the "
-                                "matrix pipe, not HBM; matrix_roof_frac = that time / the measured step",
+            "matrix_roof_ms": B * T * ALG_FLOP_PER_TIMESTEP / (BF16_MFMA_PEAK / step_products) * 1e3,
+            "matrix_roof_frac": (B * T * ALG_FLOP_PER_TIMESTEP / (BF16_MFMA_PEAK / step_products) * 1e3) / ms_per_step,
+            "frac_ceiling_under_split": (alg_step / HBM_PEAK) / (B * T * ALG_FLOP_PER_TIMESTEP / (BF16_MFMA_PEAK / step_products)),
+            "matrix_products_per_multiply": step_products,
+            "matrix_roof_note": "fp32-equivalent FLOPs of the step (SURVEY 8d: 9.27 MFLOP per timestep) at 2.5 PFLOP/s dense 16-bit "
+                                "MFMA / the products per multiply of the operand split: 6 (three bf16 pieces) for the forward and "
+                                "data-gradient contractions, 3 (two fp16 pieces, WN_FLAG_DW_F16PAIR) for the weight gradients, a "
+                                "third of the FLOPs each -> %.1f on average: the binding roof of this arithmetic is the matrix "
+                                "pipe, not HBM; matrix_roof_frac = that time / the measured step" % step_products,
             "stream_plateau_note": "a no-arithmetic float4 stream of the fused launches' bytes sustains 4.95 - 5.2 TB/s on an MI355X "
                                    "of this pool (tools/microbench/stream_mix.hip, profiles/r03/stream_mix.txt), i.e. 0.63 - 0.65 of `peak`; "
                                    "`frac` stays priced against the 8 TB/s peak",
@@ -570,7 +576,12 @@ def main():
                        "timing": "median of %d regions of %d steps" % (len(regions), args.steps),
                        "arithmetic": "fp32 storage and accumulation; contractions on the bf16 matrix cores with a 3-way "
                                      "operand split (6 products, fp32-equivalent to round-off); " +
-                                     ("the weight-gradient contractions (leaf results) take 3 of the 6 products (WN_FLAG_DW_3PRODUCT, "
+                                     ("the weight-gradient contractions (leaf results: sums over every position of the minibatch) "
+                                      "split their operands into two fp16 pieces and take 3 products on the fp16 matrix cores "
+                                      "(WN_FLAG_DW_F16PAIR: 2^-22 per product; gradient operand scaled by a power of two from the "
+                                      "loss's own bound on dlogits, out-of-range gradients detected and redone with six products); "
+                                      if (model.engine.flags & _lib.FLAG_DW_F16PAIR) else
+                                      "the weight-gradient contractions (leaf results) take 3 of the 6 products (WN_FLAG_DW_3PRODUCT, "
                                       "opt-in: it misses the golden after-Adam gate); "
                                       if (model.engine.flags & _lib.FLAG_DW_3PRODUCT) else "") +
                                      "WN_FLAG_EXACT_MFMA selects the f32 MFMA everywhere"},
@@ -584,41 +595,49 @@ def main():
         if not args.no_decode and world == 1:
             out["decode"] = decode_report(model, device, not args.no_cpu_baseline)
         if not args.no_extras and world == 1:
-            # the opt-in 3-product weight gradients on the SAME step (not the metric: the mode meets the gradient gates but not the
-            # golden after-Adam gate, engine.py / DESIGN.md 3.3), then the other workloads
-            dw3 = None
-            try:
-                base_flags = model.engine.flags
-                model.engine.flags = base_flags | _lib.FLAG_DW_3PRODUCT
-                for _ in range(3):
-                    step()
-                reg = []
-                for _ in range(3):
-                    barrier()
-                    t0 = time.perf_counter()
-                    for _ in range(args.steps):
+            # the other two arithmetic modes of the weight-gradient contractions on the SAME step, beside the metric: the six bf16
+            # products the forward / data-gradient contractions use (what the default falls back to when it has no bound on
+            # dlogits or a gradient leaves fp16's range), and the opt-in three bf16 products (misses the golden after-Adam gate)
+            base_flags = model.engine.flags
+            six_flags = base_flags & ~(_lib.FLAG_DW_F16PAIR | _lib.FLAG_DW_3PRODUCT)
+
+            def alt_mode(flags, note):
+                try:
+                    model.engine.flags = flags
+                    for _ in range(3):
                         step()
-                    barrier()
-                    reg.append((time.perf_counter() - t0) / args.steps * 1e3)
-                model.engine.flags = base_flags
-                dw3 = {"ms_per_step": sorted(reg)[1], "samples_per_sec": B * (T - rf) / (sorted(reg)[1] * 1e-3),
-                       "engine_flags": int(base_flags | _lib.FLAG_DW_3PRODUCT),
-                       "note": "WN_FLAG_DW_3PRODUCT (opt-in): weight-gradient contractions (leaf results) with 3 of the 6 products; "
-                               "worst gradient vs the oracle at the timed sizes 6.3e-6 / 6.3e-6 / 1.5e-5 of the tensor's maximum (gate 3e-5, "
-                               "tests/test_gpu_fullsize.py), but the golden after-Adam gate (1e-2 lr) is missed by 2x on the small golden "
-                               "cases -- therefore NOT the default and not the metric"}
-            except Exception as e:  # noqa: BLE001
-                dw3 = {"error": repr(e)}
+                    reg = []
+                    for _ in range(3):
+                        barrier()
+                        t0 = time.perf_counter()
+                        for _ in range(args.steps):
+                            step()
+                        barrier()
+                        reg.append((time.perf_counter() - t0) / args.steps * 1e3)
+                    return {"ms_per_step": sorted(reg)[1], "samples_per_sec": B * (T - rf) / (sorted(reg)[1] * 1e-3),
+                            "engine_flags": int(flags), "note": note}
+                except Exception as e:  # noqa: BLE001
+                    return {"error": repr(e)}
+                finally:
+                    model.engine.flags = base_flags
+            dw6 = alt_mode(six_flags, "weight-gradient contractions with the six bf16 products of every other contraction (engine.flags "
+                                      "&= ~FLAG_DW_F16PAIR): the mode the default (two fp16 pieces, three products, "
+                                      "WN_FLAG_DW_F16PAIR) falls back to without a bound on dlogits; same gates, same worst gradient "
+                                      "tensors (tests/test_gpu_fullsize.py, tests/test_gpu_dw_f16pair.py)")
+            dw3 = alt_mode(six_flags | _lib.FLAG_DW_3PRODUCT,
+                           "WN_FLAG_DW_3PRODUCT (opt-in): two bf16 pieces, three products (2^-16 per product): meets the 3e-5 gradient "
+                           "gate, misses the golden after-Adam gate (1e-2 lr) by 2x -- not a default, not the metric")
             out["extras"] = extra_workloads(model, opt, red)
+            out["extras"]["dw_six_products"] = dw6
             out["extras"]["dw_3product"] = dw3
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import recipe_bench
-                os.environ["WN_ENGINE_FLAGS"] = str(int(model.engine.flags | _lib.FLAG_DW_3PRODUCT))
-                r3 = recipe_bench.measure(resch=512, kernel_size=2, upsampling=80, T=23040, batch=4, steps=3, with_kernels=False)
-                out["extras"]["recipe_size_dw_3product"] = {k: r3[k] for k in ("model", "B", "T", "ms_per_step", "samples_per_sec")}
+                os.environ["WN_ENGINE_FLAGS"] = str(int(six_flags))
+                r6 = recipe_bench.measure(resch=512, kernel_size=2, upsampling=80, T=23040, batch=4, steps=3, with_kernels=False)
+                out["extras"]["recipe_size_dw_six_products"] = {k: r6[k] for k in ("model", "B", "T", "ms_per_step", "samples_per_sec")}
             except Exception as e:  # noqa: BLE001
-                out["extras"]["recipe_size_dw_3product"] = {"error": repr(e)}
+                out["extras"]["recipe_size_dw_six_products"] = {"error": repr(e)}
             finally:
                 os.environ.pop("WN_ENGINE_FLAGS", None)
         print(json.dumps(out), flush=True)

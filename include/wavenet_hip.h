@@ -121,6 +121,22 @@ enum {
                                * products of the 3-way operand split (h h + h m + m h; two bf16 pieces per operand: relative error
                                * ~2^-16 per product, random in sign, instead of 2^-24).  Never applied to a contraction whose
                                * output feeds another layer.  Default off: every contraction fp32-equivalent. */
+#define WN_FLAG_DW_F16PAIR (1 << 19) /* wn_backward / wn_backward_window (since ABI v8, opt-in): the weight-gradient contractions split
+                               * their operands into TWO fp16 pieces (11 + 11 significand bits) and take the three products
+                               * h h + h l + l h on v_mfma_f32_32x32x16_f16: ~2^-22 relative per product -- below the rounding of an
+                               * fp32 running sum over a minibatch's positions -- at half the matrix work of the six bf16 products.
+                               * fp16 has 5 exponent bits, so the caller states the size of the gradient it hands over:
+                               * | WN_FLAG_DW_F16_EXP(e) promises max |dlogits| <= 2^-e (0 <= e <= 63; a mean cross-entropy over n
+                               * positions has |dlogits| <= grad_scale / n).  The gradient operand of every weight-gradient
+                               * contraction is multiplied by 2^(e + WN_DW_F16_HEADROOM) before the split and the result by its
+                               * inverse; activations are taken as they are.  Values down to 2^-(e+11) keep all 22 bits.  A back-
+                               * propagated gradient more than 2^(16 - WN_DW_F16_HEADROOM) times the promise leaves fp16's range:
+                               * the launch detects it (non-finite result) and a six-product launch issued right behind every
+                               * fp16 launch, which otherwise returns at once, redoes the contraction -- the result is then the
+                               * default mode's.  Wins over WN_FLAG_DW_3PRODUCT when both are set. */
+#define WN_FLAG_DW_F16_EXP_SHIFT 20
+#define WN_FLAG_DW_F16_EXP(e) (((e) & 63) << WN_FLAG_DW_F16_EXP_SHIFT)
+#define WN_DW_F16_HEADROOM 8
 #define WN_FLAG_DW_FLUSH(n) (((n) & 0xff) << 8) /* wn_backward: issue the weight gradients of at most n walked layers per
                                * launch group (0 = default: a whole gradient bucket; 5 layers with WN_FLAG_BWD_OVERLAP).
                                * Groups never straddle a bucket.  The split-K plan of a group depends on its size, so

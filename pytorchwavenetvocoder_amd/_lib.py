@@ -78,6 +78,22 @@ FLAG_WS_FINITE = 1 << 16  # wn_forward_loss: the workspace holds only finite val
 DECODE_BY_LAUNCHES = 256  # wn_decode_layered_*: mode bit that keeps the layer-wise launches (csrc/wn_dlp.hip otherwise)
 DECODE_GRANULES = 512  # wn_decode_layered_*: mode bit, the persistent launches hand over 8-byte granules everywhere (A/B, tests)
 FLAG_DW_3PRODUCT = 1 << 18  # wn_backward: weight gradients (leaf results) with 3 of the 6 products of the operand split (opt-in)
+FLAG_DW_F16PAIR = 1 << 19  # wn_backward: weight gradients by the fp16 pair split (needs | dw_f16_exp(e): max |dlogits| <= 2^-e)
+DW_F16_EXP_SHIFT = 20
+DW_F16_HEADROOM = 8
+
+
+def dw_f16_exp(bound):
+    """WN_FLAG_DW_F16_EXP(e) for a gradient with max |dlogits| <= bound: the largest e in [0, 63] with bound <= 2^-e."""
+    import math
+    if not (bound > 0.0) or math.isinf(bound):
+        raise ValueError("bound must be a positive finite number")
+    e = int(math.floor(-math.log2(bound)))
+    while e > 0 and bound > 2.0 ** -e:    # (floating-point log2 at an exact power of two)
+        e -= 1
+    return (max(0, min(63, e)) & 63) << DW_F16_EXP_SHIFT
+
+
 FLAG_REPACK = 1 << 17  # wn_backward: rebuild the packed / pre-split weight sets from the params given to that call
 
 

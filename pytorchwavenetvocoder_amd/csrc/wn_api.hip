@@ -383,6 +383,7 @@ struct Ws {
     long X, G, Sg, Gt, Z, O1, O2;
     // scratch
     long P, dO2, dSk, dZ, dXall, dG, dw_partial, dc, tmpS, partial, rs_partial, red_scratch, loss_partial;
+    long dw_ovf;   // one word (of 64): raised by an fp16-pair weight-gradient launch whose result was not finite (WN_FLAG_DW_F16PAIR)
     long dGp, qp;  // aux-gradient partials of the gate kernel (WN_FLAG_AUX_FUSED); 0 floats when the mode cannot apply
     long img_fwd, img_taps, img_res, img_floats;  // pre-split LDS weight images of the fused split kernels (0 floats: not applicable)
     long wskipT_f, dZs;  // chain mode (wn_fused_chain_supported): skip weights as [s][l*R + i], dZs = Wskip^T dSkip (B, L*R, T)
@@ -477,6 +478,7 @@ static int make_ws(const Dims& d, int B, int T, Ws* w, bool training = true) {
     w->red_scratch_floats = 1 << 20;
     CARVE(red_scratch, w->red_scratch_floats);
     CARVE(loss_partial, 2 * wn_softmax_ce_nblocks(B, T) + 64);   // CE epilogue: one partial per 128-column block
+    CARVE(dw_ovf, 64);
     w->front_partial_floats = wn_front_dw_supported(d.R, d.K, d.Q) ? wn_front_dw_partial_floats(B, T, d.R, d.K, d.Q) : 0;
     CARVE(front_partial, w->front_partial_floats);
     {   // split-bf16 weights of the forward-type contractions (wn_gemm6): one buffer, re-packed before each use
@@ -561,6 +563,8 @@ struct Ctx {
     bool fused;
     bool split_bf16;  // forward-type contractions on the bf16 matrix cores (3-way split, fp32-equivalent)
     int dw_products;  // products per multiply of the weight-gradient contractions: 6, or 3 with WN_FLAG_DW_3PRODUCT
+    float dw_f16_mul; // > 0 (WN_FLAG_DW_F16PAIR): weight gradients by the fp16 pair split, gradient operand times this power of two;
+    int* dw_ovf;      // their overflow word (workspace): a raised word makes the six-product launch behind each of them do the work
     const float* params;   // set by the training entry points: lets fw_gemm recognise the pre-split weight sets
     bool have_pre;         // apk_pre[] of this workspace is valid (regular layout, not the decode state)
 };
@@ -580,6 +584,8 @@ static int make_ctx(Ctx* c, const WnConfig* cfg, int B, int T, void* ws, size_t 
     c->fused = wn_fused_supported(c->d.R, c->d.K, c->d.S) && !(flags & WN_FLAG_NO_FUSED);
     c->split_bf16 = !(flags & WN_FLAG_EXACT_MFMA);
     c->dw_products = (flags & WN_FLAG_DW_3PRODUCT) ? 3 : 6;
+    c->dw_f16_mul = (flags & WN_FLAG_DW_F16PAIR) ? ldexpf(1.0f, ((flags >> WN_FLAG_DW_F16_EXP_SHIFT) & 63) + WN_DW_F16_HEADROOM) : 0.0f;
+    c->dw_ovf = reinterpret_cast<int*>(c->ws + c->w.dw_ovf);
     c->params = nullptr;
     c->have_pre = true;
     return 0;

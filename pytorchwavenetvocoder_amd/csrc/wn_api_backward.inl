@@ -45,9 +45,15 @@ static int dw_gemm(const Ctx& c, WnGemmArgs g, const DwOut& o, int nl = 1) {
     g.nlayer = nl; g.nbatch = c.B; g.ksplit = p.ksplit; g.kchunk = p.kchunk;
     g.C = c.ws + c.w.partial; g.ldc = g.N; g.c_zstride = (long)g.M * g.N;
     g.a_rowsum = o.rowsum_out ? c.ws + c.w.rs_partial : nullptr;
-    if (c.split_bf16 && wn_gemm6_dw_eligible(&g))
-        WN_TRY(wn_gemm6_dw_launch(&g, c.dw_products, c.st));
-    else
+    if (c.split_bf16 && wn_gemm6_dw_eligible(&g)) {
+        if (c.dw_f16_mul > 0.0f) {
+            // fp16 pair split; the six-product launch behind it returns at once unless a gradient left fp16's range
+            WN_TRY(wn_gemm6_dw_launch(&g, 3, c.dw_f16_mul, c.dw_ovf, c.st));
+            WN_TRY(wn_gemm6_dw_launch(&g, 6, 0.0f, c.dw_ovf, c.st));
+        } else {
+            WN_TRY(wn_gemm6_dw_launch(&g, c.dw_products, 0.0f, nullptr, c.st));
+        }
+    } else
         WN_TRY(wn_gemm_launch(&g, c.st));
     return dw_reduce(c, c.ws + c.w.partial, c.ws + c.w.rs_partial, nz_layer, g.M, g.N, o, nl);
 }
@@ -76,6 +82,7 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
     if (!params || !x || !h || !dlogits || !grads) return fail(1, "NULL argument");
     c.params = params;
     if (t_first < 0 || t_first >= T) return fail(1, "t_first=%d outside [0,%d)", t_first, T);
+    if (c.dw_f16_mul > 0.0f) WN_TRY(wn_fill(c.ws + c.w.dw_ovf, 0.0f, 64, c.st));   // before the side stream forks
     // WN_FLAG_REPACK: `params` changed since the forward call (or the caller cannot tell): rebuild every re-laid-out /
     // pre-split weight set of the workspace from the buffer given HERE, so that the backward contractions use one
     // consistent set of weights (the saved activations are the forward pass's own either way).

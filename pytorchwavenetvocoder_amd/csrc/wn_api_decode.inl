@@ -251,6 +251,8 @@ static void dl_ctx(Ctx* c, const WnConfig* cfg, const Dims& d, const DlLay& y, i
     // the split path would re-split (or stream 1.5x the bytes of) the weights on every step
     c->split_bf16 = false;
     c->dw_products = 6;
+    c->dw_f16_mul = 0.0f;
+    c->dw_ovf = nullptr;
     c->params = nullptr;
     c->have_pre = false;
 }

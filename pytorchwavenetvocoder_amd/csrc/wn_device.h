@@ -120,6 +120,14 @@ static inline unsigned wn_pk_bf16(float a, float b) {
     };
     return one(a) | (one(b) << 16);
 }
+// fp16 matrix-core step (v_mfma_f32_32x32x16_f16) and the fp16 pair split of the weight gradients (wn_gemm6.hip, F16)
+static inline f32x16 mfma_f16(const wn_f4& a, const wn_f4& b, f32x16 c) {
+    return emu::mfma_f32_32x32x16f16(reinterpret_cast<const uint16_t*>(&a), reinterpret_cast<const uint16_t*>(&b), c);
+}
+// two fp32 -> two fp16 (round to nearest even, overflow -> inf) packed lo | hi << 16
+static inline unsigned wn_pk_f16(float a, float b) { return (unsigned)emu::float_to_f16_bits(a) | ((unsigned)emu::float_to_f16_bits(b) << 16); }
+static inline float wn_f16lo_f32(unsigned u) { return emu::f16_bits_to_float((uint16_t)(u & 0xffffu)); }
+static inline float wn_f16hi_f32(unsigned u) { return emu::f16_bits_to_float((uint16_t)(u >> 16)); }
 static inline float wn_bits_f32(unsigned u) {
     float f;
     memcpy(&f, &u, 4);
@@ -306,6 +314,20 @@ static __device__ __forceinline__ unsigned wn_pk_bf16(float a, float b) {
     const v2f v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, wn_bf16x2));
 }
+// fp16 matrix-core step (v_mfma_f32_32x32x16_f16, the bf16 step's rate and fragment layout) and the conversions of the fp16 pair
+// split of the weight gradients (wn_gemm6.hip, F16): v_cvt_pk_f16_f32 rounds to nearest even, overflow gives inf
+typedef _Float16 wn_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 wn_f16x2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ f32x16 mfma_f16(wn_f4 a, wn_f4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(wn_f16x8, a), __builtin_bit_cast(wn_f16x8, b), c, 0, 0, 0);
+}
+static __device__ __forceinline__ unsigned wn_pk_f16(float a, float b) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, wn_f16x2));
+}
+static __device__ __forceinline__ float wn_f16lo_f32(unsigned u) { return (float)__builtin_bit_cast(wn_f16x2, u).x; }
+static __device__ __forceinline__ float wn_f16hi_f32(unsigned u) { return (float)__builtin_bit_cast(wn_f16x2, u).y; }
 static __device__ __forceinline__ float wn_bits_f32(unsigned u) { return __builtin_bit_cast(float, u); }
 static __device__ __forceinline__ unsigned wn_f32_bits(float f) { return __builtin_bit_cast(unsigned, f); }
 // two-lane fp32 vector: fma on it is one v_pk_fma_f32

@@ -114,4 +114,6 @@ int wn_gemm6_dw_eligible(const struct WnGemmArgs* g);
 int wn_gemm6_dw_big(int M, int N);    // 1: 256 x 256 tiles, one wave per SIMD (k_gemm6_dw<4,4>); checked first
 int wn_gemm6_dw_tall(int M, int N);   // 1: 256 x 128 tiles (k_gemm6_dw<4,2>) for this output shape
 int wn_gemm6_dw_tn(int M, int N);            // otherwise: 3 = one 192-column tile (N = 192), 2 = 128-column tiles, 1 = 64-column tiles
-int wn_gemm6_dw_launch(const struct WnGemmArgs* g, int products, wn_stream_t st);   // products: 6, or 3 for leaf results (weight gradients)
+// products: 6, or 3 for leaf results (weight gradients); f16_mul > 0: the fp16 pair split (A times f16_mul, a power of two; raises
+// *ovf on a non-finite result); products 6 with ovf != NULL and f16_mul == 0: conditional redo (works only if *ovf != 0)
+int wn_gemm6_dw_launch(const struct WnGemmArgs* g, int products, float f16_mul, int* ovf, wn_stream_t st);

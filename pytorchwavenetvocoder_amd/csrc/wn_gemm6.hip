@@ -720,10 +720,24 @@ int wn_gemm6_launch(const WnGemm6Args* gp, wn_stream_t st) {
 // unified 512-register file of a lone wave), for the square weight gradients of wide models (n_resch 512: 1024 x 1024 and
 // 512 x 512 outputs) -- every operand row is read once per 256 rows of the other operand (the 256 x 128 tile moved 50.8 GB per
 // launch for 22.6 GB of operands, profiles/r05/pmc_traffic_recipe.json) and a wave reads 1.5 x fewer fragment bytes per MFMA.
-template <int TM, int TN, int NP>
-__global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) void k_gemm6_dw(WnGemmArgs g, int order G6_DBG_PARAM) {
-    static_assert(NP == 2 || NP == 3, "two or three bf16 pieces per operand");
+// F16 (round 5, NP = 2; WN_FLAG_DW_F16PAIR): the two pieces are fp16 -- 11 + 11 significand bits, the three products leave
+// ~2^-22 |a b| (64 x less than two bf16 pieces, less than the rounding of an fp32 running sum over the minibatch's positions).
+// fp16 has 5 exponent bits where bf16 has fp32's 8: the A operand (a gradient: <= 2^-e by the caller's word, ~1e-5 at the
+// benchmark's size) is multiplied by a_mul = 2^(e + WN_DW_F16_HEADROOM) at the split and the result by 1 / a_mul; B (an
+// activation, O(1)) is taken as it is.  A value beyond fp16's range becomes inf, its second piece -inf or NaN, the block's result
+// non-finite: the epilogue then raises *ovf and the caller's conditional six-product launch (below) redoes the contraction.
+template <bool F16>
+static __device__ __forceinline__ f32x16 mfma_piece(wn_f4 a, wn_f4 b, f32x16 c) {
+    if constexpr (F16) return mfma_f16(a, b, c);
+    else return mfma_bf16(a, b, c);
+}
+template <int TM, int TN, int NP, bool F16 = false>
+__global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) void k_gemm6_dw(WnGemmArgs g, int order, float a_mul, int* ovf G6_DBG_PARAM) {
+    static_assert(NP == 2 || NP == 3, "two or three pieces per operand");
+    static_assert(!F16 || NP == 2, "the fp16 split has two pieces");
     constexpr int NPROD = NP == 3 ? 6 : 3;
+    // the six-product launch behind an fp16-pair launch: runs only if that one overflowed (ovf is never written by this kernel)
+    if (!F16 && ovf != nullptr && wn_load_coherent_int(ovf) == 0) return;
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int AE = BM / 16, BE = BN / 16;            // fp32 elements per thread and step
     // 192-column tiles (TN = 3: kernel_size 3 at 64 channels, N = 3 x 64) give a thread three B rows of 4 consecutive k each
@@ -847,15 +861,26 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
         }
     };
     // split E consecutive-k values and write the three pieces of row `row` at k offset `kofs`
-    auto split_store = [&](char* base, int rows, int row, int kofs, const float* v, int E, unsigned sign = 0u) {
-        unsigned h[8], md[8], lo[8];  // E <= 16
-        for (int q = 0; q < E / 2; ++q) {
-            const float x0 = v[2 * q], x1 = v[2 * q + 1];
-            h[q] = wn_pk_bf16(x0, x1);
-            const float r0 = x0 - wn_bits_f32(h[q] << 16), r1 = x1 - wn_bits_f32(h[q] & 0xffff0000u);
-            md[q] = wn_pk_bf16(r0, r1);
-            lo[q] = NP == 3 ? wn_pk_bf16(r0 - wn_bits_f32(md[q] << 16), r1 - wn_bits_f32(md[q] & 0xffff0000u)) : 0u;
+    // one pair of consecutive-k values -> its pieces (packed lo | hi << 16)
+    auto split_pair = [&](float x0, float x1, bool is_a, unsigned& h, unsigned& md, unsigned& lo) {
+        if constexpr (F16) {
+            if (is_a) {
+                x0 *= a_mul;
+                x1 *= a_mul;
+            }
+            h = wn_pk_f16(x0, x1);
+            md = wn_pk_f16(x0 - wn_f16lo_f32(h), x1 - wn_f16hi_f32(h));
+            lo = 0u;
+        } else {
+            h = wn_pk_bf16(x0, x1);
+            const float r0 = x0 - wn_bits_f32(h << 16), r1 = x1 - wn_bits_f32(h & 0xffff0000u);
+            md = wn_pk_bf16(r0, r1);
+            lo = NP == 3 ? wn_pk_bf16(r0 - wn_bits_f32(md << 16), r1 - wn_bits_f32(md & 0xffff0000u)) : 0u;
         }
+    };
+    auto split_store = [&](char* base, int rows, int row, int kofs, const float* v, int E, bool is_a, unsigned sign = 0u) {
+        unsigned h[8], md[8], lo[8];  // E <= 16
+        for (int q = 0; q < E / 2; ++q) split_pair(v[2 * q], v[2 * q + 1], is_a, h[q], md[q], lo[q]);
         const unsigned* src[3] = {h, md, lo};
         for (int p = 0; p < NP; ++p) {
             char* d = base + p * rows * 32;
@@ -877,9 +902,9 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
             }
         }
         WN_UNROLL
-        for (int u = 0; u < AR; ++u) split_store(sa, BM, a_row + 64 * u, a_k, ra + u * AEr, AEr, a_sign);
+        for (int u = 0; u < AR; ++u) split_store(sa, BM, a_row + 64 * u, a_k, ra + u * AEr, AEr, true, a_sign);
         WN_UNROLL
-        for (int u = 0; u < BR; ++u) split_store(sa + A_BYTES, BN, b_row + 64 * u, b_k, rb + u * BEr, BEr);
+        for (int u = 0; u < BR; ++u) split_store(sa + A_BYTES, BN, b_row + 64 * u, b_k, rb + u * BEr, BEr, false);
     };
 
     f32x16 acc[TM][TN];
@@ -910,7 +935,7 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
             WN_UNROLL
             for (int t = 0; t < NPROD; ++t) {
                 WN_UNROLL
-                for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(af[PA[t]], bf[PB[t]][j], acc[i][j]);
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma_piece<F16>(af[PA[t]], bf[PB[t]][j], acc[i][j]);
             }
         }
     };
@@ -975,12 +1000,6 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
         constexpr int NPA = AE / 2, NPB = BE / 2, NSL = TM * NPROD;         // pairs of A, of B; slices
         constexpr int PPS = (NPA + NPB + NSL - 2) / (NSL - 1);              // pairs per slice (slice 0 is the loads)
         unsigned ha[NPA], ma[NPA], la[NPA], hb[NPB], mb[NPB], lb[NPB];
-        auto pair = [&](float x0, float x1, unsigned& h, unsigned& md, unsigned& lo) {
-            h = wn_pk_bf16(x0, x1);
-            const float r0 = x0 - wn_bits_f32(h << 16), r1 = x1 - wn_bits_f32(h & 0xffff0000u);
-            md = wn_pk_bf16(r0, r1);
-            lo = NP == 3 ? wn_pk_bf16(r0 - wn_bits_f32(md << 16), r1 - wn_bits_f32(md & 0xffff0000u)) : 0u;
-        };
         auto put = [&](char* base, int rows, int row, int kofs, const unsigned* h, const unsigned* md, const unsigned* lo, int np,
                        unsigned sign) {
 #ifdef WN_DWX_NOPUT
@@ -1010,7 +1029,7 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
                 const int q = (sl - 1) * PPS + u;
                 if (q < NPA) {
                     constexpr int PRA = AEr / 2;   // pairs per A row of this thread
-                    pair(ra[2 * q], ra[2 * q + 1], ha[q], ma[q], la[q]);
+                    split_pair(ra[2 * q], ra[2 * q + 1], true, ha[q], ma[q], la[q]);
                     if (do_rowsum) rowsum[q / PRA] += counted ? ra[2 * q] + ra[2 * q + 1] : 0.f;
                     if ((q + 1) % PRA == 0) {
                         const int u = q / PRA;
@@ -1018,7 +1037,7 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
                     }
                 } else if (q < NPA + NPB) {
                     const int qb = q - NPA;
-                    pair(rb[2 * qb], rb[2 * qb + 1], hb[qb], mb[qb], lb[qb]);
+                    split_pair(rb[2 * qb], rb[2 * qb + 1], false, hb[qb], mb[qb], lb[qb]);
                     constexpr int PR = BEr / 2;   // pairs per B row of this thread
                     if ((qb + 1) % PR == 0) {
                         const int u = qb / PR;
@@ -1046,7 +1065,7 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
             WN_UNROLL
             for (int t = 0; t < NPROD; ++t) {
                 WN_UNROLL
-                for (int j = 0; j < TN; ++j) acc[i][j] = mfma_bf16(af[PA[t]], bf[PB[t]][j], acc[i][j]);
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma_piece<F16>(af[PA[t]], bf[PB[t]][j], acc[i][j]);
                 slice(i * NPROD + t);
                 // One scheduling region = the TN MFMAs + their slice, issued as MFMA, <= 6 VALU, MFMA, <= 6 VALU, ...: a wave's own
                 // VALU instructions are free under an MFMA only up to 6 per MFMA (tools/microbench/mfma_valu.hip: 34.5 cycles per
@@ -1135,6 +1154,8 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
         }
     }
     const wn_rsrc_t Cr = wn_make_buf(g.C + (long)z * g.c_zstride, (unsigned)((long)g.M * g.ldc * 4));
+    const float c_mul = F16 ? 1.0f / a_mul : 1.0f;   // a power of two
+    unsigned nonfinite = 0u;
     WN_UNROLL
     for (int i = 0; i < TM; ++i) {
         WN_UNROLL
@@ -1143,11 +1164,16 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
             WN_UNROLL
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * TM + i) * 32 + mfma32_row(r, hi);
-                const float v = wn_bits_f32(__builtin_bit_cast(unsigned, (float)acc[i][j][r]) ^ (a_sign & 0x80000000u));   // * (+-1)
+                float v = wn_bits_f32(__builtin_bit_cast(unsigned, (float)acc[i][j][r]) ^ (a_sign & 0x80000000u));   // * (+-1)
+                if (F16) {
+                    nonfinite |= (~__builtin_bit_cast(unsigned, v) & 0x7f800000u) == 0u ? 1u : 0u;
+                    v *= c_mul;
+                }
                 wn_buf_store(Cr, v, (m < g.M && n < g.N) ? (m * (int)g.ldc + n) * 4 : 0x7ffffff0, 0);
             }
         }
     }
+    if (F16 && nonfinite) wn_store_coherent_int(ovf, 1);
 }
 
 // 256-row tiles for the weight gradients of wide models (>= 512 x 512 outputs: n_resch = 512 gives -2 % per step,
@@ -1178,10 +1204,20 @@ int wn_gemm6_dw_eligible(const WnGemmArgs* g) {
 }
 
 template <int TM, int TN>
-static int launch_dw(const WnGemmArgs& g, int products, wn_stream_t st) {
+static int launch_dw(const WnGemmArgs& g, int products, float f16_mul, int* ovf, wn_stream_t st) {
     dim3 grid((unsigned)((g.N + 64 * TN - 1) / (64 * TN)), (unsigned)((g.M + 64 * TM - 1) / (64 * TM)),
               (unsigned)(g.nlayer * g.nbatch * g.ksplit));
-    if (products == 3) {
+    if (f16_mul > 0.0f) {
+        constexpr int lds = 2 * (2 * 64 * TM * 32 + 2 * 64 * TN * 32);
+#ifndef WN_EMU
+        static bool attr_set = false;
+        if (lds > 65536 && !attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm6_dw<TM, TN, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 3;
+            attr_set = true;
+        }
+#endif
+        WN_LAUNCH((k_gemm6_dw<TM, TN, 2, true>), grid, dim3(G6_T), lds, st, g, xcd_block_order(), f16_mul, ovf G6_DBG_ARG(g.tag));
+    } else if (products == 3) {
         constexpr int lds = 2 * (2 * 64 * TM * 32 + 2 * 64 * TN * 32);
 #ifndef WN_EMU
         static bool attr_set = false;
@@ -1190,7 +1226,7 @@ static int launch_dw(const WnGemmArgs& g, int products, wn_stream_t st) {
             attr_set = true;
         }
 #endif
-        WN_LAUNCH((k_gemm6_dw<TM, TN, 2>), grid, dim3(G6_T), lds, st, g, xcd_block_order() G6_DBG_ARG(g.tag));
+        WN_LAUNCH((k_gemm6_dw<TM, TN, 2>), grid, dim3(G6_T), lds, st, g, xcd_block_order(), 1.0f, static_cast<int*>(nullptr) G6_DBG_ARG(g.tag));
     } else {
         constexpr int lds = 2 * (3 * 64 * TM * 32 + 3 * 64 * TN * 32);
 #ifndef WN_EMU
@@ -1200,25 +1236,29 @@ static int launch_dw(const WnGemmArgs& g, int products, wn_stream_t st) {
             attr_set = true;
         }
 #endif
-        WN_LAUNCH((k_gemm6_dw<TM, TN, 3>), grid, dim3(G6_T), lds, st, g, xcd_block_order() G6_DBG_ARG(g.tag));
+        WN_LAUNCH((k_gemm6_dw<TM, TN, 3>), grid, dim3(G6_T), lds, st, g, xcd_block_order(), 1.0f, ovf G6_DBG_ARG(g.tag));
     }
     return 0;
 }
 
-// products: 6 (default: fp32-equivalent) or 3 (h h + h m + m h: leaf results only, see k_gemm6_dw)
-int wn_gemm6_dw_launch(const WnGemmArgs* gp, int products, wn_stream_t st) {
+// products: 6 (default: fp32-equivalent) or 3 (h h + h m + m h of bf16 pieces: leaf results only, see k_gemm6_dw).
+// f16_mul > 0: the fp16 pair split instead (three products, A scaled by f16_mul = a power of two; *ovf := 1 if a block's result is
+// not finite).  f16_mul == 0, products == 6 and ovf != NULL: the launch does its work only if *ovf != 0 (the exact redo).
+int wn_gemm6_dw_launch(const WnGemmArgs* gp, int products, float f16_mul, int* ovf, wn_stream_t st) {
     const WnGemmArgs& g = *gp;
     if (products != 3 && products != 6) return 2;
+    if (f16_mul < 0.0f || (f16_mul > 0.0f && !ovf) || (ovf && f16_mul == 0.0f && products != 6)) return 2;
     if (!wn_gemm6_dw_eligible(gp)) return 1;
     if (g.K < 0 || g.nbatch <= 0 || g.ksplit <= 0 || g.nlayer <= 0 || g.b_seg_len <= 0 || g.kchunk <= 0) return 2;
-    WN_PROF(g.tag ? g.tag : "gemm6_dw", 2.0 * g.M * g.N * (double)g.K * g.nbatch * g.nlayer,
-            ((double)g.M * g.K * 4.0 + (double)g.K * 4.0 * g.N + (double)g.M * g.N * 4.0) * g.nbatch * g.nlayer, st);
+    const bool redo = ovf && f16_mul == 0.0f;   // the conditional redo: no work unless an fp16 launch overflowed
+    WN_PROF(redo ? "dw_redo_if_overflow" : (g.tag ? g.tag : "gemm6_dw"), redo ? 0.0 : 2.0 * g.M * g.N * (double)g.K * g.nbatch * g.nlayer,
+            redo ? 0.0 : ((double)g.M * g.K * 4.0 + (double)g.K * 4.0 * g.N + (double)g.M * g.N * 4.0) * g.nbatch * g.nlayer, st);
     const int tm = g.M > 64 ? 2 : 1, tn = wn_gemm6_dw_tn(g.M, g.N);
-    if (wn_gemm6_dw_big(g.M, g.N)) return launch_dw<4, 4>(g, products, st);     // 256 x 256 tiles, one wave per SIMD
-    if (wn_gemm6_dw_tall(g.M, g.N)) return launch_dw<4, 2>(g, products, st);   // 256 x 128 tiles: every B row is read once per 256 A rows
-    if (tm == 2 && tn == 3) return launch_dw<2, 3>(g, products, st);
-    if (tm == 2 && tn == 2) return launch_dw<2, 2>(g, products, st);
-    if (tm == 2) return launch_dw<2, 1>(g, products, st);
-    if (tn == 2) return launch_dw<1, 2>(g, products, st);
-    return launch_dw<1, 1>(g, products, st);
+    if (wn_gemm6_dw_big(g.M, g.N)) return launch_dw<4, 4>(g, products, f16_mul, ovf, st);     // 256 x 256 tiles, one wave per SIMD
+    if (wn_gemm6_dw_tall(g.M, g.N)) return launch_dw<4, 2>(g, products, f16_mul, ovf, st);   // 256 x 128 tiles: every B row is read once per 256 A rows
+    if (tm == 2 && tn == 3) return launch_dw<2, 3>(g, products, f16_mul, ovf, st);
+    if (tm == 2 && tn == 2) return launch_dw<2, 2>(g, products, f16_mul, ovf, st);
+    if (tm == 2) return launch_dw<2, 1>(g, products, f16_mul, ovf, st);
+    if (tn == 2) return launch_dw<1, 2>(g, products, f16_mul, ovf, st);
+    return launch_dw<1, 1>(g, products, f16_mul, ovf, st);
 }

@@ -26,7 +26,18 @@ from . import _lib
 # 2e-2 lr (tests/test_gpu_parity.py, r64_k2_up).  Parity first: every default-mode contraction stays fp32-equivalent; the flag is
 # for callers who accept that (engine.flags |= _lib.FLAG_DW_3PRODUCT, or WN_ENGINE_FLAGS=262176), bench.py reports its step time
 # beside the headline (extras.dw_3product), tests/test_gpu_fullsize.py keeps its 3e-5 gradient gate.
-DEFAULT_FLAGS = _lib.FLAG_AUX_FUSED
+# WN_FLAG_DW_F16PAIR (round 5, DEFAULT): the same contractions with TWO FP16 pieces per operand (11 + 11 significand bits) and the
+# three products h h + h l + l h on v_mfma_f32_32x32x16_f16 -- 2^-22 per product instead of the 2^-16 of two bf16 pieces, below
+# the rounding of an fp32 running sum over a minibatch's positions -- at the three-bf16-product mode's speed (headline step 9.54 ->
+# 9.08 ms, recipe size 119.0 -> 104.9 ms, configs[3] geometry 12.70 -> 12.17 ms, same box, profiles/r05/abk_f16pair_headline.txt,
+# dw3_probe_f16pair.txt).  It meets EVERY gate of the six-product mode: golden gradients and the golden weights after Adam
+# (tests/test_gpu_dw_f16pair.py), the full-size gradient gates with the six-product mode's own worst tensor (4.87e-6 / 1.49e-5,
+# tests/test_gpu_fullsize.py).  fp16's 5 exponent bits need the size of the gradient: backward() passes the bound of the
+# tensor its own loss call returned (a mean cross-entropy: |dlogits| <= grad_scale / positions), the kernels scale the gradient
+# operand by 2^(e + 8), and a gradient that still leaves fp16's range is DETECTED (non-finite block result) and redone by the
+# six-product launch issued behind every fp16 launch (an empty launch otherwise: 0.04 ms per step).  Any other gradient (autograd's
+# grad_output, the mixture-of-logistics head) keeps the six bf16 products unless the caller gives backward(dlogits_bound=...).
+DEFAULT_FLAGS = _lib.FLAG_AUX_FUSED | _lib.FLAG_DW_F16PAIR
 
 
 def _ptr(t):
@@ -66,6 +77,7 @@ class WaveNetEngine(object):
         self._fwd_window = 0      # first loss position of the last forward_loss (0: a full forward)
         self._fwd_version = None  # parameter version the last forward packed its weight sets from
         self._fwd_flags = 0       # launch-mode flags of the last forward
+        self._dlogits_bound = None  # (data_ptr, version, max |dlogits|) of the gradient the last loss call of this engine made
         self._params_epoch = 0    # bumped by every in-library parameter update (adam_step): torch cannot see those
         self._version_sources = ()  # tensors aliasing flat_params whose in-place version counters count as well
         self.ws_finite = True     # workspace() allocates zero-filled memory -> WN_FLAG_WS_FINITE (tests clear it)
@@ -219,7 +231,15 @@ class WaveNetEngine(object):
         self._fwd_window = int(t_start) if fused else 0
         self._fwd_version = self.params_version()
         self._fwd_flags = self.flags
+        self._note_bound(dlogits, grad_scale, B * (T - int(t_start)))
         return loss, dlogits
+
+    def _note_bound(self, dlogits, grad_scale, count):
+        # a mean softmax cross-entropy over `count` positions has |d loss / d logit| <= grad_scale / count: what backward() needs
+        # to know to take the fp16 pair split of the weight gradients (WN_FLAG_DW_F16PAIR)
+        self._dlogits_bound = None
+        if dlogits is not None and count > 0 and grad_scale != 0.0:
+            self._dlogits_bound = (dlogits.data_ptr(), dlogits._version, abs(float(grad_scale)) / count)
 
     def loss(self, logits, target, t_start=None, grad_scale=1.0, loss_scale=1.0, want_grad=True):
         """Softmax-CE over positions >= t_start (default: receptive field).  Returns (loss, dlogits)."""
@@ -235,6 +255,7 @@ class WaveNetEngine(object):
                                          float(grad_scale), float(loss_scale), _ptr(loss), _ptr(dlogits), _ptr(ws),
                                          ws.numel() * 4, _stream_handle(self.device))
         self.lib.check(rc, "wn_softmax_ce_loss")
+        self._note_bound(dlogits, grad_scale, B * (T - int(t_start)))
         return loss, dlogits
 
     def mol_loss(self, out, y, t_start=None, grad_scale=1.0, loss_scale=1.0, want_grad=True, num_classes=65536,
@@ -257,7 +278,7 @@ class WaveNetEngine(object):
         self.lib.check(rc, "wn_mol_loss")
         return loss, dout
 
-    def backward(self, dlogits, events=None, layers_per_bucket=0, t_first=None, repack=False):
+    def backward(self, dlogits, events=None, layers_per_bucket=0, t_first=None, repack=False, dlogits_bound=None):
         """Backward of the last ``forward`` / ``forward_loss`` call; fills ``self.grads()`` completely.  ``t_first``: the
         caller guarantees ``dlogits[:, :, :t_first] == 0`` (the training loss covers ``[:, receptive_field:]``,
         train.py:534-536): the post-net / skip part of the backward pass then runs over the loss window only
@@ -267,7 +288,12 @@ class WaveNetEngine(object):
         The parameters must not have changed since the forward call -- the workspace holds the weight sets that call
         packed from them next to its activations.  Like torch.autograd for a tensor modified in place between forward
         and backward this raises; ``repack=True`` instead rebuilds the weight sets from the current parameters
-        (``WN_FLAG_REPACK``) and back-propagates through those."""
+        (``WN_FLAG_REPACK``) and back-propagates through those.
+
+        ``dlogits_bound``: the caller's word that ``max |dlogits| <= dlogits_bound`` -- with ``FLAG_DW_F16PAIR`` in
+        ``self.flags`` the weight gradients then take the fp16 pair split (include/wavenet_hip.h).  Default: known for the
+        unmodified tensor ``forward_loss`` / ``loss`` returned (a mean cross-entropy: grad_scale / positions), unknown --
+        the six bf16 products -- for any other gradient (autograd's grad_output, the mixture-of-logistics head)."""
         if self._last_shape is None:
             raise _lib.WnError("backward() without a preceding forward()")
         if t_first is None:
@@ -277,6 +303,15 @@ class WaveNetEngine(object):
         if (flags ^ self._fwd_flags) & family:
             raise _lib.WnError("engine.flags changed the kernel family (NO_FUSED / EXACT_MFMA) since the forward call: the "
                                "two families save different activations and weight sets -- run forward again")
+        if flags & _lib.FLAG_DW_F16PAIR:
+            flags &= ~(63 << _lib.DW_F16_EXP_SHIFT)
+            nb = self._dlogits_bound
+            if dlogits_bound is None and nb is not None and nb[0] == dlogits.data_ptr() and nb[1] == dlogits._version:
+                dlogits_bound = nb[2]
+            if dlogits_bound is None:
+                flags &= ~_lib.FLAG_DW_F16PAIR
+            else:
+                flags |= _lib.dw_f16_exp(float(dlogits_bound))
         if repack:
             flags |= _lib.FLAG_REPACK
         elif self._fwd_version is not None and self._fwd_version != self.params_version():

@@ -306,6 +306,42 @@ inline float bf16_bits_to_float(uint16_t h) {
     memcpy(&f, &u, 4);
     return f;
 }
+// IEEE binary16 <-> binary32 (round to nearest even, overflow -> inf, subnormals kept): v_cvt_f16_f32 / v_cvt_f32_f16
+inline float f16_bits_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const int e = (h >> 10) & 31;
+    const uint32_t m = h & 0x3ffu;
+    float f;
+    if (e == 31) {
+        const uint32_t u = sign | 0x7f800000u | (m << 13);
+        memcpy(&f, &u, 4);
+        return f;
+    }
+    if (e == 0) {
+        f = ldexpf((float)m, -24);
+        return sign ? -f : f;
+    }
+    const uint32_t u = sign | ((uint32_t)(e + 112) << 23) | (m << 13);
+    memcpy(&f, &u, 4);
+    return f;
+}
+inline uint16_t float_to_f16_bits(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+    const uint32_t a = u & 0x7fffffffu;
+    if (a >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (a > 0x7f800000u ? 0x200u : 0u));   // inf / nan
+    float ax;
+    memcpy(&ax, &a, 4);
+    if (ax >= 65520.0f) return (uint16_t)(sign | 0x7c00u);     // rounds to inf
+    if (ax < 6.103515625e-05f) {                               // below the smallest normal 2^-14: multiples of 2^-24
+        const float q = ax * 16777216.0f;                      // exact
+        const float r = nearbyintf(q);                         // to nearest even (default rounding mode)
+        return (uint16_t)(sign | (uint16_t)r);                 // r = 1024 is the smallest normal: same bit pattern
+    }
+    const uint32_t r = a + 0xfffu + ((a >> 13) & 1u);          // to nearest even at bit 13
+    return (uint16_t)(sign | (uint16_t)((r - 0x38000000u) >> 13));
+}
 inline f32x16_t mfma_f32_32x32x16bf16(const uint16_t* a8, const uint16_t* b8, f32x16_t c) {
     State& s = S();
     int t = tid_();
@@ -323,6 +359,30 @@ inline f32x16_t mfma_f32_32x32x16bf16(const uint16_t* a8, const uint16_t* b8, f3
             memcpy(av, &s.slot_a[2 * (size_t)(base + 32 * kb + row)], 16);
             memcpy(bv, &s.slot_b[2 * (size_t)(base + 32 * kb + col)], 16);
             for (int e = 0; e < 8; ++e) acc = fmaf(bf16_bits_to_float(av[e]), bf16_bits_to_float(bv[e]), acc);
+        }
+        d[r] = acc;
+    }
+    sync_wave();
+    return d;
+}
+
+inline f32x16_t mfma_f32_32x32x16f16(const uint16_t* a8, const uint16_t* b8, f32x16_t c) {
+    State& s = S();
+    int t = tid_();
+    int base = t & ~63, l = t & 63;
+    memcpy(&s.slot_a[2 * (size_t)t], a8, 16);
+    memcpy(&s.slot_b[2 * (size_t)t], b8, 16);
+    sync_wave();
+    int col = l & 31, hi = l >> 5;
+    f32x16_t d = c;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int kb = 0; kb < 2; ++kb) {
+            uint16_t av[8], bv[8];
+            memcpy(av, &s.slot_a[2 * (size_t)(base + 32 * kb + row)], 16);
+            memcpy(bv, &s.slot_b[2 * (size_t)(base + 32 * kb + col)], 16);
+            for (int e = 0; e < 8; ++e) acc = fmaf(f16_bits_to_float(av[e]), f16_bits_to_float(bv[e]), acc);
         }
         d[r] = acc;
     }

@@ -312,7 +312,8 @@ def test_backward_chain_kernel_modes():
     from pytorchwavenetvocoder_amd import _lib
     from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS, WaveNetEngine, load_state_into_flat
     A, NC = _lib.FLAG_AUX_FUSED, _lib.FLAG_NO_CHAIN
-    assert DEFAULT_FLAGS == A      # chain + aux partials is what every default-flag test runs
+    # chain + aux partials (+ the fp16 pair split of the weight gradients) is what every default-flag test runs
+    assert DEFAULT_FLAGS == A | _lib.FLAG_DW_F16PAIR
     for flags in (0, A, NC, A | NC):
         PC.check_golden_case(GoldenCase("r64_k2_up"), emu_library(), "cpu", flags=flags)
     PC.run_oracle_vs_engine((64, 6, 64, 32, 3, 1, 1, 16), 2, 48, 41, emu_library(), "cpu", flags=A, scale=0.2)   # K = 1
@@ -570,8 +571,9 @@ def test_windowed_forward_loss_workspace_and_the_parameter_guard():
             assert PC.rel_to_max(grads[k], ref) <= PC.TOL_GRAD, k
     # the caller vouches for a workspace that is NOT finite: documents what the flag means (no fill launches)
     eng.ws_finite = True
-    log = PC.launch_log(emu_library(), lambda: eng.forward_loss(x, h, t))
+    log = PC.launch_log(emu_library(), lambda: out.update(r=eng.forward_loss(x, h, t)))
     assert log.get("fill_cols") == 1, log
+    loss, dl = out["r"]   # (the gradient tensor of the LAST loss call is the one backward() knows the bound of: fp16 pair split)
     # parameter guard
     eng.flat_params[:4] += 0.0    # an in-place write, whatever its value
     with pytest.raises(_lib.WnError):
@@ -865,3 +867,42 @@ def test_persistent_decode_residency_check_and_fall_backs(monkeypatch):
     torch.manual_seed(5)
     sp = model.engine.decode(xs, hs, ns, mode="sampling", layered=True)
     assert all(torch.equal(a, b) for a, b in zip(sf, sp))
+
+
+def test_weight_gradients_by_the_fp16_pair_split_and_their_overflow_redo():
+    """WN_FLAG_DW_F16PAIR (csrc/wn_gemm6.hip k_gemm6_dw<.., F16>): two fp16 pieces per operand, three products, the gradient
+    operand scaled by 2^(e + 8) from the caller's bound max |dlogits| <= 2^-e.  Against the six-bf16-product default: within
+    1e-6 of the largest gradient (the three-bf16-product mode: ~2e-6 ... 1e-5); every fp16 launch is followed by ONE conditional
+    six-product launch; a bound far too small drives the scaled gradients out of fp16's range -> the overflow word -> the redo
+    launches do the work: the default's result bit for bit; a gradient tensor the engine has no bound for never takes the mode.
+    (The golden gates, incl. the weights after Adam, are GPU tests: tests/test_gpu_dw_f16pair.py.)"""
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd import _lib
+    from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat
+    assert [_lib.dw_f16_exp(b) >> _lib.DW_F16_EXP_SHIFT for b in (3.0, 1.0, 0.5, 0.3, 2.0 ** -17, 6e-6, 1e-30)] == [0, 0, 1, 1, 17, 17, 63]
+    cfg_t = (32, 4, 64, 32, 7, 1, 2, 16)
+    cfg = O.OracleConfig(*cfg_t)
+    B, T = 1, 272
+    params, x, h, t, margin, sd = PC.pick_instance(cfg, B, T, 61, 0.1)
+    _, _, grads_ref = O.train_step(cfg, params, None, x, h, t)
+    eng = WaveNetEngine(*cfg_t, device="cpu", library=emu_library())
+    load_state_into_flat(eng, params)
+    res, logs = {}, {}
+    for name, flags in (("six", _lib.FLAG_AUX_FUSED), ("f16", _lib.FLAG_AUX_FUSED | _lib.FLAG_DW_F16PAIR)):
+        eng.flags = flags
+        loss, dl = eng.forward_loss(x, h, t)
+        logs[name] = PC.launch_log(emu_library(), lambda: eng.backward(dl))
+        res[name] = eng.grads().clone()
+        grads = PC.flat_to_state(eng, res[name], O.param_shapes(cfg))
+        for k, ref in grads_ref.items():
+            if ref is not None:
+                assert PC.rel_to_max(grads[k], ref) <= PC.TOL_GRAD, (name, k)
+    n_dw = sum(v for k, v in logs["six"].items() if k.startswith("dw_") and k != "dw_front_scatter")
+    assert "dw_redo_if_overflow" not in logs["six"] and logs["f16"].get("dw_redo_if_overflow") == n_dw, logs
+    scale = float(res["six"].abs().max())
+    err = float((res["f16"] - res["six"]).abs().max())
+    assert 0.0 < err <= 1e-6 * scale, (err, scale)
+    # overflow: the promise is 2^20 too small for this gradient
+    assert torch.equal(eng.backward(dl, dlogits_bound=2.0 ** -40).clone(), res["six"])
+    assert torch.equal(eng.backward(dl.clone()).clone(), res["six"])     # not the tensor the loss call returned: no bound, no fp16
+    # (the word is cleared per call, in-place modified gradients, the caller's own bound: tests/test_gpu_dw_f16pair.py)

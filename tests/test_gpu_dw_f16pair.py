@@ -1,0 +1,80 @@
+# -*- coding: utf-8 -*-
+"""WN_FLAG_DW_F16PAIR on the GPU (through the C ABI): the weight-gradient contractions with the fp16 pair split (two fp16
+pieces per operand, three products on v_mfma_f32_32x32x16_f16; csrc/wn_gemm6.hip k_gemm6_dw<.., F16>) against EVERY gate of the
+default six-bf16-product mode -- the golden gradients (1e-4 of a tensor's maximum) and the golden weights after the Adam steps
+(1e-2 lr: the gate the three-bf16-product mode WN_FLAG_DW_3PRODUCT misses) of reference train.py:527-540 --, the overflow
+fall-back (a gradient outside fp16's range makes the conditional six-product launches do the work: the default mode's result
+bit for bit) and the rule that the mode needs the caller's bound on dlogits."""
+import pytest
+import torch
+
+from tests import parity_common as PC
+from tests.golden_util import GoldenCase
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _lib():
+    from pytorchwavenetvocoder_amd import _lib as L
+    lib = L.load_library()
+    assert not lib.is_emulator
+    return lib
+
+
+def _flags():
+    from pytorchwavenetvocoder_amd import _lib as L
+    from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS
+    return (DEFAULT_FLAGS & ~L.FLAG_DW_3PRODUCT) | L.FLAG_DW_F16PAIR
+
+
+@pytest.mark.parametrize("name", ["tiny_k2_up", "tiny_k3_noup", "r64_k2_up", "r64_k3_up"])
+def test_golden_gradients_and_after_adam_state_with_the_fp16_pair_split(name, monkeypatch):
+    monkeypatch.setenv("WN_ENGINE_FLAGS", str(_flags()))
+    g = GoldenCase(name)
+    eng = PC.check_golden_case(g, _lib(), DEV)
+    assert eng.flags == _flags()
+    if name != "r64_k3_up":   # (the module-level golden cases of tests/test_gpu_parity.py)
+        model, _ = PC.check_module_training(g, _lib(), DEV)
+        x, h, t = g.x.to(DEV), g.h.to(DEV), g.t.to(DEV)
+        log = PC.launch_log(_lib(), lambda: model.loss_and_backward(x, h, t))
+        assert log.get("dw_redo_if_overflow", 0) >= 1, log   # the mode was on: every fp16 launch is followed by its conditional redo
+
+
+def test_overflow_falls_back_to_the_six_products_bit_for_bit_and_unknown_bounds_never_take_the_mode():
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd import _lib as L
+    from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat
+    cfg_t = (256, 80, 64, 256, 10, 1, 2, 80)
+    cfg = O.OracleConfig(*cfg_t)
+    B, T = 2, cfg.receptive_field + 1200
+    T = (T + 79) // 80 * 80
+    params = O.random_params(cfg, 31, scale=0.05)
+    x, h, t = O.synthetic_batch(cfg, B, T, 32)
+    eng = WaveNetEngine(*cfg_t, device=DEV, library=_lib())
+    load_state_into_flat(eng, params)
+    six = _flags() & ~L.FLAG_DW_F16PAIR
+    eng.flags = six
+    loss, dl = eng.forward_loss(x.to(DEV), h.to(DEV), t.to(DEV))
+    g6 = eng.backward(dl).clone()
+    eng.flags = _flags()
+    log = PC.launch_log(_lib(), lambda: eng.backward(dl))
+    g16 = eng.grads().clone()
+    assert log.get("dw_redo_if_overflow", 0) >= 5, log
+    scale = float(g6.abs().max())
+    err = float((g16 - g6).abs().max()) / scale
+    adam = float(((g16 - g6).abs() / (g6.abs() + 1e-8)).max())
+    print("fp16 pair vs six bf16 products, 10-layer 64/256 model, B=2, T=%d: max |diff| / max %.3g, Adam-update metric %.3g" % (T, err, adam))
+    assert err <= 1e-6 and not torch.equal(g16, g6)
+    # promise far too small: the scaled gradient leaves fp16's range, every block raises the word, the redo launches do the work
+    gov = eng.backward(dl, dlogits_bound=2.0 ** -40).clone()
+    assert torch.equal(gov, g6)
+    # and the next call with the true bound is the fp16 result again (the word is cleared per call)
+    assert torch.equal(eng.backward(dl).clone(), g16)
+    # a gradient the engine did not make (autograd's grad_output, a modified tensor): six products
+    assert torch.equal(eng.backward(dl.clone()).clone(), g6)
+    dl.mul_(1.0)
+    assert torch.equal(eng.backward(dl).clone(), g6)
+    # ... unless the caller gives its word
+    assert torch.equal(eng.backward(dl, dlogits_bound=1.0 / (B * (T - cfg.receptive_field))).clone(), g16)

@@ -39,15 +39,30 @@ def _three_product_gate(what, res, flags):
     assert worst <= TOL_GRAD_3PRODUCT, (what, worst, key)
 
 
+TOL_GRAD_F16PAIR = 1.5e-5   # gate of the fp16 pair split (WN_FLAG_DW_F16PAIR): the worst tensor of the six-product mode measures 1.5e-5
+
+
+def _f16pair_gate(what, res, flags):
+    """WN_FLAG_DW_F16PAIR: the weight-gradient contractions take three products of a two-piece fp16 split (2^-22 per product).
+    The worst gradient tensor against the oracle must stay where the six-product mode's is."""
+    worst, key = res["grads"][flags]
+    base = res["grads"][min(res["grads"])]
+    print("%s, weight gradients by the fp16 pair split (WN_FLAG_DW_F16PAIR): worst gradient %.3g (%s); six bf16 products: %.3g (%s)"
+          % (what, worst, key, base[0], base[1]))
+    assert worst <= max(TOL_GRAD_F16PAIR, 1.1 * base[0]), (what, worst, key)
+
+
 def test_cfg2_full_size_vs_oracle():
     from pytorchwavenetvocoder_amd import _lib as L
     from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS
     cfg_t = (256, 80, 64, 256, 10, 3, 2, 80)
-    SIX = DEFAULT_FLAGS & ~L.FLAG_DW_3PRODUCT
+    SIX = DEFAULT_FLAGS & ~(L.FLAG_DW_3PRODUCT | L.FLAG_DW_F16PAIR)
     res = PC.run_fullsize_vs_oracle(cfg_t, 8, 23040, 101, _lib(), DEV,
-                                    flag_sets=[SIX, SIX ^ L.FLAG_AUX_FUSED, SIX | L.FLAG_NO_CHAIN, SIX | L.FLAG_DW_3PRODUCT],
+                                    flag_sets=[SIX, SIX ^ L.FLAG_AUX_FUSED, SIX | L.FLAG_NO_CHAIN, SIX | L.FLAG_DW_3PRODUCT,
+                                               SIX | L.FLAG_DW_F16PAIR],
                                     scale=0.05)
     _three_product_gate("cfg2 FULL SIZE", res, SIX | L.FLAG_DW_3PRODUCT)
+    _f16pair_gate("cfg2 FULL SIZE", res, SIX | L.FLAG_DW_F16PAIR)
     print("cfg2 FULL SIZE (B=8, T=23040) vs oracle: logits %.3g, loss %.3g, layer inputs %.3g, grads %s; "
           "%d ReLU inputs within 1e-5 of the kink, %d sub-gradient choices differing from the oracle's sign"
           % (res["logits"], res["loss"], res["layer_inputs"], res["grads"], res["near_kink_1e-5"], res["kink_flips"]))
@@ -106,9 +121,10 @@ def test_config4_stated_size_vs_oracle():
     cfg_t = (256, 80, 64, 256, 10, 3, 3, 256)
     assert O.batch_geometry(6139, 20000, 256)["T"] == 26112
     from pytorchwavenetvocoder_amd import _lib as L
-    SIX = DEFAULT_FLAGS & ~L.FLAG_DW_3PRODUCT
-    res = PC.run_fullsize_vs_oracle(cfg_t, 8, 26112, 111, _lib(), DEV, flag_sets=[SIX, SIX | L.FLAG_DW_3PRODUCT], scale=0.05)
+    SIX = DEFAULT_FLAGS & ~(L.FLAG_DW_3PRODUCT | L.FLAG_DW_F16PAIR)
+    res = PC.run_fullsize_vs_oracle(cfg_t, 8, 26112, 111, _lib(), DEV, flag_sets=[SIX, SIX | L.FLAG_DW_3PRODUCT, SIX | L.FLAG_DW_F16PAIR], scale=0.05)
     _three_product_gate("configs[3] STATED SIZE", res, SIX | L.FLAG_DW_3PRODUCT)
+    _f16pair_gate("configs[3] STATED SIZE", res, SIX | L.FLAG_DW_F16PAIR)
     print("configs[3] STATED SIZE (K=3, U=256, B=8, T=26112) vs oracle: logits %.3g, loss %.3g, layer inputs %.3g, grads %s, "
           "%d kink flips" % (res["logits"], res["loss"], res["layer_inputs"], res["grads"], res["kink_flips"]))
 
@@ -120,9 +136,10 @@ def test_recipe_size_model_at_the_timed_size_vs_oracle():
     from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS
     cfg_t = (256, 80, 512, 256, 10, 3, 2, 80)
     from pytorchwavenetvocoder_amd import _lib as L
-    SIX = DEFAULT_FLAGS & ~L.FLAG_DW_3PRODUCT
-    res = PC.run_fullsize_vs_oracle(cfg_t, 4, 23040, 112, _lib(), DEV, flag_sets=[SIX, SIX | L.FLAG_DW_3PRODUCT], scale=0.02)
+    SIX = DEFAULT_FLAGS & ~(L.FLAG_DW_3PRODUCT | L.FLAG_DW_F16PAIR)
+    res = PC.run_fullsize_vs_oracle(cfg_t, 4, 23040, 112, _lib(), DEV, flag_sets=[SIX, SIX | L.FLAG_DW_3PRODUCT, SIX | L.FLAG_DW_F16PAIR], scale=0.02)
     _three_product_gate("recipe-size TIMED SIZE", res, SIX | L.FLAG_DW_3PRODUCT)
+    _f16pair_gate("recipe-size TIMED SIZE", res, SIX | L.FLAG_DW_F16PAIR)
     print("recipe-size model at the TIMED SIZE (B=4, T=23040) vs oracle: logits %.3g, loss %.3g, layer inputs %.3g, grads %s, "
           "%d kink flips" % (res["logits"], res["loss"], res["layer_inputs"], res["grads"], res["kink_flips"]))
 
