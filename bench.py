@@ -260,11 +260,21 @@ def extra_workloads(*release):
         out["configs3_mol"]["note"] = "mixture-of-logistics head: not in the reference (parity unpinned by it)"
         rs = recipe_bench.measure(resch=512, kernel_size=2, upsampling=80, T=23040, batch=4, steps=3, with_kernels=False)
         out["recipe_size"] = {k: rs[k] for k in ("model", "B", "T", "rf", "ms_per_step", "samples_per_sec", "approx_train_tflops")}
-        peak = BF16_MFMA_PEAK / SPLIT_PRODUCTS
+        # products per multiply of this run's arithmetic: 6 (three bf16 pieces) for the forward / data-gradient contractions, 3 for the
+        # weight gradients (a third of the FLOPs) in the engine's default mode (two fp16 pieces, WN_FLAG_DW_F16PAIR)
+        from pytorchwavenetvocoder_amd import _lib
+        from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS
+        eflags = int(os.environ.get("WN_ENGINE_FLAGS", str(DEFAULT_FLAGS)), 0)
+        dw_half = bool(eflags & (_lib.FLAG_DW_F16PAIR | _lib.FLAG_DW_3PRODUCT))
+        products = (2.0 * SPLIT_PRODUCTS + (DW_PRODUCTS if dw_half else SPLIT_PRODUCTS)) / 3.0
+        peak = BF16_MFMA_PEAK / products
         out["recipe_size"]["frac_of_split_matrix_peak"] = rs["approx_train_tflops"] * 1e12 / peak
         out["recipe_size"]["roofline"] = {"bound": "mfma", "achieved": rs["approx_train_tflops"], "peak": peak / 1e12,
                                           "unit": "TFLOP/s", "frac": rs["approx_train_tflops"] * 1e12 / peak,
-                                          "note": "fp32-equivalent work against the dense bf16 peak / 6 products of the 3-way split"}
+                                          "products_per_multiply": products,
+                                          "note": "fp32-equivalent work against the dense 16-bit MFMA peak / the products per multiply of "
+                                                  "the operand split (6 for forward and data gradients, 3 for the weight gradients "
+                                                  "in the default mode: %.1f on average)" % products}
     except Exception as e:  # noqa: BLE001 -- the extras never take the headline line down
         out["error"] = repr(e)
     return out

@@ -62,7 +62,7 @@ def split_h2(x, s):
     xs = x * s; h_ = hf(xs); l = hf(xs - h_); return h_, l
 def contract(a, b):  # a (B,M,T), b (B,N,T) -> (M,N) in fp64
     return torch.einsum("bmt,bnt->mn", a.double(), b.double())
-def study(name, A, Bm, E=6):
+def study(name, A, Bm, E=8):   # E = WN_DW_F16_HEADROOM of include/wavenet_hip.h, then 64 x less and 64 x more
     A = A.detach(); Bm = Bm.detach()
     ex = contract(A, Bm)
     amax = float(A.abs().max()); arms = float(A.pow(2).mean().sqrt())
