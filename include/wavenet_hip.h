@@ -121,7 +121,8 @@ enum {
                                * products of the 3-way operand split (h h + h m + m h; two bf16 pieces per operand: relative error
                                * ~2^-16 per product, random in sign, instead of 2^-24).  Never applied to a contraction whose
                                * output feeds another layer.  Default off: every contraction fp32-equivalent. */
-#define WN_FLAG_DW_F16PAIR (1 << 19) /* wn_backward / wn_backward_window (since ABI v8, opt-in): the weight-gradient contractions split
+#define WN_FLAG_DW_F16PAIR (1 << 19) /* wn_backward / wn_backward_window (since ABI v8; opt-in at this boundary, where flags = 0 means six
+                               * bf16 products everywhere -- the Python engine sets it by default): the weight-gradient contractions split
                                * their operands into TWO fp16 pieces (11 + 11 significand bits) and take the three products
                                * h h + h l + l h on v_mfma_f32_32x32x16_f16: ~2^-22 relative per product -- below the rounding of an
                                * fp32 running sum over a minibatch's positions -- at half the matrix work of the six bf16 products.

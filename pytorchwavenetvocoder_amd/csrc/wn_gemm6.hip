@@ -1176,11 +1176,17 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
     if (F16 && nonfinite) wn_store_coherent_int(ovf, 1);
 }
 
-// 256-row tiles for the weight gradients of wide models (>= 512 x 512 outputs: n_resch = 512 gives -2 % per step,
-// profiles/r02/ab_probe_dw_tall.txt); at 256 output rows (skip / post-net gradients of the 64/256 model) they measured
-// 0.06 - 0.1 ms SLOWER than 128 x 128 tiles at 3 workgroups per CU, so those keep the square tile.  The split-K plan of
-// the caller must use the same rule.
-int wn_gemm6_dw_tall(int M, int N) { return M >= 512 && (M % 256 == 0) && N >= 512; }
+// 256-row tiles (k_gemm6_dw<4,2>): every B row is read once per 256 A rows.  Round 2 took them for >= 512 output rows only -- at
+// 256 rows (the skip gradient: 256 x 1920, k = every position) they measured 0.06 - 0.1 ms SLOWER than 128 x 128 tiles at 3
+// workgroups per CU, and no different with this round's operand mapping under six products (0.80 ms either way): the launch was
+// matrix-bound.  With the three products of the fp16 pair split it is not: two 128-row tiles read z of every layer twice
+// (~3.2 GB at 5.5 TB/s), one 256-row tile once -- dw_skip 0.563 -> 0.501 ms, recipe size 2.38 -> 1.85, configs[3] geometry
+// 0.57 -> 0.49 (same box, profiles/r05/abk_tall256_f16.txt, dw3_probe_tall256_f16.txt).  The split-K plan of the caller must use
+// the same rule (-DWN_DW_TALL_MIN_M=512: A/B builds).
+#ifndef WN_DW_TALL_MIN_M
+#define WN_DW_TALL_MIN_M 256
+#endif
+int wn_gemm6_dw_tall(int M, int N) { return M >= WN_DW_TALL_MIN_M && (M % 256 == 0) && N >= 512; }
 // 256 x 256 tiles, one wave per SIMD (k_gemm6_dw<4,4>): square weight gradients of wide models (-DWN_DW_BIG=0: A/B builds)
 #ifndef WN_DW_BIG
 #define WN_DW_BIG 1

@@ -906,3 +906,15 @@ def test_weight_gradients_by_the_fp16_pair_split_and_their_overflow_redo():
     assert torch.equal(eng.backward(dl, dlogits_bound=2.0 ** -40).clone(), res["six"])
     assert torch.equal(eng.backward(dl.clone()).clone(), res["six"])     # not the tensor the loss call returned: no bound, no fp16
     # (the word is cleared per call, in-place modified gradients, the caller's own bound: tests/test_gpu_dw_f16pair.py)
+
+
+def test_skip_gradient_on_the_256_row_tile():
+    """n_skipch = 256 with L * n_resch >= 512: the skip weight gradient (256 x 512, k = every position) takes the 256 x 128 tile
+    k_gemm6_dw<4,2> (wn_gemm6_dw_tall, since round 5 from 256 output rows on: z of every layer is read once), in the default
+    arithmetic (fp16 pair split) and with six bf16 products, ragged k-chunks and the interior fast pass -- every gradient
+    against the oracle."""
+    from pytorchwavenetvocoder_amd import _lib
+    cfg_t = (32, 4, 64, 256, 4, 2, 2, 16)
+    for flags in (None, _lib.FLAG_AUX_FUSED):
+        e, g = PC.run_oracle_vs_engine(cfg_t, 1, 400, 71, emu_library(), "cpu", flags=flags, scale=0.1)
+        assert g <= 2e-5, (flags, g)
