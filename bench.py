@@ -258,8 +258,12 @@ def extra_workloads(*release):
                                   n_mixture=10)
         out["configs3_mol"] = {k: m3[k] for k in ("model", "B", "T", "rf", "ms_per_step", "samples_per_sec")}
         out["configs3_mol"]["note"] = "mixture-of-logistics head: not in the reference (parity unpinned by it)"
-        rs = recipe_bench.measure(resch=512, kernel_size=2, upsampling=80, T=23040, batch=4, steps=3, with_kernels=False)
+        rs = recipe_bench.measure(resch=512, kernel_size=2, upsampling=80, T=23040, batch=4, steps=3, with_kernels=True)
         out["recipe_size"] = {k: rs[k] for k in ("model", "B", "T", "rf", "ms_per_step", "samples_per_sec", "approx_train_tflops")}
+        # per-launch-tag HIP-event times of ONE extra step (serial, like `kernels` of the headline); the counters of this workload
+        # (traffic, MFMA utilisation per kernel) are committed as profiles/r05/pmc_traffic_recipe.json / pmc_mfma_recipe.json
+        out["recipe_size"]["kernels"] = {k: {"launches": v["launches"], "ms": v["ms"], "tflops": v["tflops"]}
+                                         for k, v in list(rs.get("kernels", {}).items())[:10]}
         # products per multiply of this run's arithmetic: 6 (three bf16 pieces) for the forward / data-gradient contractions, 3 for the
         # weight gradients (a third of the FLOPs) in the engine's default mode (two fp16 pieces, WN_FLAG_DW_F16PAIR)
         from pytorchwavenetvocoder_amd import _lib
