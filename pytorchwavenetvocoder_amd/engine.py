@@ -8,6 +8,7 @@ PyTorch is used here only for device memory, streams and (in ``DataParallelReduc
 import ctypes
 import os
 import warnings
+import weakref
 
 import torch
 
@@ -77,7 +78,7 @@ class WaveNetEngine(object):
         self._fwd_window = 0      # first loss position of the last forward_loss (0: a full forward)
         self._fwd_version = None  # parameter version the last forward packed its weight sets from
         self._fwd_flags = 0       # launch-mode flags of the last forward
-        self._dlogits_bound = None  # (data_ptr, version, max |dlogits|) of the gradient the last loss call of this engine made
+        self._dlogits_bound = None  # (weak reference, version, max |dlogits|) of the gradient tensor the last loss call of this engine made
         self._params_epoch = 0    # bumped by every in-library parameter update (adam_step): torch cannot see those
         self._version_sources = ()  # tensors aliasing flat_params whose in-place version counters count as well
         self.ws_finite = True     # workspace() allocates zero-filled memory -> WN_FLAG_WS_FINITE (tests clear it)
@@ -237,9 +238,23 @@ class WaveNetEngine(object):
     def _note_bound(self, dlogits, grad_scale, count):
         # a mean softmax cross-entropy over `count` positions has |d loss / d logit| <= grad_scale / count: what backward() needs
         # to know to take the fp16 pair split of the weight gradients (WN_FLAG_DW_F16PAIR)
+        # (the tensor OBJECT is remembered, weakly: an address could be handed out again by the caching allocator)
         self._dlogits_bound = None
         if dlogits is not None and count > 0 and grad_scale != 0.0:
-            self._dlogits_bound = (dlogits.data_ptr(), dlogits._version, abs(float(grad_scale)) / count)
+            self._dlogits_bound = (weakref.ref(dlogits), dlogits._version, abs(float(grad_scale)) / count)
+
+    def _dw_mode_flags(self, flags, dlogits, dlogits_bound=None):
+        """FLAG_DW_F16PAIR needs max |dlogits|: the caller's word, or the bound noted for exactly this tensor object in exactly
+        this state (no in-place write since the loss call); otherwise the flag is dropped (six bf16 products)."""
+        if not (flags & _lib.FLAG_DW_F16PAIR):
+            return flags
+        flags &= ~(63 << _lib.DW_F16_EXP_SHIFT)
+        nb = self._dlogits_bound
+        if dlogits_bound is None and nb is not None and nb[0]() is dlogits and nb[1] == dlogits._version:
+            dlogits_bound = nb[2]
+        if dlogits_bound is None:
+            return flags & ~_lib.FLAG_DW_F16PAIR
+        return flags | _lib.dw_f16_exp(float(dlogits_bound))
 
     def loss(self, logits, target, t_start=None, grad_scale=1.0, loss_scale=1.0, want_grad=True):
         """Softmax-CE over positions >= t_start (default: receptive field).  Returns (loss, dlogits)."""
@@ -276,6 +291,7 @@ class WaveNetEngine(object):
                                   float(loss_scale), int(num_classes), float(log_scale_min), _ptr(loss), _ptr(dout),
                                   _ptr(ws), ws.numel() * 4, _stream_handle(self.device))
         self.lib.check(rc, "wn_mol_loss")
+        self._dlogits_bound = None   # (the mixture head's gradient has no such bound: six bf16 products for its weight gradients)
         return loss, dout
 
     def backward(self, dlogits, events=None, layers_per_bucket=0, t_first=None, repack=False, dlogits_bound=None):
@@ -303,15 +319,7 @@ class WaveNetEngine(object):
         if (flags ^ self._fwd_flags) & family:
             raise _lib.WnError("engine.flags changed the kernel family (NO_FUSED / EXACT_MFMA) since the forward call: the "
                                "two families save different activations and weight sets -- run forward again")
-        if flags & _lib.FLAG_DW_F16PAIR:
-            flags &= ~(63 << _lib.DW_F16_EXP_SHIFT)
-            nb = self._dlogits_bound
-            if dlogits_bound is None and nb is not None and nb[0] == dlogits.data_ptr() and nb[1] == dlogits._version:
-                dlogits_bound = nb[2]
-            if dlogits_bound is None:
-                flags &= ~_lib.FLAG_DW_F16PAIR
-            else:
-                flags |= _lib.dw_f16_exp(float(dlogits_bound))
+        flags = self._dw_mode_flags(flags, dlogits, dlogits_bound)
         if repack:
             flags |= _lib.FLAG_REPACK
         elif self._fwd_version is not None and self._fwd_version != self.params_version():

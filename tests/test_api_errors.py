@@ -133,3 +133,38 @@ def test_missing_library_fails_loudly():
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
     assert r.returncode != 0
     assert "libwavenet_hip" in r.stderr
+
+
+def test_fp16_pair_mode_needs_the_bound_of_exactly_the_tensor_the_loss_call_returned():
+    """engine._dw_mode_flags (host logic of WN_FLAG_DW_F16PAIR): the exponent field comes from the bound noted for the tensor
+    OBJECT a loss call returned, in the state it was returned in; any other tensor -- another object at the same address (the
+    caching allocator hands addresses out again), a view, a tensor written in place -- drops the flag unless the caller gives
+    its own bound; without the flag nothing is touched."""
+    import torch
+    from tests.emu_util import emu_library
+    from pytorchwavenetvocoder_amd import _lib
+    from pytorchwavenetvocoder_amd.engine import WaveNetEngine
+    eng = WaveNetEngine(32, 4, 16, 16, 2, 1, 2, 4, device="cpu", library=emu_library())
+    F = _lib.FLAG_AUX_FUSED | _lib.FLAG_DW_F16PAIR
+    dl = torch.zeros(1, 32, 8)
+    assert eng._dw_mode_flags(F, dl) == _lib.FLAG_AUX_FUSED                 # nothing noted yet
+    eng._note_bound(dl, 1.0, 1000)                                          # |dlogits| <= 1e-3 -> e = 9
+    want = F | (9 << _lib.DW_F16_EXP_SHIFT)
+    assert eng._dw_mode_flags(F, dl) == want
+    assert eng._dw_mode_flags(F | (63 << _lib.DW_F16_EXP_SHIFT), dl) == want   # a stale exponent in the flag word is replaced
+    assert eng._dw_mode_flags(F, dl.view(1, 32, 8)) == _lib.FLAG_AUX_FUSED   # same memory, another object
+    assert eng._dw_mode_flags(F, dl.clone()) == _lib.FLAG_AUX_FUSED
+    assert eng._dw_mode_flags(F, dl.clone(), dlogits_bound=0.3) == F | (1 << _lib.DW_F16_EXP_SHIFT)
+    assert eng._dw_mode_flags(_lib.FLAG_AUX_FUSED, dl) == _lib.FLAG_AUX_FUSED
+    dl.add_(1.0)                                                            # written in place: the bound is void
+    assert eng._dw_mode_flags(F, dl) == _lib.FLAG_AUX_FUSED
+    eng._note_bound(dl, 0.5, 1000)
+    keep = eng._dw_mode_flags(F, dl)
+    assert keep == F | (10 << _lib.DW_F16_EXP_SHIFT)
+    del dl
+    other = torch.zeros(1, 32, 8)                                           # the noted tensor is gone; whatever takes its place does not inherit
+    assert eng._dw_mode_flags(F, other) == _lib.FLAG_AUX_FUSED
+    eng._note_bound(other, 0.0, 1000)                                       # grad_scale 0: no bound
+    assert eng._dw_mode_flags(F, other) == _lib.FLAG_AUX_FUSED
+    with pytest.raises(ValueError):
+        eng._dw_mode_flags(F, other, dlogits_bound=0.0)
