@@ -871,7 +871,7 @@ def test_persistent_decode_residency_check_and_fall_backs(monkeypatch):
 
 def test_weight_gradients_by_the_fp16_pair_split_and_their_overflow_redo():
     """WN_FLAG_DW_F16PAIR (csrc/wn_gemm6.hip k_gemm6_dw<.., F16>): two fp16 pieces per operand, three products, the gradient
-    operand scaled by 2^(e + 8) from the caller's bound max |dlogits| <= 2^-e.  Against the six-bf16-product default: within
+    operand scaled by 2^(e + 8) from the caller's bound max |dlogits| <= 2^-e.  Against the six-bf16-product mode: within
     1e-6 of the largest gradient (the three-bf16-product mode: ~2e-6 ... 1e-5); every fp16 launch is followed by ONE conditional
     six-product launch; a bound far too small drives the scaled gradients out of fp16's range -> the overflow word -> the redo
     launches do the work: the default's result bit for bit; a gradient tensor the engine has no bound for never takes the mode.

@@ -1,9 +1,9 @@
 # -*- coding: utf-8 -*-
 """WN_FLAG_DW_F16PAIR on the GPU (through the C ABI): the weight-gradient contractions with the fp16 pair split (two fp16
 pieces per operand, three products on v_mfma_f32_32x32x16_f16; csrc/wn_gemm6.hip k_gemm6_dw<.., F16>) against EVERY gate of the
-default six-bf16-product mode -- the golden gradients (1e-4 of a tensor's maximum) and the golden weights after the Adam steps
+six-bf16-product mode -- the golden gradients (1e-4 of a tensor's maximum) and the golden weights after the Adam steps
 (1e-2 lr: the gate the three-bf16-product mode WN_FLAG_DW_3PRODUCT misses) of reference train.py:527-540 --, the overflow
-fall-back (a gradient outside fp16's range makes the conditional six-product launches do the work: the default mode's result
+fall-back (a gradient outside fp16's range makes the conditional six-product launches do the work: the six-product mode's result
 bit for bit) and the rule that the mode needs the caller's bound on dlogits."""
 import pytest
 import torch
