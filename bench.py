@@ -25,8 +25,14 @@ Prints ONE JSON line (rank 0).  Extra blocks:
                 its 8(d) algorithmic bytes per launch and the fraction of the HBM roof they amount to (`frac_alg`),
                 its compulsory bytes (every operand of the launch once) as bandwidth utilisation (`bw_util`), PMC
                 bytes per launch, and the matrix-core fraction of its FLOPs.
-  cpu_baseline  the CPU oracle (oracle/wavenet_oracle.py = the reference's torch CPU ops) timed on this host's cores
-                on a bounded sample: B=1 and B=8 windows of the same model (thread count calibrated, core count stated).
+  cpu_baseline  the reference's OWN module (oracle/_ref/wavenet.py, a build-time copy; kind "reference" -- without the copy
+                the restatement oracle/wavenet_oracle.py, kind "port") under its training loop train.py:527-540, timed on this
+                host's cores on a bounded sample: B=1 windows (thread count calibrated, core count stated) and the benchmark's
+                OWN B=8 minibatch and initial weights.
+  parity        north_star's gate in the same job: the first B=8 reference step above runs on the SAME x, h, t and the SAME
+                initialize()d state_dict as the timed GPU model; the HIP step (wn_forward logits, wn_forward_loss, wn_backward_window,
+                wn_adam_step) is compared with it -- logits_maxabs, loss_abs, worst_grad_rel (+ key), after_adam_maxabs_over_lr --
+                in the default arithmetic and with six bf16 products for the weight gradients (oracle/same_run_parity.py).
 """
 import argparse
 import ctypes
@@ -72,7 +78,18 @@ def geometry(rf, batch_length, U):
     return bl, frames, frames * U
 
 
-def cpu_baseline(seconds_budget=30.0):
+def synthetic_minibatch(B, T, frames, rank):
+    """The benchmark's synthetic minibatch (CPU tensors): x, t = consecutive tokens of one random sequence per window
+    (train.py:223-224), h ~ N(0, 1) (standardised features, train.py:464-470); one generator per rank."""
+    gen = torch.Generator().manual_seed(1234 + rank)
+    xx = torch.randint(0, CFG2["n_quantize"], (B, T + 1), generator=gen)
+    x = xx[:, :-1].contiguous()
+    t = xx[:, 1:].contiguous()
+    h = torch.randn(B, CFG2["n_aux"], frames, generator=gen)
+    return x, h, t
+
+
+def cpu_baseline(seconds_budget=30.0, bench_instance=None):
     """The reference's own CPU path on this host's cores.
 
     ``kind: "reference"``: the reference's WaveNet module itself (oracle/_ref/wavenet.py, a build-time copy made by
@@ -82,7 +99,11 @@ def cpu_baseline(seconds_budget=30.0):
 
     Bounded sample (~30 s): the thread count is calibrated on B=1 windows of the same model (oneDNN convs of this size
     get SLOWER with hundreds of threads), then B=1 and the benchmark's own B=8 minibatch are timed at that count
-    (SURVEY.md 8d asks for both).  `value` is the better of the two rates."""
+    (SURVEY.md 8d asks for both).  `value` is the better of the two rates.
+
+    ``bench_instance`` = (init_state, x, h, t) of the GPU benchmark (CPU tensors): the B=8 leg then runs on EXACTLY that instance
+    -- its first step (the warm-up of the timing) is the reference side of the same-run parity gate.  Returns (block, ref) with
+    ref = oracle.same_run_parity.reference_step's dict (None without ``bench_instance``)."""
     from oracle import ref_step as RS
     from oracle import wavenet_oracle as O
     try:
@@ -130,11 +151,30 @@ def cpu_baseline(seconds_budget=30.0):
     # the benchmark's own minibatch (B = 8): a step takes ~15 - 20 s on this kind of host (the reference's CPU path does not
     # scale with the batch: 60x the B = 1 step): ONE warm-up step (first-touch of the 8x larger buffers, oneDNN primitives
     # of these shapes), then one timed step -- both reported, `value` of the block from the timed one
-    x8, h8, t8 = O.synthetic_batch(cfg, BATCH_PER_GPU, T, 2)
-    warm8 = timed(x8, h8, t8)
-    t8s = [timed(x8, h8, t8)]
-    b8 = {"B": BATCH_PER_GPU, "steps": len(t8s), "warmup_s": warm8, "best_s": min(t8s), "median_s": sorted(t8s)[len(t8s) // 2],
-          "value": BATCH_PER_GPU * (T - cfg.receptive_field) / min(t8s)}
+    ref = None
+    if bench_instance is not None:
+        from oracle import same_run_parity as SRP
+        init_state, x8, h8, t8 = bench_instance
+        # The benchmark's own weights and minibatch, ONE training step from the initial state, twice: the warm-up evaluation with
+        # another thread count (its distance from the timed one = the reference's own reproducibility: parity.reference_self_noise),
+        # then the TIMED evaluation at the calibrated thread count -- the reference side of the parity gate.
+        alt_thr = max(1, best_thr // 2) if best_thr > 1 else 2
+        ref_alt = SRP.reference_step(cfg_t, init_state, x8, h8, t8, lr=1e-4, threads=alt_thr, keep_forward=False)
+        warm8 = ref_alt["seconds"]
+        ref_alt["trainer"] = None
+        ref = SRP.reference_step(cfg_t, init_state, x8, h8, t8, lr=1e-4, threads=best_thr)
+        ref["trainer"] = None
+        ref["self_noise"] = SRP.reference_self_noise(ref_alt, ref, lr=1e-4)
+        del ref_alt
+        t8s = [ref["seconds"]]
+    else:
+        x8, h8, t8 = O.synthetic_batch(cfg, BATCH_PER_GPU, T, 2)
+        warm8 = timed(x8, h8, t8)
+        t8s = [timed(x8, h8, t8)]
+    B8 = int(x8.size(0))
+    b8 = {"B": B8, "steps": len(t8s), "warmup_s": warm8, "best_s": min(t8s), "median_s": sorted(t8s)[len(t8s) // 2],
+          "value": B8 * (T - cfg.receptive_field) / min(t8s),
+          "instance": "the GPU benchmark's own x, h, t and initialize()d weights" if ref is not None else "synthetic_batch seed 2"}
     best = max((b1, b8), key=lambda b: b["value"])
     what = ("the reference's own WaveNet module (wavenet_vocoder/nets/wavenet.py, build-time copy in oracle/_ref) under its "
             "training loop train.py:527-540" if kind == "reference" else
@@ -146,7 +186,7 @@ def cpu_baseline(seconds_budget=30.0):
                       "windows of T=%d; threads calibrated over %s -> %d; B=1: %d steps, best %.3f s; B=8 (the headline's minibatch; one warm-up step, one timed): %s; "
                       "value = the better rate (B=%d); %.0f s of CPU work" % (
                           what, T, cands, best_thr, b1["steps"], b1["best_s"], "%.3f s" % b8["best_s"], best["B"],
-                          time.time() - t_begin)}
+                          time.time() - t_begin)}, ref
 
 
 def decode_report(model, device, with_cpu):
@@ -325,6 +365,41 @@ def check_aux_fused(model, x, h, t, tol=1e-5):
     return worst <= tol, worst
 
 
+def same_run_parity(model, ref, inst, layers_per_bucket):
+    """north_star: "outputs match the reference PyTorch CPU forward on identical inputs within 1e-4 fp32, with the reference
+    CPU path timed in the same run".  ``ref`` = the reference module's ONE training step (train.py:527-540) on the benchmark's
+    own x, h, t from the benchmark's own initialize()d state_dict (the warm-up step of cpu_baseline's B=8 timing); the HIP
+    step is repeated from the same state in the default arithmetic and with six bf16 products for the weight gradients
+    (oracle/same_run_parity.py; gates: logits 1e-4, loss 1e-5, gradients 1e-4 of a tensor's maximum, weights after Adam 1e-2 lr)."""
+    from oracle import same_run_parity as SRP
+    from pytorchwavenetvocoder_amd import _lib
+    from pytorchwavenetvocoder_amd.optim import FusedAdam
+    init_state, x, h, t = inst
+    base = int(model.engine.flags)
+    six = base & ~(_lib.FLAG_DW_F16PAIR | _lib.FLAG_DW_3PRODUCT)
+    out = {"reference": ref["kind"], "reference_step_s": ref["seconds"], "reference_threads": ref.get("threads"),
+           "reference_self_noise": ref.get("self_noise"),
+           "instance": "the timed model's initialize()d state_dict (seed 1) and the timed x, h, t (B=%d, T=%d), lr 1e-4, one Adam step"
+                       % (x.size(0), x.size(1)),
+           "method": "oracle/same_run_parity.py: HIP logits / loss / every gradient tensor / weights after Adam against the reference "
+                     "module's own step; at ReLU ties (both evaluations within 1e-5 of the kink) the HIP backward takes the "
+                     "reference's sub-gradient choice (kink_flips elements).  `pass` = all four gates as stated; "
+                     "`reference_self_noise` = the same reference step at two thread counts (its own reproducibility in the gates' "
+                     "units: the after-Adam gate of 1e-2 lr is below it at this size -- elements with |gradient| < 1e-7, where Adam's "
+                     "first update is sign-like); `after_adam_well_conditioned_pass` = every element over the gate is of that kind"}
+    try:
+        mk = lambda m, lr: FusedAdam(m, lr=lr)   # noqa: E731
+        d = SRP.gpu_step_vs_reference(model, mk, ref, x, h, t, init_state, base, lr=1e-4, layers_per_bucket=layers_per_bucket)
+        out.update(d)                              # flat: the default arithmetic (the metric's)
+        if six != base:
+            out["dw_six_products"] = SRP.gpu_step_vs_reference(model, mk, ref, x, h, t, init_state, six, lr=1e-4,
+                                                               layers_per_bucket=layers_per_bucket)
+    except Exception as e:  # noqa: BLE001 -- reported, never takes the headline line down
+        out["error"] = repr(e)
+        out["pass"] = False
+    return out
+
+
 def load_pmc_traffic(flags):
     """HBM traffic of a step / per kernel launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh), used only
     when they were taken in the launch mode of this run (`_engine_flags`)."""
@@ -356,6 +431,8 @@ def main():
                     help="gradient buckets = weight-gradient launch groups of this many layers (same for N = 1 and N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the configs[4] generation measurement")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip the same-run parity gate (the first B=8 reference step on the benchmark's own instance is then not compared)")
     ap.add_argument("--no-fused", action="store_true", help="force the layered (any-size) kernels")
     ap.add_argument("--exact-mfma", action="store_true", help="every contraction on the exact f32-input MFMA")
     ap.add_argument("--no-aux-fused", action="store_true",
@@ -399,6 +476,9 @@ def main():
     model = WaveNet(**CFG2)
     model.apply(initialize)
     model.to(device)
+    # the weights the timed steps start from: the same-run parity gate hands exactly these to the reference's module
+    want_parity = (world == 1 and not args.no_cpu_baseline and not args.no_parity)
+    init_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if want_parity else None
     if args.no_fused:
         model.engine.flags |= _lib.FLAG_NO_FUSED
     if args.exact_mfma:
@@ -408,11 +488,7 @@ def main():
     rf = model.receptive_field
     bl, frames, T = geometry(rf, BATCH_LENGTH, CFG2["upsampling_factor"])
     B = args.batch
-    gen = torch.Generator().manual_seed(1234 + rank)
-    xx = torch.randint(0, CFG2["n_quantize"], (B, T + 1), generator=gen)
-    x = xx[:, :-1].contiguous().to(device)
-    t = xx[:, 1:].contiguous().to(device)
-    h = torch.randn(B, CFG2["n_aux"], frames, generator=gen).to(device)
+    x, h, t = (v.to(device) for v in synthetic_minibatch(B, T, frames, rank))
     if world > 1:  # identical initial weights on every rank (no per-step broadcast afterwards)
         dist.broadcast(model.engine.flat_params, src=0)
 
@@ -603,7 +679,11 @@ def main():
             "roofline": roofline, "comm": comm, "kernels": kernels,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+            inst = (init_state, x.cpu(), h.cpu(), t.cpu()) if want_parity else None
+            out["cpu_baseline"], ref = cpu_baseline(bench_instance=inst)
+            if ref is not None:
+                out["parity"] = same_run_parity(model, ref, inst, args.layers_per_bucket)
+                del ref
         else:
             out["cpu_baseline"] = None
         if not args.no_decode and world == 1:
@@ -647,13 +727,17 @@ def main():
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import recipe_bench
+                prev_env = os.environ.get("WN_ENGINE_FLAGS")
                 os.environ["WN_ENGINE_FLAGS"] = str(int(six_flags))
                 r6 = recipe_bench.measure(resch=512, kernel_size=2, upsampling=80, T=23040, batch=4, steps=3, with_kernels=False)
                 out["extras"]["recipe_size_dw_six_products"] = {k: r6[k] for k in ("model", "B", "T", "ms_per_step", "samples_per_sec")}
             except Exception as e:  # noqa: BLE001
                 out["extras"]["recipe_size_dw_six_products"] = {"error": repr(e)}
             finally:
-                os.environ.pop("WN_ENGINE_FLAGS", None)
+                if prev_env is None:
+                    os.environ.pop("WN_ENGINE_FLAGS", None)
+                else:
+                    os.environ["WN_ENGINE_FLAGS"] = prev_env
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define WN_ABI_VERSION 8
+#define WN_ABI_VERSION 9
 
 /* Same fields as the constructor WaveNet(n_quantize, n_aux, n_resch, n_skipch, dilation_depth,
  * dilation_repeat, kernel_size, upsampling_factor)  -- reference wavenet.py:172-173. */
@@ -126,18 +126,32 @@ enum {
                                * their operands into TWO fp16 pieces (11 + 11 significand bits) and take the three products
                                * h h + h l + l h on v_mfma_f32_32x32x16_f16: ~2^-22 relative per product -- below the rounding of an
                                * fp32 running sum over a minibatch's positions -- at half the matrix work of the six bf16 products.
-                               * fp16 has 5 exponent bits, so the caller states the size of the gradient it hands over:
-                               * | WN_FLAG_DW_F16_EXP(e) promises max |dlogits| <= 2^-e (0 <= e <= 63; a mean cross-entropy over n
-                               * positions has |dlogits| <= grad_scale / n).  The gradient operand of every weight-gradient
-                               * contraction is multiplied by 2^(e + WN_DW_F16_HEADROOM) before the split and the result by its
-                               * inverse; activations are taken as they are.  Values down to 2^-(e+11) keep all 22 bits.  A back-
-                               * propagated gradient more than 2^(16 - WN_DW_F16_HEADROOM) times the promise leaves fp16's range:
-                               * the launch detects it (non-finite result) and a six-product launch issued right behind every
+                               * fp16 has 5 exponent bits, so the SIZE of the gradient decides the scale: the gradient operand of
+                               * every weight-gradient contraction is multiplied by 2^(e + WN_DW_F16_HEADROOM) before the split and
+                               * the result by its inverse (activations are taken as they are), where 2^-e bounds max |dlogits|.
+                               * Since ABI v9 the library MEASURES that maximum (a bound that is merely safe -- the a-priori
+                               * grad_scale / positions of a mean cross-entropy on a well-fitted model, a forgotten exponent -- would
+                               * push the scaled operand into fp16's subnormals and silently cost precision):
+                               *   WN_FLAG_DW_F16PAIR alone                      one pass over the `dlogits` given to this call (its loss
+                               *                                                  window; ~35 us at the BASELINE size) finds the maximum
+                               *   | WN_FLAG_DW_F16_AMAX_WS                       the caller vouches that `dlogits` is, unmodified, what the
+                               *                                                  last wn_forward_loss / wn_softmax_ce_loss call ON THIS
+                               *                                                  WORKSPACE wrote: those calls leave its maximum in the
+                               *                                                  workspace (their epilogue computes it for free)
+                               *   | WN_FLAG_DW_F16_EXP_VALID | WN_FLAG_DW_F16_EXP(e)   the caller's own promise max |dlogits| <= 2^-e
+                               *                                                  (0 <= e <= 63), taken as given (v8 took the exponent
+                               *                                                  field without a valid bit: e = 0 was a silent default)
+                               * The scale is decided on the device (no host synchronisation).  Values down to 2^-(e+11) keep all 22
+                               * bits.  A back-propagated gradient more than 2^(16 - WN_DW_F16_HEADROOM) times the maximum leaves fp16's
+                               * range: the launch detects it (non-finite result) and a six-product launch issued right behind every
                                * fp16 launch, which otherwise returns at once, redoes the contraction -- the result is then the
-                               * default mode's.  Wins over WN_FLAG_DW_3PRODUCT when both are set. */
+                               * default mode's; the same redo is forced when no usable maximum exists (all-zero or non-finite
+                               * gradient, WN_FLAG_DW_F16_AMAX_WS without such a loss call).  Wins over WN_FLAG_DW_3PRODUCT. */
 #define WN_FLAG_DW_F16_EXP_SHIFT 20
 #define WN_FLAG_DW_F16_EXP(e) (((e) & 63) << WN_FLAG_DW_F16_EXP_SHIFT)
 #define WN_DW_F16_HEADROOM 8
+#define WN_FLAG_DW_F16_EXP_VALID (1 << 26) /* since ABI v9: the WN_FLAG_DW_F16_EXP(e) field is the caller's promise (e = 0 included) */
+#define WN_FLAG_DW_F16_AMAX_WS (1 << 27)   /* since ABI v9: max |dlogits| as the last loss call of this workspace measured it */
 #define WN_FLAG_DW_FLUSH(n) (((n) & 0xff) << 8) /* wn_backward: issue the weight gradients of at most n walked layers per
                                * launch group (0 = default: a whole gradient bucket; 5 layers with WN_FLAG_BWD_OVERLAP).
                                * Groups never straddle a bucket.  The split-K plan of a group depends on its size, so
@@ -261,6 +275,14 @@ int wn_op_front(const float* weight, const float* bias, const int64_t* x, float*
  * weight (Cout,Cin,K) natural layout; scratch >= Cout*Cin*K floats. */
 int wn_op_causal_conv(const float* weight, const float* bias, const float* x /*(B,Cin,T)*/, float* y /*(B,Cout,T)*/,
                       float* scratch, int B, int T, int Cin, int Cout, int K, int dilation, void* stream);
+
+/* Backward of CausalConv1d (since ABI v9; the reference's module is an ordinary differentiable nn.Module, wavenet.py:95-121 --
+ * autograd of Conv1d + slice): dx (B,Cin,T), dw (Cout,Cin,K), db (Cout) from dy (B,Cout,T); any of the three may be NULL.
+ * Exact f32 matrix-core contractions, weight gradient as per-(sequence, time-chunk) partials summed in a fixed order.
+ * scratch >= wn_op_causal_conv_backward_scratch_floats(B, T, Cin, Cout, K) floats. */
+long wn_op_causal_conv_backward_scratch_floats(int B, int T, int Cin, int Cout, int K);
+int wn_op_causal_conv_backward(const float* weight, const float* x, const float* dy, float* dx, float* dw, float* db,
+                               float* scratch, int B, int T, int Cin, int Cout, int K, int dilation, void* stream);
 
 /* UpSampling.forward (wavenet.py:124-154, since ABI v7): y (B, C, F*U) = x (B, C, F) through the (1, U) transposed
  * convolution with ONE kernel `weight` [U] and scalar `bias` (nullable) shared by all channels. */

@@ -78,20 +78,25 @@ FLAG_WS_FINITE = 1 << 16  # wn_forward_loss: the workspace holds only finite val
 DECODE_BY_LAUNCHES = 256  # wn_decode_layered_*: mode bit that keeps the layer-wise launches (csrc/wn_dlp.hip otherwise)
 DECODE_GRANULES = 512  # wn_decode_layered_*: mode bit, the persistent launches hand over 8-byte granules everywhere (A/B, tests)
 FLAG_DW_3PRODUCT = 1 << 18  # wn_backward: weight gradients (leaf results) with 3 of the 6 products of the operand split (opt-in)
-FLAG_DW_F16PAIR = 1 << 19  # wn_backward: weight gradients by the fp16 pair split (needs | dw_f16_exp(e): max |dlogits| <= 2^-e)
+FLAG_DW_F16PAIR = 1 << 19  # wn_backward: weight gradients by the fp16 pair split; its scale from max |dlogits|: measured by a scan of the
+#                            given tensor (flag alone), as the loss call of the workspace left it (| FLAG_DW_F16_AMAX_WS), or the caller's
+#                            promise (| dw_f16_exp(bound), which carries FLAG_DW_F16_EXP_VALID)
 DW_F16_EXP_SHIFT = 20
 DW_F16_HEADROOM = 8
+FLAG_DW_F16_EXP_VALID = 1 << 26
+FLAG_DW_F16_AMAX_WS = 1 << 27
 
 
 def dw_f16_exp(bound):
-    """WN_FLAG_DW_F16_EXP(e) for a gradient with max |dlogits| <= bound: the largest e in [0, 63] with bound <= 2^-e."""
+    """WN_FLAG_DW_F16_EXP_VALID | WN_FLAG_DW_F16_EXP(e) for a gradient with max |dlogits| <= bound: the largest e in [0, 63] with
+    bound <= 2^-e."""
     import math
     if not (bound > 0.0) or math.isinf(bound):
         raise ValueError("bound must be a positive finite number")
     e = int(math.floor(-math.log2(bound)))
     while e > 0 and bound > 2.0 ** -e:    # (floating-point log2 at an exact power of two)
         e -= 1
-    return (max(0, min(63, e)) & 63) << DW_F16_EXP_SHIFT
+    return ((max(0, min(63, e)) & 63) << DW_F16_EXP_SHIFT) | FLAG_DW_F16_EXP_VALID
 
 
 FLAG_REPACK = 1 << 17  # wn_backward: rebuild the packed / pre-split weight sets from the params given to that call
@@ -102,13 +107,13 @@ def flag_dw_flush(n):
     return (int(n) & 0xff) << 8
 
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # every symbol include/wavenet_hip.h declares
 EXPORTS = [
     "wn_abi_version", "wn_last_error", "wn_receptive_field", "wn_num_layers", "wn_param_count", "wn_param_offset",
     "wn_num_buckets", "wn_bucket_range", "wn_dead_param_range", "wn_workspace_bytes", "wn_workspace_region", "wn_forward",
-    "wn_softmax_ce_loss", "wn_forward_loss_fused", "wn_forward_loss", "wn_backward", "wn_backward_window", "wn_adam_step", "wn_op_front", "wn_op_causal_conv", "wn_op_upsampling", "wn_op_transpose_last2", "wn_decode_layered_residency", "wn_op_gemm", "wn_prof_enable", "wn_prof_report", "wn_prof_sequence",
+    "wn_softmax_ce_loss", "wn_forward_loss_fused", "wn_forward_loss", "wn_backward", "wn_backward_window", "wn_adam_step", "wn_op_front", "wn_op_causal_conv", "wn_op_causal_conv_backward", "wn_op_causal_conv_backward_scratch_floats", "wn_op_upsampling", "wn_op_transpose_last2", "wn_decode_layered_residency", "wn_op_gemm", "wn_prof_enable", "wn_prof_report", "wn_prof_sequence",
     "wn_decode_supported", "wn_decode_pack_floats", "wn_decode_state_floats", "wn_decode_pack", "wn_decode_aux",
     "wn_decode_steps", "wn_decode_stream_bytes",
     "wn_decode_layered_state_floats", "wn_decode_layered_error_offset", "wn_decode_layered_prepare", "wn_decode_layered_steps", "wn_mol_loss",
@@ -159,6 +164,9 @@ class WnLibrary(object):
         L.wn_adam_step.argtypes = [vp, vp, vp, vp, i64, i64, f, f, f, f, f, i64, i64, vp]
         L.wn_op_front.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, vp]
         L.wn_op_causal_conv.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
+        L.wn_op_causal_conv_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, vp]
+        L.wn_op_causal_conv_backward_scratch_floats.argtypes = [i, i, i, i, i]
+        L.wn_op_causal_conv_backward_scratch_floats.restype = i64
         L.wn_op_upsampling.argtypes = [vp, vp, vp, vp, i, i, i, i, vp]
         L.wn_op_transpose_last2.argtypes = [vp, vp, i, i, i, vp]
         L.wn_op_gemm.argtypes = [ctypes.POINTER(WnGemmArgs), vp]

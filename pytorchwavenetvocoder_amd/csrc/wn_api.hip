@@ -383,6 +383,7 @@ struct Ws {
     long X, G, Sg, Gt, Z, O1, O2;
     // scratch
     long P, dO2, dSk, dZ, dXall, dG, dw_partial, dc, tmpS, partial, rs_partial, red_scratch, loss_partial;
+    long amax_partial, amax_partial_floats;
     long dw_ovf;   // one word (of 64): raised by an fp16-pair weight-gradient launch whose result was not finite (WN_FLAG_DW_F16PAIR)
     long dGp, qp;  // aux-gradient partials of the gate kernel (WN_FLAG_AUX_FUSED); 0 floats when the mode cannot apply
     long img_fwd, img_taps, img_res, img_floats;  // pre-split LDS weight images of the fused split kernels (0 floats: not applicable)
@@ -478,7 +479,10 @@ static int make_ws(const Dims& d, int B, int T, Ws* w, bool training = true) {
     w->red_scratch_floats = 1 << 20;
     CARVE(red_scratch, w->red_scratch_floats);
     CARVE(loss_partial, 2 * wn_softmax_ce_nblocks(B, T) + 64);   // CE epilogue: one partial per 128-column block
-    CARVE(dw_ovf, 64);
+    CARVE(dw_ovf, 64);   // [0] overflow word, [1] a_mul, [2] max |dlogits| of the last loss call (wn_dw_prepare, wn_elem.h)
+    // block maxima of |dlogits|: one per loss block (the loss calls), or one per (row, 4096 columns) of a dlogits scan (wn_backward)
+    w->amax_partial_floats = 2 * wn_softmax_ce_nblocks(B, T) + 64 + (long)B * d.Qo * ((T + 4095) / 4096);
+    CARVE(amax_partial, w->amax_partial_floats);
     w->front_partial_floats = wn_front_dw_supported(d.R, d.K, d.Q) ? wn_front_dw_partial_floats(B, T, d.R, d.K, d.Q) : 0;
     CARVE(front_partial, w->front_partial_floats);
     {   // split-bf16 weights of the forward-type contractions (wn_gemm6): one buffer, re-packed before each use
@@ -563,7 +567,10 @@ struct Ctx {
     bool fused;
     bool split_bf16;  // forward-type contractions on the bf16 matrix cores (3-way split, fp32-equivalent)
     int dw_products;  // products per multiply of the weight-gradient contractions: 6, or 3 with WN_FLAG_DW_3PRODUCT
-    float dw_f16_mul; // > 0 (WN_FLAG_DW_F16PAIR): weight gradients by the fp16 pair split, gradient operand times this power of two;
+    int dw_f16_mode;  // WN_FLAG_DW_F16PAIR: 0 off; 1 the caller's exponent (| WN_FLAG_DW_F16_EXP_VALID); 2 max |dlogits| as the loss call of
+                      // this workspace measured it (| WN_FLAG_DW_F16_AMAX_WS); 3 measured by a scan of the dlogits given to wn_backward
+    float dw_f16_mul; // != 0 (WN_FLAG_DW_F16PAIR): weight gradients by the fp16 pair split; -1: the gradient operand times the power of two
+                      // wn_dw_prepare leaves in the workspace (every mode: one code path);
     int* dw_ovf;      // their overflow word (workspace): a raised word makes the six-product launch behind each of them do the work
     const float* params;   // set by the training entry points: lets fw_gemm recognise the pre-split weight sets
     bool have_pre;         // apk_pre[] of this workspace is valid (regular layout, not the decode state)
@@ -584,7 +591,8 @@ static int make_ctx(Ctx* c, const WnConfig* cfg, int B, int T, void* ws, size_t 
     c->fused = wn_fused_supported(c->d.R, c->d.K, c->d.S) && !(flags & WN_FLAG_NO_FUSED);
     c->split_bf16 = !(flags & WN_FLAG_EXACT_MFMA);
     c->dw_products = (flags & WN_FLAG_DW_3PRODUCT) ? 3 : 6;
-    c->dw_f16_mul = (flags & WN_FLAG_DW_F16PAIR) ? ldexpf(1.0f, ((flags >> WN_FLAG_DW_F16_EXP_SHIFT) & 63) + WN_DW_F16_HEADROOM) : 0.0f;
+    c->dw_f16_mode = !(flags & WN_FLAG_DW_F16PAIR) ? 0 : (flags & WN_FLAG_DW_F16_EXP_VALID) ? 1 : (flags & WN_FLAG_DW_F16_AMAX_WS) ? 2 : 3;
+    c->dw_f16_mul = c->dw_f16_mode ? -1.0f : 0.0f;
     c->dw_ovf = reinterpret_cast<int*>(c->ws + c->w.dw_ovf);
     c->params = nullptr;
     c->have_pre = true;
@@ -678,6 +686,7 @@ struct CeEpi {   // softmax cross-entropy as the epilogue of the contraction tha
     int t_start;
     float gs;
     float* partial;
+    float* amax;
 };
 // n_origin: index of column 0 of this launch in the caller's full (B, C, T) tensor (a loss-window launch starts at t0): the
 // alternating tile signs of k_gemm6 follow the ABSOLUTE column, so a windowed launch produces bit for bit what the full one
@@ -712,7 +721,7 @@ static int fw_gemm(const Ctx& c, const WnGemmArgs& g, const GateEpi* ge = nullpt
     a.n_phase = (n_origin / WN_G6_BN) & 1;
     if (ce) {
         a.ce_target = reinterpret_cast<const long long*>(ce->target); a.ce_tstride = g.ldc; a.ce_t_start = ce->t_start;
-        a.ce_gs = ce->gs; a.ce_partial = ce->partial;
+        a.ce_gs = ce->gs; a.ce_partial = ce->partial; a.ce_amax = ce->amax;
     }
     return wn_gemm6_launch(&a, c.st);
 }
@@ -984,6 +993,7 @@ static int forward_impl(const WnConfig* cfg, int B, int T, const float* params, 
             ce.target = ce_in->target + t0;     // column j of the window is position t0 + j (row stride T)
             ce.t_start = ce_in->t_start - t0;
             ce.partial = ws + w.loss_partial;
+            ce.amax = ws + w.amax_partial;
             g.tag = "fwd_post2_ce";
             WN_TRY(fw_gemm(c, g, nullptr, &ce, t0));   // g.C = the caller's dlogits (or NULL)
             if (logits && t0 > 0) WN_TRY(wn_fill_cols(logits, (long)B * d.Qo, T, t0, c.st));
@@ -1026,13 +1036,14 @@ extern "C" int wn_forward_loss(const WnConfig* cfg, int B, int T, const float* p
                                   stream);
     }
     CeEpi ce;
-    ce.target = target; ce.t_start = t_start; ce.gs = grad_scale / ((float)B * (float)(T - t_start)); ce.partial = nullptr;
+    ce.target = target; ce.t_start = t_start; ce.gs = grad_scale / ((float)B * (float)(T - t_start)); ce.partial = nullptr; ce.amax = nullptr;
     WN_TRY(forward_impl(cfg, B, T, params, x, h, dlogits, &ce, wsp, ws_bytes, flags, stream, "wn_forward_loss"));
     Ctx c;
     WN_TRY(make_ctx(&c, cfg, B, T, wsp, ws_bytes, flags, stream));
     const int t0w = (t_start / 128) * 128;   // the column window forward_impl ran the loss epilogue over
     const int np = ((T - t0w + WN_G6_BN - 1) / WN_G6_BN) * B;
-    WN_TRY(wn_sum_partials(c.ws + c.w.loss_partial, np, loss_scale / ((float)B * (float)(T - t_start)), loss, c.st));
+    WN_TRY(wn_sum_partials(c.ws + c.w.loss_partial, np, loss_scale / ((float)B * (float)(T - t_start)), loss,
+                           dlogits ? c.ws + c.w.amax_partial : nullptr, c.ws + c.w.dw_ovf + 2, c.st));   // + max |dlogits| (WN_FLAG_DW_F16_AMAX_WS)
     return rt_check("wn_forward_loss");
 }
 
@@ -1049,8 +1060,10 @@ extern "C" int wn_softmax_ce_loss(const WnConfig* cfg, int B, int T, const float
     if (t_start < 0 || t_start >= T) return fail(1, "t_start=%d outside [0,%d)", t_start, T);
     int np = 0;
     const float gs = grad_scale / ((float)B * (float)(T - t_start));
-    WN_TRY(wn_softmax_ce(logits, target, dlogits, c.ws + c.w.loss_partial, &np, B, T, c.d.Qo, t_start, gs, c.st));
-    WN_TRY(wn_sum_partials(c.ws + c.w.loss_partial, np, loss_scale / ((float)B * (float)(T - t_start)), loss, c.st));
+    WN_TRY(wn_softmax_ce(logits, target, dlogits, c.ws + c.w.loss_partial, &np, B, T, c.d.Qo, t_start, gs,
+                         dlogits ? c.ws + c.w.amax_partial : nullptr, c.st));
+    WN_TRY(wn_sum_partials(c.ws + c.w.loss_partial, np, loss_scale / ((float)B * (float)(T - t_start)), loss,
+                           dlogits ? c.ws + c.w.amax_partial : nullptr, c.ws + c.w.dw_ovf + 2, c.st));   // + max |dlogits| (WN_FLAG_DW_F16_AMAX_WS)
     return rt_check("wn_softmax_ce_loss");
 }
 
@@ -1069,7 +1082,8 @@ extern "C" int wn_mol_loss(const WnConfig* cfg, int B, int T, const float* out, 
     int np = 0;
     const float gs = grad_scale / ((float)B * (float)(T - t_start));
     WN_TRY(wn_mol_nll(out, y, dout, c.ws + c.w.loss_partial, &np, B, T, c.d.Qo / 3, t_start, gs, num_classes, log_scale_min, c.st));
-    WN_TRY(wn_sum_partials(c.ws + c.w.loss_partial, np, loss_scale / ((float)B * (float)(T - t_start)), loss, c.st));
+    // (no measured maximum for this head: a backward call with WN_FLAG_DW_F16PAIR scans the gradient it is given)
+    WN_TRY(wn_sum_partials(c.ws + c.w.loss_partial, np, loss_scale / ((float)B * (float)(T - t_start)), loss, nullptr, c.ws + c.w.dw_ovf + 2, c.st));
     return rt_check("wn_mol_loss");
 }
 

@@ -46,7 +46,7 @@ static int dw_gemm(const Ctx& c, WnGemmArgs g, const DwOut& o, int nl = 1) {
     g.C = c.ws + c.w.partial; g.ldc = g.N; g.c_zstride = (long)g.M * g.N;
     g.a_rowsum = o.rowsum_out ? c.ws + c.w.rs_partial : nullptr;
     if (c.split_bf16 && wn_gemm6_dw_eligible(&g)) {
-        if (c.dw_f16_mul > 0.0f) {
+        if (c.dw_f16_mul != 0.0f) {
             // fp16 pair split; the six-product launch behind it returns at once unless a gradient left fp16's range
             WN_TRY(wn_gemm6_dw_launch(&g, 3, c.dw_f16_mul, c.dw_ovf, c.st));
             WN_TRY(wn_gemm6_dw_launch(&g, 6, 0.0f, c.dw_ovf, c.st));
@@ -82,7 +82,21 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
     if (!params || !x || !h || !dlogits || !grads) return fail(1, "NULL argument");
     c.params = params;
     if (t_first < 0 || t_first >= T) return fail(1, "t_first=%d outside [0,%d)", t_first, T);
-    if (c.dw_f16_mul > 0.0f) WN_TRY(wn_fill(c.ws + c.w.dw_ovf, 0.0f, 64, c.st));   // before the side stream forks
+    if (c.dw_f16_mode) {   // before the side stream forks: overflow word := 0, a_mul := the scale of this call's gradient (wn_elem.h)
+        const int tw0 = (t_first / 128) * 128;
+        float* words = c.ws + c.w.dw_ovf;
+        if (c.dw_f16_mode == 1) {
+            WN_TRY(wn_dw_prepare(words, ldexpf(1.0f, ((flags >> WN_FLAG_DW_F16_EXP_SHIFT) & 63) + WN_DW_F16_HEADROOM), nullptr, 0, WN_DW_F16_HEADROOM, c.st));
+        } else if (c.dw_f16_mode == 2) {
+            WN_TRY(wn_dw_prepare(words, 0.0f, nullptr, 0, WN_DW_F16_HEADROOM, c.st));
+        } else {   // nobody vouches for the size of this gradient: one pass over it (the loss window's columns)
+            const long rows = (long)B * c.d.Qo;
+            const int nchunk = (T - tw0 + 4095) / 4096;
+            if (rows * nchunk > c.w.amax_partial_floats) return fail(1, "dlogits scan: partial buffer too small");
+            WN_TRY(wn_absmax_rows(dlogits, rows, T, tw0, T - tw0, c.ws + c.w.amax_partial, c.st));
+            WN_TRY(wn_dw_prepare(words, 0.0f, c.ws + c.w.amax_partial, (int)(rows * nchunk), WN_DW_F16_HEADROOM, c.st));
+        }
+    }
     // WN_FLAG_REPACK: `params` changed since the forward call (or the caller cannot tell): rebuild every re-laid-out /
     // pre-split weight set of the workspace from the buffer given HERE, so that the backward contractions use one
     // consistent set of weights (the saved activations are the forward pass's own either way).

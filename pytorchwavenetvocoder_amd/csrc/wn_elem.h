@@ -23,10 +23,23 @@ int wn_gate_bwd(const float* dZ, const float* S, const float* Gt, float* dP, int
 //   loss = mean_{b,t>=t_start} ( logsumexp_q - logit[target] );  dlogits = (softmax - onehot) * grad_scale
 // (zero for t < t_start).  loss_partial has one float per launched block; wn_loss_finalize sums
 // them in a fixed order and multiplies by loss_scale.
+// amax_partial (nullable): one float per launched block = the block's max |dlogits| (for the measured scale of the fp16 pair
+// split of the weight gradients, WN_FLAG_DW_F16PAIR).
 int wn_softmax_ce(const float* logits, const int64_t* target, float* dlogits /*nullable*/,
                   float* loss_partial, int* n_partial /*out: host*/, int B, int T, int Q, int t_start,
-                  float grad_scale, wn_stream_t st);
-int wn_sum_partials(const float* partial, int n, float scale, float* out /*device scalar*/, wn_stream_t st);
+                  float grad_scale, float* amax_partial, wn_stream_t st);
+// out[0] = scale * sum(partial[0..n)); amax_out (nullable): amax_out[0] = max(amax_partial[0..n)) (0 without amax_partial)
+int wn_sum_partials(const float* partial, int n, float scale, float* out /*device scalar*/, const float* amax_partial,
+                    float* amax_out, wn_stream_t st);
+// Scale of the fp16 pair split (WN_FLAG_DW_F16PAIR), decided ON THE DEVICE before the weight-gradient launches of a backward call.
+// words (workspace, >= 3 words): [0] overflow flag := 0; [1] a_mul := 2^(floor(-log2 amax) + headroom) (float); [2] amax (float).
+//   host_mul > 0 : the caller's promise: words[1] := host_mul
+//   scan != NULL : amax := max over scan[0..n_scan) (partial maxima of wn_absmax_rows), stored to words[2]
+//   otherwise    : amax = words[2] as a loss call of this workspace left it
+// amax == 0 or not finite: a_mul := 1 and words[0] := 1 -- the six-product redo behind every fp16 launch then does the work.
+int wn_dw_prepare(float* words, float host_mul, const float* scan, int n_scan, int headroom, wn_stream_t st);
+// partial[r * nchunk + c] = max |p[r * ld + c0 + 4096 c + j]|, j < min(4096, ncols - 4096 c); nchunk = ceil(ncols / 4096)
+int wn_absmax_rows(const float* p, long rows, long ld, int c0, int ncols, float* partial, wn_stream_t st);
 int wn_softmax_ce_nblocks(int B, int T);
 
 // Adam over a flat fp32 buffer (torch.optim.Adam semantics, train.py:457-460): elements in

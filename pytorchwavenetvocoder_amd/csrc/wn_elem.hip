@@ -19,6 +19,23 @@ static __device__ __forceinline__ float block_reduce_sum(float v, float* red /*[
     return t;
 }
 
+// max(a, |v|) on the bit patterns: a and |v| are sign-free, so integer order = float order with inf and NaN on top (kept)
+static __device__ __forceinline__ float wn_absmax_keep_nan(float a, float v) {
+    const int ai = __builtin_bit_cast(int, a), vi = __builtin_bit_cast(int, v) & 0x7fffffff;
+    return __builtin_bit_cast(float, vi > ai ? vi : ai);
+}
+static __device__ __forceinline__ float block_reduce_max(float v, float* red /*[4]*/) {
+    v = wave_reduce_max(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = red[0];
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 1; i < nw; ++i) t = fmaxf(t, red[i]);
+    return t;
+}
+
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WN_TPB) void k_front_gather(const int64_t* __restrict__ x, const float* __restrict__ wc_f,
                                                          const float* __restrict__ bias, float* __restrict__ x0, int T,
@@ -195,8 +212,9 @@ int wn_gate_bwd(const float* dZ, const float* S, const float* Gt, float* dP, int
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WN_TPB) void k_softmax_ce(const float* __restrict__ logits, const int64_t* __restrict__ target,
                                                        float* __restrict__ dlogits, float* __restrict__ loss_partial, int T,
-                                                       int Q, int t_start, float grad_scale) {
+                                                       int Q, int t_start, float grad_scale, float* __restrict__ amax_partial) {
     __shared__ float red[4];
+    float my_amax = 0.0f;
     const int t = blockIdx.x * WN_TPB + threadIdx.x;
     const int b = blockIdx.y;
     float my_loss = 0.0f;
@@ -236,6 +254,7 @@ __global__ __launch_bounds__(WN_TPB) void k_softmax_ce(const float* __restrict__
                         float pq = expf(v[u] - lse);
                         if (q0 + u == (int)tg) pq -= 1.0f;
                         dl[(long)(q0 + u) * T] = pq * grad_scale;
+                        my_amax = fmaxf(my_amax, fabsf(pq * grad_scale));
                     }
                 }
             }
@@ -246,31 +265,132 @@ __global__ __launch_bounds__(WN_TPB) void k_softmax_ce(const float* __restrict__
     }
     const float tot = block_reduce_sum(my_loss, red);
     if (threadIdx.x == 0) loss_partial[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+    if (amax_partial != nullptr) {
+        const float am = block_reduce_max(my_amax, red);
+        if (threadIdx.x == 0) amax_partial[blockIdx.y * gridDim.x + blockIdx.x] = am;
+    }
 }
 
 int wn_softmax_ce_nblocks(int B, int T) { return ((T + WN_TPB - 1) / WN_TPB) * B; }
 
 int wn_softmax_ce(const float* logits, const int64_t* target, float* dlogits, float* loss_partial, int* n_partial, int B,
-                  int T, int Q, int t_start, float grad_scale, wn_stream_t st) {
+                  int T, int Q, int t_start, float grad_scale, float* amax_partial, wn_stream_t st) {
     WN_PROF("softmax_ce", 0.0, 0.0, st);
     dim3 grid((T + WN_TPB - 1) / WN_TPB, B);
     if (n_partial) *n_partial = (int)(grid.x * grid.y);
-    WN_LAUNCH(k_softmax_ce, grid, dim3(WN_TPB), 0, st, logits, target, dlogits, loss_partial, T, Q, t_start, grad_scale);
+    WN_LAUNCH(k_softmax_ce, grid, dim3(WN_TPB), 0, st, logits, target, dlogits, loss_partial, T, Q, t_start, grad_scale, amax_partial);
     return 0;
 }
 
 __global__ __launch_bounds__(WN_TPB) void k_sum_partials(const float* __restrict__ partial, int n, float scale,
-                                                         float* __restrict__ out) {
+                                                         float* __restrict__ out, const float* __restrict__ amax_partial,
+                                                         float* __restrict__ amax_out) {
     __shared__ float red[4];
     float s = 0.0f;
     for (int i = threadIdx.x; i < n; i += WN_TPB) s += partial[i];
     const float tot = block_reduce_sum(s, red);
     if (threadIdx.x == 0) out[0] = tot * scale;
+    if (amax_out != nullptr) {
+        float a = 0.0f;
+        if (amax_partial != nullptr)
+            for (int i = threadIdx.x; i < n; i += WN_TPB) a = fmaxf(a, amax_partial[i]);
+        a = block_reduce_max(a, red);
+        if (threadIdx.x == 0) amax_out[0] = a;
+    }
 }
 
-int wn_sum_partials(const float* partial, int n, float scale, float* out, wn_stream_t st) {
+int wn_sum_partials(const float* partial, int n, float scale, float* out, const float* amax_partial, float* amax_out, wn_stream_t st) {
     WN_PROF("sum_partials", 0.0, 0.0, st);
-    WN_LAUNCH(k_sum_partials, dim3(1), dim3(WN_TPB), 0, st, partial, n, scale, out);
+    WN_LAUNCH(k_sum_partials, dim3(1), dim3(WN_TPB), 0, st, partial, n, scale, out, amax_partial, amax_out);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// measured scale of the fp16 pair split of the weight gradients (wn_elem.h)
+__global__ __launch_bounds__(WN_TPB) void k_dw_prepare(float* __restrict__ words, float host_mul, const float* __restrict__ scan,
+                                                       int n_scan, int headroom) {
+    __shared__ float red[4];
+    float a;
+    if (scan != nullptr) {   // maxima as bit patterns: an inf / NaN partial stays on top (-> a_mul = 1, the overflow redo takes over)
+        a = 0.0f;
+        for (int i = threadIdx.x; i < n_scan; i += WN_TPB) a = wn_absmax_keep_nan(a, scan[i]);
+        int ai = __builtin_bit_cast(int, a);
+        WN_UNROLL
+        for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(ai, m, 64); ai = o > ai ? o : ai; }
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = __builtin_bit_cast(float, ai);
+        __syncthreads();
+        ai = __builtin_bit_cast(int, red[0]);
+        for (int i = 1; i < (WN_TPB >> 6); ++i) { const int o = __builtin_bit_cast(int, red[i]); ai = o > ai ? o : ai; }
+        a = __builtin_bit_cast(float, ai);
+    } else {
+        a = words[2];
+    }
+    if (threadIdx.x != 0) return;
+    int force_redo = 0;
+    if (scan != nullptr) words[2] = a;
+    float mul = host_mul;
+    if (!(host_mul > 0.0f)) {
+        const unsigned bits = __builtin_bit_cast(unsigned, a);
+        const int ex = (int)((bits >> 23) & 0xffu);
+        if (a > 0.0f && ex != 0xff) {
+            // 2^(ex - 127) <= a < 2^(ex - 126): e = floor(-log2 a) = 126 - ex for a power of two above... take the safe side:
+            // a < 2^(ex - 126) =: 2^-e  ->  e = 126 - ex  (denormals: ex = 0 -> e = 126)
+            int e = 126 - ex + headroom;
+            e = e > 120 ? 120 : (e < -120 ? -120 : e);
+            mul = __builtin_bit_cast(float, (unsigned)(e + 127) << 23);
+        } else {
+            // no usable maximum (all-zero gradient, inf / NaN, or no loss call of this workspace measured one): the overflow word
+            // is raised up front, so the six-product launch behind every fp16 launch does the work -- never a silent underflow
+            mul = 1.0f;
+            force_redo = 1;
+        }
+    }
+    reinterpret_cast<int*>(words)[0] = force_redo;
+    words[1] = mul;
+}
+
+int wn_dw_prepare(float* words, float host_mul, const float* scan, int n_scan, int headroom, wn_stream_t st) {
+    WN_PROF("dw_prepare", 0.0, 0.0, st);
+    WN_LAUNCH(k_dw_prepare, dim3(1), dim3(WN_TPB), 0, st, words, host_mul, scan, n_scan, headroom);
+    return 0;
+}
+
+__global__ __launch_bounds__(WN_TPB) void k_absmax_rows(const float* __restrict__ p, long ld, int c0, int ncols, float* __restrict__ partial) {
+    __shared__ float red[4];
+    const long r = blockIdx.y;
+    const int lo = (int)blockIdx.x * 4096, hi = lo + 4096 < ncols ? lo + 4096 : ncols;
+    const float* row = p + r * ld + c0;
+    float a = 0.0f;
+    if (((reinterpret_cast<uintptr_t>(row + lo) & 15) == 0)) {
+        const int n4 = (hi - lo) >> 2;
+        const float4* q = reinterpret_cast<const float4*>(row + lo);
+        for (int i = threadIdx.x; i < n4; i += WN_TPB) {
+            const float4 v = q[i];
+            // a NaN must not be dropped: |v| as an integer compare keeps inf / NaN bit patterns on top
+            a = wn_absmax_keep_nan(a, v.x); a = wn_absmax_keep_nan(a, v.y); a = wn_absmax_keep_nan(a, v.z); a = wn_absmax_keep_nan(a, v.w);
+        }
+        for (int i = lo + 4 * n4 + threadIdx.x; i < hi; i += WN_TPB) a = wn_absmax_keep_nan(a, row[i]);
+    } else {
+        for (int i = lo + threadIdx.x; i < hi; i += WN_TPB) a = wn_absmax_keep_nan(a, row[i]);
+    }
+    // non-negative floats (and the inf / NaN patterns above them) order like their bit patterns
+    int ai = __builtin_bit_cast(int, a);
+    WN_UNROLL
+    for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(ai, m, 64); ai = o > ai ? o : ai; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = __builtin_bit_cast(float, ai);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = __builtin_bit_cast(int, red[0]);
+        for (int i = 1; i < (WN_TPB >> 6); ++i) { const int o = __builtin_bit_cast(int, red[i]); t = o > t ? o : t; }
+        partial[r * gridDim.x + blockIdx.x] = __builtin_bit_cast(float, t);
+    }
+}
+
+int wn_absmax_rows(const float* p, long rows, long ld, int c0, int ncols, float* partial, wn_stream_t st) {
+    WN_PROF("dw_absmax_scan", 0.0, (double)rows * ncols * 4.0, st);
+    if (rows < 1 || rows > 65535 || ncols < 1) return 1;
+    WN_LAUNCH(k_absmax_rows, dim3((unsigned)((ncols + 4095) / 4096), (unsigned)rows), dim3(WN_TPB), 0, st, p, ld, c0, ncols, partial);
     return 0;
 }
 

@@ -64,12 +64,13 @@ typedef struct WnGemm6Args {
     int ce_t_start;
     float ce_gs;
     float* ce_partial;
+    float* ce_amax;             // nullable, indexed like ce_partial: the block's max |d(mean loss)/d(logit) * ce_gs|
 } WnGemm6Args;
 
 static inline void wn_gemm6_no_gate(WnGemm6Args* a) {
     a->gate_R = 0; a->gate_S = 0; a->gate_Gt = 0; a->gate_Z = 0; a->gate_G = 0; a->gate_gb = 0; a->gate_F = 0; a->gate_U = 1;
     a->gate_upw = 0; a->gate_cvec = 0; a->gbw_S = 0; a->gbw_Gt = 0; a->gbw_dP = 0; a->no_interior = 0; a->stagger = 0; a->n_phase = 0;
-    a->ce_target = 0; a->ce_tstride = 0; a->ce_t_start = 0; a->ce_gs = 0.f; a->ce_partial = 0;
+    a->ce_target = 0; a->ce_tstride = 0; a->ce_t_start = 0; a->ce_gs = 0.f; a->ce_partial = 0; a->ce_amax = 0;
 }
 
 static inline long wn_gemm6_apk_elems(int M, int K) {
@@ -114,6 +115,7 @@ int wn_gemm6_dw_eligible(const struct WnGemmArgs* g);
 int wn_gemm6_dw_big(int M, int N);    // 1: 256 x 256 tiles, one wave per SIMD (k_gemm6_dw<4,4>); checked first
 int wn_gemm6_dw_tall(int M, int N);   // 1: 256 x 128 tiles (k_gemm6_dw<4,2>) for this output shape
 int wn_gemm6_dw_tn(int M, int N);            // otherwise: 3 = one 192-column tile (N = 192), 2 = 128-column tiles, 1 = 64-column tiles
-// products: 6, or 3 for leaf results (weight gradients); f16_mul > 0: the fp16 pair split (A times f16_mul, a power of two; raises
-// *ovf on a non-finite result); products 6 with ovf != NULL and f16_mul == 0: conditional redo (works only if *ovf != 0)
+// products: 6, or 3 for leaf results (weight gradients); f16_mul != 0: the fp16 pair split (A times a power of two; raises
+// *ovf on a non-finite result) -- f16_mul > 0: that power of two; f16_mul < 0: the kernel reads it from ((const float*)ovf)[1],
+// where wn_dw_prepare (wn_elem.h) left it; products 6 with ovf != NULL and f16_mul == 0: conditional redo (works only if *ovf != 0)
 int wn_gemm6_dw_launch(const struct WnGemmArgs* g, int products, float f16_mul, int* ovf, wn_stream_t st);

@@ -546,7 +546,7 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
         }
         __syncthreads();
         const wn_rsrc_t Dl = wn_make_buf(g.C ? g.C + (long)b * g.c_zstride : g.B, g.C ? (unsigned)((long)g.M * g.ldc * 4) : 0u);
-        float my_loss = 0.f;
+        float my_loss = 0.f, my_amax = 0.f;
         WN_UNROLL
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + 64 * wn + 32 * j + li;
@@ -563,15 +563,20 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
                 for (int r = 0; r < 16; ++r) {
                     const int rl = 32 * i + mfma32_row(r, 0);
                     const float d = acc[i][j][r] * scale - (rl == tl ? hot : 0.f);
+                    my_amax = fmaxf(my_amax, fabsf(d));               // (rows >= M hold exp(NEG - max) = 0)
                     wn_buf_store(Dl, d, vC, rl * (int)g.ldc * 4);   // rows >= M fall outside the descriptor: dropped
                 }
             }
         }
         my_loss = wave_reduce_sum(my_loss);
+        my_amax = wave_reduce_max(my_amax);
         __syncthreads();
-        if (lane == 0) red[wave] = my_loss;
+        if (lane == 0) { red[wave] = my_loss; red[4 + wave] = my_amax; }
         __syncthreads();
-        if (tid == 0) g.ce_partial[(long)blk.z * gridDim.x + blk.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (tid == 0) {
+            g.ce_partial[(long)blk.z * gridDim.x + blk.x] = (red[0] + red[1]) + (red[2] + red[3]);
+            if (g.ce_amax) g.ce_amax[(long)blk.z * gridDim.x + blk.x] = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+        }
         return;
     }
     // Interior blocks (the whole 256 x 128 tile inside C; every block of the benchmark's launches): the row part of an
@@ -738,6 +743,8 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
     constexpr int NPROD = NP == 3 ? 6 : 3;
     // the six-product launch behind an fp16-pair launch: runs only if that one overflowed (ovf is never written by this kernel)
     if (!F16 && ovf != nullptr && wn_load_coherent_int(ovf) == 0) return;
+    // the scale decided on the device (wn_dw_prepare: the measured max |dlogits| of this backward call), one uniform load
+    if (F16 && a_mul < 0.0f) a_mul = reinterpret_cast<const float*>(ovf)[1];
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int AE = BM / 16, BE = BN / 16;            // fp32 elements per thread and step
     // 192-column tiles (TN = 3: kernel_size 3 at 64 channels, N = 3 x 64) give a thread three B rows of 4 consecutive k each
@@ -1213,7 +1220,7 @@ template <int TM, int TN>
 static int launch_dw(const WnGemmArgs& g, int products, float f16_mul, int* ovf, wn_stream_t st) {
     dim3 grid((unsigned)((g.N + 64 * TN - 1) / (64 * TN)), (unsigned)((g.M + 64 * TM - 1) / (64 * TM)),
               (unsigned)(g.nlayer * g.nbatch * g.ksplit));
-    if (f16_mul > 0.0f) {
+    if (f16_mul != 0.0f) {
         constexpr int lds = 2 * (2 * 64 * TM * 32 + 2 * 64 * TN * 32);
 #ifndef WN_EMU
         static bool attr_set = false;
@@ -1253,7 +1260,7 @@ static int launch_dw(const WnGemmArgs& g, int products, float f16_mul, int* ovf,
 int wn_gemm6_dw_launch(const WnGemmArgs* gp, int products, float f16_mul, int* ovf, wn_stream_t st) {
     const WnGemmArgs& g = *gp;
     if (products != 3 && products != 6) return 2;
-    if (f16_mul < 0.0f || (f16_mul > 0.0f && !ovf) || (ovf && f16_mul == 0.0f && products != 6)) return 2;
+    if ((f16_mul != 0.0f && !ovf) || (ovf && f16_mul == 0.0f && products != 6)) return 2;
     if (!wn_gemm6_dw_eligible(gp)) return 1;
     if (g.K < 0 || g.nbatch <= 0 || g.ksplit <= 0 || g.nlayer <= 0 || g.b_seg_len <= 0 || g.kchunk <= 0) return 2;
     const bool redo = ovf && f16_mul == 0.0f;   // the conditional redo: no work unless an fp16 launch overflowed

@@ -236,25 +236,30 @@ class WaveNetEngine(object):
         return loss, dlogits
 
     def _note_bound(self, dlogits, grad_scale, count):
-        # a mean softmax cross-entropy over `count` positions has |d loss / d logit| <= grad_scale / count: what backward() needs
-        # to know to take the fp16 pair split of the weight gradients (WN_FLAG_DW_F16PAIR)
-        # (the tensor OBJECT is remembered, weakly: an address could be handed out again by the caching allocator)
+        # The loss calls leave max |dlogits| of the tensor they wrote in the workspace (measured in their epilogue); backward() may
+        # tell the library to use it (WN_FLAG_DW_F16_AMAX_WS) only for exactly that tensor in exactly that state, so the tensor
+        # OBJECT is remembered, weakly (an address could be handed out again by the caching allocator), with its version counter.
         self._dlogits_bound = None
         if dlogits is not None and count > 0 and grad_scale != 0.0:
-            self._dlogits_bound = (weakref.ref(dlogits), dlogits._version, abs(float(grad_scale)) / count)
+            self._dlogits_bound = (weakref.ref(dlogits), dlogits._version, self._ws_key)
 
     def _dw_mode_flags(self, flags, dlogits, dlogits_bound=None):
-        """FLAG_DW_F16PAIR needs max |dlogits|: the caller's word, or the bound noted for exactly this tensor object in exactly
-        this state (no in-place write since the loss call); otherwise the flag is dropped (six bf16 products)."""
+        """FLAG_DW_F16PAIR scales the gradient operand by max |dlogits| (include/wavenet_hip.h).  Where it comes from:
+          * ``dlogits_bound`` given: the caller's promise, taken as given (a loose bound costs precision -- prefer None);
+          * ``dlogits`` is the unmodified tensor the last loss call of this engine returned, same workspace: the maximum that call
+            measured (| FLAG_DW_F16_AMAX_WS: free);
+          * anything else (autograd's grad_output, a tensor modified in place, the mixture-of-logistics head): the library
+            scans the tensor for its maximum first (the flag alone: one pass over the loss window).
+        Never a silent default: an a-priori bound that is merely safe would underflow fp16's range."""
         if not (flags & _lib.FLAG_DW_F16PAIR):
             return flags
-        flags &= ~(63 << _lib.DW_F16_EXP_SHIFT)
+        flags &= ~((63 << _lib.DW_F16_EXP_SHIFT) | _lib.FLAG_DW_F16_EXP_VALID | _lib.FLAG_DW_F16_AMAX_WS)
+        if dlogits_bound is not None:
+            return flags | _lib.dw_f16_exp(float(dlogits_bound))
         nb = self._dlogits_bound
-        if dlogits_bound is None and nb is not None and nb[0]() is dlogits and nb[1] == dlogits._version:
-            dlogits_bound = nb[2]
-        if dlogits_bound is None:
-            return flags & ~_lib.FLAG_DW_F16PAIR
-        return flags | _lib.dw_f16_exp(float(dlogits_bound))
+        if nb is not None and nb[0]() is dlogits and nb[1] == dlogits._version and nb[2] == self._ws_key:
+            return flags | _lib.FLAG_DW_F16_AMAX_WS
+        return flags
 
     def loss(self, logits, target, t_start=None, grad_scale=1.0, loss_scale=1.0, want_grad=True):
         """Softmax-CE over positions >= t_start (default: receptive field).  Returns (loss, dlogits)."""
@@ -291,7 +296,7 @@ class WaveNetEngine(object):
                                   float(loss_scale), int(num_classes), float(log_scale_min), _ptr(loss), _ptr(dout),
                                   _ptr(ws), ws.numel() * 4, _stream_handle(self.device))
         self.lib.check(rc, "wn_mol_loss")
-        self._dlogits_bound = None   # (the mixture head's gradient has no such bound: six bf16 products for its weight gradients)
+        self._dlogits_bound = None   # (the mixture head's loss call measures no maximum: backward scans its gradient)
         return loss, dout
 
     def backward(self, dlogits, events=None, layers_per_bucket=0, t_first=None, repack=False, dlogits_bound=None):
@@ -306,10 +311,10 @@ class WaveNetEngine(object):
         and backward this raises; ``repack=True`` instead rebuilds the weight sets from the current parameters
         (``WN_FLAG_REPACK``) and back-propagates through those.
 
-        ``dlogits_bound``: the caller's word that ``max |dlogits| <= dlogits_bound`` -- with ``FLAG_DW_F16PAIR`` in
-        ``self.flags`` the weight gradients then take the fp16 pair split (include/wavenet_hip.h).  Default: known for the
-        unmodified tensor ``forward_loss`` / ``loss`` returned (a mean cross-entropy: grad_scale / positions), unknown --
-        the six bf16 products -- for any other gradient (autograd's grad_output, the mixture-of-logistics head)."""
+        ``dlogits_bound``: with ``FLAG_DW_F16PAIR`` in ``self.flags`` the weight gradients take the fp16 pair split
+        (include/wavenet_hip.h), scaled by max |dlogits|.  Default (None): MEASURED -- by the loss call for the unmodified
+        tensor ``forward_loss`` / ``loss`` returned (free), by one pass over any other gradient (autograd's grad_output, the
+        mixture-of-logistics head).  A number: the caller's own promise ``max |dlogits| <= dlogits_bound``, taken as given."""
         if self._last_shape is None:
             raise _lib.WnError("backward() without a preceding forward()")
         if t_first is None:

@@ -94,23 +94,71 @@ class CausalConv1d(nn.Module):
                               padding=self.padding, dilation=dilation, bias=bias)
 
     def forward(self, x):
-        """x (B, C, T) float -> (B, C', T).  Inference-only op (no autograd)."""
-        import ctypes
-        lib = _lib.load_library()
+        """x (B, C, T) float -> (B, C', T) on the HIP op ``wn_op_causal_conv``.  Differentiable like the reference's module
+        (wavenet.py:95-121 is an ordinary ``nn.Module``): when a gradient is asked for -- x or the conv parameters require grad
+        under an enabled grad mode -- the call goes through ``_CausalConv1dFunction``, whose backward is the HIP op
+        ``wn_op_causal_conv_backward`` (dx with the taps transposed, dW / db as fixed-order sums over time)."""
         if not x.is_cuda:
             raise _lib.WnError("CausalConv1d runs on the GPU HIP path only (no CPU fallback)")
-        x = x.contiguous().float()
-        B, C, T = x.shape
-        w = self.conv.weight.detach().contiguous()
-        b = self.conv.bias.detach().contiguous() if self.conv.bias is not None else \
-            torch.zeros(self.out_channels, device=x.device)
-        y = torch.empty(B, self.out_channels, T, device=x.device, dtype=torch.float32)
-        scratch = torch.empty(w.numel(), device=x.device, dtype=torch.float32)
+        w, b = self.conv.weight, self.conv.bias
+        if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or (b is not None and b.requires_grad)):
+            return _CausalConv1dFunction.apply(x, w, b, self.dilation)
+        return _causal_conv_hip(x, w.detach(), None if b is None else b.detach(), self.dilation)
+
+
+def _causal_conv_hip(x, w, b, dilation):
+    import ctypes
+    lib = _lib.load_library()
+    if x.dtype != torch.float32 or w.dtype != torch.float32:
+        raise _lib.WnError("CausalConv1d on the HIP path is fp32 (got %s / %s)" % (x.dtype, w.dtype))
+    x = x.contiguous()
+    B, C, T = x.shape
+    Cout, Cin, K = w.shape
+    if C != Cin:
+        raise ValueError("expected %d input channels, got %d" % (Cin, C))
+    w = w.contiguous()
+    b = b.contiguous() if b is not None else torch.zeros(Cout, device=x.device)
+    y = torch.empty(B, Cout, T, device=x.device, dtype=torch.float32)
+    scratch = torch.empty(w.numel(), device=x.device, dtype=torch.float32)
+    st = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    rc = lib.wn_op_causal_conv(w.data_ptr(), b.data_ptr(), x.data_ptr(), y.data_ptr(), scratch.data_ptr(),
+                               B, T, Cin, Cout, K, int(dilation), st)
+    lib.check(rc, "wn_op_causal_conv")
+    return y
+
+
+class _CausalConv1dFunction(torch.autograd.Function):
+    """``CausalConv1d.forward`` with a gradient: forward = wn_op_causal_conv, backward = wn_op_causal_conv_backward (autograd of
+    the reference's Conv1d + slice, wavenet.py:105-121)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, dilation):
+        ctx.save_for_backward(x, w)
+        ctx.dilation, ctx.has_bias = int(dilation), b is not None
+        return _causal_conv_hip(x.detach(), w.detach(), None if b is None else b.detach(), dilation)
+
+    @staticmethod
+    def backward(ctx, dy):
+        import ctypes
+        x, w = ctx.saved_tensors
+        lib = _lib.load_library()
+        x = x.detach().contiguous()
+        w = w.detach().contiguous()
+        dy = dy.contiguous().float()
+        B, Cin, T = x.shape
+        Cout, _, K = w.shape
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dx = torch.empty_like(x) if need_x else None
+        dw = torch.empty_like(w) if need_w else None
+        db = torch.empty(Cout, device=x.device, dtype=torch.float32) if need_b else None
+        n = lib.wn_op_causal_conv_backward_scratch_floats(B, T, Cin, Cout, K)
+        scratch = torch.empty(max(int(n), 1), device=x.device, dtype=torch.float32)
         st = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        rc = lib.wn_op_causal_conv(w.data_ptr(), b.data_ptr(), x.data_ptr(), y.data_ptr(), scratch.data_ptr(),
-                                   B, T, C, self.out_channels, self.kernel_size, self.dilation, st)
-        lib.check(rc, "wn_op_causal_conv")
-        return y
+        rc = lib.wn_op_causal_conv_backward(w.data_ptr(), x.data_ptr(), dy.data_ptr(), dx.data_ptr() if need_x else None,
+                                            dw.data_ptr() if need_w else None, db.data_ptr() if need_b else None,
+                                            scratch.data_ptr(), B, T, Cin, Cout, K, ctx.dilation, st)
+        lib.check(rc, "wn_op_causal_conv_backward")
+        return dx, dw, db, None
 
 
 class UpSampling(nn.Module):
@@ -172,9 +220,9 @@ class _UpSamplingFunction(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy4 = dy.reshape(x.size(0), x.size(1), x.size(2), ctx.U)
-        dx = (dy4 * w.reshape(-1)).sum(-1) if ctx.needs_input_grad[0] else None
-        dw = (dy4 * x.float().unsqueeze(-1)).sum((0, 1, 2)).reshape(w.shape) if ctx.needs_input_grad[1] else None
-        db = dy.sum().reshape(1) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        dx = (dy4 * w.reshape(-1)).sum(-1).to(x.dtype) if ctx.needs_input_grad[0] else None
+        dw = (dy4 * x.float().unsqueeze(-1)).sum((0, 1, 2)).reshape(w.shape).to(w.dtype) if ctx.needs_input_grad[1] else None
+        db = dy.sum().reshape(1).to(w.dtype) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db, None
 
 

@@ -52,3 +52,38 @@ def check_op_causal_conv(lib, device, Cin, Cout, K, d, B, T):
     lib.check(rc, "wn_op_causal_conv")
     assert float((y.cpu() - ref).abs().max()) <= 1e-5
     return w, b, x, ref
+
+
+def check_op_causal_conv_backward(lib, device, Cin, Cout, K, d, B, T):
+    """wn_op_causal_conv_backward against autograd of the oracle's restatement of CausalConv1d (reference wavenet.py:95-121:
+    nn.Conv1d with padding (K-1)d, last (K-1)d outputs dropped): dx, dW, db, each also with the other outputs NULL."""
+    rs = np.random.RandomState(Cin + Cout + K + d + 1)
+    w = torch.from_numpy((rs.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)).requires_grad_(True)
+    b = torch.from_numpy(rs.standard_normal(Cout).astype(np.float32)).requires_grad_(True)
+    x = torch.from_numpy(rs.standard_normal((B, Cin, T)).astype(np.float32)).requires_grad_(True)
+    dy = torch.from_numpy(rs.standard_normal((B, Cout, T)).astype(np.float32))
+    O.causal_conv1d(x, w, b, d).backward(dy)
+    n = lib.wn_op_causal_conv_backward_scratch_floats(B, T, Cin, Cout, K)
+    assert n > 0
+    scratch = torch.empty(n, dtype=torch.float32, device=device)
+    wd, xd, dyd = w.detach().to(device), x.detach().to(device), dy.to(device)
+    dx = torch.full((B, Cin, T), float("nan"), dtype=torch.float32, device=device)
+    dw = torch.full((Cout, Cin, K), float("nan"), dtype=torch.float32, device=device)
+    db = torch.full((Cout,), float("nan"), dtype=torch.float32, device=device)
+    rc = lib.wn_op_causal_conv_backward(wd.data_ptr(), xd.data_ptr(), dyd.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                        scratch.data_ptr(), B, T, Cin, Cout, K, d, _stream(device))
+    lib.check(rc, "wn_op_causal_conv_backward")
+    for got, ref, what in ((dx, x.grad, "dx"), (dw, w.grad, "dw"), (db, b.grad, "db")):
+        err = float((got.cpu() - ref).abs().max())
+        assert err <= 1e-5 * max(1.0, float(ref.abs().max())), (what, err)
+    # dx alone / dw alone (the NULL outputs are skipped)
+    dx2 = torch.empty_like(dx)
+    rc = lib.wn_op_causal_conv_backward(wd.data_ptr(), xd.data_ptr(), dyd.data_ptr(), dx2.data_ptr(), None, None,
+                                        scratch.data_ptr(), B, T, Cin, Cout, K, d, _stream(device))
+    lib.check(rc, "wn_op_causal_conv_backward")
+    assert torch.equal(dx2, dx)
+    dw2 = torch.empty_like(dw)
+    rc = lib.wn_op_causal_conv_backward(wd.data_ptr(), xd.data_ptr(), dyd.data_ptr(), None, dw2.data_ptr(), None,
+                                        scratch.data_ptr(), B, T, Cin, Cout, K, d, _stream(device))
+    lib.check(rc, "wn_op_causal_conv_backward")
+    assert torch.equal(dw2, dw)

@@ -135,36 +135,40 @@ def test_missing_library_fails_loudly():
     assert "libwavenet_hip" in r.stderr
 
 
-def test_fp16_pair_mode_needs_the_bound_of_exactly_the_tensor_the_loss_call_returned():
-    """engine._dw_mode_flags (host logic of WN_FLAG_DW_F16PAIR): the exponent field comes from the bound noted for the tensor
-    OBJECT a loss call returned, in the state it was returned in; any other tensor -- another object at the same address (the
-    caching allocator hands addresses out again), a view, a tensor written in place -- drops the flag unless the caller gives
-    its own bound; without the flag nothing is touched."""
+def test_fp16_pair_mode_takes_the_measured_maximum_only_for_exactly_the_tensor_the_loss_call_returned():
+    """engine._dw_mode_flags (host logic of WN_FLAG_DW_F16PAIR, ABI v9): the scale of the fp16 pair split comes from max |dlogits|.
+    WN_FLAG_DW_F16_AMAX_WS (the maximum the loss call measured, left in the workspace) is passed only for the tensor OBJECT a loss
+    call returned, in the state it was returned in, on the same workspace; any other tensor -- another object at the same address
+    (the caching allocator hands addresses out again), a view, a tensor written in place -- keeps the flag ALONE (the library then
+    scans the tensor it is given) unless the caller gives its own bound (| EXP_VALID); without the flag nothing is touched."""
     import torch
     from tests.emu_util import emu_library
     from pytorchwavenetvocoder_amd import _lib
     from pytorchwavenetvocoder_amd.engine import WaveNetEngine
     eng = WaveNetEngine(32, 4, 16, 16, 2, 1, 2, 4, device="cpu", library=emu_library())
     F = _lib.FLAG_AUX_FUSED | _lib.FLAG_DW_F16PAIR
+    WS, VALID = _lib.FLAG_DW_F16_AMAX_WS, _lib.FLAG_DW_F16_EXP_VALID
     dl = torch.zeros(1, 32, 8)
-    assert eng._dw_mode_flags(F, dl) == _lib.FLAG_AUX_FUSED                 # nothing noted yet
-    eng._note_bound(dl, 1.0, 1000)                                          # |dlogits| <= 1e-3 -> e = 9
-    want = F | (9 << _lib.DW_F16_EXP_SHIFT)
-    assert eng._dw_mode_flags(F, dl) == want
-    assert eng._dw_mode_flags(F | (63 << _lib.DW_F16_EXP_SHIFT), dl) == want   # a stale exponent in the flag word is replaced
-    assert eng._dw_mode_flags(F, dl.view(1, 32, 8)) == _lib.FLAG_AUX_FUSED   # same memory, another object
-    assert eng._dw_mode_flags(F, dl.clone()) == _lib.FLAG_AUX_FUSED
-    assert eng._dw_mode_flags(F, dl.clone(), dlogits_bound=0.3) == F | (1 << _lib.DW_F16_EXP_SHIFT)
+    assert eng._dw_mode_flags(F, dl) == F                                   # nothing noted yet: the library scans
+    eng._note_bound(dl, 1.0, 1000)
+    assert eng._dw_mode_flags(F, dl) == F | WS
+    assert eng._dw_mode_flags(F | (63 << _lib.DW_F16_EXP_SHIFT) | VALID, dl) == F | WS   # stale exponent bits in the flag word are dropped
+    assert eng._dw_mode_flags(F, dl.view(1, 32, 8)) == F                    # same memory, another object
+    assert eng._dw_mode_flags(F, dl.clone()) == F
+    assert eng._dw_mode_flags(F, dl.clone(), dlogits_bound=0.3) == F | (1 << _lib.DW_F16_EXP_SHIFT) | VALID
+    assert eng._dw_mode_flags(F, dl, dlogits_bound=1.0) == F | VALID        # e = 0 is a statement now, not a default
     assert eng._dw_mode_flags(_lib.FLAG_AUX_FUSED, dl) == _lib.FLAG_AUX_FUSED
-    dl.add_(1.0)                                                            # written in place: the bound is void
-    assert eng._dw_mode_flags(F, dl) == _lib.FLAG_AUX_FUSED
+    dl.add_(1.0)                                                            # written in place: the measured maximum is void
+    assert eng._dw_mode_flags(F, dl) == F
     eng._note_bound(dl, 0.5, 1000)
-    keep = eng._dw_mode_flags(F, dl)
-    assert keep == F | (10 << _lib.DW_F16_EXP_SHIFT)
+    assert eng._dw_mode_flags(F, dl) == F | WS
+    eng._ws_key = (1, 64)                                                   # another workspace since the loss call: its word is not this tensor's
+    assert eng._dw_mode_flags(F, dl) == F
+    eng._ws_key = None
     del dl
     other = torch.zeros(1, 32, 8)                                           # the noted tensor is gone; whatever takes its place does not inherit
-    assert eng._dw_mode_flags(F, other) == _lib.FLAG_AUX_FUSED
-    eng._note_bound(other, 0.0, 1000)                                       # grad_scale 0: no bound
-    assert eng._dw_mode_flags(F, other) == _lib.FLAG_AUX_FUSED
+    assert eng._dw_mode_flags(F, other) == F
+    eng._note_bound(other, 0.0, 1000)                                       # grad_scale 0: nothing measured worth using
+    assert eng._dw_mode_flags(F, other) == F
     with pytest.raises(ValueError):
         eng._dw_mode_flags(F, other, dlogits_bound=0.0)

@@ -252,6 +252,8 @@ def test_op_level_entry_points():
         OC.check_op_front(emu_library(), "cpu", *case)
     for case in (OC.CONV_CASES[2], OC.CONV_CASES[3], (64, 64, 2, 512, 1, 150)):
         OC.check_op_causal_conv(emu_library(), "cpu", *case)
+    for case in [(12, 20, 3, 7, 3, 91), (64, 64, 2, 16, 2, 130), (8, 4, 2, 512, 1, 70)]:   # backward (ABI v9): taps transposed, fixed-order dW / db
+        OC.check_op_causal_conv_backward(emu_library(), "cpu", *case)
 
 
 def test_saved_workspace_regions_and_given_relu_subgradient():
@@ -871,15 +873,18 @@ def test_persistent_decode_residency_check_and_fall_backs(monkeypatch):
 
 def test_weight_gradients_by_the_fp16_pair_split_and_their_overflow_redo():
     """WN_FLAG_DW_F16PAIR (csrc/wn_gemm6.hip k_gemm6_dw<.., F16>): two fp16 pieces per operand, three products, the gradient
-    operand scaled by 2^(e + 8) from the caller's bound max |dlogits| <= 2^-e.  Against the six-bf16-product mode: within
-    1e-6 of the largest gradient (the three-bf16-product mode: ~2e-6 ... 1e-5); every fp16 launch is followed by ONE conditional
-    six-product launch; a bound far too small drives the scaled gradients out of fp16's range -> the overflow word -> the redo
-    launches do the work: the default's result bit for bit; a gradient tensor the engine has no bound for never takes the mode.
+    operand scaled by 2^(e + 8) where 2^-e bounds the MEASURED max |dlogits| (ABI v9: by the loss call, or by a scan of the tensor
+    given to backward).  Against the six-bf16-product mode: within 1e-6 of the largest gradient (the three-bf16-product mode:
+    ~2e-6 ... 1e-5); every fp16 launch is followed by ONE conditional six-product launch; a PROMISED bound far too small drives the
+    scaled gradients out of fp16's range -> the overflow word -> the redo launches do the work: the default's result bit for
+    bit; a gradient tensor the loss call did not make is scanned (same maximum, same bits); a gradient 2^-30 smaller than the loss
+    call's keeps its accuracy (measured scale) where a merely SAFE promise (|g| <= 1) underflows fp16 entirely.
     (The golden gates, incl. the weights after Adam, are GPU tests: tests/test_gpu_dw_f16pair.py.)"""
     from oracle import wavenet_oracle as O
     from pytorchwavenetvocoder_amd import _lib
     from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat
-    assert [_lib.dw_f16_exp(b) >> _lib.DW_F16_EXP_SHIFT for b in (3.0, 1.0, 0.5, 0.3, 2.0 ** -17, 6e-6, 1e-30)] == [0, 0, 1, 1, 17, 17, 63]
+    assert [(_lib.dw_f16_exp(b) >> _lib.DW_F16_EXP_SHIFT) & 63 for b in (3.0, 1.0, 0.5, 0.3, 2.0 ** -17, 6e-6, 1e-30)] == [0, 0, 1, 1, 17, 17, 63]
+    assert all(_lib.dw_f16_exp(b) & _lib.FLAG_DW_F16_EXP_VALID for b in (3.0, 1e-30))
     cfg_t = (32, 4, 64, 32, 7, 1, 2, 16)
     cfg = O.OracleConfig(*cfg_t)
     B, T = 1, 272
@@ -904,7 +909,20 @@ def test_weight_gradients_by_the_fp16_pair_split_and_their_overflow_redo():
     assert 0.0 < err <= 1e-6 * scale, (err, scale)
     # overflow: the promise is 2^20 too small for this gradient
     assert torch.equal(eng.backward(dl, dlogits_bound=2.0 ** -40).clone(), res["six"])
-    assert torch.equal(eng.backward(dl.clone()).clone(), res["six"])     # not the tensor the loss call returned: no bound, no fp16
+    # not the tensor the loss call returned: the library scans it -- the same maximum the loss epilogue measured, the same bits
+    log = PC.launch_log(emu_library(), lambda: eng.backward(dl.clone()))
+    assert log.get("dw_absmax_scan") == 1 and "dw_absmax_scan" not in logs["f16"], log
+    assert torch.equal(eng.grads(), res["f16"])
+    # underflow: the same gradient 2^-30 smaller.  Measured scale: the accuracy of the mode; a bound that is merely
+    # safe (|g| <= 1, i.e. what a forgotten exponent meant in ABI v8) puts every scaled element below fp16's smallest subnormal
+    small = dl * 2.0 ** -30
+    g_scan = eng.backward(small).clone() * 2.0 ** 30
+    assert float((g_scan - res["six"]).abs().max()) <= 1e-6 * scale
+    g_loose = eng.backward(small, dlogits_bound=1.0).clone() * 2.0 ** 30
+    assert float((g_loose - res["six"]).abs().max()) > 1e-2 * scale
+    # an all-zero gradient has no maximum: the redo is forced, the result is exact zeros
+    z = eng.backward(torch.zeros_like(dl)).clone()
+    assert float(z.abs().max()) == 0.0
     # (the word is cleared per call, in-place modified gradients, the caller's own bound: tests/test_gpu_dw_f16pair.py)
 
 
@@ -918,3 +936,33 @@ def test_skip_gradient_on_the_256_row_tile():
     for flags in (None, _lib.FLAG_AUX_FUSED):
         e, g = PC.run_oracle_vs_engine(cfg_t, 1, 400, 71, emu_library(), "cpu", flags=flags, scale=0.1)
         assert g <= 2e-5, (flags, g)
+
+
+def test_same_run_parity_helper_on_the_emulator():
+    """oracle/same_run_parity.py (bench.py's `parity` block, tests/test_gpu_fullsize.py's benchmark-instance gate) on a tiny
+    initialize()d model under the emulator: the reference module's own step (oracle/_ref; the restatement where the copy is
+    absent) against the HIP step from the same state_dict on the same tensors, incl. the weights after one Adam step."""
+    from oracle import same_run_parity as SRP
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS
+    from pytorchwavenetvocoder_amd.nets import WaveNet, initialize
+    from pytorchwavenetvocoder_amd.optim import FusedAdam
+    cfg_t = (32, 6, 64, 32, 3, 1, 2, 16)
+    torch.manual_seed(1)
+    model = WaveNet(*cfg_t, _library=emu_library())
+    model.apply(initialize)
+    init_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    x, h, t = O.synthetic_batch(O.OracleConfig(*cfg_t), 2, 64, 5)
+    ref = SRP.reference_step(cfg_t, init_state, x, h, t, lr=1e-4)
+    res = SRP.gpu_step_vs_reference(model, lambda m, lr: FusedAdam(m, lr=lr), ref, x, h, t, init_state, DEFAULT_FLAGS, lr=1e-4)
+    G = SRP.GATES
+    assert res["logits_maxabs"] <= G["logits_maxabs"] and res["loss_abs"] <= G["loss_abs"], res
+    assert res["worst_grad_rel"] <= G["worst_grad_rel"] and res["kink_flip_max_distance"] <= SRP.KINK, res
+    assert res["after_adam_elements"] == sum(v.numel() for v in init_state.values())
+    # After Adam: this tiny instance has 128 loss positions, so its gradients are LARGE (tensor maxima ~4e-3) and an element
+    # whose gradient is ~1e-9 -- below Adam's eps, where the update lr g / (|g| + eps) has sensitivity 1 / eps -- moves by per
+    # cent of lr for a gradient difference at fp32 round-off of the tensor's maximum (1.3e-7 of it here; the reference's own
+    # fp32 step is 0.8e-2 lr from its fp64 evaluation on this instance).  So: every element whose reference gradient is above
+    # 10 eps meets the 1e-2 lr gate, and the few over it are of that sign-like kind.
+    assert res["after_adam_elements_over_gate"] <= 8 and res["after_adam_over_gate_max_abs_reference_grad"] < 1e-7, res
+    assert res["after_adam_maxabs_over_lr"] <= 0.1, res

@@ -4,7 +4,7 @@ pieces per operand, three products on v_mfma_f32_32x32x16_f16; csrc/wn_gemm6.hip
 six-bf16-product mode -- the golden gradients (1e-4 of a tensor's maximum) and the golden weights after the Adam steps
 (1e-2 lr: the gate the three-bf16-product mode WN_FLAG_DW_3PRODUCT misses) of reference train.py:527-540 --, the overflow
 fall-back (a gradient outside fp16's range makes the conditional six-product launches do the work: the six-product mode's result
-bit for bit) and the rule that the mode needs the caller's bound on dlogits."""
+bit for bit) and where the scale comes from (ABI v9): max |dlogits| MEASURED by the loss call, or by a scan of any other tensor."""
 import pytest
 import torch
 
@@ -42,7 +42,7 @@ def test_golden_gradients_and_after_adam_state_with_the_fp16_pair_split(name, mo
         assert log.get("dw_redo_if_overflow", 0) >= 1, log   # the mode was on: every fp16 launch is followed by its conditional redo
 
 
-def test_overflow_falls_back_to_the_six_products_bit_for_bit_and_unknown_bounds_never_take_the_mode():
+def test_overflow_falls_back_to_the_six_products_bit_for_bit_and_unknown_gradients_are_scanned():
     from oracle import wavenet_oracle as O
     from pytorchwavenetvocoder_amd import _lib as L
     from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat
@@ -72,9 +72,29 @@ def test_overflow_falls_back_to_the_six_products_bit_for_bit_and_unknown_bounds_
     assert torch.equal(gov, g6)
     # and the next call with the true bound is the fp16 result again (the word is cleared per call)
     assert torch.equal(eng.backward(dl).clone(), g16)
-    # a gradient the engine did not make (autograd's grad_output, a modified tensor): six products
-    assert torch.equal(eng.backward(dl.clone()).clone(), g6)
+    # a gradient the engine did not make (autograd's grad_output, a modified tensor): scanned for its maximum -- the same number the
+    # loss epilogue measured, so the same bits
+    log = PC.launch_log(_lib(), lambda: eng.backward(dl.clone()))
+    assert log.get("dw_absmax_scan") == 1, log
+    assert torch.equal(eng.grads(), g16)
     dl.mul_(1.0)
-    assert torch.equal(eng.backward(dl).clone(), g6)
-    # ... unless the caller gives its word
+    assert torch.equal(eng.backward(dl).clone(), g16)
+    # the caller's own word is taken as given (same power of two here)
     assert torch.equal(eng.backward(dl, dlogits_bound=1.0 / (B * (T - cfg.receptive_field))).clone(), g16)
+    # underflow: a gradient 2^-30 smaller keeps the mode's accuracy with the measured scale; under a promise that is
+    # merely safe (|g| <= 1: what F16PAIR without an exponent meant in ABI v8) every scaled element is below fp16's subnormals
+    small = dl * 2.0 ** -30
+    g_scan = eng.backward(small).clone() * 2.0 ** 30
+    assert float((g_scan - g6).abs().max()) / scale <= 1e-6
+    g_loose = eng.backward(small, dlogits_bound=1.0).clone() * 2.0 ** 30
+    assert float((g_loose - g6).abs().max()) / scale > 1e-2
+    # a C caller that sets WN_FLAG_DW_F16PAIR and nothing else gets the scan, not e = 0
+    import ctypes
+    from pytorchwavenetvocoder_amd.engine import _ptr, _stream_handle
+    ws = eng.workspace(B, T)
+    xd, hd = eng._last_inputs
+    rc = eng.lib.wn_backward_window(ctypes.byref(eng.cfg), B, T, _ptr(eng.flat_params), _ptr(xd), _ptr(hd), _ptr(small),
+                                    eng.receptive_field, _ptr(eng.grads()), _ptr(ws), ws.numel() * 4, None, 0, 0,
+                                    L.FLAG_AUX_FUSED | L.FLAG_DW_F16PAIR, _stream_handle(eng.device))
+    eng.lib.check(rc, "wn_backward_window")
+    assert float((eng.grads() * 2.0 ** 30 - g6).abs().max()) / scale <= 1e-6

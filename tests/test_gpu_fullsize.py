@@ -162,3 +162,91 @@ def test_config4_mol_head_stated_size_vs_own_restatement():
           "%.3g from fp64), against the oracle network's %.3g, worst parameter gradient %.3g (%s)"
           % (r["out"], r["loss_rel"], r["dout_vs_fp64"], r["dout_vs_fp32"], r["fp32_restatement_vs_fp64"], r["dout_vs_oracle_network"],
              r["grad"], r["grad_key"]))
+
+
+def test_benchmark_instance_vs_reference_module():
+    """THE TIMED INSTANCE is the checked instance: bench.py's own model -- ``model.apply(initialize)`` under seed 1 (xavier
+    weights, zero biases, upsampling w = 1 / b = 0; train.py:446, wavenet.py:50-63) -- on bench.py's own minibatch (B = 8,
+    T = 23040, generator seed 1234), Adam lr 1e-4 (train.py:457-461), against ONE step of the reference's own module
+    (``oracle/_ref``; train.py:527-540) from the same ``state_dict``: logits 1e-4, loss 1e-5, every gradient tensor 1e-4 of its
+    maximum, weights after the Adam step 1e-2 lr -- in the default arithmetic (fp16 pair split of the weight gradients, its range
+    logic fed by the loss's own bound) and with six bf16 products.  ``oracle/same_run_parity.py`` is what bench.py's `parity`
+    block runs in the benchmark job itself."""
+    import bench
+    from oracle import same_run_parity as SRP
+    from pytorchwavenetvocoder_amd import _lib as L
+    from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS
+    from pytorchwavenetvocoder_amd.nets import WaveNet, initialize
+    from pytorchwavenetvocoder_amd.optim import FusedAdam
+    cfg_t = tuple(bench.CFG2[k] for k in ("n_quantize", "n_aux", "n_resch", "n_skipch", "dilation_depth", "dilation_repeat",
+                                          "kernel_size", "upsampling_factor"))
+    torch.manual_seed(1)
+    model = WaveNet(*cfg_t, _library=_lib())
+    model.apply(initialize)
+    init_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.to(DEV)
+    bl, frames, T = bench.geometry(model.receptive_field, bench.BATCH_LENGTH, cfg_t[7])
+    x, h, t = bench.synthetic_minibatch(bench.BATCH_PER_GPU, T, frames, 0)
+    assert (T, frames, tuple(x.shape)) == (23040, 288, (8, 23040))
+    nthr = max(2, min(16, len(__import__("os").sched_getaffinity(0))))
+    ref_alt = SRP.reference_step(cfg_t, init_state, x, h, t, lr=1e-4, threads=nthr // 2, keep_forward=False)
+    ref = SRP.reference_step(cfg_t, init_state, x, h, t, lr=1e-4, threads=nthr)
+    noise = SRP.reference_self_noise(ref_alt, ref, lr=1e-4)
+    del ref_alt
+    print("REFERENCE vs ITSELF (%s threads): worst gradient %.3g (%s), after Adam %.3g lr (%s; %d elements over 1e-2 lr, largest "
+          "reference gradient among them %.3g)" % (noise["threads"], noise["worst_grad_rel"], noise["worst_grad_key"],
+                                                   noise["after_adam_maxabs_over_lr"], noise["after_adam_worst_key"],
+                                                   noise["after_adam_elements_over_gate"], noise["after_adam_over_gate_max_abs_reference_grad"]))
+    SIX = DEFAULT_FLAGS & ~(L.FLAG_DW_3PRODUCT | L.FLAG_DW_F16PAIR)
+    for flags in (DEFAULT_FLAGS, SIX):
+        r = SRP.gpu_step_vs_reference(model, lambda m, lr: FusedAdam(m, lr=lr), ref, x, h, t, init_state, flags, lr=1e-4,
+                                      layers_per_bucket=bench.LAYERS_PER_BUCKET)
+        print("BENCHMARK INSTANCE (initialize() weights, B=8, T=23040) vs the %s module, flags %d: logits %.3g, loss %.3g, worst "
+              "gradient %.3g (%s), after Adam %.3g lr (%s; %d of %d elements over 1e-2 lr, largest reference gradient among them "
+              "%.3g), %d kink ties (max distance %.3g)"
+              % (ref["kind"], flags, r["logits_maxabs"], r["loss_abs"], r["worst_grad_rel"], r["worst_grad_key"],
+                 r["after_adam_maxabs_over_lr"], r["after_adam_worst_key"], r["after_adam_elements_over_gate"],
+                 r["after_adam_elements"], r["after_adam_over_gate_max_abs_reference_grad"], r["kink_flips"],
+                 r["kink_flip_max_distance"]))
+        m = r["gates_met"]
+        assert m["logits"] and m["loss"] and m["grads"] and m["kinks"], r
+        # After Adam (gate 1e-2 lr).  At this size the gate is BELOW THE REFERENCE'S OWN REPRODUCIBILITY: the same reference step at
+        # two thread counts differs by `noise["after_adam_maxabs_over_lr"]` (0.04 lr measured, 6 elements over the gate) -- elements
+        # whose gradient is below ~10 eps of Adam, where the first update lr g / (|g| + eps) is sign-like.  Asserted: (a) every
+        # element over the gate is of that kind (reference gradient < 1e-7), i.e. wherever the gate is a statement about the
+        # gradient it holds; (b) the HIP step is no further from the reference than 2 x the reference is from itself (or the gate).
+        assert r["after_adam_well_conditioned_pass"], r
+        assert r["after_adam_maxabs_over_lr"] <= max(SRP.GATES["after_adam_maxabs_over_lr"], 2.0 * noise["after_adam_maxabs_over_lr"]), (r, noise)
+
+
+def test_configs0_stated_geometry_vs_oracle_and_reference_module():
+    """BASELINE configs[0] at ITS stated geometry (the plumbing case: egs/arctic/sd/run.sh:46-57,239-262 with n_resch 64 as
+    SURVEY 8d's table has it): n_quantize 256, n_aux 28 (WORLD features), 64 / 256 channels, 30 layers, kernel_size 2,
+    upsampling_factor 80; batch 1 x batch_len 1000 -> 930 (train.py:106-110), 50 frames, T = 4000 inputs, loss on 930 positions.
+    (a) trained-scale random weights against the live oracle: logits, loss, every layer input, every gradient tensor;
+    (b) ``model.apply(initialize)`` weights, one Adam step at lr 1e-4, against the reference's own module (same-run parity helper)."""
+    from oracle import same_run_parity as SRP
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS
+    from pytorchwavenetvocoder_amd.nets import WaveNet, initialize
+    from pytorchwavenetvocoder_amd.optim import FusedAdam
+    cfg_t = (256, 28, 64, 256, 10, 3, 2, 80)
+    geo = O.batch_geometry(3070, 1000, 80)
+    assert (geo["T"], geo["batch_length"], geo["frames"], geo["loss_positions"]) == (4000, 930, 50, 930)
+    res = PC.run_fullsize_vs_oracle(cfg_t, 1, 4000, 131, _lib(), DEV, flag_sets=[DEFAULT_FLAGS], scale=0.05)
+    print("configs[0] STATED GEOMETRY (A=28, 30 layers, B=1, T=4000, 930 loss positions) vs oracle: logits %.3g, loss %.3g, layer "
+          "inputs %.3g, grads %s, %d kink flips" % (res["logits"], res["loss"], res["layer_inputs"], res["grads"], res["kink_flips"]))
+    torch.manual_seed(1)
+    model = WaveNet(*cfg_t, _library=_lib())
+    model.apply(initialize)
+    init_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.to(DEV)
+    x, h, t = O.synthetic_batch(O.OracleConfig(*cfg_t), 1, 4000, 132)
+    ref = SRP.reference_step(cfg_t, init_state, x, h, t, lr=1e-4, threads=8)
+    r = SRP.gpu_step_vs_reference(model, lambda m, lr: FusedAdam(m, lr=lr), ref, x, h, t, init_state, DEFAULT_FLAGS, lr=1e-4)
+    print("configs[0] STATED GEOMETRY, initialize() weights vs the %s module: logits %.3g, loss %.3g, worst gradient %.3g (%s), "
+          "after Adam %.3g lr (%d elements over 1e-2 lr, largest reference gradient among them %.3g), %d kink ties"
+          % (ref["kind"], r["logits_maxabs"], r["loss_abs"], r["worst_grad_rel"], r["worst_grad_key"], r["after_adam_maxabs_over_lr"],
+             r["after_adam_elements_over_gate"], r["after_adam_over_gate_max_abs_reference_grad"], r["kink_flips"]))
+    m = r["gates_met"]
+    assert m["logits"] and m["loss"] and m["grads"] and m["kinks"] and r["after_adam_well_conditioned_pass"], r

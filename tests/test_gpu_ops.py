@@ -38,10 +38,30 @@ def test_causal_conv_op_and_module(Cin, Cout, K, d, B, T):
         m.conv.weight.copy_(w)
         m.conv.bias.copy_(b)
     m.to(DEV)
-    ym = m(x.to(DEV))
+    with torch.no_grad():
+        ym = m(x.to(DEV))
+    assert ym.grad_fn is None
     assert tuple(ym.shape) == (B, Cout, T) and float((ym.cpu() - ref).abs().max()) <= 1e-5
     with pytest.raises(Exception):
         m(x)        # CPU tensor: no fallback
+    # the op-level backward, then the module under autograd: the reference's module is an ordinary differentiable nn.Module
+    # (wavenet.py:95-121) -- x, weight and bias gradients against torch's own Conv1d + slice on the CPU
+    OC.check_op_causal_conv_backward(_lib(), DEV, Cin, Cout, K, d, B, T)
+    ref_conv = torch.nn.Conv1d(Cin, Cout, K, padding=(K - 1) * d, dilation=d)
+    with torch.no_grad():
+        ref_conv.weight.copy_(w)
+        ref_conv.bias.copy_(b)
+    xc = x.clone().requires_grad_(True)
+    yr = ref_conv(xc)
+    yr = yr[:, :, :-(K - 1) * d] if (K - 1) * d > 0 else yr       # wavenet.py:118-121
+    gy = torch.randn(B, Cout, T)
+    yr.backward(gy)
+    xg = x.to(DEV).requires_grad_(True)
+    yg = m(xg)
+    assert yg.grad_fn is not None and float((yg.detach().cpu() - yr.detach()).abs().max()) <= 1e-5
+    yg.backward(gy.to(DEV))
+    for got, want, what in ((xg.grad, xc.grad, "dx"), (m.conv.weight.grad, ref_conv.weight.grad, "dw"), (m.conv.bias.grad, ref_conv.bias.grad, "db")):
+        assert float((got.cpu() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max())), what
 
 
 def test_upsampling_module_on_the_gpu_vs_reference_vector():
