@@ -152,6 +152,15 @@ enum {
 #define WN_DW_F16_HEADROOM 8
 #define WN_FLAG_DW_F16_EXP_VALID (1 << 26) /* since ABI v9: the WN_FLAG_DW_F16_EXP(e) field is the caller's promise (e = 0 included) */
 #define WN_FLAG_DW_F16_AMAX_WS (1 << 27)   /* since ABI v9: max |dlogits| as the last loss call of this workspace measured it */
+#define WN_FLAG_MM_F16PAIR (1 << 28) /* since ABI v9, opt-in: wn_forward / wn_forward_loss / wn_backward(_window) -- the weights x activations
+                               * contractions on the split matrix-core kernel (skip sum, post-net, their data gradients, the per-layer
+                               * contractions of wide models) take the fp16 pair split too (two fp16 pieces per operand, three products,
+                               * ~2^-22 per product: the rounding of an fp32 running sum over >= 64 terms) instead of the six bf16
+                               * products.  Activations are taken as they are, back-propagated gradients scaled by the measured maximum
+                               * like the weight gradients' (the same three sources, see WN_FLAG_DW_F16PAIR); every such launch is
+                               * followed by a conditional six-product launch that redoes it if an operand left fp16's range.  The same
+                               * flag must be given to the forward and the backward call of a step (the workspace holds the weight
+                               * images the forward call packed), or wn_backward gets WN_FLAG_REPACK. */
 #define WN_FLAG_DW_FLUSH(n) (((n) & 0xff) << 8) /* wn_backward: issue the weight gradients of at most n walked layers per
                                * launch group (0 = default: a whole gradient bucket; 5 layers with WN_FLAG_BWD_OVERLAP).
                                * Groups never straddle a bucket.  The split-K plan of a group depends on its size, so

@@ -85,6 +85,7 @@ DW_F16_EXP_SHIFT = 20
 DW_F16_HEADROOM = 8
 FLAG_DW_F16_EXP_VALID = 1 << 26
 FLAG_DW_F16_AMAX_WS = 1 << 27
+FLAG_MM_F16PAIR = 1 << 28  # forward / data-gradient split contractions (k_gemm6) by the fp16 pair split too, each with its conditional redo
 
 
 def dw_f16_exp(bound):

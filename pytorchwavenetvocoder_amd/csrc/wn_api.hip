@@ -393,6 +393,7 @@ struct Ws {
     long apk_floats;
     long apk_pre[6];   // the six weight sets of a training step, split ONCE per step (pack_weights): offsets, -1 = none
     long apk_wide[5];  // wide models (n_resch % 128 == 0, any-size path): the five per-layer weight sets of a step, all layers, split
+    long apk_pre16[6], apk_wide16[5];   // the same sets as two-piece fp16 images (WN_FLAG_MM_F16PAIR; same sizes and layer strides)
     long apk_wide_l[5];   // once per step as well (round 3: 149 little pack launches per step); offset of layer 0 / floats per layer
     long front_partial, front_partial_floats;
     long total;
@@ -503,6 +504,12 @@ static int make_ws(const Dims& d, int B, int T, Ws* w, bool training = true) {
             w->apk_pre[i] = o;
             o += al64((wn_gemm6_apk_elems(pre[i][0], pre[i][1]) + 1) / 2);
         }
+        for (int i = 0; i < 6; ++i) {
+            w->apk_pre16[i] = -1;
+            if (w->apk_pre[i] < 0) continue;
+            w->apk_pre16[i] = o;
+            o += al64((wn_gemm6_apk_elems(pre[i][0], pre[i][1]) + 1) / 2);
+        }
     }
         {   // (same order as wide_jobs())
             const bool wide = training && d.R % 128 == 0 && !wn_fused_supported(d.R, d.K, d.S);
@@ -512,6 +519,12 @@ static int make_ws(const Dims& d, int B, int T, Ws* w, bool training = true) {
                 w->apk_wide_l[i] = al64((wn_gemm6_apk_elems(mk[i][0], mk[i][1]) + 1) / 2);
                 if (!wide) continue;
                 w->apk_wide[i] = o;
+                o += w->apk_wide_l[i] * d.L;
+            }
+            for (int i = 0; i < 5; ++i) {
+                w->apk_wide16[i] = -1;
+                if (!wide) continue;
+                w->apk_wide16[i] = o;
                 o += w->apk_wide_l[i] * d.L;
             }
         }
@@ -567,7 +580,9 @@ struct Ctx {
     bool fused;
     bool split_bf16;  // forward-type contractions on the bf16 matrix cores (3-way split, fp32-equivalent)
     int dw_products;  // products per multiply of the weight-gradient contractions: 6, or 3 with WN_FLAG_DW_3PRODUCT
-    int dw_f16_mode;  // WN_FLAG_DW_F16PAIR: 0 off; 1 the caller's exponent (| WN_FLAG_DW_F16_EXP_VALID); 2 max |dlogits| as the loss call of
+    bool mm_f16;      // WN_FLAG_MM_F16PAIR: the forward / data-gradient split contractions (k_gemm6) take the fp16 pair split as well, each
+                      // followed by its conditional six-product redo
+    int dw_f16_mode;  // WN_FLAG_DW_F16PAIR / WN_FLAG_MM_F16PAIR: 0 off; 1 the caller's exponent (| WN_FLAG_DW_F16_EXP_VALID); 2 max |dlogits| as the loss call of
                       // this workspace measured it (| WN_FLAG_DW_F16_AMAX_WS); 3 measured by a scan of the dlogits given to wn_backward
     float dw_f16_mul; // != 0 (WN_FLAG_DW_F16PAIR): weight gradients by the fp16 pair split; -1: the gradient operand times the power of two
                       // wn_dw_prepare leaves in the workspace (every mode: one code path);
@@ -591,8 +606,9 @@ static int make_ctx(Ctx* c, const WnConfig* cfg, int B, int T, void* ws, size_t 
     c->fused = wn_fused_supported(c->d.R, c->d.K, c->d.S) && !(flags & WN_FLAG_NO_FUSED);
     c->split_bf16 = !(flags & WN_FLAG_EXACT_MFMA);
     c->dw_products = (flags & WN_FLAG_DW_3PRODUCT) ? 3 : 6;
-    c->dw_f16_mode = !(flags & WN_FLAG_DW_F16PAIR) ? 0 : (flags & WN_FLAG_DW_F16_EXP_VALID) ? 1 : (flags & WN_FLAG_DW_F16_AMAX_WS) ? 2 : 3;
-    c->dw_f16_mul = c->dw_f16_mode ? -1.0f : 0.0f;
+    c->mm_f16 = c->split_bf16 && (flags & WN_FLAG_MM_F16PAIR);
+    c->dw_f16_mode = !((flags & WN_FLAG_DW_F16PAIR) || c->mm_f16) ? 0 : (flags & WN_FLAG_DW_F16_EXP_VALID) ? 1 : (flags & WN_FLAG_DW_F16_AMAX_WS) ? 2 : 3;
+    c->dw_f16_mul = (flags & WN_FLAG_DW_F16PAIR) ? -1.0f : 0.0f;
     c->dw_ovf = reinterpret_cast<int*>(c->ws + c->w.dw_ovf);
     c->params = nullptr;
     c->have_pre = true;
@@ -619,18 +635,18 @@ static int dzs_layers(const Dims& d) { return d.L; }   // layers bwd_dz_skip_all
 // The weight sets of the split contractions every training step launches: (A, lda, M, K) and where their split form lives.
 // They are split ONCE per step by one launch at the end of pack_weights (six dependent little launches in front of the
 // contractions otherwise); wn_backward finds them in the workspace wn_forward left.
-struct PreJob { const float* A; long lda; int M, K; long off; };
+struct PreJob { const float* A; long lda; int M, K; long off, off16; };
 static int pre_jobs(const Ctx& c, const float* params, PreJob (&j)[6]) {
     const Dims& d = c.d;
     const Lay& y = c.y;
     const Ws& w = c.w;
     float* ws = c.ws;
-    const PreJob all[6] = {{ws + w.wskip_f, d.S, d.S, d.L * d.R, w.apk_pre[0]},
-                           {ws + w.w1_f, d.S, d.S, d.S, w.apk_pre[1]},
-                           {ws + w.w2_f, d.Qo, d.Qo, d.S, w.apk_pre[2]},
-                           {params ? params + y.post2_w : nullptr, d.S, d.S, d.Qo, w.apk_pre[3]},
-                           {params ? params + y.post1_w : nullptr, d.S, d.S, d.S, w.apk_pre[4]},
-                           {ws + w.wskipT_f, (long)d.L * d.R, dzs_layers(d) * d.R, d.S, w.apk_pre[5]}};
+    const PreJob all[6] = {{ws + w.wskip_f, d.S, d.S, d.L * d.R, w.apk_pre[0], w.apk_pre16[0]},
+                           {ws + w.w1_f, d.S, d.S, d.S, w.apk_pre[1], w.apk_pre16[1]},
+                           {ws + w.w2_f, d.Qo, d.Qo, d.S, w.apk_pre[2], w.apk_pre16[2]},
+                           {params ? params + y.post2_w : nullptr, d.S, d.S, d.Qo, w.apk_pre[3], w.apk_pre16[3]},
+                           {params ? params + y.post1_w : nullptr, d.S, d.S, d.S, w.apk_pre[4], w.apk_pre16[4]},
+                           {ws + w.wskipT_f, (long)d.L * d.R, dzs_layers(d) * d.R, d.S, w.apk_pre[5], w.apk_pre16[5]}};
     int n = 0;
     if (!c.have_pre || !c.split_bf16) return 0;
     for (int i = 0; i < 6; ++i)
@@ -640,7 +656,7 @@ static int pre_jobs(const Ctx& c, const float* params, PreJob (&j)[6]) {
 // The per-layer weight sets of a wide model's step (any-size path with the split contractions, n_resch % 128 == 0): layer l of
 // set i lives at A + l * lstride (floats) and its split form at apk_wide[i] + l * apk_wide_l[i].  Set 0 is packed with the
 // gate row permutation (gate_R = R: the forward gate epilogue), the others plainly.
-struct WideJob { const float* A; long lstride, lda; int M, K, gate_R, nl; long off, off_l; };
+struct WideJob { const float* A; long lstride, lda; int M, K, gate_R, nl; long off, off_l, off16; };
 static int wide_jobs(const Ctx& c, const float* params, WideJob (&j)[5]) {
     const Dims& d = c.d;
     const Lay& y = c.y;
@@ -648,20 +664,24 @@ static int wide_jobs(const Ctx& c, const float* params, WideJob (&j)[5]) {
     if (!c.have_pre || !c.split_bf16 || c.fused || w.apk_wide[0] < 0 || !params) return 0;
     const long lb0 = layer_base(y, d, 0);
     const WideJob all[5] = {
-        {c.ws + w.wd_f, (long)d.K * d.R * 2 * d.R, 2 * d.R, 2 * d.R, d.K * d.R, d.R, d.L, w.apk_wide[0], w.apk_wide_l[0]},   // fwd_dilated_gate
-        {c.ws + w.wres_f, (long)d.R * d.R, d.R, d.R, d.R, 0, d.L, w.apk_wide[1], w.apk_wide_l[1]},                          // fwd_res
-        {params + y.skip0, y.ls_skip, d.R, d.R, d.S, 0, d.L, w.apk_wide[2], w.apk_wide_l[2]},                               // bwd_dz_skip
-        {params + lb0 + y.o_res_w, -y.LB, d.R, d.R, d.R, 0, d.L, w.apk_wide[3], w.apk_wide_l[3]},                           // bwd_dz_res
-        {c.ws + w.wd_b, (long)d.K * 2 * d.R * d.R, d.R, d.R, d.K * 2 * d.R, 0, d.L, w.apk_wide[4], w.apk_wide_l[4]}};      // bwd_dx_dilated
+        {c.ws + w.wd_f, (long)d.K * d.R * 2 * d.R, 2 * d.R, 2 * d.R, d.K * d.R, d.R, d.L, w.apk_wide[0], w.apk_wide_l[0], w.apk_wide16[0]},   // fwd_dilated_gate
+        {c.ws + w.wres_f, (long)d.R * d.R, d.R, d.R, d.R, 0, d.L, w.apk_wide[1], w.apk_wide_l[1], w.apk_wide16[1]},                          // fwd_res
+        {params + y.skip0, y.ls_skip, d.R, d.R, d.S, 0, d.L, w.apk_wide[2], w.apk_wide_l[2], w.apk_wide16[2]},                               // bwd_dz_skip
+        {params + lb0 + y.o_res_w, -y.LB, d.R, d.R, d.R, 0, d.L, w.apk_wide[3], w.apk_wide_l[3], w.apk_wide16[3]},                           // bwd_dz_res
+        {c.ws + w.wd_b, (long)d.K * 2 * d.R * d.R, d.R, d.R, d.K * 2 * d.R, 0, d.L, w.apk_wide[4], w.apk_wide_l[4], w.apk_wide16[4]}};      // bwd_dx_dilated
     for (int i = 0; i < 5; ++i) j[i] = all[i];
     return 5;
 }
-static long prepacked_offset(const Ctx& c, const WnGemmArgs& g, int gate_R = 0) {
+static long prepacked_offset(const Ctx& c, const WnGemmArgs& g, int gate_R = 0, long* off16 = nullptr) {
+    if (off16) *off16 = -1;
     if (gate_R == 0) {
         PreJob j[6];
         const int n = pre_jobs(c, c.params, j);
         for (int i = 0; i < n; ++i)
-            if (j[i].A == g.A && j[i].lda == g.lda && j[i].M == g.M && j[i].K == g.K) return j[i].off;
+            if (j[i].A == g.A && j[i].lda == g.lda && j[i].M == g.M && j[i].K == g.K) {
+                if (off16) *off16 = j[i].off16;
+                return j[i].off;
+            }
     }
     WideJob wj[5];
     const int nw = wide_jobs(c, c.params, wj);
@@ -670,7 +690,10 @@ static long prepacked_offset(const Ctx& c, const WnGemmArgs& g, int gate_R = 0) 
         const long diff = g.A - wj[i].A;
         if (diff % wj[i].lstride != 0) continue;
         const long l = diff / wj[i].lstride;
-        if (l >= 0 && l < wj[i].nl) return wj[i].off + l * wj[i].off_l;
+        if (l >= 0 && l < wj[i].nl) {
+            if (off16 && wj[i].off16 >= 0) *off16 = wj[i].off16 + l * wj[i].off_l;
+            return wj[i].off + l * wj[i].off_l;
+        }
     }
     return -1;
 }
@@ -691,14 +714,17 @@ struct CeEpi {   // softmax cross-entropy as the epilogue of the contraction tha
 // n_origin: index of column 0 of this launch in the caller's full (B, C, T) tensor (a loss-window launch starts at t0): the
 // alternating tile signs of k_gemm6 follow the ABSOLUTE column, so a windowed launch produces bit for bit what the full one
 // produces on those columns (same ReLU masks in the training step's and the module's forward).
-static int fw_gemm(const Ctx& c, const WnGemmArgs& g, const GateEpi* ge = nullptr, const CeEpi* ce = nullptr, int n_origin = 0) {
+// grad_b: the B operand is a back-propagated gradient (fp16 pair mode: scaled by the measured 2^8 / max |dlogits|, wn_dw_prepare)
+static int fw_gemm(const Ctx& c, const WnGemmArgs& g, const GateEpi* ge = nullptr, const CeEpi* ce = nullptr, int n_origin = 0,
+                   bool grad_b = false) {
     const bool ok = c.split_bf16 && g.M >= 128 && !g.a_kmajor && !g.b_kmajor &&
                     (g.b_seg_len >= g.K || g.b_seg_len % 16 == 0) && g.ksplit == 1 && g.nlayer == 1 && !g.b_relu &&
                     !g.b_index && g.a_zstride == 0 && !g.a_rowsum &&
                     wn_gemm6_apk_elems(g.M, g.K) <= 2 * c.w.apk_floats && (long)g.M * g.ldc * 4 < 0x7ffffff0L;
     if (!ok) return (ge || ce) ? fail(3, "gate / loss epilogue needs the split contraction") : wn_gemm_launch(&g, c.st);
     unsigned short* apk = reinterpret_cast<unsigned short*>(c.ws + c.w.apk);
-    const long pre = prepacked_offset(c, g, ge ? ge->gate_R : 0);   // (gate' epilogues use the plain packing: gate_R = 0)
+    long pre16 = -1;
+    const long pre = prepacked_offset(c, g, ge ? ge->gate_R : 0, &pre16);   // (gate' epilogues use the plain packing: gate_R = 0)
     if (pre >= 0)
         apk = reinterpret_cast<unsigned short*>(c.ws + pre);   // split once per step by pack_weights
     else
@@ -722,6 +748,15 @@ static int fw_gemm(const Ctx& c, const WnGemmArgs& g, const GateEpi* ge = nullpt
     if (ce) {
         a.ce_target = reinterpret_cast<const long long*>(ce->target); a.ce_tstride = g.ldc; a.ce_t_start = ce->t_start;
         a.ce_gs = ce->gs; a.ce_partial = ce->partial; a.ce_amax = ce->amax;
+    }
+    // WN_FLAG_MM_F16PAIR: the fp16 pair split with the conditional six-product redo behind it -- for the weight sets pack_weights
+    // split both ways, and only where a redo may simply run again (no C += result, no in-place residual)
+    const bool writes_acc = g.accumulate && !(ge && ge->bw_dP);
+    if (c.mm_f16 && c.dw_ovf && pre >= 0 && pre16 >= 0 && !writes_acc && !(g.D && g.D == g.C)) {
+        WnGemm6Args h = a;
+        h.f16 = 1; h.Apk = reinterpret_cast<unsigned short*>(c.ws + pre16); h.b_mul = grad_b ? -1.0f : 16.0f; h.ovf = c.dw_ovf;   // activations times 2^4: second pieces normal down to 2^-7
+        WN_TRY(wn_gemm6_launch(&h, c.st));
+        a.ovf = c.dw_ovf;   // f16 = 0 with ovf: works only if the launch above raised the word
     }
     return wn_gemm6_launch(&a, c.st);
 }
@@ -810,13 +845,26 @@ static int pack_weights(const Ctx& c, const float* params) {
                 jobs.dst[i] = reinterpret_cast<unsigned short*>(ws + pj[i].off);
                 wn_gemm6_pack_job_single(&jobs, i);
             }
+            int nj = n + nw;
             for (int i = 0; i < nw; ++i) {   // every layer of a wide model's five per-layer sets: one launch instead of 5 L - 1
                 const int q = n + i;
                 jobs.src[q] = wj[i].A; jobs.lda[q] = wj[i].lda; jobs.M[q] = wj[i].M; jobs.K[q] = wj[i].K;
                 jobs.dst[q] = reinterpret_cast<unsigned short*>(ws + wj[i].off);
                 jobs.nl[q] = wj[i].nl; jobs.src_lstride[q] = wj[i].lstride; jobs.dst_lstride[q] = 2 * wj[i].off_l;
-                jobs.gate_R[q] = wj[i].gate_R;
+                jobs.gate_R[q] = wj[i].gate_R; jobs.f16[q] = 0;
             }
+            if (c.mm_f16) {   // ... and as two-piece fp16 images (the bf16 ones stay: the redo launches contract with them)
+                for (int q = 0; q < n + nw; ++q) {
+                    const long o16 = q < n ? pj[q].off16 : wj[q - n].off16;
+                    if (o16 < 0 || nj >= WN_G6_PACK_MAXJOBS) continue;
+                    jobs.src[nj] = jobs.src[q]; jobs.lda[nj] = jobs.lda[q]; jobs.M[nj] = jobs.M[q]; jobs.K[nj] = jobs.K[q];
+                    jobs.nl[nj] = jobs.nl[q]; jobs.src_lstride[nj] = jobs.src_lstride[q]; jobs.dst_lstride[nj] = jobs.dst_lstride[q];
+                    jobs.gate_R[nj] = jobs.gate_R[q]; jobs.f16[nj] = 1;
+                    jobs.dst[nj] = reinterpret_cast<unsigned short*>(ws + o16);
+                    ++nj;
+                }
+            }
+            jobs.njobs = nj;
             WN_TRY(wn_gemm6_pack_batch(&jobs, c.st));
         }
     }
@@ -860,6 +908,7 @@ static int forward_stack(const Ctx& c, const float* params, const int64_t* x, co
     const long BRT = (long)B * d.R * T;
 
     WN_TRY(pack_weights(c, params));
+    if (c.mm_f16 && c.dw_ovf) WN_TRY(wn_fill(c.ws + c.w.dw_ovf, 0.0f, 1, c.st));   // overflow word of the fp16 pair launches of this pass
     // front: one-hot + causal conv as a gather  (wavenet.py:513-516)
     WN_TRY(wn_front_gather(x, ws + w.wc_f, params + y.causal_b, ws + w.X, B, T, d.Q, d.R, d.K, c.st));
     // frame-rate aux projection for all layers at once: G[b][l*2R+o'][f] = Waux_l . h[b][:, f]

@@ -135,7 +135,7 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
         g.C = ws + w.dO2 + t0; g.ldc = T; g.c_zstride = (long)d.S * T;
         g.E = ws + w.O2 + t0; g.lde = T; g.e_zstride = (long)d.S * T;
         g.nbatch = B; g.tag = "bwd_post2_dx";
-        WN_TRY(fw_gemm(c, g, nullptr, nullptr, t0));
+        WN_TRY(fw_gemm(c, g, nullptr, nullptr, t0, true));
     }
     {   // dSkip = W1^T dO2, masked by relu'(skip-sum)
         WnGemmArgs g = wn_gemm_default();
@@ -145,7 +145,7 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
         g.C = ws + w.dSk + t0; g.ldc = T; g.c_zstride = (long)d.S * T;
         g.E = ws + w.O1 + t0; g.lde = T; g.e_zstride = (long)d.S * T;
         g.nbatch = B; g.tag = "bwd_post1_dx";
-        WN_TRY(fw_gemm(c, g, nullptr, nullptr, t0));
+        WN_TRY(fw_gemm(c, g, nullptr, nullptr, t0, true));
         if (t0 > 0) WN_TRY(wn_fill_cols(ws + w.dSk, (long)B * d.S, T, t0, c.st));
     }
     WN_TRY(side_link(side.rt, c.st, cs.st));  // fork: dO2, dSkip (and everything before this call) are ready
@@ -207,7 +207,7 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
         g.B = ws + w.dSk + t0; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = Tw;
         g.C = ws + w.dZs + t0; g.ldc = T; g.c_zstride = zs_bstride;
         g.nbatch = B; g.tag = "bwd_dz_skip_all";
-        WN_TRY(fw_gemm(c, g, nullptr, nullptr, t0));
+        WN_TRY(fw_gemm(c, g, nullptr, nullptr, t0, true));
         // dZs[.., t < t0] stays unwritten: the chain kernel takes it as zero without reading it (ChainArgs.zs_t0)
     }
     // WN_FLAG_BWD_OVERLAP_HEAD: only the post-net / skip weight gradients (matrix-bound) go to the side stream, the
@@ -356,16 +356,16 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
             ge.bw_S = Sl; ge.bw_Gt = Gtl; ge.bw_dP = dP;
             if (epi) {
                 if (dXn) {
-                    WN_TRY(fw_gemm(c, gs));
+                    WN_TRY(fw_gemm(c, gs, nullptr, nullptr, 0, true));
                     gr.tag = "bwd_dz_res_gate";
-                    WN_TRY(fw_gemm(c, gr, &ge));
+                    WN_TRY(fw_gemm(c, gr, &ge, nullptr, 0, true));
                 } else {
                     gs.tag = "bwd_dz_skip_gate";
-                    WN_TRY(fw_gemm(c, gs, &ge));
+                    WN_TRY(fw_gemm(c, gs, &ge, nullptr, 0, true));
                 }
             } else {
-                WN_TRY(fw_gemm(c, gs));
-                if (dXn) WN_TRY(fw_gemm(c, gr));
+                WN_TRY(fw_gemm(c, gs, nullptr, nullptr, 0, true));
+                if (dXn) WN_TRY(fw_gemm(c, gr, nullptr, nullptr, 0, true));
                 WN_TRY(wn_gate_bwd(ws + w.dZ, Sl, Gtl, dP, B, T, d.R, c.st));
             }
             {   // dX_l = dX_{l+1} + sum_tap W_tap^T dP[t + (K-1-tap) d]
@@ -377,7 +377,7 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
                 g.C = dXl; g.ldc = T; g.c_zstride = (long)d.R * T;
                 if (dXn) { g.D = dXn; g.ldd = T; g.d_zstride = (long)d.R * T; }
                 g.nbatch = B; g.tag = "bwd_dx_dilated";
-                WN_TRY(fw_gemm(c, g));
+                WN_TRY(fw_gemm(c, g, nullptr, nullptr, 0, true));
             }
         }
         const int done = d.L - l;  // layers walked

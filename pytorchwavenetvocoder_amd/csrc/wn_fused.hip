@@ -30,6 +30,12 @@
 
 #include <stdlib.h>
 
+// -DWN_EXP_NPROD=3: TIMING-ONLY experiment builds (tools/build_variant.sh): the split fused kernels issue 3 of their 6 products per
+// multiply -- numerically WRONG, what the matrix work of a two-piece operand split would cost.  The product is built with 6.
+#ifndef WN_EXP_NPROD
+#define WN_EXP_NPROD 6
+#endif
+
 #ifdef WN_TIMING
 // Experimental build only (tools/exp): per-phase cycle stamps of block 0, lane 0 of every wave.
 static long long* g_dbg = nullptr;
@@ -730,7 +736,7 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_s(FwdArgs a) {
                             af[q][p] = *reinterpret_cast<const wn_f4*>(Wl + p * (128 * 32) + (qh + q) * 1024);
                     }
                     WN_UNROLL
-                    for (int t6 = 0; t6 < 6; ++t6) {
+                    for (int t6 = 0; t6 < WN_EXP_NPROD; ++t6) {
                         acc[qh] = mfma_bf16(af[0][PA[t6]], bf[PB[t6]], acc[qh]);
                         acc[qh + 1] = mfma_bf16(af[1][PA[t6]], bf[PB[t6]], acc[qh + 1]);
                     }
@@ -773,7 +779,7 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_s(FwdArgs a) {
                             af[q][p] = *reinterpret_cast<const wn_f4*>(Wl + p * (128 * 32) + (qh + q) * 1024);
                     }
                     WN_UNROLL
-                    for (int t6 = 0; t6 < 6; ++t6) {
+                    for (int t6 = 0; t6 < WN_EXP_NPROD; ++t6) {
                         acc[qh] = mfma_bf16(af[0][PA[t6]], bf[PB[t6]], acc[qh]);
                         acc[qh + 1] = mfma_bf16(af[1][PA[t6]], bf[PB[t6]], acc[qh + 1]);
                     }
@@ -882,7 +888,7 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_s(FwdArgs a) {
                 if (kb + 1 < 4) res_frags(kb + 1, afr[(kb + 1) & 1]);
                 constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
                 WN_UNROLL
-                for (int t6 = 0; t6 < 6; ++t6) {
+                for (int t6 = 0; t6 < WN_EXP_NPROD; ++t6) {
                     racc[0] = mfma_bf16(afr[kb & 1][0][PA[t6]], bf[PB[t6]], racc[0]);
                     racc[1] = mfma_bf16(afr[kb & 1][1][PA[t6]], bf[PB[t6]], racc[1]);
                 }
@@ -1613,7 +1619,7 @@ __global__ __launch_bounds__(WN_LB) void k_chain64s(ChainArgs a) {
             }
             constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};  // small terms first
             WN_UNROLL
-            for (int t6 = 0; t6 < 6; ++t6) {
+            for (int t6 = 0; t6 < WN_EXP_NPROD; ++t6) {
                 acc[0] = mfma_bf16(af[0][PA[t6]], bf[PB[t6]], acc[0]);
                 acc[1] = mfma_bf16(af[1][PA[t6]], bf[PB[t6]], acc[1]);
             }
@@ -1746,7 +1752,7 @@ __global__ __launch_bounds__(WN_LB) void k_chain64s(ChainArgs a) {
                 if (kb + 1 < 4) res_frags(kb + 1, afr[(kb + 1) & 1]);
                 constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
                 WN_UNROLL
-                for (int t6 = 0; t6 < 6; ++t6) {
+                for (int t6 = 0; t6 < WN_EXP_NPROD; ++t6) {
                     dz[0] = mfma_bf16(afr[kb & 1][0][PA[t6]], bf[PB[t6]], dz[0]);
                     dz[1] = mfma_bf16(afr[kb & 1][1][PA[t6]], bf[PB[t6]], dz[1]);
                 }

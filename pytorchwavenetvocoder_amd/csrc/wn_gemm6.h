@@ -4,6 +4,7 @@
 #pragma once
 #include "wn_device.h"
 
+#define WN_G6_F16_WSCALE 64   // power of two the fp16 pair images of the weights are scaled by (wn_gemm6_pack_batch, f16 jobs)
 #define WN_G6_BM 256
 #define WN_G6_BN 128
 
@@ -65,12 +66,20 @@ typedef struct WnGemm6Args {
     float ce_gs;
     float* ce_partial;
     float* ce_amax;             // nullable, indexed like ce_partial: the block's max |d(mean loss)/d(logit) * ce_gs|
+    // fp16 pair split (k_gemm6<.., F16>): f16 != 0 -> Apk is the two-piece fp16 image (wn_gemm6_pack_batch, f16 job), B is
+    // multiplied by b_mul at the split (> 0: that power of two; < 0: the one at ((const float*)ovf)[1]) and the accumulators by
+    // its inverse, *ovf := 1 when a block's accumulators are not finite.  f16 == 0 with ovf != NULL: the conditional six-product
+    // redo behind such a launch (returns at once unless *ovf != 0).
+    int f16;
+    float b_mul;
+    int* ovf;
 } WnGemm6Args;
 
 static inline void wn_gemm6_no_gate(WnGemm6Args* a) {
     a->gate_R = 0; a->gate_S = 0; a->gate_Gt = 0; a->gate_Z = 0; a->gate_G = 0; a->gate_gb = 0; a->gate_F = 0; a->gate_U = 1;
     a->gate_upw = 0; a->gate_cvec = 0; a->gbw_S = 0; a->gbw_Gt = 0; a->gbw_dP = 0; a->no_interior = 0; a->stagger = 0; a->n_phase = 0;
     a->ce_target = 0; a->ce_tstride = 0; a->ce_t_start = 0; a->ce_gs = 0.f; a->ce_partial = 0; a->ce_amax = 0;
+    a->f16 = 0; a->b_mul = 0.f; a->ovf = 0;
 }
 
 static inline long wn_gemm6_apk_elems(int M, int K) {
@@ -82,7 +91,7 @@ static inline long wn_gemm6_apk_elems(int M, int K) {
 // rows followed by the 64 tanh rows of the same channels (the pairing of the forward gate epilogue).
 int wn_gemm6_pack(const float* src, long lda, int M, int K, unsigned short* Apk, int gate_R, wn_stream_t st);
 // several weight sets in ONE launch (the six of a training step are split once per step: wn_api.hip pack_weights)
-#define WN_G6_PACK_MAXJOBS 12
+#define WN_G6_PACK_MAXJOBS 24
 typedef struct WnGemm6PackJobs {
     int njobs;
     int blk0[WN_G6_PACK_MAXJOBS + 1];   // first block of job j (filled by wn_gemm6_pack_batch)
@@ -95,9 +104,10 @@ typedef struct WnGemm6PackJobs {
     int nl[WN_G6_PACK_MAXJOBS];
     long src_lstride[WN_G6_PACK_MAXJOBS], dst_lstride[WN_G6_PACK_MAXJOBS];
     int gate_R[WN_G6_PACK_MAXJOBS];
+    int f16[WN_G6_PACK_MAXJOBS];   // != 0: the two-piece fp16 image [kb][2][Mpad][16] of k_gemm6<.., F16> instead of the three bf16 pieces
 } WnGemm6PackJobs;
 static inline void wn_gemm6_pack_job_single(WnGemm6PackJobs* j, int i) {
-    j->nl[i] = 1; j->src_lstride[i] = 0; j->dst_lstride[i] = 0; j->gate_R[i] = 0;
+    j->nl[i] = 1; j->src_lstride[i] = 0; j->dst_lstride[i] = 0; j->gate_R[i] = 0; j->f16[i] = 0;
 }
 int wn_gemm6_pack_batch(WnGemm6PackJobs* jobs, wn_stream_t st);
 static __host__ __device__ inline int wn_gemm6_gate_row(int p, int R) {

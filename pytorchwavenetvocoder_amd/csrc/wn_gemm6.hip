@@ -29,7 +29,7 @@
 #define G6_T 256
 
 static __device__ __forceinline__ void gemm6_pack_elem(const float* src, long lda, int M, int K, int Mpad, unsigned short* Apk,
-                                                       int gate_R, long idx);
+                                                       int gate_R, long idx, int f16 = 0);
 __global__ void k_gemm6_pack(const float* src, long lda, int M, int K, int Mpad, unsigned short* Apk, int gate_R) {
     gemm6_pack_elem(src, lda, M, K, Mpad, Apk, gate_R, (long)blockIdx.x * 256 + threadIdx.x);
 }
@@ -40,10 +40,12 @@ __global__ void k_gemm6_pack_batch(WnGemm6PackJobs a) {
     const int per = (int)(((long)((a.K[j] + 15) / 16) * Mpad + 255) / 256);   // blocks per weight set of this job
     const int rel = (int)blockIdx.x - a.blk0[j], li = rel / per;
     gemm6_pack_elem(a.src[j] + (long)li * a.src_lstride[j], a.lda[j], a.M[j], a.K[j], Mpad, a.dst[j] + (long)li * a.dst_lstride[j],
-                    a.gate_R[j], (long)(rel - li * per) * 256 + threadIdx.x);
+                    a.gate_R[j], (long)(rel - li * per) * 256 + threadIdx.x, a.f16[j]);
 }
+// f16 != 0: the fp16 pair split of k_gemm6<.., F16> -- TWO pieces per value (x ~ h + l, 11 + 11 significand bits), laid out
+// [kb][2][Mpad][16] (two thirds of the bf16 image)
 static __device__ __forceinline__ void gemm6_pack_elem(const float* src, long lda, int M, int K, int Mpad, unsigned short* Apk,
-                                                       int gate_R, long idx) {
+                                                       int gate_R, long idx, int f16) {
     // one thread per (kb, m): 16 k values -> 3 x 16 bf16
     const int nkb = (K + 15) / 16;
     if (idx >= (long)nkb * Mpad) return;
@@ -60,6 +62,15 @@ static __device__ __forceinline__ void gemm6_pack_elem(const float* src, long ld
             const int k = kb * 16 + e + u;
             x[u] = (m < M && k < K) ? src[(long)k * lda + ms] : 0.f;
         }
+        if (f16) {   // weights times 2^6: a second piece stays a normal fp16 number down to |w| = 2^-9 (full 22 bits); the kernel divides it out
+            x[0] *= (float)WN_G6_F16_WSCALE;
+            x[1] *= (float)WN_G6_F16_WSCALE;
+            const unsigned h = wn_pk_f16(x[0], x[1]);
+            hh[e / 2] = h;
+            mm[e / 2] = wn_pk_f16(x[0] - wn_f16lo_f32(h), x[1] - wn_f16hi_f32(h));
+            ll[e / 2] = 0u;
+            continue;
+        }
         const unsigned h = wn_pk_bf16(x[0], x[1]);
         const float r0 = x[0] - wn_bits_f32(h << 16), r1 = x[1] - wn_bits_f32(h & 0xffff0000u);
         const unsigned md = wn_pk_bf16(r0, r1);
@@ -69,9 +80,9 @@ static __device__ __forceinline__ void gemm6_pack_elem(const float* src, long ld
     }
     unsigned* d = reinterpret_cast<unsigned*>(Apk);
     const unsigned* src3[3] = {hh, mm, ll};
-    WN_UNROLL
-    for (int p = 0; p < 3; ++p) {
-        wn_f4* dst = reinterpret_cast<wn_f4*>(d + (((long)kb * 3 + p) * Mpad + m) * 8);   // 32-byte rows: 16-byte aligned
+    const int np = f16 ? 2 : 3;
+    for (int p = 0; p < np; ++p) {
+        wn_f4* dst = reinterpret_cast<wn_f4*>(d + (((long)kb * np + p) * Mpad + m) * 8);   // 32-byte rows: 16-byte aligned
         WN_UNROLL
         for (int q = 0; q < 2; ++q) {
             wn_f4 v;
@@ -161,11 +172,21 @@ static long long* g6_dbg_for(const char* tag) { return (g6_dbg_buf && tag && str
 
 // CE = true: the instantiation with the softmax cross-entropy epilogue (its own kernel, so that the register allocation of
 // the plain one does not depend on it)
-template <bool CE>
+// F16 (round 6, WN_FLAG_MM_F16PAIR): TWO fp16 pieces per operand (x ~ h + l, 11 + 11 significand bits) and the three products
+// h h + h l + l h on v_mfma_f32_32x32x16_f16 -- ~2^-22 |a b| per product, the rounding of an fp32 running sum over >= 64 terms -- at
+// half the matrix work and two thirds of the LDS traffic of the six bf16 products.  fp16 has 5 exponent bits: the B operand (an
+// activation, or a gradient ~1e-5 ... 1e-8) is multiplied by g.b_mul (a power of two; < 0: the scale wn_dw_prepare left at
+// ((float*)g.ovf)[1], i.e. 2^8 / max |dlogits| measured) at the split and the accumulators by its inverse; a value beyond fp16's
+// range makes the block's accumulators non-finite: the epilogue raises *g.ovf, and the six-product launch issued behind every
+// fp16 launch (this kernel with F16 = false and g.ovf set: it returns at its first instruction otherwise) redoes the contraction.
+template <bool CE, bool F16 = false>
 __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_DBG_PARAM) {
     WN_DYN_SMEM(smem_raw);
-    // stage s: A pieces [3][256][16] bf16 (24 KB) then B pieces [3][128][16] bf16 (12 KB)
-    constexpr int A_BYTES = 3 * WN_G6_BM * 32, B_BYTES = 3 * WN_G6_BN * 32, ST_BYTES = A_BYTES + B_BYTES;
+    if (!F16 && g.ovf != nullptr && wn_load_coherent_int(g.ovf) == 0) return;   // the conditional redo behind an fp16 launch
+    constexpr int NP = F16 ? 2 : 3;          // pieces per operand
+    constexpr int NPROD = F16 ? 3 : 6;       // products per multiply
+    // stage s: A pieces [NP][256][16] (24 / 16 KB) then B pieces [NP][128][16] (12 / 8 KB)
+    constexpr int A_BYTES = NP * WN_G6_BM * 32, B_BYTES = NP * WN_G6_BN * 32, ST_BYTES = A_BYTES + B_BYTES;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
@@ -187,6 +208,10 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
     // sequence it cancels instead of adding up (same probe: 9.0e-6).  Exact in every other respect: -x splits into the
     // negated pieces of x.
     const float fs = ((blk.x + g.n_phase) & 1) ? -1.0f : 1.0f;
+    float b_mul = 1.0f;
+    if (F16) b_mul = g.b_mul < 0.0f ? reinterpret_cast<const float*>(g.ovf)[1] : g.b_mul;   // (one uniform load)
+    const float fsm = fs * b_mul;            // what a B element is multiplied by at the split
+    const float fsc = F16 ? fs / (b_mul * (float)WN_G6_F16_WSCALE) : fs; // ... and an accumulator in the epilogue (powers of two)
     // De-phase the two blocks that share a CU (WN_G6_STAGGER, A/B knob).  They start together, do the same work and so
     // stay in lock step: both in their prologue (HBM latency) and both in their epilogue (stores) at the same time, with the
     // matrix pipe idle.  The second resident of the first round -- its waves sit in wave slot 1 of their SIMDs -- starts
@@ -195,7 +220,7 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
         for (int i = 0; i < g.stagger; ++i) WN_SLEEP(127);
 
     // the split weights go global -> LDS directly (their packed layout IS the LDS layout)
-    const wn_rsrc_t Ar = wn_make_buf(g.Apk, (unsigned)((long)nk * 3 * g.Mpad * 32));
+    const wn_rsrc_t Ar = wn_make_buf(g.Apk, (unsigned)((long)nk * NP * g.Mpad * 32));
     const int wave_u = WN_UNIFORM(wave);
     float rb0[8], rb1[8];  // activations are fetched two steps ahead (HBM latency), weights one (L2)
     const int bn = tid & 127, bkh = tid >> 7;  // this thread's B column and k half (8 k values)
@@ -209,8 +234,8 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
         char* sa = smem_raw + st * ST_BYTES + wave_u * 1024;
         const int kc = kb < nk ? kb : nk - 1;
         WN_UNROLL
-        for (int p = 0; p < 3; ++p) {
-            const unsigned src = (unsigned)((kc * 3 + p) * g.Mpad + m0) * 32u;
+        for (int p = 0; p < NP; ++p) {
+            const unsigned src = (unsigned)((kc * NP + p) * g.Mpad + m0) * 32u;
             // slot tid of the piece = row tid >> 1, stored half tid & 1, which holds the k half wn_frag_off says
             wn_buf_load_lds16(Ar, sa + p * (WN_G6_BM * 32), a_voff, src);
             wn_buf_load_lds16(Ar, sa + p * (WN_G6_BM * 32) + 4096, a_voff, src + 4096u);
@@ -241,7 +266,13 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
     };
     // split of one pair of this thread's 8 activations into its three bf16 pieces (9 VALU instructions)
     auto split_pair = [&](int q, const float (&rb)[8], unsigned (&h)[4], unsigned (&md)[4], unsigned (&lo)[4]) {
-        const float x0 = rb[2 * q] * fs, x1 = rb[2 * q + 1] * fs;
+        const float x0 = rb[2 * q] * fsm, x1 = rb[2 * q + 1] * fsm;
+        if constexpr (F16) {
+            h[q] = wn_pk_f16(x0, x1);
+            md[q] = wn_pk_f16(x0 - wn_f16lo_f32(h[q]), x1 - wn_f16hi_f32(h[q]));
+            lo[q] = 0u;
+            return;
+        }
         h[q] = wn_pk_bf16(x0, x1);
         const float r0 = x0 - wn_bits_f32(h[q] << 16), r1 = x1 - wn_bits_f32(h[q] & 0xffff0000u);
         md[q] = wn_pk_bf16(r0, r1);
@@ -254,8 +285,10 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
         *reinterpret_cast<wn_f4*>(sb) = v;
         v.x = wn_bits_f32(md[0]); v.y = wn_bits_f32(md[1]); v.z = wn_bits_f32(md[2]); v.w = wn_bits_f32(md[3]);
         *reinterpret_cast<wn_f4*>(sb + WN_G6_BN * 32) = v;
-        v.x = wn_bits_f32(lo[0]); v.y = wn_bits_f32(lo[1]); v.z = wn_bits_f32(lo[2]); v.w = wn_bits_f32(lo[3]);
-        *reinterpret_cast<wn_f4*>(sb + 2 * WN_G6_BN * 32) = v;
+        if constexpr (!F16) {
+            v.x = wn_bits_f32(lo[0]); v.y = wn_bits_f32(lo[1]); v.z = wn_bits_f32(lo[2]); v.w = wn_bits_f32(lo[3]);
+            *reinterpret_cast<wn_f4*>(sb + 2 * WN_G6_BN * 32) = v;
+        }
     };
     auto stage = [&](int st, const float (&rb)[8]) {
         unsigned h[4], md[4], lo[4];
@@ -295,9 +328,9 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
         const char* sb = sa + A_BYTES;
         unsigned h[4], md[4], lo[4];
         float r0[4], r1[4];
-        wn_f4 bf[3][2];
+        wn_f4 bf[NP][2];
         WN_UNROLL
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
             WN_UNROLL
             for (int j = 0; j < 2; ++j)
                 bf[p][j] = *reinterpret_cast<const wn_f4*>(sb + p * (WN_G6_BN * 32) + wn_frag_off(64 * wn + 32 * j + li, hi));
@@ -311,21 +344,47 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
         const int kc = ka < nk ? ka : nk - 1;
         WN_UNROLL
         for (int i = 0; i < 4; ++i) {
-            wn_f4 af[3];
+            wn_f4 af[NP];
             WN_UNROLL
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < NP; ++p)
                 af[p] = *reinterpret_cast<const wn_f4*>(sa + p * (WN_G6_BM * 32) + wn_frag_off(128 * wm + 32 * i + li, hi));
-            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+            // small terms first; F16: h l, l h, h h
+            constexpr int PA[6] = {0, F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0}, PB[6] = {F16 ? 1 : 2, 0, F16 ? 0 : 1, 1, 0, 0};
             WN_UNROLL
-            for (int t = 0; t < 6; ++t) {
+            for (int t = 0; t < NPROD; ++t) {
                 WN_UNROLL
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_bf16(af[PA[t]], bf[PB[t]][j], acc[i][j]);
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (F16) acc[i][j] = mfma_f16(af[PA[t]], bf[PB[t]][j], acc[i][j]);
+                    else acc[i][j] = mfma_bf16(af[PA[t]], bf[PB[t]][j], acc[i][j]);
+                }
                 if (last) continue;   // the final step has nothing to prepare
-                const int sl = i * 6 + t;
+                const int sl = i * NPROD + t;
 #ifdef WN_G6_NO_PAIR_INTERLEAVE   // (round 4's order: the pair of MFMAs, then its piece)
                 WN_SCHED_FENCE_ALU();
 #endif
-                if (sl < 6) {
+                if constexpr (F16) {
+                    // 12 slots: 0-3 the weight slab (4 LDS-DMA pieces), 4-7 the 8 activation loads (two per slot), 8-11 the operand
+                    // split, one pair per slot, and the two LDS writes of the pieces behind the last pair
+                    if (sl < 4) {
+                        const int p = sl >> 1;
+                        const unsigned src = (unsigned)((kc * NP + p) * g.Mpad + m0) * 32u + ((sl & 1) ? 4096u : 0u);
+                        wn_buf_load_lds16(Ar, sda + p * (WN_G6_BM * 32) + ((sl & 1) ? 4096 : 0), a_voff, src);
+                    } else if (sl < 8) {
+                        WN_UNROLL
+                        for (int u = 0; u < 2; ++u) {
+                            const int e = 2 * (sl - 4) + u;
+                            int r = fb_rr + 8 * bkh_u + e;
+                            r = r < rlast ? r : rlast;
+                            rbn[e] = wn_buf_load(Br, voff, r * (int)g.ldb * 4);
+                        }
+                    } else {
+                        const int q = sl - 8;
+                        const float x0 = rb[2 * q] * fsm, x1 = rb[2 * q + 1] * fsm;
+                        h[q] = wn_pk_f16(x0, x1);
+                        md[q] = wn_pk_f16(x0 - wn_f16lo_f32(h[q]), x1 - wn_f16hi_f32(h[q]));
+                        if (sl == 11) write_pieces(stn, h, md, lo);
+                    }
+                } else if (sl < 6) {
                     const int p = sl >> 1;
                     const unsigned src = (unsigned)((kc * 3 + p) * g.Mpad + m0) * 32u + ((sl & 1) ? 4096u : 0u);
                     wn_buf_load_lds16(Ar, sda + p * (WN_G6_BM * 32) + ((sl & 1) ? 4096 : 0), a_voff, src);
@@ -392,6 +451,19 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
     }
     if (nk & 1) step(0, 1, rb1, rb0, 0, true);   // odd number of steps: the last one is staged in LDS stage 0
     WN_WAIT_VMCNT(0);
+    if constexpr (F16) {   // an operand left fp16's range: inf pieces -> inf / NaN accumulators -> the six-product launch behind this one redoes it
+        unsigned nonfinite = 0u;
+        WN_UNROLL
+        for (int i = 0; i < 4; ++i) {
+            WN_UNROLL
+            for (int j = 0; j < 2; ++j) {
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r)
+                    nonfinite |= (~__builtin_bit_cast(unsigned, (float)acc[i][j][r]) & 0x7f800000u) == 0u ? 1u : 0u;
+            }
+        }
+        if (nonfinite) wn_store_coherent_int(g.ovf, 1);
+    }
 
     // epilogue: bias, mask, relu; rows of a lane are (r&3) + 8*(r>>2) + 4*hi, its column is li.
     // Buffer accesses with out-of-range offsets for the ragged edges (reads give 0, writes are dropped).
@@ -428,8 +500,8 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
                 WN_UNROLL
                 for (int r = 0; r < 16; ++r) {
                     const int c = cb + mfma32_row(r, 0);
-                    const float pa = acc[i][j][r] * fs + (wj * ga[r] + g.gate_cvec[c]);
-                    const float pg = acc[i + 2][j][r] * fs + (wj * gg[r] + g.gate_cvec[R + c]);
+                    const float pa = acc[i][j][r] * fsc + (wj * ga[r] + g.gate_cvec[c]);
+                    const float pg = acc[i + 2][j][r] * fsc + (wj * gg[r] + g.gate_cvec[R + c]);
                     const float sv = wn_sigmoid(pa), gv = wn_tanh(pg);
                     const int off = ok ? (cb * (int)g.ldc + col) * 4 : 0x7ffffff0;
                     wn_buf_store(Sr, sv, off, mfma32_row(r, 0) * T4);
@@ -465,7 +537,7 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
                 for (int r = 0; r < 16; ++r) {
                     const int row = rb + mfma32_row(r, 0);
                     const int off = (row < R && col < g.N) ? (row * (int)g.ldc + col) * 4 : 0x7ffffff0;
-                    const float dz = acc[i][j][r] * fs + cv[r];
+                    const float dz = acc[i][j][r] * fsc + cv[r];
                     wn_buf_store(Pr, dz * gv[r] * (sv[r] * (1.0f - sv[r])), off, 0);
                     wn_buf_store(Pr, dz * sv[r] * (1.0f - gv[r] * gv[r]), off, R * T4);
                 }
@@ -509,7 +581,7 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
                 WN_UNROLL
                 for (int r = 0; r < 16; ++r) {
                     const int row = 128 * wm + 32 * i + mfma32_row(r, hi);
-                    float v = acc[i][j][r] * fs + bv[r];
+                    float v = acc[i][j][r] * fsc + bv[r];
                     v = row < g.M ? v : NEG;
                     acc[i][j][r] = v;
                     mx[j] = fmaxf(mx[j], v);
@@ -621,7 +693,7 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
                 WN_SCHED_BARRIER();
                 WN_UNROLL
                 for (int r = 0; r < 16; ++r) {
-                    float v = acc[i][j][r] * fs;
+                    float v = acc[i][j][r] * fsc;
                     v += bv[r] + dv[r];
                     if (g.relu) v = fmaxf(v, 0.f);
                     if (g.E) v = (ev[r] > 0.f) ? v : 0.f;
@@ -661,7 +733,7 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
             WN_UNROLL
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + 128 * wm + 32 * i + mfma32_row(r, hi);
-                float v = acc[i][j][r] * fs;
+                float v = acc[i][j][r] * fsc;
                 v += bv[r] + dv[r];
                 if (g.relu) v = fmaxf(v, 0.f);
                 if (g.E) v = (ev[r] > 0.f) ? v : 0.f;
@@ -688,21 +760,33 @@ int wn_gemm6_launch(const WnGemm6Args* gp, wn_stream_t st) {
     if (g.b_seg_len < g.K && (g.b_seg_len % 16) != 0) return 2;
     if (g.ce_target && (g.Mpad != WN_G6_BM || !g.ce_partial || g.gate_S || g.gbw_dP || g.E || g.D || g.accumulate || g.relu)) return 4;
     constexpr int lds = 2 * (3 * WN_G6_BM * 32 + 3 * WN_G6_BN * 32);
+    constexpr int lds16 = 2 * (2 * WN_G6_BM * 32 + 2 * WN_G6_BN * 32);
+    if (g.f16 && (!g.ovf || g.b_mul == 0.0f)) return 5;
 #ifndef WN_EMU
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm6<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
                 hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm6<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+                hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm6<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds16) !=
+                hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm6<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds16) !=
                 hipSuccess)
             return 3;
         attr_set = true;
     }
 #endif
-    WN_PROF(g.tag ? g.tag : "gemm6", 2.0 * g.M * g.N * (double)g.K * g.nbatch,
-            ((double)g.M * g.K * 6.0 + (double)g.K * g.N * 4.0 + (double)g.M * g.N * (g.E ? 8.0 : 4.0)) * g.nbatch, st);
+    const bool redo = !g.f16 && g.ovf != nullptr;   // the conditional redo: no work unless an fp16 launch overflowed
+    WN_PROF(redo ? "mm_redo_if_overflow" : (g.tag ? g.tag : "gemm6"), redo ? 0.0 : 2.0 * g.M * g.N * (double)g.K * g.nbatch,
+            redo ? 0.0 : ((double)g.M * g.K * (g.f16 ? 4.0 : 6.0) + (double)g.K * g.N * 4.0 + (double)g.M * g.N * (g.E ? 8.0 : 4.0)) * g.nbatch, st);
     dim3 grid((unsigned)((g.N + WN_G6_BN - 1) / WN_G6_BN), (unsigned)(g.Mpad / WN_G6_BM), (unsigned)g.nbatch);
-    if (g.ce_target)
+    if (g.f16) {
+        if (g.ce_target)
+            WN_LAUNCH((k_gemm6<true, true>), grid, dim3(G6_T), lds16, st, g, xcd_block_order() ? 2 : 0 G6_DBG_ARG(g.tag));
+        else
+            WN_LAUNCH((k_gemm6<false, true>), grid, dim3(G6_T), lds16, st, g, xcd_block_order() ? 2 : 0 G6_DBG_ARG(g.tag));
+    } else if (g.ce_target)
         WN_LAUNCH(k_gemm6<true>, grid, dim3(G6_T), lds, st, g, xcd_block_order() ? 2 : 0 G6_DBG_ARG(g.tag));
     else
         WN_LAUNCH(k_gemm6<false>, grid, dim3(G6_T), lds, st, g, xcd_block_order() ? 2 : 0 G6_DBG_ARG(g.tag));

@@ -320,10 +320,10 @@ class WaveNetEngine(object):
         if t_first is None:
             t_first = self._fwd_window
         flags = self.flags
-        family = _lib.FLAG_NO_FUSED | _lib.FLAG_EXACT_MFMA
-        if (flags ^ self._fwd_flags) & family:
-            raise _lib.WnError("engine.flags changed the kernel family (NO_FUSED / EXACT_MFMA) since the forward call: the "
-                               "two families save different activations and weight sets -- run forward again")
+        family = _lib.FLAG_NO_FUSED | _lib.FLAG_EXACT_MFMA | _lib.FLAG_MM_F16PAIR
+        if (flags ^ self._fwd_flags) & family and not repack:
+            raise _lib.WnError("engine.flags changed the kernel family (NO_FUSED / EXACT_MFMA / MM_F16PAIR) since the forward call: "
+                               "the families save different activations and weight sets -- run forward again")
         flags = self._dw_mode_flags(flags, dlogits, dlogits_bound)
         if repack:
             flags |= _lib.FLAG_REPACK

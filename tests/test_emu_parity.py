@@ -966,3 +966,55 @@ def test_same_run_parity_helper_on_the_emulator():
     # 10 eps meets the 1e-2 lr gate, and the few over it are of that sign-like kind.
     assert res["after_adam_elements_over_gate"] <= 8 and res["after_adam_over_gate_max_abs_reference_grad"] < 1e-7, res
     assert res["after_adam_maxabs_over_lr"] <= 0.1, res
+
+
+def test_split_contractions_by_the_fp16_pair_split_and_their_redo():
+    """WN_FLAG_MM_F16PAIR (csrc/wn_gemm6.hip k_gemm6<.., F16>): the weights x activations contractions on the split matrix-core
+    kernel -- skip sum, post-net (incl. the cross-entropy epilogue), their data gradients, the all-layer skip gradient -- with two
+    fp16 pieces per operand and three products, each launch followed by ONE conditional six-product launch.  Forward, loss and
+    every gradient against the oracle at the gates of every mode; against the six-product mode within 2e-6 of the largest value;
+    an activation beyond fp16's range raises the overflow word and the redo launches produce the six-product mode's bits."""
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd import _lib
+    from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat
+    cfg_t = (256, 4, 64, 256, 3, 1, 2, 16)
+    cfg = O.OracleConfig(*cfg_t)
+    B, T = 2, 48   # (few loss positions: with 512 ReLU inputs per position a kink-free instance must still exist)
+    params, x, h, t, margin, sd = PC.pick_instance(cfg, B, T, 81, 0.1)
+    loss_ref, logits_ref, grads_ref = O.train_step(cfg, params, None, x, h, t)
+    eng = WaveNetEngine(*cfg_t, device="cpu", library=emu_library())
+    load_state_into_flat(eng, params)
+    base = _lib.FLAG_AUX_FUSED | _lib.FLAG_DW_F16PAIR
+    res, logs = {}, {}
+    for name, flags in (("six", base), ("f16", base | _lib.FLAG_MM_F16PAIR)):
+        eng.flags = flags
+        logits = eng.forward(x, h)
+        assert float((logits.transpose(1, 2) - logits_ref).abs().max()) <= PC.TOL_LOGITS
+        box = {}
+
+        def run():
+            box["loss"], box["dl"] = eng.forward_loss(x, h, t)
+            eng.backward(box["dl"])
+        logs[name] = PC.launch_log(emu_library(), run)
+        assert abs(float(box["loss"]) - float(loss_ref)) <= PC.TOL_LOSS
+        res[name] = (logits.clone(), eng.grads().clone())
+        grads = PC.flat_to_state(eng, res[name][1], O.param_shapes(cfg))
+        for k, ref in grads_ref.items():
+            if ref is not None:
+                assert PC.rel_to_max(grads[k], ref) <= PC.TOL_GRAD, (name, k)
+    # forward + backward of the training step: skip sum, post1, post2 + CE, post2_dx, post1_dx, dz_skip_all
+    assert "mm_redo_if_overflow" not in logs["six"] and logs["f16"].get("mm_redo_if_overflow") == 6, logs
+    for a, b, what in ((res["f16"][0], res["six"][0], "logits"), (res["f16"][1], res["six"][1], "gradients")):
+        err = float((a - b).abs().max()) / float(b.abs().max())
+        assert 0.0 < err <= 2e-6, (what, err)
+    # overflow: conv_post_1's input relu(skip sum) beyond 65504 (a bias of 1e5 on the skip connections): the fp16 launch of
+    # conv_post_1 yields non-finite accumulators, raises the word, and every redo launch of the pass does the work
+    big = {k: v.clone() for k, v in params.items()}
+    big["skip_1x1.0.bias"] = big["skip_1x1.0.bias"] + 1.0e5
+    load_state_into_flat(eng, big)
+    eng.flags = base
+    want = eng.forward(x, h).clone()
+    assert bool(torch.isfinite(want).all())
+    eng.flags = base | _lib.FLAG_MM_F16PAIR
+    got = eng.forward(x, h).clone()
+    assert torch.equal(got, want)
