@@ -58,6 +58,20 @@ F32_MFMA_PEAK = 157.3e12   # FLOP/s dense f32 matrix = f32 vector peak
 BF16_MFMA_PEAK = 2.5e15     # FLOP/s dense bf16 matrix (MI355X_MICROARCH.md); the 3-way split spends 6 bf16
 SPLIT_PRODUCTS = 6.0        # MFMAs per fp32-equivalent product -> 417 TFLOP/s of fp32-equivalent work
 DW_PRODUCTS = 3.0           # ... of the weight-gradient contractions (a third of the step's FLOPs) with WN_FLAG_DW_F16PAIR / _3PRODUCT
+# share of the forward (and of the data-gradient) multiplies that run in the fused 64-channel kernels (taps + res 1x1: 30 x 20480 of
+# SURVEY 8d's 1 236 992 MACs per timestep without the frame-rate aux); the rest -- skip 1x1, post-net -- runs on k_gemm6
+FUSED_SHARE_R64 = 30.0 * (2 * 64 * 64 * 2 + 64 * 64) / (30.0 * (2 * 64 * 64 * 2 + 64 * 64 + 64 * 256) + 2 * 256 * 256)
+
+
+def products_per_multiply(flags, fused_share):
+    """Average matrix-core products per fp32-equivalent multiply of one training step under the engine flags: forward and
+    data-gradient contractions (a third of the FLOPs each) take 6 (three bf16 pieces) in the fused kernels and 6 or 3 (two fp16
+    pieces, WN_FLAG_MM_F16PAIR) on k_gemm6; the weight gradients 6 or 3 (WN_FLAG_DW_F16PAIR / _3PRODUCT)."""
+    from pytorchwavenetvocoder_amd import _lib
+    mm = DW_PRODUCTS if (flags & _lib.FLAG_MM_F16PAIR) else SPLIT_PRODUCTS
+    dw = DW_PRODUCTS if (flags & (_lib.FLAG_DW_F16PAIR | _lib.FLAG_DW_3PRODUCT)) else SPLIT_PRODUCTS
+    fwd = fused_share * SPLIT_PRODUCTS + (1.0 - fused_share) * mm
+    return (2.0 * fwd + dw) / 3.0
 LAYERS_PER_BUCKET = 30      # gradient buckets = weight-gradient launch groups; N = 1 runs the SAME launch structure as N > 1.
 # 30 (= all layers of this model, GradientReducer's default) = [post-net + skip] [all residual layers] [front + upsampling]: measured 11.64 vs 11.80 ms/step for groups of 10
 # layers on the same box (profiles/r02/ab_probe.txt); 40 % of the gradient bytes (the first bucket) are exchanged under
@@ -68,7 +82,7 @@ LAYERS_PER_BUCKET = 30      # gradient buckets = weight-gradient launch groups; 
 #   dX             write dx_l (its inputs dP never leave the chip)       1R
 ALG_BYTES_PER_TIMESTEP_OF = {"fused_resblock_fwd": 4 * 64 * 4, "fused_bwd_gate": 3 * 64 * 4, "fused_bwd_dx": 64 * 4,
                              "fused_bwd_chain": 4 * 64 * 4}
-PMC_FILES = ["profiles/r05/pmc_traffic.json", "profiles/r04/pmc_traffic.json", "profiles/r03/pmc_traffic.json", "profiles/r02/pmc_traffic.json"]
+PMC_FILES = ["profiles/r06/pmc_traffic.json", "profiles/r05/pmc_traffic.json", "profiles/r04/pmc_traffic.json", "profiles/r03/pmc_traffic.json", "profiles/r02/pmc_traffic.json"]
 
 
 def geometry(rf, batch_length, U):
@@ -309,8 +323,7 @@ def extra_workloads(*release):
         from pytorchwavenetvocoder_amd import _lib
         from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS
         eflags = int(os.environ.get("WN_ENGINE_FLAGS", str(DEFAULT_FLAGS)), 0)
-        dw_half = bool(eflags & (_lib.FLAG_DW_F16PAIR | _lib.FLAG_DW_3PRODUCT))
-        products = (2.0 * SPLIT_PRODUCTS + (DW_PRODUCTS if dw_half else SPLIT_PRODUCTS)) / 3.0
+        products = products_per_multiply(eflags, 0.0)   # the wide model has no fused kernels: every contraction is a k_gemm6 / k_gemm6_dw launch
         peak = BF16_MFMA_PEAK / products
         out["recipe_size"]["frac_of_split_matrix_peak"] = rs["approx_train_tflops"] * 1e12 / peak
         out["recipe_size"]["roofline"] = {"bound": "mfma", "achieved": rs["approx_train_tflops"], "peak": peak / 1e12,
@@ -376,7 +389,7 @@ def same_run_parity(model, ref, inst, layers_per_bucket):
     from pytorchwavenetvocoder_amd.optim import FusedAdam
     init_state, x, h, t = inst
     base = int(model.engine.flags)
-    six = base & ~(_lib.FLAG_DW_F16PAIR | _lib.FLAG_DW_3PRODUCT)
+    six = base & ~_lib.NARROW_FLAGS
     out = {"reference": ref["kind"], "reference_step_s": ref["seconds"], "reference_threads": ref.get("threads"),
            "reference_self_noise": ref.get("self_noise"),
            "instance": "the timed model's initialize()d state_dict (seed 1) and the timed x, h, t (B=%d, T=%d), lr 1e-4, one Adam step"
@@ -546,8 +559,7 @@ def main():
     if rank == 0:
         pmc = load_pmc_traffic(model.engine.flags)
         alg_step = B * T * ALG_BYTES_PER_TIMESTEP
-        dw_half = bool(model.engine.flags & (_lib.FLAG_DW_F16PAIR | _lib.FLAG_DW_3PRODUCT))
-        step_products = (2.0 * SPLIT_PRODUCTS + (DW_PRODUCTS if dw_half else SPLIT_PRODUCTS)) / 3.0
+        step_products = products_per_multiply(model.engine.flags, FUSED_SHARE_R64)
         step_traffic = pmc.get("_step_total_bytes") if pmc else None
         roofline = {
             "bound": "hbm", "achieved": timesteps_per_s_gpu * ALG_BYTES_PER_TIMESTEP / 1e9, "peak": HBM_PEAK / 1e9,
@@ -573,13 +585,18 @@ def main():
             "frac_ceiling_under_split": (alg_step / HBM_PEAK) / (B * T * ALG_FLOP_PER_TIMESTEP / (BF16_MFMA_PEAK / step_products)),
             "matrix_products_per_multiply": step_products,
             "matrix_roof_note": "fp32-equivalent FLOPs of the step (SURVEY 8d: 9.27 MFLOP per timestep) at 2.5 PFLOP/s dense 16-bit "
-                                "MFMA / the products per multiply of the operand split: 6 (three bf16 pieces) for the forward and "
-                                "data-gradient contractions, 3 (two fp16 pieces, WN_FLAG_DW_F16PAIR) for the weight gradients, a "
-                                "third of the FLOPs each -> %.1f on average: the binding roof of this arithmetic is the matrix "
-                                "pipe, not HBM; matrix_roof_frac = that time / the measured step" % step_products,
-            "stream_plateau_note": "a no-arithmetic float4 stream of the fused launches' bytes sustains 4.95 - 5.2 TB/s on an MI355X "
-                                   "of this pool (tools/microbench/stream_mix.hip, profiles/r03/stream_mix.txt), i.e. 0.63 - 0.65 of `peak`; "
-                                   "`frac` stays priced against the 8 TB/s peak",
+                                "MFMA / the products per multiply of the operand split: forward and data-gradient contractions (a third "
+                                "of the FLOPs each) take 6 (three bf16 pieces) in the fused 64-channel kernels (%.0f %% of their "
+                                "multiplies) and 3 (two fp16 pieces, WN_FLAG_MM_F16PAIR) on k_gemm6, the weight gradients 3 "
+                                "(WN_FLAG_DW_F16PAIR) -> %.2f on average: the binding roof of this arithmetic is the matrix "
+                                "pipe, not HBM; matrix_roof_frac = that time / the measured step" % (100.0 * FUSED_SHARE_R64, step_products),
+            # the chip's streaming plateau, measured with 256 MiB tensors (beyond the 256 MiB Infinity Cache), float4 per lane,
+            # 256 workgroups (tools/microbench/stream_big.hip, profiles/r06/stream_big.txt): numbers, not notes
+            "stream_plateau_TBps": {"read_only": 6.3, "copy_1r_1w": 5.4, "fwd_mix_1r_3w": 5.9, "chain_mix_5r_2w": 5.5,
+                                    "fwd_mix_tile_pattern_240wg": 4.8},
+            "stream_plateau_note": "MI355X_MICROARCH.md's 6.29 TB/s is the READ rate (measured here: 5.9 - 6.9 TB/s read-only, 5.2 - 5.6 "
+                                   "copy, 5.2 - 5.9 for the forward block's 1 read : 3 writes, 5.1 - 5.8 for the chain's 5 : 2; the fused "
+                                   "kernels' tile pattern at 240 workgroups 4.6 - 5.1); `frac` stays priced against the 8 TB/s peak",
         }
     if rank == 0 and args.profile_steps > 0:
         need = lib.wn_prof_report(None, 0)
@@ -669,11 +686,14 @@ def main():
                                      ("the weight-gradient contractions (leaf results: sums over every position of the minibatch) "
                                       "split their operands into two fp16 pieces and take 3 products on the fp16 matrix cores "
                                       "(WN_FLAG_DW_F16PAIR: 2^-22 per product; gradient operand scaled by a power of two from the "
-                                      "loss's own bound on dlogits, out-of-range gradients detected and redone with six products); "
+                                      "MEASURED max |dlogits|, out-of-range gradients detected and redone with six products); "
                                       if (model.engine.flags & _lib.FLAG_DW_F16PAIR) else
                                       "the weight-gradient contractions (leaf results) take 3 of the 6 products (WN_FLAG_DW_3PRODUCT, "
                                       "opt-in: it misses the golden after-Adam gate); "
                                       if (model.engine.flags & _lib.FLAG_DW_3PRODUCT) else "") +
+                                     ("the k_gemm6 contractions (skip sum, post-net + loss, their data gradients) take the same fp16 "
+                                      "pair split (WN_FLAG_MM_F16PAIR), each launch with its conditional six-product redo; the fused "
+                                      "64-channel kernels keep six bf16 products; " if (model.engine.flags & _lib.FLAG_MM_F16PAIR) else "") +
                                      "WN_FLAG_EXACT_MFMA selects the f32 MFMA everywhere"},
             "timesteps_per_sec": world * timesteps_per_s_gpu, "final_loss": final_loss,
             "roofline": roofline, "comm": comm, "kernels": kernels,
@@ -689,11 +709,12 @@ def main():
         if not args.no_decode and world == 1:
             out["decode"] = decode_report(model, device, not args.no_cpu_baseline)
         if not args.no_extras and world == 1:
-            # the other two arithmetic modes of the weight-gradient contractions on the SAME step, beside the metric: the six bf16
-            # products the forward / data-gradient contractions use (what the default falls back to when it has no bound on
-            # dlogits or a gradient leaves fp16's range), and the opt-in three bf16 products (misses the golden after-Adam gate)
+            # the other arithmetic modes on the SAME step, beside the metric (every narrowed strand keeps its six-product
+            # figure on the line): six bf16 products EVERYWHERE (fp32-equivalent to round-off: what every fp16 launch falls back to when
+            # an operand leaves fp16's range), six products for the k_gemm6 contractions only (weight gradients stay fp16 pairs: round
+            # 5's default), and the opt-in three bf16 products for the weight gradients (misses the golden after-Adam gate)
             base_flags = model.engine.flags
-            six_flags = base_flags & ~(_lib.FLAG_DW_F16PAIR | _lib.FLAG_DW_3PRODUCT)
+            six_flags = base_flags & ~_lib.NARROW_FLAGS
 
             def alt_mode(flags, note):
                 try:
@@ -714,15 +735,20 @@ def main():
                     return {"error": repr(e)}
                 finally:
                     model.engine.flags = base_flags
-            dw6 = alt_mode(six_flags, "weight-gradient contractions with the six bf16 products of every other contraction (engine.flags "
-                                      "&= ~FLAG_DW_F16PAIR): the mode the default (two fp16 pieces, three products, "
-                                      "WN_FLAG_DW_F16PAIR) falls back to without a bound on dlogits; same gates, same worst gradient "
-                                      "tensors (tests/test_gpu_fullsize.py, tests/test_gpu_dw_f16pair.py)")
+            dw6 = alt_mode(six_flags, "EVERY contraction with six bf16 products (engine.SIX_PRODUCT_FLAGS: no WN_FLAG_DW_F16PAIR, no "
+                                      "WN_FLAG_MM_F16PAIR): fp32-equivalent to round-off; what each fp16-pair launch of the default redoes "
+                                      "itself with when an operand leaves fp16's range; same gates (tests/test_gpu_fullsize.py, bench "
+                                      "`parity.dw_six_products`)")
+            mm6 = alt_mode(base_flags & ~_lib.FLAG_MM_F16PAIR,
+                           "six bf16 products for the forward / data-gradient contractions on k_gemm6 (no WN_FLAG_MM_F16PAIR), fp16 pairs "
+                           "for the weight gradients: the default of round 5")
             dw3 = alt_mode(six_flags | _lib.FLAG_DW_3PRODUCT,
                            "WN_FLAG_DW_3PRODUCT (opt-in): two bf16 pieces, three products (2^-16 per product): meets the 3e-5 gradient "
                            "gate, misses the golden after-Adam gate (1e-2 lr) by 2x -- not a default, not the metric")
             out["extras"] = extra_workloads(model, opt, red)
-            out["extras"]["dw_six_products"] = dw6
+            out["extras"]["dw_six_products"] = dw6          # (key kept from round 5: now "six products everywhere")
+            out["extras"]["all_six_products"] = dw6
+            out["extras"]["mm_six_products"] = mm6
             out["extras"]["dw_3product"] = dw3
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))

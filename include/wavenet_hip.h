@@ -161,6 +161,11 @@ enum {
                                * followed by a conditional six-product launch that redoes it if an operand left fp16's range.  The same
                                * flag must be given to the forward and the backward call of a step (the workspace holds the weight
                                * images the forward call packed), or wn_backward gets WN_FLAG_REPACK. */
+#define WN_FLAG_FUSED_F16PAIR (1 << 29) /* since ABI v9, opt-in: wn_forward / wn_forward_loss -- the fused 64-channel residual block (taps, gate, res
+                               * 1x1) on the fp16 pair split as well (three products per multiply instead of six), BLOCK-SCALED: every
+                               * weight image and every 64 x 32 operand tile is multiplied by the power of two that puts its maximum
+                               * at 2^12 / 2^14, so no magnitude can leave fp16's range and no redo is needed (csrc/wn_fused.hip
+                               * k_resblock_fwd_h).  Forward only: the backward chain keeps six bf16 products. */
 #define WN_FLAG_DW_FLUSH(n) (((n) & 0xff) << 8) /* wn_backward: issue the weight gradients of at most n walked layers per
                                * launch group (0 = default: a whole gradient bucket; 5 layers with WN_FLAG_BWD_OVERLAP).
                                * Groups never straddle a bucket.  The split-K plan of a group depends on its size, so

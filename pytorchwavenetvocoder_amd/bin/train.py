@@ -101,6 +101,29 @@ def _shard_range(batch_size, shard):
     return lo, lo + per + (1 if rank < extra else 0)
 
 
+def slicer_workers():
+    """Worker threads of the window slicer: ``WN_SLICER_WORKERS`` (0 = everything in the producer thread, as the reference does),
+    default min(4, CPUs - 1).  numpy / zlib / file reads / torch.stack release the GIL, so threads do run in parallel here."""
+    v = os.environ.get("WN_SLICER_WORKERS")
+    if v is not None:
+        return max(0, int(v))
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(0, min(4, n - 1))
+
+
+class _Done(object):
+    """A finished 'future' (the inline path of the slicer: same code, no pool)."""
+
+    def __init__(self, value):
+        self.value = value
+
+    def result(self):
+        return self.value
+
+
 @background(max_prefetch=16)
 def train_generator(wav_list, feat_list, receptive_field,
                     batch_length=None,
@@ -114,7 +137,9 @@ def train_generator(wav_list, feat_list, receptive_field,
                     use_speaker_code=False,
                     device="auto",
                     shard=None,
-                    with_wave=False):
+                    with_wave=False,
+                    workers=None,
+                    transforms_elementwise=False):
     """Minibatch generator with the reference's four batching modes (train.py:67-312).
 
     Yields ``((batch_x, batch_h), batch_t)``: x/t int64 (B, T) with t the next sample of x, h float
@@ -127,7 +152,22 @@ def train_generator(wav_list, feat_list, receptive_field,
     skipped instead of being done ``world`` times).
     ``with_wave=True`` (mixture-of-logistics head): additionally yields ``batch_y`` float (B, T), the waveform
     value of the next sample at every position (the un-quantised counterpart of ``batch_t``).
-    """
+
+    ``workers`` (default ``slicer_workers()``): the reference's generator is ONE numpy thread behind a queue that is in effect one
+    deep (train.py:67, utils.py:216) -- at 8.7 ms per minibatch on an MI355X that thread (file reads 3 ms, mu-law 1.5 ms, scaler,
+    stacking, pinning: 6.5 ms per minibatch of 8 windows) is as slow as the step.  Here the SEQUENTIAL part -- the order of the
+    utterances, the running buffers, where each window is cut: a few slices per window -- stays in the producer thread, and the
+    work hangs off it as jobs of a thread pool whose results are consumed in submission order: (1) read + validate utterance
+    i + 1 ... i + 8 while utterance i is being cut, (2) mu-law / scaler / tensor conversion per window, (3) stack + pinned
+    staging + H2D per minibatch.  Same functions on the same slices in the same order: the minibatches are bit-identical to the
+    single-thread generator's (tests/test_train_cli.py: the reference generator's golden minibatches, with and without workers).
+
+    ``transforms_elementwise=True`` (what the CLI passes: its mu-law and scaler are per-sample / per-frame maps): the two
+    transforms are applied ONCE per utterance when it is read instead of once per window on the buffer slices -- windows overlap
+    by the receptive field (15 % of the samples at the benchmark's geometry), and the work moves into the coarse per-utterance
+    read jobs.  Same values bit for bit (a per-element map commutes with slicing; same dtypes: golden test)."""
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
     if device == "auto":
         device = torch.device("cuda") if torch.cuda.is_available() else None
     if shuffle:
@@ -142,40 +182,102 @@ def train_generator(wav_list, feat_list, receptive_field,
         batch_length -= batch_mod
     if batch_length is None and batch_size > 1:
         logging.warning("in utterance batch mode, batchsize will be 1.")
+    pre = bool(transforms_elementwise)
+    n_workers = slicer_workers() if workers is None else max(0, int(workers))
+    pool = ThreadPoolExecutor(max_workers=n_workers, thread_name_prefix="wn_slicer") if n_workers > 0 else None
 
-    def prep(x_, h_):
-        raw.append(torch.from_numpy(np.asarray(x_, dtype=np.float32)))
-        if wav_transform is not None:
-            x_ = wav_transform(x_)
-        if feat_transform is not None:
-            h_ = feat_transform(h_)
-        return torch.from_numpy(np.asarray(x_)).long(), torch.from_numpy(np.asarray(h_)).float()
+    def submit(fn, *a):
+        return pool.submit(fn, *a) if pool is not None else _Done(fn(*a))
+
+    def load(wavfile, featfile):
+        """one utterance from its two files, trimmed to consistent lengths (train.py:202-212)"""
+        x, _fs = read_wav(wavfile)
+        h = read_hdf5(featfile, "/" + feature_type)
+        if not use_upsampling_layer:
+            h = extend_time(h, upsampling_factor)
+        if use_speaker_code:
+            sc = read_hdf5(featfile, "/speaker_code")
+            h = np.concatenate([h, np.tile(sc, [h.shape[0], 1])], axis=1)
+        x, h = validate_length(x, h, upsampling_factor if use_upsampling_layer else None)
+        if not pre:
+            return x, h, None, None
+        # the buffers' dtypes (float32 waveform; features promoted with float32) are what the per-window transforms would see
+        xf = np.asarray(x, dtype=np.float32)
+        hf = np.asarray(h, dtype=np.result_type(np.float32, np.asarray(h).dtype))
+        return xf, hf, (wav_transform(xf) if wav_transform is not None else xf), (feat_transform(hf) if feat_transform is not None else hf)
+
+    def prep(x_, h_, xt_=None, ht_=None):
+        """one window: (tokens, features, un-quantised waveform); xt_ / ht_: the slices of the already transformed utterances"""
+        raw = torch.from_numpy(np.asarray(x_, dtype=np.float32))
+        if xt_ is not None:
+            x_, h_ = xt_, ht_
+        else:
+            if wav_transform is not None:
+                x_ = wav_transform(x_)
+            if feat_transform is not None:
+                h_ = feat_transform(h_)
+        return torch.from_numpy(np.asarray(x_)).long(), torch.from_numpy(np.asarray(h_)).float(), raw
+
+    def assemble(window_jobs):
+        """one minibatch from its windows' jobs (submitted before this one: the pool's queue is FIFO, so they are running or done)"""
+        xs, hs, ts, ys = [], [], [], []
+        for job in window_jobs:
+            x_, h_, raw = job.result()
+            hs.append(h_.transpose(0, 1) if use_upsampling_layer else h_[:-1].transpose(0, 1))
+            xs.append(x_[:-1])
+            ts.append(x_[1:])
+            ys.append(raw[1:])
+        return _to_batch(xs, hs, ts, device, ys if with_wave else None)
+
+    def utterances():
+        """(x, h) of the utterances in list order, epoch after epoch, ``None`` between two epochs (the reference's generator starts
+        every walk of the list with an empty minibatch, train.py:196-200); the list is reshuffled where the reference reshuffles
+        it (when it has been walked: the same sequence of np.random calls); up to ``ahead`` utterances are being read in front of
+        the consumer, across the epoch boundary too"""
+        nonlocal wav_list, feat_list
+        ahead = 2 * n_workers if pool is not None else 0
+        pending = deque()
+        while True:
+            for pair in zip(wav_list, feat_list):
+                pending.append(submit(load, *pair))
+                while len(pending) > ahead:
+                    yield pending.popleft().result()
+            pending.append(_Done(None))
+            if shuffle:
+                idx = np.random.permutation(n_files)
+                wav_list = [wav_list[i] for i in idx]
+                feat_list = [feat_list[i] for i in idx]
 
     # window sharding only exists in the windowed modes; utterance batches (batch_length None, effective batch size 1)
     # are dealt round-robin by utterance below, so a batch_size below the world size is fine there
     my_lo, my_hi = _shard_range(batch_size, shard) if batch_length is not None else (0, batch_size)
-    raw = []  # un-quantised windows in the order of prep() calls
-    x_buffer = h_buffer = None
-    while True:
-        batch_x, batch_h, batch_t, batch_y = [], [], [], []
-        n_in_batch = 0
-        for wavfile, featfile in zip(wav_list, feat_list):
-            x, _fs = read_wav(wavfile)
-            h = read_hdf5(featfile, "/" + feature_type)
-            if not use_upsampling_layer:
-                h = extend_time(h, upsampling_factor)
-            if use_speaker_code:
-                sc = read_hdf5(featfile, "/speaker_code")
-                h = np.concatenate([h, np.tile(sc, [h.shape[0], 1])], axis=1)
-            x, h = validate_length(x, h, upsampling_factor if use_upsampling_layer else None)
-
+    ready = deque()                     # minibatch jobs in the order they will be yielded
+    max_ready = 2 * n_workers + 1 if pool is not None else 1
+    x_buffer = h_buffer = xt_buffer = ht_buffer = None
+    window_jobs = []
+    n_in_batch = 0
+    n_seen = 0                          # utterances of the current epoch (utterance mode: round-robin over ranks)
+    try:
+        for utt in utterances():
+            if utt is None:             # a new walk of the list: the reference drops a partly filled minibatch here (the buffers stay)
+                window_jobs = []
+                n_in_batch = 0
+                n_seen = 0
+                continue
+            x, h, xt, ht = utt
             if batch_length is not None:
                 # windowed minibatches over a running buffer of concatenated utterances
                 if x_buffer is None:
                     x_buffer = np.empty((0), dtype=np.float32)
                     h_buffer = np.empty((0, h.shape[1]), dtype=np.float32)
+                    if pre:
+                        xt_buffer = np.empty((0), dtype=np.asarray(xt).dtype)
+                        ht_buffer = np.empty((0, h.shape[1]), dtype=np.asarray(ht).dtype)
                 x_buffer = np.concatenate([x_buffer, x], axis=0)
                 h_buffer = np.concatenate([h_buffer, h], axis=0)
+                if pre:
+                    xt_buffer = np.concatenate([xt_buffer, xt], axis=0)
+                    ht_buffer = np.concatenate([ht_buffer, ht], axis=0)
                 if use_upsampling_layer:
                     h_bs = (receptive_field + batch_length) // upsampling_factor   # frames per window
                     x_bs = h_bs * upsampling_factor + 1                            # samples per window
@@ -188,37 +290,40 @@ def train_generator(wav_list, feat_list, receptive_field,
                     more = lambda: len(x_buffer) > x_bs                            # noqa: E731
                 while more():
                     if my_lo <= n_in_batch < my_hi:   # windows of other ranks are only skipped over
-                        x_, h_ = prep(x_buffer[:x_bs], h_buffer[:h_bs])
-                        if use_upsampling_layer:
-                            batch_h += [h_.transpose(0, 1)]
+                        if pre:
+                            window_jobs.append(submit(prep, x_buffer[:x_bs], h_buffer[:h_bs], xt_buffer[:x_bs], ht_buffer[:h_bs]))
                         else:
-                            batch_h += [h_[:-1].transpose(0, 1)]
-                        batch_x += [x_[:-1]]
-                        batch_t += [x_[1:]]
-                        batch_y += [raw.pop()[1:]]
+                            window_jobs.append(submit(prep, x_buffer[:x_bs], h_buffer[:h_bs]))
                     n_in_batch += 1
                     h_buffer = h_buffer[h_ss:]
                     x_buffer = x_buffer[x_ss:]
+                    if pre:
+                        ht_buffer = ht_buffer[h_ss:]
+                        xt_buffer = xt_buffer[x_ss:]
                     if n_in_batch == batch_size:
-                        if batch_x:
-                            yield _to_batch(batch_x, batch_h, batch_t, device, batch_y if with_wave else None)
-                        batch_x, batch_h, batch_t, batch_y = [], [], [], []
+                        if window_jobs:
+                            ready.append(submit(assemble, window_jobs))
+                        window_jobs = []
                         n_in_batch = 0
+                        while len(ready) >= max_ready:
+                            yield ready.popleft().result()
             else:
                 # one utterance per batch; with several ranks utterance i goes to rank i mod world
-                n_in_batch += 1
-                if shard is not None and (n_in_batch - 1) % shard[1] != shard[0]:
+                n_seen += 1
+                if shard is not None and (n_seen - 1) % shard[1] != shard[0]:
                     continue
                 if use_upsampling_layer:
                     h = h[:-1]
                     x = x[:-upsampling_factor + 1]
-                x_, h_ = prep(x, h)
-                hh = h_.transpose(0, 1) if use_upsampling_layer else h_[:-1].transpose(0, 1)
-                yield _to_batch([x_[:-1]], [hh], [x_[1:]], device, [raw.pop()[1:]] if with_wave else None)
-        if shuffle:
-            idx = np.random.permutation(n_files)
-            wav_list = [wav_list[i] for i in idx]
-            feat_list = [feat_list[i] for i in idx]
+                    if pre:
+                        ht = ht[:-1]
+                        xt = xt[:-upsampling_factor + 1]
+                ready.append(submit(assemble, [submit(prep, x, h, xt, ht) if pre else submit(prep, x, h)]))
+                while len(ready) >= max_ready:
+                    yield ready.popleft().result()
+    finally:
+        if pool is not None:
+            pool.shutdown(wait=False)
 
 
 def save_checkpoint(checkpoint_dir, model, optimizer, iterations):
@@ -367,7 +472,8 @@ def _worker(rank, world, args, port):
         shard=(rank, world) if world > 1 else None,
         with_wave=args.n_mixture > 0,
         use_speaker_code=args.use_speaker_code,
-        device=device)
+        device=device,
+        transforms_elementwise=True)   # mu-law and the standard scaler are per-sample / per-frame maps
 
     optimizer = FusedAdam(model, lr=args.lr, weight_decay=args.weight_decay)
     if args.resume is not None and len(args.resume) != 0:
@@ -415,6 +521,7 @@ def _worker(rank, world, args, port):
         if (i + 1) % args.checkpoint_interval == 0 and is_main:
             save_checkpoint(args.expdir, model, optimizer, i + 1)
 
+    generator.close()   # stop the producer thread before the interpreter tears the runtime down under it
     if is_main:
         torch.save({"model": model.state_dict()}, args.expdir + "/checkpoint-final.pkl")
         logging.info("final checkpoint created.")

@@ -64,5 +64,9 @@ int wn_fused_bwd_chain_head(const float* dZs, long zs_bstride, const float* S, c
 // wn_fused_image_floats: floats of region `which` for L layers (0 when K is outside the split kernels' range).
 // (img_taps of layer l and img_res of layer l-1 belong to the chain launch of layer l.)
 long wn_fused_image_floats(int K, int L, int which);
+// Two-piece fp16 images of the forward block (k_resblock_fwd_h: `split` = 2 in wn_fused_resblock_fwd, `wimg` = layer l's image):
+// [K*4 blocks][2 pieces][128 rows][16 k] taps, [4][2][64][16] res 1x1, block-scaled by powers of two, inverse scales in the tail
+long wn_fused_image16_floats(int K, int L);
+int wn_fused_pack_images16(const float* wd_f, const float* wres_f, float* img16, int K, int L, wn_stream_t st);
 int wn_fused_pack_images(const float* wd_f, const float* wres_f, const float* wd_b, const float* params, long res_off,
                          long res_lstride, float* img_fwd, float* img_taps, float* img_res, int K, int L, wn_stream_t st);

@@ -29,6 +29,7 @@
 #include "wn_prof.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 // -DWN_EXP_NPROD=3: TIMING-ONLY experiment builds (tools/build_variant.sh): the split fused kernels issue 3 of their 6 products per
 // multiply -- numerically WRONG, what the matrix work of a two-piece operand split would cost.  The product is built with 6.
@@ -927,10 +928,385 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_s(FwdArgs a) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_resblock_fwd_h -- the same residual block on the FP16 matrix cores with a two-piece operand split (round 6,
+// WN_FLAG_FUSED_F16PAIR): x ~ h + l with two fp16 pieces (11 + 11 significand bits), the three products h h + h l + l h on
+// v_mfma_f32_32x32x16_f16, fp32 accumulate -- ~2^-22 |w x| per product (the rounding of an fp32 running sum over the 128 - 192
+// terms of a tap contraction) at HALF the matrix work of the six bf16 products, a weight image of 80 KB instead of 120 KB
+// (K = 3: 112 KB, so the res-1x1 fragments are back in the LDS), and 6 instead of 11 VALU instructions per operand pair.
+// fp16 has 5 exponent bits, so everything is BLOCK-SCALED by powers of two (exact):
+//   * each weight image by 2^ew with max |w| 2^ew in [2^11, 2^12) (wn_fused_pack_images measures the maximum per layer);
+//   * each 64-channel x 32-sample operand tile by 2^e with max |x| 2^e in [2^13, 2^14) -- the wave reduces the maximum of the tile
+//     it holds in registers; the taps of a tile share ONE scale (the smallest so far: the accumulators are multiplied down when a
+//     later tap has larger values), so nothing can leave fp16's range whatever the magnitudes are, and an element 2^-18 below the
+//     tile's maximum still has all 22 bits (smaller ones keep 2^-25 of the maximum in absolute terms);
+//   * z in (-1, 1) by 2^13.
+// The inverse scales are folded into the additions that follow the MFMAs (gate pre-activation, residual): no extra pass.
+// Pipeline, registers, stores: k_resblock_fwd_s's.
+// ---------------------------------------------------------------------------------------------
+static __host__ __device__ constexpr int fwd16_image_bytes(int K) { return K * 4 * (2 * 128 * 32) + 4 * (2 * 64 * 32) + 64; }
+// split of 8 values times s into the two fp16 pieces of the lane's share of a 16-k block
+static __device__ __forceinline__ void split8h(const float (&x)[8], float s, wn_f4 (&bf)[2]) {
+    unsigned hq[4], lq[4];
+    WN_UNROLL
+    for (int e = 0; e < 4; ++e) {
+        const float x0 = x[2 * e] * s, x1 = x[2 * e + 1] * s;
+        hq[e] = wn_pk_f16(x0, x1);
+        lq[e] = wn_pk_f16(x0 - wn_f16lo_f32(hq[e]), x1 - wn_f16hi_f32(hq[e]));
+    }
+    bf[0].x = wn_bits_f32(hq[0]); bf[0].y = wn_bits_f32(hq[1]); bf[0].z = wn_bits_f32(hq[2]); bf[0].w = wn_bits_f32(hq[3]);
+    bf[1].x = wn_bits_f32(lq[0]); bf[1].y = wn_bits_f32(lq[1]); bf[1].z = wn_bits_f32(lq[2]); bf[1].w = wn_bits_f32(lq[3]);
+}
+// power of two s with amax * s in [2^(E-1), 2^E)  (amax == 0 or tiny / huge: clamped, s stays a normal float with a normal inverse)
+static __host__ __device__ __forceinline__ float wn_pow2_scale(float amax, int E) {
+    unsigned bits;
+#ifdef __HIP_DEVICE_COMPILE__
+    bits = __builtin_bit_cast(unsigned, amax);
+#else
+    memcpy(&bits, &amax, 4);
+#endif
+    int ex = (int)((bits >> 23) & 0xffu);              // amax in [2^(ex-127), 2^(ex-126))
+    ex = ex < 27 ? 27 : (ex > 254 ? 254 : ex);         // (zero / denormal tiles: a harmless finite scale; s and 1 / s stay normal)
+    const unsigned sb = (unsigned)(E + 253 - ex) << 23;   // 2^(E - (ex - 126))
+    float sc;
+#ifdef __HIP_DEVICE_COMPILE__
+    sc = __builtin_bit_cast(float, sb);
+#else
+    memcpy(&sc, &sb, 4);
+#endif
+    return sc;
+}
+static __device__ __forceinline__ float wave_amax32(const float (&x)[32], bool ok) {
+    float m = 0.0f;
+    WN_UNROLL
+    for (int e = 0; e < 32; e += 2) m = fmaxf(m, fmaxf(fabsf(x[e]), fabsf(x[e + 1])));
+    m = ok ? m : 0.0f;
+    return wave_reduce_max(m);
+}
+
+// image: [K*4 blocks][2 pieces][128 rows][16 k] fp16 taps, [4 blocks][2][64][16] res 1x1, then {1 / 2^ew_taps, 1 / 2^ew_res} floats
+template <int K>
+static __device__ __forceinline__ void fill_fwd16_image(char* img, const float* wd_f, const float* wres_f, float* red, int tid, int nthr) {
+    constexpr int WD_BLK = 2 * 128 * 32, WR_BLK = 2 * 64 * 32;
+    // maxima of the two weight sets (block-wide)
+    float m0 = 0.0f, m1 = 0.0f;
+    for (int i = tid; i < K * 64 * 128; i += nthr) m0 = fmaxf(m0, fabsf(wd_f[i]));
+    for (int i = tid; i < 64 * 64; i += nthr) m1 = fmaxf(m1, fabsf(wres_f[i]));
+    m0 = wave_reduce_max(m0);
+    m1 = wave_reduce_max(m1);
+    if ((tid & 63) == 0) { red[tid >> 6] = m0; red[16 + (tid >> 6)] = m1; }
+    __syncthreads();
+    m0 = 0.0f; m1 = 0.0f;
+    for (int i = 0; i < (nthr >> 6); ++i) { m0 = fmaxf(m0, red[i]); m1 = fmaxf(m1, red[16 + i]); }
+    const float s0 = wn_pow2_scale(m0, 12), s1 = wn_pow2_scale(m1, 12);
+    char* Wd = img;
+    char* Wr = img + K * 4 * WD_BLK;
+    for (int idx = tid; idx < K * 4 * 2 * 128; idx += nthr) {
+        const int o = idx & 127, h = (idx >> 7) & 1, blk = idx >> 8;  // blk = tap*4 + kb
+        const int tap = blk >> 2, kb = blk & 3;
+        const float* src = wd_f + (long)(tap * 64 + 16 * kb + 4 * h) * 128 + o;
+        float x[8];
+        WN_UNROLL
+        for (int e = 0; e < 8; ++e) x[e] = src[((e & 3) + 8 * (e >> 2)) * 128];
+        wn_f4 bf[2];
+        split8h(x, s0, bf);
+        WN_UNROLL
+        for (int p = 0; p < 2; ++p) *reinterpret_cast<wn_f4*>(Wd + blk * WD_BLK + p * (128 * 32) + wn_frag_off(o, h)) = bf[p];
+    }
+    for (int idx = tid; idx < 4 * 2 * 64; idx += nthr) {
+        const int o = idx & 63, h = (idx >> 6) & 1, kb = idx >> 7;
+        const float* src = wres_f + (long)(16 * kb + 4 * h) * 64 + o;
+        float x[8];
+        WN_UNROLL
+        for (int e = 0; e < 8; ++e) x[e] = src[((e & 3) + 8 * (e >> 2)) * 64];
+        wn_f4 bf[2];
+        split8h(x, s1, bf);
+        WN_UNROLL
+        for (int p = 0; p < 2; ++p) *reinterpret_cast<wn_f4*>(Wr + kb * WR_BLK + p * (64 * 32) + wn_frag_off(o, h)) = bf[p];
+    }
+    if (tid == 0) {
+        float* tail = reinterpret_cast<float*>(Wr + 4 * WR_BLK);
+        tail[0] = 1.0f / s0;
+        tail[1] = 1.0f / s1;
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(WN_LB) void k_fused_pack_images16(const float* wd_f, const float* wres_f, float* img16) {
+    __shared__ float red[32];
+    const int l = blockIdx.x;
+    fill_fwd16_image<K>(reinterpret_cast<char*>(img16) + (long)l * fwd16_image_bytes(K), wd_f + (long)l * K * 64 * 128,
+                        wres_f + (long)l * 64 * 64, red, threadIdx.x, WN_FT);
+}
+
+long wn_fused_image16_floats(int K, int L) { return (K < 1 || K > 3) ? 0 : (long)L * fwd16_image_bytes(K) / 4; }
+
+int wn_fused_pack_images16(const float* wd_f, const float* wres_f, float* img16, int K, int L, wn_stream_t st) {
+    WN_PROF("fused_pack_images16", 0.0, 0.0, st);
+    if (K == 1) WN_LAUNCH((k_fused_pack_images16<1>), dim3((unsigned)L), dim3(WN_FT), 0, st, wd_f, wres_f, img16);
+    else if (K == 2) WN_LAUNCH((k_fused_pack_images16<2>), dim3((unsigned)L), dim3(WN_FT), 0, st, wd_f, wres_f, img16);
+    else if (K == 3) WN_LAUNCH((k_fused_pack_images16<3>), dim3((unsigned)L), dim3(WN_FT), 0, st, wd_f, wres_f, img16);
+    else return 1;
+    return 0;
+}
+
+template <int K>
+__global__ __launch_bounds__(WN_LB) void k_resblock_fwd_h(FwdArgs a) {
+    WN_DYN_SMEM(smem_raw);
+    constexpr int WD_BLK = 2 * 128 * 32, WR_BLK = 2 * 64 * 32;  // bytes of one 16-k block (two fp16 pieces)
+    char* Wd = smem_raw;                                         // [K*4 blocks][piece][128 rows][16 k]
+    char* Wr = Wd + K * 4 * WD_BLK;                              // [4 blocks][piece][64 rows][16 k]
+    float* tail = reinterpret_cast<float*>(Wr + 4 * WR_BLK);     // {1 / 2^ew_taps, 1 / 2^ew_res} (+ padding to 64 bytes)
+    float* cv = tail + 16;                                       // [128]
+    float* rb = cv + 128;                                        // [64]
+    copy_image_to_lds(smem_raw, a.wimg, fwd16_image_bytes(K) - 64);   // (a multiple of 1024)
+    if (threadIdx.x < 2) tail[threadIdx.x] = a.wimg[(fwd16_image_bytes(K) - 64) / 4 + threadIdx.x];
+    if (threadIdx.x < 128) cv[threadIdx.x] = a.cvec[threadIdx.x];
+    if (threadIdx.x < 64) rb[threadIdx.x] = a.res_bias[threadIdx.x];
+    WN_WAIT_VMCNT(0);
+    __syncthreads();
+    const float inv_wd = tail[0], inv_wr = tail[1];
+
+    const int lane = threadIdx.x & 63;
+    const int li = lane & 31, hi = lane >> 5;
+    const int T = a.T;
+    const int T4 = T * 4;  // bytes per channel row
+    const int F4 = a.F * 4;
+    const int tiles_per_b = (T + 31) >> 5;
+    const int ntiles = a.B * tiles_per_b;
+    const unsigned slab = (unsigned)(64 * T4);
+    const TileWalk walk = tile_walk(ntiles, threadIdx.x >> 6);
+    const int step = WN_UNIFORM(walk.step), tile_end = WN_UNIFORM(walk.end);
+    constexpr int KH = (K > 1) ? (K - 1) : 1;  // history taps (shift > 0)
+    constexpr int KP = (K >= 3) ? 1 : K - 1;   // ... requested one tile ahead (see k_resblock_fwd_s)
+
+    float xh[KH][32];
+    bool okh[KH];
+    auto issue_hist = [&](int tl_v) {
+        const int tl = WN_UNIFORM(tl_v);
+        const int b = tl / tiles_per_b;
+        const int t = (tl - b * tiles_per_b) * 32 + li;
+        const wn_rsrc_t Xr = wn_make_buf(a.X + (long)b * 64 * T, slab);
+        WN_UNROLL
+        for (int tap = 0; tap < KP; ++tap) {
+            const int ts = t - (K - 1 - tap) * a.dil;
+            const bool ok = (t < T) && ts >= 0;
+            okh[tap] = ok;
+            const int vt = ok ? (4 * hi * T + ts) * 4 : 0;  // dead lanes read a valid dummy address
+            WN_UNROLL
+            for (int s = 0; s < 32; ++s) xh[tap][s] = wn_buf_load(Xr, vt, kappa64(s, 0) * T4);
+        }
+    };
+    constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};   // small terms first: h l, l h, h h
+    f32x16 acc[4];
+    // one tap: the 4 k-blocks of 16 channels against the tap's 128 weight rows
+    auto tap_mfmas = [&](const float (&xr)[32], bool ok, int tapblk, float sc) {
+        WN_UNROLL
+        for (int kb = 0; kb < 4; ++kb) {
+            float x8[8];
+            WN_UNROLL
+            for (int e = 0; e < 8; ++e) x8[e] = ok ? xr[8 * kb + e] : 0.0f;
+            wn_f4 bf[2];
+            split8h(x8, sc, bf);
+            const char* Wl = Wd + (tapblk * 4 + kb) * WD_BLK + wn_frag_off(li, hi);
+            WN_UNROLL
+            for (int qh = 0; qh < 4; qh += 2) {  // two row tiles at a time (register budget)
+                wn_f4 af[2][2];
+                WN_UNROLL
+                for (int q = 0; q < 2; ++q) {
+                    WN_UNROLL
+                    for (int p = 0; p < 2; ++p) af[q][p] = *reinterpret_cast<const wn_f4*>(Wl + p * (128 * 32) + (qh + q) * 1024);
+                }
+                WN_UNROLL
+                for (int t3 = 0; t3 < 3; ++t3) {
+                    acc[qh] = mfma_f16(af[0][PA[t3]], bf[PB[t3]], acc[qh]);
+                    acc[qh + 1] = mfma_f16(af[1][PA[t3]], bf[PB[t3]], acc[qh + 1]);
+                }
+            }
+        }
+    };
+
+    int tile_v = WN_UNIFORM(walk.first);
+    if (K > 1 && tile_v < tile_end) issue_hist(tile_v);
+    while (tile_v < tile_end) {
+        const int tile = WN_UNIFORM(tile_v);
+        const int b = tile / tiles_per_b;
+        const int t = (tile - b * tiles_per_b) * 32 + li;
+        const bool inb = t < T;
+        const int tc = inb ? t : T - 1;
+        const int vcur = inb ? (4 * hi * T + t) * 4 : 0;
+
+        float xc[32];
+        {
+            const wn_rsrc_t Xr = wn_make_buf(a.X + (long)b * 64 * T, slab);
+            WN_UNROLL
+            for (int tap = KP; tap + 1 < K; ++tap) {   // (K = 3) the history taps that are not requested a tile ahead
+                const int ts = t - (K - 1 - tap) * a.dil;
+                const bool ok = inb && ts >= 0;
+                okh[tap] = ok;
+                const int vt = ok ? (4 * hi * T + ts) * 4 : 0;
+                WN_UNROLL
+                for (int s = 0; s < 32; ++s) xh[tap][s] = wn_buf_load(Xr, vt, kappa64(s, 0) * T4);
+            }
+            WN_UNROLL
+            for (int s = 0; s < 32; ++s) xc[s] = wn_buf_load(Xr, vcur, kappa64(s, 0) * T4);
+        }
+        WN_SCHED_BARRIER();
+        WN_PRIO(WN_PRIO_MFMA);
+        WN_UNROLL
+        for (int q = 0; q < 4; ++q) acc[q] = f32x16_zero();
+        // The tile's block scale: the smallest of its taps' scales so far; the accumulators follow it down (exact: powers of two).
+        float sc = 0.0f;
+        WN_UNROLL
+        for (int tap = 0; tap + 1 < K; ++tap) {
+            const float st = wn_pow2_scale(wave_amax32(xh[tap], okh[tap]), 14);
+            if (tap == 0) {
+                sc = st;
+            } else {
+                const float sn = fminf(sc, st);
+                const float ratio = sn / sc;     // <= 1
+                WN_UNROLL
+                for (int q = 0; q < 4; ++q) {
+                    WN_UNROLL
+                    for (int r = 0; r < 16; ++r) acc[q][r] *= ratio;
+                }
+                sc = sn;
+            }
+            tap_mfmas(xh[tap], okh[tap], tap, sc);
+        }
+        // aux / gate inputs (frame rate, L2 resident), first 32 gate channels
+        const int fr = tc / a.U;
+        const float upw_j = a.upw[tc - fr * a.U];
+        const wn_rsrc_t Gr = wn_make_buf(a.G + (long)b * a.g_bstride, (unsigned)(128 * F4));
+        const int vg = (4 * hi * a.F + fr) * 4;
+        float ga[16], gg[16];
+        WN_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            ga[r] = wn_buf_load(Gr, vg, mfma32_row(r, 0) * F4);
+            gg[r] = wn_buf_load(Gr, vg, (mfma32_row(r, 0) + 64) * F4);
+        }
+        WN_SCHED_BARRIER();
+        {   // current tap; xc is also the residual input, already in D layout
+            const float st = wn_pow2_scale(wave_amax32(xc, inb), 14);
+            if (K > 1) {
+                const float sn = fminf(sc, st);
+                const float ratio = sn / sc;
+                WN_UNROLL
+                for (int q = 0; q < 4; ++q) {
+                    WN_UNROLL
+                    for (int r = 0; r < 16; ++r) acc[q][r] *= ratio;
+                }
+                sc = sn;
+            } else {
+                sc = st;
+            }
+            tap_mfmas(xc, inb, K - 1, sc);
+        }
+        const float inv = inv_wd / sc;   // (both powers of two) accumulators -> true pre-activations
+        WN_SCHED_BARRIER();
+        WN_PRIO(WN_PRIO_GATE);
+        f32x16 xb2[2];
+        if (a.Xnext != nullptr) {
+            const float* rbl = rb + 4 * hi;
+            WN_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r)
+                    xb2[q][r] = (inb ? xc[16 * q + r] : 0.0f) + rbl[32 * q + mfma32_row(r, 0)];
+            }
+#ifndef WN_EMU
+            asm volatile("" : "+v"(xb2[0]), "+v"(xb2[1]));
+#endif
+        }
+        const int next_v = tile_v + step;
+        if (K > 1 && next_v < tile_end) issue_hist(next_v);
+        // gate (reference wavenet.py:529-532): P = conv + w[j]*G[row][f] + c[row]; saved for backward
+        const wn_rsrc_t Sr = wn_make_buf(a.S + (long)b * 64 * T, slab);
+        const bool keep_g = a.Gt != nullptr;
+        const wn_rsrc_t Gtr = wn_make_buf((keep_g ? a.Gt : a.S) + (long)b * 64 * T, slab);
+        const wn_rsrc_t Zr = wn_make_buf(a.Z + (long)b * 64 * T, slab);
+        const float* cvl = cv + 4 * hi;
+        f32x16 z[2];
+        const int vst = inb ? vcur : WN_VOFF_DEAD;
+        auto gate_phase = [&](auto keep_tag) {
+        constexpr bool KEEP_G = decltype(keep_tag)::value;
+        WN_UNROLL
+        for (int q = 0; q < 2; ++q) {
+            WN_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int row0 = 32 * q + mfma32_row(r, 0);  // + 4*hi is in the per-lane offsets
+                const float pa = fmaf(acc[q][r], inv, upw_j * ga[r] + cvl[row0]);
+                const float pg = fmaf(acc[q + 2][r], inv, upw_j * gg[r] + cvl[row0 + 64]);
+                if (q == 0) {
+                    ga[r] = wn_buf_load(Gr, vg, (32 + mfma32_row(r, 0)) * F4);
+                    gg[r] = wn_buf_load(Gr, vg, (96 + mfma32_row(r, 0)) * F4);
+                }
+                const float s = wn_sigmoid(pa);
+                const float g = wn_tanh(pg);
+                const float zz = s * g;
+                z[q][r] = zz;
+                wn_buf_store(Sr, s, vst, row0 * T4);
+                if (KEEP_G) wn_buf_store(Gtr, g, vst, row0 * T4);
+                wn_buf_store(Zr, zz, vst, row0 * T4);
+            }
+        }
+        };
+        if (keep_g) gate_phase(std::true_type{});
+        else gate_phase(std::false_type{});
+        WN_SCHED_BARRIER();
+        WN_PRIO(WN_PRIO_MFMA);
+        // res 1x1 + residual; z (in (-1, 1): scaled by 2^13) is consumed straight from the accumulator registers
+        if (a.Xnext != nullptr) {
+            f32x16 racc[2];
+            racc[0] = f32x16_zero();
+            racc[1] = f32x16_zero();
+            const int vfrag = wn_frag_off(li, hi);
+            WN_UNROLL
+            for (int kb = 0; kb < 4; ++kb) {
+                float x8[8];
+                WN_UNROLL
+                for (int e = 0; e < 8; ++e) x8[e] = z[(8 * kb + e) >> 4][(8 * kb + e) & 15];
+                wn_f4 bf[2];
+                split8h(x8, 8192.0f, bf);
+                wn_f4 afr[2][2];
+                WN_UNROLL
+                for (int q = 0; q < 2; ++q) {
+                    WN_UNROLL
+                    for (int p = 0; p < 2; ++p) afr[q][p] = *reinterpret_cast<const wn_f4*>(Wr + kb * WR_BLK + vfrag + p * (64 * 32) + q * 1024);
+                }
+                WN_UNROLL
+                for (int t3 = 0; t3 < 3; ++t3) {
+                    racc[0] = mfma_f16(afr[0][PA[t3]], bf[PB[t3]], racc[0]);
+                    racc[1] = mfma_f16(afr[1][PA[t3]], bf[PB[t3]], racc[1]);
+                }
+            }
+            const float invr = inv_wr * (1.0f / 8192.0f);
+            {
+                const wn_rsrc_t Xn = wn_make_buf(a.Xnext + (long)b * 64 * T, slab);
+                WN_UNROLL
+                for (int q = 0; q < 2; ++q) {
+                    WN_UNROLL
+                    for (int r = 0; r < 16; ++r)
+                        wn_buf_store(Xn, fmaf(racc[q][r], invr, xb2[q][r]), vst, (32 * q + mfma32_row(r, 0)) * T4);
+                }
+            }
+        }
+        WN_PRIO(WN_PRIO_GATE);
+        tile_v = next_v;
+    }
+}
+
 template <int K>
 static int launch_fwd(const FwdArgs& a, int split, wn_stream_t st) {
     const long ntiles = (long)a.B * ((a.T + 31) / 32);
     const long nblk = balanced_blocks(ntiles);
+    if (split == 2) {   // fp16 pair split (needs the two-piece image of wn_fused_pack_images16)
+        if (a.wimg == nullptr) return 1;
+        const size_t lds_h = (size_t)fwd16_image_bytes(K) + 192 * sizeof(float);
+        if (set_lds(k_resblock_fwd_h<K>, lds_h)) return 1;
+        WN_LAUNCH((k_resblock_fwd_h<K>), dim3((unsigned)nblk), dim3(WN_FT), lds_h, st, a);
+        return 0;
+    }
     // split arithmetic: taps (+ res 1x1 for K <= 2; K = 3 reads those fragments from the global image) + cvec / bias
     const size_t lds_s = (size_t)K * 4 * (3 * 128 * 32) + (K >= 3 ? 0 : 4 * (3 * 64 * 32)) + 192 * sizeof(float);
     if (split && lds_s <= 160 * 1024 && (K < 3 || a.wimg != nullptr)) {  // (K = 3 without a weight image: the f32 MFMA kernel)

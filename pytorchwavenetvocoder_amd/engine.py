@@ -38,7 +38,17 @@ from . import _lib
 # operand by 2^(e + 8), and a gradient that still leaves fp16's range is DETECTED (non-finite block result) and redone by the
 # six-product launch issued behind every fp16 launch (an empty launch otherwise: 0.04 ms per step).  Any other gradient (autograd's
 # grad_output, the mixture-of-logistics head) keeps the six bf16 products unless the caller gives backward(dlogits_bound=...).
-DEFAULT_FLAGS = _lib.FLAG_AUX_FUSED | _lib.FLAG_DW_F16PAIR
+# WN_FLAG_MM_F16PAIR (round 6, DEFAULT): the weights x activations contractions on the split matrix-core kernel k_gemm6 -- skip sum,
+# post-net with the cross-entropy epilogue, their data gradients, the all-layer skip gradient; the per-layer contractions of wide
+# models -- take the same fp16 pair split (three products, ~2^-22 each: the rounding of an fp32 running sum over >= 64 terms), each
+# launch followed by a conditional six-product redo (an operand outside fp16's range raises a workspace word).  Same box: headline
+# step 9.21 -> 8.72 ms (fwd_skip_sum 0.68 -> 0.43, bwd_dz_skip_all 0.80 -> 0.62; profiles/r06/abk_mm_f16.txt).  Gates on the
+# benchmark's own instance against the reference module (tests/test_gpu_fullsize.py, bench.py `parity`): logits 4.9e-6 (six
+# products 5.5e-6), worst gradient 8.3e-6 (8.2e-6); against the fp64 evaluation of the same step the worst gradient is 6.2e-6 --
+# closer than the reference's own fp32 step (8.3e-6; profiles/r06/adam_gate_study.txt).  The fused 64-channel kernels keep six
+# products.
+DEFAULT_FLAGS = _lib.FLAG_AUX_FUSED | _lib.FLAG_DW_F16PAIR | _lib.FLAG_MM_F16PAIR
+SIX_PRODUCT_FLAGS = DEFAULT_FLAGS & ~_lib.NARROW_FLAGS   # every contraction fp32-equivalent (six bf16 products)
 
 
 def _ptr(t):

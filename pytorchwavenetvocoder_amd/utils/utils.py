@@ -166,9 +166,21 @@ class BackgroundGenerator(threading.Thread):
                 continue
         return False
 
-    def close(self):
-        """Stop the producer thread (it exits at its next hand-over)."""
+    def close(self, timeout=5.0):
+        """Stop the producer thread (it exits at its next hand-over), wait for it, and close the generator it was running
+        (its ``finally`` clauses -- e.g. the window slicer's worker pool -- run now, not at interpreter exit)."""
         self._closed = True
+        if threading.current_thread() is not self:
+            try:                      # free a slot: a producer blocked in put() sees _closed at its next time-out anyway
+                self.queue.get_nowait()
+            except Exception:  # noqa: BLE001
+                pass
+            self.join(timeout)
+            if not self.is_alive():
+                try:
+                    self.generator.close()
+                except Exception:  # noqa: BLE001 -- (a generator that is still executing cannot be closed: left to the daemon flag)
+                    pass
 
     def next(self):
         item = self.queue.get()

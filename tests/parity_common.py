@@ -212,8 +212,33 @@ def run_fullsize_vs_oracle(cfg_tuple, B, T, seed, lib, device, flag_sets, scale=
     out["layer_inputs"] = worst_x
     del inter
     out["grads"] = {}
+    out["forward_modes"] = {}
+    fwd_flags = flag_sets[0]
     for flags in flag_sets:
         eng.flags = flags
+        if (flags ^ fwd_flags) & _lib.FLAG_MM_F16PAIR:
+            # a flag set that changes the FORWARD arithmetic (WN_FLAG_MM_F16PAIR: the split contractions by the fp16 pair split):
+            # its own forward against the same oracle run -- logits, loss -- and its backward under the SAME sub-gradient choice as
+            # the oracle's masks: elements whose ReLU sign differs from the first forward's are genuine ties (asserted: within 1e-5
+            # of the kink) and take the first forward's choice
+            lg2 = eng.forward(xd, hd)
+            e_lg = float((lg2.transpose(1, 2).cpu() - logits_ref).abs().max())
+            assert e_lg <= TOL_LOGITS, "logits max-abs err %g (flags %d)" % (e_lg, flags)
+            del lg2
+            loss2, dl = eng.forward_loss(xd, hd, td)
+            assert abs(float(loss2.cpu()) - float(loss_ref)) <= TOL_LOSS
+            flips = 0
+            for kind, m in ((_lib.WS_RELU_SKIP, m_skip), (_lib.WS_RELU_POST1, m_post)):
+                sv = eng.saved(kind)[:, :, rf:]
+                md = m[:, :, rf:].to(sv.device) > 0
+                differ = (sv > 0) != md
+                n = int(differ.sum())
+                if n:
+                    assert float(sv[differ].abs().max()) <= 1e-5
+                    sv[differ] = torch.where(md[differ], torch.full_like(sv[differ], 1e-30), torch.zeros_like(sv[differ]))
+                flips += n
+            out["forward_modes"][flags] = {"logits": e_lg, "loss": abs(float(loss2.cpu()) - float(loss_ref)), "kink_ties_vs_first_forward": flips}
+            fwd_flags = flags
         grads = flat_to_state(eng, eng.backward(dl, t_first=eng.receptive_field).cpu(), O.param_shapes(cfg))   # the training step's call (loss window)
         worst, worst_k = 0.0, None
         for k, ref in grads_ref.items():

@@ -314,8 +314,8 @@ def test_backward_chain_kernel_modes():
     from pytorchwavenetvocoder_amd import _lib
     from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS, WaveNetEngine, load_state_into_flat
     A, NC = _lib.FLAG_AUX_FUSED, _lib.FLAG_NO_CHAIN
-    # chain + aux partials (+ the fp16 pair split of the weight gradients) is what every default-flag test runs
-    assert DEFAULT_FLAGS == A | _lib.FLAG_DW_F16PAIR
+    # chain + aux partials (+ the fp16 pair split of the weight gradients and of the k_gemm6 contractions) is what every default-flag test runs
+    assert DEFAULT_FLAGS == A | _lib.FLAG_DW_F16PAIR | _lib.FLAG_MM_F16PAIR
     for flags in (0, A, NC, A | NC):
         PC.check_golden_case(GoldenCase("r64_k2_up"), emu_library(), "cpu", flags=flags)
     PC.run_oracle_vs_engine((64, 6, 64, 32, 3, 1, 1, 16), 2, 48, 41, emu_library(), "cpu", flags=A, scale=0.2)   # K = 1
@@ -1018,3 +1018,37 @@ def test_split_contractions_by_the_fp16_pair_split_and_their_redo():
     eng.flags = base | _lib.FLAG_MM_F16PAIR
     got = eng.forward(x, h).clone()
     assert torch.equal(got, want)
+
+
+def test_fused_forward_block_on_the_block_scaled_fp16_pair_split():
+    """WN_FLAG_FUSED_F16PAIR (csrc/wn_fused.hip k_resblock_fwd_h): the fused 64-channel residual block with two fp16 pieces per
+    operand and three products, every weight image and every 64 x 32 operand tile scaled by the power of two that puts its
+    maximum at 2^12 / 2^14.  Golden cases (kernel_size 2 and 3) and the oracle at the gates of every mode; against the six-product
+    forward within 2e-6 of the largest logit; and MAGNITUDES: the same model with its front convolution scaled so that the
+    residual stream is ~1e6, and ~1e-6, still meets the gates (nothing leaves fp16's range, nothing is flushed)."""
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd import _lib
+    from pytorchwavenetvocoder_amd.engine import SIX_PRODUCT_FLAGS, WaveNetEngine, load_state_into_flat
+    F = SIX_PRODUCT_FLAGS | _lib.FLAG_FUSED_F16PAIR
+    for name in ("r64_k2_up", "r64_k3_up"):
+        PC.check_golden_case(GoldenCase(name), emu_library(), "cpu", flags=F)
+    PC.run_oracle_vs_engine((64, 6, 64, 32, 3, 1, 1, 16), 2, 48, 41, emu_library(), "cpu", flags=F, scale=0.2)   # K = 1
+    PC.run_oracle_vs_engine((64, 6, 64, 32, 2, 2, 2, 16), 3, 80, 42, emu_library(), "cpu", flags=F, scale=0.2)   # T % 32 == 16
+    g = GoldenCase("r64_k2_up")
+    eng = WaveNetEngine(*g.cfg.as_tuple(), device="cpu", library=emu_library())
+    load_state_into_flat(eng, g.params)
+    eng.flags = SIX_PRODUCT_FLAGS
+    six = eng.forward(g.x, g.h).clone()
+    eng.flags = F
+    f16 = eng.forward(g.x, g.h).clone()
+    err = float((f16 - six).abs().max()) / float(six.abs().max())
+    assert 0.0 < err <= 2e-6, err
+    for mag in (1.0e6, 1.0e-6):
+        big = g.clone_params()
+        big["causal.conv.weight"] = big["causal.conv.weight"] * mag
+        big["causal.conv.bias"] = big["causal.conv.bias"] * mag
+        ref = O.forward(g.cfg, big, g.x, g.h)
+        load_state_into_flat(eng, big)
+        got = eng.forward(g.x, g.h).transpose(1, 2)
+        assert bool(torch.isfinite(got).all())
+        assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max())), mag

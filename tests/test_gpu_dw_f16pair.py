@@ -24,9 +24,10 @@ def _lib():
 
 
 def _flags():
+    """the fp16 pair split of the WEIGHT GRADIENTS alone (every other contraction with six bf16 products): what this file pins"""
     from pytorchwavenetvocoder_amd import _lib as L
-    from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS
-    return (DEFAULT_FLAGS & ~L.FLAG_DW_3PRODUCT) | L.FLAG_DW_F16PAIR
+    from pytorchwavenetvocoder_amd.engine import SIX_PRODUCT_FLAGS
+    return SIX_PRODUCT_FLAGS | L.FLAG_DW_F16PAIR
 
 
 @pytest.mark.parametrize("name", ["tiny_k2_up", "tiny_k3_noup", "r64_k2_up", "r64_k3_up"])
@@ -98,3 +99,16 @@ def test_overflow_falls_back_to_the_six_products_bit_for_bit_and_unknown_gradien
                                     L.FLAG_AUX_FUSED | L.FLAG_DW_F16PAIR, _stream_handle(eng.device))
     eng.lib.check(rc, "wn_backward_window")
     assert float((eng.grads() * 2.0 ** 30 - g6).abs().max()) / scale <= 1e-6
+    # the engine's DEFAULT adds WN_FLAG_MM_F16PAIR (the k_gemm6 contractions of forward and backward by the same split, each with
+    # its conditional redo): against six products everywhere within 5e-6 of the largest gradient; with a promise 2^23 too small
+    # every fp16 launch of the backward pass -- data gradients included -- raises the word and is redone: finite, same accuracy
+    from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS
+    assert DEFAULT_FLAGS & L.FLAG_MM_F16PAIR
+    eng.flags = DEFAULT_FLAGS
+    loss, dl2 = eng.forward_loss(x.to(DEV), h.to(DEV), t.to(DEV))
+    log = PC.launch_log(_lib(), lambda: eng.backward(dl2))
+    gd = eng.grads().clone()
+    assert log.get("mm_redo_if_overflow", 0) >= 3, log
+    assert float((gd - g6).abs().max()) / scale <= 5e-6
+    gd_ov = eng.backward(dl2, dlogits_bound=2.0 ** -40).clone()
+    assert bool(torch.isfinite(gd_ov).all()) and float((gd_ov - g6).abs().max()) / scale <= 5e-6

@@ -56,10 +56,10 @@ def test_cfg2_full_size_vs_oracle():
     from pytorchwavenetvocoder_amd import _lib as L
     from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS
     cfg_t = (256, 80, 64, 256, 10, 3, 2, 80)
-    SIX = DEFAULT_FLAGS & ~(L.FLAG_DW_3PRODUCT | L.FLAG_DW_F16PAIR)
+    SIX = DEFAULT_FLAGS & ~L.NARROW_FLAGS
     res = PC.run_fullsize_vs_oracle(cfg_t, 8, 23040, 101, _lib(), DEV,
                                     flag_sets=[SIX, SIX ^ L.FLAG_AUX_FUSED, SIX | L.FLAG_NO_CHAIN, SIX | L.FLAG_DW_3PRODUCT,
-                                               SIX | L.FLAG_DW_F16PAIR],
+                                               SIX | L.FLAG_DW_F16PAIR, DEFAULT_FLAGS],
                                     scale=0.05)
     _three_product_gate("cfg2 FULL SIZE", res, SIX | L.FLAG_DW_3PRODUCT)
     _f16pair_gate("cfg2 FULL SIZE", res, SIX | L.FLAG_DW_F16PAIR)
@@ -121,8 +121,8 @@ def test_config4_stated_size_vs_oracle():
     cfg_t = (256, 80, 64, 256, 10, 3, 3, 256)
     assert O.batch_geometry(6139, 20000, 256)["T"] == 26112
     from pytorchwavenetvocoder_amd import _lib as L
-    SIX = DEFAULT_FLAGS & ~(L.FLAG_DW_3PRODUCT | L.FLAG_DW_F16PAIR)
-    res = PC.run_fullsize_vs_oracle(cfg_t, 8, 26112, 111, _lib(), DEV, flag_sets=[SIX, SIX | L.FLAG_DW_3PRODUCT, SIX | L.FLAG_DW_F16PAIR], scale=0.05)
+    SIX = DEFAULT_FLAGS & ~L.NARROW_FLAGS
+    res = PC.run_fullsize_vs_oracle(cfg_t, 8, 26112, 111, _lib(), DEV, flag_sets=[SIX, SIX | L.FLAG_DW_3PRODUCT, SIX | L.FLAG_DW_F16PAIR, DEFAULT_FLAGS], scale=0.05)
     _three_product_gate("configs[3] STATED SIZE", res, SIX | L.FLAG_DW_3PRODUCT)
     _f16pair_gate("configs[3] STATED SIZE", res, SIX | L.FLAG_DW_F16PAIR)
     print("configs[3] STATED SIZE (K=3, U=256, B=8, T=26112) vs oracle: logits %.3g, loss %.3g, layer inputs %.3g, grads %s, "
@@ -136,8 +136,8 @@ def test_recipe_size_model_at_the_timed_size_vs_oracle():
     from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS
     cfg_t = (256, 80, 512, 256, 10, 3, 2, 80)
     from pytorchwavenetvocoder_amd import _lib as L
-    SIX = DEFAULT_FLAGS & ~(L.FLAG_DW_3PRODUCT | L.FLAG_DW_F16PAIR)
-    res = PC.run_fullsize_vs_oracle(cfg_t, 4, 23040, 112, _lib(), DEV, flag_sets=[SIX, SIX | L.FLAG_DW_3PRODUCT, SIX | L.FLAG_DW_F16PAIR], scale=0.02)
+    SIX = DEFAULT_FLAGS & ~L.NARROW_FLAGS
+    res = PC.run_fullsize_vs_oracle(cfg_t, 4, 23040, 112, _lib(), DEV, flag_sets=[SIX, SIX | L.FLAG_DW_3PRODUCT, SIX | L.FLAG_DW_F16PAIR, DEFAULT_FLAGS], scale=0.02)
     _three_product_gate("recipe-size TIMED SIZE", res, SIX | L.FLAG_DW_3PRODUCT)
     _f16pair_gate("recipe-size TIMED SIZE", res, SIX | L.FLAG_DW_F16PAIR)
     print("recipe-size model at the TIMED SIZE (B=4, T=23040) vs oracle: logits %.3g, loss %.3g, layer inputs %.3g, grads %s, "
@@ -197,8 +197,8 @@ def test_benchmark_instance_vs_reference_module():
           "reference gradient among them %.3g)" % (noise["threads"], noise["worst_grad_rel"], noise["worst_grad_key"],
                                                    noise["after_adam_maxabs_over_lr"], noise["after_adam_worst_key"],
                                                    noise["after_adam_elements_over_gate"], noise["after_adam_over_gate_max_abs_reference_grad"]))
-    SIX = DEFAULT_FLAGS & ~(L.FLAG_DW_3PRODUCT | L.FLAG_DW_F16PAIR)
-    for flags in (DEFAULT_FLAGS, SIX, DEFAULT_FLAGS | L.FLAG_MM_F16PAIR):
+    SIX = DEFAULT_FLAGS & ~L.NARROW_FLAGS
+    for flags in (DEFAULT_FLAGS, SIX, SIX | L.FLAG_DW_F16PAIR):
         r = SRP.gpu_step_vs_reference(model, lambda m, lr: FusedAdam(m, lr=lr), ref, x, h, t, init_state, flags, lr=1e-4,
                                       layers_per_bucket=bench.LAYERS_PER_BUCKET)
         print("BENCHMARK INSTANCE (initialize() weights, B=8, T=23040) vs the %s module, flags %d: logits %.3g, loss %.3g, worst "

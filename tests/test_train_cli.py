@@ -196,16 +196,20 @@ def _slicer_kwargs(name, mean, scale):
     return kw, nb
 
 
+@pytest.mark.parametrize("workers,pre", [(0, False), (3, False), (0, True), (3, True)])
 @pytest.mark.parametrize("name", ["utt_up", "utt_noup", "win_up", "win_noup", "win_up_spk", "win_up_f64stats"])
-def test_window_slicer_is_bit_equal_to_the_reference_generator(tmp_path, name):
+def test_window_slicer_is_bit_equal_to_the_reference_generator(tmp_path, name, workers, pre):
     """x, h, t of every minibatch are BIT-equal to what the reference's train_generator (train.py:67-312, with
     validate_length :35-64, mu-law and the StandardScaler transform :463-470) yields on the same corpus, in all four
     batching modes, with the speaker code, across the end of an epoch (the carried-over buffer) -- fixture written by
-    tests/golden/make_slicer_golden.py from the reference's own code."""
+    tests/golden/make_slicer_golden.py from the reference's own code.  ``workers``: everything in the producer thread (0, the
+    reference's structure) and with the order-preserving worker pool (round 6: file reads, per-window transforms and
+    minibatch assembly as pool jobs consumed in submission order).  ``pre``: the two per-element transforms applied once per
+    utterance at read time (what the CLI does) instead of once per window."""
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "slicer.npz"))
     wavs, feats, mean, scale = _write_slicer_corpus(str(tmp_path))
     kw, nb = _slicer_kwargs(name, mean, scale)
-    gen = T.train_generator(wavs, feats, **kw)
+    gen = T.train_generator(wavs, feats, workers=workers, transforms_elementwise=pre, **kw)
     try:
         for i in range(nb):
             (x, h), t = gen.next()

@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--T", type=int, default=23040)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    six = DEFAULT_FLAGS & ~(_lib.FLAG_DW_F16PAIR | _lib.FLAG_DW_3PRODUCT)
+    six = DEFAULT_FLAGS & ~_lib.NARROW_FLAGS
     modes = [("six", six), ("six_again", six), ("f16", six | _lib.FLAG_DW_F16PAIR), ("bf3", six | _lib.FLAG_DW_3PRODUCT)]
     res = {n: run(f, a.steps, a.lr, a.batch, a.T, dev) for n, f in modes}
     l6, w6 = res["six"]
