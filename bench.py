@@ -65,13 +65,16 @@ FUSED_SHARE_R64 = 30.0 * (2 * 64 * 64 * 2 + 64 * 64) / (30.0 * (2 * 64 * 64 * 2 
 
 def products_per_multiply(flags, fused_share):
     """Average matrix-core products per fp32-equivalent multiply of one training step under the engine flags: forward and
-    data-gradient contractions (a third of the FLOPs each) take 6 (three bf16 pieces) in the fused kernels and 6 or 3 (two fp16
-    pieces, WN_FLAG_MM_F16PAIR) on k_gemm6; the weight gradients 6 or 3 (WN_FLAG_DW_F16PAIR / _3PRODUCT)."""
+    data-gradient contractions (a third of the FLOPs each) take 6 (three bf16 pieces) or 3 (two fp16 pieces) -- the fused forward
+    block by WN_FLAG_FUSED_F16PAIR, the k_gemm6 launches by WN_FLAG_MM_F16PAIR, the fused backward chain always 6; the weight
+    gradients 6 or 3 (WN_FLAG_DW_F16PAIR / _3PRODUCT)."""
     from pytorchwavenetvocoder_amd import _lib
     mm = DW_PRODUCTS if (flags & _lib.FLAG_MM_F16PAIR) else SPLIT_PRODUCTS
     dw = DW_PRODUCTS if (flags & (_lib.FLAG_DW_F16PAIR | _lib.FLAG_DW_3PRODUCT)) else SPLIT_PRODUCTS
-    fwd = fused_share * SPLIT_PRODUCTS + (1.0 - fused_share) * mm
-    return (2.0 * fwd + dw) / 3.0
+    ff = DW_PRODUCTS if (flags & _lib.FLAG_FUSED_F16PAIR) else SPLIT_PRODUCTS     # fused FORWARD block; the backward chain keeps six
+    fwd = fused_share * ff + (1.0 - fused_share) * mm
+    bwd = fused_share * SPLIT_PRODUCTS + (1.0 - fused_share) * mm
+    return (fwd + bwd + dw) / 3.0
 LAYERS_PER_BUCKET = 30      # gradient buckets = weight-gradient launch groups; N = 1 runs the SAME launch structure as N > 1.
 # 30 (= all layers of this model, GradientReducer's default) = [post-net + skip] [all residual layers] [front + upsampling]: measured 11.64 vs 11.80 ms/step for groups of 10
 # layers on the same box (profiles/r02/ab_probe.txt); 40 % of the gradient bytes (the first bucket) are exchanged under
@@ -398,8 +401,12 @@ def same_run_parity(model, ref, inst, layers_per_bucket):
                      "module's own step; at ReLU ties (both evaluations within 1e-5 of the kink) the HIP backward takes the "
                      "reference's sub-gradient choice (kink_flips elements).  `pass` = all four gates as stated; "
                      "`reference_self_noise` = the same reference step at two thread counts (its own reproducibility in the gates' "
-                     "units: the after-Adam gate of 1e-2 lr is below it at this size -- elements with |gradient| < 1e-7, where Adam's "
-                     "first update is sign-like); `after_adam_well_conditioned_pass` = every element over the gate is of that kind"}
+                     "units; host- and thread-count dependent: 0.004 - 0.04 lr after Adam).  The after-Adam gate of 1e-2 lr is below what "
+                     "fp32 resolves at this size: against the fp64 evaluation of the same step the reference's own fp32 step is 0.016 - "
+                     "0.024 lr (7 - 8 elements over the gate) and the HIP step 0.035 - 0.042 lr (11 - 17 elements), while the HIP step's "
+                     "worst gradient tensor is CLOSER to fp64 than the reference's (6.2e-6 vs 8.3e-6; profiles/r06/adam_gate_study.txt) "
+                     "-- the elements concerned have |gradient| < 1e-7, where Adam's first update lr g / (|g| + eps) is sign-like; "
+                     "`after_adam_well_conditioned_pass` = every element over the gate is of that kind"}
     try:
         mk = lambda m, lr: FusedAdam(m, lr=lr)   # noqa: E731
         d = SRP.gpu_step_vs_reference(model, mk, ref, x, h, t, init_state, base, lr=1e-4, layers_per_bucket=layers_per_bucket)
@@ -585,10 +592,10 @@ def main():
             "frac_ceiling_under_split": (alg_step / HBM_PEAK) / (B * T * ALG_FLOP_PER_TIMESTEP / (BF16_MFMA_PEAK / step_products)),
             "matrix_products_per_multiply": step_products,
             "matrix_roof_note": "fp32-equivalent FLOPs of the step (SURVEY 8d: 9.27 MFLOP per timestep) at 2.5 PFLOP/s dense 16-bit "
-                                "MFMA / the products per multiply of the operand split: forward and data-gradient contractions (a third "
-                                "of the FLOPs each) take 6 (three bf16 pieces) in the fused 64-channel kernels (%.0f %% of their "
-                                "multiplies) and 3 (two fp16 pieces, WN_FLAG_MM_F16PAIR) on k_gemm6, the weight gradients 3 "
-                                "(WN_FLAG_DW_F16PAIR) -> %.2f on average: the binding roof of this arithmetic is the matrix "
+                                "MFMA / the products per multiply of the operand split: 3 (two fp16 pieces) for the fused forward block, "
+                                "the k_gemm6 launches and the weight gradients (WN_FLAG_FUSED_F16PAIR / _MM_F16PAIR / _DW_F16PAIR), 6 "
+                                "(three bf16 pieces) for the fused backward chain (%.0f %% of the data-gradient multiplies) "
+                                "-> %.2f on average: the binding roof of this arithmetic is the matrix "
                                 "pipe, not HBM; matrix_roof_frac = that time / the measured step" % (100.0 * FUSED_SHARE_R64, step_products),
             # the chip's streaming plateau, measured with 256 MiB tensors (beyond the 256 MiB Infinity Cache), float4 per lane,
             # 256 workgroups (tools/microbench/stream_big.hip, profiles/r06/stream_big.txt): numbers, not notes
@@ -692,8 +699,11 @@ def main():
                                       "opt-in: it misses the golden after-Adam gate); "
                                       if (model.engine.flags & _lib.FLAG_DW_3PRODUCT) else "") +
                                      ("the k_gemm6 contractions (skip sum, post-net + loss, their data gradients) take the same fp16 "
-                                      "pair split (WN_FLAG_MM_F16PAIR), each launch with its conditional six-product redo; the fused "
-                                      "64-channel kernels keep six bf16 products; " if (model.engine.flags & _lib.FLAG_MM_F16PAIR) else "") +
+                                      "pair split (WN_FLAG_MM_F16PAIR), each launch with its conditional six-product redo; "
+                                      if (model.engine.flags & _lib.FLAG_MM_F16PAIR) else "") +
+                                     ("the fused 64-channel forward block takes it block-scaled (WN_FLAG_FUSED_F16PAIR: every weight image "
+                                      "and operand tile by the power of two of its own maximum); the fused backward chain keeps six bf16 "
+                                      "products; " if (model.engine.flags & _lib.FLAG_FUSED_F16PAIR) else "") +
                                      "WN_FLAG_EXACT_MFMA selects the f32 MFMA everywhere"},
             "timesteps_per_sec": world * timesteps_per_s_gpu, "final_loss": final_loss,
             "roofline": roofline, "comm": comm, "kernels": kernels,
@@ -739,9 +749,9 @@ def main():
                                       "WN_FLAG_MM_F16PAIR): fp32-equivalent to round-off; what each fp16-pair launch of the default redoes "
                                       "itself with when an operand leaves fp16's range; same gates (tests/test_gpu_fullsize.py, bench "
                                       "`parity.dw_six_products`)")
-            mm6 = alt_mode(base_flags & ~_lib.FLAG_MM_F16PAIR,
-                           "six bf16 products for the forward / data-gradient contractions on k_gemm6 (no WN_FLAG_MM_F16PAIR), fp16 pairs "
-                           "for the weight gradients: the default of round 5")
+            mm6 = alt_mode(base_flags & ~(_lib.FLAG_MM_F16PAIR | _lib.FLAG_FUSED_F16PAIR),
+                           "six bf16 products for every forward / data-gradient contraction (no WN_FLAG_MM_F16PAIR, no "
+                           "WN_FLAG_FUSED_F16PAIR), fp16 pairs for the weight gradients: the default of round 5")
             dw3 = alt_mode(six_flags | _lib.FLAG_DW_3PRODUCT,
                            "WN_FLAG_DW_3PRODUCT (opt-in): two bf16 pieces, three products (2^-16 per product): meets the 3e-5 gradient "
                            "gate, misses the golden after-Adam gate (1e-2 lr) by 2x -- not a default, not the metric")

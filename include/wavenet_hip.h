@@ -166,6 +166,12 @@ enum {
                                * weight image and every 64 x 32 operand tile is multiplied by the power of two that puts its maximum
                                * at 2^12 / 2^14, so no magnitude can leave fp16's range and no redo is needed (csrc/wn_fused.hip
                                * k_resblock_fwd_h).  Forward only: the backward chain keeps six bf16 products. */
+#define WN_FLAG_CHAIN_F16PAIR (1 << 30) /* since ABI v9, opt-in: wn_forward(_loss) packs and wn_backward(_window) uses -- the fused backward data chain
+                               * (dX_l from dP_l, gate' of layer l-1) on the block-scaled fp16 pair split (k_chain64s<.., H16>): weight
+                               * images by the power of two of their maximum, the dP operand of a tile by the maximum of the producer
+                               * tiles it reads (every chain launch records max |dP| per 32-sample tile beside dP), the dX operand by
+                               * its own maximum.  Same flag for the forward and the backward call of a step (the images are packed by
+                               * the forward call), or WN_FLAG_REPACK. */
 #define WN_FLAG_DW_FLUSH(n) (((n) & 0xff) << 8) /* wn_backward: issue the weight gradients of at most n walked layers per
                                * launch group (0 = default: a whole gradient bucket; 5 layers with WN_FLAG_BWD_OVERLAP).
                                * Groups never straddle a bucket.  The split-K plan of a group depends on its size, so

@@ -101,8 +101,9 @@ def dw_f16_exp(bound):
 
 
 FLAG_FUSED_F16PAIR = 1 << 29  # the fused 64-channel forward block on the block-scaled fp16 pair split (k_resblock_fwd_h)
+FLAG_CHAIN_F16PAIR = 1 << 30  # the fused backward chain on the block-scaled fp16 pair split (k_chain64s<.., H16>)
 # every flag that narrows a contraction below the six bf16 products (engine.SIX_PRODUCT_FLAGS = DEFAULT_FLAGS without them)
-NARROW_FLAGS = FLAG_DW_3PRODUCT | FLAG_DW_F16PAIR | FLAG_MM_F16PAIR | FLAG_FUSED_F16PAIR
+NARROW_FLAGS = FLAG_DW_3PRODUCT | FLAG_DW_F16PAIR | FLAG_MM_F16PAIR | FLAG_FUSED_F16PAIR | FLAG_CHAIN_F16PAIR
 FLAG_REPACK = 1 << 17  # wn_backward: rebuild the packed / pre-split weight sets from the params given to that call
 
 

@@ -406,14 +406,21 @@ def _worker(rank, world, args, port):
     if not torch.cuda.is_available():
         logging.error("gpu is not available. please check the setting.")  # reference train.py:524-525
         sys.exit(1)
-    torch.cuda.set_device(rank)
-    device = torch.device("cuda", rank)
+    # WN_TRAIN_BACKEND=gloo lets the N-rank control flow (sharded slicer, bucketed exchange, identical Adam) be exercised on a box
+    # with fewer GPUs than ranks -- the ranks then share devices; real runs use nccl (= RCCL), one rank per GPU.
+    backend = os.environ.get("WN_TRAIN_BACKEND", "nccl")
+    dev_index = rank if backend == "nccl" else rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(port))
-        from pytorchwavenetvocoder_amd.distributed import rccl_footprint_defaults
-        rccl_footprint_defaults()
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            from pytorchwavenetvocoder_amd.distributed import rccl_footprint_defaults
+            rccl_footprint_defaults()
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     is_main = rank == 0
     if is_main:
         for key, value in vars(args).items():

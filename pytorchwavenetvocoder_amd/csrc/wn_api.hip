@@ -387,6 +387,8 @@ struct Ws {
     long dw_ovf;   // one word (of 64): raised by an fp16-pair weight-gradient launch whose result was not finite (WN_FLAG_DW_F16PAIR)
     long dGp, qp;  // aux-gradient partials of the gate kernel (WN_FLAG_AUX_FUSED); 0 floats when the mode cannot apply
     long img_fwd16, img16_floats;  // two-piece fp16 images of the fused forward block (WN_FLAG_FUSED_F16PAIR)
+    long img_taps16, img_res16, img_taps16_floats, img_res16_floats;   // ... of the backward chain (WN_FLAG_CHAIN_F16PAIR)
+    long amaxP, amaxP_lfloats;     // max |dP_l| per 32-sample tile, [L][B * ceil(T / 32)]
     long img_fwd, img_taps, img_res, img_floats;  // pre-split LDS weight images of the fused split kernels (0 floats: not applicable)
     long wskipT_f, dZs;  // chain mode (wn_fused_chain_supported): skip weights as [s][l*R + i], dZs = Wskip^T dSkip (B, L*R, T)
     long dZs_floats;
@@ -451,8 +453,14 @@ static int make_ws(const Dims& d, int B, int T, Ws* w, bool training = true) {
         CARVE(img_fwd, w->img_floats);
         CARVE(img_taps, img ? wn_fused_image_floats(d.K, d.L, 1) : 0);
         CARVE(img_res, img ? wn_fused_image_floats(d.K, d.L, 2) : 0);
-        w->img16_floats = img ? wn_fused_image16_floats(d.K, d.L) : 0;
+        w->img16_floats = img ? wn_fused_image16_floats(d.K, d.L, 0) : 0;
         CARVE(img_fwd16, w->img16_floats);
+        w->img_taps16_floats = img ? wn_fused_image16_floats(d.K, d.L, 1) : 0;
+        CARVE(img_taps16, w->img_taps16_floats);
+        w->img_res16_floats = img ? wn_fused_image16_floats(d.K, d.L, 2) : 0;
+        CARVE(img_res16, w->img_res16_floats);
+        w->amaxP_lfloats = img ? al64((long)B * ((T + 31) / 32)) : 0;
+        CARVE(amaxP, w->amaxP_lfloats * d.L);
     }
     {
         const bool chain = wn_fused_chain_supported(d.R, d.K, d.S) && d.L > 1;
@@ -583,6 +591,7 @@ struct Ctx {
     bool fused;
     bool split_bf16;  // forward-type contractions on the bf16 matrix cores (3-way split, fp32-equivalent)
     int dw_products;  // products per multiply of the weight-gradient contractions: 6, or 3 with WN_FLAG_DW_3PRODUCT
+    bool chain_f16;   // WN_FLAG_CHAIN_F16PAIR: the backward chain kernel on the block-scaled fp16 pair split (k_chain64s<.., H16>)
     bool fused_f16;   // WN_FLAG_FUSED_F16PAIR: the fused 64-channel forward block on the fp16 pair split (block-scaled, k_resblock_fwd_h)
     bool mm_f16;      // WN_FLAG_MM_F16PAIR: the forward / data-gradient split contractions (k_gemm6) take the fp16 pair split as well, each
                       // followed by its conditional six-product redo
@@ -612,6 +621,7 @@ static int make_ctx(Ctx* c, const WnConfig* cfg, int B, int T, void* ws, size_t 
     c->dw_products = (flags & WN_FLAG_DW_3PRODUCT) ? 3 : 6;
     c->mm_f16 = c->split_bf16 && (flags & WN_FLAG_MM_F16PAIR);
     c->fused_f16 = c->fused && c->split_bf16 && (flags & WN_FLAG_FUSED_F16PAIR) && c->w.img16_floats > 0;
+    c->chain_f16 = c->fused && c->split_bf16 && (flags & WN_FLAG_CHAIN_F16PAIR) && c->w.img_taps16_floats > 0;
     c->dw_f16_mode = !((flags & WN_FLAG_DW_F16PAIR) || c->mm_f16) ? 0 : (flags & WN_FLAG_DW_F16_EXP_VALID) ? 1 : (flags & WN_FLAG_DW_F16_AMAX_WS) ? 2 : 3;
     c->dw_f16_mul = (flags & WN_FLAG_DW_F16PAIR) ? -1.0f : 0.0f;
     c->dw_ovf = reinterpret_cast<int*>(c->ws + c->w.dw_ovf);
@@ -824,8 +834,10 @@ static int pack_weights(const Ctx& c, const float* params) {
     if (c.fused && c.split_bf16 && w.img_floats > 0)   // LDS images of the split kernels: one launch for all layers
         WN_TRY(wn_fused_pack_images(ws + w.wd_f, ws + w.wres_f, ws + w.wd_b, params, lb0 + y.o_res_w, lstep, ws + w.img_fwd,
                                     ws + w.img_taps, ws + w.img_res, d.K, d.L, c.st));
-    if (c.fused_f16)
-        WN_TRY(wn_fused_pack_images16(ws + w.wd_f, ws + w.wres_f, ws + w.img_fwd16, d.K, d.L, c.st));
+    if (c.fused_f16 || c.chain_f16)
+        WN_TRY(wn_fused_pack_images16(ws + w.wd_f, ws + w.wres_f, ws + w.wd_b, params, lb0 + y.o_res_w, lstep,
+                                      c.fused_f16 ? ws + w.img_fwd16 : nullptr, c.chain_f16 ? ws + w.img_taps16 : nullptr,
+                                      ws + w.img_res16, d.K, d.L, c.st));
     // cvec / rowsum_aux / bskip / one
     WnCvecArgs ca;
     ca.params = params;

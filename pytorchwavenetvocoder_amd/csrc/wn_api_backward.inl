@@ -309,7 +309,8 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
                 WN_TRY(wn_fused_bwd_chain_head(ws + w.dZs + (long)l * d.R * T, zs_bstride, Sl, Zl, gz, dP,
                                                ws + w.G + (long)l * 2 * d.R * F, g_bstride, upw, Ue, F,
                                                aux_fused ? ws + w.dGp + (long)l * B * 2 * d.R * (T / 16) : nullptr,
-                                               aux_fused ? ws + w.qp + (long)l * B * T : nullptr, B, T, t0, c.st));
+                                               aux_fused ? ws + w.qp + (long)l * B * T : nullptr, B, T, t0,
+                                               c.chain_f16 ? ws + w.amaxP + (long)l * w.amaxP_lfloats : nullptr, c.st));
             }
             if (l > 0) {  // dX_l from dP_l, and gate' of layer l-1 from it
                 const long lbp = layer_base(y, d, l - 1);
@@ -319,9 +320,12 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
                                           ws + w.G + (long)(l - 1) * 2 * d.R * F, g_bstride, upw, Ue, F,
                                           aux_fused ? ws + w.dGp + (long)(l - 1) * B * 2 * d.R * (T / 16) : nullptr,
                                           aux_fused ? ws + w.qp + (long)(l - 1) * B * T : nullptr, B, T, d.K, dil,
-                                          (w.img_floats > 0) ? ws + w.img_taps + (long)l * (wn_fused_image_floats(d.K, d.L, 1) / d.L) : nullptr,
-                                          (w.img_floats > 0) ? ws + w.img_res + (long)(l - 1) * (wn_fused_image_floats(d.K, d.L, 2) / d.L) : nullptr,
-                                          t0, c.st));
+                                          c.chain_f16 ? ws + w.img_taps16 + (long)l * (w.img_taps16_floats / d.L)
+                                                      : ((w.img_floats > 0) ? ws + w.img_taps + (long)l * (wn_fused_image_floats(d.K, d.L, 1) / d.L) : nullptr),
+                                          c.chain_f16 ? ws + w.img_res16 + (long)(l - 1) * (w.img_res16_floats / d.L)
+                                                      : ((w.img_floats > 0) ? ws + w.img_res + (long)(l - 1) * (wn_fused_image_floats(d.K, d.L, 2) / d.L) : nullptr),
+                                          t0, c.chain_f16 ? ws + w.amaxP + (long)l * w.amaxP_lfloats : nullptr,
+                                          c.chain_f16 ? ws + w.amaxP + (long)(l - 1) * w.amaxP_lfloats : nullptr, c.st));
             } else {      // tail: dX_0
                 WN_TRY(wn_fused_bwd_dx(ws + w.wd_b, dP, dXn, dXl, B, T, d.K, dil, 1, c.st));
             }

@@ -255,6 +255,7 @@ static void dl_ctx(Ctx* c, const WnConfig* cfg, const Dims& d, const DlLay& y, i
     c->dw_f16_mode = 0;
     c->mm_f16 = false;
     c->fused_f16 = false;
+    c->chain_f16 = false;
     c->dw_ovf = nullptr;
     c->params = nullptr;
     c->have_pre = false;

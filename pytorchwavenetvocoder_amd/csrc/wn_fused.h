@@ -50,12 +50,14 @@ int wn_fused_chain_supported(int R, int K, int S);
 int wn_fused_bwd_chain(const float* wd_b, const float* dP, const float* dXn, float* dX, const float* wres_prev, const float* dZs,
                        long zs_bstride, const float* S, const float* Gt, int gt_is_z, float* dP_prev, const float* G, long g_bstride,
                        const float* upw, int U, int F, float* dGp, float* qp, int B, int T, int K, int dilation,
-                       const float* img_taps, const float* img_res, int zs_t0, wn_stream_t st);
+                       const float* img_taps, const float* img_res, int zs_t0, const float* amaxP, float* amaxPm, wn_stream_t st);
 // zs_t0: dZs[.., t < zs_t0] is taken as zero and never read (loss window, wn_backward_window)
+// amaxP != NULL: the fp16 pair split (k_chain64s<.., H16>): img_taps / img_res are the two-piece images of wn_fused_pack_images16,
+// amaxP (B, ceil(T/32)) holds max |dP| per 32-sample tile as the launch that wrote dP left it, amaxPm receives it for dP_prev
 // top of the chain: dP_{L-1} = gate'(dZs_{L-1}) alone (the last layer has no residual gradient); same aux outputs
 int wn_fused_bwd_chain_head(const float* dZs, long zs_bstride, const float* S, const float* Gt, int gt_is_z, float* dP_prev,
                             const float* G, long g_bstride, const float* upw, int U, int F, float* dGp, float* qp, int B, int T,
-                            int zs_t0, wn_stream_t st);
+                            int zs_t0, float* amaxPm, wn_stream_t st);
 
 // LDS weight images of the split kernels, built ONCE per step for all L layers instead of once per workgroup per launch:
 //   which = 0  forward block of layer l (taps + res 1x1)      from wd_f, wres_f
@@ -66,7 +68,9 @@ int wn_fused_bwd_chain_head(const float* dZs, long zs_bstride, const float* S, c
 long wn_fused_image_floats(int K, int L, int which);
 // Two-piece fp16 images of the forward block (k_resblock_fwd_h: `split` = 2 in wn_fused_resblock_fwd, `wimg` = layer l's image):
 // [K*4 blocks][2 pieces][128 rows][16 k] taps, [4][2][64][16] res 1x1, block-scaled by powers of two, inverse scales in the tail
-long wn_fused_image16_floats(int K, int L);
-int wn_fused_pack_images16(const float* wd_f, const float* wres_f, float* img16, int K, int L, wn_stream_t st);
+// which = 0 forward block, 1 chain taps, 2 chain Wres^T (k_chain64s<.., H16>); img_taps16 == NULL: the forward image only
+long wn_fused_image16_floats(int K, int L, int which);
+int wn_fused_pack_images16(const float* wd_f, const float* wres_f, const float* wd_b, const float* params, long res_off,
+                           long res_lstride, float* img_fwd16, float* img_taps16, float* img_res16, int K, int L, wn_stream_t st);
 int wn_fused_pack_images(const float* wd_f, const float* wres_f, const float* wd_b, const float* params, long res_off,
                          long res_lstride, float* img_fwd, float* img_taps, float* img_res, int K, int L, wn_stream_t st);

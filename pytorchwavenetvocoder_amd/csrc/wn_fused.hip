@@ -1031,21 +1031,100 @@ static __device__ __forceinline__ void fill_fwd16_image(char* img, const float* 
     }
 }
 
-template <int K>
-__global__ __launch_bounds__(WN_LB) void k_fused_pack_images16(const float* wd_f, const float* wres_f, float* img16) {
-    __shared__ float red[32];
-    const int l = blockIdx.x;
-    fill_fwd16_image<K>(reinterpret_cast<char*>(img16) + (long)l * fwd16_image_bytes(K), wd_f + (long)l * K * 64 * 128,
-                        wres_f + (long)l * 64 * 64, red, threadIdx.x, WN_FT);
+// block-wide maximum of |w[0 .. n)| (every thread returns it); red: 16 floats of shared memory
+static __device__ __forceinline__ float block_amax(const float* w, int n, float* red, int tid, int nthr) {
+    float m = 0.0f;
+    for (int i = tid; i < n; i += nthr) m = fmaxf(m, fabsf(w[i]));
+    m = wave_reduce_max(m);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = 0.0f;
+    for (int i = 0; i < (nthr >> 6); ++i) m = fmaxf(m, red[i]);
+    return m;
+}
+// two-piece fp16 images of the backward chain (k_chain64s<.., H16>): the tap blocks in fill_chain_taps' order, 4 KB each, and
+// Wres^T (4 blocks); each image is followed by the inverse of the power of two it was scaled by (64-byte tail)
+static __host__ __device__ constexpr int chain_taps16_bytes(int K) { return K * 8 * 4096 + 64; }
+#define WN_RES_T16_BYTES (4 * 4096 + 64)
+static __device__ __forceinline__ void fill_chain_taps16(char* W, const float* wd_b, int K, float* red, int tid, int nthr) {
+    const float sc = wn_pow2_scale(block_amax(wd_b, K * 128 * 64, red, tid, nthr), 12);
+    for (int idx = tid; idx < K * 4 * 2 * 128; idx += nthr) {
+        const int o = idx & 63, h = (idx >> 6) & 1, kbg = idx >> 7;
+        const int q = kbg >> 1;
+        const int tap = q % K;
+        const int c = (q / K) * 32 + (kbg & 1) * 16 + 8 * h;
+        const float* src = wd_b + ((long)tap * 128 + c) * 64 + o;
+        float x[8];
+        WN_UNROLL
+        for (int e = 0; e < 8; ++e) x[e] = src[e * 64];
+        wn_f4 bf[2];
+        split8h(x, sc, bf);
+        WN_UNROLL
+        for (int p = 0; p < 2; ++p) *reinterpret_cast<wn_f4*>(W + kbg * 4096 + p * 2048 + wn_frag_off(o, h)) = bf[p];
+    }
+    if (tid == 0) *reinterpret_cast<float*>(W + K * 8 * 4096) = 1.0f / sc;
+}
+static __device__ __forceinline__ void fill_res_t16(char* Wr, const float* wres, float* red, int tid, int nthr) {
+    const float sc = wn_pow2_scale(block_amax(wres, 64 * 64, red, tid, nthr), 12);
+    for (int idx = tid; idx < 4 * 2 * 64; idx += nthr) {
+        const int o = idx & 63, h = (idx >> 6) & 1, kb = idx >> 7;
+        const float* src = wres + (long)(16 * kb + 4 * h) * 64 + o;
+        float x[8];
+        WN_UNROLL
+        for (int e = 0; e < 8; ++e) x[e] = src[((e & 3) + 8 * (e >> 2)) * 64];
+        wn_f4 bf[2];
+        split8h(x, sc, bf);
+        WN_UNROLL
+        for (int p = 0; p < 2; ++p) *reinterpret_cast<wn_f4*>(Wr + kb * 4096 + p * 2048 + wn_frag_off(o, h)) = bf[p];
+    }
+    if (tid == 0) *reinterpret_cast<float*>(Wr + 4 * 4096) = 1.0f / sc;
 }
 
-long wn_fused_image16_floats(int K, int L) { return (K < 1 || K > 3) ? 0 : (long)L * fwd16_image_bytes(K) / 4; }
+struct PackImg16Args {
+    const float* wd_f;    // [L][K*64][128]
+    const float* wres_f;  // [L][64][64]
+    const float* wd_b;    // [L][K][128][64]
+    const float* params;  // natural res_1x1 weight of layer l at params + res_off + l * res_lstride
+    long res_off, res_lstride;
+    float* img_fwd16;     // [L][fwd16_image_bytes / 4] or NULL
+    float* img_taps16;    // [L][chain_taps16_bytes / 4] or NULL
+    float* img_res16;     // [L][WN_RES_T16_BYTES / 4]
+};
+template <int K>
+__global__ __launch_bounds__(WN_LB) void k_fused_pack_images16(PackImg16Args a) {
+    __shared__ float red[32];
+    const int l = blockIdx.x, kind = blockIdx.y;
+    if (kind == 0) {
+        if (a.img_fwd16)
+            fill_fwd16_image<K>(reinterpret_cast<char*>(a.img_fwd16) + (long)l * fwd16_image_bytes(K), a.wd_f + (long)l * K * 64 * 128,
+                                a.wres_f + (long)l * 64 * 64, red, threadIdx.x, WN_FT);
+    } else if (a.img_taps16) {
+        if (kind == 1)
+            fill_chain_taps16(reinterpret_cast<char*>(a.img_taps16) + (long)l * chain_taps16_bytes(K), a.wd_b + (long)l * K * 128 * 64, K,
+                              red, threadIdx.x, WN_FT);
+        else
+            fill_res_t16(reinterpret_cast<char*>(a.img_res16) + (long)l * WN_RES_T16_BYTES, a.params + a.res_off + (long)l * a.res_lstride,
+                         red, threadIdx.x, WN_FT);
+    }
+}
 
-int wn_fused_pack_images16(const float* wd_f, const float* wres_f, float* img16, int K, int L, wn_stream_t st) {
+long wn_fused_image16_floats(int K, int L, int which) {
+    if (K < 1 || K > 3) return 0;
+    const long per = which == 0 ? fwd16_image_bytes(K) : which == 1 ? chain_taps16_bytes(K) : WN_RES_T16_BYTES;
+    return (long)L * per / 4;
+}
+
+int wn_fused_pack_images16(const float* wd_f, const float* wres_f, const float* wd_b, const float* params, long res_off,
+                           long res_lstride, float* img_fwd16, float* img_taps16, float* img_res16, int K, int L, wn_stream_t st) {
     WN_PROF("fused_pack_images16", 0.0, 0.0, st);
-    if (K == 1) WN_LAUNCH((k_fused_pack_images16<1>), dim3((unsigned)L), dim3(WN_FT), 0, st, wd_f, wres_f, img16);
-    else if (K == 2) WN_LAUNCH((k_fused_pack_images16<2>), dim3((unsigned)L), dim3(WN_FT), 0, st, wd_f, wres_f, img16);
-    else if (K == 3) WN_LAUNCH((k_fused_pack_images16<3>), dim3((unsigned)L), dim3(WN_FT), 0, st, wd_f, wres_f, img16);
+    PackImg16Args a;
+    a.wd_f = wd_f; a.wres_f = wres_f; a.wd_b = wd_b; a.params = params; a.res_off = res_off; a.res_lstride = res_lstride;
+    a.img_fwd16 = img_fwd16; a.img_taps16 = img_taps16; a.img_res16 = img_res16;
+    const dim3 grid((unsigned)L, img_taps16 ? 3u : 1u);
+    if (K == 1) WN_LAUNCH((k_fused_pack_images16<1>), grid, dim3(WN_FT), 0, st, a);
+    else if (K == 2) WN_LAUNCH((k_fused_pack_images16<2>), grid, dim3(WN_FT), 0, st, a);
+    else if (K == 3) WN_LAUNCH((k_fused_pack_images16<3>), grid, dim3(WN_FT), 0, st, a);
     else return 1;
     return 0;
 }
@@ -1917,6 +1996,9 @@ struct ChainArgs {
     int U, F;
     float* dGp;          // (B, 128, T/16)
     float* qp;           // (B, T)
+    // H16 (fp16 pair split, block-scaled): img_taps / img_res are the two-piece images of wn_fused_pack_images16
+    const float* amaxP;  // (B, tiles) max |dP_l| of every 32-sample tile, written by the launch that produced dP_l
+    float* amaxPm;       // (B, tiles) out: max |dP_{l-1}| per tile (nullable)
 };
 
 // 8 fp32 values -> the three bf16 pieces of the lane's share of a 16-k block
@@ -1930,17 +2012,33 @@ static __device__ __forceinline__ void split8v(const float (&x)[8], bool ok, wn_
 // HEAD = true: the top of the chain.  The last layer's residual output is dead (wavenet.py:231-238), so dP_{L-1} is the gate'
 // epilogue alone on dZs_{L-1} (which bwd_dz_skip_all now produces for ALL layers): no taps, no Wres^T, no dX -- its own
 // instantiation, so that the main one compiles exactly as before.
-template <int AUX, int K, bool HEAD = false>
+// H16 (round 6, WN_FLAG_CHAIN_F16PAIR): the fp16 pair split, block-scaled like k_resblock_fwd_h -- two fp16 pieces per operand, three
+// products; the weight images by the power of two of their own maximum (wn_fused_pack_images16); the dP operand of a tile by the
+// power of two that puts the maximum of the producer tiles it reads at 2^14 (every launch leaves max |dP| per 32-sample tile beside
+// the tensor it writes: `amaxPm`; the consumer looks up the tiles its shifted taps cover: `amaxP`), the dX operand of the res-1x1
+// transpose by its own wave-wide maximum.  Nothing can leave fp16's range, whatever the size of the gradients.  Images: 64 + 16 KB
+// for K = 2, 96 + 16 KB for K = 3 (the Wres^T fragments are back in the LDS).
+template <int AUX, int K, bool HEAD = false, bool H16 = false>
 __global__ __launch_bounds__(WN_LB) void k_chain64s(ChainArgs a) {
     WN_DYN_SMEM(smem_raw);
     char* W = smem_raw;                      // tap blocks: chunk q (32 channels) = tap q % K, channel group q / K; 2 blocks of 6 KB each
     constexpr int NCH = K * 4;               // chunks of the dX part
-    char* Wr = W + NCH * 2 * 6144;           // Wres^T: 4 blocks [piece][64 rows][16 k], k order = accumulator register order
+    constexpr int BLKB = H16 ? 4096 : 6144;  // bytes of one [piece][64 rows][16 k] block
+    constexpr int PCB = 2048;                // ... of one piece of it
+    char* Wr = W + NCH * 2 * BLKB;           // Wres^T: 4 blocks [piece][64 rows][16 k], k order = accumulator register order
     // K = 3: the taps alone fill the LDS (144 KB); the Wres^T fragments (24 KB, L2 resident) are read from the pre-split image
     // in global memory, one 16-k block ahead of their MFMAs (the launcher only takes K = 3 with images)
-    constexpr bool RG = (K >= 3);
+    constexpr bool RG = (K >= 3) && !H16;
+    float inv_wd = 1.0f, inv_wr = 1.0f;
+    (void)inv_wd; (void)inv_wr; (void)PCB;
     if (HEAD) {
         // no weights
+    } else if (H16) {
+        copy_image_to_lds(W, a.img_taps, NCH * 2 * BLKB);
+        copy_image_to_lds(Wr, a.img_res, 4 * BLKB);
+        inv_wd = a.img_taps[NCH * 2 * BLKB / 4];
+        inv_wr = a.img_res[4 * BLKB / 4];
+        WN_WAIT_VMCNT(0);
     } else if (RG) {
         copy_image_to_lds(W, a.img_taps, chain_taps_bytes(K));
         WN_WAIT_VMCNT(0);
@@ -1978,26 +2076,44 @@ __global__ __launch_bounds__(WN_LB) void k_chain64s(ChainArgs a) {
         for (int s = 0; s < 16; ++s) xr[s] = wn_buf_load(Sr, vt, (c0 + 16 * (s >> 3) + (s & 7)) * T4);
     };
     f32x16 acc[2];
+    float s_dp = 1.0f;   // H16: block scale of this tile's dP operand
     auto consume = [&](int q, const float (&xr)[16], bool okr) {
         WN_UNROLL
         for (int blk = 0; blk < 2; ++blk) {
             float x8[8];
             WN_UNROLL
-            for (int e = 0; e < 8; ++e) x8[e] = xr[8 * blk + e];
-            wn_f4 bf[3];
-            split8v(x8, okr, bf);
-            const char* Wl = W + (2 * q + blk) * 6144 + wn_frag_off(li, hi);
-            wn_f4 af[2][3];
-            WN_UNROLL
-            for (int rt = 0; rt < 2; ++rt) {
+            for (int e = 0; e < 8; ++e) x8[e] = H16 ? (okr ? xr[8 * blk + e] : 0.0f) : xr[8 * blk + e];
+            const char* Wl = W + (2 * q + blk) * BLKB + wn_frag_off(li, hi);
+            if constexpr (H16) {
+                wn_f4 bf[2];
+                split8h(x8, s_dp, bf);
+                wn_f4 af[2][2];
                 WN_UNROLL
-                for (int p = 0; p < 3; ++p) af[rt][p] = *reinterpret_cast<const wn_f4*>(Wl + p * 2048 + rt * 1024);
-            }
-            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};  // small terms first
-            WN_UNROLL
-            for (int t6 = 0; t6 < WN_EXP_NPROD; ++t6) {
-                acc[0] = mfma_bf16(af[0][PA[t6]], bf[PB[t6]], acc[0]);
-                acc[1] = mfma_bf16(af[1][PA[t6]], bf[PB[t6]], acc[1]);
+                for (int rt = 0; rt < 2; ++rt) {
+                    WN_UNROLL
+                    for (int p = 0; p < 2; ++p) af[rt][p] = *reinterpret_cast<const wn_f4*>(Wl + p * PCB + rt * 1024);
+                }
+                constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};   // small terms first: h l, l h, h h
+                WN_UNROLL
+                for (int t3 = 0; t3 < 3; ++t3) {
+                    acc[0] = mfma_f16(af[0][PA[t3]], bf[PB[t3]], acc[0]);
+                    acc[1] = mfma_f16(af[1][PA[t3]], bf[PB[t3]], acc[1]);
+                }
+            } else {
+                wn_f4 bf[3];
+                split8v(x8, okr, bf);
+                wn_f4 af[2][3];
+                WN_UNROLL
+                for (int rt = 0; rt < 2; ++rt) {
+                    WN_UNROLL
+                    for (int p = 0; p < 3; ++p) af[rt][p] = *reinterpret_cast<const wn_f4*>(Wl + p * 2048 + rt * 1024);
+                }
+                constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};  // small terms first
+                WN_UNROLL
+                for (int t6 = 0; t6 < WN_EXP_NPROD; ++t6) {
+                    acc[0] = mfma_bf16(af[0][PA[t6]], bf[PB[t6]], acc[0]);
+                    acc[1] = mfma_bf16(af[1][PA[t6]], bf[PB[t6]], acc[1]);
+                }
             }
         }
     };
@@ -2039,6 +2155,22 @@ __global__ __launch_bounds__(WN_LB) void k_chain64s(ChainArgs a) {
                 }
             }
         } else {
+            if constexpr (H16) {
+                // block scale of the dP operand: the largest |dP_l| over the producer tiles this tile's taps read (shift
+                // (K - 1 - tap) d ahead: at most two tiles each), as the launch that wrote dP_l recorded them
+                const int tb = tile - b * tiles_per_b;
+                const float* am = a.amaxP + (long)b * tiles_per_b;
+                float m = 0.0f;
+                WN_UNROLL
+                for (int tap = 0; tap < K; ++tap) {
+                    const int sh = (K - 1 - tap) * a.dil;
+                    const int t_lo = tb * 32 + sh, t_hi = t_lo + 31;
+                    const int i0 = t_lo >> 5, i1 = t_hi >> 5;
+                    if (i0 < tiles_per_b) m = fmaxf(m, am[i0]);
+                    if (i1 < tiles_per_b && i1 != i0) m = fmaxf(m, am[i1]);
+                }
+                s_dp = wn_pow2_scale(m, 14);
+            }
             WN_PRIO(WN_PRIO_MFMA);
             // The tap products are accumulated FROM ZERO and the residual input dX_{l+1} is added once, in fp32 VALU
             // arithmetic, after the last tap.  (Round 2 loaded it straight into the accumulators as their initial value, which
@@ -2090,7 +2222,14 @@ __global__ __launch_bounds__(WN_LB) void k_chain64s(ChainArgs a) {
                 e0[1][r] = wn_buf_load_once(Ssr, vcur, so);
                 e1[1][r] = wn_buf_load_once(Gsr, vcur, so);
             }
-            if (have_res) {
+            if constexpr (H16) {   // accumulators -> true values (the inverse scales are powers of two), then the residual
+                const float inv = inv_wd / s_dp;
+                WN_UNROLL
+                for (int qq = 0; qq < 2; ++qq) {
+                    WN_UNROLL
+                    for (int r = 0; r < 16; ++r) acc[qq][r] = have_res ? fmaf(acc[qq][r], inv, rx[qq][r]) : acc[qq][r] * inv;
+                }
+            } else if (have_res) {
                 WN_UNROLL
                 for (int qq = 0; qq < 2; ++qq) {
                     WN_UNROLL
@@ -2116,6 +2255,47 @@ __global__ __launch_bounds__(WN_LB) void k_chain64s(ChainArgs a) {
                     }
                 }
             };
+            if constexpr (H16) {
+                // dX operand: its own wave-wide maximum decides the block scale; the skip part dZs (true scale, loaded into dz) is
+                // added by the fma that scales the products back
+                float m = 0.0f;
+                WN_UNROLL
+                for (int qq = 0; qq < 2; ++qq) {
+                    WN_UNROLL
+                    for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(acc[qq][r]));
+                }
+                m = inb ? m : 0.0f;
+                const float s_dx = wn_pow2_scale(wave_reduce_max(m), 14);
+                f32x16 dzm[2];
+                dzm[0] = f32x16_zero();
+                dzm[1] = f32x16_zero();
+                constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};
+                WN_UNROLL
+                for (int kb = 0; kb < 4; ++kb) {
+                    float x8[8];
+                    WN_UNROLL
+                    for (int e = 0; e < 8; ++e) x8[e] = inb ? acc[kb >> 1][8 * (kb & 1) + e] : 0.0f;
+                    wn_f4 bf[2];
+                    split8h(x8, s_dx, bf);
+                    wn_f4 af[2][2];
+                    WN_UNROLL
+                    for (int rt = 0; rt < 2; ++rt) {
+                        WN_UNROLL
+                        for (int p = 0; p < 2; ++p) af[rt][p] = *reinterpret_cast<const wn_f4*>(Wr + kb * BLKB + vfrag + p * PCB + rt * 1024);
+                    }
+                    WN_UNROLL
+                    for (int t3 = 0; t3 < 3; ++t3) {
+                        dzm[0] = mfma_f16(af[0][PA[t3]], bf[PB[t3]], dzm[0]);
+                        dzm[1] = mfma_f16(af[1][PA[t3]], bf[PB[t3]], dzm[1]);
+                    }
+                }
+                const float invz = inv_wr / s_dx;
+                WN_UNROLL
+                for (int qq = 0; qq < 2; ++qq) {
+                    WN_UNROLL
+                    for (int r = 0; r < 16; ++r) dz[qq][r] = fmaf(dzm[qq][r], invz, dz[qq][r]);
+                }
+            } else {
             wn_f4 afr[2][2][3];
             res_frags(0, afr[0]);
             WN_UNROLL
@@ -2132,6 +2312,7 @@ __global__ __launch_bounds__(WN_LB) void k_chain64s(ChainArgs a) {
                     dz[0] = mfma_bf16(afr[kb & 1][0][PA[t6]], bf[PB[t6]], dz[0]);
                     dz[1] = mfma_bf16(afr[kb & 1][1][PA[t6]], bf[PB[t6]], dz[1]);
                 }
+            }
             }
             WN_SCHED_BARRIER();
             // the next tile's first operand chunks go out before this tile's stores (vmcnt counts loads and stores in order)
@@ -2165,6 +2346,8 @@ __global__ __launch_bounds__(WN_LB) void k_chain64s(ChainArgs a) {
             const int l16 = li & 15;
             const int h16 = (((tile - b * tiles_per_b) * 32) >> 4) + (li >> 4);
             float qsum = 0.0f;
+            float pmax = 0.0f;
+            (void)pmax;
             WN_UNROLL
             for (int q = 0; q < 2; ++q) {
                 float ga[16], gg[16];
@@ -2181,6 +2364,7 @@ __global__ __launch_bounds__(WN_LB) void k_chain64s(ChainArgs a) {
                     const float dpa = dzv * g * (s * (1.0f - s)), dpg = dzv * s * (1.0f - g * g);
                     wn_buf_store(Or, dpa, vst, so);   // lanes past T: out-of-range offset, dropped (no branch per element)
                     wn_buf_store(Or, dpg, vst, so + 64 * T4);
+                    if (H16) pmax = fmaxf(pmax, fmaxf(fabsf(dpa), fabsf(dpg)));
                     qsum += dpa * ga[r] + dpg * gg[r];
                     const float ra = wn_row16_sum(wj * dpa), rg = wn_row16_sum(wj * dpg);
                     keep_a = (l16 == r) ? ra : keep_a;
@@ -2194,16 +2378,28 @@ __global__ __launch_bounds__(WN_LB) void k_chain64s(ChainArgs a) {
             }
             qsum += __shfl_xor(qsum, 32, 64);
             if (hi == 0 && inb) a.qp[(long)b * T + t] = qsum;
+            if (H16 && a.amaxPm != nullptr) {
+                pmax = wave_reduce_max(pmax);
+                if (lane == 0) a.amaxPm[(long)b * tiles_per_b + (tile - b * tiles_per_b)] = pmax;
+            }
         } else {
+            float pmax = 0.0f;
+            (void)pmax;
             WN_UNROLL
             for (int q = 0; q < 2; ++q) {
                 WN_UNROLL
                 for (int r = 0; r < 16; ++r) {
                     const int so = (32 * q + mfma32_row(r, 0)) * T4;
-                    const float s = e0[q][r], g = a.gz ? e1[q][r] * wn_rcp(e0[q][r]) : e1[q][r], dzv = dz[q][r];
-                    wn_buf_store(Or, dzv * g * (s * (1.0f - s)), vst, so);
-                    wn_buf_store(Or, dzv * s * (1.0f - g * g), vst, so + 64 * T4);
+                    const float s = e0[q][r], g = a.gz ? e1[q][r] * wn_rcp(e0[q][r]) : e1[q][r], dzv = H16 ? (inb ? dz[q][r] : 0.0f) : dz[q][r];
+                    const float dpa = dzv * g * (s * (1.0f - s)), dpg = dzv * s * (1.0f - g * g);
+                    wn_buf_store(Or, dpa, vst, so);
+                    wn_buf_store(Or, dpg, vst, so + 64 * T4);
+                    if (H16) pmax = fmaxf(pmax, fmaxf(fabsf(dpa), fabsf(dpg)));
                 }
+            }
+            if (H16 && a.amaxPm != nullptr) {
+                pmax = wave_reduce_max(pmax);
+                if (lane == 0) a.amaxPm[(long)b * tiles_per_b + (tile - b * tiles_per_b)] = pmax;
             }
         }
         tile_v = next_v;
@@ -2217,7 +2413,7 @@ int wn_fused_chain_supported(int R, int K, int S) {
 int wn_fused_bwd_chain(const float* wd_b, const float* dP, const float* dXn, float* dX, const float* wres_prev, const float* dZs,
                        long zs_bstride, const float* S, const float* Gt, int gt_is_z, float* dP_prev, const float* G, long g_bstride,
                        const float* upw, int U, int F, float* dGp, float* qp, int B, int T, int K, int dilation,
-                       const float* img_taps, const float* img_res, int zs_t0, wn_stream_t st) {
+                       const float* img_taps, const float* img_res, int zs_t0, const float* amaxP, float* amaxPm, wn_stream_t st) {
     // dP (, dXn), dZs, S, Gt in; dX, dP_prev out (+ dGp 8 / qp 1 words per timestep with the aux partials)
     const bool aux = dGp != nullptr;
     WN_PROF("fused_bwd_chain", 2.0 * (double)B * T * 64.0 * (K * 128.0 + 64.0),
@@ -2231,8 +2427,29 @@ int wn_fused_bwd_chain(const float* wd_b, const float* dP, const float* dXn, flo
     a.wres = wres_prev; a.dZs = dZs; a.zs_bstride = zs_bstride; a.zs_t0 = zs_t0; a.S = S; a.Gt = Gt; a.gz = gt_is_z; a.dPm = dP_prev;
     a.B = B; a.T = T; a.K = K; a.dil = dilation;
     a.G = G; a.g_bstride = g_bstride; a.upw = upw; a.U = U; a.F = F; a.dGp = dGp; a.qp = qp;
+    a.amaxP = amaxP; a.amaxPm = amaxPm;
     const long ntiles = (long)B * ((T + 31) / 32);
     const long nblk = balanced_blocks(ntiles);
+    if (amaxP != nullptr) {   // fp16 pair split: img_taps / img_res are the two-piece images (wn_fused_pack_images16)
+        if (!img_taps || !img_res) return 1;
+        const size_t lds16 = (size_t)(K * 8 + 4) * 4096;
+#define WN_CHAIN_LAUNCH16(AUXV, KV)                                                                               \
+    do {                                                                                                          \
+        if (set_lds(k_chain64s<AUXV, KV, false, true>, lds16)) return 1;                                          \
+        WN_LAUNCH((k_chain64s<AUXV, KV, false, true>), dim3((unsigned)nblk), dim3(WN_FT), lds16, st, a);          \
+    } while (0)
+        if (aux) {
+            if (K == 1) WN_CHAIN_LAUNCH16(1, 1);
+            else if (K == 2) WN_CHAIN_LAUNCH16(1, 2);
+            else WN_CHAIN_LAUNCH16(1, 3);
+        } else {
+            if (K == 1) WN_CHAIN_LAUNCH16(0, 1);
+            else if (K == 2) WN_CHAIN_LAUNCH16(0, 2);
+            else WN_CHAIN_LAUNCH16(0, 3);
+        }
+#undef WN_CHAIN_LAUNCH16
+        return 0;
+    }
     const size_t lds = (size_t)(K * 8 + (K >= 3 ? 0 : 4)) * 6144;
 #define WN_CHAIN_LAUNCH(AUXV, KV)                                                                       \
     do {                                                                                                \
@@ -2255,7 +2472,7 @@ int wn_fused_bwd_chain(const float* wd_b, const float* dP, const float* dXn, flo
 // Top of the chain: dP_{L-1} = gate'(dZs_{L-1}) (k_chain64s<AUX, K, true>: no weights, no LDS, the epilogue only)
 int wn_fused_bwd_chain_head(const float* dZs, long zs_bstride, const float* S, const float* Gt, int gt_is_z, float* dP_prev,
                             const float* G, long g_bstride, const float* upw, int U, int F, float* dGp, float* qp, int B, int T,
-                            int zs_t0, wn_stream_t st) {
+                            int zs_t0, float* amaxPm, wn_stream_t st) {
     const bool aux = dGp != nullptr;
     WN_PROF("fused_bwd_gate", 0.0, 4.0 * (double)B * T * (64.0 + 128.0 + 128.0 + (aux ? 9.0 : 0.0)), st);
     if (aux && (U < 16 || (U & 15) || (T & 15) || (long)U * F != T)) return 1;
@@ -2264,11 +2481,17 @@ int wn_fused_bwd_chain_head(const float* dZs, long zs_bstride, const float* S, c
     a.dZs = dZs; a.zs_bstride = zs_bstride; a.zs_t0 = zs_t0; a.S = S; a.Gt = Gt; a.gz = gt_is_z; a.dPm = dP_prev;
     a.B = B; a.T = T; a.K = 1; a.dil = 1;
     a.G = G; a.g_bstride = g_bstride; a.upw = upw; a.U = U; a.F = F; a.dGp = dGp; a.qp = qp;
+    a.amaxP = nullptr; a.amaxPm = amaxPm;
     const long ntiles = (long)B * ((T + 31) / 32);
     long nblk = (ntiles + WN_FW - 1) / WN_FW;   // one tile per wave up to 1024 workgroups (HBM-bound, nothing to amortise)
     if (nblk > 1024) nblk = 1024;
     if (nblk >= 8) nblk &= ~7L;                 // whole XCD rounds for the tile walk
-    if (aux)
+    if (amaxPm != nullptr) {   // the fp16 pair chain follows: also record max |dP| per tile
+        if (aux)
+            WN_LAUNCH((k_chain64s<1, 1, true, true>), dim3((unsigned)nblk), dim3(WN_FT), 0, st, a);
+        else
+            WN_LAUNCH((k_chain64s<0, 1, true, true>), dim3((unsigned)nblk), dim3(WN_FT), 0, st, a);
+    } else if (aux)
         WN_LAUNCH((k_chain64s<1, 1, true>), dim3((unsigned)nblk), dim3(WN_FT), 0, st, a);
     else
         WN_LAUNCH((k_chain64s<0, 1, true>), dim3((unsigned)nblk), dim3(WN_FT), 0, st, a);

@@ -752,9 +752,12 @@ int wn_gemm6_launch(const WnGemm6Args* gp, wn_stream_t st) {
         // (K <= 512: the post-net and the all-layer skip gradient, 16 steps per block), where a block's prologue and epilogue
         // are a third of its life; measured on MI355X (profiles/r02/ab_probe_loss_window_stagger.txt): bwd_post{1,2}_dx
         // 0.172 -> 0.147 ms each, while the long skip-sum (120 steps per block) only pays for the late start (+0.04 ms).
-        const int pct = 50;
-        // ~4000 cycles per 16-k step with two blocks per CU; one s_sleep(127) = 8128 cycles
-        g.stagger = g.K <= 512 ? (int)(((long)pct * ((g.K + 15) / 16) * 4000L) / (100L * 8128L)) : 0;
+        static int pct_env = -1;   // WN_G6_STAGGER_PCT: A/B knob
+        if (pct_env < 0) { const char* e = getenv("WN_G6_STAGGER_PCT"); pct_env = e ? atoi(e) : 50; }
+        const int pct = pct_env;
+        // ~4000 cycles per 16-k step with two blocks per CU (six products; ~2000 with the three of the fp16 pair split); one
+        // s_sleep(127) = 8128 cycles
+        g.stagger = g.K <= 512 ? (int)(((long)pct * ((g.K + 15) / 16) * (g.f16 ? 2000L : 4000L)) / (100L * 8128L)) : 0;
     }
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.nbatch <= 0) return 1;
     if (g.b_seg_len < g.K && (g.b_seg_len % 16) != 0) return 2;

@@ -45,9 +45,12 @@ from . import _lib
 # step 9.21 -> 8.72 ms (fwd_skip_sum 0.68 -> 0.43, bwd_dz_skip_all 0.80 -> 0.62; profiles/r06/abk_mm_f16.txt).  Gates on the
 # benchmark's own instance against the reference module (tests/test_gpu_fullsize.py, bench.py `parity`): logits 4.9e-6 (six
 # products 5.5e-6), worst gradient 8.3e-6 (8.2e-6); against the fp64 evaluation of the same step the worst gradient is 6.2e-6 --
-# closer than the reference's own fp32 step (8.3e-6; profiles/r06/adam_gate_study.txt).  The fused 64-channel kernels keep six
-# products.
-DEFAULT_FLAGS = _lib.FLAG_AUX_FUSED | _lib.FLAG_DW_F16PAIR | _lib.FLAG_MM_F16PAIR
+# closer than the reference's own fp32 step (8.3e-6; profiles/r06/adam_gate_study.txt).
+# WN_FLAG_FUSED_F16PAIR (round 6, DEFAULT): the fused 64-channel FORWARD block (taps, gate, res 1x1: k_resblock_fwd_h) on the same
+# split, block-scaled -- every weight image and every 64 x 32 operand tile by the power of two that puts its maximum at 2^12 /
+# 2^14, so no magnitude leaves fp16's range and no redo exists.  Same box: 8.64 -> 8.43 ms per step (forward blocks 1.79 -> 1.55 ms,
+# profiles/r06/abk_fused_f16.txt).  The backward data chain (k_chain64s) keeps six bf16 products.
+DEFAULT_FLAGS = _lib.FLAG_AUX_FUSED | _lib.FLAG_DW_F16PAIR | _lib.FLAG_MM_F16PAIR | _lib.FLAG_FUSED_F16PAIR
 SIX_PRODUCT_FLAGS = DEFAULT_FLAGS & ~_lib.NARROW_FLAGS   # every contraction fp32-equivalent (six bf16 products)
 
 
@@ -330,7 +333,7 @@ class WaveNetEngine(object):
         if t_first is None:
             t_first = self._fwd_window
         flags = self.flags
-        family = _lib.FLAG_NO_FUSED | _lib.FLAG_EXACT_MFMA | _lib.FLAG_MM_F16PAIR
+        family = _lib.FLAG_NO_FUSED | _lib.FLAG_EXACT_MFMA | _lib.FLAG_MM_F16PAIR | _lib.FLAG_CHAIN_F16PAIR
         if (flags ^ self._fwd_flags) & family and not repack:
             raise _lib.WnError("engine.flags changed the kernel family (NO_FUSED / EXACT_MFMA / MM_F16PAIR) since the forward call: "
                                "the families save different activations and weight sets -- run forward again")

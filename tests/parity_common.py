@@ -210,14 +210,13 @@ def run_fullsize_vs_oracle(cfg_tuple, B, T, seed, lib, device, flag_sets, scale=
         worst_x = max(worst_x, e)
         assert e <= TOL_LOGITS, "layer %d input max-abs err %g" % (l, e)
     out["layer_inputs"] = worst_x
-    del inter
     out["grads"] = {}
     out["forward_modes"] = {}
     fwd_flags = flag_sets[0]
     for flags in flag_sets:
         eng.flags = flags
-        if (flags ^ fwd_flags) & _lib.FLAG_MM_F16PAIR:
-            # a flag set that changes the FORWARD arithmetic (WN_FLAG_MM_F16PAIR: the split contractions by the fp16 pair split):
+        if (flags ^ fwd_flags) & (_lib.FLAG_MM_F16PAIR | _lib.FLAG_FUSED_F16PAIR | _lib.FLAG_CHAIN_F16PAIR):
+            # a flag set that changes the FORWARD arithmetic (WN_FLAG_MM_F16PAIR / _FUSED_F16PAIR: contractions by the fp16 pair split):
             # its own forward against the same oracle run -- logits, loss -- and its backward under the SAME sub-gradient choice as
             # the oracle's masks: elements whose ReLU sign differs from the first forward's are genuine ties (asserted: within 1e-5
             # of the kink) and take the first forward's choice
@@ -227,6 +226,13 @@ def run_fullsize_vs_oracle(cfg_tuple, B, T, seed, lib, device, flag_sets, scale=
             del lg2
             loss2, dl = eng.forward_loss(xd, hd, td)
             assert abs(float(loss2.cpu()) - float(loss_ref)) <= TOL_LOSS
+            X2 = eng.saved(_lib.WS_X)
+            worst_x2 = 0.0
+            for l in range(len(cfg.dilations)):
+                ref_x = inter["x0"] if l == 0 else inter["layer_out"][l - 1]
+                e_x = float((X2[l].cpu() - ref_x).abs().max())
+                worst_x2 = max(worst_x2, e_x)
+                assert e_x <= TOL_LOGITS, "layer %d input max-abs err %g (flags %d)" % (l, e_x, flags)
             flips = 0
             for kind, m in ((_lib.WS_RELU_SKIP, m_skip), (_lib.WS_RELU_POST1, m_post)):
                 sv = eng.saved(kind)[:, :, rf:]
@@ -237,7 +243,8 @@ def run_fullsize_vs_oracle(cfg_tuple, B, T, seed, lib, device, flag_sets, scale=
                     assert float(sv[differ].abs().max()) <= 1e-5
                     sv[differ] = torch.where(md[differ], torch.full_like(sv[differ], 1e-30), torch.zeros_like(sv[differ]))
                 flips += n
-            out["forward_modes"][flags] = {"logits": e_lg, "loss": abs(float(loss2.cpu()) - float(loss_ref)), "kink_ties_vs_first_forward": flips}
+            out["forward_modes"][flags] = {"logits": e_lg, "loss": abs(float(loss2.cpu()) - float(loss_ref)), "layer_inputs": worst_x2,
+                                           "kink_ties_vs_first_forward": flips}
             fwd_flags = flags
         grads = flat_to_state(eng, eng.backward(dl, t_first=eng.receptive_field).cpu(), O.param_shapes(cfg))   # the training step's call (loss window)
         worst, worst_k = 0.0, None

@@ -315,7 +315,7 @@ def test_backward_chain_kernel_modes():
     from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS, WaveNetEngine, load_state_into_flat
     A, NC = _lib.FLAG_AUX_FUSED, _lib.FLAG_NO_CHAIN
     # chain + aux partials (+ the fp16 pair split of the weight gradients and of the k_gemm6 contractions) is what every default-flag test runs
-    assert DEFAULT_FLAGS == A | _lib.FLAG_DW_F16PAIR | _lib.FLAG_MM_F16PAIR
+    assert DEFAULT_FLAGS == A | _lib.FLAG_DW_F16PAIR | _lib.FLAG_MM_F16PAIR | _lib.FLAG_FUSED_F16PAIR
     for flags in (0, A, NC, A | NC):
         PC.check_golden_case(GoldenCase("r64_k2_up"), emu_library(), "cpu", flags=flags)
     PC.run_oracle_vs_engine((64, 6, 64, 32, 3, 1, 1, 16), 2, 48, 41, emu_library(), "cpu", flags=A, scale=0.2)   # K = 1
@@ -1052,3 +1052,38 @@ def test_fused_forward_block_on_the_block_scaled_fp16_pair_split():
         got = eng.forward(g.x, g.h).transpose(1, 2)
         assert bool(torch.isfinite(got).all())
         assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max())), mag
+
+
+def test_backward_chain_on_the_block_scaled_fp16_pair_split():
+    """WN_FLAG_CHAIN_F16PAIR (csrc/wn_fused.hip k_chain64s<.., H16>): the fused backward data chain with two fp16 pieces per
+    operand and three products; weight images, the dP operand of every tile (by the per-tile maxima the producing launch
+    recorded) and the dX operand (by its own maximum) scaled by powers of two.  Golden gradients (kernel_size 2 and 3, with and
+    without the aux partial sums), the oracle on a half-full last tile and kernel_size 1, against six products within 2e-6 of the
+    largest gradient, and MAGNITUDES: the same loss scaled by 2^-60 and by 2^+40 gives the same gradients times that factor
+    (nothing leaves fp16's range, nothing is flushed)."""
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd import _lib
+    from pytorchwavenetvocoder_amd.engine import SIX_PRODUCT_FLAGS, WaveNetEngine, load_state_into_flat
+    F = SIX_PRODUCT_FLAGS | _lib.FLAG_CHAIN_F16PAIR
+    for name in ("r64_k2_up", "r64_k3_up"):
+        PC.check_golden_case(GoldenCase(name), emu_library(), "cpu", flags=F)
+    PC.check_golden_case(GoldenCase("r64_k2_up"), emu_library(), "cpu", flags=F & ~_lib.FLAG_AUX_FUSED)
+    PC.check_golden_case(GoldenCase("r64_k2_up"), emu_library(), "cpu", flags=F | _lib.FLAG_FUSED_F16PAIR | _lib.FLAG_MM_F16PAIR | _lib.FLAG_DW_F16PAIR)
+    PC.run_oracle_vs_engine((64, 6, 64, 32, 3, 1, 1, 16), 2, 48, 41, emu_library(), "cpu", flags=F, scale=0.2)   # K = 1
+    PC.run_oracle_vs_engine((64, 6, 64, 32, 2, 2, 2, 16), 3, 80, 42, emu_library(), "cpu", flags=F, scale=0.2)   # T % 32 == 16
+    g = GoldenCase("r64_k2_up")
+    eng = WaveNetEngine(*g.cfg.as_tuple(), device="cpu", library=emu_library())
+    load_state_into_flat(eng, g.params)
+    res = {}
+    for name, flags in (("six", SIX_PRODUCT_FLAGS), ("f16", F)):
+        eng.flags = flags
+        loss, dl = eng.forward_loss(g.x, g.h, g.t)
+        res[name] = eng.backward(dl).clone()
+    scale = float(res["six"].abs().max())
+    err = float((res["f16"] - res["six"]).abs().max()) / scale
+    assert 0.0 < err <= 2e-6, err
+    for e in (-60, 40):
+        loss, dl = eng.forward_loss(g.x, g.h, g.t, grad_scale=2.0 ** e)
+        got = eng.backward(dl).clone() * 2.0 ** -e
+        assert bool(torch.isfinite(got).all())
+        assert float((got - res["six"]).abs().max()) / scale <= 2e-6, e

@@ -26,6 +26,14 @@ def _lib():
     return lib
 
 
+def _extra_flag_sets():
+    """WN_TEST_CHAIN16=1: also the default with WN_FLAG_CHAIN_F16PAIR toggled (A/B visits of an opt-in / newly adopted mode)"""
+    import os
+    from pytorchwavenetvocoder_amd import _lib as L
+    from pytorchwavenetvocoder_amd.engine import DEFAULT_FLAGS
+    return [DEFAULT_FLAGS ^ L.FLAG_CHAIN_F16PAIR] if os.environ.get("WN_TEST_CHAIN16") else []
+
+
 TOL_GRAD_3PRODUCT = 3e-5   # gate of the opt-in 3-product weight gradients (WN_FLAG_DW_3PRODUCT): tighter than the 1e-4 of every mode
 
 
@@ -59,13 +67,14 @@ def test_cfg2_full_size_vs_oracle():
     SIX = DEFAULT_FLAGS & ~L.NARROW_FLAGS
     res = PC.run_fullsize_vs_oracle(cfg_t, 8, 23040, 101, _lib(), DEV,
                                     flag_sets=[SIX, SIX ^ L.FLAG_AUX_FUSED, SIX | L.FLAG_NO_CHAIN, SIX | L.FLAG_DW_3PRODUCT,
-                                               SIX | L.FLAG_DW_F16PAIR, DEFAULT_FLAGS],
+                                               SIX | L.FLAG_DW_F16PAIR, DEFAULT_FLAGS] + _extra_flag_sets(),
                                     scale=0.05)
     _three_product_gate("cfg2 FULL SIZE", res, SIX | L.FLAG_DW_3PRODUCT)
     _f16pair_gate("cfg2 FULL SIZE", res, SIX | L.FLAG_DW_F16PAIR)
     print("cfg2 FULL SIZE (B=8, T=23040) vs oracle: logits %.3g, loss %.3g, layer inputs %.3g, grads %s; "
-          "%d ReLU inputs within 1e-5 of the kink, %d sub-gradient choices differing from the oracle's sign"
-          % (res["logits"], res["loss"], res["layer_inputs"], res["grads"], res["near_kink_1e-5"], res["kink_flips"]))
+          "%d ReLU inputs within 1e-5 of the kink, %d sub-gradient choices differing from the oracle's sign; forward of the default "
+          "arithmetic (fp16 pair split in the fused forward block and on k_gemm6): %s"
+          % (res["logits"], res["loss"], res["layer_inputs"], res["grads"], res["near_kink_1e-5"], res["kink_flips"], res["forward_modes"]))
 
 
 def test_cfg2_full_size_bucketed_backward_matches_single_group():
@@ -122,7 +131,7 @@ def test_config4_stated_size_vs_oracle():
     assert O.batch_geometry(6139, 20000, 256)["T"] == 26112
     from pytorchwavenetvocoder_amd import _lib as L
     SIX = DEFAULT_FLAGS & ~L.NARROW_FLAGS
-    res = PC.run_fullsize_vs_oracle(cfg_t, 8, 26112, 111, _lib(), DEV, flag_sets=[SIX, SIX | L.FLAG_DW_3PRODUCT, SIX | L.FLAG_DW_F16PAIR, DEFAULT_FLAGS], scale=0.05)
+    res = PC.run_fullsize_vs_oracle(cfg_t, 8, 26112, 111, _lib(), DEV, flag_sets=[SIX, SIX | L.FLAG_DW_3PRODUCT, SIX | L.FLAG_DW_F16PAIR, DEFAULT_FLAGS] + _extra_flag_sets(), scale=0.05)
     _three_product_gate("configs[3] STATED SIZE", res, SIX | L.FLAG_DW_3PRODUCT)
     _f16pair_gate("configs[3] STATED SIZE", res, SIX | L.FLAG_DW_F16PAIR)
     print("configs[3] STATED SIZE (K=3, U=256, B=8, T=26112) vs oracle: logits %.3g, loss %.3g, layer inputs %.3g, grads %s, "

@@ -92,3 +92,31 @@ def test_two_ranks_on_one_gpu_through_the_cuda_reducer(tmp_path):
     opt.step()
     torch.cuda.synchronize()
     assert float((model.engine.flat_params.cpu() - r0["params"]).abs().max()) <= 1e-2 * 1e-3
+
+
+def test_train_cli_with_eight_ranks_on_one_gpu(tmp_path):
+    """``train.py --n_gpus 8`` (reference flag train.py:388-389; there: nn.DataParallel over 8 devices, :449-454) as EIGHT
+    processes: the argument path, the rendezvous, the slicer's window sharding with UNEVEN shards (batch_size 11 over 8 ranks:
+    three ranks own two windows, five own one), the weighted loss, the bucketed exchange, identical Adam steps and rank 0's
+    checkpoints.  The pool's boxes have one GPU, so the ranks share it and rendezvous over gloo (WN_TRAIN_BACKEND=gloo: the
+    all-reduce of CUDA tensors stages through the host); everything above the transport is what an 8-GPU node runs."""
+    import subprocess
+    import sys
+    import numpy as np
+    from tests.test_train_cli import make_corpus
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    wavs, feats, stats = make_corpus(str(tmp_path), n=12)
+    (tmp_path / "wav.scp").write_text("\n".join(wavs) + "\n")
+    (tmp_path / "feats.scp").write_text("\n".join(feats) + "\n")
+    expdir = str(tmp_path / "exp")
+    env = dict(os.environ, WN_TRAIN_BACKEND="gloo", PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "wavenet_vocoder.bin.train", "--waveforms", str(tmp_path / "wav.scp"), "--feats", str(tmp_path / "feats.scp"),
+           "--stats", stats, "--expdir", expdir, "--feature_type", "melspc", "--n_aux", "7", "--n_resch", "64", "--n_skipch", "32",
+           "--dilation_depth", "3", "--dilation_repeat", "1", "--upsampling_factor", "80", "--batch_length", "400", "--batch_size", "11",
+           "--iters", "6", "--intervals", "3", "--checkpoint_interval", "3", "--n_gpus", "8", "--verbose", "1"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "(iter:6) average loss" in r.stderr and "final checkpoint created." in r.stderr
+    ck3 = torch.load(os.path.join(expdir, "checkpoint-3.pkl"), weights_only=False)
+    assert ck3["iterations"] == 3 and np.isfinite(float(next(iter(ck3["model"].values())).abs().sum()))
+    assert os.path.exists(os.path.join(expdir, "checkpoint-final.pkl"))
