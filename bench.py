@@ -73,7 +73,7 @@ def products_per_multiply(flags, fused_share):
     dw = DW_PRODUCTS if (flags & (_lib.FLAG_DW_F16PAIR | _lib.FLAG_DW_3PRODUCT)) else SPLIT_PRODUCTS
     ff = DW_PRODUCTS if (flags & _lib.FLAG_FUSED_F16PAIR) else SPLIT_PRODUCTS     # fused FORWARD block; the backward chain keeps six
     fwd = fused_share * ff + (1.0 - fused_share) * mm
-    bwd = fused_share * SPLIT_PRODUCTS + (1.0 - fused_share) * mm
+    bwd = fused_share * (DW_PRODUCTS if (flags & _lib.FLAG_CHAIN_F16PAIR) else SPLIT_PRODUCTS) + (1.0 - fused_share) * mm
     return (fwd + bwd + dw) / 3.0
 LAYERS_PER_BUCKET = 30      # gradient buckets = weight-gradient launch groups; N = 1 runs the SAME launch structure as N > 1.
 # 30 (= all layers of this model, GradientReducer's default) = [post-net + skip] [all residual layers] [front + upsampling]: measured 11.64 vs 11.80 ms/step for groups of 10

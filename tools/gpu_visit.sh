@@ -160,5 +160,11 @@ fi
 if has tworank; then
   WN_BENCH_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 2 --repeats 2 --no-cpu-baseline --no-decode --no-extras > $OUT/bench_2rank_gloo.json 2> $OUT/bench_2rank_gloo.err; echo "2-rank gloo rc=$?"; cut -c1-300 $OUT/bench_2rank_gloo.json
 fi
+if has eightrank; then
+  # world 8 on ONE GPU (functional: the ranks share the device and rendezvous over gloo): bench.py's N = 8 control flow -- eight
+  # processes, three gradient buckets each, the exposed-exchange measurement, the max-over-ranks timing -- and train.py --n_gpus 8
+  WN_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 8 --steps 3 --warmup 1 --repeats 1 --profile-steps 0 --no-cpu-baseline --no-decode --no-extras > $OUT/bench_8rank_gloo.json 2> $OUT/bench_8rank_gloo.err; echo "8-rank gloo rc=$?"; cut -c1-300 $OUT/bench_8rank_gloo.json
+fi
 lscpu | grep -E "Model name|^CPU\(s\)|Socket" > $OUT/host.txt
+free -g | head -2 >> $OUT/host.txt
 echo "elapsed $(( $(date +%s) - $(cat $OUT/t0) )) s"
