@@ -24,7 +24,8 @@ from pmc_summary import summarize  # noqa: E402
 # bench.py tag -> kernel symbol(s) that implement it (the first one present in the trace is reported)
 # (prefixes: the first kernel of the trace that starts with one of them)
 TAGS = {"fused_bwd_gate": ["void k_conv64s<2>", "void k_conv64s<0>"],
-        "fused_resblock_fwd": ["void k_resblock_fwd_s<2", "void k_resblock_fwd_s<3", "void k_resblock_fwd_s<1"],
+        "fused_resblock_fwd": ["void k_resblock_fwd_h<2", "void k_resblock_fwd_h<3", "void k_resblock_fwd_h<1",
+                               "void k_resblock_fwd_s<2", "void k_resblock_fwd_s<3", "void k_resblock_fwd_s<1"],
         "fused_bwd_dx": ["void k_conv64s<1>"],
         "fused_bwd_chain": ["void k_chain64s<1, 2, false", "void k_chain64s<0, 2, false", "void k_chain64s<1, 3, false", "void k_chain64s<1, 1, false",
                             "void k_chain64s<0, 1, false", "void k_chain64s<1, 2>", "void k_chain64s<0, 2>"]}
