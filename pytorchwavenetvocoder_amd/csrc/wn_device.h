@@ -33,6 +33,9 @@ static inline int wn_coop_capacity(Kn, int, size_t) {
     const int o = wn_coop_capacity_override();
     return o >= 0 ? o : 0x7fffffff;
 }
+#define WN_COOP_MAXDEV 64
+template <typename Kn>
+static inline int wn_coop_capacity_cached(int (&)[WN_COOP_MAXDEV], bool&, Kn k, int b, size_t l) { return wn_coop_capacity(k, b, l); }
 #define WN_DYN_SMEM(name) char* name = emu::S().dyn_smem
 static inline f32x16 mfma32(float a, float b, f32x16 c) { return emu::mfma_f32_32x32x2f32(a, b, c); }
 typedef emu::f32x4_t f32x4;
@@ -167,10 +170,29 @@ static inline int wn_coop_capacity(Kn kernel, int block, size_t lds) {
     const int o = wn_coop_capacity_override();
     if (o >= 0) return o;
     int dev = 0, cus = 0, per = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kernel, block, lds) != hipSuccess) return 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kernel, block, lds) != hipSuccess) {
+        (void)hipGetLastError();   // a failed query must not leave a sticky error for the caller's next launch check
+        return 0;
+    }
     return per * cus;
+}
+// The same, cached PER DEVICE (one process may decode on several devices, and a node's devices need not be alike:
+// partitioned GPUs).  `cache` = a static array of WN_COOP_MAXDEV ints initialised to -1 by the caller's first use.
+#define WN_COOP_MAXDEV 64
+template <typename Kn>
+static inline int wn_coop_capacity_cached(int (&cache)[WN_COOP_MAXDEV], bool& init, Kn kernel, int block, size_t lds) {
+    const int o = wn_coop_capacity_override();
+    if (o >= 0) return o;
+    if (!init) {
+        for (int i = 0; i < WN_COOP_MAXDEV; ++i) cache[i] = -1;
+        init = true;
+    }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (dev < 0 || dev >= WN_COOP_MAXDEV) return wn_coop_capacity(kernel, block, lds);
+    if (cache[dev] < 0) cache[dev] = wn_coop_capacity(kernel, block, lds);
+    return cache[dev];
 }
 #define WN_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 static __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {

@@ -616,7 +616,8 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlp(WnDlpArgs a) {
 // LDS attribute (once) and the number of workgroups of this class the device keeps resident (cached; 0: the query failed)
 template <int RS, int NSP, int NSX>
 static int capacity_cls(long lds_bytes) {
-    static int cap = -1;
+    static int cap[WN_COOP_MAXDEV];
+    static bool cap_init = false;
 #ifndef WN_EMU
     static bool attr_set = false;
     if (!attr_set) {
@@ -627,8 +628,7 @@ static int capacity_cls(long lds_bytes) {
     }
 #endif
     if (wn_coop_capacity_override() >= 0) return wn_coop_capacity_override();
-    if (cap < 0) cap = wn_coop_capacity(k_dlp<RS, NSP, NSX>, WN_DLP_T, (size_t)lds_bytes);
-    return cap;
+    return wn_coop_capacity_cached(cap, cap_init, k_dlp<RS, NSP, NSX>, WN_DLP_T, (size_t)lds_bytes);
 }
 
 template <int RS, int NSP, int NSX>

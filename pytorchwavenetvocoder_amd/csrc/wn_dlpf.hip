@@ -476,7 +476,8 @@ static constexpr size_t lds_flags() {
 
 template <int NSP, int NSX>
 static int capacity_flags() {   // as capacity_cls of wn_dlp.hip
-    static int cap = -1;
+    static int cap[WN_COOP_MAXDEV];
+    static bool cap_init = false;
     constexpr size_t lds = lds_flags<NSP, NSX>();
 #ifndef WN_EMU
     static bool attr_set = false;
@@ -488,8 +489,7 @@ static int capacity_flags() {   // as capacity_cls of wn_dlp.hip
     }
 #endif
     if (wn_coop_capacity_override() >= 0) return wn_coop_capacity_override();
-    if (cap < 0) cap = wn_coop_capacity(k_dlpf<NSP, NSX>, WN_DLP_T, lds);
-    return cap;
+    return wn_coop_capacity_cached(cap, cap_init, k_dlpf<NSP, NSX>, WN_DLP_T, lds);
 }
 
 template <int NSP, int NSX>

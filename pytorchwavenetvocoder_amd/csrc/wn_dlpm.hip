@@ -452,7 +452,8 @@ __global__ __launch_bounds__(WN_DLP_T, 2) void k_dlpm(WnDlpArgs a) {
 
 template <int NSP, int NSX>
 static int capacity_wide(long lds_bytes) {   // as capacity_cls of wn_dlp.hip
-    static int cap = -1;
+    static int cap[WN_COOP_MAXDEV];
+    static bool cap_init = false;
 #ifndef WN_EMU
     static bool attr_set = false;
     if (!attr_set) {
@@ -463,8 +464,7 @@ static int capacity_wide(long lds_bytes) {   // as capacity_cls of wn_dlp.hip
     }
 #endif
     if (wn_coop_capacity_override() >= 0) return wn_coop_capacity_override();
-    if (cap < 0) cap = wn_coop_capacity(k_dlpm<NSP, NSX>, WN_DLP_T, (size_t)lds_bytes);
-    return cap;
+    return wn_coop_capacity_cached(cap, cap_init, k_dlpm<NSP, NSX>, WN_DLP_T, (size_t)lds_bytes);
 }
 
 template <int NSP, int NSX>

@@ -2118,10 +2118,31 @@ __global__ __launch_bounds__(WN_LB) void k_chain64s(ChainArgs a) {
         }
     };
 
+    // H16: block scale of a tile's dP operand = the largest |dP_l| over the producer tiles its taps read (shift (K - 1 - tap) d
+    // ahead: at most two tiles each), as the launch that wrote dP_l recorded them.  Looked up together with the tile's first
+    // operand chunks, i.e. a tile ahead: the loads are off the critical path of the tile's first MFMA.
+    auto tile_amax = [&](int tl_v) -> float {
+        const int tl = WN_UNIFORM(tl_v);
+        const int b = tl / tiles_per_b, tb = tl - b * tiles_per_b;
+        const float* am = a.amaxP + (long)b * tiles_per_b;
+        float m = 0.0f;
+        WN_UNROLL
+        for (int tap = 0; tap < K; ++tap) {
+            const int sh = (K - 1 - tap) * a.dil;
+            const int t_lo = tb * 32 + sh, t_hi = t_lo + 31;
+            const int i0 = t_lo >> 5, i1 = t_hi >> 5;
+            if (i0 < tiles_per_b) m = fmaxf(m, am[i0]);
+            if (i1 < tiles_per_b && i1 != i0) m = fmaxf(m, am[i1]);
+        }
+        return m;
+    };
+    float m_tile = 0.0f, m_next = 0.0f;
+    (void)m_tile; (void)m_next;
     int tile_v = walk.first;
     if (!HEAD && tile_v < tile_end) {
         issue(tile_v, 0, xa, oka);
         issue(tile_v, 1, xb, okb);
+        if constexpr (H16) m_next = tile_amax(tile_v);
     }
     while (tile_v < tile_end) {
         const int tile = WN_UNIFORM(tile_v);
@@ -2156,20 +2177,8 @@ __global__ __launch_bounds__(WN_LB) void k_chain64s(ChainArgs a) {
             }
         } else {
             if constexpr (H16) {
-                // block scale of the dP operand: the largest |dP_l| over the producer tiles this tile's taps read (shift
-                // (K - 1 - tap) d ahead: at most two tiles each), as the launch that wrote dP_l recorded them
-                const int tb = tile - b * tiles_per_b;
-                const float* am = a.amaxP + (long)b * tiles_per_b;
-                float m = 0.0f;
-                WN_UNROLL
-                for (int tap = 0; tap < K; ++tap) {
-                    const int sh = (K - 1 - tap) * a.dil;
-                    const int t_lo = tb * 32 + sh, t_hi = t_lo + 31;
-                    const int i0 = t_lo >> 5, i1 = t_hi >> 5;
-                    if (i0 < tiles_per_b) m = fmaxf(m, am[i0]);
-                    if (i1 < tiles_per_b && i1 != i0) m = fmaxf(m, am[i1]);
-                }
-                s_dp = wn_pow2_scale(m, 14);
+                m_tile = m_next;
+                s_dp = wn_pow2_scale(m_tile, 14);   // (looked up a tile ahead: tile_amax above)
             }
             WN_PRIO(WN_PRIO_MFMA);
             // The tap products are accumulated FROM ZERO and the residual input dX_{l+1} is added once, in fp32 VALU
@@ -2319,6 +2328,7 @@ __global__ __launch_bounds__(WN_LB) void k_chain64s(ChainArgs a) {
             if (next_v < tile_end) {
                 issue(next_v, 0, xa, oka);
                 issue(next_v, 1, xb, okb);
+                if constexpr (H16) m_next = tile_amax(next_v);
             }
             {
                 const wn_rsrc_t Xr = wn_make_buf(a.dX + (long)b * 64 * T, (unsigned)(64 * T4));

@@ -594,6 +594,9 @@ class WaveNetEngine(object):
                                                       _ptr(uniforms), _ptr(logits),
                                                       {"argmax": 0, "sampling": 1, "mol": 2}[mode] | mbits,
                                                       _ptr(wave), float(log_scale_min), st)
+                if rc == 4 and eoff >= 0:   # the persistent grid would not be resident at once (the device changed under a cached
+                    # layout, a partitioned GPU): the same fall-back as a time-out
+                    raise _lib.WnDecodeTimeout("the persistent decode launch was refused: its %s" % self.lib.wn_last_error().decode())
                 self.lib.check(rc, "wn_decode_layered_steps")
                 # the persistent launch bounds every wait between its workgroups and reports a time-out in the state; a launch
                 # that finds the word set returns at once, so it is looked at after every chunk (one word, once per chunk)

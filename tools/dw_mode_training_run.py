@@ -58,7 +58,9 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     six = DEFAULT_FLAGS & ~_lib.NARROW_FLAGS
-    modes = [("six", six), ("six_again", six), ("f16", six | _lib.FLAG_DW_F16PAIR), ("bf3", six | _lib.FLAG_DW_3PRODUCT)]
+    # round 6: "default" = fp16 pairs for the weight gradients, the k_gemm6 contractions and the fused forward block (DEFAULT_FLAGS)
+    modes = [("six", six), ("six_again", six), ("f16", six | _lib.FLAG_DW_F16PAIR), ("bf3", six | _lib.FLAG_DW_3PRODUCT),
+             ("default", DEFAULT_FLAGS)]
     res = {n: run(f, a.steps, a.lr, a.batch, a.T, dev) for n, f in modes}
     l6, w6 = res["six"]
     out = {"steps": a.steps, "lr": a.lr, "B": a.batch, "T": a.T, "loss_first": float(l6[0]), "loss_last": float(l6[-1])}
