@@ -1138,6 +1138,13 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_h(FwdArgs a) {
     float* tail = reinterpret_cast<float*>(Wr + 4 * WR_BLK);     // {1 / 2^ew_taps, 1 / 2^ew_res} (+ padding to 64 bytes)
     float* cv = tail + 16;                                       // [128]
     float* rb = cv + 128;                                        // [64]
+#ifdef WN_TIMING
+    if (a.dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
+        a.dbg[((threadIdx.x >> 6) * 4) * 16 + 5] = (long long)__builtin_readcyclecounter();
+        a.dbg[((threadIdx.x >> 6) * 4) * 16 + 7] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+    if (a.dbg && threadIdx.x == 0) a.dbg[512 + blockIdx.x * 4 + 0] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
     copy_image_to_lds(smem_raw, a.wimg, fwd16_image_bytes(K) - 64);   // (a multiple of 1024)
     if (threadIdx.x < 2) tail[threadIdx.x] = a.wimg[(fwd16_image_bytes(K) - 64) / 4 + threadIdx.x];
     if (threadIdx.x < 128) cv[threadIdx.x] = a.cvec[threadIdx.x];
@@ -1145,7 +1152,11 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_h(FwdArgs a) {
     WN_WAIT_VMCNT(0);
     __syncthreads();
     const float inv_wd = tail[0], inv_wr = tail[1];
-
+#ifdef WN_TIMING
+    if (a.dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0)
+        a.dbg[((threadIdx.x >> 6) * 4) * 16 + 6] = (long long)__builtin_readcyclecounter();
+    const int wave = threadIdx.x >> 6;
+#endif
     const int lane = threadIdx.x & 63;
     const int li = lane & 31, hi = lane >> 5;
     const int T = a.T;
@@ -1206,8 +1217,11 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_h(FwdArgs a) {
     };
 
     int tile_v = WN_UNIFORM(walk.first);
+    int tcount = 0;
+    (void)tcount;
     if (K > 1 && tile_v < tile_end) issue_hist(tile_v);
     while (tile_v < tile_end) {
+        WN_STAMP(0);
         const int tile = WN_UNIFORM(tile_v);
         const int b = tile / tiles_per_b;
         const int t = (tile - b * tiles_per_b) * 32 + li;
@@ -1253,6 +1267,7 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_h(FwdArgs a) {
             }
             tap_mfmas(xh[tap], okh[tap], tap, sc);
         }
+        WN_STAMP(1);  // after history-tap MFMAs
         // aux / gate inputs (frame rate, L2 resident), first 32 gate channels
         const int fr = tc / a.U;
         const float upw_j = a.upw[tc - fr * a.U];
@@ -1284,6 +1299,7 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_h(FwdArgs a) {
         const float inv = inv_wd / sc;   // (both powers of two) accumulators -> true pre-activations
         WN_SCHED_BARRIER();
         WN_PRIO(WN_PRIO_GATE);
+        WN_STAMP(2);  // after current-tap MFMAs
         f32x16 xb2[2];
         if (a.Xnext != nullptr) {
             const float* rbl = rb + 4 * hi;
@@ -1332,6 +1348,7 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_h(FwdArgs a) {
         };
         if (keep_g) gate_phase(std::true_type{});
         else gate_phase(std::false_type{});
+        WN_STAMP(3);  // after gate math + S/Gt/Z stores issued
         WN_SCHED_BARRIER();
         WN_PRIO(WN_PRIO_MFMA);
         // res 1x1 + residual; z (in (-1, 1): scaled by 2^13) is consumed straight from the accumulator registers
@@ -1371,8 +1388,23 @@ __global__ __launch_bounds__(WN_LB) void k_resblock_fwd_h(FwdArgs a) {
             }
         }
         WN_PRIO(WN_PRIO_GATE);
+        WN_STAMP(4);  // tile done
+        ++tcount;
         tile_v = next_v;
     }
+#ifdef WN_TIMING
+    if (a.dbg && blockIdx.x == 0 && lane == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        a.dbg[(wave * 4) * 16 + 8] = (long long)__builtin_amdgcn_s_memrealtime();
+        a.dbg[(wave * 4) * 16 + 9] = (long long)__builtin_readcyclecounter();
+    }
+    if (a.dbg && lane == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        if (wave == 0) a.dbg[512 + blockIdx.x * 4 + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+        if (wave == 7) a.dbg[512 + blockIdx.x * 4 + 2] = (long long)__builtin_amdgcn_s_memrealtime();
+        if (wave == 0) a.dbg[512 + blockIdx.x * 4 + 3] = tcount;
+    }
+#endif
 }
 
 template <int K>
