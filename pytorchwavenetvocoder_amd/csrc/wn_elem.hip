@@ -355,9 +355,11 @@ int wn_dw_prepare(float* words, float host_mul, const float* scan, int n_scan, i
     return 0;
 }
 
-__global__ __launch_bounds__(WN_TPB) void k_absmax_rows(const float* __restrict__ p, long ld, int c0, int ncols, float* __restrict__ partial) {
+__global__ __launch_bounds__(WN_TPB) void k_absmax_rows(const float* __restrict__ p, long rows, long ld, int c0, int ncols,
+                                                        float* __restrict__ partial) {
     __shared__ float red[4];
-    const long r = blockIdx.y;
+    for (long r = blockIdx.y; r < rows; r += gridDim.y) {   // (more rows than a grid has y blocks: a block walks several)
+    __syncthreads();
     const int lo = (int)blockIdx.x * 4096, hi = lo + 4096 < ncols ? lo + 4096 : ncols;
     const float* row = p + r * ld + c0;
     float a = 0.0f;
@@ -385,12 +387,14 @@ __global__ __launch_bounds__(WN_TPB) void k_absmax_rows(const float* __restrict_
         for (int i = 1; i < (WN_TPB >> 6); ++i) { const int o = __builtin_bit_cast(int, red[i]); t = o > t ? o : t; }
         partial[r * gridDim.x + blockIdx.x] = __builtin_bit_cast(float, t);
     }
+    }
 }
 
 int wn_absmax_rows(const float* p, long rows, long ld, int c0, int ncols, float* partial, wn_stream_t st) {
     WN_PROF("dw_absmax_scan", 0.0, (double)rows * ncols * 4.0, st);
-    if (rows < 1 || rows > 65535 || ncols < 1) return 1;
-    WN_LAUNCH(k_absmax_rows, dim3((unsigned)((ncols + 4095) / 4096), (unsigned)rows), dim3(WN_TPB), 0, st, p, ld, c0, ncols, partial);
+    if (rows < 1 || ncols < 1) return 1;
+    WN_LAUNCH(k_absmax_rows, dim3((unsigned)((ncols + 4095) / 4096), (unsigned)(rows < 32768 ? rows : 32768)), dim3(WN_TPB), 0, st, p,
+              rows, ld, c0, ncols, partial);
     return 0;
 }
 

@@ -745,6 +745,240 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_gemm6n -- the fp16 pair contraction for SHORT contractions (K <= 512: post-net, the all-layer skip gradient: 16 - 32 k-steps
+// per block).  At 256 x 128 the blocks of k_gemm6 spend two thirds of their life in their prologue (operand latency) and their
+// 128 KB epilogue, two per CU: the matrix pipe idles while a block stores, the store path idles while it contracts
+// (bwd_dz_skip_all: 0.18 ms of MFMA work, 0.28 ms of HBM time, 0.62 ms measured).  Here a block owns 128 x 128 (wave tile 64 x 64:
+// 64 accumulator registers), 32 KB of LDS and <= 168 registers: THREE blocks per CU are in different phases at any time.  Same
+// operand layouts, same pre-split fp16 images (a block takes rows m0 .. m0 + 127 of the [kb][2][Mpad][16] image), same
+// alternating tile signs, same overflow word; plain epilogue only (bias, residual D, relu, mask E): no gate / loss epilogues, no
+// C += result.
+// ---------------------------------------------------------------------------------------------
+#define WN_G6N_BM 128
+__global__ __launch_bounds__(G6_T, 3) void k_gemm6n(WnGemm6Args g, int order) {
+    WN_DYN_SMEM(smem_raw);
+    constexpr int NP = 2;
+    constexpr int A_BYTES = NP * WN_G6N_BM * 32, B_BYTES = NP * WN_G6_BN * 32, ST_BYTES = A_BYTES + B_BYTES;   // 8 + 8 KB per stage
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const WnBlock blk = wn_block_order(order);
+    const int b = WN_UNIFORM(blk.z);
+    const int m0 = WN_UNIFORM(blk.y) * WN_G6N_BM, n0 = WN_UNIFORM(blk.x) * WN_G6_BN;
+    const float* __restrict__ Bz = g.B + (long)b * g.b_zstride;
+    const int nk = (g.K + 15) / 16;
+    const bool one_seg = g.b_seg_len >= g.K;
+    const float fs = ((blk.x + g.n_phase) & 1) ? -1.0f : 1.0f;
+    const float b_mul = g.b_mul < 0.0f ? reinterpret_cast<const float*>(g.ovf)[1] : g.b_mul;
+    const float fsm = fs * b_mul;
+    const float fsc = fs / (b_mul * (float)WN_G6_F16_WSCALE);
+    const wn_rsrc_t Ar = wn_make_buf(g.Apk, (unsigned)((long)nk * NP * g.Mpad * 32));
+    const int wave_u = WN_UNIFORM(wave);
+    float rb0[8], rb1[8];
+    const int bn = tid & 127, bkh = tid >> 7;
+    const bool n_ok = (n0 + bn) < g.N;
+    const int a_voff = (tid >> 1) * 32 + (wn_frag_off(tid >> 1, tid & 1) & 16);
+    const int bkh_u = WN_UNIFORM(bkh);
+    const int seg_rows = one_seg ? nk * 16 : g.b_seg_len;
+    int fb_k0 = 0, fb_seg = 0, fb_rr = 0;
+    auto fetch_a = [&](int kb, int st) {   // 128 rows x 32 bytes per piece = 4 KB = one 16-byte slot per thread
+        char* sa = smem_raw + st * ST_BYTES + wave_u * 1024;
+        const int kc = kb < nk ? kb : nk - 1;
+        WN_UNROLL
+        for (int p = 0; p < NP; ++p)
+            wn_buf_load_lds16(Ar, sa + p * (WN_G6N_BM * 32), a_voff, (unsigned)((kc * NP + p) * g.Mpad + m0) * 32u);
+    };
+    auto advance_b = [&]() {
+        const bool more = fb_k0 + 16 < nk * 16;
+        const bool wrap = fb_rr + 16 >= seg_rows;
+        fb_k0 = more ? fb_k0 + 16 : fb_k0;
+        fb_seg = (more && wrap) ? fb_seg + 1 : fb_seg;
+        fb_rr = more ? (wrap ? 0 : fb_rr + 16) : fb_rr;
+    };
+    auto fetch_b = [&](float (&rb)[8]) {
+        const wn_rsrc_t Br = wn_make_buf(Bz + (long)fb_seg * g.b_seg_stride, (unsigned)((long)(one_seg ? g.K : g.b_seg_len) * g.ldb * 4));
+        const int cc = n0 + bn - (g.b_shift0 + fb_seg * g.b_shift_step);
+        const int voff = (n_ok && cc >= 0 && cc < g.b_clen) ? cc * 4 : 0x7ffffff0;
+        const int rlast = g.K - 1 - (fb_k0 - fb_rr);
+        WN_UNROLL
+        for (int e = 0; e < 8; ++e) {
+            int r = fb_rr + 8 * bkh_u + e;
+            r = r < rlast ? r : rlast;
+            rb[e] = wn_buf_load(Br, voff, r * (int)g.ldb * 4);
+        }
+        advance_b();
+    };
+    auto write_pieces = [&](int st, const unsigned (&h)[4], const unsigned (&md)[4]) {
+        char* sb = smem_raw + st * ST_BYTES + A_BYTES + wn_frag_off(bn, bkh);
+        wn_f4 v;
+        v.x = wn_bits_f32(h[0]); v.y = wn_bits_f32(h[1]); v.z = wn_bits_f32(h[2]); v.w = wn_bits_f32(h[3]);
+        *reinterpret_cast<wn_f4*>(sb) = v;
+        v.x = wn_bits_f32(md[0]); v.y = wn_bits_f32(md[1]); v.z = wn_bits_f32(md[2]); v.w = wn_bits_f32(md[3]);
+        *reinterpret_cast<wn_f4*>(sb + WN_G6_BN * 32) = v;
+    };
+    auto split_pair = [&](int q, const float (&rb)[8], unsigned (&h)[4], unsigned (&md)[4]) {
+        const float x0 = rb[2 * q] * fsm, x1 = rb[2 * q + 1] * fsm;
+        h[q] = wn_pk_f16(x0, x1);
+        md[q] = wn_pk_f16(x0 - wn_f16lo_f32(h[q]), x1 - wn_f16hi_f32(h[q]));
+    };
+    auto stage = [&](int st, const float (&rb)[8]) {
+        unsigned h[4], md[4];
+        WN_UNROLL
+        for (int q = 0; q < 4; ++q) split_pair(q, rb, h, md);
+        write_pieces(st, h, md);
+    };
+    f32x16 acc[2][2];
+    WN_UNROLL
+    for (int i = 0; i < 2; ++i) {
+        acc[i][0] = f32x16_zero();
+        acc[i][1] = f32x16_zero();
+    }
+    // One k-step: 12 MFMAs (2 row tiles x 3 products x 2 column tiles) in 6 pairs; behind pair s:
+    //   0, 1: one LDS-DMA piece of the next weight slab + two activation loads each    2: the other four loads
+    //   3, 4: two pair splits each        5: the two LDS writes of the split pieces
+    auto step = [&](int st, int stn, const float (&rb)[8], float (&rbn)[8], int ka, bool last) {
+        const char* sa = smem_raw + st * ST_BYTES;
+        const char* sb = sa + A_BYTES;
+        unsigned h[4], md[4];
+        wn_f4 bf[NP][2];
+        WN_UNROLL
+        for (int p = 0; p < NP; ++p) {
+            WN_UNROLL
+            for (int j = 0; j < 2; ++j)
+                bf[p][j] = *reinterpret_cast<const wn_f4*>(sb + p * (WN_G6_BN * 32) + wn_frag_off(64 * wn + 32 * j + li, hi));
+        }
+        const wn_rsrc_t Br = wn_make_buf(Bz + (long)fb_seg * g.b_seg_stride, (unsigned)((long)(one_seg ? g.K : g.b_seg_len) * g.ldb * 4));
+        const int cc = n0 + bn - (g.b_shift0 + fb_seg * g.b_shift_step);
+        const int voff = (n_ok && cc >= 0 && cc < g.b_clen) ? cc * 4 : 0x7ffffff0;
+        const int rlast = g.K - 1 - (fb_k0 - fb_rr);
+        char* sda = smem_raw + stn * ST_BYTES + wave_u * 1024;
+        const int kc = ka < nk ? ka : nk - 1;
+        auto load_b = [&](int e) {
+            int r = fb_rr + 8 * bkh_u + e;
+            r = r < rlast ? r : rlast;
+            rbn[e] = wn_buf_load(Br, voff, r * (int)g.ldb * 4);
+        };
+        WN_UNROLL
+        for (int i = 0; i < 2; ++i) {
+            wn_f4 af[NP];
+            WN_UNROLL
+            for (int p = 0; p < NP; ++p)
+                af[p] = *reinterpret_cast<const wn_f4*>(sa + p * (WN_G6N_BM * 32) + wn_frag_off(64 * wm + 32 * i + li, hi));
+            constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};   // small terms first: h l, l h, h h
+            WN_UNROLL
+            for (int t = 0; t < 3; ++t) {
+                WN_UNROLL
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_f16(af[PA[t]], bf[PB[t]][j], acc[i][j]);
+                if (last) continue;
+                const int sl = i * 3 + t;
+                if (sl == 0) {   // the slab BEFORE the activation loads: "at most 8 loads outstanding" == "the slab has landed"
+                    wn_buf_load_lds16(Ar, sda, a_voff, (unsigned)((kc * NP) * g.Mpad + m0) * 32u);
+                    wn_buf_load_lds16(Ar, sda + WN_G6N_BM * 32, a_voff, (unsigned)((kc * NP + 1) * g.Mpad + m0) * 32u);
+                } else if (sl < 3) {
+                    load_b(4 * sl - 4); load_b(4 * sl - 3); load_b(4 * sl - 2); load_b(4 * sl - 1);
+                } else if (sl < 5) {
+                    split_pair(2 * (sl - 3), rb, h, md);
+                    split_pair(2 * (sl - 3) + 1, rb, h, md);
+                } else {
+                    write_pieces(stn, h, md);
+                }
+                WN_SGB_MFMA(1);
+                WN_SGB_VALU(8);
+                WN_SGB_MFMA(1);
+                WN_SCHED_FENCE_ALU();
+            }
+        }
+        if (!last) advance_b();
+    };
+    fetch_a(0, 0);
+    fetch_b(rb0);
+    fetch_b(rb1);
+    stage(0, rb0);
+    WN_WAIT_VMCNT(8);
+    __syncthreads();
+    const int npair = nk >> 1;
+    for (int kp = 0; kp < npair; ++kp) {
+        const int kb = 2 * kp;
+        step(0, 1, rb1, rb0, kb + 1, false);
+        WN_WAIT_VMCNT(8);
+        __syncthreads();
+        step(1, 0, rb0, rb1, kb + 2, false);
+        WN_WAIT_VMCNT(8);
+        __syncthreads();
+    }
+    if (nk & 1) step(0, 1, rb1, rb0, 0, true);
+    WN_WAIT_VMCNT(0);
+    {   // an operand left fp16's range -> the six-product launch behind this one redoes the contraction
+        unsigned nonfinite = 0u;
+        WN_UNROLL
+        for (int i = 0; i < 2; ++i) {
+            WN_UNROLL
+            for (int j = 0; j < 2; ++j) {
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r)
+                    nonfinite |= (~__builtin_bit_cast(unsigned, (float)acc[i][j][r]) & 0x7f800000u) == 0u ? 1u : 0u;
+            }
+        }
+        if (nonfinite) wn_store_coherent_int(g.ovf, 1);
+    }
+    // epilogue: bias, residual, relu, mask.  A lane's rows are m0 + 64 wm + 32 i + (r & 3) + 8 (r >> 2) + 4 hi (all inside M: whole
+    // row blocks only), its columns n0 + 64 wn + 32 j + li: the row part of an address is a wave-uniform scalar offset, a column
+    // past N carries an out-of-range lane offset (loads give 0, stores are dropped)
+    const wn_rsrc_t Cr = wn_make_buf(g.C + (long)b * g.c_zstride, (unsigned)((long)g.M * g.ldc * 4));
+    const wn_rsrc_t Er = wn_make_buf(g.E ? g.E + (long)b * g.e_zstride : g.C, g.E ? (unsigned)((long)g.M * g.lde * 4) : 0u);
+    const wn_rsrc_t Dr = wn_make_buf(g.D ? g.D + (long)b * g.d_zstride : g.C, g.D ? (unsigned)((long)g.M * g.ldd * 4) : 0u);
+    const wn_rsrc_t Biasr = wn_make_buf(g.bias ? g.bias : g.C, g.bias ? (unsigned)(g.M * 4) : 0u);
+    const int rl = m0 + 64 * wm + 4 * hi;
+    WN_UNROLL
+    for (int i = 0; i < 2; ++i) {
+        float bv[16];
+        WN_UNROLL
+        for (int r = 0; r < 16; ++r) bv[r] = 0.f;
+        if (g.bias) {
+            WN_UNROLL
+            for (int r = 0; r < 16; ++r) bv[r] = wn_buf_load(Biasr, (rl + 32 * i) * 4, mfma32_row(r, 0) * 4);
+        }
+        WN_UNROLL
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + 64 * wn + 32 * j + li;
+            const bool cok = col < g.N;
+            const int vC = cok ? ((rl + 32 * i) * (int)g.ldc + col) * 4 : 0x7ffffff0;
+            const int vE = cok ? ((rl + 32 * i) * (int)g.lde + col) * 4 : 0x7ffffff0;
+            const int vD = cok ? ((rl + 32 * i) * (int)g.ldd + col) * 4 : 0x7ffffff0;
+            float ev[16], dv[16];
+            if (g.E) {
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) ev[r] = wn_buf_load(Er, vE, mfma32_row(r, 0) * (int)g.lde * 4);
+            }
+            WN_UNROLL
+            for (int r = 0; r < 16; ++r) dv[r] = 0.f;
+            if (g.D) {
+                WN_UNROLL
+                for (int r = 0; r < 16; ++r) dv[r] = wn_buf_load(Dr, vD, mfma32_row(r, 0) * (int)g.ldd * 4);
+            }
+            WN_SCHED_BARRIER();
+            WN_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][j][r] * fsc;
+                v += bv[r] + dv[r];
+                if (g.relu) v = fmaxf(v, 0.f);
+                if (g.E) v = (ev[r] > 0.f) ? v : 0.f;
+                wn_buf_store(Cr, v, vC, mfma32_row(r, 0) * (int)g.ldc * 4);
+            }
+        }
+    }
+}
+
+// 1: this launch takes k_gemm6n (fp16 pair, short contraction, plain epilogue, whole 128-row blocks)
+static bool gemm6n_applies(const WnGemm6Args& g) {
+    static int on = -1;   // WN_G6_NARROW=0: A/B knob
+    if (on < 0) { const char* e = getenv("WN_G6_NARROW"); on = e ? atoi(e) : 1; }
+    return on && g.f16 && g.K <= 512 && (g.M % WN_G6N_BM) == 0 && !g.ce_target && !g.gate_S && !g.gbw_dP && !g.accumulate && !g.no_interior &&
+           (long)g.M * g.ldc * 4 < 0x7ffffff0L && (!g.E || (long)g.M * g.lde * 4 < 0x7ffffff0L) && (!g.D || (long)g.M * g.ldd * 4 < 0x7ffffff0L);
+}
+
 int wn_gemm6_launch(const WnGemm6Args* gp, wn_stream_t st) {
     WnGemm6Args g = *gp;
     g.no_interior = 0;
@@ -784,7 +1018,11 @@ int wn_gemm6_launch(const WnGemm6Args* gp, wn_stream_t st) {
     WN_PROF(redo ? "mm_redo_if_overflow" : (g.tag ? g.tag : "gemm6"), redo ? 0.0 : 2.0 * g.M * g.N * (double)g.K * g.nbatch,
             redo ? 0.0 : ((double)g.M * g.K * (g.f16 ? 4.0 : 6.0) + (double)g.K * g.N * 4.0 + (double)g.M * g.N * (g.E ? 8.0 : 4.0)) * g.nbatch, st);
     dim3 grid((unsigned)((g.N + WN_G6_BN - 1) / WN_G6_BN), (unsigned)(g.Mpad / WN_G6_BM), (unsigned)g.nbatch);
-    if (g.f16) {
+    if (g.f16 && gemm6n_applies(g)) {
+        constexpr int ldsn = 2 * (2 * WN_G6N_BM * 32 + 2 * WN_G6_BN * 32);
+        dim3 gridn((unsigned)((g.N + WN_G6_BN - 1) / WN_G6_BN), (unsigned)(g.M / WN_G6N_BM), (unsigned)g.nbatch);
+        WN_LAUNCH(k_gemm6n, gridn, dim3(G6_T), ldsn, st, g, xcd_block_order() ? 2 : 0);
+    } else if (g.f16) {
         if (g.ce_target)
             WN_LAUNCH((k_gemm6<true, true>), grid, dim3(G6_T), lds16, st, g, xcd_block_order() ? 2 : 0 G6_DBG_ARG(g.tag));
         else
