@@ -335,6 +335,23 @@ extern "C" int wn_dead_param_range(const WnConfig* cfg, int64_t* lo, int64_t* hi
 struct DwPlan {
     int ksplit, kchunk, nz;
 };
+// Split-K plan of the fused skip + res launch (wn_gemm6.h WnDwSkipRes): one resident round of its workgroups (512 threads, 96 KB
+// of LDS: one per CU)
+static DwPlan dw_skipres_plan(int S, int nl, int Kdim, int nbatch) {
+    const long tiles = (long)(S / 256) * ((nl + 1) / 2) * nbatch;
+    long ks = 256 / (tiles > 0 ? tiles : 1);
+    const long maxks = (Kdim + 255) / 256;
+    if (ks > maxks) ks = maxks;
+    if (ks < 1) ks = 1;
+    int kchunk = (int)((Kdim + ks - 1) / ks);
+    kchunk = (kchunk + 31) / 32 * 32;
+    DwPlan p;
+    p.kchunk = kchunk;
+    p.ksplit = (Kdim + kchunk - 1) / kchunk;
+    if (p.ksplit < 1) p.ksplit = 1;
+    p.nz = p.ksplit * nbatch;
+    return p;
+}
 static DwPlan dw_plan(int M, int N, int Kdim, int nbatch) {
     const int tm = (M + (M > 64 ? 127 : 63)) / (M > 64 ? 128 : 64);
     // column tile width the kernel will use (the 256-row tiles of wn_gemm6_dw_tall always come with 128 columns)
@@ -383,6 +400,7 @@ struct Ws {
     long X, G, Sg, Gt, Z, O1, O2;
     // scratch
     long P, dO2, dSk, dZ, dXall, dG, dw_partial, dc, tmpS, partial, rs_partial, red_scratch, loss_partial;
+    long partial2, rs_partial2;   // res_1x1 partials of the fused skip + res weight-gradient launch (wn_dw_skipres_launch)
     long amax_partial, amax_partial_floats;
     long dw_ovf;   // one word (of 64): raised by an fp16-pair weight-gradient launch whose result was not finite (WN_FLAG_DW_F16PAIR)
     long dGp, qp;  // aux-gradient partials of the gate kernel (WN_FLAG_AUX_FUSED); 0 floats when the mode cannot apply
@@ -486,8 +504,20 @@ static int make_ws(const Dims& d, int B, int T, Ws* w, bool training = true) {
             }
         }
     }
+    long p2max = 0, r2max = 0;
+    for (int nl = 1; nl <= d.L; ++nl) {   // the fused skip + res launch of any bucket size: its own plan for both outputs
+        if (!wn_dw_skipres_supported(d.S, d.R, nl, nl > 1 ? nl - 1 : 1)) continue;
+        const DwPlan p = dw_skipres_plan(d.S, nl, T, B);
+        const long need = (long)p.nz * d.S * d.R * nl, rneed = (long)p.nz * d.S;
+        if (need > pmax) pmax = need;
+        if (rneed > rmax) rmax = rneed;
+        if ((long)p.nz * nl * d.R * d.R > p2max) p2max = (long)p.nz * nl * d.R * d.R;
+        if ((long)p.nz * nl * d.R > r2max) r2max = (long)p.nz * nl * d.R;
+    }
     CARVE(partial, pmax);
     CARVE(rs_partial, rmax);
+    CARVE(partial2, p2max);
+    CARVE(rs_partial2, r2max);
     w->red_scratch_floats = 1 << 20;
     CARVE(red_scratch, w->red_scratch_floats);
     CARVE(loss_partial, 2 * wn_softmax_ce_nblocks(B, T) + 64);   // CE epilogue: one partial per 128-column block

@@ -163,7 +163,12 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
         g.B = ws + w.O1 + t0; g.ldb = T; g.b_zstride = (long)d.S * T; g.b_clen = Tw; g.tag = "dw_post1";
         WN_TRY(dw_gemm(cs, g, dw_out_plain(grads + y.post1_w, d.S, grads + y.post1_b)));
     }
-    {   // d skip_1x1.l.weight for all layers in one contraction; bias = rowsum(dSkip) for every layer
+    // Fused skip + res weight gradients (k_dw_skipres: z of every layer read once instead of twice): with the fp16 pair split on,
+    // the skip gradients wait for the data chain and are produced per bucket together with the res_1x1 gradients.
+    // Only with ONE layer bucket: the skip weights belong to the head bucket (wn_bucket_range), whose event would otherwise be the
+    // last one recorded and hold back the exchange of every layer bucket behind it (distributed.py waits in bucket order).
+    const bool skipres = c.split_bf16 && c.dw_f16_mul != 0.0f && d.L > 1 && lpb >= d.L && wn_dw_skipres_supported(d.S, d.R, d.L, d.L - 1);
+    if (!skipres) {   // d skip_1x1.l.weight for all layers in one contraction; bias = rowsum(dSkip) for every layer
         WnGemmArgs g = wn_gemm_default();
         g.M = d.S; g.N = d.L * d.R; g.K = Tw;
         g.A = ws + w.dSk + t0; g.lda = T; g.a_zstride = (long)d.S * T;
@@ -181,7 +186,7 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
         cp.d0 = 0; cp.d1 = 0; cp.d2 = 1; cp.dl = y.ls_skip;
         WN_TRY(wn_copy4(grads + y.skip0 + (long)d.S * d.R, ws + w.tmpS, &cp, cs.st));
     }
-    if (events) rt_event_record(events[bucket], cs.st);
+    if (events && !skipres) rt_event_record(events[bucket], cs.st);   // (fused skip + res: the head bucket completes with the last flush)
     bucket++;
 
     // ---- residual stack, last layer first (wavenet.py:525-536 reversed) ----
@@ -241,8 +246,58 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
             cp.d1 = y.o_atanh_b - y.o_asig_b;
             WN_TRY(wn_copy4(grads + lb_lo + y.o_asig_b, dc, &cp, c.st));
         }
-        {   // d res_1x1.l = dX_{l+1} . z_l^T ; the last layer's res_1x1 is dead -> zeros
-            const int hi_res = hi < d.L ? hi : d.L - 1;
+        const int hi_res = hi < d.L ? hi : d.L - 1;
+        const bool fuse = skipres && hi_res > lo;   // (a bucket holding only the last layer has no res_1x1 gradient)
+        if (fuse) {
+            // skip_1x1 and res_1x1 of layers [lo, hi) against one read of z; the partial sums land where the two separate launches
+            // put them, so their conditional six-product launches (same split-K plan) and their reductions follow unchanged
+            if (hi == d.L) WN_TRY(wn_fill(grads + layer_base(y, d, d.L - 1) + y.o_res_w, 0.0f, (long)d.R * d.R + d.R, c.st));
+            const DwPlan p = dw_skipres_plan(d.S, nl, T, B);
+            const int n_res = hi_res - lo;
+            WnDwSkipRes a;
+            a.S = d.S; a.nl = nl; a.n_res = n_res; a.K = T; a.nbatch = B; a.ksplit = p.ksplit; a.kchunk = p.kchunk;
+            a.dS = ws + w.dSk; a.ds_ld = T; a.ds_zstride = (long)d.S * T;
+            a.Z = ws + w.Z + (long)lo * BRT; a.z_ld = T; a.z_zstride = (long)d.R * T; a.z_lstride = BRT;
+            a.dX = ws + w.dXall + (long)(lo + 1) * BRT; a.dx_ld = T; a.dx_zstride = (long)d.R * T; a.dx_lstride = BRT;
+            a.Cskip = ws + w.partial; a.Cres = ws + w.partial2;
+            a.rs_skip = hi == d.L ? ws + w.rs_partial : nullptr;   // rowsum(dSkip): once per step, by the first bucket
+            a.rs_res = ws + w.rs_partial2;
+            WN_TRY(wn_dw_skipres_launch(&a, c.dw_f16_mul, c.dw_ovf, c.st));
+            // the redo launches (no work unless the word is up) and the reductions
+            WnGemmArgs gs = wn_gemm_default();
+            gs.M = d.S; gs.N = nl * d.R; gs.K = T;
+            gs.A = a.dS; gs.lda = T; gs.a_zstride = a.ds_zstride;
+            gs.B = a.Z; gs.ldb = T; gs.b_zstride = a.z_zstride; gs.b_clen = T;
+            gs.b_seg_len = d.R; gs.b_seg_stride = BRT; gs.tag = "dw_skip";
+            gs.a_kmajor = 1; gs.b_kmajor = 1; gs.nlayer = 1; gs.nbatch = B; gs.ksplit = p.ksplit; gs.kchunk = p.kchunk;
+            gs.C = a.Cskip; gs.ldc = gs.N; gs.c_zstride = (long)gs.M * gs.N;
+            gs.a_rowsum = a.rs_skip;
+            WN_TRY(wn_gemm6_dw_launch(&gs, 6, 0.0f, c.dw_ovf, c.st));
+            WnGemmArgs gr = wn_gemm_default();
+            gr.M = d.R; gr.N = d.R; gr.K = T;
+            gr.A = a.dX; gr.lda = T; gr.a_zstride = a.dx_zstride; gr.a_lstride = BRT;
+            gr.B = a.Z; gr.ldb = T; gr.b_zstride = a.z_zstride; gr.b_lstride = BRT; gr.b_clen = T; gr.tag = "dw_res";
+            gr.a_kmajor = 1; gr.b_kmajor = 1; gr.nlayer = n_res; gr.nbatch = B; gr.ksplit = p.ksplit; gr.kchunk = p.kchunk;
+            gr.C = a.Cres; gr.ldc = gr.N; gr.c_zstride = (long)gr.M * gr.N;
+            gr.a_rowsum = a.rs_res;
+            WN_TRY(wn_gemm6_dw_launch(&gr, 6, 0.0f, c.dw_ovf, c.st));
+            DwOut o;
+            o.out = grads + y.skip0 + (long)lo * y.ls_skip; o.m_seg = 0x7fffffff; o.m_seg_stride = 0; o.m_stride = d.R;
+            o.n_seg = d.R; o.n_seg_stride = y.ls_skip; o.n_stride = 1;
+            o.addend_m = nullptr; o.addend_scale_ptr = nullptr; o.rowsum_out = a.rs_skip ? ws + w.tmpS : nullptr;
+            o.out_lstride = 0; o.addend_lstride = 0; o.rowsum_lstride = 0;
+            WN_TRY(dw_reduce(c, a.Cskip, a.rs_skip, p.nz, d.S, nl * d.R, o, 1));
+            if (a.rs_skip) {   // skip_1x1.l.bias = rowsum(dSkip) for every layer of the stack
+                WnCopy4 cp;
+                cp.n0 = 1; cp.n1 = 1; cp.n2 = d.S; cp.nl = d.L;
+                cp.s0 = 0; cp.s1 = 0; cp.s2 = 1; cp.sl = 0;
+                cp.d0 = 0; cp.d1 = 0; cp.d2 = 1; cp.dl = y.ls_skip;
+                WN_TRY(wn_copy4(grads + y.skip0 + (long)d.S * d.R, ws + w.tmpS, &cp, c.st));
+            }
+            DwOut r = dw_out_plain(grads + lb_lo + y.o_res_w, d.R, grads + lb_lo + y.o_res_b);
+            r.out_lstride = -y.LB; r.rowsum_lstride = -y.LB;
+            WN_TRY(dw_reduce(c, a.Cres, a.rs_res, p.nz, d.R, d.R, r, n_res));
+        } else {   // d res_1x1.l = dX_{l+1} . z_l^T ; the last layer's res_1x1 is dead -> zeros
             if (hi == d.L) WN_TRY(wn_fill(grads + layer_base(y, d, d.L - 1) + y.o_res_w, 0.0f, (long)d.R * d.R + d.R, c.st));
             if (hi_res > lo) {
                 WnGemmArgs g = wn_gemm_default();
@@ -393,6 +448,7 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
             WN_TRY(flush_bucket(l, bucket_hi));
             bucket_hi = l;
             if (bucket_end) {
+                if (events && skipres && l == 0) rt_event_record(events[0], cl.st);   // head bucket: post-net + every layer's skip_1x1
                 if (events) rt_event_record(events[bucket], cl.st);
                 bucket++;
             }

@@ -129,3 +129,23 @@ int wn_gemm6_dw_tn(int M, int N);            // otherwise: 3 = one 192-column ti
 // *ovf on a non-finite result) -- f16_mul > 0: that power of two; f16_mul < 0: the kernel reads it from ((const float*)ovf)[1],
 // where wn_dw_prepare (wn_elem.h) left it; products 6 with ovf != NULL and f16_mul == 0: conditional redo (works only if *ovf != 0)
 int wn_gemm6_dw_launch(const struct WnGemmArgs* g, int products, float f16_mul, int* ovf, wn_stream_t st);
+
+// Skip + residual 1x1 weight gradients of a run of layers in ONE launch (k_dw_skipres, fp16 pair split only):
+//   dWskip_i[s][c] = sum_{b,t} dS[b][s][t] z_i[b][c][t]        dWres_i[m][c] = sum_{b,t} dX_{i+1}[b][m][t] z_i[b][c][t]
+// Both contract against z_i (64 channels, every position): as two launches z of every layer was read from HBM twice
+// (2 x 1.4 GB of the benchmark's 36 GB per step).  A block takes 256 rows of dS, the 128 z rows of two layers and the 64 dX rows
+// of each of those layers over one k-chunk (one workgroup of 512 threads per CU); partial sums go to the buffers the two separate launches would have filled
+// (same layout, so the conditional six-product redo launches and the reductions behind them are the existing ones):
+//   Cskip[zr][S][64 nl]   Cres[i][zr][64][64]   rs_skip[zr][S] (row sums of dS: column block 0 only)   rs_res[i][zr][64]
+// zr = b * ksplit + ks.  Layers i >= n_res have no live res_1x1 (the last layer of the stack): nothing is stored for them.
+typedef struct WnDwSkipRes {
+    int S, nl, n_res, K;
+    int nbatch, ksplit, kchunk;   // kchunk % 32 == 0
+    const float* dS; long ds_ld, ds_zstride;
+    const float* Z; long z_ld, z_zstride, z_lstride;
+    const float* dX; long dx_ld, dx_zstride, dx_lstride;   // dX + i dx_lstride = the gradient at the OUTPUT of layer i's res_1x1
+    float* Cskip; float* Cres; float* rs_skip; float* rs_res;
+} WnDwSkipRes;
+int wn_dw_skipres_supported(int S, int R, int nl, int n_res);
+// f16_mul / ovf as wn_gemm6_dw_launch (fp16 pair split; *ovf := 1 on a non-finite result)
+int wn_dw_skipres_launch(const WnDwSkipRes* a, float f16_mul, int* ovf, wn_stream_t st);

@@ -1508,6 +1508,307 @@ __global__ __launch_bounds__(G6_T, (TM * TN > 8 ? 1 : (TM * TN > 4 ? 2 : 3))) vo
     if (F16 && nonfinite) wn_store_coherent_int(ovf, 1);
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_dw_skipres8 -- skip_1x1 and res_1x1 weight gradients against ONE read of z (WnDwSkipRes, wn_gemm6.h).  The 256 x 128 tile of
+// k_gemm6_dw<4, 2, 2, true> (dS rows x the z rows of two layers; same split, same alternating sign of the partials) plus the 64 dX
+// rows of each of the two layers as a fifth row tile.  EIGHT waves (4 x 2, wave tile 64 x 64): two per SIMD at <= 256 registers,
+// so that one wave's splits, LDS writes and barrier waits sit under the other's MFMAs -- four waves with 128 x 64 wave tiles
+// needed 346 registers (one wave per SIMD) and took 0.84 - 0.92 ms where this takes 0.80 - 0.83 (the two separate launches:
+// 0.97 - 1.03; profiles/r06/abk_dw_skipres.txt).  The dX row tile goes to the waves wm = 0, 1 (SIMD = wave % 4: each SIMD hosts one
+// wave with and one without it).  A thread stages 4 consecutive k of two dS rows, one z row and one dX row.  No shifted taps, whole
+// 64-row segments: every full 16-position step takes the branch-free pipelined pass; a tile half past the last layer (nl odd)
+// reads the last layer again and stores nothing.
+// ---------------------------------------------------------------------------------------------
+#define WN_SR8_T 512
+__global__ __launch_bounds__(WN_SR8_T) void k_dw_skipres8(WnDwSkipRes g, int order, float a_mul, int* ovf) {
+    constexpr int NP = 2, NPROD = 3, TMW = 2, TN = 2;
+    if (a_mul < 0.0f) a_mul = reinterpret_cast<const float*>(ovf)[1];
+    constexpr int BM = 256, BN = 128;
+    constexpr int AE = 8, BE = 4;               // fp32 elements per thread and step: 4 consecutive k of two dS rows / one z / one dX row
+    constexpr int A_BYTES = NP * BM * 32, B_BYTES = NP * BN * 32, ST_BYTES = A_BYTES + 2 * B_BYTES;   // dS, z, dX
+    WN_DYN_SMEM(smem_raw);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int wm = WN_UNIFORM(wave >> 1), wn = WN_UNIFORM(wave & 1);
+    const bool has_r = wm < 2;
+    const WnBlock blk = wn_block_order(order);
+    const int zr = WN_UNIFORM(blk.z);
+    const int b = zr / g.ksplit;
+    const int ks = zr - b * g.ksplit;
+    const int kbeg = ks * g.kchunk;
+    const int kend = (g.K - kbeg > g.kchunk) ? (kbeg + g.kchunk) : g.K;
+    const int bx = WN_UNIFORM(blk.x);
+    const int m0 = WN_UNIFORM(blk.y) * BM;
+    const int l0 = bx * TN;
+    const bool with_res = blk.y == 0;
+    const int N = 64 * g.nl;
+    const float* __restrict__ Az = g.dS + (long)b * g.ds_zstride;
+    const float* __restrict__ Bz = g.Z + (long)b * g.z_zstride;
+    const float* __restrict__ Rz = g.dX + (long)b * g.dx_zstride;
+
+    const int a_row = tid >> 2, a_k = (tid & 3) * 4;     // dS rows a_row, a_row + 128; tile row a_row of z and dX = row a_row & 63 of layer l0 + (a_row >> 6)
+    long a_off[2], b_off, r_off;
+    a_off[0] = (long)(m0 + a_row) * g.ds_ld;
+    a_off[1] = (long)(m0 + a_row + 128) * g.ds_ld;
+    {
+        const int lt = l0 + (a_row >> 6);
+        const int lb = lt < g.nl ? lt : g.nl - 1;                        // (a layer past the last: valid addresses, no stores)
+        const int lr = lb < g.n_res ? lb : (g.n_res > 0 ? g.n_res - 1 : 0);
+        b_off = (long)lb * g.z_lstride + (long)(a_row & 63) * g.z_ld;
+        r_off = (long)lr * g.dx_lstride + (long)(a_row & 63) * g.dx_ld;
+    }
+    float rowsum[2] = {0.f, 0.f}, rowsum_r = 0.f;
+    const bool do_rowsum = g.rs_skip != nullptr && bx == 0;
+    const unsigned a_sign = WN_UNIFORM((zr & 1) ? 0x80008000u : 0u);
+
+    auto fetch_a = [&](int k0, float (&ra)[AE]) {
+        WN_UNROLL
+        for (int u = 0; u < 2; ++u) {
+            const wn_f4 v = wn_ld4_unaligned(Az + a_off[u] + k0 + a_k);
+            ra[4 * u] = v.x; ra[4 * u + 1] = v.y; ra[4 * u + 2] = v.z; ra[4 * u + 3] = v.w;
+        }
+    };
+    auto fetch_br = [&](int k0, float (&rb)[BE], float (&rr)[BE]) {
+        const wn_f4 v = wn_ld4_unaligned(Bz + b_off + k0 + a_k);
+        rb[0] = v.x; rb[1] = v.y; rb[2] = v.z; rb[3] = v.w;
+        const wn_f4 w = wn_ld4_unaligned(Rz + r_off + k0 + a_k);
+        rr[0] = w.x; rr[1] = w.y; rr[2] = w.z; rr[3] = w.w;
+    };
+    auto fetch_edge = [&](int k0, float (&ra)[AE], float (&rb)[BE], float (&rr)[BE]) {   // the ragged end of the last k-chunk
+        WN_UNROLL
+        for (int e = 0; e < AE; ++e) {
+            const int k = k0 + a_k + (e & 3);
+            ra[e] = k < kend ? Az[a_off[e >> 2] + k] : 0.f;
+        }
+        WN_UNROLL
+        for (int e = 0; e < BE; ++e) {
+            const int k = k0 + a_k + e;
+            rb[e] = k < kend ? Bz[b_off + k] : 0.f;
+            rr[e] = k < kend ? Rz[r_off + k] : 0.f;
+        }
+    };
+    auto split_pair = [&](float x0, float x1, bool scaled, unsigned& h, unsigned& md) {
+        if (scaled) {
+            x0 *= a_mul;
+            x1 *= a_mul;
+        }
+        h = wn_pk_f16(x0, x1);
+        md = wn_pk_f16(x0 - wn_f16lo_f32(h), x1 - wn_f16hi_f32(h));
+    };
+    auto put = [&](char* base, int rows, int row, const unsigned* h, const unsigned* md, unsigned sign) {
+        const unsigned* src[2] = {h, md};
+        WN_UNROLL
+        for (int p = 0; p < NP; ++p) {
+            char* d = base + p * rows * 32;
+            WN_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                const int kq = (a_k >> 1) + q;
+                *reinterpret_cast<unsigned*>(d + wn_frag_off(row, kq >> 2) + (kq & 3) * 4) = src[p][q] ^ sign;
+            }
+        }
+    };
+    // row jobs of a step: 0, 1 = this thread's dS rows, 2 = its z row, 3 = its dX row
+    auto row_job = [&](int q, char* sa, const float (&ra)[AE], const float (&rb)[BE], const float (&rr)[BE], bool counted) {
+        unsigned h[2], md[2];
+        if (q < 2) {
+            rowsum[q] += counted ? (ra[4 * q] + ra[4 * q + 1]) + (ra[4 * q + 2] + ra[4 * q + 3]) : 0.f;
+            split_pair(ra[4 * q], ra[4 * q + 1], true, h[0], md[0]);
+            split_pair(ra[4 * q + 2], ra[4 * q + 3], true, h[1], md[1]);
+            put(sa, BM, a_row + 128 * q, h, md, a_sign);
+        } else if (q == 2) {
+            split_pair(rb[0], rb[1], false, h[0], md[0]);
+            split_pair(rb[2], rb[3], false, h[1], md[1]);
+            put(sa + A_BYTES, BN, a_row, h, md, 0u);
+        } else {
+            rowsum_r += counted ? (rr[0] + rr[1]) + (rr[2] + rr[3]) : 0.f;
+            split_pair(rr[0], rr[1], true, h[0], md[0]);
+            split_pair(rr[2], rr[3], true, h[1], md[1]);
+            put(sa + A_BYTES + B_BYTES, BN, a_row, h, md, a_sign);
+        }
+    };
+    auto stage = [&](int st, const float (&ra)[AE], const float (&rb)[BE], const float (&rr)[BE]) {
+        WN_UNROLL
+        for (int q = 0; q < 4; ++q) row_job(q, smem_raw + st * ST_BYTES, ra, rb, rr, true);
+    };
+    f32x16 acc[TMW][TN], acc_r[TN];
+    WN_UNROLL
+    for (int j = 0; j < TN; ++j) {
+        acc[0][j] = f32x16_zero();
+        acc[1][j] = f32x16_zero();
+        acc_r[j] = f32x16_zero();
+    }
+    const int r_frag_row = wn * 64 + (wm & 1) * 32 + li;   // (waves wm = 0, 1 only)
+    constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};   // small terms first: h m, m h, h h
+    // One step: 12 MFMAs in six groups with one job behind each (0: the loads of later steps; 1 - 4: the row jobs of the next step;
+    // WITH = false: a plain step on stage `st`), then the six MFMAs of the dX row tile (waves wm = 0, 1)
+    auto step = [&](int st, int stn, const float (&ra)[AE], const float (&rb)[BE], const float (&rr)[BE], float (&ran)[AE],
+                    float (&rbn)[BE], float (&rrn)[BE], int ka_next, int kb_next, bool counted, bool pipelined) {
+        const char* sa = smem_raw + st * ST_BYTES;
+        const char* sb = sa + A_BYTES;
+        char* da = smem_raw + stn * ST_BYTES;
+        wn_f4 bf[NP][TN];
+        WN_UNROLL
+        for (int p = 0; p < NP; ++p) {
+            WN_UNROLL
+            for (int j = 0; j < TN; ++j)
+                bf[p][j] = *reinterpret_cast<const wn_f4*>(sb + p * (BN * 32) + wn_frag_off((wn * TN + j) * 32 + li, hi));
+        }
+        WN_UNROLL
+        for (int i = 0; i < TMW; ++i) {
+            wn_f4 af[NP];
+            WN_UNROLL
+            for (int p = 0; p < NP; ++p)
+                af[p] = *reinterpret_cast<const wn_f4*>(sa + p * (BM * 32) + wn_frag_off((wm * TMW + i) * 32 + li, hi));
+            WN_UNROLL
+            for (int t = 0; t < NPROD; ++t) {
+                WN_UNROLL
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma_f16(af[PA[t]], bf[PB[t]][j], acc[i][j]);
+                if (!pipelined) continue;
+                const int sl = i * NPROD + t;
+                if (sl == 0) {
+                    fetch_a(ka_next, ran);
+                    fetch_br(kb_next, rbn, rrn);
+                } else if (sl <= 4) {
+                    row_job(sl - 1, da, ra, rb, rr, counted);
+                }
+                WN_UNROLL
+                for (int j = 0; j < TN; ++j) {
+                    WN_SGB_MFMA(1);
+                    WN_SGB_VALU(12);
+                }
+                WN_SCHED_FENCE_ALU();
+            }
+        }
+        if (has_r) {
+            wn_f4 af[NP];
+            WN_UNROLL
+            for (int p = 0; p < NP; ++p)
+                af[p] = *reinterpret_cast<const wn_f4*>(sb + B_BYTES + p * (BN * 32) + wn_frag_off(r_frag_row, hi));
+            WN_UNROLL
+            for (int t = 0; t < NPROD; ++t) {
+                WN_UNROLL
+                for (int j = 0; j < TN; ++j) acc_r[j] = mfma_f16(af[PA[t]], bf[PB[t]][j], acc_r[j]);
+            }
+        }
+    };
+    // The pipelined pass: THREE LDS stages.  Step k runs its MFMAs on stage k % 3, splits the operands of step k + 2 into stage
+    // (k + 2) % 3 and loads step k + 4 into the register set step k + 1 left: the barrier behind a step never waits for LDS writes
+    // its next step reads (with two stages every step began with that wait, one workgroup per CU: nothing else to run meanwhile).
+    const int nfull = (kend > kbeg) ? (kend - kbeg) / 16 : 0;   // whole 16-position steps of this chunk
+    const int nfast = nfull >= 9 ? nfull - nfull % 3 : 0;
+    if (nfast > 0) {
+        float ra0[AE], rb0[BE], rr0[BE], ra1[AE], rb1[BE], rr1[BE], ra2[AE], rb2[BE], rr2[BE];
+        const int k_last = kbeg + (nfast - 1) * 16;
+        auto kk = [&](int s_) { const int k = kbeg + s_ * 16; return k < k_last ? k : k_last; };   // past the end: the last step again (staged, never read)
+        fetch_a(kbeg, ra0);
+        fetch_br(kbeg, rb0, rr0);
+        fetch_a(kbeg + 16, ra1);
+        fetch_br(kbeg + 16, rb1, rr1);
+        fetch_a(kbeg + 32, ra2);
+        fetch_br(kbeg + 32, rb2, rr2);
+        stage(0, ra0, rb0, rr0);
+        fetch_a(kbeg + 48, ra0);
+        fetch_br(kbeg + 48, rb0, rr0);
+        stage(1, ra1, rb1, rr1);
+        __syncthreads();
+        for (int kb = 0; kb < nfast; kb += 3) {
+            step(0, 2, ra2, rb2, rr2, ra1, rb1, rr1, kk(kb + 4), kk(kb + 4), kb + 2 < nfast, true);
+            __syncthreads();
+            step(1, 0, ra0, rb0, rr0, ra2, rb2, rr2, kk(kb + 5), kk(kb + 5), kb + 3 < nfast, true);
+            __syncthreads();
+            step(2, 1, ra1, rb1, rr1, ra0, rb0, rr0, kk(kb + 6), kk(kb + 6), kb + 4 < nfast, true);
+            __syncthreads();
+        }
+    }
+    for (int k0 = kbeg + 16 * nfast; k0 < kend; k0 += 16) {   // up to three whole steps and / or the ragged end: one at a time
+        float ra[AE], rb[BE], rr[BE];
+        fetch_edge(k0, ra, rb, rr);
+        stage(0, ra, rb, rr);
+        __syncthreads();
+        step(0, 1, ra, rb, rr, ra, rb, rr, 0, 0, false, false);
+        __syncthreads();
+    }
+
+    // row sums (bias gradients): the 4 threads of a row are adjacent lanes
+    WN_UNROLL
+    for (int u = 0; u < 2; ++u) {
+        float rs = rowsum[u];
+        rs += __shfl_xor(rs, 1, 64);
+        rs += __shfl_xor(rs, 2, 64);
+        if (do_rowsum && a_k == 0) g.rs_skip[(long)zr * g.S + m0 + a_row + 128 * u] = rs;
+    }
+    const long nz = (long)g.nbatch * g.ksplit;
+    {
+        float rs = rowsum_r;
+        rs += __shfl_xor(rs, 1, 64);
+        rs += __shfl_xor(rs, 2, 64);
+        const int lt = l0 + (a_row >> 6);
+        if (with_res && a_k == 0 && lt < g.n_res) g.rs_res[((long)lt * nz + zr) * 64 + (a_row & 63)] = rs;
+    }
+    const float c_mul = 1.0f / a_mul;   // a power of two
+    const unsigned osign = a_sign & 0x80000000u;
+    unsigned nonfinite = 0u;
+    const wn_rsrc_t Cr = wn_make_buf(g.Cskip + (long)zr * g.S * N, (unsigned)((long)g.S * N * 4));
+    WN_UNROLL
+    for (int i = 0; i < TMW; ++i) {
+        WN_UNROLL
+        for (int j = 0; j < TN; ++j) {
+            const int n = 64 * l0 + (wn * TN + j) * 32 + li;
+            WN_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TMW + i) * 32 + mfma32_row(r, hi);
+                float v = wn_bits_f32(__builtin_bit_cast(unsigned, (float)acc[i][j][r]) ^ osign);
+                nonfinite |= (~__builtin_bit_cast(unsigned, v) & 0x7f800000u) == 0u ? 1u : 0u;
+                v *= c_mul;
+                wn_buf_store(Cr, v, n < N ? (m * N + n) * 4 : 0x7ffffff0, 0);
+            }
+        }
+    }
+    const int lw = l0 + wn;   // the layer of this wave's columns
+    if (has_r && with_res && lw < g.n_res) {
+        float* Cw = g.Cres + ((long)lw * nz + zr) * 64 * 64;
+        WN_UNROLL
+        for (int j = 0; j < TN; ++j) {
+            const int n = j * 32 + li;   // z channel inside the layer
+            WN_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int m = (wm & 1) * 32 + mfma32_row(r, hi);
+                float v = wn_bits_f32(__builtin_bit_cast(unsigned, (float)acc_r[j][r]) ^ osign);
+                nonfinite |= (~__builtin_bit_cast(unsigned, v) & 0x7f800000u) == 0u ? 1u : 0u;
+                Cw[m * 64 + n] = v * c_mul;
+            }
+        }
+    }
+    if (nonfinite) wn_store_coherent_int(ovf, 1);
+}
+
+int wn_dw_skipres_supported(int S, int R, int nl, int n_res) {
+    static int on = -1;   // WN_DW_SKIPRES=0: A/B knob (the two separate launches)
+    if (on < 0) { const char* e = getenv("WN_DW_SKIPRES"); on = e ? atoi(e) : 1; }
+    return on && R == 64 && S >= 256 && S % 256 == 0 && nl >= 1 && n_res >= 1 && n_res <= nl;
+}
+int wn_dw_skipres_launch(const WnDwSkipRes* ap, float f16_mul, int* ovf, wn_stream_t st) {
+    const WnDwSkipRes& a = *ap;
+    if (f16_mul == 0.0f || !ovf || !wn_dw_skipres_supported(a.S, 64, a.nl, a.n_res)) return 2;
+    if (a.K <= 0 || a.nbatch <= 0 || a.ksplit <= 0 || a.kchunk <= 0 || a.kchunk % 32 != 0) return 2;
+    if ((long)a.S * 64 * a.nl * 4 >= 0x7ffffff0L) return 2;
+    const double cols = 64.0 * a.nl, rows = (double)a.S + 64.0;
+    WN_PROF("dw_skip_res", 2.0 * rows * cols * (double)a.K * a.nbatch,
+            ((double)a.S * a.K + 2.0 * cols * a.K) * 4.0 * a.nbatch, st);
+    dim3 grid((unsigned)((a.nl + 1) / 2), (unsigned)(a.S / 256), (unsigned)(a.nbatch * a.ksplit));
+    constexpr int lds = 3 * (2 * 256 * 32 + 2 * 2 * 128 * 32);   // three stages of dS, z, dX pieces: 96 KB
+#ifndef WN_EMU
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_dw_skipres8), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 3;
+        attr_set = true;
+    }
+#endif
+    WN_LAUNCH(k_dw_skipres8, grid, dim3(WN_SR8_T), lds, st, a, xcd_block_order(), f16_mul, ovf);
+    return 0;
+}
+
 // 256-row tiles (k_gemm6_dw<4,2>): every B row is read once per 256 A rows.  Round 2 took them for >= 512 output rows only -- at
 // 256 rows (the skip gradient: 256 x 1920, k = every position) they measured 0.06 - 0.1 ms SLOWER than 128 x 128 tiles at 3
 // workgroups per CU, and no different with this round's operand mapping under six products (0.80 ms either way): the launch was

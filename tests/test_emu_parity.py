@@ -938,6 +938,57 @@ def test_skip_gradient_on_the_256_row_tile():
         assert g <= 2e-5, (flags, g)
 
 
+def test_skip_and_res_weight_gradients_in_one_launch():
+    """k_dw_skipres8 (csrc/wn_gemm6.hip, WnDwSkipRes): with the fp16 pair split and ONE layer bucket the skip_1x1 and res_1x1 weight
+    gradients of every layer come from one launch that reads z once (reference: wavenet.py:534-536 backward).  Five layers (the
+    last column tile is half empty, the last layer's res_1x1 is dead), 512 skip channels (two row blocks: the second one has no
+    dX product), k-chunks of 10 and 9 steps (pipelined pass of 9 + a single step): every gradient against the oracle; the two
+    separate launches (taken when the layers are flushed in several buckets) agree with it to fp32 summation order; a promise far
+    too small raises the overflow word and the redo launches (six products, the fused launch's split-K plan) do the work."""
+    from oracle import wavenet_oracle as O
+    from pytorchwavenetvocoder_amd import _lib
+    from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat
+    cfg_t = (32, 4, 64, 512, 5, 1, 2, 16)
+    cfg = O.OracleConfig(*cfg_t)
+    B, T = 1, 304   # (one sequence: 1024 ReLU inputs per position, and a kink-free instance must still exist)
+    params, x, h, t, margin, sd = PC.pick_instance(cfg, B, T, 91, 0.1, tries=400)
+    _, _, grads_ref = O.train_step(cfg, params, None, x, h, t)
+    eng = WaveNetEngine(*cfg_t, device="cpu", library=emu_library())
+    load_state_into_flat(eng, params)
+    eng.flags = _lib.FLAG_AUX_FUSED | _lib.FLAG_DW_F16PAIR
+    loss, dl = eng.forward_loss(x, h, t)
+    res, logs = {}, {}
+    for name, lpb in (("fused", 0), ("buckets", 2)):
+        logs[name] = PC.launch_log(emu_library(), lambda: eng.backward(dl, layers_per_bucket=lpb))
+        res[name] = eng.grads().clone()
+        grads = PC.flat_to_state(eng, res[name], O.param_shapes(cfg))
+        for k, ref in grads_ref.items():
+            if ref is not None:
+                assert PC.rel_to_max(grads[k], ref) <= PC.TOL_GRAD, (name, k)
+    assert logs["fused"].get("dw_skip_res") == 1 and "dw_skip" not in logs["fused"] and "dw_res" not in logs["fused"], logs["fused"]
+    assert "dw_skip_res" not in logs["buckets"] and logs["buckets"].get("dw_skip") == 1 and logs["buckets"].get("dw_res") == 3, logs["buckets"]
+    scale = float(res["buckets"].abs().max())
+    assert float((res["fused"] - res["buckets"]).abs().max()) <= 1e-6 * scale
+    # the dead res_1x1 of the last layer stays exactly zero
+    lo, hi = eng.dead_range
+    assert float(res["fused"][lo:hi].abs().max()) == 0.0
+    # bucket events (distributed.GradientReducer): the head bucket holds the skip_1x1 weights, so its event now follows the fused
+    # launch and its reductions -- still in bucket order (0, 1, 2), so a consumer that waits in that order is not held back
+    seq = PC.launch_sequence(emu_library(), lambda: eng.backward(dl, events=[1, 2, 3], layers_per_bucket=0))
+    ev = [i for i, s_ in enumerate(seq) if s_ == "bucket_event"]
+    assert len(ev) == 3 and ev[-1] == len(seq) - 1, seq
+    fused_at = seq.index("dw_skip_res")
+    assert fused_at < ev[0] < ev[1] and "reduce_partials" in seq[fused_at:ev[0]], seq
+    assert max(i for i, s_ in enumerate(seq) if s_ in ("dw_post2", "dw_post1", "fused_bwd_chain", "fused_bwd_dx")) < ev[0], seq
+    # overflow -> the conditional six-product launches behind the fused one: the six-product mode's arithmetic
+    eng.flags = _lib.FLAG_AUX_FUSED
+    six = eng.backward(dl).clone()
+    eng.flags = _lib.FLAG_AUX_FUSED | _lib.FLAG_DW_F16PAIR
+    gov = eng.backward(dl, dlogits_bound=2.0 ** -40).clone()
+    assert bool(torch.isfinite(gov).all()) and float((gov - six).abs().max()) <= 2e-7 * scale
+    assert 0.0 < float((res["fused"] - six).abs().max()) <= 1e-6 * scale
+
+
 def test_same_run_parity_helper_on_the_emulator():
     """oracle/same_run_parity.py (bench.py's `parity` block, tests/test_gpu_fullsize.py's benchmark-instance gate) on a tiny
     initialize()d model under the emulator: the reference module's own step (oracle/_ref; the restatement where the copy is
