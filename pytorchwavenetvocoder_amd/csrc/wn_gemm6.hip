@@ -975,7 +975,7 @@ __global__ __launch_bounds__(G6_T, 3) void k_gemm6n(WnGemm6Args g, int order) {
 static bool gemm6n_applies(const WnGemm6Args& g) {
     static int on = -1;   // WN_G6_NARROW=0: A/B knob
     if (on < 0) { const char* e = getenv("WN_G6_NARROW"); on = e ? atoi(e) : 1; }
-    return on && g.f16 && g.K <= 512 && (g.M % WN_G6N_BM) == 0 && !g.ce_target && !g.gate_S && !g.gbw_dP && !g.accumulate && !g.no_interior &&
+    return on && g.f16 && g.K <= 512 && g.M > WN_G6_BM && (g.M % WN_G6N_BM) == 0 && !g.ce_target && !g.gate_S && !g.gbw_dP && !g.accumulate && !g.no_interior &&
            (long)g.M * g.ldc * 4 < 0x7ffffff0L && (!g.E || (long)g.M * g.lde * 4 < 0x7ffffff0L) && (!g.D || (long)g.M * g.ldd * 4 < 0x7ffffff0L);
 }
 
@@ -1662,15 +1662,21 @@ __global__ __launch_bounds__(WN_SR8_T) void k_dw_skipres8(WnDwSkipRes g, int ord
                 af[p] = *reinterpret_cast<const wn_f4*>(sa + p * (BM * 32) + wn_frag_off((wm * TMW + i) * 32 + li, hi));
             WN_UNROLL
             for (int t = 0; t < NPROD; ++t) {
+#ifndef WN_SRX_NOMFMA   // (WN_SRX_*: what-if builds that drop one part of the k-step -- timing only, tools/build_variant.sh)
                 WN_UNROLL
                 for (int j = 0; j < TN; ++j) acc[i][j] = mfma_f16(af[PA[t]], bf[PB[t]][j], acc[i][j]);
+#endif
                 if (!pipelined) continue;
                 const int sl = i * NPROD + t;
                 if (sl == 0) {
+#ifndef WN_SRX_NOLOAD
                     fetch_a(ka_next, ran);
                     fetch_br(kb_next, rbn, rrn);
+#endif
                 } else if (sl <= 4) {
+#ifndef WN_SRX_NOJOB
                     row_job(sl - 1, da, ra, rb, rr, counted);
+#endif
                 }
                 WN_UNROLL
                 for (int j = 0; j < TN; ++j) {
@@ -1687,8 +1693,10 @@ __global__ __launch_bounds__(WN_SR8_T) void k_dw_skipres8(WnDwSkipRes g, int ord
                 af[p] = *reinterpret_cast<const wn_f4*>(sb + B_BYTES + p * (BN * 32) + wn_frag_off(r_frag_row, hi));
             WN_UNROLL
             for (int t = 0; t < NPROD; ++t) {
+#ifndef WN_SRX_NOMFMA
                 WN_UNROLL
                 for (int j = 0; j < TN; ++j) acc_r[j] = mfma_f16(af[PA[t]], bf[PB[t]][j], acc_r[j]);
+#endif
             }
         }
     };
