@@ -76,9 +76,9 @@ def products_per_multiply(flags, fused_share):
     bwd = fused_share * (DW_PRODUCTS if (flags & _lib.FLAG_CHAIN_F16PAIR) else SPLIT_PRODUCTS) + (1.0 - fused_share) * mm
     return (fwd + bwd + dw) / 3.0
 LAYERS_PER_BUCKET = 30      # gradient buckets = weight-gradient launch groups; N = 1 runs the SAME launch structure as N > 1.
-# 30 (= all layers of this model, GradientReducer's default) = [post-net + skip] [all residual layers] [front + upsampling]: measured 11.64 vs 11.80 ms/step for groups of 10
-# layers on the same box (profiles/r02/ab_probe.txt); 40 % of the gradient bytes (the first bucket) are exchanged under
-# the whole backward chain, the rest under the front-conv / upsampling gradients
+# 30 (= all layers of this model, GradientReducer's default) = [post-net] [skip_1x1 + all residual layers] [front + upsampling]: measured 11.64 vs 11.80 ms/step for groups of 10
+# layers on the same box (profiles/r02/ab_probe.txt); the post-net bucket is exchanged under the whole backward chain, the
+# rest under the front-conv / upsampling gradients
 # SURVEY.md 8(d) algorithmic bytes per timestep of ONE launch of the per-layer chain kernels (R = 64 words of 4 B):
 #   forward block  read x_l, write x_{l+1}, save s, g                   4R
 #   gate'          read s, g and dx_{l+1}                                3R   (dSkip is on chip in 8(d)'s accounting)

@@ -194,7 +194,10 @@ int wn_param_offset(const WnConfig* cfg, int kind, int layer, int64_t* offset, i
 
 /* Gradient buckets for data-parallel all-reduce: bucket 0 = post-net + all skip_1x1; then groups of
  * `layers_per_bucket` residual layers from the last layer down; the final bucket = causal +
- * upsampling.  [lo, hi) are float offsets into the flat gradient buffer. */
+ * upsampling.  With ONE layer group (layers_per_bucket <= 0 or >= the number of layers) the skip_1x1
+ * tensors belong to that group's bucket instead (bucket 0 = post-net only): their gradients may then
+ * be produced behind the data chain, together with the res_1x1 gradients.  The buckets are contiguous,
+ * disjoint and cover the buffer; [lo, hi) are float offsets into the flat gradient buffer. */
 int wn_num_buckets(const WnConfig* cfg, int layers_per_bucket);
 int wn_bucket_range(const WnConfig* cfg, int layers_per_bucket, int bucket, int64_t* lo, int64_t* hi);
 /* [lo, hi) of parameters that never receive a gradient (res_1x1 of the last layer; reference:

@@ -298,15 +298,19 @@ extern "C" int wn_bucket_range(const WnConfig* cfg, int lpb, int bucket, int64_t
     const Lay y = make_lay(d);
     const int ngroups = (d.L + lpb - 1) / lpb;
     long a, b;
+    // ONE layer bucket: the skip_1x1 parameters (laid out right in front of the layers) belong to it, not to the head -- their
+    // gradients may come from the same launch as the res_1x1 gradients (k_dw_skipres8, behind the data chain), and the head
+    // bucket (post-net only) is final, and its event recorded, before the chain starts either way.
+    const bool skip_with_layers = ngroups == 1;
     if (bucket == 0) {
         a = 0;
-        b = y.layers0;
+        b = skip_with_layers ? y.skip0 : y.layers0;
     } else if (bucket <= ngroups) {
         const int g = bucket - 1;  // layers processed: L-1-g*lpb ... down
         const int first = g * lpb;
         int last = first + lpb;
         if (last > d.L) last = d.L;
-        a = y.layers0 + (long)first * y.LB;
+        a = skip_with_layers ? y.skip0 : y.layers0 + (long)first * y.LB;
         b = y.layers0 + (long)last * y.LB;
     } else if (bucket == ngroups + 1) {
         a = y.causal_w;

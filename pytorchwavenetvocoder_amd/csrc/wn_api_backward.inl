@@ -165,8 +165,8 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
     }
     // Fused skip + res weight gradients (k_dw_skipres: z of every layer read once instead of twice): with the fp16 pair split on,
     // the skip gradients wait for the data chain and are produced per bucket together with the res_1x1 gradients.
-    // Only with ONE layer bucket: the skip weights belong to the head bucket (wn_bucket_range), whose event would otherwise be the
-    // last one recorded and hold back the exchange of every layer bucket behind it (distributed.py waits in bucket order).
+    // Only with ONE layer bucket, where the skip weights belong to that bucket (wn_bucket_range); with several, they are part of the
+    // head bucket, whose event would then be the last one recorded and hold back the exchange of every layer bucket behind it.
     const bool skipres = c.split_bf16 && c.dw_f16_mul != 0.0f && d.L > 1 && lpb >= d.L && wn_dw_skipres_supported(d.S, d.R, d.L, d.L - 1);
     if (!skipres) {   // d skip_1x1.l.weight for all layers in one contraction; bias = rowsum(dSkip) for every layer
         WnGemmArgs g = wn_gemm_default();
@@ -186,7 +186,7 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
         cp.d0 = 0; cp.d1 = 0; cp.d2 = 1; cp.dl = y.ls_skip;
         WN_TRY(wn_copy4(grads + y.skip0 + (long)d.S * d.R, ws + w.tmpS, &cp, cs.st));
     }
-    if (events && !skipres) rt_event_record(events[bucket], cs.st);   // (fused skip + res: the head bucket completes with the last flush)
+    if (events) rt_event_record(events[bucket], cs.st);   // head bucket: the post-net (+ every skip_1x1 with several layer buckets)
     bucket++;
 
     // ---- residual stack, last layer first (wavenet.py:525-536 reversed) ----
@@ -448,7 +448,6 @@ extern "C" int wn_backward_window(const WnConfig* cfg, int B, int T, const float
             WN_TRY(flush_bucket(l, bucket_hi));
             bucket_hi = l;
             if (bucket_end) {
-                if (events && skipres && l == 0) rt_event_record(events[0], cl.st);   // head bucket: post-net + every layer's skip_1x1
                 if (events) rt_event_record(events[bucket], cl.st);
                 bucket++;
             }

@@ -31,12 +31,14 @@ class GradientReducer(object):
         """``layers_per_bucket``: residual layers per gradient bucket = per weight-gradient launch group of wn_backward.
         Default (None): chosen by the size of the gradient.
           * small models (the BASELINE 64 / 256 model: 6.4 MB): ALL layers in one bucket, i.e. three buckets
-            [post-net + skip] [residual layers] [front + upsampling].  Measured on MI355X at N = 1
+            [post-net] [skip_1x1 + residual layers] [front + upsampling] (wn_bucket_range: with one layer bucket the skip tensors
+            belong to it -- their gradients are made behind the chain, in the launch that also makes the res_1x1 gradients).
+            Measured on MI355X at N = 1
             (profiles/r03/visit3_chain_dw_pipelined_lpb_chainpairdiff.txt): 10.42 ms per step with one layer bucket, 10.49 with
             two (15 layers each), 10.64 with three -- the weight-gradient contractions are most efficient as ONE layer-batched
-            launch per tensor kind.  What a split would hide is the all-reduce of the 3.7 MB layer bucket, a latency-bound
-            ring of ~0.1 ms over xGMI: splitting costs as much compute as it could hide, so it is not done; the first bucket
-            (40 % of the bytes) travels under the whole backward chain either way.
+            launch per tensor kind.  What a split would hide is the all-reduce of the 5.7 MB layer bucket, a latency-bound
+            ring of ~0.1 ms over xGMI: splitting costs as much compute as it could hide, so it is not done; the post-net
+            bucket travels under the whole backward chain either way.
           * large models (gradient above 32 MB; the recipe-size 512 / 256 model: 185 MB, ~2 - 3 ms of ring time against a
             131 ms step): groups of 10 layers, so that two thirds of the layer gradients travel under the rest of the chain;
             at that width the launch-group cost is below 0.5 % of the step."""

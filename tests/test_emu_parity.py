@@ -972,14 +972,22 @@ def test_skip_and_res_weight_gradients_in_one_launch():
     # the dead res_1x1 of the last layer stays exactly zero
     lo, hi = eng.dead_range
     assert float(res["fused"][lo:hi].abs().max()) == 0.0
-    # bucket events (distributed.GradientReducer): the head bucket holds the skip_1x1 weights, so its event now follows the fused
-    # launch and its reductions -- still in bucket order (0, 1, 2), so a consumer that waits in that order is not held back
+    # bucket events (distributed.GradientReducer): with one layer bucket the skip_1x1 tensors are part of THAT bucket
+    # (wn_bucket_range), so the head bucket (post-net) is still final before the chain starts, and the layer bucket's event follows
+    # the fused launch and its reductions
     seq = PC.launch_sequence(emu_library(), lambda: eng.backward(dl, events=[1, 2, 3], layers_per_bucket=0))
     ev = [i for i, s_ in enumerate(seq) if s_ == "bucket_event"]
     assert len(ev) == 3 and ev[-1] == len(seq) - 1, seq
     fused_at = seq.index("dw_skip_res")
-    assert fused_at < ev[0] < ev[1] and "reduce_partials" in seq[fused_at:ev[0]], seq
-    assert max(i for i, s_ in enumerate(seq) if s_ in ("dw_post2", "dw_post1", "fused_bwd_chain", "fused_bwd_dx")) < ev[0], seq
+    chain_at = [i for i, s_ in enumerate(seq) if s_ in ("fused_bwd_chain", "fused_bwd_gate", "fused_bwd_dx")]
+    assert max(seq.index("dw_post2"), seq.index("dw_post1")) < ev[0] < chain_at[0], seq
+    assert chain_at[-1] < fused_at < ev[1] and "reduce_partials" in seq[fused_at:ev[1]], seq
+    ranges = eng.bucket_ranges(0)
+    skip_lo, _ = eng.param_slice(_lib.P_SKIP_W, 0)
+    assert ranges[0] == (0, skip_lo) and ranges[1][0] == skip_lo and ranges[-1][1] == eng.n_params, ranges
+    assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:])), ranges
+    many = eng.bucket_ranges(2)   # several layer buckets: the skip_1x1 tensors stay in the head bucket
+    assert many[0][0] == 0 and many[0][1] > skip_lo and all(a[1] == b[0] for a, b in zip(many, many[1:])) and many[-1][1] == eng.n_params, many
     # overflow -> the conditional six-product launches behind the fused one: the six-product mode's arithmetic
     eng.flags = _lib.FLAG_AUX_FUSED
     six = eng.backward(dl).clone()

@@ -73,7 +73,7 @@ def test_a_16_workgroup_kernel_runs_beside_the_full_size_backward_chain():
         t_ev[0 if with_side else 2].record(main)
         lib.stamp_launch(marks.data_ptr(), main.cuda_stream)
         eng.backward(dl, events=[e.cuda_event for e in events], layers_per_bucket=eng.n_layers)
-        if with_side:   # where GradientReducer issues the all-reduce of bucket 0
+        if with_side:   # where GradientReducer issues the all-reduce of bucket 0 (the post-net: final before the chain starts)
             side.wait_event(events[0])
             rc = lib.occupy_launch(buf.data_ptr(), buf.numel(), 2, stamps.data_ptr(), 16, side.cuda_stream)   # ~25 MB of traffic: a ring all-reduce of 6.4 MB moves ~11 MB per GPU
             assert rc == 0
