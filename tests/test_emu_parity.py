@@ -997,6 +997,42 @@ def test_skip_and_res_weight_gradients_in_one_launch():
     assert 0.0 < float((res["fused"] - six).abs().max()) <= 1e-6 * scale
 
 
+def test_launch_knobs_of_the_split_contractions_agree_with_each_other(tmp_path):
+    """The A/B knobs of csrc/wn_gemm6.hip are read once per process (-> subprocesses).  WN_G6_NARROW=0 takes the all-layer skip
+    gradient (M = 64 L > 256 rows, K = n_skipch) back from k_gemm6n's 128-row blocks to k_gemm6's 256-row blocks: the same bits (same
+    k order, product order and tile signs).  WN_DW_SKIPRES=0 takes the skip_1x1 / res_1x1 weight gradients back from the fused launch
+    to the two separate ones: the same values to fp32 summation order.  Six layers: M = 384 = three 128-row blocks, 1.5 256-row ones."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "from tests.emu_util import emu_library\n"
+        "from oracle import wavenet_oracle as O\n"
+        "from pytorchwavenetvocoder_amd.engine import WaveNetEngine, load_state_into_flat, DEFAULT_FLAGS\n"
+        "cfg_t = (32, 4, 64, 256, 3, 2, 2, 16)\n"
+        "cfg = O.OracleConfig(*cfg_t)\n"
+        "params = O.random_params(cfg, 7, scale=0.1); x, h, t = O.synthetic_batch(cfg, 1, 304, 8)\n"
+        "eng = WaveNetEngine(*cfg_t, device='cpu', library=emu_library())\n"
+        "load_state_into_flat(eng, params)\n"
+        "eng.flags = DEFAULT_FLAGS\n"
+        "loss, dl = eng.forward_loss(x, h, t)\n"
+        "eng.backward(dl)\n"
+        "torch.save(eng.grads().clone(), sys.argv[1])\n" % root)
+    out = {}
+    for name, env in (("default", {}), ("wide_rows", {"WN_G6_NARROW": "0"}), ("separate", {"WN_DW_SKIPRES": "0"})):
+        path = str(tmp_path / (name + ".pt"))
+        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        assert r.returncode == 0, r.stdout.decode()[-2000:]
+        out[name] = torch.load(path)
+    assert bool(torch.isfinite(out["default"]).all()) and float(out["default"].abs().max()) > 0.0
+    assert torch.equal(out["default"], out["wide_rows"])
+    scale = float(out["separate"].abs().max())
+    diff = float((out["default"] - out["separate"]).abs().max())
+    assert 0.0 < diff <= 1e-6 * scale, (diff, scale)
+
+
 def test_same_run_parity_helper_on_the_emulator():
     """oracle/same_run_parity.py (bench.py's `parity` block, tests/test_gpu_fullsize.py's benchmark-instance gate) on a tiny
     initialize()d model under the emulator: the reference module's own step (oracle/_ref; the restatement where the copy is
