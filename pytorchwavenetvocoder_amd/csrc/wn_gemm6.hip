@@ -746,11 +746,13 @@ __global__ __launch_bounds__(G6_T, 2) void k_gemm6(WnGemm6Args g, int order G6_D
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_gemm6n -- the fp16 pair contraction for SHORT contractions (K <= 512: post-net, the all-layer skip gradient: 16 - 32 k-steps
-// per block).  At 256 x 128 the blocks of k_gemm6 spend two thirds of their life in their prologue (operand latency) and their
-// 128 KB epilogue, two per CU: the matrix pipe idles while a block stores, the store path idles while it contracts
-// (bwd_dz_skip_all: 0.18 ms of MFMA work, 0.28 ms of HBM time, 0.62 ms measured).  Here a block owns 128 x 128 (wave tile 64 x 64:
-// 64 accumulator registers), 32 KB of LDS and <= 168 registers: THREE blocks per CU are in different phases at any time.  Same
+// k_gemm6n -- the fp16 pair contraction for SHORT contractions (K <= 512: 16 - 32 k-steps per block) with MORE than 256 output
+// rows: the all-layer skip gradient (M = 64 L).  At 256 x 128 the blocks of k_gemm6 spend two thirds of their life in their
+// prologue (operand latency) and their 128 KB epilogue, two per CU: the matrix pipe idles while a block stores, the store path
+// idles while it contracts (bwd_dz_skip_all: 0.3 ms of MFMAs at full rate, 0.28 ms of HBM time, 0.62 ms measured), and 1920 rows are
+// 7.5 blocks of 256.  Here a block owns 128 x 128 (wave tile 64 x 64: 64 accumulator registers), 32 KB of LDS and <= 168 registers:
+// THREE blocks per CU are in different phases at any time: 0.59 ms (profiles/r06/abk_gemm6_narrow.txt; the 256-row post-net launches
+// measured 0.004 ms slower each on it and stay on k_gemm6).  Same
 // operand layouts, same pre-split fp16 images (a block takes rows m0 .. m0 + 127 of the [kb][2][Mpad][16] image), same
 // alternating tile signs, same overflow word; plain epilogue only (bias, residual D, relu, mask E): no gate / loss epilogues, no
 // C += result.
@@ -1640,8 +1642,8 @@ __global__ __launch_bounds__(WN_SR8_T) void k_dw_skipres8(WnDwSkipRes g, int ord
     }
     const int r_frag_row = wn * 64 + (wm & 1) * 32 + li;   // (waves wm = 0, 1 only)
     constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};   // small terms first: h m, m h, h h
-    // One step: 12 MFMAs in six groups with one job behind each (0: the loads of later steps; 1 - 4: the row jobs of the next step;
-    // WITH = false: a plain step on stage `st`), then the six MFMAs of the dX row tile (waves wm = 0, 1)
+    // One step: 12 MFMAs in six groups with one job behind each (0: the loads of a later step; 1 - 4: the row jobs of the step being
+    // split into stage `stn`; pipelined = false: a plain step on stage `st`), then the six MFMAs of the dX row tile (waves wm = 0, 1)
     auto step = [&](int st, int stn, const float (&ra)[AE], const float (&rb)[BE], const float (&rr)[BE], float (&ran)[AE],
                     float (&rbn)[BE], float (&rrn)[BE], int ka_next, int kb_next, bool counted, bool pipelined) {
         const char* sa = smem_raw + st * ST_BYTES;
@@ -1729,7 +1731,7 @@ __global__ __launch_bounds__(WN_SR8_T) void k_dw_skipres8(WnDwSkipRes g, int ord
             __syncthreads();
         }
     }
-    for (int k0 = kbeg + 16 * nfast; k0 < kend; k0 += 16) {   // up to three whole steps and / or the ragged end: one at a time
+    for (int k0 = kbeg + 16 * nfast; k0 < kend; k0 += 16) {   // what the pipelined pass left (<= two whole steps, or a chunk below nine) and the ragged end: one step at a time
         float ra[AE], rb[BE], rr[BE];
         fetch_edge(k0, ra, rb, rr);
         stage(0, ra, rb, rr);
