@@ -55,7 +55,7 @@ if has abk; then
 import json
 d = json.load(open("$OUT/bench_abk.json"))
 ks = d.get("kernels", {})
-sel = "${WN_ABK_KERNELS:-bwd_dz_skip_all fwd_skip_sum dw_skip bwd_post2_dx bwd_post1_dx fwd_post1 fwd_post2 dw_post1 dw_post2 fill_cols softmax_ce fused_bwd_chain fused_resblock_fwd}".split()
+sel = "${WN_ABK_KERNELS:-bwd_dz_skip_all fwd_skip_sum dw_skip_res dw_skip dw_res dw_dilated bwd_post2_dx bwd_post1_dx fwd_post1 fwd_post2 dw_post1 dw_post2 fill_cols softmax_ce fused_bwd_chain fused_resblock_fwd}".split()
 print("%-32s ms/step median %.3f min %.3f max %.3f | " % ("$cfg", d["ms_per_step"], d["ms_per_step_min"], d["ms_per_step_max"]) +
       " ".join("%s %.3f" % (k, ks[k]["ms_per_step"]) for k in sel if k in ks))
 P
